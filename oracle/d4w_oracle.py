@@ -1,0 +1,616 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A float64 NumPy restatement of the DAS4Whales `dsp` / `detect` hot path (reference:
+leabouffaut/DAS4Whales @ 2024_08_07, files cited per function as `dsp.py:LINE` /
+`detect.py:LINE`, relative to /root/reference/src/das4whales/).  It exists so that the HIP path
+can be checked on the GPU box, where /root/reference is absent.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it; the product
+package `das4whales_amd` never does (tests/test_boundary.py enforces that).
+
+Parity pinning: every function here is compared against the *real* reference functions, run in
+the build container under oracle/ref_harness.py, through the committed fixtures in
+tests/golden/*.npz (generator: tests/golden/make_golden.py) -- see tests/test_oracle_golden.py.
+The reference's own tests pin only `taper_data` and `snr_tr_array` values
+(tests/test_dsp.py:85-88,136-141); those vectors are checked too.
+
+Third-party arithmetic the reference delegates to and that is NOT under /root/reference:
+  numpy.fft (pocketfft; reference pins numpy<2, pyproject.toml:31; here 2.2.6),
+  scipy.signal / scipy.ndimage (unpinned; authors' env 1.12.0, here 1.15.3): butter, freqz,
+  lfilter, hilbert, chirp, find_peaks, gaussian_filter -- their published algorithms are
+  restated below where the HIP path re-implements them (filtfilt, sosfiltfilt, chirp, hilbert,
+  correlate, fftconvolve-same, find_peaks-prominence); `butter`/`freqz`/`lfilter` are used as
+  primitives.
+  librosa.stft (unpinned; authors' env 0.10.1; ABSENT here) -- restated in `librosa_stft`
+  following librosa >= 0.10 defaults; anything downstream of it is a "restated-oracle" result.
+"""
+import numpy as np
+import scipy.signal as sps
+from scipy import ndimage
+
+
+# --------------------------------------------------------------------------------------------
+# axes
+# --------------------------------------------------------------------------------------------
+def _shifted_axes(trace_shape, selected_channels, dx, fs):
+    """(k[:,None], f[None,:]) on the fftshift-ed grid -- dsp.py:129-130, 210-211, 344-345."""
+    nx, ns = trace_shape
+    f = np.fft.fftshift(np.fft.fftfreq(ns, d=1.0 / fs))
+    k = np.fft.fftshift(np.fft.fftfreq(nx, d=selected_channels[2] * dx))
+    return k, f
+
+
+# --------------------------------------------------------------------------------------------
+# f-k mask designs (closed forms of the reference's row/column loops)
+# --------------------------------------------------------------------------------------------
+def fk_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400, cp_min=1450,
+                     cp_max=3400, cs_max=3500):
+    """Classic speed fan with sine tapers -- dsp.py:85-171.
+
+    Row rule (dsp.py:140-161): rows with |k| < 0.005 are zero; otherwise with s = |f/k|:
+    ramp up on [cs_min, cp_min], ramp down on [cp_max, cs_max] (assigned in that order, so at an
+    overlap the later assignment wins), then s >= cs_max -> 0 and s < cs_min -> 0.
+    Returned dense float64, Fortran order like the reference (dsp.py:137).
+    """
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    K = k[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.abs(f[None, :] / K)
+        m = np.ones(s.shape)
+        up = (s >= cs_min) & (s <= cp_min)
+        m = np.where(up, np.sin(0.5 * np.pi * (s - cs_min) / (cp_min - cs_min)), m)
+        dn = (s >= cp_max) & (s <= cs_max)
+        m = np.where(dn, 1.0 - np.sin(0.5 * np.pi * (s - cp_max) / (cs_max - cp_max)), m)
+        m = np.where(s >= cs_max, 0.0, m)
+        m = np.where(s < cs_min, 0.0, m)
+    m = np.where(np.abs(K) < 0.005, 0.0, m)
+    return np.asfortranarray(m)
+
+
+def _first_index_ge(f, val):
+    """np.argmax(f >= val) -- dsp.py:221-222 (returns 0 if no element qualifies)."""
+    return int(np.argmax(f >= val))
+
+
+def hybrid_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450.,
+                         fmin=15., fmax=25.):
+    """Band-pass (4 Hz sine/cos tapers) x speed high-pass -- dsp.py:174-305 (dense result).
+
+    The reference returns sparse.COO.from_numpy(M) (dsp.py:305); the oracle returns M dense.
+    """
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    fp_lo, fp_hi = fmin - 4.0, fmax + 4.0                       # dsp.py:216-219
+    H = np.zeros_like(f)
+    up = (f >= fp_lo) & (f <= fmin)
+    H[up] = np.sin(0.5 * np.pi * (f[up] - fp_lo) / (fmin - fp_lo))            # dsp.py:225-226
+    H[(f >= fmin) & (f <= fmax)] = 1.0                                          # dsp.py:228
+    dn = (f >= fmax) & (f <= fp_hi)
+    H[dn] = np.cos(0.5 * np.pi * (f[dn] - fmax) / (fmax - fp_hi))               # dsp.py:230-231
+    i0, i1 = _first_index_ge(f, fp_lo), _first_index_ge(f, fp_hi)               # dsp.py:221-222
+    M = np.tile(H, (len(k), 1))                                                 # dsp.py:234
+    if i1 > i0:
+        fc = f[i0:i1][None, :]
+        K = k[:, None]
+        ks, kp = fc / cs_min, fc / cp_min                                       # dsp.py:243-244
+        col = np.zeros((len(k), i1 - i0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            neq = (ks != kp)
+            a = neq & (K >= -ks) & (K <= -kp)                                   # dsp.py:249-250
+            col = np.where(a, -np.sin(0.5 * np.pi * (K + ks) / (kp - ks)), col)
+            b = neq & (-K >= -ks) & (-K <= -kp)                                 # dsp.py:253-254
+            col = np.where(b, np.sin(0.5 * np.pi * (K - ks) / (kp - ks)), col)
+        col = np.where((K < kp) & (K > -kp), 1.0, col)                          # dsp.py:258
+        M[:, i0:i1] *= col                                                      # dsp.py:261
+    M = M + np.fliplr(M)                                                        # dsp.py:264
+    return M
+
+
+def hybrid_ninf_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400.,
+                              cp_min=1450., cp_max=3400, cs_max=3500, fmin=15., fmax=25.):
+    """Butterworth-|H|^2 band-pass x speed band-pass -- dsp.py:308-454 (dense result).
+
+    This is the design every reference script uses (scripts/main_mfdetect.py:46-47).
+    """
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    ns = len(f)
+    b, a = sps.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp")              # dsp.py:348
+    H = np.concatenate((np.zeros(ns // 2),
+                        np.abs(sps.freqz(b, a, worN=ns // 2)[1]) ** 2))         # dsp.py:349
+    fp_lo, fp_hi = fmin - 14.0, fmax + 14.0                                     # dsp.py:354-357
+    i0, i1 = _first_index_ge(f, fp_lo), _first_index_ge(f, fp_hi)               # dsp.py:359-360
+    M = np.tile(H, (len(k), 1))                                                 # dsp.py:372
+    if i1 > i0:
+        fc = f[i0:i1][None, :]
+        K = k[:, None]
+        ks_min, kp_min = fc / cs_max, fc / cp_max                               # dsp.py:381-382
+        ks_max, kp_max = fc / cs_min, fc / cp_min                               # dsp.py:384-385
+        col = np.zeros((len(k), i1 - i0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            a_ = (ks_min != kp_min) & (K >= ks_min) & (K <= kp_min)             # dsp.py:388-391
+            col = np.where(a_, np.sin(0.5 * np.pi * (K - ks_min) / (kp_min - ks_min)), col)
+            b_ = (ks_max != kp_max) & (K >= kp_max) & (K <= ks_max)             # dsp.py:392-395
+            col = np.where(b_, -np.sin(0.5 * np.pi * (K - ks_max) / (ks_max - kp_max)), col)
+        col = np.where((K > kp_min) & (K < kp_max), 1.0, col)                   # dsp.py:399
+        M[:, i0:i1] *= col                                                      # dsp.py:402
+    M = M + np.fliplr(M)                                                        # dsp.py:405
+    M = M + np.flipud(M)                                                        # dsp.py:406
+    return M
+
+
+def hybrid_gs_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450.,
+                            fmin=15., fmax=25.):
+    """Box band x box |k| < f/cp_min, Gaussian-blurred (sigma 20) -- dsp.py:457-579."""
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    H = np.zeros_like(f)
+    H[(f >= fmin) & (f <= fmax)] = 1.0                                          # dsp.py:508
+    i0, i1 = _first_index_ge(f, fmin - 4.0), _first_index_ge(f, fmax + 4.0)     # dsp.py:503-505
+    M = np.tile(H, (len(k), 1))                                                 # dsp.py:511
+    if i1 > i0:
+        kp = f[i0:i1][None, :] / cp_min
+        K = k[:, None]
+        M[:, i0:i1] *= np.where((K < kp) & (K > -kp), 1.0, 0.0)                 # dsp.py:533-536
+    M = M + np.fliplr(M)                                                        # dsp.py:539
+    return ndimage.gaussian_filter(M, 20)                                       # dsp.py:540
+
+
+def hybrid_ninf_gs_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400.,
+                                 cp_min=1450., cp_max=3400, cs_max=3500, fmin=15., fmax=25.):
+    """Box band x box -f/cp_min < k < -f/cp_max, blur THEN flips -- dsp.py:582-702."""
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    H = np.zeros_like(f)
+    H[(f >= fmin) & (f <= fmax)] = 1.0                                          # dsp.py:633
+    i0, i1 = _first_index_ge(f, fmin - 4.0), _first_index_ge(f, fmax + 4.0)     # dsp.py:628-630
+    M = np.tile(H, (len(k), 1))
+    if i1 > i0:
+        fc = f[i0:i1][None, :]
+        K = k[:, None]
+        M[:, i0:i1] *= np.where((K > -fc / cp_min) & (K < -fc / cp_max), 1.0, 0.0)  # dsp.py:653
+    M = ndimage.gaussian_filter(M, 20)                                          # dsp.py:659
+    M = M + np.fliplr(M)                                                        # dsp.py:660
+    M = M + np.flipud(M)                                                        # dsp.py:661
+    return M
+
+
+# --------------------------------------------------------------------------------------------
+# f-k mask application
+# --------------------------------------------------------------------------------------------
+def tukey_window(n, alpha=0.03):
+    """scipy.signal.windows.tukey(n, alpha) restated (symmetric form) -- used at dsp.py:721."""
+    if n == 1:
+        return np.ones(1)
+    if alpha <= 0:
+        return np.ones(n)
+    if alpha >= 1:
+        return np.hanning(n)
+    i = np.arange(n, dtype=float)
+    width = int(np.floor(alpha * (n - 1) / 2.0))
+    w = np.ones(n)
+    n1 = i[: width + 1]
+    w[: width + 1] = 0.5 * (1 + np.cos(np.pi * (-1 + 2.0 * n1 / alpha / (n - 1))))
+    n3 = i[n - width - 1:]
+    w[n - width - 1:] = 0.5 * (1 + np.cos(np.pi * (-2.0 / alpha + 1 + 2.0 * n3 / alpha / (n - 1))))
+    return w
+
+
+def taper_data(trace):
+    """trace * tukey(ns, 0.03) along time -- dsp.py:705-722 (returns a new array)."""
+    return np.asarray(trace, dtype=float) * tukey_window(trace.shape[1], 0.03)[None, :]
+
+
+def fk_filter_filt(trace, fk_filter_matrix, tapering=False):
+    """real(ifft2(ifftshift(fftshift(fft2(x)) * M))) -- dsp.py:725-756 and :759-786.
+
+    `fk_filter_matrix` is the dense mask on the shifted grid (the COO variant, dsp.py:759-786,
+    is arithmetically identical).
+    """
+    x = np.asarray(trace, dtype=float)
+    if tapering:
+        x = taper_data(x)                                                       # dsp.py:744-745
+    F = np.fft.fftshift(np.fft.fft2(x))                                         # dsp.py:748
+    return np.fft.ifft2(np.fft.ifftshift(F * np.asarray(fk_filter_matrix))).real  # dsp.py:751-756
+
+
+def fold_mask_half(fk_filter_matrix):
+    """Hermitian fold M_h = (M'(k,f) + M'(-k,-f))/2 on the UNSHIFTED grid.
+
+    Because x is real, Re(ifft2(F*M')) == ifft2(F*M_h); so the HIP path may always work on the
+    half spectrum.  Returns M_h[:, :ns//2+1] (float64).
+    """
+    Mu = np.fft.ifftshift(np.asarray(fk_filter_matrix, dtype=float))
+    nx, ns = Mu.shape
+    refl = Mu[(-np.arange(nx)) % nx][:, (-np.arange(ns)) % ns]
+    return (0.5 * (Mu + refl))[:, : ns // 2 + 1]
+
+
+def fk_filter_filt_half(trace, fk_filter_matrix):
+    """Same result as fk_filter_filt via rfft2 / folded half mask (even ns) -- checks A.3."""
+    x = np.asarray(trace, dtype=float)
+    Mh = fold_mask_half(fk_filter_matrix)
+    return np.fft.irfft2(np.fft.rfft2(x) * Mh, s=x.shape)
+
+
+def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
+    """Self-designing Gaussian-tapered speed band -- dsp.py:883-953."""
+    x = np.asarray(data, dtype=float)
+    nx, ns = x.shape
+    f = np.fft.fftshift(np.fft.fftfreq(ns, d=tint / fs))                        # dsp.py:923
+    k = np.fft.fftshift(np.fft.fftfreq(nx, d=xint * dx))                        # dsp.py:924
+    ff, kk = np.meshgrid(f, k)
+    g = 1.0 * ((ff < kk * c_min) & (ff < -kk * c_min))                          # dsp.py:930
+    g2 = 1.0 * ((ff < kk * c_max) & (ff < -kk * c_max))                         # dsp.py:931
+    g = g + np.fliplr(g)                                                        # dsp.py:934
+    g = g - (g2 + np.fliplr(g2))                                                # dsp.py:936
+    g = ndimage.gaussian_filter(g, 20)                                          # dsp.py:940
+    g = (g - g.min()) / (g.max() - g.min())                                     # dsp.py:945
+    F = np.fft.fftshift(np.fft.fft2(x)) * g                                     # dsp.py:919,948
+    return np.fft.ifft2(np.fft.ifftshift(F)).real                               # dsp.py:950,953
+
+
+# --------------------------------------------------------------------------------------------
+# 1-D zero-phase IIR filters
+# --------------------------------------------------------------------------------------------
+def odd_ext(x, n):
+    """scipy.signal._arraytools.odd_ext along the last axis."""
+    left = 2 * x[..., :1] - x[..., n:0:-1]
+    right = 2 * x[..., -1:] - x[..., -2:-(n + 2):-1]
+    return np.concatenate((left, x, right), axis=-1)
+
+
+def filtfilt_ba(b, a, x):
+    """scipy.signal.filtfilt(b, a, x, axis=-1) with its defaults, restated.
+
+    padtype='odd', padlen = 3*max(len(a), len(b)); forward lfilter started at zi*ext[0],
+    backward lfilter on the reversed output started at zi*y[-1]; crop.
+    """
+    x = np.asarray(x, dtype=float)
+    padlen = 3 * max(len(a), len(b))
+    if x.shape[-1] <= padlen:
+        raise ValueError("The length of the input vector x must be greater than padlen, "
+                         "which is %d." % padlen)
+    ext = odd_ext(x, padlen)
+    zi = sps.lfilter_zi(b, a)
+    y, _ = sps.lfilter(b, a, ext, axis=-1, zi=zi * ext[..., :1])
+    y, _ = sps.lfilter(b, a, y[..., ::-1], axis=-1, zi=zi * y[..., -1:])
+    return y[..., ::-1][..., padlen:-padlen]
+
+
+def bp_filt(data, fs, fmin, fmax):
+    """Butterworth-8 band-pass, ba form, filtfilt along time -- dsp.py:859-880."""
+    b, a = sps.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp")              # dsp.py:878
+    return filtfilt_ba(b, a, data)                                              # dsp.py:879
+
+
+def butterworth_filter(filterspec, fs):
+    """SOS Butterworth design -- dsp.py:789-827."""
+    order, crit, kind = filterspec
+    return sps.butter(order, np.array(crit) / (fs / 2), btype=kind, output="sos")  # dsp.py:821-825
+
+
+def sosfiltfilt(sos, x):
+    """scipy.signal.sosfiltfilt(sos, x, axis=-1) restated (user-side call, Example.py:55).
+
+    padlen = 3*(2*n_sections + 1 - min(#(b2==0), #(a2==0))), odd extension, per-section
+    steady-state initial conditions (sosfilt_zi) scaled by the first sample, forward/backward.
+    """
+    sos = np.atleast_2d(np.asarray(sos, dtype=float))
+    x = np.asarray(x, dtype=float)
+    nsec = sos.shape[0]
+    ntaps = 2 * nsec + 1
+    ntaps -= min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())
+    padlen = 3 * ntaps
+    if x.shape[-1] <= padlen:
+        raise ValueError("The length of the input vector x must be greater than padlen, "
+                         "which is %d." % padlen)
+    ext = odd_ext(x, padlen)
+    zi = sps.sosfilt_zi(sos)                                   # (nsec, 2)
+    zshape = (nsec,) + (1,) * (x.ndim - 1) + (2,)
+    zi = zi.reshape(zshape)
+    y, _ = sps.sosfilt(sos, ext, axis=-1, zi=zi * ext[..., :1][None])
+    y, _ = sps.sosfilt(sos, y[..., ::-1], axis=-1, zi=zi * y[..., -1:][None])
+    return y[..., ::-1][..., padlen:-padlen]
+
+
+# --------------------------------------------------------------------------------------------
+# spectral views / metrics
+# --------------------------------------------------------------------------------------------
+def hilbert(x):
+    """scipy.signal.hilbert along the last axis: ifft(fft(x) * h), h = [1,2,..,2,(1),0,..]."""
+    x = np.asarray(x, dtype=float)
+    n = x.shape[-1]
+    h = np.zeros(n)
+    if n % 2 == 0:
+        h[0] = h[n // 2] = 1
+        h[1:n // 2] = 2
+    else:
+        h[0] = 1
+        h[1:(n + 1) // 2] = 2
+    return np.fft.ifft(np.fft.fft(x, axis=-1) * h, axis=-1)
+
+
+def envelope(x):
+    """|hilbert(x)| along time (scripts/main_mfdetect.py:58; detect.py:192)."""
+    return np.abs(hilbert(x))
+
+
+def snr_tr_array(trace, env=False):
+    """10 log10(x^2 / std(x)^2) (population std), optionally on the envelope -- dsp.py:956-976."""
+    x = np.asarray(trace, dtype=float)
+    sd = np.std(x, axis=1, keepdims=True)
+    with np.errstate(divide="ignore"):
+        if env:
+            return 10 * np.log10(np.abs(hilbert(x)) ** 2 / sd ** 2)             # dsp.py:975
+        return 10 * np.log10(x ** 2 / sd ** 2)                                  # dsp.py:976
+
+
+def get_fx(trace, nfft):
+    """2|fftshift(fft(x, nfft))|/nfft * 1e9 -- dsp.py:18-38."""
+    return 2 * np.abs(np.fft.fftshift(np.fft.fft(trace, nfft), axes=1)) / nfft * 1e9
+
+
+def instant_freq(channel, fs):
+    """diff(unwrap(angle(hilbert(x))))/(2 pi) fs -- dsp.py:830-856."""
+    return np.diff(np.unwrap(np.angle(hilbert(channel)))) / (2.0 * np.pi) * fs
+
+
+def librosa_stft(y, n_fft=2048, hop_length=None, **_ignored):
+    """Restatement of librosa.stft as the reference calls it (dsp.py:66-68, detect.py:382).
+
+    librosa >= 0.10 defaults: win_length = n_fft, periodic Hann window, center=True with
+    pad_mode='constant' (zeros), frame t starts at t*hop in the padded signal,
+    n_frames = 1 + len(y)//hop, rows = rfft bins 0..n_fft/2.  
+    """
+    y = np.asarray(y, dtype=float)
+    if hop_length is None:
+        hop_length = n_fft // 4
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)     # get_window('hann', fftbins=True)
+    yp = np.concatenate((np.zeros(n_fft // 2), y, np.zeros(n_fft // 2)))
+    n_frames = 1 + (len(yp) - n_fft) // hop_length
+    idx = np.arange(n_fft)[:, None] + hop_length * np.arange(n_frames)[None, :]
+    return np.fft.rfft(yp[idx] * win[:, None], axis=0)
+
+
+def get_spectrogram(waveform, fs, nfft=128, overlap_pct=0.8):
+    """dB spectrogram normalised by its max -- dsp.py:41-78."""
+    hop = int(np.floor(nfft * (1 - overlap_pct)))                               # dsp.py:68
+    S = np.abs(librosa_stft(waveform, n_fft=nfft, hop_length=hop))              # dsp.py:66
+    tt = np.linspace(0, len(waveform) / fs, num=S.shape[1])                     # dsp.py:74
+    ff = np.linspace(0, fs / 2, num=S.shape[0])                                 # dsp.py:75
+    with np.errstate(divide="ignore"):
+        p = 20 * np.log10(S / np.max(S))                                        # dsp.py:76
+    return p, tt, ff
+
+
+# --------------------------------------------------------------------------------------------
+# matched filter
+# --------------------------------------------------------------------------------------------
+def chirp_linear(t, f0, f1, t1):
+    """scipy.signal.chirp(..., method='linear'): cos(2 pi (f0 t + (f1-f0)/(2 t1) t^2))."""
+    return np.cos(2 * np.pi * (f0 * t + 0.5 * (f1 - f0) / t1 * t * t))
+
+
+def chirp_hyperbolic(t, f0, f1, t1):
+    """scipy.signal.chirp(..., method='hyperbolic') restated (f0 != f1):
+
+    sing = -f1 t1/(f0 - f1); phase = 2 pi (-sing f0) log|1 - t/sing|.
+    """
+    if f0 == f1:
+        return np.cos(2 * np.pi * f0 * t)
+    sing = -f1 * t1 / (f0 - f1)
+    return np.cos(2 * np.pi * (-sing * f0) * np.log(np.abs(1 - t / sing)))
+
+
+def gen_linear_chirp(fmin, fmax, duration, sampling_rate):
+    """Down-sweep fmax -> fmin, linear -- detect.py:20-41."""
+    t = np.arange(0, duration, 1 / sampling_rate)
+    return chirp_linear(t, fmax, fmin, duration)
+
+
+def gen_hyperbolic_chirp(fmin, fmax, duration, sampling_rate):
+    """Down-sweep fmax -> fmin, hyperbolic -- detect.py:44-65."""
+    t = np.arange(0, duration, 1 / sampling_rate)
+    return chirp_hyperbolic(t, fmax, fmin, duration)
+
+
+def gen_template_fincall(time, fs, fmin=15., fmax=25., duration=1., window=True):
+    """Hann-windowed hyperbolic chirp zero-padded to len(time) -- detect.py:68-93."""
+    c = gen_hyperbolic_chirp(fmin, fmax, duration, fs)
+    tpl = np.zeros(np.shape(time))
+    tpl[:len(c)] = c * np.hanning(len(c)) if window else c                      # detect.py:87-90
+    return tpl
+
+
+def shift_xcorr(x, y):
+    """Positive-lag cross-correlation c[k] = sum_n x[n+k] y[n], k = 0..N-1 -- detect.py:96-112.
+
+    (scipy.signal.correlate(x, y, 'full', 'fft')[len(x)-1:]; computed here with zero-padded FFTs.)
+    """
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    n = len(x) + len(y) - 1
+    nfft = 1 << int(np.ceil(np.log2(n)))
+    c = np.fft.irfft(np.fft.rfft(x, nfft) * np.conj(np.fft.rfft(y, nfft)), nfft)
+    return c[: len(x)]
+
+
+def shift_nxcorr(x, y):
+    """shift_xcorr / (std(x) std(y) len(x)) -- detect.py:115-137."""
+    return shift_xcorr(x, y) / (np.std(x) * np.std(y) * len(x))
+
+
+def compute_cross_correlogram(data, template):
+    """Peak-normalised matched filter, row by row -- detect.py:140-166.
+
+    rows: (x - mean)/max|x| (max of the UN-de-meaned row, detect.py:157); template:
+    (y - mean)/max|y| over its zero-padded length (detect.py:158).  Output floating point
+    (the reference's np.empty_like(data) would truncate for integer input -- not replicated).
+    """
+    x = np.asarray(data, dtype=float)
+    xn = (x - x.mean(axis=1, keepdims=True)) / np.max(np.abs(x), axis=1, keepdims=True)
+    t = np.asarray(template, dtype=float)
+    t = (t - t.mean()) / np.max(np.abs(t))
+    n = x.shape[1] + len(t) - 1
+    nfft = 1 << int(np.ceil(np.log2(n)))
+    T = np.conj(np.fft.rfft(t, nfft))
+    c = np.fft.irfft(np.fft.rfft(xn, nfft, axis=1) * T[None, :], nfft, axis=1)
+    return c[:, : x.shape[1]]
+
+
+# --------------------------------------------------------------------------------------------
+# peak picking
+# --------------------------------------------------------------------------------------------
+def find_peaks_prominence(x, threshold):
+    """scipy.signal.find_peaks(x, prominence=threshold)[0] restated.
+
+    Strict local maxima (plateaus -> middle sample, floor); prominence with wlen=None: walk left
+    and right until a sample higher than the peak (or the array end), take the minimum on each
+    side, prominence = peak - max(left_min, right_min); keep prominence >= threshold.
+    Pure-Python loops: small cases only.
+    """
+    x = np.asarray(x, dtype=float)
+    n = len(x)
+    peaks = []
+    i = 1
+    while i < n - 1:
+        if x[i - 1] < x[i]:
+            j = i + 1
+            while j < n - 1 and x[j] == x[i]:
+                j += 1
+            if x[j] < x[i]:
+                peaks.append((i + j - 1) // 2)
+                i = j
+                continue
+        i += 1
+    out = []
+    for p in peaks:
+        lo = x[p]
+        q = p
+        while q >= 0 and x[q] <= x[p]:
+            lo = min(lo, x[q])
+            q -= 1
+        ro = x[p]
+        q = p
+        while q < n and x[q] <= x[p]:
+            ro = min(ro, x[q])
+            q += 1
+        if x[p] - max(lo, ro) >= threshold:
+            out.append(p)
+    return np.asarray(out, dtype=np.int64)
+
+
+def pick_times_env(corr_m, threshold):
+    """Per row find_peaks(|hilbert(c)|, prominence=thr) -- detect.py:169-195 (row order)."""
+    return [sps.find_peaks(np.abs(hilbert(c)), prominence=threshold)[0] for c in np.asarray(corr_m, dtype=float)]
+
+
+def pick_times(corr_m, threshold):
+    """Per row find_peaks(c, prominence=thr) -- detect.py:249-274."""
+    return [sps.find_peaks(c, prominence=threshold)[0] for c in np.asarray(corr_m, dtype=float)]
+
+
+def convert_pick_times(peaks_indexes_m):
+    """Ragged list -> 2 x K array, row 0 = channel index, row 1 = time index -- detect.py:277-303."""
+    ch = [np.full(len(p), i, dtype=np.int64) for i, p in enumerate(peaks_indexes_m)]
+    if not ch:
+        return np.zeros((2, 0))
+    return np.asarray((np.concatenate(ch), np.concatenate([np.asarray(p) for p in peaks_indexes_m])))
+
+
+def select_picked_times(idx_tp, tstart, tend, fs):
+    """Keep picks with tstart*fs <= time index <= tend*fs -- detect.py:306-330."""
+    keep = (idx_tp[1] >= tstart * fs) & (idx_tp[1] <= tend * fs)
+    return (idx_tp[0][keep], idx_tp[1][keep])
+
+
+# --------------------------------------------------------------------------------------------
+# spectrogram correlation
+# --------------------------------------------------------------------------------------------
+def get_sliced_nspectrogram(trace, fs, fmin, fmax, nperseg, nhop):
+    """|STFT| / max, rows with fmin <= f <= fmax -- detect.py:334-408."""
+    S = np.abs(librosa_stft(trace, n_fft=nperseg, hop_length=nhop))             # detect.py:382
+    nf, nt = S.shape
+    tt = np.linspace(0, len(trace) / fs, num=nt)                                # detect.py:385
+    ff = np.linspace(0, fs / 2, num=nf)                                         # detect.py:386
+    p = S / np.max(S)                                                           # detect.py:387
+    keep = np.where((ff >= fmin) & (ff <= fmax))                                # detect.py:390
+    return p[keep], ff[keep], tt
+
+
+def buildkernel(f0, f1, bdwdth, dur, f, t, samp, fmin, fmax):
+    """Hat-function kernel along a hyperbolic sweep, Hann-weighted in time -- detect.py:411-492."""
+    nt = np.size(np.nonzero((t < dur * 8) & (t > dur * 7)))                     # detect.py:456
+    tvec = np.linspace(0, dur, nt)
+    fcurve = f0 * f1 * dur / ((f0 - f1) * tvec + f1 * dur)                      # detect.py:470
+    x = np.asarray(f)[:, None] - fcurve[None, :]
+    K = (1 - x ** 2 / bdwdth ** 2) * np.exp(-x ** 2 / (2 * bdwdth ** 2))        # detect.py:471
+    return tvec, np.asarray(f), K * np.hanning(nt)[None, :]                     # detect.py:474
+
+
+def xcorr2d(spectro, kernel):
+    """Sum over f of per-row 'same' correlation with the kernel, clipped, / (median * n_t) -- detect.py:579-602."""
+    S = np.asarray(spectro, dtype=float)
+    K = np.asarray(kernel, dtype=float)
+    nt, nk = S.shape[1], K.shape[1]
+    full = np.zeros(nt + nk - 1)
+    for r in range(S.shape[0]):
+        full += np.convolve(S[r], K[r, ::-1])                                   # detect.py:597-598
+    start = (nk - 1) // 2                                                       # centred 'same' crop
+    c = full[start:start + nt]
+    c[c < 0] = 0                                                                # detect.py:599
+    return c / (np.median(S) * nk)                                              # detect.py:600
+
+
+def spectrocorr_params(fs, flims, kernel, win_size, overlap_pct):
+    """Parameter derivation of compute_cross_correlogram_spectrocorr -- detect.py:680-696."""
+    nperseg = int(win_size * fs)
+    nhop = int(np.floor(nperseg * (1 - overlap_pct)))
+    fmin, fmax = flims
+    f1, f0, dur, bw = kernel["f1"], kernel["f0"], kernel["dur"], kernel["bdwidth"]
+    if fmax - f1 < 2 * bw:
+        fmax = f1 + 3 * bw
+    if f0 - fmin < 2 * bw:
+        fmin = f0 - 3 * bw
+    return nperseg, nhop, fmin, fmax, f0, f1, dur, bw
+
+
+def compute_cross_correlogram_spectrocorr(data, fs, flims, kernel, win_size, overlap_pct):
+    """Per-channel spectrogram x hat-kernel correlation -- detect.py:650-709."""
+    data = np.asarray(data, dtype=float)
+    nperseg, nhop, fmin, fmax, f0, f1, dur, bw = spectrocorr_params(fs, flims, kernel, win_size, overlap_pct)
+    _, ff, tt = get_sliced_nspectrogram(data[0], fs, fmin, fmax, nperseg, nhop)   # detect.py:699
+    _, _, ker = buildkernel(f0, f1, bw, dur, ff, tt, fs, fmin, fmax)              # detect.py:702
+    out = np.empty((data.shape[0], len(tt)))
+    for i in range(data.shape[0]):                                                # detect.py:705-707
+        S, _, _ = get_sliced_nspectrogram(data[i], fs, fmin, fmax, nperseg, nhop)
+        out[i] = xcorr2d(S, ker)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# deterministic synthetic strain block (SURVEY.md 8d "S-small" recipe, scaled by arguments)
+# --------------------------------------------------------------------------------------------
+def synth_block(nx, ns, fs=200.0, dx=2.0419046878814697, step=4, seed=1234, n_calls=6,
+                n_waves=40):
+    """White noise + slow 'ocean-wave' plane waves + fin-whale notes on hyperbolic moveouts."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(ns) / fs
+    xpos = np.arange(nx) * step * dx
+    d = 1e-9 * rng.standard_normal((nx, ns))
+    for _ in range(n_waves):
+        f = rng.uniform(0.5, 8.0)
+        c = rng.uniform(5.0, 300.0) * rng.choice([-1.0, 1.0])
+        ph = rng.uniform(0, 2 * np.pi)
+        d += 1e-8 / np.sqrt(n_waves) * np.cos(2 * np.pi * f * (t[None, :] - xpos[:, None] / c) + ph)
+    hf = gen_template_fincall(t, fs, 17.8, 28.8, 0.68)
+    lf = gen_template_fincall(t, fs, 14.7, 21.8, 0.78)
+    for i in range(n_calls):
+        tpl = hf if i % 2 == 0 else lf
+        L = int(np.max(np.nonzero(tpl)[0])) + 1
+        x0 = rng.uniform(xpos[0], xpos[-1])
+        r = rng.uniform(1000.0, 5000.0)
+        t0 = rng.uniform(0.05, 0.7) * ns / fs
+        arr = t0 + np.sqrt(r * r + (xpos - x0) ** 2) / 1500.0
+        idx = np.round(arr * fs).astype(int)
+        for c_i in range(nx):
+            a = idx[c_i]
+            if 0 <= a < ns - L:
+                d[c_i, a:a + L] += 5e-9 * tpl[:L]
+    return d
