@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the DAS4Whales hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 20000] [--ns 120000]
+
+One "step" = one pass of the hot path over one [nx x ns] float32 strain block that is already
+resident in HBM: the f-k filter (dsp.fk_filter_filt) followed -- when --stages includes them -- by
+the zero-phase band-pass and the HF+LF matched filter.  Default workload = BASELINE.json
+configs[2] (20 000 channels x 120 000 samples, the shape the metric's target is quoted on).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank filters its own block
+(independent channel blocks / files -- SURVEY.md 8e "replicas", BASELINE config 5), no collective
+in the data path, weak scaling; the timed region is bracketed by barrier + synchronize and the
+MAX over ranks is reported.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+live HIP-event timing) and `cpu_baseline` (NumPy oracle on a bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PASS_NAMES = ["fk_passA_fwd", "fk_passC_fwd", "fk_passB_mid", "fk_passC_inv", "fk_passA_inv"]
+
+
+def classic_mask_shifted(nx, ns, step_dx, fs, device, cs_min=1400., cp_min=1450., cp_max=3400., cs_max=3500.):
+    """dsp.fk_filter_design's speed fan (reference dsp.py:140-161) evaluated with torch ops, row
+    blocks at a time -- bench set-up only (not timed, not the product's design path)."""
+    f = torch.fft.fftshift(torch.fft.fftfreq(ns, d=1.0 / fs, dtype=torch.float64, device=device))
+    k = torch.fft.fftshift(torch.fft.fftfreq(nx, d=step_dx, dtype=torch.float64, device=device))
+    out = torch.empty((nx, ns), dtype=torch.float32, device=device)
+    rb = max(1, (1 << 26) // ns)
+    for r0 in range(0, nx, rb):
+        kk = k[r0:r0 + rb, None]
+        s = (f[None, :] / kk).abs()
+        m = torch.ones_like(s)
+        up = (s >= cs_min) & (s <= cp_min)
+        m = torch.where(up, torch.sin(0.5 * np.pi * (s - cs_min) / (cp_min - cs_min)), m)
+        dn = (s >= cp_max) & (s <= cs_max)
+        m = torch.where(dn, 1.0 - torch.sin(0.5 * np.pi * (s - cp_max) / (cs_max - cp_max)), m)
+        m = torch.where(s >= cs_max, torch.zeros_like(m), m)
+        m = torch.where(s < cs_min, torch.zeros_like(m), m)
+        m = torch.where(kk.abs() < 0.005, torch.zeros_like(m), m)
+        m = torch.nan_to_num(m, nan=0.0)
+        out[r0:r0 + rb] = m.to(torch.float32)
+    return out
+
+
+def cpu_baseline(sample_nx, sample_ns):
+    """NumPy float64 restatement of the reference f-k filter (oracle) on a bounded sample."""
+    from oracle import d4w_oracle as orc
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal((sample_nx, sample_ns))
+    mask = orc.fk_filter_design((sample_nx, sample_ns), [0, sample_nx, 1], 2.0419046878814697, 200.0)
+    mask = np.ascontiguousarray(mask)
+    t0 = time.perf_counter()
+    orc.fk_filter_filt(x, mask)
+    dt = time.perf_counter() - t0
+    return {"value": sample_nx * sample_ns / dt, "unit": "channel-samples/s", "cores": 1, "kind": "port",
+            "sample": "oracle fk_filter_filt (numpy.fft float64, single thread) on %d x %d, %.1f s"
+                      % (sample_nx, sample_ns, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=20000)
+    ap.add_argument("--ns", type=int, default=120000)
+    ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
+    ap.add_argument("--cpu-sample", type=str, default="4000x12000")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=device)
+
+    import das4whales_amd as dw
+    nx, ns = args.nx, args.ns
+    fs, dx = 200.0, 2.0419046878814697
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    x = torch.randn((nx, ns), dtype=torch.float32, device=device, generator=gen)
+    y = torch.empty_like(x)
+    opts = [int(v) for v in args.plan.split(",")] if args.plan else None
+    plan = dw.dsp.FkPlan(nx, ns, opts=opts, device=device)
+    mask = classic_mask_shifted(nx, ns, dx, fs, device)
+    plan.set_mask(mask)
+    del mask
+    torch.cuda.empty_cache()
+
+    def step():
+        plan.apply(x, out=y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    samples = float(nx) * ns
+    value = samples * world / (dt / args.steps)
+
+    # per-kernel HIP-event timing (same inputs, same stream), averaged over the same K
+    acc = np.zeros(5)
+    for _ in range(args.steps):
+        _, ms = plan.apply_timed(x, out=y)
+        acc += np.array(ms)
+    acc /= args.steps
+    dom = int(np.argmax(acc))
+    pass_bytes = 8.0 * samples                       # one read + one write of the block per pass
+    achieved = pass_bytes / (acc[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": PASS_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms": {PASS_NAMES[i]: float(acc[i]) for i in range(5)},
+                "fk_algorithmic_GBps": 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9,
+                "fk_algorithmic_frac": 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if rank == 0:
+        out = {"metric": "channel-samples/sec through f-k filter", "value": value,
+               "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%d channels x %d samples float32 per GPU, classic f-k fan mask "
+                                      "(fk_filter_design defaults), f-k filter" % (nx, ns),
+                          "plan": plan.info(), "parallelism": "independent channel blocks x%d" % world},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu:
+            snx, sns = [int(v) for v in args.cpu_sample.split("x")]
+            out["cpu_baseline"] = cpu_baseline(snx, sns)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

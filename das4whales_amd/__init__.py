@@ -1,0 +1,11 @@
+"""das4whales_amd -- MI355X-native hot path of DAS4Whales (f-k filter, band-pass, matched filter).
+
+Mirrors the reference namespace: `import das4whales_amd as dw; dw.dsp.fk_filter_filt(...)`,
+`dw.detect.compute_cross_correlogram(...)` (reference: src/das4whales/__init__.py:1).
+All array arithmetic runs in hand-written HIP kernels (das4whales_amd/csrc, libd4w.so) behind the
+C ABI in include/d4w.h; PyTorch-ROCm is used only for device memory, streams and RCCL.
+"""
+from . import _lib  # noqa: F401  (fails loudly if the native library is missing)
+from . import dsp  # noqa: F401
+
+__all__ = ["dsp"]

@@ -1,0 +1,58 @@
+"""ctypes binding of libd4w.so -- the C-ABI boundary declared in include/d4w.h.
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing (not built) the import fails loudly with the build command.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libd4w.so")
+
+D4W_OK = 0
+_ERRORS = {-1: ValueError, -2: MemoryError, -3: RuntimeError}
+
+
+class D4WLibraryMissing(ImportError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise D4WLibraryMissing(
+            "das4whales_amd: native library %s not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    c_int, c_void_p, c_char_p = ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p
+    P = ctypes.POINTER
+    sigs = {
+        "d4w_last_error": (c_char_p, []),
+        "d4w_version": (c_char_p, []),
+        "d4w_fk_plan_create": (c_int, [c_int, c_int, P(c_void_p)]),
+        "d4w_fk_plan_create_ex": (c_int, [c_int, c_int, P(c_int), P(c_void_p)]),
+        "d4w_fk_plan_destroy": (c_int, [c_void_p]),
+        "d4w_fk_plan_info": (c_int, [c_void_p, P(c_int)]),
+        "d4w_fk_set_mask_dense_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
+        "d4w_fk_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+        "d4w_fk_apply_timed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(ctypes.c_float)]),
+        "d4w_taper_f32": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sigs
+
+
+lib, SIGNATURES = _load()
+
+
+def check(rc):
+    if rc != D4W_OK:
+        msg = lib.d4w_last_error().decode("utf-8", "replace")
+        raise _ERRORS.get(rc, RuntimeError)("d4w: " + msg)
+
+
+def version():
+    return lib.d4w_version().decode()

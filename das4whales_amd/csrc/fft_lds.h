@@ -1,0 +1,172 @@
+// In-place mixed-radix FFT stages on an LDS-resident tile.
+//
+// Forward = decimation in frequency (natural order in, digit-reversed order out), inverse =
+// decimation in time (digit-reversed in, natural out), so a forward/inverse pair never needs a
+// reordering pass: every butterfly reads R elements and writes the same R LDS locations, one
+// __syncthreads() per stage.  The digit-reversed position <-> frequency map is materialised on
+// the host (FkPlan tables) for the one place that needs actual frequencies (the f-k pair op).
+//
+// Position p of frequency k for radices (R0, R1, ..., Rn-1), L = prod R:
+//     k = d0 + R0*(d1 + R1*(d2 + ...)),   p = d0*L/R0 + d1*L/(R0 R1) + ... + d_{n-1}
+// hence frequency L-1-k sits at position L-1-p (digit-wise complement).
+#pragma once
+#include "fft_radix.h"
+
+namespace d4w {
+
+constexpr int kMaxStages = 10;
+
+struct AxisDesc {
+    int L;                    // transform length
+    int nstage;               // number of radix stages (0 when L == 1)
+    int radix[kMaxStages];    // DIF order
+    const float2* tw;         // device table W_L^i = exp(-2 pi i * i / L), i in [0, L)
+};
+
+// One radix-R stage over `nb0*nb1` independent transforms living in the same LDS tile.
+//   element (transform b = (b0, b1), index n) is at  buf[b0*bs0 + b1*bs1 + n*es]
+//   BATCH_FAST: consecutive threads walk the batch index (strided-axis tiles: conflict-free,
+//   twiddle loads are wave-uniform); otherwise consecutive threads walk the butterfly index
+//   (contiguous rows).
+template <int R, bool INV, bool BATCH_FAST>
+__device__ __forceinline__ void lds_stage(float2* buf, int L, int Ls, int es, int nb0, int bs0,
+                                          int nb1, int bs1, const float2* __restrict__ tw,
+                                          int tid, int nthr) {
+    const int m = Ls / R;          // butterflies per sub-transform group
+    const int nbf = L / R;         // butterflies per transform
+    const int nb = nb0 * nb1;
+    const int total = nbf * nb;
+    const int twstep = L / Ls;
+    const int qs = m * es;
+    for (int w = tid; w < total; w += nthr) {
+        int bf, b;
+        if (BATCH_FAST) {
+            bf = w / nb;
+            b = w - bf * nb;
+        } else {
+            b = w / nbf;
+            bf = w - b * nbf;
+        }
+        const int g = bf / m;
+        const int j = bf - g * m;
+        const int b1 = b / nb0;
+        const int b0 = b - b1 * nb0;
+        float2* p = buf + b0 * bs0 + b1 * bs1 + (g * Ls + j) * es;
+        float2 x[R];
+        static_for<R>([&](auto qq) { constexpr int q = decltype(qq)::value; x[q] = p[q * qs]; });
+        if (!INV) {
+            dft<R>(x);
+            if (m > 1) {
+                static_for<R - 1>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value + 1;
+                    x[q] = c_mul(x[q], tw[j * q * twstep]);
+                });
+            }
+        } else {
+            if (m > 1) {
+                static_for<R - 1>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value + 1;
+                    x[q] = c_mulc(x[q], tw[j * q * twstep]);
+                });
+            }
+            idft<R>(x);
+        }
+        static_for<R>([&](auto qq) { constexpr int q = decltype(qq)::value; p[q * qs] = x[q]; });
+    }
+}
+
+// Loop-based stage for larger prime radices (7 <= R <= 31 in the generic kernels): the naive
+// O(R^2) DFT with LDS re-reads and a private result array.  Compact and register-light, slow;
+// it exists so that the real OOI channel counts (5510 = 2*5*19*29, 11020) are supported.
+template <bool INV, bool BATCH_FAST>
+__device__ __attribute__((noinline)) void lds_stage_prime(int R, float2* buf, int L, int Ls, int es,
+                                                          int nb0, int bs0, int nb1, int bs1,
+                                                          const float2* __restrict__ tw, int tid, int nthr) {
+    const int m = Ls / R;
+    const int nbf = L / R;
+    const int nb = nb0 * nb1;
+    const int total = nbf * nb;
+    const int twstep = L / Ls;
+    const int wr = L / R;          // W_R^a = tw[a * wr]
+    const int qs = m * es;
+    for (int w = tid; w < total; w += nthr) {
+        int bf, b;
+        if (BATCH_FAST) {
+            bf = w / nb;
+            b = w - bf * nb;
+        } else {
+            b = w / nbf;
+            bf = w - b * nbf;
+        }
+        const int g = bf / m;
+        const int j = bf - g * m;
+        const int b1 = b / nb0;
+        const int b0 = b - b1 * nb0;
+        float2* p = buf + b0 * bs0 + b1 * bs1 + (g * Ls + j) * es;
+        float2 y[32];
+#pragma unroll 1
+        for (int k = 0; k < R; ++k) {
+            float2 acc = make_float2(0.f, 0.f);
+            int a = 0;                                   // (q*k) mod R
+#pragma unroll 1
+            for (int q = 0; q < R; ++q) {
+                float2 x = p[q * qs];
+                if (INV) {
+                    x = c_mulc(x, tw[j * q * twstep]);
+                    acc = c_add(acc, c_mulc(x, tw[a * wr]));
+                } else {
+                    acc = c_add(acc, c_mul(x, tw[a * wr]));
+                }
+                a += k;
+                if (a >= R) a -= R;
+            }
+            if (!INV) acc = c_mul(acc, tw[j * k * twstep]);
+            y[k] = acc;
+        }
+#pragma unroll 1
+        for (int k = 0; k < R; ++k) p[k * qs] = y[k];
+    }
+}
+
+// Radices the planner may emit.  FAST kernels carry only the fully unrolled small set (what the
+// benchmark shapes 4000/20000 x 12000/120000 need); GENERIC kernels add the loop-based primes.
+#define D4W_FOR_EACH_FAST_RADIX(X) X(2) X(3) X(4) X(5) X(6) X(8) X(10)
+
+template <bool INV, bool BATCH_FAST, bool GENERIC>
+__device__ __forceinline__ void lds_stage_dispatch(int R, float2* buf, int L, int Ls, int es,
+                                                   int nb0, int bs0, int nb1, int bs1,
+                                                   const float2* __restrict__ tw, int tid, int nthr) {
+    switch (R) {
+#define D4W_CASE(RR) \
+    case RR: lds_stage<RR, INV, BATCH_FAST>(buf, L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr); break;
+        D4W_FOR_EACH_FAST_RADIX(D4W_CASE)
+#undef D4W_CASE
+        default:
+            if (GENERIC) lds_stage_prime<INV, BATCH_FAST>(R, buf, L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr);
+            break;
+    }
+}
+
+// Full transform along one axis of an LDS tile.  The caller must have synchronised the tile
+// before the call; on return the tile is synchronised again.
+template <bool INV, bool BATCH_FAST, bool GENERIC>
+__device__ __forceinline__ void lds_fft(float2* buf, const AxisDesc& ax, int es, int nb0, int bs0,
+                                        int nb1, int bs1, int tid, int nthr) {
+    if (!INV) {
+        int Ls = ax.L;
+        for (int s = 0; s < ax.nstage; ++s) {
+            lds_stage_dispatch<false, BATCH_FAST, GENERIC>(ax.radix[s], buf, ax.L, Ls, es, nb0, bs0, nb1, bs1, ax.tw, tid, nthr);
+            Ls /= ax.radix[s];
+            __syncthreads();
+        }
+    } else {
+        int Ls = 1;
+        for (int s = ax.nstage - 1; s >= 0; --s) {
+            Ls *= ax.radix[s];
+            lds_stage_dispatch<true, BATCH_FAST, GENERIC>(ax.radix[s], buf, ax.L, Ls, es, nb0, bs0, nb1, bs1, ax.tw, tid, nthr);
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace d4w

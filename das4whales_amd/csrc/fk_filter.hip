@@ -1,0 +1,648 @@
+// f-k filter application on MI355X (gfx950): y = real(ifft2(fft2(x) * M')), M' = unshifted mask.
+// Replaces dsp.fk_filter_filt / dsp.fk_filter_sparsefilt (reference dsp.py:725-786).
+//
+// Formulation (see DESIGN.md "f-k filter"):
+//   * the real [nx][ns] block is reinterpreted as a complex [nx][M] block, M = ns/2
+//     (z[c][m] = x[c][2m] + i x[c][2m+1]) -- no conversion pass, the bytes are the same;
+//   * a 2-D complex FFT of z is computed with both axes split four-step style,
+//     nx = C1*C2 (c = c1*C2 + c2) and M = N1*N2 (m = n1*N2 + n2), every 1-D sub-transform running
+//     in LDS as an in-place DIF (forward) / DIT (inverse) pair, so spectra stay in digit-reversed
+//     order and no transposition is ever written to HBM;
+//   * because x is real, the spectrum X(k,f) of x follows from Z(k,f) and conj(Z(-k,M-f)); the
+//     "pair op" in the middle pass untangles the two, applies the Hermitian-folded mask to
+//     X(k,f) and X(k,f+M), and re-tangles -- so no R2C/C2R pass exists either.
+//
+// Five HBM passes, each reading and writing the block once, all in place on y:
+//   A  fwd : tile (all c1) x (all n1) x TA contiguous n2 : 2-D FFT over (c1,n1), 4-step twiddles
+//   C  fwd : tile (all c2) x TC contiguous columns       : FFT over c2
+//   B  mid : two contiguous sub-rows of N2 (a row and its Hermitian partner):
+//            FFT over n2 -> pair op with mask -> inverse FFT over n2
+//   C' inv, A' inv (+ 1/(nx*M) scale).
+#include <algorithm>
+#include <map>
+
+#include "fft_lds.h"
+
+namespace d4w {
+
+struct FkDims {
+    int nx, ns, M, C1, C2, N1, N2, TA, TC;
+};
+
+struct FkDev {  // kernel argument block (by value)
+    FkDims d;
+    AxisDesc ax_c1, ax_c2, ax_n1, ax_n2;
+    const float2* twc;        // [C1 pos q][C2]   W_nx^{c2 * kc1(q)}
+    const float2* twt;        // [N1 pos q1][N2]  W_M^{n2 * k1(q1)}
+    const float2* win;        // [M] packed tukey(ns, 0.03): (w[2m], w[2m+1])
+    const int* row_partner;   // [nx] row position of wavenumber -k
+    const int* q1_partner;    // [N1] position of (N1 - k1) mod N1
+    const int* mirror0;       // [N2] position of (N2 - k2) mod N2
+    const float2* wrow;       // [N1] W_ns^{k1(q1)}
+    const float2* wcol;       // [N2] W_ns^{N1 * k2(i)}
+    const float* mask;        // [nx pos r][N1 pos q1][N2 pos i] folded mask M_h(k, f), f < M
+    const float* nyq;         // [nx pos r] M_h(k, M)
+    float scale;              // 1 / (nx * M)
+};
+
+constexpr int kThreads = 256;
+constexpr int kMaxTile = 8192;   // complex elements per LDS tile (64 KiB)
+
+// ---------------------------------------------------------------------------------------------
+// pass A : (c1, n1) strided 2-D sub-transform
+// ---------------------------------------------------------------------------------------------
+template <bool TAPER, bool GENERIC>
+__global__ __launch_bounds__(kThreads) void fk_passA_fwd(FkDev P, const float2* __restrict__ src,
+                                                          float2* __restrict__ dst) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TA = d.TA;
+    const int b0 = blockIdx.x * TA;
+    const int c2 = blockIdx.y;
+    const int ncol = min(TA, d.N2 - b0);
+    const int nelem = d.C1 * d.N1 * TA;
+    for (int w = tid; w < nelem; w += nthr) {
+        const int seg = w / TA, t = w - seg * TA;
+        const int c1 = seg / d.N1, n1 = seg - c1 * d.N1;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < ncol) {
+            const size_t row = (size_t)c1 * d.C2 + c2;
+            const int col = n1 * d.N2 + b0 + t;
+            v = src[row * d.M + col];
+            if (TAPER) {
+                const float2 wv = P.win[col];
+                v.x *= wv.x;
+                v.y *= wv.y;
+            }
+        }
+        tile[w] = v;
+    }
+    __syncthreads();
+    lds_fft<false, true, GENERIC>(tile, P.ax_c1, d.N1 * TA, d.N1 * TA, 1, 1, 0, tid, nthr);
+    lds_fft<false, true, GENERIC>(tile, P.ax_n1, TA, TA, 1, d.C1, d.N1 * TA, tid, nthr);
+    for (int w = tid; w < nelem; w += nthr) {
+        const int seg = w / TA, t = w - seg * TA;
+        const int q = seg / d.N1, q1 = seg - q * d.N1;
+        if (t < ncol) {
+            float2 v = tile[w];
+            v = c_mul(v, P.twc[q * d.C2 + c2]);
+            v = c_mul(v, P.twt[q1 * d.N2 + b0 + t]);
+            const size_t row = (size_t)q * d.C2 + c2;
+            dst[row * d.M + q1 * d.N2 + b0 + t] = v;
+        }
+    }
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kThreads) void fk_passA_inv(FkDev P, float2* __restrict__ data) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TA = d.TA;
+    const int b0 = blockIdx.x * TA;
+    const int c2 = blockIdx.y;
+    const int ncol = min(TA, d.N2 - b0);
+    const int nelem = d.C1 * d.N1 * TA;
+    for (int w = tid; w < nelem; w += nthr) {
+        const int seg = w / TA, t = w - seg * TA;
+        const int q = seg / d.N1, q1 = seg - q * d.N1;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < ncol) {
+            const size_t row = (size_t)q * d.C2 + c2;
+            v = data[row * d.M + q1 * d.N2 + b0 + t];
+            v = c_mulc(v, P.twc[q * d.C2 + c2]);
+            v = c_mulc(v, P.twt[q1 * d.N2 + b0 + t]);
+        }
+        tile[w] = v;
+    }
+    __syncthreads();
+    lds_fft<true, true, GENERIC>(tile, P.ax_n1, TA, TA, 1, d.C1, d.N1 * TA, tid, nthr);
+    lds_fft<true, true, GENERIC>(tile, P.ax_c1, d.N1 * TA, d.N1 * TA, 1, 1, 0, tid, nthr);
+    for (int w = tid; w < nelem; w += nthr) {
+        const int seg = w / TA, t = w - seg * TA;
+        const int c1 = seg / d.N1, n1 = seg - c1 * d.N1;
+        if (t < ncol) {
+            const size_t row = (size_t)c1 * d.C2 + c2;
+            data[row * d.M + n1 * d.N2 + b0 + t] = c_scale(tile[w], P.scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass C : c2 sub-transform over C2 consecutive rows, TC contiguous columns
+// ---------------------------------------------------------------------------------------------
+template <bool INV, bool GENERIC>
+__global__ __launch_bounds__(kThreads) void fk_passC(FkDev P, float2* __restrict__ data) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TC = d.TC;
+    const int p0 = blockIdx.x * TC;
+    const int q = blockIdx.y;
+    const int ncol = min(TC, d.M - p0);
+    const int nelem = d.C2 * TC;
+    float2* base = data + ((size_t)q * d.C2) * d.M + p0;
+    for (int w = tid; w < nelem; w += nthr) {
+        const int c2 = w / TC, t = w - c2 * TC;
+        tile[w] = (t < ncol) ? base[(size_t)c2 * d.M + t] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    lds_fft<INV, true, GENERIC>(tile, P.ax_c2, TC, TC, 1, 1, 0, tid, nthr);
+    for (int w = tid; w < nelem; w += nthr) {
+        const int c2 = w / TC, t = w - c2 * TC;
+        if (t < ncol) base[(size_t)c2 * d.M + t] = tile[w];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass B : contiguous n2 transform + real-spectrum pair op + mask + inverse
+//
+// For packed element a = (k, f), f = k1 + N1*k2 in [0, M), with partner b = (-k, (M - f) mod M):
+//   A = Z[a], B = conj(Z[b]);  E = (A+B)/2 (even-sample spectrum), O = -i (A-B)/2 (odd-sample)
+//   X(k, f)   = E + W O,  X(k, f+M) = E - W O,  W = exp(-2 pi i f / ns)
+//   Y+ = M_h(k, f) X(k, f),  Y- = M_h(k, f+M) X(k, f+M),  M_h(k, f+M) = M_h(-k, M-f) (Nyquist
+//   column M_h(k, M) when f = 0)
+//   Zy[a] = S + D,  Zy[b] = conj(S - D),  S = (Y+ + Y-)/2,  D = i conj(W) (Y+ - Y-)/2.
+// ---------------------------------------------------------------------------------------------
+template <bool GENERIC>
+__global__ __launch_bounds__(kThreads) void fk_passB(FkDev P, float2* __restrict__ data) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int q1 = blockIdx.x;
+    const int r = blockIdx.y;
+    const int rp = P.row_partner[r];
+    const int q1p = P.q1_partner[q1];
+    const long keyA = (long)r * d.N1 + q1;
+    const long keyB = (long)rp * d.N1 + q1p;
+    if (keyB < keyA) return;   // the partner block owns this pair
+    const bool same = (keyA == keyB);
+    const int N2 = d.N2;
+    float2* rowA = data + (size_t)keyA * N2;
+    float2* rowB = data + (size_t)keyB * N2;
+    float2* A = tile;
+    float2* B = same ? tile : tile + N2;
+    for (int i = tid; i < N2; i += nthr) A[i] = rowA[i];
+    if (!same)
+        for (int i = tid; i < N2; i += nthr) B[i] = rowB[i];
+    __syncthreads();
+    const int nrows = same ? 1 : 2;
+    lds_fft<false, false, GENERIC>(tile, P.ax_n2, 1, nrows, N2, 1, 0, tid, nthr);
+
+    const bool k1zero = (q1 == 0);
+    const float* mA = P.mask + (size_t)keyA * N2;
+    const float* mB = P.mask + (size_t)keyB * N2;
+    const float2 wr = P.wrow[q1];
+    const float nyq = P.nyq[r];
+    for (int i = tid; i < N2; i += nthr) {
+        const int j = k1zero ? P.mirror0[i] : (N2 - 1 - i);
+        if (same && j < i) continue;
+        const float2 a = A[i];
+        const float2 Bc = c_conj(B[j]);
+        const float ma = mA[i];
+        const float mb = (k1zero && i == 0) ? nyq : mB[j];
+        const float2 w = c_mul(wr, P.wcol[i]);
+        const float2 E = c_scale(c_add(a, Bc), 0.5f);
+        const float2 O = c_mul_mi(c_scale(c_sub(a, Bc), 0.5f));
+        const float2 t = c_mul(w, O);
+        const float2 Yp = c_scale(c_add(E, t), ma);
+        const float2 Ym = c_scale(c_sub(E, t), mb);
+        const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
+        const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+        A[i] = c_add(S, D);
+        B[j] = c_conj(c_sub(S, D));
+    }
+    __syncthreads();
+    lds_fft<true, false, GENERIC>(tile, P.ax_n2, 1, nrows, N2, 1, 0, tid, nthr);
+    for (int i = tid; i < N2; i += nthr) rowA[i] = A[i];
+    if (!same)
+        for (int i = tid; i < N2; i += nthr) rowB[i] = B[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// mask fold + permutation into pass-B order (one-off per mask)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* __restrict__ ms,
+                                                          const int* __restrict__ rowk,
+                                                          const int* __restrict__ k1_of_q1,
+                                                          const int* __restrict__ k2_of_i,
+                                                          float* __restrict__ mask,
+                                                          float* __restrict__ nyq) {
+    const int r = blockIdx.y;
+    const int k = rowk[r];
+    const int km = (d.nx - k) % d.nx;
+    const int sx = d.nx / 2, st = d.ns / 2;
+    const size_t rowp = (size_t)((k + sx) % d.nx) * d.ns;    // shifted-grid row of +k
+    const size_t rowm = (size_t)((km + sx) % d.nx) * d.ns;   // shifted-grid row of -k
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.M; p += gridDim.x * blockDim.x) {
+        const int q1 = p / d.N2, i = p - q1 * d.N2;
+        const int f = k1_of_q1[q1] + d.N1 * k2_of_i[i];
+        const int fm = (d.ns - f) % d.ns;
+        const float v = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+        mask[(size_t)r * d.M + p] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int f = d.M, fm = d.ns - d.M;
+        nyq[r] = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void taper_rows(float* __restrict__ x, const float* __restrict__ win,
+                                                        size_t total, int ns) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        x[i] *= win[i % ns];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: planner
+// ---------------------------------------------------------------------------------------------
+static const int kSupportedRadix[] = {2, 3, 4, 5, 6, 7, 8, 10, 11, 13, 17, 19, 23, 29, 31};
+static const int kFastRadix[] = {2, 3, 4, 5, 6, 8, 10};   // keep in sync with D4W_FOR_EACH_FAST_RADIX
+
+static bool factor_radices(int L, std::vector<int>& out) {
+    out.clear();
+    if (L <= 0) return false;
+    int e2 = 0, e3 = 0, e5 = 0;
+    while (L % 2 == 0) { L /= 2; ++e2; }
+    while (L % 3 == 0) { L /= 3; ++e3; }
+    while (L % 5 == 0) { L /= 5; ++e5; }
+    std::vector<int> other;
+    for (int p = 7; p <= 31 && L > 1; ++p)
+        while (L % p == 0) { L /= p; other.push_back(p); }
+    if (L != 1) return false;   // prime factor > 31: needs Bluestein (not implemented)
+    if (e2 % 3 == 1 && e2 >= 4) { out.push_back(4); out.push_back(4); e2 -= 4; }
+    while (e2 >= 3) { out.push_back(8); e2 -= 3; }
+    if (e2 == 2) { out.push_back(4); e2 = 0; }
+    if (e2 == 1) {
+        if (e5 > 0) { out.push_back(10); --e5; }
+        else if (e3 > 0) { out.push_back(6); --e3; }
+        else out.push_back(2);
+    }
+    std::sort(out.begin(), out.end(), [](int a, int b) {   // even radices first, large first
+        const bool pa = (a & (a - 1)) == 0, pb = (b & (b - 1)) == 0;
+        if (pa != pb) return pa;
+        return a > b;
+    });
+    for (int i = 0; i < e5; ++i) out.push_back(5);
+    for (int i = 0; i < e3; ++i) out.push_back(3);
+    for (int p : other) out.push_back(p);
+    if ((int)out.size() > kMaxStages) return false;
+    for (int r : out) {
+        bool ok = false;
+        for (int s : kSupportedRadix) ok |= (s == r);
+        if (!ok) return false;
+    }
+    return true;
+}
+
+// position -> frequency for the DIF digit order (see fft_lds.h)
+static std::vector<int> pos_to_freq(int L, const std::vector<int>& rad) {
+    std::vector<int> f(L, 0);
+    for (int p = 0; p < L; ++p) {
+        int rem = p, weight = L, k = 0, mult = 1;
+        for (int r : rad) {
+            weight /= r;
+            const int dgt = rem / weight;
+            rem -= dgt * weight;
+            k += dgt * mult;
+            mult *= r;
+        }
+        f[p] = k;
+    }
+    return f;
+}
+
+static std::vector<float2> twiddle_table(int L) {
+    std::vector<float2> t(L);
+    for (int i = 0; i < L; ++i) {
+        const double a = -2.0 * M_PI * (double)i / (double)L;
+        t[i] = make_float2((float)cos(a), (float)sin(a));
+    }
+    return t;
+}
+
+static inline float2 wexp(long long num, long long den) {   // exp(-2 pi i num/den)
+    num %= den;
+    const double a = -2.0 * M_PI * (double)num / (double)den;
+    return make_float2((float)cos(a), (float)sin(a));
+}
+
+// scipy.signal.windows.tukey(n, alpha), symmetric (used by dsp.taper_data, dsp.py:721)
+static std::vector<float> tukey_window(int n, double alpha) {
+    std::vector<float> w(n, 1.0f);
+    if (n <= 1 || alpha <= 0) return w;
+    if (alpha >= 1.0) {
+        for (int i = 0; i < n; ++i) w[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / (n - 1)));
+        return w;
+    }
+    const int width = (int)floor(alpha * (n - 1) / 2.0);
+    for (int i = 0; i <= width; ++i)
+        w[i] = (float)(0.5 * (1.0 + cos(M_PI * (-1.0 + 2.0 * i / alpha / (n - 1)))));
+    for (int i = n - width - 1; i < n; ++i)
+        w[i] = (float)(0.5 * (1.0 + cos(M_PI * (-2.0 / alpha + 1.0 + 2.0 * i / alpha / (n - 1)))));
+    return w;
+}
+
+}  // namespace d4w
+
+using namespace d4w;
+
+struct d4w_fk_plan {
+    FkDev dev;
+    std::vector<void*> allocs;
+    int* d_rowk = nullptr;
+    int* d_k1 = nullptr;
+    int* d_k2 = nullptr;
+    float* d_mask = nullptr;
+    float* d_nyq = nullptr;
+    float* d_win_flat = nullptr;
+    bool has_mask = false;
+    bool genericA = false, genericB = false, genericC = false;
+    size_t ldsA = 0, ldsB = 0, ldsC = 0;
+};
+
+template <typename T>
+static int upload(d4w_fk_plan* pl, const std::vector<T>& h, const T** out) {
+    void* p = nullptr;
+    D4W_HIP(hipMalloc(&p, std::max<size_t>(h.size(), 1) * sizeof(T)));
+    pl->allocs.push_back(p);
+    D4W_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return D4W_OK;
+}
+
+static int make_axis(d4w_fk_plan* pl, int L, AxisDesc* ax, std::vector<int>* p2f) {
+    std::vector<int> rad;
+    if (!factor_radices(L, rad))
+        return fail(D4W_EINVAL, "length %d has a prime factor > 31 (Bluestein fallback not implemented)", L);
+    ax->L = L;
+    ax->nstage = (L == 1) ? 0 : (int)rad.size();
+    for (int i = 0; i < kMaxStages; ++i) ax->radix[i] = (i < (int)rad.size() && L > 1) ? rad[i] : 1;
+    if (L == 1) rad.clear();
+    *p2f = pos_to_freq(L, rad);
+    return upload(pl, twiddle_table(L), &ax->tw);
+}
+
+template <typename K, typename... Args>
+static int launch_k(K kern, dim3 grid, dim3 blk, size_t lds, void* stream, Args... args) {
+    hipLaunchKernelGGL(kern, grid, blk, lds, (hipStream_t)stream, args...);
+    D4W_HIP(hipGetLastError());
+    return D4W_OK;
+}
+
+static int largest_divisor_le(int n, int lim) {
+    int best = 1;
+    for (int dd = 1; dd <= lim && dd <= n; ++dd)
+        if (n % dd == 0) best = dd;
+    return best;
+}
+
+extern "C" {
+
+const char* d4w_last_error(void) { return d4w::g_err; }
+
+const char* d4w_version(void) {
+#ifdef D4W_EMU
+    return "d4w 0.1 emu";
+#else
+    return "d4w 0.1 gfx950";
+#endif
+}
+
+int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
+    if (!pl) return D4W_OK;
+    for (void* p : pl->allocs) (void)hipFree(p);
+    delete pl;
+    return D4W_OK;
+}
+
+int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
+    if (!out) return fail(D4W_EINVAL, "plan pointer is NULL");
+    *out = nullptr;
+    if (nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad shape %d x %d", nx, ns);
+    if (ns % 2) return fail(D4W_EINVAL, "ns = %d must be even (packed real transform)", ns);
+    const int M = ns / 2;
+    int o[6] = {0, 0, 0, 0, 0, 0};
+    if (opts) memcpy(o, opts, sizeof(o));
+
+    // --- split the time axis: smallest N1 whose N2 = M/N1 fits one LDS row pair
+    int N1 = o[2], N2 = o[3];
+    if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
+        N1 = 0;
+        for (int cand = 1; cand <= M; ++cand) {
+            if (M % cand) continue;
+            if (M / cand <= kMaxTile / 2) { N1 = cand; break; }
+        }
+        N2 = M / N1;
+    }
+    // --- split the channel axis
+    int C1 = o[0], C2 = o[1];
+    if (C1 <= 0 || C2 <= 0 || C1 * C2 != nx) {
+        C2 = largest_divisor_le(nx, 512);
+        C1 = nx / C2;
+    }
+    int TC = o[5] > 0 ? o[5] : 16;
+    while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
+    int TA = o[4] > 0 ? o[4] : 16;
+    while (TA > 1 && (long)C1 * N1 * TA > kMaxTile) TA /= 2;
+    if ((long)C2 * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * N2 > kMaxTile)
+        return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling (C1=%d C2=%d N1=%d N2=%d)",
+                    nx, ns, C1, C2, N1, N2);
+
+    d4w_fk_plan* pl = new d4w_fk_plan();
+    memset(&pl->dev, 0, sizeof(pl->dev));
+    FkDims& d = pl->dev.d;
+    d = FkDims{nx, ns, M, C1, C2, N1, N2, TA, TC};
+    pl->dev.scale = (float)(1.0 / ((double)nx * (double)M));
+    int rc;
+    std::vector<int> f_c1, f_c2, f_n1, f_n2;
+#define D4W_TRY(x) do { rc = (x); if (rc != D4W_OK) { d4w_fk_plan_destroy(pl); return rc; } } while (0)
+    D4W_TRY(make_axis(pl, C1, &pl->dev.ax_c1, &f_c1));
+    D4W_TRY(make_axis(pl, C2, &pl->dev.ax_c2, &f_c2));
+    D4W_TRY(make_axis(pl, N1, &pl->dev.ax_n1, &f_n1));
+    D4W_TRY(make_axis(pl, N2, &pl->dev.ax_n2, &f_n2));
+
+    // inverse maps frequency -> position
+    std::vector<int> p_c1(C1), p_c2(C2), p_n1(N1), p_n2(N2);
+    for (int p = 0; p < C1; ++p) p_c1[f_c1[p]] = p;
+    for (int p = 0; p < C2; ++p) p_c2[f_c2[p]] = p;
+    for (int p = 0; p < N1; ++p) p_n1[f_n1[p]] = p;
+    for (int p = 0; p < N2; ++p) p_n2[f_n2[p]] = p;
+
+    // four-step twiddles
+    std::vector<float2> twc((size_t)C1 * C2), twt((size_t)N1 * N2);
+    for (int q = 0; q < C1; ++q)
+        for (int c2 = 0; c2 < C2; ++c2) twc[(size_t)q * C2 + c2] = wexp((long long)c2 * f_c1[q], nx);
+    for (int q1 = 0; q1 < N1; ++q1)
+        for (int b = 0; b < N2; ++b) twt[(size_t)q1 * N2 + b] = wexp((long long)b * f_n1[q1], M);
+    D4W_TRY(upload(pl, twc, &pl->dev.twc));
+    D4W_TRY(upload(pl, twt, &pl->dev.twt));
+
+    // Hermitian partner maps
+    std::vector<int> rowk(nx), rowpart(nx), q1part(N1), mirror0(N2);
+    for (int q = 0; q < C1; ++q)
+        for (int p2 = 0; p2 < C2; ++p2) rowk[q * C2 + p2] = f_c1[q] + C1 * f_c2[p2];
+    for (int r = 0; r < nx; ++r) {
+        const int km = (nx - rowk[r]) % nx;
+        rowpart[r] = p_c1[km % C1] * C2 + p_c2[km / C1];
+    }
+    for (int q1 = 0; q1 < N1; ++q1) q1part[q1] = p_n1[(N1 - f_n1[q1]) % N1];
+    for (int i = 0; i < N2; ++i) mirror0[i] = p_n2[(N2 - f_n2[i]) % N2];
+    D4W_TRY(upload(pl, rowpart, &pl->dev.row_partner));
+    D4W_TRY(upload(pl, q1part, &pl->dev.q1_partner));
+    D4W_TRY(upload(pl, mirror0, &pl->dev.mirror0));
+    const int *c_rowk, *c_k1, *c_k2;
+    D4W_TRY(upload(pl, rowk, &c_rowk));
+    D4W_TRY(upload(pl, f_n1, &c_k1));
+    D4W_TRY(upload(pl, f_n2, &c_k2));
+    pl->d_rowk = const_cast<int*>(c_rowk);
+    pl->d_k1 = const_cast<int*>(c_k1);
+    pl->d_k2 = const_cast<int*>(c_k2);
+
+    std::vector<float2> wrow(N1), wcol(N2);
+    for (int q1 = 0; q1 < N1; ++q1) wrow[q1] = wexp(f_n1[q1], ns);
+    for (int i = 0; i < N2; ++i) wcol[i] = wexp((long long)N1 * f_n2[i], ns);
+    D4W_TRY(upload(pl, wrow, &pl->dev.wrow));
+    D4W_TRY(upload(pl, wcol, &pl->dev.wcol));
+
+    // tukey(ns, 0.03) both flat (taper_data) and packed (pass A)
+    std::vector<float> win = tukey_window(ns, 0.03);
+    std::vector<float2> winp(M);
+    for (int m = 0; m < M; ++m) winp[m] = make_float2(win[2 * m], win[2 * m + 1]);
+    D4W_TRY(upload(pl, winp, &pl->dev.win));
+
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)nx * M * sizeof(float)) != hipSuccess) {
+        d4w_fk_plan_destroy(pl);
+        return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte mask failed", (size_t)nx * M * sizeof(float));
+    }
+    pl->allocs.push_back(p);
+    pl->d_mask = (float*)p;
+    pl->dev.mask = pl->d_mask;
+    if (hipMalloc(&p, (size_t)nx * sizeof(float)) != hipSuccess) {
+        d4w_fk_plan_destroy(pl);
+        return fail(D4W_ENOMEM, "hipMalloc failed");
+    }
+    pl->allocs.push_back(p);
+    pl->d_nyq = (float*)p;
+    pl->dev.nyq = pl->d_nyq;
+#undef D4W_TRY
+
+    auto needs_generic = [](const AxisDesc& ax) {
+        for (int s = 0; s < ax.nstage; ++s) {
+            bool fast = false;
+            for (int r : kFastRadix) fast |= (r == ax.radix[s]);
+            if (!fast) return true;
+        }
+        return false;
+    };
+    pl->genericA = needs_generic(pl->dev.ax_c1) || needs_generic(pl->dev.ax_n1);
+    pl->genericB = needs_generic(pl->dev.ax_n2);
+    pl->genericC = needs_generic(pl->dev.ax_c2);
+    pl->ldsA = (size_t)C1 * N1 * TA * sizeof(float2);
+    pl->ldsC = (size_t)C2 * TC * sizeof(float2);
+    pl->ldsB = (size_t)2 * N2 * sizeof(float2);
+    *out = pl;
+    return D4W_OK;
+}
+
+int d4w_fk_plan_create(int nx, int ns, d4w_fk_plan** out) { return d4w_fk_plan_create_ex(nx, ns, nullptr, out); }
+
+int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
+    if (!pl || !info) return fail(D4W_EINVAL, "NULL argument");
+    const FkDims& d = pl->dev.d;
+    const int v[8] = {d.nx, d.ns, d.C1, d.C2, d.N1, d.N2, d.TA, d.TC};
+    memcpy(info, v, sizeof(v));
+    return D4W_OK;
+}
+
+int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* stream) {
+    if (!pl || !mask_shifted) return fail(D4W_EINVAL, "NULL argument");
+    const FkDims& d = pl->dev.d;
+    dim3 grid(std::min(ceil_div(d.M, kThreads), 64), d.nx);
+    D4W_LAUNCH(fk_fold_mask, grid, dim3(kThreads), 0, stream, d, mask_shifted, (const int*)pl->d_rowk,
+               (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq);
+    pl->has_mask = true;
+    return D4W_OK;
+}
+
+static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev) {
+    if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl->has_mask) return fail(D4W_EINVAL, "no mask set on this plan");
+    const FkDev& P = pl->dev;
+    const FkDims& d = P.d;
+    const float2* src = reinterpret_cast<const float2*>(x);
+    float2* dst = reinterpret_cast<float2*>(y);
+    const dim3 blk(kThreads);
+    const dim3 gridA(ceil_div(d.N2, d.TA), d.C2);
+    const dim3 gridC(ceil_div(d.M, d.TC), d.C1);
+    const dim3 gridB(d.N1, d.nx);
+    hipStream_t st = (hipStream_t)stream;
+    // FAST kernels carry only the unrolled radices; GENERIC ones add the loop-based primes
+    const bool gA = pl->genericA, gB = pl->genericB, gC = pl->genericC;
+    int rc;
+#define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
+    D4W_MARK(0);
+    if (taper)
+        rc = launch_k(gA ? fk_passA_fwd<true, true> : fk_passA_fwd<true, false>, gridA, blk, pl->ldsA, stream, P, src, dst);
+    else
+        rc = launch_k(gA ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, gridA, blk, pl->ldsA, stream, P, src, dst);
+    if (rc) return rc;
+    D4W_MARK(1);
+    if ((rc = launch_k(gC ? fk_passC<false, true> : fk_passC<false, false>, gridC, blk, pl->ldsC, stream, P, dst))) return rc;
+    D4W_MARK(2);
+    if ((rc = launch_k(gB ? fk_passB<true> : fk_passB<false>, gridB, blk, pl->ldsB, stream, P, dst))) return rc;
+    D4W_MARK(3);
+    if ((rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst))) return rc;
+    D4W_MARK(4);
+    if ((rc = launch_k(gA ? fk_passA_inv<true> : fk_passA_inv<false>, gridA, blk, pl->ldsA, stream, P, dst))) return rc;
+    D4W_MARK(5);
+#undef D4W_MARK
+    return D4W_OK;
+}
+
+int d4w_fk_apply_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream) {
+    return fk_apply_impl(pl, x, y, taper, stream, nullptr);
+}
+
+int d4w_fk_apply_timed_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, float* ms5) {
+    if (!ms5) return fail(D4W_EINVAL, "NULL argument");
+    hipEvent_t ev[6];
+    for (int i = 0; i < 6; ++i) D4W_HIP(hipEventCreate(&ev[i]));
+    int rc = fk_apply_impl(pl, x, y, taper, stream, ev);
+    if (rc == D4W_OK) {
+        hipError_t e = hipEventSynchronize(ev[5]);
+        if (e != hipSuccess) rc = fail(D4W_EHIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+        for (int i = 0; i < 5 && rc == D4W_OK; ++i) {
+            e = hipEventElapsedTime(&ms5[i], ev[i], ev[i + 1]);
+            if (e != hipSuccess) rc = fail(D4W_EHIP, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+int d4w_taper_f32(float* x, int nx, int ns, void* stream) {
+    if (!x || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    std::vector<float> win = tukey_window(ns, 0.03);
+    float* dwin = nullptr;
+    D4W_HIP(hipMalloc((void**)&dwin, (size_t)ns * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(dwin, win.data(), (size_t)ns * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);   // win is a host temporary
+    if (e != hipSuccess) { (void)hipFree(dwin); return fail(D4W_EHIP, "tukey upload failed: %s", hipGetErrorString(e)); }
+    const size_t total = (size_t)nx * ns;
+    const int blocks = (int)std::min<size_t>((total + kThreads - 1) / kThreads, 4096);
+    hipLaunchKernelGGL(taper_rows, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, (const float*)dwin, total, ns);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(dwin);
+    if (e != hipSuccess) return fail(D4W_EHIP, "taper kernel failed: %s", hipGetErrorString(e));
+    return D4W_OK;
+}
+
+}  // extern "C"

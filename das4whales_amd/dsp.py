@@ -1,0 +1,147 @@
+"""dsp -- MI355X-native mirror of das4whales.dsp (reference: src/das4whales/dsp.py).
+
+Same function names, positional signatures and array conventions as the reference; the array
+arithmetic runs in the HIP library (include/d4w.h).  Filter *design* of 1-D IIR coefficients stays
+on the host in float64 (SciPy), exactly like the reference does.
+"""
+import ctypes
+import threading
+import weakref
+
+import numpy as np
+import torch
+
+from . import _device as dev
+from ._lib import lib, check
+
+
+# ---------------------------------------------------------------------------------------------
+# f-k plans (one per device x shape), with the most recent mask kept folded on the device
+# ---------------------------------------------------------------------------------------------
+class FkPlan:
+    """Owns a d4w_fk_plan (include/d4w.h).  `opts` = (C1, C2, N1, N2, TA, TC) overrides."""
+
+    def __init__(self, nx, ns, opts=None, device=None):
+        dev.require_gpu()
+        self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.nx, self.ns = int(nx), int(ns)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            o = (ctypes.c_int * 6)(*[int(v) for v in opts]) if opts is not None else None
+            check(lib.d4w_fk_plan_create_ex(self.nx, self.ns, o, ctypes.byref(self._h)))
+        self._mask_key = None
+        self._mask_ref = None
+
+    def info(self):
+        v = (ctypes.c_int * 8)()
+        check(lib.d4w_fk_plan_info(self._h, v))
+        return dict(zip(("nx", "ns", "C1", "C2", "N1", "N2", "TA", "TC"), list(v)))
+
+    def set_mask(self, fk_filter_matrix):
+        """Dense ndarray (any order / float dtype), sparse.COO-like (.todense()) or CUDA tensor,
+        on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return."""
+        m = fk_filter_matrix
+        key = (id(m), getattr(m, "_version", None))
+        if self._mask_key == key and self._mask_ref is not None and self._mask_ref() is m:
+            return
+        if hasattr(m, "todense") and not dev.is_tensor(m):
+            md = m.todense()
+        else:
+            md = m
+        shape = tuple(md.shape)
+        if shape != (self.nx, self.ns):
+            raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s"
+                             % (self.nx, self.ns, shape))
+        t = dev.to_device_f32(md, self.device)
+        with torch.cuda.device(self.device):
+            check(lib.d4w_fk_set_mask_dense_f32(self._h, dev.ptr(t), dev.stream_ptr(t)))
+            torch.cuda.current_stream().synchronize()   # t may be a temporary
+        try:
+            self._mask_ref = weakref.ref(m)
+            self._mask_key = key
+        except TypeError:
+            self._mask_ref, self._mask_key = None, None
+
+    def apply(self, x, out=None, taper=False):
+        """x: float32 CUDA tensor [nx, ns]; returns the filtered tensor (out may alias x)."""
+        if tuple(x.shape) != (self.nx, self.ns):
+            raise ValueError("trace shape %s does not match the plan (%d, %d)" % (tuple(x.shape), self.nx, self.ns))
+        if out is None:
+            out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            check(lib.d4w_fk_apply_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.stream_ptr(x)))
+        return out
+
+    def apply_timed(self, x, out=None, taper=False):
+        """Like apply() but returns (out, [ms per pass A, C, B, C', A']) via HIP events."""
+        if out is None:
+            out = torch.empty_like(x)
+        ms = (ctypes.c_float * 5)()
+        with torch.cuda.device(self.device):
+            check(lib.d4w_fk_apply_timed_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.stream_ptr(x), ms))
+        return out, list(ms)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.d4w_fk_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_plans = {}
+_plans_lock = threading.Lock()
+
+
+def get_fk_plan(nx, ns, device=None):
+    device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+    key = (str(device), int(nx), int(ns))
+    with _plans_lock:
+        p = _plans.get(key)
+        if p is None:
+            if len(_plans) >= 4:          # plans hold an nx*ns/2 float mask each: keep few
+                _plans.pop(next(iter(_plans)))
+            p = _plans[key] = FkPlan(nx, ns, device=device)
+        return p
+
+
+def _fk_apply(trace, fk_filter_matrix, tapering):
+    if getattr(trace, "ndim", 0) != 2:
+        raise ValueError("trace must be a 2-D [channel x time] array")
+    nx, ns = trace.shape
+    device = trace.device if dev.is_tensor(trace) and trace.is_cuda else None
+    plan = get_fk_plan(nx, ns, device)
+    plan.set_mask(fk_filter_matrix)
+    x = dev.to_device_f32(trace, plan.device)
+    y = plan.apply(x, taper=tapering)
+    return dev.like_input(y, trace)
+
+
+def fk_filter_filt(trace, fk_filter_matrix, tapering=False):
+    """Apply a pre-computed f-k mask (dense, on the fftshift-ed grid) -- reference dsp.py:725-756.
+
+    Unlike the reference, `tapering=True` does not modify `trace` in place."""
+    return _fk_apply(trace, fk_filter_matrix, tapering)
+
+
+def fk_filter_sparsefilt(trace, fk_filter_matrix, tapering=False):
+    """Same with a sparse.COO mask -- reference dsp.py:759-786 (dense masks are accepted too)."""
+    return _fk_apply(trace, fk_filter_matrix, tapering)
+
+
+fk_filter = fk_filter_filt      # north-star spelling
+
+
+def taper_data(trace):
+    """trace *= tukey(ns, 0.03) along time, IN PLACE like the reference -- dsp.py:705-722."""
+    if dev.is_tensor(trace) and trace.is_cuda and trace.dtype == torch.float32 and trace.is_contiguous():
+        check(lib.d4w_taper_f32(dev.ptr(trace), trace.shape[0], trace.shape[1], dev.stream_ptr(trace)))
+        return trace
+    x = dev.to_device_f32(trace)
+    check(lib.d4w_taper_f32(dev.ptr(x), x.shape[0], x.shape[1], dev.stream_ptr(x)))
+    if dev.is_tensor(trace):
+        trace.copy_(x.to(trace.dtype))
+    else:
+        trace[...] = x.cpu().numpy().astype(trace.dtype, copy=False)
+    return trace

@@ -1,0 +1,64 @@
+"""f-k filter kernel LOGIC on the CPU emulator build (tests/emu/hip_emu.h): same HIP sources,
+same C ABI, host pointers.  Complements -- never replaces -- the -m gpu parity tests."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import d4w_oracle as orc
+from tests.emu_util import load_emu, vp
+
+TOL = 1e-5   # north-star tolerance: max|y - ref| <= 1e-5 * max|ref| in float32
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return load_emu()
+
+
+def fk_emu(lib, x, mask, opts=None, taper=0):
+    nx, ns = x.shape
+    plan = ctypes.c_void_p()
+    o = (ctypes.c_int * 6)(*opts) if opts else None
+    rc = lib.d4w_fk_plan_create_ex(nx, ns, o, ctypes.byref(plan))
+    assert rc == 0, lib.d4w_last_error()
+    m = np.ascontiguousarray(mask, dtype=np.float32)
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(xf)
+    assert lib.d4w_fk_set_mask_dense_f32(plan, vp(m), None) == 0
+    assert lib.d4w_fk_apply_f32(plan, vp(xf), vp(y), taper, None) == 0, lib.d4w_last_error()
+    lib.d4w_fk_plan_destroy(plan)
+    return y
+
+
+def rel(y, ref):
+    return np.max(np.abs(y - ref)) / np.max(np.abs(ref))
+
+
+def test_golden_masks(emu, golden):
+    g = golden("fk_40x480.npz")
+    x = g["x"]
+    assert rel(fk_emu(emu, x, g["m_classic"]), g["y_classic"]) < TOL
+    assert rel(fk_emu(emu, x, g["m_ninf"], opts=[8, 5, 6, 40, 8, 7]), g["y_ninf"]) < TOL     # non-Hermitian mask
+    assert rel(fk_emu(emu, x, g["m_classic"], opts=[4, 10, 8, 30, 7, 16], taper=1), g["y_classic_taper"]) < TOL
+
+
+def test_odd_channels_and_prime_radices(emu):
+    rng = np.random.default_rng(0)
+    for nx, ns, opts in [(38, 406, [19, 2, 7, 29, 4, 4]), (7, 14, None), (1, 64, None), (64, 2, None)]:
+        x = rng.standard_normal((nx, ns))
+        m = rng.random((nx, ns))
+        assert rel(fk_emu(emu, x, m, opts), orc.fk_filter_filt(x, m)) < TOL
+
+
+def test_in_place(emu, golden):
+    g = golden("fk_30x360.npz")
+    nx, ns = g["x"].shape
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+    m = np.ascontiguousarray(g["m_ninf"], dtype=np.float32)
+    buf = np.ascontiguousarray(g["x"], dtype=np.float32)
+    assert emu.d4w_fk_set_mask_dense_f32(plan, vp(m), None) == 0
+    assert emu.d4w_fk_apply_f32(plan, vp(buf), vp(buf), 0, None) == 0
+    emu.d4w_fk_plan_destroy(plan)
+    assert rel(buf, g["y_ninf"]) < TOL

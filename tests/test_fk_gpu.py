@@ -1,0 +1,143 @@
+"""GPU parity tests of the f-k filter: HIP path (through the C ABI) vs the reference's golden
+outputs and vs the CPU oracle on seeded inputs; size-independent properties at full size.
+
+Tolerance (north star): max|y - y_ref| <= 1e-5 * max|y_ref| with float32 arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def rel(y, ref):
+    return float(np.max(np.abs(np.asarray(y, dtype=np.float64) - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import das4whales_amd as dw_
+    from das4whales_amd import _lib
+    assert "gfx950" in _lib.version()
+    return dw_
+
+
+def test_golden_all_masks(dw, golden):
+    g = golden("fk_40x480.npz")
+    x = g["x"]
+    for km, ky in [("m_classic", "y_classic"), ("m_ninf", "y_ninf"), ("m_hybrid", "y_hybrid"),
+                   ("m_ninf_gs", "y_ninf_gs")]:
+        y = dw.dsp.fk_filter_filt(x, g[km])
+        assert y.dtype == np.float64 and y.shape == x.shape
+        assert rel(y, g[ky]) < TOL, km
+    # Fortran-ordered mask (what fk_filter_design returns, dsp.py:137) and the sparse entry point
+    yf = dw.dsp.fk_filter_sparsefilt(x, np.asfortranarray(g["m_classic"]))
+    assert rel(yf, g["y_classic"]) < TOL
+    xc = x.copy()
+    yt = dw.dsp.fk_filter_filt(xc, g["m_classic"], tapering=True)
+    assert rel(yt, g["y_classic_taper"]) < TOL
+    assert np.array_equal(xc, x)            # not modified in place (documented deviation)
+
+
+def test_golden_second_shape_and_coo(dw, golden):
+    h = golden("fk_30x360.npz")
+
+    class COO:                               # sparse.COO duck type: .todense(), .shape
+        def __init__(self, d):
+            self._d, self.shape = d, d.shape
+
+        def todense(self):
+            return self._d
+    assert rel(dw.dsp.fk_filter_sparsefilt(h["x"], COO(h["m_ninf"])), h["y_ninf"]) < TOL
+    assert rel(dw.dsp.fk_filter_filt(h["x"].astype(np.float32), h["m_classic"]), h["y_classic"]) < TOL
+
+
+@pytest.mark.parametrize("nx,ns,opts", [
+    (38, 406, (19, 2, 7, 29, 4, 4)),        # loop-based prime radices 19, 29, 7
+    (93, 286, (31, 3, 11, 13, 2, 2)),
+    (7, 14, None), (1, 64, None), (64, 2, None), (3, 4, None),
+    (551, 1200, None),                       # 19 * 29 channels (OOI 5510 = 10 * 551)
+    (250, 3000, (5, 50, 3, 500, 8, 16)),
+    (250, 3000, (25, 10, 15, 100, 16, 16)),
+    (1000, 2400, None),
+])
+def test_random_shapes_vs_oracle(dw, nx, ns, opts):
+    rng = np.random.default_rng(nx * 7919 + ns)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))                 # arbitrary, non-Hermitian mask
+    ref = orc.fk_filter_filt(x, m)
+    plan = dw.dsp.FkPlan(nx, ns, opts=opts)
+    plan.set_mask(m)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    y = plan.apply(xt)
+    assert rel(y.cpu().numpy(), ref) < TOL
+    # in place
+    plan.apply(xt, out=xt)
+    assert rel(xt.cpu().numpy(), ref) < TOL
+
+
+def test_config1_block_vs_oracle(dw):
+    """BASELINE configs[0]/[1] geometry: 4000 channels x 12000 samples, scripts' hybrid_ninf mask
+    and the classic fan, synthetic OOI-like block (SURVEY 8d 'S-small')."""
+    nx, ns, fs, dx = 4000, 12000, 200.0, 2.0419046878814697
+    sel = [9794, 25794, 4]
+    x = orc.synth_block(nx, ns, fs=fs, dx=dx, step=4, seed=1234, n_calls=6, n_waves=10) * 1e9
+    m = orc.hybrid_ninf_filter_design((nx, ns), sel, dx, fs, cs_min=1350., cp_min=1450., cp_max=3300,
+                                      cs_max=3450, fmin=14., fmax=30.)
+    ref = orc.fk_filter_filt(x, m)
+    y = dw.dsp.fk_filter_sparsefilt(x, m)
+    e = rel(y, ref)
+    print("config-1 block, hybrid_ninf: rel err %.3e" % e)
+    assert e < TOL
+    # tensor in -> tensor out, no host round trip
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    yt = dw.dsp.fk_filter_filt(xt, m)
+    assert isinstance(yt, torch.Tensor) and yt.is_cuda and yt.dtype == torch.float32
+    assert rel(yt.cpu().numpy(), ref) < TOL
+
+
+def test_plane_wave_known_answer(dw):
+    """a plane wave inside the speed fan passes, one outside is removed."""
+    nx, ns, fs, dx = 1000, 2400, 200.0, 8.0
+    m = orc.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)
+    t = np.arange(ns) / fs
+    xpos = np.arange(nx) * dx
+    f0 = 20.0
+
+    def wave(c):
+        k0 = np.round(f0 / c * nx * dx) / (nx * dx)          # on-grid wavenumber
+        return np.cos(2 * np.pi * (f0 * t[None, :] - k0 * xpos[:, None]))
+    y_in = dw.dsp.fk_filter_filt(wave(2000.0), m)
+    y_out = dw.dsp.fk_filter_filt(wave(300.0), m)
+    assert rel(y_in, wave(2000.0)) < 1e-4
+    assert np.max(np.abs(y_out)) < 1e-4
+
+
+def test_full_size_properties(dw):
+    """BASELINE configs[2] shape 20000 x 120000 (9.6 GB): all-pass mask == identity, linearity,
+    and zero mask == zero -- size-independent properties, no oracle at this size."""
+    nx, ns = 20000, 120000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 45e9:
+        pytest.skip("needs ~45 GB of HBM")
+    plan = dw.dsp.FkPlan(nx, ns)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    x = torch.randn((nx, ns), dtype=torch.float32, device="cuda", generator=gen)
+    ones = torch.ones((nx, ns), dtype=torch.float32, device="cuda")
+    plan.set_mask(ones)
+    del ones
+    y = plan.apply(x)
+    err = float((y - x).abs().max() / x.abs().max())
+    print("20000x120000 identity-mask error %.3e" % err)
+    assert err < TOL
+    # linearity: F(2x) == 2 F(x) with a non-trivial (half-strength) mask
+    half = torch.full((nx, ns), 0.5, dtype=torch.float32, device="cuda")
+    plan.set_mask(half)
+    del half
+    plan.apply(x, out=y)
+    err2 = float((y - 0.5 * x).abs().max() / x.abs().max())
+    assert err2 < TOL
