@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--nx", type=int, default=20000)
     ap.add_argument("--ns", type=int, default=120000)
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
-    ap.add_argument("--cpu-sample", type=str, default="4000x12000")
+    ap.add_argument("--cpu-sample", type=str, default="8000x24000")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -70,5 +70,25 @@ __device__ __forceinline__ float2 c_mul_mi(float2 a) { return make_float2(a.y, -
 // multiply by +i : (x, y) -> (-y, x)
 __device__ __forceinline__ float2 c_mul_pi(float2 a) { return make_float2(-a.y, a.x); }
 
+// 24-bit integer multiply (full-rate v_mul_i32_i24; v_mul_lo_u32 is quarter rate) and fast reciprocal
+#ifdef D4W_EMU
+__device__ __forceinline__ int d4w_mul24(int a, int b) { return a * b; }
+__device__ __forceinline__ float d4w_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ int d4w_mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ float d4w_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() on gfx9 lowers to
+// `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, which would drain the global prefetch loads and the
+// tile stores that the pipelined pass kernels deliberately keep in flight across the FFT stages.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef D4W_EMU
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace d4w

@@ -20,7 +20,43 @@ struct AxisDesc {
     int L;                    // transform length
     int nstage;               // number of radix stages (0 when L == 1)
     int radix[kMaxStages];    // DIF order
-    const float2* tw;         // device table W_L^i = exp(-2 pi i * i / L), i in [0, L)
+    int nhi;                  // entries of the coarse twiddle table = ceil(L / 64)
+    const float2* tw2;        // device table, two-level: [0,64) -> W_L^a ; [64, 64+nhi) -> W_L^(64 b)
+};
+
+// Two-level twiddle table staged in LDS: W_L^t = lo[t & 63] * hi[t >> 6]  (one extra rounding).
+// Keeping twiddles in LDS means the FFT stages issue no vector-memory loads, so global prefetch
+// loads of the next tile stay in flight across the whole compute phase (vmcnt is in-order).
+constexpr int kTwLo = 64;
+struct TwLds {
+    const float2* lo;
+    const float2* hi;
+    __device__ __forceinline__ float2 get(int t) const { return c_mul(lo[t & (kTwLo - 1)], hi[t >> 6]); }
+};
+__device__ __forceinline__ int tw_lds_elems(const AxisDesc& ax) { return kTwLo + ax.nhi; }
+// cooperative copy of an axis table into LDS (caller synchronises)
+__device__ __forceinline__ TwLds tw_stage(const AxisDesc& ax, float2* dst, int tid, int nthr) {
+    const int n = kTwLo + ax.nhi;
+    for (int i = tid; i < n; i += nthr) dst[i] = ax.tw2[i];
+    TwLds t;
+    t.lo = dst;
+    t.hi = dst + kTwLo;
+    return t;
+}
+
+// a / d for 0 <= a < 2^24 via a float reciprocal and a +-1 fix-up (~6 VALU ops instead of the
+// ~35 of a 32-bit integer division)
+struct FDiv {
+    int d;
+    float rd;
+    __device__ __forceinline__ explicit FDiv(int d_) : d(d_), rd(d4w_rcp((float)d_)) {}
+    __device__ __forceinline__ int div(int a) const {
+        int q = (int)((float)a * rd);
+        const int r = a - d4w_mul24(q, d);
+        q += (r >= d) ? 1 : 0;
+        q -= (r < 0) ? 1 : 0;
+        return q;
+    }
 };
 
 // One radix-R stage over `nb0*nb1` independent transforms living in the same LDS tile.
@@ -28,9 +64,11 @@ struct AxisDesc {
 //   BATCH_FAST: consecutive threads walk the batch index (strided-axis tiles: conflict-free,
 //   twiddle loads are wave-uniform); otherwise consecutive threads walk the butterfly index
 //   (contiguous rows).
+// Twiddles: ONE table load w = W_Ls^j per butterfly; the powers w^2..w^(R-1) are formed by a
+// log-depth product tree in registers (<= 4 roundings deep for R = 10), instead of R-1 gathers.
 template <int R, bool INV, bool BATCH_FAST>
 __device__ __forceinline__ void lds_stage(float2* buf, int L, int Ls, int es, int nb0, int bs0,
-                                          int nb1, int bs1, const float2* __restrict__ tw,
+                                          int nb1, int bs1, const TwLds tw,
                                           int tid, int nthr) {
     const int m = Ls / R;          // butterflies per sub-transform group
     const int nbf = L / R;         // butterflies per transform
@@ -38,38 +76,45 @@ __device__ __forceinline__ void lds_stage(float2* buf, int L, int Ls, int es, in
     const int total = nbf * nb;
     const int twstep = L / Ls;
     const int qs = m * es;
+    const FDiv d_outer(BATCH_FAST ? nb : nbf), d_m(m), d_nb0(nb0);
     for (int w = tid; w < total; w += nthr) {
         int bf, b;
         if (BATCH_FAST) {
-            bf = w / nb;
-            b = w - bf * nb;
+            bf = d_outer.div(w);
+            b = w - d4w_mul24(bf, nb);
         } else {
-            b = w / nbf;
-            bf = w - b * nbf;
+            b = d_outer.div(w);
+            bf = w - d4w_mul24(b, nbf);
         }
-        const int g = bf / m;
-        const int j = bf - g * m;
-        const int b1 = b / nb0;
-        const int b0 = b - b1 * nb0;
-        float2* p = buf + b0 * bs0 + b1 * bs1 + (g * Ls + j) * es;
+        const int g = d_m.div(bf);
+        const int j = bf - d4w_mul24(g, m);
+        const int b1 = (nb1 == 1) ? 0 : d_nb0.div(b);
+        const int b0 = b - d4w_mul24(b1, nb0);
+        float2* p = buf + d4w_mul24(b0, bs0) + d4w_mul24(b1, bs1) + d4w_mul24(d4w_mul24(g, Ls) + j, es);
         float2 x[R];
         static_for<R>([&](auto qq) { constexpr int q = decltype(qq)::value; x[q] = p[q * qs]; });
-        if (!INV) {
-            dft<R>(x);
-            if (m > 1) {
+        if (m > 1) {
+            float2 pw[R];
+            pw[1] = tw.get(d4w_mul24(j, twstep));
+            static_for<R - 2>([&](auto qq) {
+                constexpr int q = decltype(qq)::value + 2;
+                pw[q] = c_mul(pw[q / 2], pw[q - q / 2]);
+            });
+            if (!INV) {
+                dft<R>(x);
                 static_for<R - 1>([&](auto qq) {
                     constexpr int q = decltype(qq)::value + 1;
-                    x[q] = c_mul(x[q], tw[j * q * twstep]);
+                    x[q] = c_mul(x[q], pw[q]);
                 });
+            } else {
+                static_for<R - 1>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value + 1;
+                    x[q] = c_mulc(x[q], pw[q]);
+                });
+                idft<R>(x);
             }
         } else {
-            if (m > 1) {
-                static_for<R - 1>([&](auto qq) {
-                    constexpr int q = decltype(qq)::value + 1;
-                    x[q] = c_mulc(x[q], tw[j * q * twstep]);
-                });
-            }
-            idft<R>(x);
+            if (!INV) dft<R>(x); else idft<R>(x);
         }
         static_for<R>([&](auto qq) { constexpr int q = decltype(qq)::value; p[q * qs] = x[q]; });
     }
@@ -81,7 +126,7 @@ __device__ __forceinline__ void lds_stage(float2* buf, int L, int Ls, int es, in
 template <bool INV, bool BATCH_FAST>
 __device__ __attribute__((noinline)) void lds_stage_prime(int R, float2* buf, int L, int Ls, int es,
                                                           int nb0, int bs0, int nb1, int bs1,
-                                                          const float2* __restrict__ tw, int tid, int nthr) {
+                                                          const TwLds tw, int tid, int nthr) {
     const int m = Ls / R;
     const int nbf = L / R;
     const int nb = nb0 * nb1;
@@ -112,15 +157,15 @@ __device__ __attribute__((noinline)) void lds_stage_prime(int R, float2* buf, in
             for (int q = 0; q < R; ++q) {
                 float2 x = p[q * qs];
                 if (INV) {
-                    x = c_mulc(x, tw[j * q * twstep]);
-                    acc = c_add(acc, c_mulc(x, tw[a * wr]));
+                    x = c_mulc(x, tw.get(j * q * twstep));
+                    acc = c_add(acc, c_mulc(x, tw.get(a * wr)));
                 } else {
-                    acc = c_add(acc, c_mul(x, tw[a * wr]));
+                    acc = c_add(acc, c_mul(x, tw.get(a * wr)));
                 }
                 a += k;
                 if (a >= R) a -= R;
             }
-            if (!INV) acc = c_mul(acc, tw[j * k * twstep]);
+            if (!INV) acc = c_mul(acc, tw.get(j * k * twstep));
             y[k] = acc;
         }
 #pragma unroll 1
@@ -135,7 +180,7 @@ __device__ __attribute__((noinline)) void lds_stage_prime(int R, float2* buf, in
 template <bool INV, bool BATCH_FAST, bool GENERIC>
 __device__ __forceinline__ void lds_stage_dispatch(int R, float2* buf, int L, int Ls, int es,
                                                    int nb0, int bs0, int nb1, int bs1,
-                                                   const float2* __restrict__ tw, int tid, int nthr) {
+                                                   const TwLds tw, int tid, int nthr) {
     switch (R) {
 #define D4W_CASE(RR) \
     case RR: lds_stage<RR, INV, BATCH_FAST>(buf, L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr); break;
@@ -150,21 +195,21 @@ __device__ __forceinline__ void lds_stage_dispatch(int R, float2* buf, int L, in
 // Full transform along one axis of an LDS tile.  The caller must have synchronised the tile
 // before the call; on return the tile is synchronised again.
 template <bool INV, bool BATCH_FAST, bool GENERIC>
-__device__ __forceinline__ void lds_fft(float2* buf, const AxisDesc& ax, int es, int nb0, int bs0,
-                                        int nb1, int bs1, int tid, int nthr) {
+__device__ __forceinline__ void lds_fft(float2* buf, const AxisDesc& ax, const TwLds tw, int es, int nb0,
+                                        int bs0, int nb1, int bs1, int tid, int nthr) {
     if (!INV) {
         int Ls = ax.L;
         for (int s = 0; s < ax.nstage; ++s) {
-            lds_stage_dispatch<false, BATCH_FAST, GENERIC>(ax.radix[s], buf, ax.L, Ls, es, nb0, bs0, nb1, bs1, ax.tw, tid, nthr);
+            lds_stage_dispatch<false, BATCH_FAST, GENERIC>(ax.radix[s], buf, ax.L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr);
             Ls /= ax.radix[s];
-            __syncthreads();
+            lds_barrier();
         }
     } else {
         int Ls = 1;
         for (int s = ax.nstage - 1; s >= 0; --s) {
             Ls *= ax.radix[s];
-            lds_stage_dispatch<true, BATCH_FAST, GENERIC>(ax.radix[s], buf, ax.L, Ls, es, nb0, bs0, nb1, bs1, ax.tw, tid, nthr);
-            __syncthreads();
+            lds_stage_dispatch<true, BATCH_FAST, GENERIC>(ax.radix[s], buf, ax.L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr);
+            lds_barrier();
         }
     }
 }

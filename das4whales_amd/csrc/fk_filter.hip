@@ -19,6 +19,7 @@
 //            FFT over n2 -> pair op with mask -> inverse FFT over n2
 //   C' inv, A' inv (+ 1/(nx*M) scale).
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 
 #include "fft_lds.h"
@@ -42,119 +43,211 @@ struct FkDev {  // kernel argument block (by value)
     const float2* wcol;       // [N2] W_ns^{N1 * k2(i)}
     const float* mask;        // [nx pos r][N1 pos q1][N2 pos i] folded mask M_h(k, f), f < M
     const float* nyq;         // [nx pos r] M_h(k, M)
+    const int2* pairs;        // pass-B work list (keyA, keyB)
     float scale;              // 1 / (nx * M)
 };
 
-constexpr int kThreads = 256;
-constexpr int kMaxTile = 8192;   // complex elements per LDS tile (64 KiB)
+constexpr int kThreads = 256;      // threads of the small helper kernels
+#ifndef D4W_FK_THREADS
+#define D4W_FK_THREADS 512
+#endif
+constexpr int kMaxThreads = D4W_FK_THREADS;   // block size of the pass kernels
+constexpr int kMaxTile = 8192;     // complex elements per LDS tile (64 KiB)
+constexpr int kPF = kMaxTile / kMaxThreads;   // prefetch registers (float2) per thread
+
+// Every pass kernel is persistent (grid = 2 workgroups per CU) and software-pipelined:
+//     prefetch tile i+1 (global -> registers, no wait) | FFT stages of tile i in LDS | store tile i
+// The FFT stages touch only LDS (twiddles included), so the prefetch loads stay in flight across
+// the whole compute phase and the stores of tile i drain under the next iteration.
 
 // ---------------------------------------------------------------------------------------------
-// pass A : (c1, n1) strided 2-D sub-transform
+// pass A : (c1, n1) strided 2-D sub-transform.  tile id = c2 * ntx + bx  (bx fastest: adjacent
+// workgroups touch adjacent 64/128-byte segments of the same rows)
 // ---------------------------------------------------------------------------------------------
 template <bool TAPER, bool GENERIC>
-__global__ __launch_bounds__(kThreads) void fk_passA_fwd(FkDev P, const float2* __restrict__ src,
-                                                          float2* __restrict__ dst) {
+__global__ __launch_bounds__(kMaxThreads) void fk_passA_fwd(FkDev P, const float2* __restrict__ src,
+                                                            float2* __restrict__ dst, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const FkDims& d = P.d;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int TA = d.TA;
-    const int b0 = blockIdx.x * TA;
-    const int c2 = blockIdx.y;
-    const int ncol = min(TA, d.N2 - b0);
     const int nelem = d.C1 * d.N1 * TA;
-    for (int w = tid; w < nelem; w += nthr) {
-        const int seg = w / TA, t = w - seg * TA;
-        const int c1 = seg / d.N1, n1 = seg - c1 * d.N1;
-        float2 v = make_float2(0.f, 0.f);
-        if (t < ncol) {
-            const size_t row = (size_t)c1 * d.C2 + c2;
-            const int col = n1 * d.N2 + b0 + t;
-            v = src[row * d.M + col];
-            if (TAPER) {
-                const float2 wv = P.win[col];
-                v.x *= wv.x;
-                v.y *= wv.y;
+    const int ntx = (d.N2 + TA - 1) / TA;
+    const FDiv dTA(TA), dN1(d.N1), dntx(ntx);
+    const TwLds tw_c1 = tw_stage(P.ax_c1, tile + nelem, tid, nthr);
+    const TwLds tw_n1 = tw_stage(P.ax_n1, tile + nelem + tw_lds_elems(P.ax_c1), tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int seg = dTA.div(w), tt = w - seg * TA;
+                const int c1 = dN1.div(seg), n1 = seg - c1 * d.N1;
+                if (tt < ncol) {
+                    const size_t row = (size_t)c1 * d.C2 + c2;
+                    const int col = n1 * d.N2 + b0 + tt;
+                    v = src[row * d.M + col];
+                    if (TAPER) {
+                        const float2 wv = P.win[col];
+                        v.x *= wv.x;
+                        v.y *= wv.y;
+                    }
+                }
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) tile[w] = pf[it];
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<false, true, GENERIC>(tile, P.ax_c1, tw_c1, d.N1 * TA, d.N1 * TA, 1, 1, 0, tid, nthr);
+        lds_fft<false, true, GENERIC>(tile, P.ax_n1, tw_n1, TA, TA, 1, d.C1, d.N1 * TA, tid, nthr);
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int seg = dTA.div(w), tt = w - seg * TA;
+            const int q = dN1.div(seg), q1 = seg - q * d.N1;
+            if (tt < ncol) {
+                const float2 t1 = P.twc[q * d.C2 + c2];
+                const float2 t2 = P.twt[q1 * d.N2 + b0 + tt];
+                const size_t row = (size_t)q * d.C2 + c2;
+                dst[row * d.M + q1 * d.N2 + b0 + tt] = c_mul(tile[w], c_mul(t1, t2));
             }
         }
-        tile[w] = v;
-    }
-    __syncthreads();
-    lds_fft<false, true, GENERIC>(tile, P.ax_c1, d.N1 * TA, d.N1 * TA, 1, 1, 0, tid, nthr);
-    lds_fft<false, true, GENERIC>(tile, P.ax_n1, TA, TA, 1, d.C1, d.N1 * TA, tid, nthr);
-    for (int w = tid; w < nelem; w += nthr) {
-        const int seg = w / TA, t = w - seg * TA;
-        const int q = seg / d.N1, q1 = seg - q * d.N1;
-        if (t < ncol) {
-            float2 v = tile[w];
-            v = c_mul(v, P.twc[q * d.C2 + c2]);
-            v = c_mul(v, P.twt[q1 * d.N2 + b0 + t]);
-            const size_t row = (size_t)q * d.C2 + c2;
-            dst[row * d.M + q1 * d.N2 + b0 + t] = v;
-        }
+        lds_barrier();
+        t = next;
     }
 }
 
 template <bool GENERIC>
-__global__ __launch_bounds__(kThreads) void fk_passA_inv(FkDev P, float2* __restrict__ data) {
+__global__ __launch_bounds__(kMaxThreads) void fk_passA_inv(FkDev P, float2* __restrict__ data, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const FkDims& d = P.d;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int TA = d.TA;
-    const int b0 = blockIdx.x * TA;
-    const int c2 = blockIdx.y;
-    const int ncol = min(TA, d.N2 - b0);
     const int nelem = d.C1 * d.N1 * TA;
-    for (int w = tid; w < nelem; w += nthr) {
-        const int seg = w / TA, t = w - seg * TA;
-        const int q = seg / d.N1, q1 = seg - q * d.N1;
-        float2 v = make_float2(0.f, 0.f);
-        if (t < ncol) {
-            const size_t row = (size_t)q * d.C2 + c2;
-            v = data[row * d.M + q1 * d.N2 + b0 + t];
-            v = c_mulc(v, P.twc[q * d.C2 + c2]);
-            v = c_mulc(v, P.twt[q1 * d.N2 + b0 + t]);
+    const int ntx = (d.N2 + TA - 1) / TA;
+    const FDiv dTA(TA), dN1(d.N1), dntx(ntx);
+    const TwLds tw_c1 = tw_stage(P.ax_c1, tile + nelem, tid, nthr);
+    const TwLds tw_n1 = tw_stage(P.ax_n1, tile + nelem + tw_lds_elems(P.ax_c1), tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int seg = dTA.div(w), tt = w - seg * TA;
+                const int q = dN1.div(seg), q1 = seg - q * d.N1;
+                if (tt < ncol) {
+                    const size_t row = (size_t)q * d.C2 + c2;
+                    v = data[row * d.M + q1 * d.N2 + b0 + tt];
+                }
+            }
+            pf[it] = v;
         }
-        tile[w] = v;
-    }
-    __syncthreads();
-    lds_fft<true, true, GENERIC>(tile, P.ax_n1, TA, TA, 1, d.C1, d.N1 * TA, tid, nthr);
-    lds_fft<true, true, GENERIC>(tile, P.ax_c1, d.N1 * TA, d.N1 * TA, 1, 1, 0, tid, nthr);
-    for (int w = tid; w < nelem; w += nthr) {
-        const int seg = w / TA, t = w - seg * TA;
-        const int c1 = seg / d.N1, n1 = seg - c1 * d.N1;
-        if (t < ncol) {
-            const size_t row = (size_t)c1 * d.C2 + c2;
-            data[row * d.M + n1 * d.N2 + b0 + t] = c_scale(tile[w], P.scale);
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) {
+                const int seg = dTA.div(w), tt = w - seg * TA;
+                const int q = dN1.div(seg), q1 = seg - q * d.N1;
+                float2 v = pf[it];
+                if (tt < ncol) v = c_mulc(v, c_mul(P.twc[q * d.C2 + c2], P.twt[q1 * d.N2 + b0 + tt]));
+                tile[w] = v;
+            }
         }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<true, true, GENERIC>(tile, P.ax_n1, tw_n1, TA, TA, 1, d.C1, d.N1 * TA, tid, nthr);
+        lds_fft<true, true, GENERIC>(tile, P.ax_c1, tw_c1, d.N1 * TA, d.N1 * TA, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int seg = dTA.div(w), tt = w - seg * TA;
+            const int c1 = dN1.div(seg), n1 = seg - c1 * d.N1;
+            if (tt < ncol) {
+                const size_t row = (size_t)c1 * d.C2 + c2;
+                data[row * d.M + n1 * d.N2 + b0 + tt] = c_scale(tile[w], P.scale);
+            }
+        }
+        lds_barrier();
+        t = next;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass C : c2 sub-transform over C2 consecutive rows, TC contiguous columns
+// pass C : c2 sub-transform over C2 consecutive rows, TC contiguous columns; tile id = q*ntx + bx
 // ---------------------------------------------------------------------------------------------
 template <bool INV, bool GENERIC>
-__global__ __launch_bounds__(kThreads) void fk_passC(FkDev P, float2* __restrict__ data) {
+__global__ __launch_bounds__(kMaxThreads) void fk_passC(FkDev P, float2* __restrict__ data, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const FkDims& d = P.d;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int TC = d.TC;
-    const int p0 = blockIdx.x * TC;
-    const int q = blockIdx.y;
-    const int ncol = min(TC, d.M - p0);
     const int nelem = d.C2 * TC;
-    float2* base = data + ((size_t)q * d.C2) * d.M + p0;
-    for (int w = tid; w < nelem; w += nthr) {
-        const int c2 = w / TC, t = w - c2 * TC;
-        tile[w] = (t < ncol) ? base[(size_t)c2 * d.M + t] : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
-    lds_fft<INV, true, GENERIC>(tile, P.ax_c2, TC, TC, 1, 1, 0, tid, nthr);
-    for (int w = tid; w < nelem; w += nthr) {
-        const int c2 = w / TC, t = w - c2 * TC;
-        if (t < ncol) base[(size_t)c2 * d.M + t] = tile[w];
+    const int ntx = (d.M + TC - 1) / TC;
+    const FDiv dTC(TC), dntx(ntx);
+    const TwLds tw = tw_stage(P.ax_c2, tile + nelem, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int q = dntx.div(t), p0 = (t - q * ntx) * TC;
+        const int ncol = min(TC, d.M - p0);
+        const float2* base = data + ((size_t)q * d.C2) * d.M + p0;
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int c2 = dTC.div(w), tt = w - c2 * TC;
+                if (tt < ncol) v = base[(size_t)c2 * d.M + tt];
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) tile[w] = pf[it];
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<INV, true, GENERIC>(tile, P.ax_c2, tw, TC, TC, 1, 1, 0, tid, nthr);
+        const int q = dntx.div(t), p0 = (t - q * ntx) * TC;
+        const int ncol = min(TC, d.M - p0);
+        float2* base = data + ((size_t)q * d.C2) * d.M + p0;
+        for (int w = tid; w < nelem; w += nthr) {
+            const int c2 = dTC.div(w), tt = w - c2 * TC;
+            if (tt < ncol) base[(size_t)c2 * d.M + tt] = tile[w];
+        }
+        lds_barrier();
+        t = next;
     }
 }
 
@@ -167,61 +260,85 @@ __global__ __launch_bounds__(kThreads) void fk_passC(FkDev P, float2* __restrict
 //   Y+ = M_h(k, f) X(k, f),  Y- = M_h(k, f+M) X(k, f+M),  M_h(k, f+M) = M_h(-k, M-f) (Nyquist
 //   column M_h(k, M) when f = 0)
 //   Zy[a] = S + D,  Zy[b] = conj(S - D),  S = (Y+ + Y-)/2,  D = i conj(W) (Y+ - Y-)/2.
+// Work list: P.pairs[t] = (keyA, keyB), key = row position * N1 + q1, keyA <= keyB, each
+// Hermitian pair of sub-rows exactly once (keyA == keyB for the self-paired ones).
 // ---------------------------------------------------------------------------------------------
 template <bool GENERIC>
-__global__ __launch_bounds__(kThreads) void fk_passB(FkDev P, float2* __restrict__ data) {
+__global__ __launch_bounds__(kMaxThreads) void fk_passB(FkDev P, float2* __restrict__ data, int npairs) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const FkDims& d = P.d;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int q1 = blockIdx.x;
-    const int r = blockIdx.y;
-    const int rp = P.row_partner[r];
-    const int q1p = P.q1_partner[q1];
-    const long keyA = (long)r * d.N1 + q1;
-    const long keyB = (long)rp * d.N1 + q1p;
-    if (keyB < keyA) return;   // the partner block owns this pair
-    const bool same = (keyA == keyB);
     const int N2 = d.N2;
-    float2* rowA = data + (size_t)keyA * N2;
-    float2* rowB = data + (size_t)keyB * N2;
-    float2* A = tile;
-    float2* B = same ? tile : tile + N2;
-    for (int i = tid; i < N2; i += nthr) A[i] = rowA[i];
-    if (!same)
-        for (int i = tid; i < N2; i += nthr) B[i] = rowB[i];
-    __syncthreads();
-    const int nrows = same ? 1 : 2;
-    lds_fft<false, false, GENERIC>(tile, P.ax_n2, 1, nrows, N2, 1, 0, tid, nthr);
+    const TwLds tw = tw_stage(P.ax_n2, tile + 2 * N2, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int2 pr = P.pairs[t];
+        const float2* rowA = data + (size_t)pr.x * N2;
+        const float2* rowB = data + (size_t)pr.y * N2;
+        const int nload = (pr.x == pr.y) ? N2 : 2 * N2;
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nload) v = (w < N2) ? rowA[w] : rowB[w - N2];
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < npairs) issue(t);
+    while (t < npairs) {
+        const int2 pr = P.pairs[t];
+        const bool same = (pr.x == pr.y);
+        const int nload = same ? N2 : 2 * N2;
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nload) tile[w] = pf[it];
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < npairs) issue(next);
+        float2* A = tile;
+        float2* B = same ? tile : tile + N2;
+        const int nrows = same ? 1 : 2;
+        lds_fft<false, false, GENERIC>(tile, P.ax_n2, tw, 1, nrows, N2, 1, 0, tid, nthr);
 
-    const bool k1zero = (q1 == 0);
-    const float* mA = P.mask + (size_t)keyA * N2;
-    const float* mB = P.mask + (size_t)keyB * N2;
-    const float2 wr = P.wrow[q1];
-    const float nyq = P.nyq[r];
-    for (int i = tid; i < N2; i += nthr) {
-        const int j = k1zero ? P.mirror0[i] : (N2 - 1 - i);
-        if (same && j < i) continue;
-        const float2 a = A[i];
-        const float2 Bc = c_conj(B[j]);
-        const float ma = mA[i];
-        const float mb = (k1zero && i == 0) ? nyq : mB[j];
-        const float2 w = c_mul(wr, P.wcol[i]);
-        const float2 E = c_scale(c_add(a, Bc), 0.5f);
-        const float2 O = c_mul_mi(c_scale(c_sub(a, Bc), 0.5f));
-        const float2 t = c_mul(w, O);
-        const float2 Yp = c_scale(c_add(E, t), ma);
-        const float2 Ym = c_scale(c_sub(E, t), mb);
-        const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
-        const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
-        A[i] = c_add(S, D);
-        B[j] = c_conj(c_sub(S, D));
+        const int r = pr.x / d.N1, q1 = pr.x - r * d.N1;
+        const bool k1zero = (q1 == 0);
+        const float* mA = P.mask + (size_t)pr.x * N2;
+        const float* mB = P.mask + (size_t)pr.y * N2;
+        const float2 wr = P.wrow[q1];
+        const float nyq = P.nyq[r];
+        for (int i = tid; i < N2; i += nthr) {
+            const int j = k1zero ? P.mirror0[i] : (N2 - 1 - i);
+            if (same && j < i) continue;
+            const float2 a = A[i];
+            const float2 Bc = c_conj(B[j]);
+            const float ma = mA[i];
+            const float mb = (k1zero && i == 0) ? nyq : mB[j];
+            const float2 w = c_mul(wr, P.wcol[i]);
+            const float2 E = c_scale(c_add(a, Bc), 0.5f);
+            const float2 O = c_mul_mi(c_scale(c_sub(a, Bc), 0.5f));
+            const float2 tO = c_mul(w, O);
+            const float2 Yp = c_scale(c_add(E, tO), ma);
+            const float2 Ym = c_scale(c_sub(E, tO), mb);
+            const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
+            const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+            A[i] = c_add(S, D);
+            B[j] = c_conj(c_sub(S, D));
+        }
+        lds_barrier();
+        lds_fft<true, false, GENERIC>(tile, P.ax_n2, tw, 1, nrows, N2, 1, 0, tid, nthr);
+        float2* rowA = data + (size_t)pr.x * N2;
+        float2* rowB = data + (size_t)pr.y * N2;
+        for (int w = tid; w < nload; w += nthr) {
+            if (w < N2) rowA[w] = tile[w];
+            else rowB[w - N2] = tile[w];
+        }
+        lds_barrier();
+        t = next;
     }
-    __syncthreads();
-    lds_fft<true, false, GENERIC>(tile, P.ax_n2, 1, nrows, N2, 1, 0, tid, nthr);
-    for (int i = tid; i < N2; i += nthr) rowA[i] = A[i];
-    if (!same)
-        for (int i = tid; i < N2; i += nthr) rowB[i] = B[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,26 +392,28 @@ static bool factor_radices(int L, std::vector<int>& out) {
     for (int p = 7; p <= 31 && L > 1; ++p)
         while (L % p == 0) { L /= p; other.push_back(p); }
     if (L != 1) return false;   // prime factor > 31: needs Bluestein (not implemented)
-    if (e2 % 3 == 1 && e2 >= 4) { out.push_back(4); out.push_back(4); e2 -= 4; }
-    while (e2 >= 3) { out.push_back(8); e2 -= 3; }
-    if (e2 == 2) { out.push_back(4); e2 = 0; }
+    // fewest stages with radices <= 10: pair 2s with 5s into 10s, then 8/4, then 6 = 2*3
+    std::vector<int> even, odd;
+    int n10 = std::min(e2, e5);
+    // keep 2^3 groups for radix 8 when that saves a stage: e.g. 2^5 5^3 -> 4,10,10,10 (4 stages)
+    e2 -= n10; e5 -= n10;
+    if (e2 % 3 == 1 && e2 >= 4) { even.push_back(4); even.push_back(4); e2 -= 4; }
+    while (e2 >= 3) { even.push_back(8); e2 -= 3; }
+    if (e2 == 2) { even.push_back(4); e2 = 0; }
     if (e2 == 1) {
-        if (e5 > 0) { out.push_back(10); --e5; }
-        else if (e3 > 0) { out.push_back(6); --e3; }
-        else out.push_back(2);
+        if (e3 > 0) { even.push_back(6); --e3; }
+        else even.push_back(2);
     }
-    std::sort(out.begin(), out.end(), [](int a, int b) {   // even radices first, large first
-        const bool pa = (a & (a - 1)) == 0, pb = (b & (b - 1)) == 0;
-        if (pa != pb) return pa;
-        return a > b;
-    });
+    std::sort(even.begin(), even.end(), [](int x, int y) { return x > y; });
+    out = even;                                   // power-of-two-ish radices first (large strides)
+    for (int i = 0; i < n10; ++i) out.push_back(10);
     for (int i = 0; i < e5; ++i) out.push_back(5);
     for (int i = 0; i < e3; ++i) out.push_back(3);
     for (int p : other) out.push_back(p);
     if ((int)out.size() > kMaxStages) return false;
     for (int r : out) {
         bool ok = false;
-        for (int s : kSupportedRadix) ok |= (s == r);
+        for (int sr : kSupportedRadix) ok |= (sr == r);
         if (!ok) return false;
     }
     return true;
@@ -317,12 +436,19 @@ static std::vector<int> pos_to_freq(int L, const std::vector<int>& rad) {
     return f;
 }
 
-static std::vector<float2> twiddle_table(int L) {
-    std::vector<float2> t(L);
-    for (int i = 0; i < L; ++i) {
-        const double a = -2.0 * M_PI * (double)i / (double)L;
+// two-level table (fft_lds.h TwLds): [0,64) -> W_L^a, [64, 64+nhi) -> W_L^(64 b)
+static std::vector<float2> twiddle_table2(int L, int* nhi_out) {
+    const int nhi = (L + kTwLo - 1) / kTwLo;
+    std::vector<float2> t(kTwLo + nhi);
+    for (int i = 0; i < kTwLo; ++i) {
+        const double a = -2.0 * M_PI * (double)(i % L) / (double)L;
         t[i] = make_float2((float)cos(a), (float)sin(a));
     }
+    for (int b = 0; b < nhi; ++b) {
+        const double a = -2.0 * M_PI * (double)((kTwLo * (long long)b) % L) / (double)L;
+        t[kTwLo + b] = make_float2((float)cos(a), (float)sin(a));
+    }
+    *nhi_out = nhi;
     return t;
 }
 
@@ -364,6 +490,10 @@ struct d4w_fk_plan {
     bool has_mask = false;
     bool genericA = false, genericB = false, genericC = false;
     size_t ldsA = 0, ldsB = 0, ldsC = 0;
+    int threads = kMaxThreads;
+    int npairs = 0;
+    int num_cu = 256;
+    int wg_per_cu = 2;
 };
 
 template <typename T>
@@ -385,7 +515,7 @@ static int make_axis(d4w_fk_plan* pl, int L, AxisDesc* ax, std::vector<int>* p2f
     for (int i = 0; i < kMaxStages; ++i) ax->radix[i] = (i < (int)rad.size() && L > 1) ? rad[i] : 1;
     if (L == 1) rad.clear();
     *p2f = pos_to_freq(L, rad);
-    return upload(pl, twiddle_table(L), &ax->tw);
+    return upload(pl, twiddle_table2(L, &ax->nhi), &ax->tw2);
 }
 
 template <typename K, typename... Args>
@@ -443,7 +573,9 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     // --- split the channel axis
     int C1 = o[0], C2 = o[1];
     if (C1 <= 0 || C2 <= 0 || C1 * C2 != nx) {
-        C2 = largest_divisor_le(nx, 512);
+        // measured on MI355X (20000 x 120000): a long c2 axis with 64-byte column segments in
+        // pass C leaves room for 128-byte segments in the 2-D pass A and wins overall
+        C2 = largest_divisor_le(nx, kMaxTile / 8);
         C1 = nx / C2;
     }
     int TC = o[5] > 0 ? o[5] : 16;
@@ -493,6 +625,17 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     }
     for (int q1 = 0; q1 < N1; ++q1) q1part[q1] = p_n1[(N1 - f_n1[q1]) % N1];
     for (int i = 0; i < N2; ++i) mirror0[i] = p_n2[(N2 - f_n2[i]) % N2];
+    {   // pass-B work list: every Hermitian pair of sub-rows once
+        std::vector<int2> pairs;
+        pairs.reserve((size_t)nx * N1 / 2 + 4);
+        for (int r = 0; r < nx; ++r)
+            for (int q1 = 0; q1 < N1; ++q1) {
+                const long keyA = (long)r * N1 + q1, keyB = (long)rowpart[r] * N1 + q1part[q1];
+                if (keyB >= keyA) pairs.push_back(make_int2((int)keyA, (int)keyB));
+            }
+        pl->npairs = (int)pairs.size();
+        D4W_TRY(upload(pl, pairs, &pl->dev.pairs));
+    }
     D4W_TRY(upload(pl, rowpart, &pl->dev.row_partner));
     D4W_TRY(upload(pl, q1part, &pl->dev.q1_partner));
     D4W_TRY(upload(pl, mirror0, &pl->dev.mirror0));
@@ -544,9 +687,38 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     pl->genericA = needs_generic(pl->dev.ax_c1) || needs_generic(pl->dev.ax_n1);
     pl->genericB = needs_generic(pl->dev.ax_n2);
     pl->genericC = needs_generic(pl->dev.ax_c2);
-    pl->ldsA = (size_t)C1 * N1 * TA * sizeof(float2);
-    pl->ldsC = (size_t)C2 * TC * sizeof(float2);
-    pl->ldsB = (size_t)2 * N2 * sizeof(float2);
+    pl->ldsA = ((size_t)C1 * N1 * TA + 2 * kTwLo + pl->dev.ax_c1.nhi + pl->dev.ax_n1.nhi) * sizeof(float2);
+    pl->ldsC = ((size_t)C2 * TC + kTwLo + pl->dev.ax_c2.nhi) * sizeof(float2);
+    pl->ldsB = ((size_t)2 * N2 + kTwLo + pl->dev.ax_n2.nhi) * sizeof(float2);
+    auto env_int = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return (v && atoi(v) > 0) ? atoi(v) : dflt;
+    };
+    pl->wg_per_cu = env_int("D4W_FK_WG_PER_CU", 2048 / kMaxThreads);     // tuning knob
+#ifndef D4W_EMU
+    {
+        int devid = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+            pl->num_cu = prop.multiProcessorCount;
+        const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
+        if (lds_max > 64 * 1024) {
+            // tiles are capped at 64 KiB; the twiddle tables push the request slightly above the
+            // default dynamic-LDS limit
+            const void* fns[] = {
+                (const void*)fk_passA_fwd<true, true>, (const void*)fk_passA_fwd<true, false>,
+                (const void*)fk_passA_fwd<false, true>, (const void*)fk_passA_fwd<false, false>,
+                (const void*)fk_passA_inv<true>, (const void*)fk_passA_inv<false>,
+                (const void*)fk_passC<false, true>, (const void*)fk_passC<false, false>,
+                (const void*)fk_passC<true, true>, (const void*)fk_passC<true, false>,
+                (const void*)fk_passB<true>, (const void*)fk_passB<false>};
+            for (const void* f : fns)
+                (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        }
+    }
+#else
+    pl->num_cu = 3;
+#endif
     *out = pl;
     return D4W_OK;
 }
@@ -578,10 +750,12 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     const FkDims& d = P.d;
     const float2* src = reinterpret_cast<const float2*>(x);
     float2* dst = reinterpret_cast<float2*>(y);
-    const dim3 blk(kThreads);
-    const dim3 gridA(ceil_div(d.N2, d.TA), d.C2);
-    const dim3 gridC(ceil_div(d.M, d.TC), d.C1);
-    const dim3 gridB(d.N1, d.nx);
+    const dim3 blk(pl->threads);
+    const int ntA = ceil_div(d.N2, d.TA) * d.C2;
+    const int ntC = ceil_div(d.M, d.TC) * d.C1;
+    const int ntB = pl->npairs;
+    const int persist = pl->num_cu * pl->wg_per_cu;
+    const dim3 gridA(std::min(ntA, persist)), gridC(std::min(ntC, persist)), gridB(std::min(ntB, persist));
     hipStream_t st = (hipStream_t)stream;
     // FAST kernels carry only the unrolled radices; GENERIC ones add the loop-based primes
     const bool gA = pl->genericA, gB = pl->genericB, gC = pl->genericC;
@@ -589,18 +763,18 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
 #define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
     D4W_MARK(0);
     if (taper)
-        rc = launch_k(gA ? fk_passA_fwd<true, true> : fk_passA_fwd<true, false>, gridA, blk, pl->ldsA, stream, P, src, dst);
+        rc = launch_k(gA ? fk_passA_fwd<true, true> : fk_passA_fwd<true, false>, gridA, blk, pl->ldsA, stream, P, src, dst, ntA);
     else
-        rc = launch_k(gA ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, gridA, blk, pl->ldsA, stream, P, src, dst);
+        rc = launch_k(gA ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, gridA, blk, pl->ldsA, stream, P, src, dst, ntA);
     if (rc) return rc;
     D4W_MARK(1);
-    if ((rc = launch_k(gC ? fk_passC<false, true> : fk_passC<false, false>, gridC, blk, pl->ldsC, stream, P, dst))) return rc;
+    if ((rc = launch_k(gC ? fk_passC<false, true> : fk_passC<false, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC))) return rc;
     D4W_MARK(2);
-    if ((rc = launch_k(gB ? fk_passB<true> : fk_passB<false>, gridB, blk, pl->ldsB, stream, P, dst))) return rc;
+    if ((rc = launch_k(gB ? fk_passB<true> : fk_passB<false>, gridB, blk, pl->ldsB, stream, P, dst, ntB))) return rc;
     D4W_MARK(3);
-    if ((rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst))) return rc;
+    if ((rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC))) return rc;
     D4W_MARK(4);
-    if ((rc = launch_k(gA ? fk_passA_inv<true> : fk_passA_inv<false>, gridA, blk, pl->ldsA, stream, P, dst))) return rc;
+    if ((rc = launch_k(gA ? fk_passA_inv<true> : fk_passA_inv<false>, gridA, blk, pl->ldsA, stream, P, dst, ntA))) return rc;
     D4W_MARK(5);
 #undef D4W_MARK
     return D4W_OK;
