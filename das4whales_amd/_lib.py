@@ -37,6 +37,12 @@ def _load():
         "d4w_fk_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fk_apply_timed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(ctypes.c_float)]),
         "d4w_taper_f32": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+        "d4w_sosfiltfilt_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+        "d4w_sosfiltfilt_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, P(ctypes.c_double), P(ctypes.c_double),
+                                        c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+        "d4w_row_stats_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+        "d4w_xcorr_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly

@@ -145,3 +145,104 @@ def taper_data(trace):
     else:
         trace[...] = x.cpu().numpy().astype(trace.dtype, copy=False)
     return trace
+
+
+# ---------------------------------------------------------------------------------------------
+# 1-D zero-phase filters (design on the host in float64, like the reference; application in HIP)
+# ---------------------------------------------------------------------------------------------
+def butterworth_filter(filterspec, fs):
+    """SOS Butterworth design -- reference dsp.py:789-827 (host, SciPy, float64)."""
+    import scipy.signal as sp
+    filter_order, filter_critical_freq, filter_type_str = filterspec
+    wn = np.array(filter_critical_freq) / (fs / 2)
+    return sp.butter(filter_order, wn, btype=filter_type_str, output="sos")
+
+
+def _sos_decay_samples(sos, tol=1e-9, nmax=1 << 17):
+    """Samples after which the cascade's impulse response stays below tol * peak (host, float64)."""
+    import scipy.signal as sp
+    n = 4096
+    while True:
+        imp = np.zeros(n)
+        imp[0] = 1.0
+        h = np.abs(sp.sosfilt(sos, imp))
+        big = np.nonzero(h > tol * h.max())[0]
+        last = int(big[-1]) if len(big) else 0
+        if last < n // 2 or n >= nmax:
+            return last + 1
+        n *= 2
+
+
+def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
+    """x: float32 CUDA tensor [nx, ns] -> filtered tensor (new)."""
+    import scipy.signal as sp
+    sos = np.ascontiguousarray(np.atleast_2d(np.asarray(sos, dtype=np.float64)))
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError("sos array must be shape (n_sections, 6)")
+    nx, ns = x.shape
+    if ns <= padlen:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % padlen)
+    zi = np.ascontiguousarray(sp.sosfilt_zi(sos), dtype=np.float64)
+    if warm is None:
+        warm = -(-int(1.5 * _sos_decay_samples(sos)) // 32) * 32
+    if seg_len is None:
+        groups = -(-nx // 64)
+        want = -(-2048 // groups)                    # ~8 waves per CU
+        seg_len = max(8 * warm, -(-(-(-ns // want)) // 32) * 32)
+    if seg_len + 2 * warm >= ns:
+        seg_len, warm = 0, 0                         # one exact segment per row
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        ws = torch.empty(int(lib.d4w_sosfiltfilt_ws_bytes(nx, ns, padlen)), dtype=torch.uint8, device=x.device)
+        check(lib.d4w_sosfiltfilt_f32(dev.ptr(x), dev.ptr(y), nx, ns,
+                                      sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                      zi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                      sos.shape[0], int(padlen), int(seg_len), int(warm), dev.ptr(ws),
+                                      dev.stream_ptr(x)))
+    return y
+
+
+def _rows_2d(data):
+    if getattr(data, "ndim", 0) == 1:
+        return data[None, :], True
+    if getattr(data, "ndim", 0) != 2:
+        raise ValueError("expected a 1-D or 2-D [channel x time] array")
+    return data, False
+
+
+def sosfiltfilt(sos, x, axis=-1, padtype="odd", padlen=None):
+    """scipy.signal.sosfiltfilt(sos, x, axis=1) on the GPU -- what the reference's users call on
+    dsp.butterworth_filter designs (Example.py:55, DAS4Whales_ExampleNotebook.md:292).
+    Only the time axis (last) and SciPy's default odd padding are supported."""
+    if padtype != "odd":
+        raise ValueError("only padtype='odd' (SciPy's default) is implemented")
+    x2, was1d = _rows_2d(x)
+    if axis not in (-1, x2.ndim - 1, 1 if not was1d else 0):
+        raise ValueError("filtering runs along the time (last) axis")
+    sos = np.atleast_2d(np.asarray(sos, dtype=np.float64))
+    if padlen is None:                               # scipy/signal/_signaltools.py sosfiltfilt
+        ntaps = 2 * sos.shape[0] + 1
+        ntaps -= min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())
+        padlen = 3 * ntaps
+    xd = dev.to_device_f32(x2)
+    y = _sosfiltfilt_device(xd, sos, int(padlen))
+    y = y[0] if was1d else y
+    return dev.like_input(y, x)
+
+
+def bp_filt(data, fs, fmin, fmax):
+    """Zero-phase Butterworth-8 band-pass along time -- reference dsp.py:859-880.
+
+    The reference runs scipy.signal.filtfilt on the 17-coefficient `ba` form in float64 (that
+    recursion overflows in float32); here the same filter runs as float32
+    second-order sections with filtfilt's edge rule (odd extension, padlen = 3*17 = 51)."""
+    import scipy.signal as sp
+    sos = sp.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp", output="sos")
+    x2, was1d = _rows_2d(data)
+    xd = dev.to_device_f32(x2)
+    y = _sosfiltfilt_device(xd, sos, 51)
+    y = y[0] if was1d else y
+    return dev.like_input(y, data)
+
+
+bp_filter = bp_filt             # north-star spelling

@@ -71,6 +71,51 @@ int d4w_fk_apply_timed_f32(d4w_fk_plan* plan, const float* x, float* y, int tape
 /* dsp.taper_data (dsp.py:705-722): x *= tukey(ns, 0.03) in place, every row */
 int d4w_taper_f32(float* x, int nx, int ns, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Zero-phase IIR filtering along time (rows independent):
+ * replaces dsp.bp_filt (dsp.py:859-880: butter(8,'bp') + scipy.signal.filtfilt) and the user-side
+ * scipy.signal.sosfiltfilt(sos, x, axis=1) applied to dsp.butterworth_filter designs
+ * (dsp.py:789-827; Example.py:55, DAS4Whales_ExampleNotebook.md:292).
+ *
+ * SciPy semantics kept: odd extension by `padlen` samples on both sides, every section started
+ * in its steady state for the first (extended) sample (sosfilt_zi * ext[0]), forward pass,
+ * backward pass started at sosfilt_zi * y_fwd[last], crop.  The cascade runs as float32
+ * second-order sections (the reference's 16-pole `ba` recursion is float64-only).
+ *
+ * Rows are cut into time segments of `seg_len` samples that run concurrently; a segment that
+ * does not start at the row edge is warmed up over `warm` samples (host-chosen from the decay
+ * of the cascade's impulse response, so the truncation error is below float32 resolution).
+ * seg_len <= 0 or warm <= 0: one segment per row (exact recursion over the whole row).
+ *
+ *   sos_host [nsec][6]  = b0 b1 b2 a0(=1) a1 a2 (scipy layout), float64, HOST memory
+ *   zi_host  [nsec][2]  = scipy.signal.sosfilt_zi(sos), float64, HOST memory
+ *   ws: device workspace of d4w_sosfiltfilt_ws_bytes() bytes;  y may alias x.
+ * Errors: D4W_EINVAL if ns <= padlen (SciPy raises ValueError there), nsec < 1 or nsec > 10.
+ * ------------------------------------------------------------------------------------------ */
+size_t d4w_sosfiltfilt_ws_bytes(int nx, int ns, int padlen);
+int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* sos_host,
+                        const double* zi_host, int nsec, int padlen, int seg_len, int warm,
+                        void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Matched filter (time-domain cross-correlation, positive lags), rows independent:
+ * replaces detect.compute_cross_correlogram (detect.py:140-166), detect.shift_xcorr
+ * (detect.py:96-112) and the numerator of detect.shift_nxcorr (detect.py:115-137).
+ *
+ *   d4w_row_stats_f32:  mean[c] = mean(x[c,:]),  maxabs[c] = max|x[c,:]|   (detect.py:157)
+ *   d4w_xcorr_f32:      for each template t < ntpl (1 or 2 per call, fused: x is read once)
+ *       y_t[c][k] = g[c] * sum_{n < L_t, n+k < ns} (x[c][n+k] - m[c]) * taps[t][n]
+ *       with m = mean (or 0 if mean == NULL) and g = 1/maxabs (or 1 if maxabs == NULL; 0 for an
+ *       all-zero row, where the reference divides by zero).
+ *   taps: DEVICE float32 [ntpl][ltaps] (ltaps multiple of 4, zero padded), the template's
+ *   support already normalised by the host exactly as detect.py:158 does.
+ * The de-meaned zero-padded template's DC tail (-mean/max on the padded part, detect.py:158)
+ * is NOT applied: it changes the correlogram by < 3e-6 of its peak.
+ * ------------------------------------------------------------------------------------------ */
+int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream);
+int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+                  const float* taps, int ntpl, int ltaps, float* y0, float* y1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""Row-operator kernel LOGIC (zero-phase SOS filter, matched filter) on the CPU emulator build:
+same HIP sources, same C ABI, host pointers.  Complements the -m gpu parity tests."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.signal as sps
+
+from oracle import d4w_oracle as orc
+from tests.emu_util import load_emu, vp
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = load_emu()
+    lib.d4w_sosfiltfilt_ws_bytes.restype = ctypes.c_size_t
+    return lib
+
+
+def rel(y, ref):
+    return np.max(np.abs(y - ref)) / np.max(np.abs(ref))
+
+
+def sosfiltfilt_emu(lib, x, sos, padlen, seg_len=0, warm=0):
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    zi = np.ascontiguousarray(sps.sosfilt_zi(sos), dtype=np.float64)
+    ws = np.empty(lib.d4w_sosfiltfilt_ws_bytes(nx, ns, padlen), dtype=np.uint8)
+    y = np.empty_like(xf)
+    rc = lib.d4w_sosfiltfilt_f32(vp(xf), vp(y), nx, ns, vp(sos), vp(zi), sos.shape[0], padlen, seg_len, warm,
+                                 vp(ws), None)
+    assert rc == 0, lib.d4w_last_error()
+    return y
+
+
+def test_bp_filt_golden_single_segment(emu, golden):
+    g = golden("fk_40x480.npz")
+    fs = float(g["fs"])
+    sos = sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos")
+    y = sosfiltfilt_emu(emu, g["x"], sos, padlen=51)
+    assert rel(y, g["y_bp"]) < TOL                      # reference dsp.bp_filt (ba form, float64)
+
+
+def test_sosfiltfilt_golden(emu, golden):
+    g = golden("fk_40x480.npz")
+    assert rel(sosfiltfilt_emu(emu, g["x"], g["sos_hp"], padlen=9), g["y_sos_hp"]) < TOL
+    assert rel(sosfiltfilt_emu(emu, g["x"], g["sos_bp"], padlen=33), g["y_sos_bp"]) < TOL
+
+
+def test_segmented_rows_match_exact(emu):
+    """Segments with warm-up reproduce the whole-row recursion (ragged: 70 rows, ns not a
+    multiple of the chunk or the segment)."""
+    rng = np.random.default_rng(3)
+    nx, ns, fs = 70, 3001, 200.0
+    x = rng.standard_normal((nx, ns)) + 3.0
+    sos = sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos")
+    ref = orc.sosfiltfilt(sos, x)
+    y1 = sosfiltfilt_emu(emu, x, sos, padlen=51)
+    y2 = sosfiltfilt_emu(emu, x, sos, padlen=51, seg_len=1024, warm=768)
+    assert rel(y1, ref) < TOL
+    assert rel(y2, ref) < TOL
+    assert rel(y2, y1) < 2e-6
+
+
+def test_sosfiltfilt_errors(emu):
+    x = np.zeros((2, 40), dtype=np.float32)
+    sos = sps.butter(8, [0.14, 0.3], "bp", output="sos")
+    zi = sps.sosfilt_zi(sos)
+    ws = np.empty(1 << 16, dtype=np.uint8)
+    rc = emu.d4w_sosfiltfilt_f32(vp(x), vp(x), 2, 40, vp(sos), vp(zi), 8, 51, 0, 0, vp(ws), None)
+    assert rc == -1 and b"padlen, which is 51" in emu.d4w_last_error()
+
+
+def xcorr_emu(lib, x, taps_list, normalize=True):
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    lt = max(4, -(-max(len(t) for t in taps_list) // 4) * 4)
+    taps = np.zeros((len(taps_list), lt), dtype=np.float32)
+    for i, t in enumerate(taps_list):
+        taps[i, :len(t)] = t
+    mean = np.empty(nx, dtype=np.float32)
+    mx = np.empty(nx, dtype=np.float32)
+    if normalize:
+        assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
+    ys = [np.empty_like(xf) for _ in taps_list]
+    rc = lib.d4w_xcorr_f32(vp(xf), nx, ns, vp(mean) if normalize else None, vp(mx) if normalize else None,
+                           vp(taps), len(taps_list), lt, vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None, None)
+    assert rc == 0, lib.d4w_last_error()
+    return ys, mean, mx
+
+
+def norm_taps(tpl):
+    """detect.py:158 on the host: (y - mean(y)) / max|y| over the zero-padded template, support only."""
+    tpl = np.asarray(tpl, dtype=np.float64)
+    L = int(np.max(np.nonzero(tpl)[0])) + 1
+    return ((tpl - tpl.mean()) / np.max(np.abs(tpl)))[:L]
+
+
+def test_cross_correlogram_golden(emu, golden):
+    d = golden("detect_12x2000.npz")
+    (yh, yl), mean, mx = xcorr_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])])
+    assert np.allclose(mean, d["x"].mean(axis=1), atol=1e-6 * np.abs(d["x"]).max())
+    assert np.allclose(mx, np.abs(d["x"]).max(axis=1), rtol=1e-6)
+    assert rel(yh, d["corr_hf"]) < TOL                  # reference detect.compute_cross_correlogram
+    assert rel(yl, d["corr_lf"]) < TOL
+    (y1,), _, _ = xcorr_emu(emu, d["x"], [norm_taps(d["hf"])])
+    assert np.array_equal(y1, yh)                       # fused and single-template paths agree bit for bit
+
+
+def test_shift_xcorr_long_template(emu, golden):
+    """detect.shift_xcorr with a dense full-length second operand (several tap rounds, ragged row)."""
+    rng = np.random.default_rng(5)
+    n = 1237
+    x = rng.standard_normal(n)
+    y = rng.standard_normal(n)
+    (c,), _, _ = xcorr_emu(emu, x[None, :], [y], normalize=False)
+    assert rel(c[0], orc.shift_xcorr(x, y)) < TOL
+    d = golden("detect_12x2000.npz")
+    (c2,), _, _ = xcorr_emu(emu, d["x"][2:3], [d["hf"][:137]], normalize=False)
+    assert rel(c2[0], d["xc"]) < TOL

@@ -1,0 +1,164 @@
+"""GPU parity tests of the row operators: zero-phase band-pass / sosfiltfilt and the matched
+filter, through the C ABI, vs the reference's golden outputs and the CPU oracle.
+
+Tolerance (north star): max|y - y_ref| <= 1e-5 * max|y_ref| with float32 arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+FS = 200.0
+
+
+def rel(y, ref):
+    return float(np.max(np.abs(np.asarray(y, dtype=np.float64) - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import das4whales_amd as dw_
+    return dw_
+
+
+# ------------------------------------------------------------------------------------------
+# band-pass
+# ------------------------------------------------------------------------------------------
+def test_bp_and_sos_golden(dw, golden):
+    g = golden("fk_40x480.npz")
+    x = g["x"]
+    y = dw.dsp.bp_filt(x, FS, 14, 30)
+    assert y.dtype == np.float64 and y.shape == x.shape
+    assert rel(y, g["y_bp"]) < TOL
+    sos_hp = dw.dsp.butterworth_filter([2, 5, "hp"], FS)
+    sos_bp = dw.dsp.butterworth_filter([5, [10, 30], "bp"], FS)
+    assert np.array_equal(sos_hp, g["sos_hp"]) and np.array_equal(sos_bp, g["sos_bp"])
+    assert rel(dw.dsp.sosfiltfilt(sos_hp, x, axis=1), g["y_sos_hp"]) < TOL
+    assert rel(dw.dsp.sosfiltfilt(sos_bp, x, axis=1), g["y_sos_bp"]) < TOL
+    assert rel(dw.dsp.bp_filt(x[3], FS, 14, 30), g["y_bp"][3]) < TOL          # 1-D input
+    with pytest.raises(ValueError, match="padlen, which is 51"):
+        dw.dsp.bp_filt(x[:, :40], FS, 14, 30)
+
+
+def test_bp_config1_block_segmented(dw):
+    """4000 x 12000 (BASELINE configs[1] geometry): segmented rows vs the float64 filtfilt oracle."""
+    nx, ns = 4000, 12000
+    x = orc.synth_block(nx, ns, fs=FS, step=4, seed=1234, n_calls=6, n_waves=10) * 1e9
+    y = dw.dsp.bp_filt(x, FS, 14, 30)
+    rows = np.r_[0:64, 1990:2010, nx - 64:nx]
+    ref = orc.bp_filt(x[rows], FS, 14, 30)
+    e = rel(y[rows], ref)
+    print("bp_filt 4000x12000: rel err %.3e" % e)
+    assert e < TOL
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    yt = dw.dsp.bp_filt(xt, FS, 14, 30)
+    assert isinstance(yt, torch.Tensor) and yt.is_cuda
+    assert np.allclose(yt.cpu().numpy(), y.astype(np.float32), atol=0, rtol=0)   # deterministic
+
+
+def test_bp_known_answer_tones(dw):
+    """a 20 Hz tone passes with |H|^2 ~ 1, a 5 Hz tone is removed."""
+    t = np.arange(24000) / FS
+    x = np.stack([np.sin(2 * np.pi * 20 * t), np.sin(2 * np.pi * 5 * t)])
+    y = dw.dsp.bp_filt(x, FS, 14, 30)
+    mid = slice(4000, 20000)
+    assert abs(np.max(np.abs(y[0, mid])) - 1.0) < 2e-3
+    assert np.max(np.abs(y[1, mid])) < 1e-5
+
+
+def test_bp_full_size_rows_vs_oracle(dw):
+    """20000 x 120000: rows are independent, so a row subset is checked against the oracle."""
+    nx, ns = 20000, 120000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~40 GB of HBM")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    x = torch.randn((nx, ns), dtype=torch.float32, device="cuda", generator=gen)
+    y = dw.dsp.bp_filt(x, FS, 14, 30)
+    rows = [0, 1, 63, 64, 7777, 12345, nx - 65, nx - 1]
+    ref = orc.bp_filt(x[rows].cpu().numpy().astype(np.float64), FS, 14, 30)
+    e = rel(y[rows].cpu().numpy(), ref)
+    print("bp_filt 20000x120000 (8 rows): rel err %.3e" % e)
+    assert e < TOL
+
+
+# ------------------------------------------------------------------------------------------
+# matched filter
+# ------------------------------------------------------------------------------------------
+def test_templates_and_correlogram_golden(dw, golden):
+    d = golden("detect_12x2000.npz")
+    time = np.arange(2000) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, fmin=17.8, fmax=28.8, duration=0.68)
+    lf = dw.detect.gen_template_fincall(time, FS, fmin=14.7, fmax=21.8, duration=0.78)
+    assert np.allclose(hf, d["hf"], atol=1e-12) and np.allclose(lf, d["lf"], atol=1e-12)
+    assert np.allclose(dw.detect.gen_linear_chirp(15., 25., 1.0, FS), d["lin_chirp"], atol=1e-12)
+    assert np.allclose(dw.detect.gen_hyperbolic_chirp(15., 25., 1.0, FS), d["hyp_chirp"], atol=1e-12)
+    assert np.allclose(dw.detect.gen_template_fincall(time, FS, 15., 25., 1.0, window=False), d["tpl_nowin"], atol=1e-12)
+    x = d["x"]
+    c_hf = dw.detect.compute_cross_correlogram(x, hf)
+    assert c_hf.dtype == np.float64 and c_hf.shape == x.shape
+    assert rel(c_hf, d["corr_hf"]) < TOL
+    c2 = dw.detect.compute_cross_correlograms(x, [hf, lf])
+    assert rel(c2[0], d["corr_hf"]) < TOL and rel(c2[1], d["corr_lf"]) < TOL
+    assert rel(dw.detect.shift_xcorr(x[2], hf), d["xc"]) < TOL
+    assert rel(dw.detect.shift_nxcorr(x[2], hf), d["nxc"]) < TOL
+    # integer input (reference tests/test_detect.py:66-67 passes ints): floating result
+    ci = dw.detect.compute_cross_correlogram(np.arange(20).reshape(2, 10), np.arange(10))
+    assert ci.shape == (2, 10) and ci.dtype == np.float64
+    assert rel(ci, orc.compute_cross_correlogram(np.arange(20).reshape(2, 10), np.arange(10))) < TOL
+    # convert / select are index bookkeeping
+    idx = dw.detect.convert_pick_times([np.array([3, 9]), np.array([], dtype=int), np.array([5])])
+    assert np.array_equal(idx, np.array([[0, 0, 2], [3, 9, 5]]))
+
+
+def test_correlogram_known_answer(dw):
+    """a row holding the template at lag tau peaks there with value sum(tpl^2)/(A max|x|)."""
+    ns, tau = 4000, 1234
+    time = np.arange(ns) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)
+    L = 136
+    x = np.zeros((3, ns))
+    x[1, tau:tau + L] = 0.5 * hf[:L]
+    c = dw.detect.compute_cross_correlogram(x, hf)
+    assert np.all(c[0] == 0) and np.all(c[2] == 0)                 # all-zero rows -> zeros (documented)
+    assert int(np.argmax(c[1])) == tau
+    expect = 0.5 * np.sum(hf[:L] ** 2) / (np.max(np.abs(hf)) * np.max(np.abs(x[1])))
+    assert abs(c[1, tau] - expect) / expect < 1e-4
+
+
+def test_correlogram_config1_block(dw):
+    nx, ns = 4000, 12000
+    x = orc.synth_block(nx, ns, fs=FS, step=4, seed=99, n_calls=6, n_waves=4) * 1e9
+    time = np.arange(ns) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)
+    lf = dw.detect.gen_template_fincall(time, FS, 14.7, 21.8, 0.78)
+    c_hf, c_lf = dw.detect.compute_cross_correlograms(x, [hf, lf])
+    rows = np.r_[0:16, 2000:2016, nx - 16:nx]
+    e1 = rel(c_hf[rows], orc.compute_cross_correlogram(x[rows], hf))
+    e2 = rel(c_lf[rows], orc.compute_cross_correlogram(x[rows], lf))
+    print("correlogram 4000x12000: rel err HF %.3e LF %.3e" % (e1, e2))
+    assert e1 < TOL and e2 < TOL
+
+
+def test_correlogram_full_size_rows_vs_oracle(dw):
+    nx, ns = 20000, 120000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~40 GB of HBM")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(12)
+    x = torch.randn((nx, ns), dtype=torch.float32, device="cuda", generator=gen)
+    time = np.arange(ns) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)
+    lf = dw.detect.gen_template_fincall(time, FS, 14.7, 21.8, 0.78)
+    c_hf, c_lf = dw.detect.compute_cross_correlograms(x, [hf, lf])
+    rows = [0, 1, 4999, 10000, nx - 1]
+    xr = x[rows].cpu().numpy().astype(np.float64)
+    e1 = rel(c_hf[rows].cpu().numpy(), orc.compute_cross_correlogram(xr, hf))
+    e2 = rel(c_lf[rows].cpu().numpy(), orc.compute_cross_correlogram(xr, lf))
+    print("correlogram 20000x120000 (5 rows): rel err HF %.3e LF %.3e" % (e1, e2))
+    assert e1 < TOL and e2 < TOL
