@@ -4,9 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 20000] [--ns 120000]
 
 One "step" = one pass of the hot path over one [nx x ns] float32 strain block that is already
-resident in HBM: the f-k filter (dsp.fk_filter_filt) followed -- when --stages includes them -- by
-the zero-phase band-pass and the HF+LF matched filter.  Default workload = BASELINE.json
-configs[2] (20 000 channels x 120 000 samples, the shape the metric's target is quoted on).
+resident in HBM: the f-k filter (dsp.fk_filter_filt) followed by the HF+LF fin-whale matched filter
+(detect.compute_cross_correlogram x2, fused) -- BASELINE.json's metric "channel-samples/sec through
+f-k filter + matched-filter".  --stages selects fk / mf / bp (zero-phase band-pass, run first).
+Default workload = BASELINE.json configs[2] (20 000 channels x 120 000 samples, the shape the
+metric's target is quoted on).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank filters its own block
 (independent channel blocks / files -- SURVEY.md 8e "replicas", BASELINE config 5), no collective
@@ -55,19 +57,42 @@ def classic_mask_shifted(nx, ns, step_dx, fs, device, cs_min=1400., cp_min=1450.
     return out
 
 
-def cpu_baseline(sample_nx, sample_ns):
-    """NumPy float64 restatement of the reference f-k filter (oracle) on a bounded sample."""
+def cpu_baseline(sample_nx, sample_ns, stages):
+    """NumPy float64 restatement of the reference path (oracle) on a bounded sample: each stage is
+    timed on its own sample and the per-sample times are added (same composition as a GPU step)."""
     from oracle import d4w_oracle as orc
     rng = np.random.default_rng(1234)
     x = rng.standard_normal((sample_nx, sample_ns))
-    mask = orc.fk_filter_design((sample_nx, sample_ns), [0, sample_nx, 1], 2.0419046878814697, 200.0)
-    mask = np.ascontiguousarray(mask)
-    t0 = time.perf_counter()
-    orc.fk_filter_filt(x, mask)
-    dt = time.perf_counter() - t0
-    return {"value": sample_nx * sample_ns / dt, "unit": "channel-samples/s", "cores": 1, "kind": "port",
-            "sample": "oracle fk_filter_filt (numpy.fft float64, single thread) on %d x %d, %.1f s"
-                      % (sample_nx, sample_ns, dt)}
+    per_sample, notes = 0.0, []
+    if "bp" in stages:
+        rows = min(sample_nx, 1000)
+        t0 = time.perf_counter()
+        orc.bp_filt(x[:rows], 200.0, 14, 30)
+        dt = time.perf_counter() - t0
+        per_sample += dt / (rows * sample_ns)
+        notes.append("bp_filt %d x %d %.1f s" % (rows, sample_ns, dt))
+    if "fk" in stages:
+        mask = np.ascontiguousarray(orc.fk_filter_design((sample_nx, sample_ns), [0, sample_nx, 1],
+                                                         2.0419046878814697, 200.0))
+        t0 = time.perf_counter()
+        orc.fk_filter_filt(x, mask)
+        dt = time.perf_counter() - t0
+        per_sample += dt / (sample_nx * sample_ns)
+        notes.append("fk_filter_filt %d x %d %.1f s" % (sample_nx, sample_ns, dt))
+    if "mf" in stages:
+        rows = min(sample_nx, 1500)
+        tt = np.arange(sample_ns) / 200.0
+        hf = orc.gen_template_fincall(tt, 200.0, 17.8, 28.8, 0.68)
+        lf = orc.gen_template_fincall(tt, 200.0, 14.7, 21.8, 0.78)
+        t0 = time.perf_counter()
+        for r0 in range(0, rows, 250):
+            orc.compute_cross_correlogram(x[r0:r0 + 250], hf)
+            orc.compute_cross_correlogram(x[r0:r0 + 250], lf)
+        dt = time.perf_counter() - t0
+        per_sample += dt / (rows * sample_ns)
+        notes.append("compute_cross_correlogram x2 %d x %d %.1f s" % (rows, sample_ns, dt))
+    return {"value": 1.0 / per_sample, "unit": "channel-samples/s", "cores": 1, "kind": "port",
+            "sample": "oracle (numpy.fft / scipy float64, single thread): " + "; ".join(notes)}
 
 
 def main():
@@ -80,7 +105,10 @@ def main():
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="8000x24000")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
     args = ap.parse_args()
+    stages = [t for t in args.stages.split(",") if t]
+    assert set(stages) <= {"bp", "fk", "mf"} and stages, "--stages: comma list of bp, fk, mf"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,8 +137,23 @@ def main():
     del mask
     torch.cuda.empty_cache()
 
+    from das4whales_amd import detect as ddet, dsp as ddsp
+    time_ax = np.arange(ns) / fs
+    tpl = [ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 17.8, 28.8, 0.68)),
+           ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 14.7, 21.8, 0.78))]
+    import scipy.signal as sps
+    sos_bp = sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos")
+
     def step():
-        plan.apply(x, out=y)
+        cur = x
+        if "bp" in stages:
+            cur = ddsp._sosfiltfilt_device(cur, sos_bp, 51)
+        if "fk" in stages:
+            plan.apply(cur, out=y)
+            cur = y
+        if "mf" in stages:
+            return ddet._xcorr_device(cur, tpl, normalize=True)
+        return cur
 
     for _ in range(args.warmup):
         step()
@@ -134,33 +177,74 @@ def main():
     samples = float(nx) * ns
     value = samples * world / (dt / args.steps)
 
-    # per-kernel HIP-event timing (same inputs, same stream), averaged over the same K
+    # per-stage / per-kernel timing with HIP events on the launch stream (torch's current stream
+    # is the stream every d4w_* call is issued on), averaged over the same K steps
+    def ev_time(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    stage_ms = {}
     acc = np.zeros(5)
     for _ in range(args.steps):
-        _, ms = plan.apply_timed(x, out=y)
-        acc += np.array(ms)
+        if "bp" in stages:
+            stage_ms["bp_sosfiltfilt"] = stage_ms.get("bp_sosfiltfilt", 0.0) + ev_time(
+                lambda: ddsp._sosfiltfilt_device(x, sos_bp, 51))
+        if "fk" in stages:
+            _, ms = plan.apply_timed(x, out=y)
+            acc += np.array(ms)
+        if "mf" in stages:
+            stage_ms["mf_rowstats_xcorr"] = stage_ms.get("mf_rowstats_xcorr", 0.0) + ev_time(
+                lambda: ddet._xcorr_device(y if "fk" in stages else x, tpl, normalize=True))
     acc /= args.steps
-    dom = int(np.argmax(acc))
-    pass_bytes = 8.0 * samples                       # one read + one write of the block per pass
-    achieved = pass_bytes / (acc[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": PASS_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms": {PASS_NAMES[i]: float(acc[i]) for i in range(5)},
-                "fk_algorithmic_GBps": 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9,
-                "fk_algorithmic_frac": 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
+    kernel_ms = {PASS_NAMES[i]: float(acc[i]) for i in range(5)} if "fk" in stages else {}
+    if "fk" in stages:
+        stage_ms["fk_filter"] = float(acc.sum())
+    # algorithmic bytes per launch: an f-k pass reads and writes the block once
+    # (8 B/sample); band-pass 2 x (4+4) B/sample; matched filter 4 + 4 (stats) + 8 B/sample
+    alg_bytes = {n: 8.0 * samples for n in PASS_NAMES}
+    cand = dict(kernel_ms)
+    if "mf" in stages:
+        cand["mf_rowstats_xcorr"] = stage_ms["mf_rowstats_xcorr"]
+        alg_bytes["mf_rowstats_xcorr"] = 16.0 * samples
+    if "bp" in stages:
+        cand["bp_sosfiltfilt"] = stage_ms["bp_sosfiltfilt"]
+        alg_bytes["bp_sosfiltfilt"] = 16.0 * samples
+    dom = max(cand, key=cand.get)
+    achieved = alg_bytes[dom] / (cand[dom] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by scripts/pmc_summary.py
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel_ms": kernel_ms, "stage_ms": stage_ms}
+    if "fk" in stages:
+        fk_gbs = 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9
+        roofline.update({"fk_algorithmic_GBps": fk_gbs, "fk_algorithmic_frac": fk_gbs / HBM_PEAK_GBS,
+                         "fk_only_samples_per_s": samples / (float(acc.sum()) * 1e-3)})
 
     if rank == 0:
-        out = {"metric": "channel-samples/sec through f-k filter", "value": value,
+        out = {"metric": "channel-samples/sec through " + " + ".join(
+                   {"bp": "band-pass", "fk": "f-k filter", "mf": "matched-filter"}[t] for t in stages), "value": value,
                "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%d channels x %d samples float32 per GPU, classic f-k fan mask "
-                                      "(fk_filter_design defaults), f-k filter" % (nx, ns),
+                                      "(fk_filter_design defaults), stages %s, HF+LF fin-call templates"
+                                      % (nx, ns, "+".join(stages)),
                           "plan": plan.info(), "parallelism": "independent channel blocks x%d" % world},
                "roofline": roofline}
         if world == 1 and not args.no_cpu:
             snx, sns = [int(v) for v in args.cpu_sample.split("x")]
-            out["cpu_baseline"] = cpu_baseline(snx, sns)
+            out["cpu_baseline"] = cpu_baseline(snx, sns, stages)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,76 @@
+"""world_size-2 gloo tests (CPU) of the channel-block sharding + single all-gather reassembly that
+the multi-GPU path uses with RCCL on the GPUs."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _load_shard():
+    """Import das4whales_amd/shard.py without triggering the package's GPU-library import."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("d4w_shard", os.path.join(ROOT, "das4whales_amd", "shard.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _worker(rank, world, port, nx, ns, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = _load_shard()
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn((nx, ns), generator=g)                     # same on every rank
+        fn = lambda blk: torch.cumsum(blk, dim=1) * 0.5 + blk.flip(1)   # row-independent stand-in
+        a, b = shard.channel_block(nx, world, rank)
+        y_local = fn(x[a:b])
+        y = shard.all_gather_rows(y_local, nx)
+        y2 = shard.map_channel_blocks(fn, x)
+        ok = bool(torch.equal(y, fn(x)) and torch.equal(y2, y))
+        q.put((rank, ok, (a, b)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nx,ns", [(10, 33), (7, 16)])                # even and uneven blocks
+def test_all_gather_rows_world2(nx, ns):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nx, ns, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    blocks = sorted(b for _, _, b in res)
+    assert blocks[0][0] == 0 and blocks[0][1] == blocks[1][0] and blocks[1][1] == nx
+
+
+def test_channel_block_partition():
+    shard = _load_shard()
+    for nx in (1, 7, 8, 20000, 11020):
+        for world in (1, 2, 3, 8):
+            blocks = [shard.channel_block(nx, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == nx
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
