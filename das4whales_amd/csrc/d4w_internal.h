@@ -90,5 +90,38 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// 16-byte LDS read that stays one ds_read_b128: left to itself hipcc splits a float4 LDS load into
+// ds_read2_b32 pairs, whose banking (dword index mod 32) turns a 16-byte lane stride into a 4-way
+// conflict.  The volatile ext-vector access is not split.
+__device__ __forceinline__ float4 lds_read4(const float4* p) {
+#ifdef D4W_EMU
+    return *p;
+#else
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef const volatile f4_t __attribute__((address_space(3))) * lds_f4_ptr;
+    const f4_t v = *(lds_f4_ptr)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+
+// two-lane packed float (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on gfx950)
+#ifdef D4W_EMU
+struct v2f { float x, y; };
+__device__ __forceinline__ v2f v2_make(float x, float y) { return v2f{x, y}; }
+__device__ __forceinline__ float v2_x(v2f a) { return a.x; }
+__device__ __forceinline__ float v2_y(v2f a) { return a.y; }
+// a * s + c  (s broadcast)
+__device__ __forceinline__ v2f v2_fma(v2f a, float s, v2f c) { return v2f{fmaf(a.x, s, c.x), fmaf(a.y, s, c.y)}; }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f v2_make(float x, float y) { v2f r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ float v2_x(v2f a) { return a.x; }
+__device__ __forceinline__ float v2_y(v2f a) { return a.y; }
+__device__ __forceinline__ v2f v2_fma(v2f a, float s, v2f c) {
+    v2f sv; sv.x = s; sv.y = s;
+    return __builtin_elementwise_fma(a, sv, c);
+}
+#endif
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace d4w

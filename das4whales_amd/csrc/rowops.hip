@@ -178,77 +178,108 @@ __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restric
 // =============================================================================================
 // matched filter: direct-form correlation, NT templates fused over one read of x
 //   y_t[c][k] = g[c] * sum_n (x[c][n+k] - m[c]) * taps[t][n]
-// A workgroup owns kXcTile consecutive lags of one row.  The de-meaned row piece sits in LDS;
-// every thread keeps 4 consecutive lags in registers and slides an 8-sample window over the
-// taps (one conflict-free ds_read_b128 per 16*NT FMAs).  Taps are wave-uniform -> scalar loads.
-// VALU-bound: 2*(L_0 + L_1) flop per 4 + 4*NT bytes.
+// VALU-bound (2*(L_0 + L_1) flop per 4 + 4*NT bytes), and on gfx950 a scalar
+// v_fma_f32 costs the same 4 issue cycles as a packed v_pk_fma_f32 (measured: VALU 100 % busy at
+// 4 cycles per instruction), so the kernel is built around packed FMAs:
+//   * a workgroup owns TWO rows x kXcTile lags; the de-meaned pieces sit in LDS interleaved as
+//     (xA[j], xB[j]) pairs, so every v_pk_fma_f32 advances the same lag of both rows and the tap is
+//     one broadcast SGPR (taps are wave-uniform scalar loads);
+//   * a thread keeps two groups of 2 consecutive lags (kXcTile/2 apart) in registers and slides a
+//     16-byte window over the taps: one conflict-free ds_read_b128 (lane stride 16 B) per group
+//     per two taps, i.e. per 4*NT packed FMAs.
 // =============================================================================================
 constexpr int kXcThreads = 256;
-constexpr int kXcTile = kXcThreads * 4;   // lags per workgroup
-constexpr int kXcTapBlock = 256;          // taps per LDS staging round
+constexpr int kXcGroups = 2;
+constexpr int kXcTile = kXcThreads * 2 * kXcGroups;   // lags per workgroup (1024)
+constexpr int kXcTapBlock = 256;                      // taps per LDS staging round
 
 template <int NT>
-__global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict__ x, int ns,
+__global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict__ x, int nx, int ns,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ maxabs,
                                                         const float* __restrict__ taps, int ltaps,
                                                         float* __restrict__ y0, float* __restrict__ y1) {
-    __shared__ __attribute__((aligned(16))) float xs[kXcTile + kXcTapBlock + 4];
+    // xs4[f] = (xA[2f], xB[2f], xA[2f+1], xB[2f+1])
+    __shared__ float4 xs4[(kXcTile + kXcTapBlock) / 2 + 2];
+    float2* xs2 = reinterpret_cast<float2*>(xs4);
     const int tid = threadIdx.x;
-    const int rowi = blockIdx.y;
+    const int rowA = 2 * blockIdx.y;
+    const bool hasB = (rowA + 1 < nx);
+    const int rowB = hasB ? rowA + 1 : rowA;
     const int k0 = blockIdx.x * kXcTile;
-    const float* row = x + (size_t)rowi * ns;
-    const float m = mean ? mean[rowi] : 0.f;
-    float g = 1.f;
+    const float* pa = x + (size_t)rowA * ns;
+    const float* pb = x + (size_t)rowB * ns;
+    const float ma = mean ? mean[rowA] : 0.f, mb = mean ? mean[rowB] : 0.f;
+    float ga = 1.f, gb = 1.f;
     if (maxabs) {
-        const float a = maxabs[rowi];
-        g = (a > 0.f) ? 1.0f / a : 0.f;
+        const float a = maxabs[rowA], b = maxabs[rowB];
+        ga = (a > 0.f) ? 1.0f / a : 0.f;
+        gb = (b > 0.f) ? 1.0f / b : 0.f;
     }
-    float acc[NT][4];
+    v2f acc[NT][kXcGroups][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+        for (int g = 0; g < kXcGroups; ++g) acc[t][g][0] = acc[t][g][1] = v2_make(0.f, 0.f);
 
     for (int n0 = 0; n0 < ltaps; n0 += kXcTapBlock) {
         const int nb = min(kXcTapBlock, ltaps - n0);          // taps in this round (multiple of 4)
         const int need = kXcTile + nb;                        // samples k0+n0 .. k0+n0+need-1
         for (int j = tid; j < need; j += kXcThreads) {
             const int i = k0 + n0 + j;
-            xs[j] = (i < ns) ? row[i] - m : 0.f;              // beyond the row: zero padding
+            float2 v = make_float2(0.f, 0.f);                 // beyond the row: zero padding
+            if (i < ns) v = make_float2(pa[i] - ma, pb[i] - mb);
+            xs2[j] = v;
         }
         __syncthreads();
-        const float4* win = reinterpret_cast<const float4*>(xs) + tid;
-        float4 lo = win[0];
-        for (int tb = 0; tb < nb / 4; ++tb) {
-            const float4 hi = win[tb + 1];
-            const float w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float4* win[kXcGroups];
+        float4 cur[kXcGroups];
+#pragma unroll
+        for (int g = 0; g < kXcGroups; ++g) {
+            win[g] = xs4 + tid + g * (kXcTile / (2 * kXcGroups));
+            cur[g] = lds_read4(win[g]);
+        }
+        for (int tb = 0; tb < nb / 2; ++tb) {                 // two taps per step
+            float c[NT][2];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float* tp = taps + (size_t)t * ltaps + n0 + 4 * tb;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float c = tp[q];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(w[r + q], c, acc[t][r]);
-                }
+                c[t][0] = taps[(size_t)t * ltaps + n0 + 2 * tb];
+                c[t][1] = taps[(size_t)t * ltaps + n0 + 2 * tb + 1];
             }
-            lo = hi;
+#pragma unroll
+            for (int g = 0; g < kXcGroups; ++g) {
+                const float4 nxt = lds_read4(win[g] + tb + 1);
+                const v2f w0 = v2_make(cur[g].x, cur[g].y), w1 = v2_make(cur[g].z, cur[g].w),
+                          w2 = v2_make(nxt.x, nxt.y);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t][g][0] = v2_fma(w0, c[t][0], acc[t][g][0]);
+                    acc[t][g][1] = v2_fma(w1, c[t][0], acc[t][g][1]);
+                    acc[t][g][0] = v2_fma(w1, c[t][1], acc[t][g][0]);
+                    acc[t][g][1] = v2_fma(w2, c[t][1], acc[t][g][1]);
+                }
+                cur[g] = nxt;
+            }
         }
         __syncthreads();
     }
-    const int k = k0 + 4 * tid;
-    if (k < ns) {
+#pragma unroll
+    for (int g = 0; g < kXcGroups; ++g) {
+        const int k = k0 + g * (kXcTile / kXcGroups) + 2 * tid;
+        if (k >= ns) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float* out = (t == 0 ? y0 : y1) + (size_t)rowi * ns + k;
-            if (k + 3 < ns && (((size_t)rowi * ns + k) & 3) == 0) {
-                *reinterpret_cast<float4*>(out) =
-                    make_float4(acc[t][0] * g, acc[t][1] * g, acc[t][2] * g, acc[t][3] * g);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k + r < ns) out[r] = acc[t][r] * g;
+            float* base = (t == 0 ? y0 : y1);
+            const float a0 = v2_x(acc[t][g][0]) * ga, a1 = v2_x(acc[t][g][1]) * ga;
+            const float b0 = v2_y(acc[t][g][0]) * gb, b1 = v2_y(acc[t][g][1]) * gb;
+            float* oa = base + (size_t)rowA * ns + k;
+            float* ob = base + (size_t)rowB * ns + k;
+            const bool pair = (k + 1 < ns);
+            if (pair && ((((size_t)rowA * ns + k) & 1) == 0)) *reinterpret_cast<float2*>(oa) = make_float2(a0, a1);
+            else { oa[0] = a0; if (pair) oa[1] = a1; }
+            if (hasB) {
+                if (pair && ((((size_t)rowB * ns + k) & 1) == 0)) *reinterpret_cast<float2*>(ob) = make_float2(b0, b1);
+                else { ob[0] = b0; if (pair) ob[1] = b1; }
             }
         }
     }
@@ -324,12 +355,12 @@ int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float
     if (!x || !taps || !y0 || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
     if (ltaps < 4 || (ltaps & 3)) return fail(D4W_EINVAL, "ltaps = %d must be a positive multiple of 4", ltaps);
-    const dim3 grid(ceil_div(ns, kXcTile), nx);
-    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    const dim3 grid(ceil_div(ns, kXcTile), ceil_div(nx, 2));
+    if (grid.y > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
     if (ntpl == 1)
-        D4W_LAUNCH(xcorr_fir<1>, grid, dim3(kXcThreads), 0, stream, x, ns, mean, maxabs, taps, ltaps, y0, y1);
+        D4W_LAUNCH(xcorr_fir<1>, grid, dim3(kXcThreads), 0, stream, x, nx, ns, mean, maxabs, taps, ltaps, y0, y1);
     else
-        D4W_LAUNCH(xcorr_fir<2>, grid, dim3(kXcThreads), 0, stream, x, ns, mean, maxabs, taps, ltaps, y0, y1);
+        D4W_LAUNCH(xcorr_fir<2>, grid, dim3(kXcThreads), 0, stream, x, nx, ns, mean, maxabs, taps, ltaps, y0, y1);
     return D4W_OK;
 }
 

@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel trace, PMC traffic passes.
 # Logs -> gpurun_out/ (copied into profiles/ afterwards).
 set -u
-mkdir -p gpurun_out
+mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 echo "== pytest -m gpu"
@@ -18,14 +18,6 @@ cd $R
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "d4w|Name" "$f" | cut -c1-200
 find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
 echo "== pmc FETCH_SIZE / WRITE_SIZE"
-cd /tmp
-i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmc/g$i -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/pmc/g$i.log 2>&1
-  echo "group $i rc=$?"
-done
-cd $R
-python scripts/pmc_summary.py gpurun_out/pmc --traffic gpurun_out/pmc_traffic.json | tee gpurun_out/pmc/summary.txt
-find gpurun_out/pmc -name "*.csv" -size +8M -delete
+PMC_GROUPS="fetch write" bash scripts/pmc.sh gpurun_out/pmc
+cp gpurun_out/pmc/pmc_traffic.json gpurun_out/pmc_traffic.json
 fi
