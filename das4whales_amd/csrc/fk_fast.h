@@ -1,0 +1,498 @@
+// Shape-specialised f-k pass kernels ("fat-stage" register FFTs).
+//
+// Same five-pass factorisation, tables and digit-reversed in-place conventions as the generic
+// kernels in fk_filter.hip, but every axis is cut into at most three radices (<= 32) that are
+// compile-time constants:
+//   * a whole radix-R butterfly lives in one thread's registers; the FIRST butterfly of a pass is
+//     applied directly to the registers the global prefetch landed in and the LAST one feeds the
+//     global stores, so a two-radix axis costs ONE LDS exchange (write, barrier, read) instead of
+//     tile-in + one round trip per radix + tile-out;
+//   * pass B fuses [last forward radix | real-spectrum pair op x mask | first inverse radix] on
+//     one thread (a group of NC consecutive positions and its Hermitian partner group);
+//   * all index arithmetic is constant-folded, twiddles of the exchange stages sit in LDS, the
+//     four-step twiddles W_nx^(c2 kc1) are wave-uniform scalar loads;
+//   * persistent workgroups prefetch the next tile's butterfly inputs straight into registers
+//     while the current tile is in its LDS phase.
+// Instantiated for the shapes listed in fk_filter.hip (kFastShapes); any other shape runs the
+// generic kernels.
+#pragma once
+#include "fft_lds.h"
+
+namespace d4w {
+
+template <int C1_, int C2A_, int C2B_, int N1_, int NA_, int NB_, int NC_, int TA_, int TC_, int THRA_,
+          int THRC_, int THRB_>
+struct FkFastCfg {
+    static constexpr int C1 = C1_, C2A = C2A_, C2B = C2B_, C2 = C2A_ * C2B_, NX = C1_ * C2A_ * C2B_;
+    static constexpr int N1 = N1_, NA = NA_, NB = NB_, NC = NC_, N2 = NA_ * NB_ * NC_, M = N1_ * NA_ * NB_ * NC_;
+    static constexpr int TA = TA_, TC = TC_, THRA = THRA_, THRC = THRC_, THRB = THRB_;
+    // pass A: tile [C1][N1][TA] + double-buffered four-step twiddle strip [2][N1][TA]
+    static constexpr size_t ldsA = (size_t)(C1 * N1 * TA + 2 * N1 * TA) * sizeof(float2);
+    // pass C: tile [(C2A)(C2B + 1)][TC] (one pad row per C2B rows) + twiddles [C2A][C2B]
+    static constexpr size_t ldsC = (size_t)(C2A * (C2B + 1) * TC + C2A * C2B) * sizeof(float2);
+    // pass B: two rows of N2 (+ one pad element per NC) + tw1 [NB*NC] + tw2 [NB][NC]
+    static constexpr int ROWP = N2 + NA * NB;
+    static constexpr size_t ldsB = (size_t)(2 * ROWP + 2 * NB * NC) * sizeof(float2);
+    static_assert(N1 * TA <= THRA && C1 * TA <= THRA, "pass A: one butterfly per thread");
+    static_assert(C2B * TC <= THRC && C2A * TC <= THRC, "pass C: one butterfly per thread");
+    static_assert(2 * NB * NC <= THRB && NA * NB <= THRB, "pass B: one S1 / mid item per thread");
+    static_assert(N2 % TA == 0 && M % TC == 0, "tiles must divide the axes");
+};
+
+// extra device tables of a fast plan (FkDev carries the generic ones)
+struct FkFastDev {
+    const float2* twC;    // [C2A][C2B]  W_C2^(j a)
+    const float2* twB1;   // [NB*NC]     W_N2^j
+    const float2* twB2;   // [NB][NC]    W_(NB*NC)^(j2 b)
+};
+
+template <int R>
+__device__ __forceinline__ void pw_tree(float2 w1, float2 (&pw)[R]) {
+    pw[0] = make_float2(1.f, 0.f);
+    if constexpr (R > 1) pw[1] = w1;
+    static_for<(R > 2 ? R - 2 : 0)>([&](auto qq) {
+        constexpr int q = decltype(qq)::value + 2;
+        pw[q] = c_mul(pw[q / 2], pw[q - q / 2]);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass A forward: tile = (all c1) x (all n1) x TA columns of one c2.
+//   S1 item (n1, tt): DFT over c1 in the prefetch registers, x W_nx^(c2 kc1)   -> LDS
+//   S2 item (q,  tt): DFT over n1, x W_M^(n2 k1) (strip staged in LDS)         -> global
+// ---------------------------------------------------------------------------------------------
+template <class G, bool TAPER>
+__global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* __restrict__ src,
+                                                         float2* __restrict__ dst, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = tile + G::C1 * G::N1 * G::TA;
+    constexpr int NBX = G::N2 / G::TA;
+    const int tid = threadIdx.x;
+    const int hi = tid / G::TA, tt = tid % G::TA;      // hi = n1 (S1) or q (S2)
+    const bool act1 = hi < G::N1, act2 = hi < G::C1;
+    float2 pf[G::C1];
+    float2 ptw = make_float2(0.f, 0.f), pwin = make_float2(1.f, 1.f);
+    auto issue = [&](int t) {
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int col = hi * G::N2 + b0 + tt;
+        const float2* p = src + (size_t)c2 * G::M + col;
+        static_for<G::C1>([&](auto cc) {
+            constexpr int c1 = decltype(cc)::value;
+            pf[c1] = p[(size_t)c1 * G::C2 * G::M];
+        });
+        ptw = P.twt[col];
+        if (TAPER) pwin = P.win[col];
+    };
+    int t = blockIdx.x;
+    if (t < ntiles && act1) issue(t);
+    int par = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        float2* tw_cur = twl + par * (G::N1 * G::TA);
+        if (act1) {
+            if (TAPER) {
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    pf[c1].x *= pwin.x;
+                    pf[c1].y *= pwin.y;
+                });
+            }
+            dft<G::C1>(pf);
+            static_for<G::C1>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                tile[(q * G::N1 + hi) * G::TA + tt] = c_mul(pf[q], P.twc[q * G::C2 + c2]);
+            });
+            tw_cur[hi * G::TA + tt] = ptw;
+        }
+        lds_barrier();
+        const int nt = t + gridDim.x;
+        if (nt < ntiles && act1) issue(nt);
+        float2 v[G::N1];
+        if (act2) {
+            static_for<G::N1>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                v[k] = tile[(hi * G::N1 + k) * G::TA + tt];
+            });
+        }
+        lds_barrier();
+        if (act2) {
+            dft<G::N1>(v);
+            float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+            static_for<G::N1>([&](auto kk) {
+                constexpr int q1 = decltype(kk)::value;
+                o[q1 * G::N2] = c_mul(v[q1], tw_cur[q1 * G::TA + tt]);
+            });
+        }
+        par ^= 1;
+    }
+}
+
+// pass A inverse: S1' item (q1, tt): x conj(twiddles), inverse DFT over q (c1 axis) -> LDS;
+//                 S2' item (c1, tt): inverse DFT over q1 (n1 axis), x 1/(nx M)     -> global
+template <class G>
+__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    constexpr int NBX = G::N2 / G::TA;
+    const int tid = threadIdx.x;
+    const int hi = tid / G::TA, tt = tid % G::TA;      // hi = q1 (S1') or c1 (S2')
+    const bool act1 = hi < G::N1, act2 = hi < G::C1;
+    float2 pf[G::C1];
+    float2 ptw = make_float2(1.f, 0.f);
+    auto issue = [&](int t) {
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int col = hi * G::N2 + b0 + tt;
+        const float2* p = data + (size_t)c2 * G::M + col;
+        static_for<G::C1>([&](auto cc) {
+            constexpr int q = decltype(cc)::value;
+            pf[q] = p[(size_t)q * G::C2 * G::M];
+        });
+        ptw = P.twt[col];
+    };
+    int t = blockIdx.x;
+    if (t < ntiles && act1) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        if (act1) {
+            static_for<G::C1>([&](auto cc) {
+                constexpr int q = decltype(cc)::value;
+                pf[q] = c_mulc(pf[q], c_mul(P.twc[q * G::C2 + c2], ptw));
+            });
+            idft<G::C1>(pf);
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                tile[(c1 * G::N1 + hi) * G::TA + tt] = pf[c1];
+            });
+        }
+        lds_barrier();
+        const int nt = t + gridDim.x;
+        if (nt < ntiles && act1) issue(nt);
+        float2 v[G::N1];
+        if (act2) {
+            static_for<G::N1>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                v[k] = tile[(hi * G::N1 + k) * G::TA + tt];
+            });
+        }
+        lds_barrier();
+        if (act2) {
+            idft<G::N1>(v);
+            float2* o = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+            static_for<G::N1>([&](auto kk) {
+                constexpr int n1 = decltype(kk)::value;
+                o[n1 * G::N2] = c_scale(v[n1], P.scale);
+            });
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass C: FFT over c2 = C2A x C2B for TC contiguous columns of one c1-position q.
+//   forward : S1 item (j < C2B, tt): radix C2A over rows j + a C2B, x W_C2^(j a') -> LDS
+//             S2 item (g < C2A, tt): radix C2B over rows g C2B + b               -> global
+//   inverse : the same two steps backwards.
+// LDS row index c2 + c2 / C2B (one pad row per C2B rows) keeps the S2 reads conflict-free.
+// ---------------------------------------------------------------------------------------------
+template <class G, bool INV>
+__global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float2* __restrict__ data, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = tile + G::C2A * (G::C2B + 1) * G::TC;
+    constexpr int NBX = G::M / G::TC;
+    constexpr int RA = G::C2A, RB = G::C2B, TC = G::TC;
+    const int tid = threadIdx.x;
+    const int hi = tid / TC, tt = tid % TC;            // hi = j (radix-RA items) or g (radix-RB items)
+    const bool actA = hi < RB;                         // items of the radix-RA step
+    const bool actB = hi < RA;                         // items of the radix-RB step
+    for (int i = tid; i < RA * RB; i += G::THRC) twl[i] = F.twC[i];
+    __syncthreads();
+    constexpr int NPF = INV ? RB : RA;
+    float2 pf[NPF];
+    auto issue = [&](int t) {
+        const int q = t / NBX, p0 = (t % NBX) * TC;
+        const float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
+        if constexpr (!INV) {
+            static_for<RA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                pf[a] = base[(size_t)(hi + a * RB) * G::M];
+            });
+        } else {
+            static_for<RB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                pf[b] = base[(size_t)(hi * RB + b) * G::M];
+            });
+        }
+    };
+    const bool act_first = INV ? actB : actA;
+    const bool act_second = INV ? actA : actB;
+    int t = blockIdx.x;
+    if (t < ntiles && act_first) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const int q = t / NBX, p0 = (t % NBX) * TC;
+        float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
+        if (act_first) {
+            if constexpr (!INV) {
+                dft<RA>(pf);
+                static_for<RA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const float2 v = (a == 0) ? pf[0] : c_mul(pf[a], twl[a * RB + hi]);
+                    tile[(hi + a * (RB + 1)) * TC + tt] = v;
+                });
+            } else {
+                idft<RB>(pf);
+                static_for<RB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    tile[(hi * (RB + 1) + b) * TC + tt] = pf[b];
+                });
+            }
+        }
+        lds_barrier();
+        const int nt = t + gridDim.x;
+        if (nt < ntiles && act_first) issue(nt);
+        constexpr int NV = INV ? RA : RB;
+        float2 v[NV];
+        if (act_second) {
+            if constexpr (!INV) {
+                static_for<RB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    v[b] = tile[(hi * (RB + 1) + b) * TC + tt];
+                });
+            } else {
+                static_for<RA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    v[a] = tile[(hi + a * (RB + 1)) * TC + tt];
+                });
+            }
+        }
+        lds_barrier();
+        if (act_second) {
+            if constexpr (!INV) {
+                dft<RB>(v);
+                static_for<RB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    base[(size_t)(hi * RB + b) * G::M] = v[b];
+                });
+            } else {
+                static_for<RA - 1>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value + 1;
+                    v[a] = c_mulc(v[a], twl[a * RB + hi]);
+                });
+                idft<RA>(v);
+                static_for<RA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    base[(size_t)(hi + a * RB) * G::M] = v[a];
+                });
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass B: contiguous n2 transform (N2 = NA NB NC) of a sub-row and its Hermitian partner,
+// real-spectrum pair op with the folded mask, inverse.  See fk_filter.hip (fk_passB) for the
+// pair-op algebra; positions here are e = d0 (NB NC) + d1 NC + d2 (digit-reversed, in place).
+//   S1  item (row, j < NB NC)       : radix NA on the prefetch registers, x W_N2^(j a')  -> LDS
+//   S2  item (row, g < NA, j2 < NC) : radix NB in place, x W_(NB NC)^(j2 b')
+//   MID item (G < NA NB)            : radix NC on group G of row A and on its partner group of
+//                                     row B, pair op x mask, inverse radix NC, in place
+//   S2', S1' : inverse of S2, S1; S1' feeds the global stores.
+// LDS position e lives at e + e / NC (one pad per group: the MID reads are conflict-free).
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float2* __restrict__ data, int npairs) {
+    D4W_DYN_LDS(smem_raw);
+    constexpr int N2 = G::N2, NA = G::NA, NB = G::NB, NC = G::NC, M1 = NB * NC, NG = NA * NB, ROWP = G::ROWP;
+    constexpr int THR = G::THRB;
+    float2* rows = reinterpret_cast<float2*>(smem_raw);
+    float2* tw1 = rows + 2 * ROWP;          // [M1]      W_N2^j
+    float2* tw2 = tw1 + M1;                 // [NB][NC]  W_M1^(j2 b)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < M1; i += THR) {
+        tw1[i] = F.twB1[i];
+        tw2[i] = F.twB2[i];
+    }
+    __syncthreads();
+    auto ad = [](int e) { return e + e / NC; };
+
+    // S1 / S1' item
+    const int r1 = tid / M1, j1 = tid % M1;
+    const bool it1 = tid < 2 * M1;
+    float2 pf[NA];
+    auto issue = [&](int t) {
+        const int2 pr = P.pairs[t];
+        if (it1 && (r1 == 0 || pr.x != pr.y)) {
+            const float2* p = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                pf[a] = p[a * M1];
+            });
+        }
+    };
+    int t = blockIdx.x;
+    if (t < npairs) issue(t);
+    for (; t < npairs; t += gridDim.x) {
+        const int2 pr = P.pairs[t];
+        const bool same = (pr.x == pr.y);
+        const int nrows = same ? 1 : 2;
+        const int rpos = pr.x / G::N1, q1 = pr.x - rpos * G::N1;
+        const bool k1zero = (q1 == 0);
+        // ---------------- S1
+        if (it1 && r1 < nrows) {
+            dft<NA>(pf);
+            float2 pw[NA];
+            pw_tree<NA>(tw1[j1], pw);
+            float2* row = rows + r1 * ROWP;
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                row[ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+            });
+        }
+        lds_barrier();
+        // ---------------- MID operands that come from global memory: issued BEFORE the prefetch of
+        // the next tile so that waiting for them does not wait for the prefetch (vmcnt is in order)
+        const int Gi = tid;
+        const bool midrange = Gi < NG;
+        int PG = 0;
+        float ma[NC], mbr[NC];
+        float2 wc[NC];
+        float nyq = 0.f;
+        float2 wr = make_float2(1.f, 0.f);
+        if (midrange) {
+            PG = k1zero ? (P.mirror0[Gi * NC] / NC) : (NG - 1 - Gi);
+            const float* mA = P.mask + (size_t)pr.x * N2 + Gi * NC;
+            const float* mB = P.mask + (size_t)pr.y * N2 + PG * NC;
+            const float2* wcp = P.wcol + Gi * NC;
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                ma[d] = mA[d];
+                mbr[d] = mB[d];
+                wc[d] = wcp[d];
+            });
+            nyq = P.nyq[rpos];
+            wr = P.wrow[q1];
+        }
+        const int nt = t + gridDim.x;
+        if (nt < npairs) issue(nt);
+        // ---------------- S2 (in place)
+        for (int it = tid; it < nrows * NA * NC; it += THR) {
+            const int r = it / (NA * NC), rem = it - r * (NA * NC);
+            const int g = rem / NC, j2 = rem - g * NC;
+            float2* row = rows + r * ROWP;
+            float2 v[NB];
+            static_for<NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                v[b] = row[ad(g * M1 + j2 + b * NC)];
+            });
+            dft<NB>(v);
+            static_for<NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                row[ad(g * M1 + j2 + b * NC)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
+            });
+        }
+        lds_barrier();
+        // ---------------- MID
+        if (midrange && (!same || PG >= Gi)) {
+            const bool selfg = same && (PG == Gi);
+            const bool rev0 = k1zero && (Gi == 0);           // partner digit (NC - d) % NC instead of NC-1-d
+            float2* ga = rows + ad(Gi * NC);
+            float2* gb = rows + (same ? 0 : ROWP) + ad(PG * NC);
+            float2 a[NC], b[NC];
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                a[d] = ga[d];
+                b[d] = gb[d];
+            });
+            dft<NC>(a);
+            dft<NC>(b);
+            float2 na[NC], nb[NC];                           // new A[d], new B[partner(d)]
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pn = NC - 1 - d, pz = (NC - d) % NC;
+                const float2 bs = rev0 ? b[pz] : b[pn];
+                float mb = rev0 ? mbr[pz] : mbr[pn];
+                if (d == 0 && rev0) mb = nyq;
+                const float2 Bc = c_conj(bs);
+                const float2 w = c_mul(wr, wc[d]);
+                const float2 E = c_scale(c_add(a[d], Bc), 0.5f);
+                const float2 O = c_mul_mi(c_scale(c_sub(a[d], Bc), 0.5f));
+                const float2 tO = c_mul(w, O);
+                const float2 Yp = c_scale(c_add(E, tO), ma[d]);
+                const float2 Ym = c_scale(c_sub(E, tO), mb);
+                const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
+                const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+                na[d] = c_add(S, D);
+                nb[d] = c_conj(c_sub(S, D));
+            });
+            if (!selfg) {
+                static_for<NC>([&](auto dd) {                 // un-permute the partner results
+                    constexpr int e = decltype(dd)::value;
+                    constexpr int pn = NC - 1 - e, pz = (NC - e) % NC;
+                    a[e] = na[e];
+                    b[e] = rev0 ? nb[pz] : nb[pn];
+                });
+                idft<NC>(a);
+                idft<NC>(b);
+                static_for<NC>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    ga[d] = a[d];
+                    gb[d] = b[d];
+                });
+            } else {
+                // group paired with itself: position e takes A's value when it is the first member
+                // of its pair, B's value otherwise (self-paired positions: B's, as the generic kernel)
+                static_for<NC>([&](auto dd) {
+                    constexpr int e = decltype(dd)::value;
+                    constexpr int pn = NC - 1 - e, pz = (NC - e) % NC;
+                    const float2 vn = (e < pn) ? na[e] : nb[pn];
+                    const float2 vz = (e < pz) ? na[e] : nb[pz];
+                    a[e] = rev0 ? vz : vn;
+                });
+                idft<NC>(a);
+                static_for<NC>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    ga[d] = a[d];
+                });
+            }
+        }
+        lds_barrier();
+        // ---------------- S2'
+        for (int it = tid; it < nrows * NA * NC; it += THR) {
+            const int r = it / (NA * NC), rem = it - r * (NA * NC);
+            const int g = rem / NC, j2 = rem - g * NC;
+            float2* row = rows + r * ROWP;
+            float2 v[NB];
+            static_for<NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                const float2 x = row[ad(g * M1 + j2 + b * NC)];
+                v[b] = (b == 0) ? x : c_mulc(x, tw2[b * NC + j2]);
+            });
+            idft<NB>(v);
+            static_for<NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                row[ad(g * M1 + j2 + b * NC)] = v[b];
+            });
+        }
+        lds_barrier();
+        // ---------------- S1' -> global
+        if (it1 && r1 < nrows) {
+            float2 v[NA], pw[NA];
+            pw_tree<NA>(tw1[j1], pw);
+            const float2* row = rows + r1 * ROWP;
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                const float2 x = row[ad(j1 + a * M1)];
+                v[a] = (a == 0) ? x : c_mulc(x, pw[a]);
+            });
+            idft<NA>(v);
+            float2* o = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                o[a * M1] = v[a];
+            });
+        }
+        lds_barrier();
+    }
+}
+
+}  // namespace d4w

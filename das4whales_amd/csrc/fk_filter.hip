@@ -47,6 +47,12 @@ struct FkDev {  // kernel argument block (by value)
     float scale;              // 1 / (nx * M)
 };
 
+}  // namespace d4w
+
+#include "fk_fast.h"
+
+namespace d4w {
+
 constexpr int kThreads = 256;      // threads of the small helper kernels
 #ifndef D4W_FK_THREADS
 #define D4W_FK_THREADS 512
@@ -474,6 +480,55 @@ static std::vector<float> tukey_window(int n, double alpha) {
     return w;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// shape-specialised kernels (fk_fast.h): one table entry per instantiated shape
+// ---------------------------------------------------------------------------------------------
+struct FkFastEntry {
+    int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
+    size_t ldsA, ldsC, ldsB;
+    int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
+    void (*A_fwd)(FkDev, const float2*, float2*, int);
+    void (*A_fwd_taper)(FkDev, const float2*, float2*, int);
+    void (*A_inv)(FkDev, float2*, int);
+    void (*C_fwd)(FkDev, FkFastDev, float2*, int);
+    void (*C_inv)(FkDev, FkFastDev, float2*, int);
+    void (*B_mid)(FkDev, FkFastDev, float2*, int);
+};
+
+template <class G>
+static FkFastEntry fast_entry(int wgA, int wgC, int wgB) {
+    FkFastEntry e;
+    e.nx = G::NX; e.ns = 2 * G::M;
+    e.C1 = G::C1; e.C2A = G::C2A; e.C2B = G::C2B; e.N1 = G::N1; e.NA = G::NA; e.NB = G::NB; e.NC = G::NC;
+    e.TA = G::TA; e.TC = G::TC; e.thrA = G::THRA; e.thrC = G::THRC; e.thrB = G::THRB;
+    e.ldsA = G::ldsA; e.ldsC = G::ldsC; e.ldsB = G::ldsB;
+    e.wgA = wgA; e.wgC = wgC; e.wgB = wgB;
+    e.A_fwd = fkf_passA_fwd<G, false>;
+    e.A_fwd_taper = fkf_passA_fwd<G, true>;
+    e.A_inv = fkf_passA_inv<G>;
+    e.C_fwd = fkf_passC<G, false>;
+    e.C_inv = fkf_passC<G, true>;
+    e.B_mid = fkf_passB<G>;
+    return e;
+}
+
+//                 C1  C2A C2B  N1  NA  NB  NC  TA  TC  thrA thrC thrB
+using FkShapeBench = FkFastCfg<25, 25, 32, 25, 20, 12, 10, 16, 8, 448, 256, 256>;   // 20000 x 120000
+using FkShapeT1 = FkFastCfg<3, 2, 3, 2, 2, 3, 2, 2, 2, 64, 64, 64>;                 // 18 x 48    (tests)
+using FkShapeT2 = FkFastCfg<2, 2, 2, 2, 8, 3, 5, 2, 2, 64, 64, 64>;                 // 8 x 480    (tests)
+using FkShapeT3 = FkFastCfg<5, 4, 5, 5, 4, 3, 5, 4, 4, 64, 64, 64>;                 // 100 x 600  (tests)
+
+static const std::vector<FkFastEntry>& fast_shapes() {
+    static const std::vector<FkFastEntry> v = {
+        fast_entry<FkShapeBench>(1, 2, 2),
+        fast_entry<FkShapeT1>(2, 2, 2),
+        fast_entry<FkShapeT2>(2, 2, 2),
+        fast_entry<FkShapeT3>(2, 2, 2),
+    };
+    return v;
+}
+
 }  // namespace d4w
 
 using namespace d4w;
@@ -494,6 +549,9 @@ struct d4w_fk_plan {
     int npairs = 0;
     int num_cu = 256;
     int wg_per_cu = 2;
+    const FkFastEntry* fast = nullptr;     // shape-specialised kernels, or nullptr = generic passes
+    FkFastDev fdev;
+    int wgA = 1, wgC = 1, wgB = 1;
 };
 
 template <typename T>
@@ -506,9 +564,11 @@ static int upload(d4w_fk_plan* pl, const std::vector<T>& h, const T** out) {
     return D4W_OK;
 }
 
-static int make_axis(d4w_fk_plan* pl, int L, AxisDesc* ax, std::vector<int>* p2f) {
+static int make_axis(d4w_fk_plan* pl, int L, AxisDesc* ax, std::vector<int>* p2f,
+                     const std::vector<int>* forced = nullptr) {
     std::vector<int> rad;
-    if (!factor_radices(L, rad))
+    if (forced) rad = *forced;
+    else if (!factor_radices(L, rad))
         return fail(D4W_EINVAL, "length %d has a prime factor > 31 (Bluestein fallback not implemented)", L);
     ax->L = L;
     ax->nstage = (L == 1) ? 0 : (int)rad.size();
@@ -560,6 +620,18 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     int o[6] = {0, 0, 0, 0, 0, 0};
     if (opts) memcpy(o, opts, sizeof(o));
 
+    // --- shape-specialised kernels (unless the caller pins a tiling or asks for the generic path
+    //     with opts[0] = -1 / D4W_FK_GENERIC=1)
+    const FkFastEntry* fast = nullptr;
+    {
+        bool pinned = false;
+        for (int i = 0; i < 6; ++i) pinned |= (o[i] != 0);
+        if (o[0] < 0) o[0] = 0;                      // -1 = "generic kernels, planner's tiling"
+        const char* g = getenv("D4W_FK_GENERIC");
+        if (!pinned && !(g && atoi(g) > 0))
+            for (const FkFastEntry& e : fast_shapes())
+                if (e.nx == nx && e.ns == ns) fast = &e;
+    }
     // --- split the time axis: smallest N1 whose N2 = M/N1 fits one LDS row pair
     int N1 = o[2], N2 = o[3];
     if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
@@ -582,7 +654,13 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
     int TA = o[4] > 0 ? o[4] : 16;
     while (TA > 1 && (long)C1 * N1 * TA > kMaxTile) TA /= 2;
-    if ((long)C2 * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * N2 > kMaxTile)
+    std::vector<int> r_c1, r_c2, r_n1, r_n2;
+    if (fast) {
+        C1 = fast->C1; C2 = fast->C2A * fast->C2B; N1 = fast->N1; N2 = fast->NA * fast->NB * fast->NC;
+        TA = fast->TA; TC = fast->TC;
+        r_c1 = {C1}; r_c2 = {fast->C2A, fast->C2B}; r_n1 = {N1}; r_n2 = {fast->NA, fast->NB, fast->NC};
+    }
+    if (!fast && ((long)C2 * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * N2 > kMaxTile))
         return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling (C1=%d C2=%d N1=%d N2=%d)",
                     nx, ns, C1, C2, N1, N2);
 
@@ -594,10 +672,23 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     int rc;
     std::vector<int> f_c1, f_c2, f_n1, f_n2;
 #define D4W_TRY(x) do { rc = (x); if (rc != D4W_OK) { d4w_fk_plan_destroy(pl); return rc; } } while (0)
-    D4W_TRY(make_axis(pl, C1, &pl->dev.ax_c1, &f_c1));
-    D4W_TRY(make_axis(pl, C2, &pl->dev.ax_c2, &f_c2));
-    D4W_TRY(make_axis(pl, N1, &pl->dev.ax_n1, &f_n1));
-    D4W_TRY(make_axis(pl, N2, &pl->dev.ax_n2, &f_n2));
+    pl->fast = fast;
+    D4W_TRY(make_axis(pl, C1, &pl->dev.ax_c1, &f_c1, fast ? &r_c1 : nullptr));
+    D4W_TRY(make_axis(pl, C2, &pl->dev.ax_c2, &f_c2, fast ? &r_c2 : nullptr));
+    D4W_TRY(make_axis(pl, N1, &pl->dev.ax_n1, &f_n1, fast ? &r_n1 : nullptr));
+    D4W_TRY(make_axis(pl, N2, &pl->dev.ax_n2, &f_n2, fast ? &r_n2 : nullptr));
+    if (fast) {     // exchange-stage twiddles of the specialised kernels
+        const int RA = fast->C2A, RB = fast->C2B, M1 = fast->NB * fast->NC;
+        std::vector<float2> twC((size_t)RA * RB), twB1(M1), twB2(M1);
+        for (int a = 0; a < RA; ++a)
+            for (int j = 0; j < RB; ++j) twC[(size_t)a * RB + j] = wexp((long long)j * a, C2);
+        for (int j = 0; j < M1; ++j) twB1[j] = wexp(j, N2);
+        for (int b = 0; b < fast->NB; ++b)
+            for (int j2 = 0; j2 < fast->NC; ++j2) twB2[(size_t)b * fast->NC + j2] = wexp((long long)j2 * b, M1);
+        D4W_TRY(upload(pl, twC, &pl->fdev.twC));
+        D4W_TRY(upload(pl, twB1, &pl->fdev.twB1));
+        D4W_TRY(upload(pl, twB2, &pl->fdev.twB2));
+    }
 
     // inverse maps frequency -> position
     std::vector<int> p_c1(C1), p_c2(C2), p_n1(N1), p_n2(N2);
@@ -695,14 +786,27 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         return (v && atoi(v) > 0) ? atoi(v) : dflt;
     };
     pl->wg_per_cu = env_int("D4W_FK_WG_PER_CU", 2048 / kMaxThreads);     // tuning knob
+    if (fast) {
+        pl->wgA = env_int("D4W_FK_WG_A", fast->wgA);
+        pl->wgC = env_int("D4W_FK_WG_C", fast->wgC);
+        pl->wgB = env_int("D4W_FK_WG_B", fast->wgB);
+    }
 #ifndef D4W_EMU
     {
         int devid = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
             pl->num_cu = prop.multiProcessorCount;
+        if (fast) {
+            (void)hipFuncSetAttribute((const void*)fast->A_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
+            (void)hipFuncSetAttribute((const void*)fast->A_fwd_taper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
+            (void)hipFuncSetAttribute((const void*)fast->A_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
+            (void)hipFuncSetAttribute((const void*)fast->C_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+            (void)hipFuncSetAttribute((const void*)fast->C_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+            (void)hipFuncSetAttribute((const void*)fast->B_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
+        }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
-        if (lds_max > 64 * 1024) {
+        if (!fast && lds_max > 64 * 1024) {
             // tiles are capped at 64 KiB; the twiddle tables push the request slightly above the
             // default dynamic-LDS limit
             const void* fns[] = {
@@ -757,6 +861,27 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     const int persist = pl->num_cu * pl->wg_per_cu;
     const dim3 gridA(std::min(ntA, persist)), gridC(std::min(ntC, persist)), gridB(std::min(ntB, persist));
     hipStream_t st = (hipStream_t)stream;
+    if (pl->fast) {
+        const FkFastEntry& F = *pl->fast;
+        const int fA = (d.N2 / d.TA) * d.C2, fC = (d.M / d.TC) * d.C1;
+        const dim3 gA(std::min(fA, pl->num_cu * pl->wgA)), gC(std::min(fC, pl->num_cu * pl->wgC)),
+            gB(std::min(ntB, pl->num_cu * pl->wgB));
+        int rc;
+#define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
+        D4W_MARK(0);
+        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, fA))) return rc;
+        D4W_MARK(1);
+        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, fC))) return rc;
+        D4W_MARK(2);
+        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, ntB))) return rc;
+        D4W_MARK(3);
+        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, fC))) return rc;
+        D4W_MARK(4);
+        if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, fA))) return rc;
+        D4W_MARK(5);
+#undef D4W_MARK
+        return D4W_OK;
+    }
     // FAST kernels carry only the unrolled radices; GENERIC ones add the loop-based primes
     const bool gA = pl->genericA, gB = pl->genericB, gC = pl->genericC;
     int rc;

@@ -35,7 +35,12 @@ if "--traffic" in sys.argv:
         if name == "fk_passC":
             name = "fk_passC_inv" if "<true" in k else "fk_passC_fwd"
         name = alias.get(name, name)
+        # gfx950: FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM), so
+        # kernels whose reads are >= 128-byte contiguous per row piece are doubled; pass C reads
+        # 64-byte column strips (TC = 8 complex) whose requests are counted in full -- calibrated
+        # on the known byte count of the block (raw FETCH_SIZE == 9.6 GB == the block).
+        factor = 1.0 if name.startswith("fk_passC") else 2.0
         out[name] = {"kernel": k, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
-                     "hbm_bytes_per_launch": 2.0 * fetch + write,
-                     "note": "FETCH_SIZE doubled (gfx950 wide-read caveat), KiB units"}
+                     "fetch_factor": factor, "hbm_bytes_per_launch": factor * fetch + write,
+                     "note": "FETCH_SIZE in KiB; x2 for wide (>=128 B) requests, x1 for 64-byte strips"}
     json.dump(out, open(sys.argv[sys.argv.index("--traffic") + 1], "w"), indent=1, sort_keys=True)

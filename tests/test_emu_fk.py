@@ -62,3 +62,24 @@ def test_in_place(emu, golden):
     assert emu.d4w_fk_apply_f32(plan, vp(buf), vp(buf), 0, None) == 0
     emu.d4w_fk_plan_destroy(plan)
     assert rel(buf, g["y_ninf"]) < TOL
+
+
+@pytest.mark.parametrize("nx,ns", [(18, 48), (8, 480), (100, 600)])
+def test_shape_specialised_kernels(emu, nx, ns):
+    """Shapes in fk_filter.hip's kFastShapes run the fat-stage register-FFT kernels (fk_fast.h);
+    opts[0] = -1 forces the generic passes on the same shape: both must match the oracle."""
+    rng = np.random.default_rng(nx + ns)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))                 # arbitrary non-Hermitian mask
+    ref = orc.fk_filter_filt(x, m)
+    y_fast = fk_emu(emu, x, m)
+    assert rel(y_fast, ref) < TOL
+    y_gen = fk_emu(emu, x, m, opts=[-1, 0, 0, 0, 0, 0])
+    assert rel(y_gen, ref) < TOL
+    assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+    info = (ctypes.c_int * 8)()
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+    emu.d4w_fk_plan_info(plan, info)
+    emu.d4w_fk_plan_destroy(plan)
+    assert list(info)[:2] == [nx, ns]

@@ -79,6 +79,22 @@ def test_random_shapes_vs_oracle(dw, nx, ns, opts):
     assert rel(xt.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("nx,ns", [(18, 48), (8, 480), (100, 600)])
+def test_shape_specialised_kernels_vs_oracle(dw, nx, ns):
+    """Shapes with specialised (fat-stage register FFT) kernels, and the generic passes forced on
+    the same shapes (opts[0] = -1)."""
+    rng = np.random.default_rng(nx + ns)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    ref = orc.fk_filter_filt(x, m)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    for opts in (None, (-1, 0, 0, 0, 0, 0)):
+        plan = dw.dsp.FkPlan(nx, ns, opts=opts)
+        plan.set_mask(m)
+        assert rel(plan.apply(xt).cpu().numpy(), ref) < TOL
+        assert rel(plan.apply(xt, taper=True).cpu().numpy(), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+
+
 def test_config1_block_vs_oracle(dw):
     """BASELINE configs[0]/[1] geometry: 4000 channels x 12000 samples, scripts' hybrid_ninf mask
     and the classic fan, synthetic OOI-like block (SURVEY 8d 'S-small')."""
@@ -137,7 +153,20 @@ def test_full_size_properties(dw):
     # linearity: F(2x) == 2 F(x) with a non-trivial (half-strength) mask
     half = torch.full((nx, ns), 0.5, dtype=torch.float32, device="cuda")
     plan.set_mask(half)
-    del half
     plan.apply(x, out=y)
     err2 = float((y - 0.5 * x).abs().max() / x.abs().max())
     assert err2 < TOL
+    # the specialised kernels (default plan at this shape) against the generic five passes on a
+    # random, non-Hermitian mask: two independent implementations of the same filter
+    del half
+    gen.manual_seed(6)
+    mask = torch.rand((nx, ns), dtype=torch.float32, device="cuda", generator=gen)
+    plan.set_mask(mask)
+    plan.apply(x, out=y)
+    plan_g = dw.dsp.FkPlan(nx, ns, opts=(-1, 0, 0, 0, 0, 0))
+    plan_g.set_mask(mask)
+    del mask
+    yg = plan_g.apply(x)
+    err3 = float((y - yg).abs().max() / yg.abs().max())
+    print("20000x120000 specialised vs generic kernels: %.3e" % err3)
+    assert err3 < TOL
