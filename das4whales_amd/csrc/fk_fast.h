@@ -18,18 +18,25 @@
 #pragma once
 #include "fft_lds.h"
 
+#ifndef D4W_ABL
+#define D4W_ABL 0      // timing-ablation switch for scripts/ab.sh experiments (0 = product code)
+#endif
+
 namespace d4w {
 
 template <int C1_, int C2A_, int C2B_, int N1_, int NA_, int NB_, int NC_, int TA_, int TC_, int THRA_,
-          int THRC_, int THRB_>
+          int THRC_, int THRB_, bool CTREE_ = false>
 struct FkFastCfg {
+    // CTREE: pass C forms W_C2^(j a) as powers of W_C2^j in registers instead of reading a
+    // [C2A][C2B] table from LDS (frees C2A*C2B*8 bytes of LDS per workgroup)
+    static constexpr bool CTREE = CTREE_;
     static constexpr int C1 = C1_, C2A = C2A_, C2B = C2B_, C2 = C2A_ * C2B_, NX = C1_ * C2A_ * C2B_;
     static constexpr int N1 = N1_, NA = NA_, NB = NB_, NC = NC_, N2 = NA_ * NB_ * NC_, M = N1_ * NA_ * NB_ * NC_;
     static constexpr int TA = TA_, TC = TC_, THRA = THRA_, THRC = THRC_, THRB = THRB_;
     // pass A: tile [C1][N1][TA] + double-buffered four-step twiddle strip [2][N1][TA]
     static constexpr size_t ldsA = (size_t)(C1 * N1 * TA + 2 * N1 * TA) * sizeof(float2);
     // pass C: tile [(C2A)(C2B + 1)][TC] (one pad row per C2B rows) + twiddles [C2A][C2B]
-    static constexpr size_t ldsC = (size_t)(C2A * (C2B + 1) * TC + C2A * C2B) * sizeof(float2);
+    static constexpr size_t ldsC = (size_t)(C2A * (C2B + 1) * TC + (CTREE_ ? C2B : C2A * C2B)) * sizeof(float2);
     // pass B: two rows of N2 (+ one pad element per NC) + tw1 [NB*NC] + tw2 [NB][NC]
     static constexpr int ROWP = N2 + NA * NB;
     static constexpr size_t ldsB = (size_t)(2 * ROWP + 2 * NB * NC) * sizeof(float2);
@@ -58,8 +65,11 @@ __device__ __forceinline__ void pw_tree(float2 w1, float2 (&pw)[R]) {
 
 // ---------------------------------------------------------------------------------------------
 // pass A forward: tile = (all c1) x (all n1) x TA columns of one c2.
-//   S1 item (n1, tt): DFT over c1 in the prefetch registers, x W_nx^(c2 kc1)   -> LDS
-//   S2 item (q,  tt): DFT over n1, x W_M^(n2 k1) (strip staged in LDS)         -> global
+//   S1 item (n1, tt): DFT over c1 in the prefetch registers                       -> LDS
+//   S2 item (q,  tt): DFT over n1, x W_M^(n2 k1) (strip staged in LDS by the S1 items)
+//                     x W_nx^(c2 kc1(q)) (one prefetched value per thread)        -> global
+// (The four-step twiddles must not be wave-uniform scalar loads inside the tile loop: 25
+//  s_loads per tile on the critical path cost 2 ms of a 5.6 ms pass.)
 // ---------------------------------------------------------------------------------------------
 template <class G, bool TAPER>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* __restrict__ src,
@@ -73,23 +83,28 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
     const bool act1 = hi < G::N1, act2 = hi < G::C1;
     float2 pf[G::C1];
     float2 ptw = make_float2(0.f, 0.f), pwin = make_float2(1.f, 1.f);
+    float2 tc_next = make_float2(1.f, 0.f), tc_cur = make_float2(1.f, 0.f);
     auto issue = [&](int t) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
-        const int col = hi * G::N2 + b0 + tt;
-        const float2* p = src + (size_t)c2 * G::M + col;
-        static_for<G::C1>([&](auto cc) {
-            constexpr int c1 = decltype(cc)::value;
-            pf[c1] = p[(size_t)c1 * G::C2 * G::M];
-        });
-        ptw = P.twt[col];
-        if (TAPER) pwin = P.win[col];
+        if (act1) {
+            const int col = hi * G::N2 + b0 + tt;
+            const float2* p = src + (size_t)c2 * G::M + col;
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                pf[c1] = p[(size_t)c1 * G::C2 * G::M];
+            });
+            ptw = P.twt[col];
+            if (TAPER) pwin = P.win[col];
+        }
+        if (act2) tc_next = P.twc[hi * G::C2 + c2];
     };
     int t = blockIdx.x;
-    if (t < ntiles && act1) issue(t);
+    if (t < ntiles) issue(t);
     int par = 0;
     for (; t < ntiles; t += gridDim.x) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
         float2* tw_cur = twl + par * (G::N1 * G::TA);
+        tc_cur = tc_next;
         if (act1) {
             if (TAPER) {
                 static_for<G::C1>([&](auto cc) {
@@ -101,13 +116,13 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
             dft<G::C1>(pf);
             static_for<G::C1>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
-                tile[(q * G::N1 + hi) * G::TA + tt] = c_mul(pf[q], P.twc[q * G::C2 + c2]);
+                tile[(q * G::N1 + hi) * G::TA + tt] = pf[q];
             });
             tw_cur[hi * G::TA + tt] = ptw;
         }
         lds_barrier();
         const int nt = t + gridDim.x;
-        if (nt < ntiles && act1) issue(nt);
+        if (nt < ntiles) issue(nt);
         float2 v[G::N1];
         if (act2) {
             static_for<G::N1>([&](auto kk) {
@@ -121,69 +136,89 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
             float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
             static_for<G::N1>([&](auto kk) {
                 constexpr int q1 = decltype(kk)::value;
-                o[q1 * G::N2] = c_mul(v[q1], tw_cur[q1 * G::TA + tt]);
+                o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur));
             });
         }
         par ^= 1;
     }
 }
 
-// pass A inverse: S1' item (q1, tt): x conj(twiddles), inverse DFT over q (c1 axis) -> LDS;
-//                 S2' item (c1, tt): inverse DFT over q1 (n1 axis), x 1/(nx M)     -> global
+// pass A inverse (axes in the opposite order, so that each thread again needs ONE W_nx value):
+//   S1' item (q,  tt): x conj(W_M^(n2 k1) W_nx^(c2 kc1(q))), inverse DFT over q1 (n1 axis) -> LDS
+//   S2' item (n1, tt): inverse DFT over q (c1 axis), x 1/(nx M)                            -> global
+// The W_M strip of tile i+1 is loaded one iteration ahead and written to the other half of the
+// double buffer before the first barrier of iteration i, so no extra barrier is needed.
 template <class G>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = tile + G::C1 * G::N1 * G::TA;
     constexpr int NBX = G::N2 / G::TA;
     const int tid = threadIdx.x;
-    const int hi = tid / G::TA, tt = tid % G::TA;      // hi = q1 (S1') or c1 (S2')
-    const bool act1 = hi < G::N1, act2 = hi < G::C1;
-    float2 pf[G::C1];
-    float2 ptw = make_float2(1.f, 0.f);
-    auto issue = [&](int t) {
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
-        const int col = hi * G::N2 + b0 + tt;
-        const float2* p = data + (size_t)c2 * G::M + col;
-        static_for<G::C1>([&](auto cc) {
-            constexpr int q = decltype(cc)::value;
-            pf[q] = p[(size_t)q * G::C2 * G::M];
-        });
-        ptw = P.twt[col];
+    const int hi = tid / G::TA, tt = tid % G::TA;      // hi = q (S1') or n1 (S2'); also q1 for the strip
+    const bool act1 = hi < G::C1, act2 = hi < G::N1;
+    float2 pf[G::N1];
+    float2 tc_next = make_float2(1.f, 0.f), ptw_next = make_float2(1.f, 0.f);
+    auto issue = [&](int t) {                           // data + W_nx value of tile t
+        if (act1) {
+            const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+            const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+            static_for<G::N1>([&](auto kk) {
+                constexpr int q1 = decltype(kk)::value;
+                pf[q1] = p[q1 * G::N2];
+            });
+            tc_next = P.twc[hi * G::C2 + c2];
+        }
+    };
+    auto issue_tw = [&](int t) {                        // strip element (q1 = hi, tt) of tile t
+        if (act2) ptw_next = P.twt[hi * G::N2 + (t % NBX) * G::TA + tt];
     };
     int t = blockIdx.x;
-    if (t < ntiles && act1) issue(t);
+    if (t < ntiles) {
+        issue_tw(t);
+        if (act2) twl[hi * G::TA + tt] = ptw_next;      // strip of the first tile -> buffer 0
+        issue(t);
+        if (t + (int)gridDim.x < ntiles) issue_tw(t + gridDim.x);
+    }
+    __syncthreads();
+    int par = 0;
     for (; t < ntiles; t += gridDim.x) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const float2* tw_cur = twl + par * (G::N1 * G::TA);
+        const int nt = t + gridDim.x, nt2 = nt + gridDim.x;
         if (act1) {
-            static_for<G::C1>([&](auto cc) {
-                constexpr int q = decltype(cc)::value;
-                pf[q] = c_mulc(pf[q], c_mul(P.twc[q * G::C2 + c2], ptw));
-            });
-            idft<G::C1>(pf);
-            static_for<G::C1>([&](auto cc) {
-                constexpr int c1 = decltype(cc)::value;
-                tile[(c1 * G::N1 + hi) * G::TA + tt] = pf[c1];
-            });
-        }
-        lds_barrier();
-        const int nt = t + gridDim.x;
-        if (nt < ntiles && act1) issue(nt);
-        float2 v[G::N1];
-        if (act2) {
+            const float2 tc = tc_next;
             static_for<G::N1>([&](auto kk) {
-                constexpr int k = decltype(kk)::value;
-                v[k] = tile[(hi * G::N1 + k) * G::TA + tt];
+                constexpr int q1 = decltype(kk)::value;
+                pf[q1] = c_mulc(pf[q1], c_mul(tw_cur[q1 * G::TA + tt], tc));
             });
-        }
-        lds_barrier();
-        if (act2) {
-            idft<G::N1>(v);
-            float2* o = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+            idft<G::N1>(pf);
             static_for<G::N1>([&](auto kk) {
                 constexpr int n1 = decltype(kk)::value;
-                o[n1 * G::N2] = c_scale(v[n1], P.scale);
+                tile[(hi * G::N1 + n1) * G::TA + tt] = pf[n1];
             });
         }
+        if (nt < ntiles && act2) twl[(par ^ 1) * (G::N1 * G::TA) + hi * G::TA + tt] = ptw_next;
+        lds_barrier();
+        if (nt < ntiles) issue(nt);
+        if (nt2 < ntiles) issue_tw(nt2);
+        float2 v[G::C1];
+        if (act2) {
+            static_for<G::C1>([&](auto cc) {
+                constexpr int q = decltype(cc)::value;
+                v[q] = tile[(q * G::N1 + hi) * G::TA + tt];
+            });
+        }
+        lds_barrier();
+        if (act2) {
+            idft<G::C1>(v);
+            float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                o[(size_t)c1 * G::C2 * G::M] = c_scale(v[c1], P.scale);
+            });
+        }
+        par ^= 1;
     }
 }
 
@@ -205,7 +240,8 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     const int hi = tid / TC, tt = tid % TC;            // hi = j (radix-RA items) or g (radix-RB items)
     const bool actA = hi < RB;                         // items of the radix-RA step
     const bool actB = hi < RA;                         // items of the radix-RB step
-    for (int i = tid; i < RA * RB; i += G::THRC) twl[i] = F.twC[i];
+    // table layout [a][j]; row a = 1 is W_C2^j, all the tree variant needs
+    for (int i = tid; i < (G::CTREE ? RB : RA * RB); i += G::THRC) twl[i] = F.twC[(G::CTREE ? RB : 0) + i];
     __syncthreads();
     constexpr int NPF = INV ? RB : RA;
     float2 pf[NPF];
@@ -234,9 +270,12 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
         if (act_first) {
             if constexpr (!INV) {
                 dft<RA>(pf);
+                float2 pw[RA];
+                if constexpr (G::CTREE) pw_tree<RA>(twl[hi], pw);
                 static_for<RA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    const float2 v = (a == 0) ? pf[0] : c_mul(pf[a], twl[a * RB + hi]);
+                    const float2 w = G::CTREE ? pw[a] : twl[a * RB + hi];
+                    const float2 v = (a == 0) ? pf[0] : c_mul(pf[a], w);
                     tile[(hi + a * (RB + 1)) * TC + tt] = v;
                 });
             } else {
@@ -274,9 +313,11 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                     base[(size_t)(hi * RB + b) * G::M] = v[b];
                 });
             } else {
+                float2 pw[RA];
+                if constexpr (G::CTREE) pw_tree<RA>(twl[hi], pw);
                 static_for<RA - 1>([&](auto aa) {
                     constexpr int a = decltype(aa)::value + 1;
-                    v[a] = c_mulc(v[a], twl[a * RB + hi]);
+                    v[a] = c_mulc(v[a], G::CTREE ? pw[a] : twl[a * RB + hi]);
                 });
                 idft<RA>(v);
                 static_for<RA>([&](auto aa) {
@@ -319,8 +360,7 @@ __global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float
     const int r1 = tid / M1, j1 = tid % M1;
     const bool it1 = tid < 2 * M1;
     float2 pf[NA];
-    auto issue = [&](int t) {
-        const int2 pr = P.pairs[t];
+    auto issue = [&](int2 pr) {
         if (it1 && (r1 == 0 || pr.x != pr.y)) {
             const float2* p = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;
             static_for<NA>([&](auto aa) {
@@ -329,10 +369,18 @@ __global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float
             });
         }
     };
+    // the work list is read two tiles ahead (wave-uniform scalar loads whose latency would
+    // otherwise sit in front of every prefetch)
     int t = blockIdx.x;
-    if (t < npairs) issue(t);
-    for (; t < npairs; t += gridDim.x) {
-        const int2 pr = P.pairs[t];
+    const int gstep = gridDim.x;
+    int2 pr_cur = make_int2(0, 0), pr_nxt = make_int2(0, 0);
+    if (t < npairs) pr_cur = P.pairs[t];
+    if (t + gstep < npairs) pr_nxt = P.pairs[t + gstep];
+    if (t < npairs) issue(pr_cur);
+    for (; t < npairs; t += gstep) {
+        const int2 pr = pr_cur;
+        int2 pr_nn = pr_cur;
+        if (t + 2 * gstep < npairs) pr_nn = P.pairs[t + 2 * gstep];
         const bool same = (pr.x == pr.y);
         const int nrows = same ? 1 : 2;
         const int rpos = pr.x / G::N1, q1 = pr.x - rpos * G::N1;
@@ -372,8 +420,7 @@ __global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float
             nyq = P.nyq[rpos];
             wr = P.wrow[q1];
         }
-        const int nt = t + gridDim.x;
-        if (nt < npairs) issue(nt);
+        if (t + gstep < npairs) issue(pr_nxt);
         // ---------------- S2 (in place)
         for (int it = tid; it < nrows * NA * NC; it += THR) {
             const int r = it / (NA * NC), rem = it - r * (NA * NC);
@@ -492,6 +539,8 @@ __global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float
             });
         }
         lds_barrier();
+        pr_cur = pr_nxt;
+        pr_nxt = pr_nn;
     }
 }
 

@@ -485,6 +485,7 @@ static std::vector<float> tukey_window(int n, double alpha) {
 // shape-specialised kernels (fk_fast.h): one table entry per instantiated shape
 // ---------------------------------------------------------------------------------------------
 struct FkFastEntry {
+    int variant;           // D4W_FK_VARIANT picks among entries of one shape (0 = default)
     int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
     size_t ldsA, ldsC, ldsB;
     int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
@@ -497,8 +498,9 @@ struct FkFastEntry {
 };
 
 template <class G>
-static FkFastEntry fast_entry(int wgA, int wgC, int wgB) {
+static FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0) {
     FkFastEntry e;
+    e.variant = variant;
     e.nx = G::NX; e.ns = 2 * G::M;
     e.C1 = G::C1; e.C2A = G::C2A; e.C2B = G::C2B; e.N1 = G::N1; e.NA = G::NA; e.NB = G::NB; e.NC = G::NC;
     e.TA = G::TA; e.TC = G::TC; e.thrA = G::THRA; e.thrC = G::THRC; e.thrB = G::THRB;
@@ -514,14 +516,15 @@ static FkFastEntry fast_entry(int wgA, int wgC, int wgB) {
 }
 
 //                 C1  C2A C2B  N1  NA  NB  NC  TA  TC  thrA thrC thrB
-using FkShapeBench = FkFastCfg<25, 25, 32, 25, 20, 12, 10, 16, 8, 448, 256, 256>;   // 20000 x 120000
+// 20000 x 120000: 128-byte column strips in pass C (TC = 16) are worth 3.8 vs 6.9 ms per pass over 64-byte ones
+using FkShapeBench = FkFastCfg<25, 25, 32, 25, 20, 12, 10, 16, 16, 448, 512, 256>;
 using FkShapeT1 = FkFastCfg<3, 2, 3, 2, 2, 3, 2, 2, 2, 64, 64, 64>;                 // 18 x 48    (tests)
 using FkShapeT2 = FkFastCfg<2, 2, 2, 2, 8, 3, 5, 2, 2, 64, 64, 64>;                 // 8 x 480    (tests)
 using FkShapeT3 = FkFastCfg<5, 4, 5, 5, 4, 3, 5, 4, 4, 64, 64, 64>;                 // 100 x 600  (tests)
 
 static const std::vector<FkFastEntry>& fast_shapes() {
     static const std::vector<FkFastEntry> v = {
-        fast_entry<FkShapeBench>(1, 2, 2),
+        fast_entry<FkShapeBench>(1, 1, 2),
         fast_entry<FkShapeT1>(2, 2, 2),
         fast_entry<FkShapeT2>(2, 2, 2),
         fast_entry<FkShapeT3>(2, 2, 2),
@@ -628,9 +631,11 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         for (int i = 0; i < 6; ++i) pinned |= (o[i] != 0);
         if (o[0] < 0) o[0] = 0;                      // -1 = "generic kernels, planner's tiling"
         const char* g = getenv("D4W_FK_GENERIC");
+        const char* vs = getenv("D4W_FK_VARIANT");
+        const int want = vs ? atoi(vs) : 0;
         if (!pinned && !(g && atoi(g) > 0))
             for (const FkFastEntry& e : fast_shapes())
-                if (e.nx == nx && e.ns == ns) fast = &e;
+                if (e.nx == nx && e.ns == ns && (e.variant == want || (!fast && e.variant == 0))) fast = &e;
     }
     // --- split the time axis: smallest N1 whose N2 = M/N1 fits one LDS row pair
     int N1 = o[2], N2 = o[3];
