@@ -25,8 +25,9 @@
 namespace d4w {
 
 template <int C1_, int C2A_, int C2B_, int N1_, int NA_, int NB_, int NC_, int TA_, int TC_, int THRA_,
-          int THRC_, int THRB_, bool CTREE_ = false>
+          int THRC_, int THRB_, bool CTREE_ = false, int WAVES_B_ = 1>
 struct FkFastCfg {
+    static constexpr int WAVES_B = WAVES_B_;   // min waves per SIMD pass B is compiled for (register cap)
     // CTREE: pass C forms W_C2^(j a) as powers of W_C2^j in registers instead of reading a
     // [C2A][C2B] table from LDS (frees C2A*C2B*8 bytes of LDS per workgroup)
     static constexpr bool CTREE = CTREE_;
@@ -71,9 +72,17 @@ __device__ __forceinline__ void pw_tree(float2 w1, float2 (&pw)[R]) {
 // (The four-step twiddles must not be wave-uniform scalar loads inside the tile loop: 25
 //  s_loads per tile on the critical path cost 2 ms of a 5.6 ms pass.)
 // ---------------------------------------------------------------------------------------------
+template <int N>
+struct FkPrefetchA {          // what one thread prefetches for one pass-A tile
+    float2 pf[N];
+    float2 tw;                // strip element W_M^(n2 k1) this thread stages (forward: its own S1 item)
+    float2 win;               // packed Tukey window of the item's column (forward, TAPER)
+    float2 tc;                // W_nx^(c2 kc1(q)) of the thread's q
+};
+
 template <class G, bool TAPER>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* __restrict__ src,
-                                                         float2* __restrict__ dst, int ntiles) {
+                                                         float2* __restrict__ dst, int tbase, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
@@ -81,48 +90,44 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
     const int tid = threadIdx.x;
     const int hi = tid / G::TA, tt = tid % G::TA;      // hi = n1 (S1) or q (S2)
     const bool act1 = hi < G::N1, act2 = hi < G::C1;
-    float2 pf[G::C1];
-    float2 ptw = make_float2(0.f, 0.f), pwin = make_float2(1.f, 1.f);
-    float2 tc_next = make_float2(1.f, 0.f), tc_cur = make_float2(1.f, 0.f);
-    auto issue = [&](int t) {
+    const int gstep = gridDim.x;
+    typedef FkPrefetchA<G::C1> Pre;
+    Pre A, B;       // two register sets, see fkf_passC
+    auto issue = [&](Pre& R, int t) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
         if (act1) {
             const int col = hi * G::N2 + b0 + tt;
             const float2* p = src + (size_t)c2 * G::M + col;
             static_for<G::C1>([&](auto cc) {
                 constexpr int c1 = decltype(cc)::value;
-                pf[c1] = p[(size_t)c1 * G::C2 * G::M];
+                R.pf[c1] = p[(size_t)c1 * G::C2 * G::M];
             });
-            ptw = P.twt[col];
-            if (TAPER) pwin = P.win[col];
+            R.tw = P.twt[col];
+            if (TAPER) R.win = P.win[col];
         }
-        if (act2) tc_next = P.twc[hi * G::C2 + c2];
+        if (act2) R.tc = P.twc[hi * G::C2 + c2];
     };
-    int t = blockIdx.x;
-    if (t < ntiles) issue(t);
     int par = 0;
-    for (; t < ntiles; t += gridDim.x) {
+    auto body = [&](Pre& R, Pre& Rn, int t) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
         float2* tw_cur = twl + par * (G::N1 * G::TA);
-        tc_cur = tc_next;
+        if (t + gstep < ntiles) issue(Rn, t + gstep);
         if (act1) {
             if (TAPER) {
                 static_for<G::C1>([&](auto cc) {
                     constexpr int c1 = decltype(cc)::value;
-                    pf[c1].x *= pwin.x;
-                    pf[c1].y *= pwin.y;
+                    R.pf[c1].x *= R.win.x;
+                    R.pf[c1].y *= R.win.y;
                 });
             }
-            dft<G::C1>(pf);
+            dft<G::C1>(R.pf);
             static_for<G::C1>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
-                tile[(q * G::N1 + hi) * G::TA + tt] = pf[q];
+                tile[(q * G::N1 + hi) * G::TA + tt] = R.pf[q];
             });
-            tw_cur[hi * G::TA + tt] = ptw;
+            tw_cur[hi * G::TA + tt] = R.tw;
         }
         lds_barrier();
-        const int nt = t + gridDim.x;
-        if (nt < ntiles) issue(nt);
         float2 v[G::N1];
         if (act2) {
             static_for<G::N1>([&](auto kk) {
@@ -136,72 +141,79 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
             float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
             static_for<G::N1>([&](auto kk) {
                 constexpr int q1 = decltype(kk)::value;
-                o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur));
+                o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
             });
         }
         par ^= 1;
+    };
+    int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
+    if (t < ntiles) issue(A, t);
+    for (; t < ntiles; t += 2 * gstep) {
+        body(A, B, t);
+        if (t + gstep < ntiles) body(B, A, t + gstep);
     }
 }
 
 // pass A inverse (axes in the opposite order, so that each thread again needs ONE W_nx value):
 //   S1' item (q,  tt): x conj(W_M^(n2 k1) W_nx^(c2 kc1(q))), inverse DFT over q1 (n1 axis) -> LDS
 //   S2' item (n1, tt): inverse DFT over q (c1 axis), x 1/(nx M)                            -> global
-// The W_M strip of tile i+1 is loaded one iteration ahead and written to the other half of the
-// double buffer before the first barrier of iteration i, so no extra barrier is needed.
+// The W_M strip element of tile i+1 travels with the data prefetch of tile i+1 (issued at the top
+// of iteration i) and is written to the other half of the strip double buffer before the first
+// barrier of iteration i+... see the body: it is in LDS one full iteration before it is read.
 template <class G>
-__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int ntiles) {
+__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int tbase, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
     constexpr int NBX = G::N2 / G::TA;
+    constexpr int STRIP = G::N1 * G::TA;
     const int tid = threadIdx.x;
     const int hi = tid / G::TA, tt = tid % G::TA;      // hi = q (S1') or n1 (S2'); also q1 for the strip
     const bool act1 = hi < G::C1, act2 = hi < G::N1;
-    float2 pf[G::N1];
-    float2 tc_next = make_float2(1.f, 0.f), ptw_next = make_float2(1.f, 0.f);
-    auto issue = [&](int t) {                           // data + W_nx value of tile t
+    const int gstep = gridDim.x;
+    typedef FkPrefetchA<G::N1> Pre;
+    Pre A, B;
+    auto issue = [&](Pre& R, int t) {                   // data + W_nx value + strip element of tile t
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        // strip element FIRST: it is consumed one iteration before the data, and vmcnt retires
+        // loads in order -- waiting for the oldest load of a set does not wait for the rest
+        if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
         if (act1) {
-            const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
             const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
             static_for<G::N1>([&](auto kk) {
                 constexpr int q1 = decltype(kk)::value;
-                pf[q1] = p[q1 * G::N2];
+                R.pf[q1] = p[q1 * G::N2];
             });
-            tc_next = P.twc[hi * G::C2 + c2];
+            R.tc = P.twc[hi * G::C2 + c2];
         }
     };
-    auto issue_tw = [&](int t) {                        // strip element (q1 = hi, tt) of tile t
-        if (act2) ptw_next = P.twt[hi * G::N2 + (t % NBX) * G::TA + tt];
-    };
-    int t = blockIdx.x;
-    if (t < ntiles) {
-        issue_tw(t);
-        if (act2) twl[hi * G::TA + tt] = ptw_next;      // strip of the first tile -> buffer 0
-        issue(t);
-        if (t + (int)gridDim.x < ntiles) issue_tw(t + gridDim.x);
-    }
-    __syncthreads();
     int par = 0;
-    for (; t < ntiles; t += gridDim.x) {
+    // strip of tile i lives in twl[par(i)]: written during iteration i-1 (before its first barrier)
+    auto body = [&](Pre& R, Pre& Rn, int t, bool first) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
-        const float2* tw_cur = twl + par * (G::N1 * G::TA);
-        const int nt = t + gridDim.x, nt2 = nt + gridDim.x;
+        const float2* tw_cur = twl + par * STRIP;
+        const bool more = (t + gstep < ntiles);
+        if (first) {                                    // very first tile of this workgroup
+            if (act2) twl[par * STRIP + hi * G::TA + tt] = R.tw;
+            __syncthreads();
+        }
+        // the NEXT tile's registers were issued one iteration ago (or in the prologue): its strip
+        // element is already here, publish it; then start the loads of the tile after that
+        if (more && act2) twl[(par ^ 1) * STRIP + hi * G::TA + tt] = Rn.tw;
         if (act1) {
-            const float2 tc = tc_next;
             static_for<G::N1>([&](auto kk) {
                 constexpr int q1 = decltype(kk)::value;
-                pf[q1] = c_mulc(pf[q1], c_mul(tw_cur[q1 * G::TA + tt], tc));
+                R.pf[q1] = c_mulc(R.pf[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
             });
-            idft<G::N1>(pf);
+            idft<G::N1>(R.pf);
             static_for<G::N1>([&](auto kk) {
                 constexpr int n1 = decltype(kk)::value;
-                tile[(hi * G::N1 + n1) * G::TA + tt] = pf[n1];
+                tile[(hi * G::N1 + n1) * G::TA + tt] = R.pf[n1];
             });
         }
-        if (nt < ntiles && act2) twl[(par ^ 1) * (G::N1 * G::TA) + hi * G::TA + tt] = ptw_next;
         lds_barrier();
-        if (nt < ntiles) issue(nt);
-        if (nt2 < ntiles) issue_tw(nt2);
+        // R's registers are free now: prefetch tile t + 2 gstep into them
+        if (t + 2 * gstep < ntiles) issue(R, t + 2 * gstep);
         float2 v[G::C1];
         if (act2) {
             static_for<G::C1>([&](auto cc) {
@@ -219,6 +231,15 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
             });
         }
         par ^= 1;
+    };
+    int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
+    if (t < ntiles) issue(A, t);
+    if (t + gstep < ntiles) issue(B, t + gstep);
+    bool first = true;
+    for (; t < ntiles; t += 2 * gstep) {
+        body(A, B, t, first);
+        first = false;
+        if (t + gstep < ntiles) body(B, A, t + gstep, false);
     }
 }
 
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
 // LDS row index c2 + c2 / C2B (one pad row per C2B rows) keeps the S2 reads conflict-free.
 // ---------------------------------------------------------------------------------------------
 template <class G, bool INV>
-__global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float2* __restrict__ data, int ntiles) {
+__global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int ntiles) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C2A * (G::C2B + 1) * G::TC;
@@ -244,8 +265,11 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     for (int i = tid; i < (G::CTREE ? RB : RA * RB); i += G::THRC) twl[i] = F.twC[(G::CTREE ? RB : 0) + i];
     __syncthreads();
     constexpr int NPF = INV ? RB : RA;
-    float2 pf[NPF];
-    auto issue = [&](int t) {
+    // Two register sets: the loads of tile i+1 are issued at the TOP of iteration i (before the
+    // butterflies of tile i), so the memory pipe never idles while a tile is in its compute
+    // phases; the loop is unrolled by two so that the sets swap roles without copies.
+    float2 pfA[NPF], pfB[NPF];
+    auto issue = [&](float2 (&pf)[NPF], int t) {
         const int q = t / NBX, p0 = (t % NBX) * TC;
         const float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
         if constexpr (!INV) {
@@ -262,11 +286,21 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     };
     const bool act_first = INV ? actB : actA;
     const bool act_second = INV ? actA : actB;
-    int t = blockIdx.x;
-    if (t < ntiles && act_first) issue(t);
-    for (; t < ntiles; t += gridDim.x) {
+    const int gstep = gridDim.x;
+    auto body = [&](float2 (&pf)[NPF], float2 (&pn)[NPF], int t) {
         const int q = t / NBX, p0 = (t % NBX) * TC;
         float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
+        if (t + gstep < ntiles && act_first) issue(pn, t + gstep);
+        if (D4W_ABL == 4) {          // timing ablation: stream the tile through registers only
+            if (act_first) {
+                static_for<NPF>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    if constexpr (!INV) base[(size_t)(hi + a * RB) * G::M] = pf[a];
+                    else base[(size_t)(hi * RB + a) * G::M] = pf[a];
+                });
+            }
+            return;
+        }
         if (act_first) {
             if constexpr (!INV) {
                 dft<RA>(pf);
@@ -287,8 +321,6 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
             }
         }
         lds_barrier();
-        const int nt = t + gridDim.x;
-        if (nt < ntiles && act_first) issue(nt);
         constexpr int NV = INV ? RA : RB;
         float2 v[NV];
         if (act_second) {
@@ -326,6 +358,12 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 });
             }
         }
+    };
+    int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
+    if (t < ntiles && act_first) issue(pfA, t);
+    for (; t < ntiles; t += 2 * gstep) {
+        body(pfA, pfB, t);
+        if (t + gstep < ntiles) body(pfB, pfA, t + gstep);
     }
 }
 
@@ -341,7 +379,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
 // LDS position e lives at e + e / NC (one pad per group: the MID reads are conflict-free).
 // ---------------------------------------------------------------------------------------------
 template <class G>
-__global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float2* __restrict__ data, int npairs) {
+__global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int npairs) {
     D4W_DYN_LDS(smem_raw);
     constexpr int N2 = G::N2, NA = G::NA, NB = G::NB, NC = G::NC, M1 = NB * NC, NG = NA * NB, ROWP = G::ROWP;
     constexpr int THR = G::THRB;
@@ -371,7 +409,7 @@ __global__ __launch_bounds__(G::THRB) void fkf_passB(FkDev P, FkFastDev F, float
     };
     // the work list is read two tiles ahead (wave-uniform scalar loads whose latency would
     // otherwise sit in front of every prefetch)
-    int t = blockIdx.x;
+    int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
     const int gstep = gridDim.x;
     int2 pr_cur = make_int2(0, 0), pr_nxt = make_int2(0, 0);
     if (t < npairs) pr_cur = P.pairs[t];

@@ -489,12 +489,12 @@ struct FkFastEntry {
     int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
     size_t ldsA, ldsC, ldsB;
     int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
-    void (*A_fwd)(FkDev, const float2*, float2*, int);
-    void (*A_fwd_taper)(FkDev, const float2*, float2*, int);
-    void (*A_inv)(FkDev, float2*, int);
-    void (*C_fwd)(FkDev, FkFastDev, float2*, int);
-    void (*C_inv)(FkDev, FkFastDev, float2*, int);
-    void (*B_mid)(FkDev, FkFastDev, float2*, int);
+    void (*A_fwd)(FkDev, const float2*, float2*, int, int);
+    void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int);
+    void (*A_inv)(FkDev, float2*, int, int);
+    void (*C_fwd)(FkDev, FkFastDev, float2*, int, int);
+    void (*C_inv)(FkDev, FkFastDev, float2*, int, int);
+    void (*B_mid)(FkDev, FkFastDev, float2*, int, int);
 };
 
 template <class G>
@@ -874,15 +874,15 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         int rc;
 #define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
         D4W_MARK(0);
-        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, fA))) return rc;
+        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA))) return rc;
         D4W_MARK(1);
-        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, fC))) return rc;
+        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
         D4W_MARK(2);
-        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, ntB))) return rc;
+        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, ntB))) return rc;
         D4W_MARK(3);
-        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, fC))) return rc;
+        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
         D4W_MARK(4);
-        if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, fA))) return rc;
+        if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA))) return rc;
         D4W_MARK(5);
 #undef D4W_MARK
         return D4W_OK;
@@ -929,6 +929,25 @@ int d4w_fk_apply_timed_f32(d4w_fk_plan* pl, const float* x, float* y, int taper,
     }
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+/* measurement aid (not in d4w.h): run ONE pass of a shape-specialised plan over the tile range
+ * [t_begin, t_end) in place on `data`.  pass: 0 A, 1 C, 2 B, 3 C', 4 A'. */
+int d4w_fk_debug_run_pass(d4w_fk_plan* pl, float* data, int pass, int t_begin, int t_end, void* stream) {
+    if (!pl || !data || !pl->fast) return fail(D4W_EINVAL, "needs a shape-specialised plan");
+    const FkFastEntry& F = *pl->fast;
+    const FkDev& P = pl->dev;
+    float2* d2 = reinterpret_cast<float2*>(data);
+    const int n = t_end - t_begin;
+    if (n <= 0) return D4W_OK;
+    switch (pass) {
+        case 0: return launch_k(F.A_fwd, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, (const float2*)d2, d2, t_begin, t_end);
+        case 1: return launch_k(F.C_fwd, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end);
+        case 2: return launch_k(F.B_mid, dim3(std::min(n, pl->num_cu * pl->wgB)), dim3(F.thrB), F.ldsB, stream, P, pl->fdev, d2, t_begin, t_end);
+        case 3: return launch_k(F.C_inv, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end);
+        case 4: return launch_k(F.A_inv, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, d2, t_begin, t_end);
+    }
+    return fail(D4W_EINVAL, "pass %d", pass);
 }
 
 int d4w_taper_f32(float* x, int nx, int ns, void* stream) {
