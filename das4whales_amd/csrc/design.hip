@@ -1,0 +1,269 @@
+// f-k mask design on the device (one-off per shape): closed-form, loop-free restatements of
+// dsp.fk_filter_design / hybrid_filter_design / hybrid_ninf_filter_design (reference dsp.py:85-454,
+// SURVEY.md A.8), the box indicators of the *_gs designs and of dsp.fk_filt (dsp.py:457-702,
+// 883-953), the separable sigma-20 Gaussian (scipy.ndimage.gaussian_filter, reflect boundary) and
+// the min/max used by fk_filt's normalisation.  Axis values and tapers are evaluated in float64
+// exactly as NumPy forms them (integer index x 1/(n d)); masks are stored as float32 on the
+// fftshift-ed (k, f) grid, row-major [nx][ns] -- the layout d4w_fk_set_mask_dense_f32 takes.
+#include <algorithm>
+
+#include "d4w_internal.h"
+
+namespace d4w {
+
+struct DesignArgs {
+    int nx, ns;
+    double kval, fval;            // 1/(nx*dk_spacing), 1/(ns*dt): axis value = (idx - n/2) * val
+    double p[8];                  // speeds / band edges, meaning depends on the design
+    int i0, i1;                   // half-open column range the reference's loops run over
+    const double* hrow;           // [ns] band-pass row H(f) (hybrid_ninf: host-computed |H|^2)
+};
+
+__device__ __forceinline__ double axis_val(int idx, int n, double val) { return (double)(idx - n / 2) * val; }
+
+constexpr double kHalfPi = 1.57079632679489661923;
+
+// ---- classic speed fan, dsp.py:140-161 ---------------------------------------------------------
+__device__ __forceinline__ double d_classic(const DesignArgs& A, int i, int j) {
+    const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
+    const double cs_min = A.p[0], cp_min = A.p[1], cp_max = A.p[2], cs_max = A.p[3];
+    const double s = fabs(f / k);
+    double m = 1.0;
+    if (s >= cs_min && s <= cp_min) m = sin(kHalfPi * (s - cs_min) / (cp_min - cs_min));
+    if (s >= cp_max && s <= cs_max) m = 1.0 - sin(kHalfPi * (s - cp_max) / (cs_max - cp_max));
+    if (s >= cs_max) m = 0.0;
+    if (s < cs_min) m = 0.0;
+    if (fabs(k) < 0.005) m = 0.0;
+    return m;
+}
+
+// ---- hybrid: sine-tapered band x speed high-pass, before the flip (dsp.py:214-261) --------------
+__device__ __forceinline__ double d_hybrid_core(const DesignArgs& A, int i, int j) {
+    const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
+    const double cs_min = A.p[0], cp_min = A.p[1], fmin = A.p[2], fmax = A.p[3];
+    const double fp_lo = fmin - 4.0, fp_hi = fmax + 4.0;
+    double H = 0.0;
+    if (f >= fp_lo && f <= fmin) H = sin(kHalfPi * (f - fp_lo) / (fmin - fp_lo));
+    if (f >= fmin && f <= fmax) H = 1.0;
+    if (f >= fmax && f <= fp_hi) H = cos(kHalfPi * (f - fmax) / (fmax - fp_hi));
+    if (j < A.i0 || j >= A.i1) return H;
+    const double ks = f / cs_min, kp = f / cp_min;
+    double col = 0.0;
+    if (ks != kp && k >= -ks && k <= -kp) col = -sin(kHalfPi * (k + ks) / (kp - ks));
+    if (ks != kp && -k >= -ks && -k <= -kp) col = sin(kHalfPi * (k - ks) / (kp - ks));
+    if (k < kp && k > -kp) col = 1.0;
+    return H * col;
+}
+
+// ---- hybrid_ninf: Butterworth |H|^2 row x speed band-pass, before the flips (dsp.py:348-402) ----
+__device__ __forceinline__ double d_ninf_core(const DesignArgs& A, int i, int j) {
+    const double H = A.hrow[j];
+    if (j < A.i0 || j >= A.i1) return H;
+    const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
+    const double cs_min = A.p[0], cp_min = A.p[1], cp_max = A.p[2], cs_max = A.p[3];
+    const double ks_min = f / cs_max, kp_min = f / cp_max, ks_max = f / cs_min, kp_max = f / cp_min;
+    double col = 0.0;
+    if (ks_min != kp_min && k >= ks_min && k <= kp_min) col = sin(kHalfPi * (k - ks_min) / (kp_min - ks_min));
+    if (ks_max != kp_max && k >= kp_max && k <= ks_max) col = -sin(kHalfPi * (k - ks_max) / (ks_max - kp_max));
+    if (k > kp_min && k < kp_max) col = 1.0;
+    return H * col;
+}
+
+// ---- box cores of the Gaussian designs ------------------------------------------------------------
+__device__ __forceinline__ double d_gs_core(const DesignArgs& A, int i, int j) {       // dsp.py:508-536
+    const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
+    const double cp_min = A.p[1], fmin = A.p[2], fmax = A.p[3];
+    const double H = (f >= fmin && f <= fmax) ? 1.0 : 0.0;
+    if (j < A.i0 || j >= A.i1) return H;
+    const double kp = f / cp_min;
+    return (k < kp && k > -kp) ? H : 0.0;
+}
+__device__ __forceinline__ double d_ninf_gs_core(const DesignArgs& A, int i, int j) {  // dsp.py:633-653
+    const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
+    const double cp_min = A.p[1], cp_max = A.p[2], fmin = A.p[4], fmax = A.p[5];
+    const double H = (f >= fmin && f <= fmax) ? 1.0 : 0.0;
+    if (j < A.i0 || j >= A.i1) return H;
+    return (k > -f / cp_min && k < -f / cp_max) ? H : 0.0;
+}
+__device__ __forceinline__ double d_wedge(const DesignArgs& A, int i, int j, double c) {  // dsp.py:930-931
+    const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
+    return (f < k * c && f < -k * c) ? 1.0 : 0.0;
+}
+
+// mode: 0 classic | 1 hybrid (C + fliplr C) | 2 hybrid_ninf (C + fliplr, + flipud) |
+//       3 hybrid_gs pre-blur (C + fliplr C) | 4 hybrid_ninf_gs pre-blur (C) | 5 fk_filt wedge pre-blur
+__global__ __launch_bounds__(256) void design_kernel(DesignArgs A, int mode, float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int ri = A.nx - 1 - i;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < A.ns; j += gridDim.x * blockDim.x) {
+        const int rj = A.ns - 1 - j;
+        double m;
+        switch (mode) {
+            case 0: m = d_classic(A, i, j); break;
+            case 1: m = d_hybrid_core(A, i, j) + d_hybrid_core(A, i, rj); break;
+            case 2: m = (d_ninf_core(A, i, j) + d_ninf_core(A, i, rj)) + (d_ninf_core(A, ri, j) + d_ninf_core(A, ri, rj)); break;
+            case 3: m = d_gs_core(A, i, j) + d_gs_core(A, i, rj); break;
+            case 4: m = d_ninf_gs_core(A, i, j); break;
+            default:
+                m = (d_wedge(A, i, j, A.p[0]) + d_wedge(A, i, rj, A.p[0])) -
+                    (d_wedge(A, i, j, A.p[1]) + d_wedge(A, i, rj, A.p[1]));
+        }
+        out[(size_t)i * A.ns + j] = (float)m;
+    }
+}
+
+// out = in + fliplr(in) (+ flipud of that)  -- the post-blur flips of hybrid_ninf_gs, dsp.py:660-661
+__global__ __launch_bounds__(256) void flip_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int nx, int ns) {
+    const int i = blockIdx.y, ri = nx - 1 - i;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += gridDim.x * blockDim.x) {
+        const int rj = ns - 1 - j;
+        out[(size_t)i * ns + j] = (in[(size_t)i * ns + j] + in[(size_t)i * ns + rj]) +
+                                  (in[(size_t)ri * ns + j] + in[(size_t)ri * ns + rj]);
+    }
+}
+
+// scipy.ndimage reflect boundary: (d c b a | a b c d | d c b a)
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return (i < n) ? i : period - 1 - i;
+}
+
+constexpr int kBlurMaxR = 128;
+struct BlurTaps {
+    int radius;
+    float w[2 * kBlurMaxR + 1];
+};
+
+// along the contiguous axis: one workgroup per (row, 1024-column chunk), chunk + halo in LDS
+__global__ __launch_bounds__(256) void blur_rows_kernel(BlurTaps T, const float* __restrict__ in,
+                                                        float* __restrict__ out, int nx, int ns) {
+    __shared__ float buf[1024 + 2 * kBlurMaxR];
+    const int i = blockIdx.y, j0 = blockIdx.x * 1024, R = T.radius;
+    const float* row = in + (size_t)i * ns;
+    for (int t = threadIdx.x; t < 1024 + 2 * R; t += 256) buf[t] = row[reflect_idx(j0 - R + t, ns)];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) {
+        const int j = j0 + t;
+        if (j >= ns) break;
+        float acc = 0.f;
+        for (int q = 0; q <= 2 * R; ++q) acc = fmaf(T.w[q], buf[t + q], acc);
+        out[(size_t)i * ns + j] = acc;
+    }
+}
+
+// along the strided axis: a thread owns one column position and 8 consecutive rows (sliding sum)
+__global__ __launch_bounds__(256) void blur_cols_kernel(BlurTaps T, const float* __restrict__ in,
+                                                        float* __restrict__ out, int nx, int ns) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * 8, R = T.radius;
+    if (j >= ns) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = -R; q <= R + 7; ++q) {
+        const float v = in[(size_t)reflect_idx(i0 + q, nx) * ns + j];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int tap = q - r + R;
+            if (tap >= 0 && tap <= 2 * R) acc[r] = fmaf(T.w[tap], v, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (i0 + r < nx) out[(size_t)(i0 + r) * ns + j] = acc[r];
+}
+
+// per-block min / max partials (finished on the host: a few hundred floats)
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+    __shared__ float smin[4], smax[4];
+    float lo = 3.4e38f, hi = -3.4e38f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x / 64] = lo;
+        smax[threadIdx.x / 64] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        part[2 * blockIdx.x + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ x, size_t n, float a, float b) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = fmaf(x[i], a, b);
+}
+
+}  // namespace d4w
+
+using namespace d4w;
+
+extern "C" {
+
+int d4w_design_mask_f32(int mode, int nx, int ns, double k_spacing, double t_spacing, const double* params8_host,
+                        int i0, int i1, const double* hrow_dev, float* mask, void* stream) {
+    if (!mask || !params8_host || nx < 1 || ns < 1 || mode < 0 || mode > 5) return fail(D4W_EINVAL, "bad argument");
+    if (mode == 2 && !hrow_dev) return fail(D4W_EINVAL, "hybrid_ninf needs the |H|^2 row");
+    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    DesignArgs A;
+    A.nx = nx; A.ns = ns;
+    A.kval = 1.0 / ((double)nx * k_spacing);       // numpy.fft.fftfreq: val = 1.0 / (n * d)
+    A.fval = 1.0 / ((double)ns * t_spacing);
+    for (int i = 0; i < 8; ++i) A.p[i] = params8_host[i];
+    A.i0 = i0; A.i1 = i1; A.hrow = hrow_dev;
+    D4W_LAUNCH(design_kernel, dim3(std::min(ceil_div(ns, 256), 64), nx), dim3(256), 0, stream, A, mode, mask);
+    return D4W_OK;
+}
+
+int d4w_flip_sum_f32(const float* in, float* out, int nx, int ns, void* stream) {
+    if (!in || !out || in == out || nx < 1 || ns < 1 || nx > 65535) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(flip_sum_kernel, dim3(std::min(ceil_div(ns, 256), 64), nx), dim3(256), 0, stream, in, out, nx, ns);
+    return D4W_OK;
+}
+
+int d4w_gaussian_filter_f32(const float* in, float* out, float* tmp, int nx, int ns, double sigma, void* stream) {
+    if (!in || !out || !tmp || nx < 1 || ns < 1 || sigma <= 0) return fail(D4W_EINVAL, "bad argument");
+    const int R = (int)(4.0 * sigma + 0.5);        // scipy: int(truncate * sd + 0.5), truncate = 4
+    if (R > kBlurMaxR) return fail(D4W_EINVAL, "sigma = %g needs radius %d > %d", sigma, R, kBlurMaxR);
+    if (ceil_div(nx, 8) > 65535 || nx > 65535) return fail(D4W_EINVAL, "nx too large");
+    BlurTaps T;
+    T.radius = R;
+    double sum = 0.0;
+    std::vector<double> w(2 * R + 1);
+    for (int i = -R; i <= R; ++i) { w[i + R] = exp(-0.5 * (double)i * i / (sigma * sigma)); sum += w[i + R]; }
+    for (int i = 0; i <= 2 * R; ++i) T.w[i] = (float)(w[i] / sum);
+    // scipy filters axis 0 first, then axis 1
+    D4W_LAUNCH(blur_cols_kernel, dim3(ceil_div(ns, 256), ceil_div(nx, 8)), dim3(256), 0, stream, T, in, tmp, nx, ns);
+    D4W_LAUNCH(blur_rows_kernel, dim3(ceil_div(ns, 1024), nx), dim3(256), 0, stream, T, (const float*)tmp, out, nx, ns);
+    return D4W_OK;
+}
+
+/* (x - min) / (max - min) in place (dsp.fk_filt, dsp.py:945); synchronises the stream */
+int d4w_minmax_normalise_f32(float* x, size_t n, void* stream) {
+    if (!x || n < 1) return fail(D4W_EINVAL, "bad argument");
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    float* part = nullptr;
+    D4W_HIP(hipMalloc((void**)&part, sizeof(float) * 2 * blocks));
+    hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, part);
+    std::vector<float> h(2 * blocks);
+    hipError_t e = hipMemcpyAsync(h.data(), part, sizeof(float) * 2 * blocks, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(part);
+    if (e != hipSuccess) return fail(D4W_EHIP, "min/max reduction failed: %s", hipGetErrorString(e));
+    float lo = h[0], hi = h[1];
+    for (int b = 1; b < blocks; ++b) { lo = std::min(lo, h[2 * b]); hi = std::max(hi, h[2 * b + 1]); }
+    if (!(hi > lo)) return fail(D4W_EINVAL, "mask is constant: cannot normalise");
+    const float a = 1.0f / (hi - lo);
+    D4W_LAUNCH(affine_kernel, dim3(blocks), dim3(256), 0, stream, x, n, a, -lo * a);
+    return D4W_OK;
+}
+
+}  // extern "C"

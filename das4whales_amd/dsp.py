@@ -41,6 +41,8 @@ class FkPlan:
         """Dense ndarray (any order / float dtype), sparse.COO-like (.todense()) or CUDA tensor,
         on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return."""
         m = fk_filter_matrix
+        if isinstance(m, DeviceMask):
+            m = m.tensor
         key = (id(m), getattr(m, "_version", None))
         if self._mask_key == key and self._mask_ref is not None and self._mask_ref() is m:
             return
@@ -246,3 +248,137 @@ def bp_filt(data, fs, fmin, fmax):
 
 
 bp_filter = bp_filt             # north-star spelling
+
+
+# ---------------------------------------------------------------------------------------------
+# f-k mask design (device kernels, one-off per shape)
+# ---------------------------------------------------------------------------------------------
+class DeviceMask:
+    """An f-k mask that stays on the GPU: float32 CUDA tensor [nx, ns] on the fftshift-ed grid.
+
+    Accepted directly by fk_filter_filt / fk_filter_sparsefilt (no host round trip).  It also
+    quacks like what the reference's designers return: `.shape`, `.todense()` (sparse.COO, used by
+    fk_filter_sparsefilt, dsp.py:784), `.data` (non-zero values, used by tools.disp_comprate,
+    tools.py:248), and `np.asarray(mask)` (the dense ndarray fk_filter_design returns)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.shape = tuple(tensor.shape)
+        self.ndim = 2
+        self.dtype = np.dtype(np.float64)
+
+    def todense(self):
+        return self.tensor.cpu().numpy().astype(np.float64)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.todense()
+        return a if dtype is None else a.astype(dtype)
+
+    @property
+    def data(self):
+        d = self.tensor[self.tensor != 0]
+        return d.cpu().numpy().astype(np.float64)
+
+    @property
+    def nnz(self):
+        return int(torch.count_nonzero(self.tensor))
+
+
+def _shifted_axis(n, d):
+    return np.fft.fftshift(np.fft.fftfreq(n, d=d))
+
+
+def _design(mode, trace_shape, selected_channels, dx, fs, params, i0=0, i1=0, hrow=None, device=None):
+    dev.require_gpu()
+    nx, ns = int(trace_shape[0]), int(trace_shape[1])
+    device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+    out = torch.empty((nx, ns), dtype=torch.float32, device=device)
+    p8 = (ctypes.c_double * 8)(*([float(v) for v in params] + [0.0] * (8 - len(params))))
+    h = None
+    if hrow is not None:
+        h = torch.from_numpy(np.ascontiguousarray(hrow, dtype=np.float64)).to(device)
+    with torch.cuda.device(device):
+        check(lib.d4w_design_mask_f32(mode, nx, ns, float(selected_channels[2] * dx), 1.0 / float(fs), p8,
+                                      int(i0), int(i1), dev.ptr(h) if h is not None else None, dev.ptr(out),
+                                      dev.stream_ptr(out)))
+        if h is not None:
+            torch.cuda.current_stream().synchronize()       # h is a temporary
+    return out
+
+
+def _gaussian_filter(t, sigma):
+    out, tmp = torch.empty_like(t), torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        check(lib.d4w_gaussian_filter_f32(dev.ptr(t), dev.ptr(out), dev.ptr(tmp), t.shape[0], t.shape[1],
+                                          float(sigma), dev.stream_ptr(t)))
+    return out
+
+
+def _first_index_ge(f, val):
+    return int(np.argmax(f >= val))
+
+
+def fk_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400, cp_min=1450, cp_max=3400, cs_max=3500):
+    """Classic speed fan with sine tapers -- reference dsp.py:85-171.  Returns a DeviceMask
+    (np.asarray(mask) gives the dense array; the reference returns a Fortran-ordered ndarray)."""
+    return DeviceMask(_design(0, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, cp_max, cs_max]))
+
+
+def hybrid_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., fmin=15., fmax=25.,
+                         display_filter=False):
+    """Band-pass (4 Hz sine tapers) x speed high-pass -- reference dsp.py:174-305 (display_filter is
+    a plotting path of the reference and is ignored)."""
+    f = _shifted_axis(trace_shape[1], 1.0 / fs)
+    i0, i1 = _first_index_ge(f, fmin - 4.0), _first_index_ge(f, fmax + 4.0)     # dsp.py:216-222
+    return DeviceMask(_design(1, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, fmin, fmax], i0, i1))
+
+
+def hybrid_ninf_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., cp_max=3400,
+                              cs_max=3500, fmin=15., fmax=25., display_filter=False):
+    """Butterworth-|H|^2 band-pass x speed band-pass, the design every reference script uses --
+    reference dsp.py:308-454.  The 1-D |H|^2 row is designed on the host (SciPy, float64)."""
+    import scipy.signal as sp
+    ns = int(trace_shape[1])
+    if ns % 2:
+        raise ValueError("hybrid_ninf_filter_design needs an even number of time samples (dsp.py:349,372)")
+    f = _shifted_axis(ns, 1.0 / fs)
+    b, a = sp.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp")               # dsp.py:348
+    H = np.concatenate((np.zeros(ns // 2), np.abs(sp.freqz(b, a, worN=ns // 2)[1]) ** 2))   # dsp.py:349
+    i0, i1 = _first_index_ge(f, fmin - 14.0), _first_index_ge(f, fmax + 14.0)   # dsp.py:354-360
+    return DeviceMask(_design(2, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, cp_max, cs_max], i0, i1, H))
+
+
+def hybrid_gs_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., fmin=15., fmax=25.,
+                            display_filter=False):
+    """Box band x box |k| < f/cp_min, Gaussian-blurred (sigma 20) -- reference dsp.py:457-579."""
+    f = _shifted_axis(trace_shape[1], 1.0 / fs)
+    i0, i1 = _first_index_ge(f, fmin - 4.0), _first_index_ge(f, fmax + 4.0)     # dsp.py:503-505
+    m = _design(3, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, fmin, fmax], i0, i1)
+    return DeviceMask(_gaussian_filter(m, 20))                                  # dsp.py:540
+
+
+def hybrid_ninf_gs_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., cp_max=3400,
+                                 cs_max=3500, fmin=15., fmax=25., display_filter=False):
+    """Box band x box speed band, blur THEN flips -- reference dsp.py:582-702."""
+    f = _shifted_axis(trace_shape[1], 1.0 / fs)
+    i0, i1 = _first_index_ge(f, fmin - 4.0), _first_index_ge(f, fmax + 4.0)     # dsp.py:628-630
+    m = _design(4, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, cp_max, cs_max, fmin, fmax], i0, i1)
+    g = _gaussian_filter(m, 20)                                                 # dsp.py:659
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        check(lib.d4w_flip_sum_f32(dev.ptr(g), dev.ptr(out), g.shape[0], g.shape[1], dev.stream_ptr(g)))   # dsp.py:660-661
+    return DeviceMask(out)
+
+
+def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
+    """Self-designing Gaussian-tapered speed band: design + apply -- reference dsp.py:883-953."""
+    if getattr(data, "ndim", 0) != 2:
+        raise ValueError("data must be a 2-D [channel x time] array")
+    nx, ns = data.shape
+    device = data.device if dev.is_tensor(data) and data.is_cuda else None
+    # axes: fftfreq(ns, tint/fs), fftfreq(nx, xint*dx) (dsp.py:923-924) -> spacing arguments
+    g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=device)    # dsp.py:930-936
+    g = _gaussian_filter(g, 20)                                                 # dsp.py:940
+    with torch.cuda.device(g.device):
+        check(lib.d4w_minmax_normalise_f32(dev.ptr(g), g.numel(), dev.stream_ptr(g)))        # dsp.py:945
+    return _fk_apply(data, DeviceMask(g), False)

@@ -116,6 +116,31 @@ int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs
 int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
                   const float* taps, int ntpl, int ltaps, float* y0, float* y1, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * f-k mask design on the device (one-off per shape), float32 masks on the fftshift-ed (k, f)
+ * grid, row-major [nx][ns] -- what d4w_fk_set_mask_dense_f32 takes.  Closed forms of the
+ * reference's row / column loops; axis values in float64 as NumPy forms them.
+ *   mode 0  dsp.fk_filter_design          dsp.py:85-171    params {cs_min, cp_min, cp_max, cs_max}
+ *   mode 1  dsp.hybrid_filter_design      dsp.py:174-305   params {cs_min, cp_min, fmin, fmax}
+ *   mode 2  dsp.hybrid_ninf_filter_design dsp.py:308-454   params {cs_min, cp_min, cp_max, cs_max};
+ *           hrow_dev = DEVICE float64 [ns] band-pass row (zeros ++ |freqz(butter)|^2, dsp.py:348-349)
+ *   mode 3  hybrid_gs_filter_design      before the blur (dsp.py:508-539)  params {-, cp_min, fmin, fmax}
+ *   mode 4  hybrid_ninf_gs_filter_design before the blur (dsp.py:633-653)  params {-, cp_min, cp_max, -, fmin, fmax}
+ *   mode 5  dsp.fk_filt wedge            before the blur (dsp.py:930-936)  params {c_min, c_max}
+ * k_spacing = selected_channels[2]*dx (dsp.py:130), t_spacing = 1/fs; [i0, i1) = the half-open
+ * column range the reference's loop runs over (np.argmax(f >= ...), host).
+ * d4w_gaussian_filter_f32 = scipy.ndimage.gaussian_filter(., sigma) (truncate 4, reflect), used at
+ * dsp.py:540,659,940; d4w_flip_sum_f32 = M + fliplr(M), then + flipud (dsp.py:660-661);
+ * d4w_minmax_normalise_f32 = (g - min)/(max - min) in place (dsp.py:945), synchronises `stream`.
+ * ------------------------------------------------------------------------------------------ */
+int d4w_design_mask_f32(int mode, int nx, int ns, double k_spacing, double t_spacing,
+                        const double* params8_host, int i0, int i1, const double* hrow_dev,
+                        float* mask, void* stream);
+int d4w_flip_sum_f32(const float* in, float* out, int nx, int ns, void* stream);
+int d4w_gaussian_filter_f32(const float* in, float* out, float* tmp, int nx, int ns, double sigma,
+                            void* stream);
+int d4w_minmax_normalise_f32(float* x, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,61 @@
+"""GPU parity tests of the f-k mask designers (dsp.fk_filter_design, hybrid_*_filter_design) and of
+the self-designing dsp.fk_filt, vs the masks / outputs of the real reference (golden fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ARGS = dict(cs_min=1350., cp_min=1450., cp_max=3300, cs_max=3450, fmin=14., fmax=30.)
+
+
+def rel(y, ref):
+    return float(np.max(np.abs(np.asarray(y, dtype=np.float64) - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available()
+    import das4whales_amd as dw_
+    return dw_
+
+
+def test_designs_golden(dw, golden):
+    g = golden("fk_40x480.npz")
+    shape, sel, dx, fs = g["x"].shape, list(g["sel"]), float(g["dx"]), float(g["fs"])
+    m = dw.dsp.fk_filter_design(shape, sel, dx, fs)
+    assert m.shape == shape and np.max(np.abs(np.asarray(m) - g["m_classic"])) < 5e-7
+    mh = dw.dsp.hybrid_filter_design(shape, sel, dx, fs, cs_min=1350., cp_min=1450., fmin=14., fmax=30.)
+    assert np.max(np.abs(mh.todense() - g["m_hybrid"])) < 5e-7
+    mn = dw.dsp.hybrid_ninf_filter_design(shape, sel, dx, fs, **ARGS)
+    assert np.max(np.abs(mn.todense() - g["m_ninf"])) < 1e-6
+    mg = dw.dsp.hybrid_gs_filter_design(shape, sel, dx, fs, cs_min=1350., cp_min=1450., fmin=14., fmax=30.)
+    assert np.max(np.abs(mg.todense() - g["m_gs"])) < 3e-6
+    mng = dw.dsp.hybrid_ninf_gs_filter_design(shape, sel, dx, fs, **ARGS)
+    assert np.max(np.abs(mng.todense() - g["m_ninf_gs"])) < 3e-6
+    # sparse.COO duck typing used by tools.disp_comprate (tools.py:248) and dsp.py:784
+    assert mn.data.ndim == 1 and len(mn.data) == np.count_nonzero(mn.todense()) == mn.nnz
+    # design -> apply without leaving the device, as the scripts chain them (main_mfdetect.py:46-55)
+    x = g["x"]
+    assert rel(dw.dsp.fk_filter_sparsefilt(x, mn), g["y_ninf"]) < 1e-5
+    assert rel(dw.dsp.fk_filter_filt(x, m), g["y_classic"]) < 1e-5
+    assert rel(dw.dsp.fk_filter_sparsefilt(x, mng), g["y_ninf_gs"]) < 1e-5
+    with pytest.raises(ValueError):
+        dw.dsp.hybrid_ninf_filter_design((40, 481), sel, dx, fs)
+
+
+def test_fk_filt_golden(dw, golden):
+    g = golden("fk_40x480.npz")
+    y = dw.dsp.fk_filt(g["x"], 1, float(g["fs"]), 4, float(g["dx"]), 1400., 3400.)
+    assert rel(y, g["y_fkfilt"]) < 1e-5
+
+
+def test_designs_config1_shape_vs_oracle(dw):
+    shape, sel, dx, fs = (4000, 12000), [9794, 25794, 4], 2.0419046878814697, 200.0
+    m = dw.dsp.hybrid_ninf_filter_design(shape, sel, dx, fs, **ARGS).todense()
+    ref = orc.hybrid_ninf_filter_design(shape, sel, dx, fs, **ARGS)
+    assert np.max(np.abs(m - ref)) < 1e-6
+    del m, ref
+    mc = dw.dsp.fk_filter_design(shape, sel, dx, fs).todense()
+    assert np.max(np.abs(mc - orc.fk_filter_design(shape, sel, dx, fs))) < 1e-6

@@ -1,0 +1,79 @@
+"""Mask-design kernels (design.hip) on the CPU emulator build vs the golden masks produced by the
+real reference and vs the oracle's closed forms."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.signal as sps
+
+from oracle import d4w_oracle as orc
+from tests.emu_util import load_emu, vp
+
+ARGS = dict(cs_min=1350., cp_min=1450., cp_max=3300., cs_max=3450., fmin=14., fmax=30.)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = load_emu()
+    lib.d4w_design_mask_f32.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+    lib.d4w_gaussian_filter_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    lib.d4w_minmax_normalise_f32.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    return lib
+
+
+def design(lib, mode, shape, step_dx, fs, params, i0=0, i1=0, hrow=None):
+    nx, ns = shape
+    out = np.empty((nx, ns), dtype=np.float32)
+    p8 = np.zeros(8)
+    p8[:len(params)] = params
+    h = np.ascontiguousarray(hrow, dtype=np.float64) if hrow is not None else None
+    rc = lib.d4w_design_mask_f32(mode, nx, ns, step_dx, 1.0 / fs, vp(p8), i0, i1, vp(h) if h is not None else None,
+                                 vp(out), None)
+    assert rc == 0, lib.d4w_last_error()
+    return out
+
+
+def gauss(lib, m, sigma=20.0):
+    out, tmp = np.empty_like(m), np.empty_like(m)
+    assert lib.d4w_gaussian_filter_f32(vp(m), vp(out), vp(tmp), m.shape[0], m.shape[1], sigma, None) == 0
+    return out
+
+
+def first_ge(f, v):
+    return int(np.argmax(f >= v))
+
+
+def test_designs_vs_reference_golden(emu, golden):
+    g = golden("fk_40x480.npz")
+    shape, sel, dx, fs = g["x"].shape, list(g["sel"]), float(g["dx"]), float(g["fs"])
+    step = sel[2] * dx
+    f = np.fft.fftshift(np.fft.fftfreq(shape[1], d=1 / fs))
+    A = ARGS
+    m0 = design(emu, 0, shape, step, fs, [1400, 1450, 3400, 3500])
+    assert np.max(np.abs(m0 - g["m_classic"])) < 2e-7
+    m1 = design(emu, 1, shape, step, fs, [A["cs_min"], A["cp_min"], A["fmin"], A["fmax"]],
+                first_ge(f, A["fmin"] - 4), first_ge(f, A["fmax"] + 4))
+    assert np.max(np.abs(m1 - g["m_hybrid"])) < 2e-7
+    b, a = sps.butter(8, [A["fmin"] / (fs / 2), A["fmax"] / (fs / 2)], "bp")
+    H = np.concatenate((np.zeros(shape[1] // 2), np.abs(sps.freqz(b, a, worN=shape[1] // 2)[1]) ** 2))
+    m2 = design(emu, 2, shape, step, fs, [A["cs_min"], A["cp_min"], A["cp_max"], A["cs_max"]],
+                first_ge(f, A["fmin"] - 14), first_ge(f, A["fmax"] + 14), H)
+    assert np.max(np.abs(m2 - g["m_ninf"])) < 5e-7
+    m3 = gauss(emu, design(emu, 3, shape, step, fs, [A["cs_min"], A["cp_min"], A["fmin"], A["fmax"]],
+                           first_ge(f, A["fmin"] - 4), first_ge(f, A["fmax"] + 4)))
+    assert np.max(np.abs(m3 - g["m_gs"])) < 2e-6
+
+
+def test_gaussian_and_normalise(emu):
+    rng = np.random.default_rng(1)
+    from scipy import ndimage
+    for shape in [(37, 201), (100, 64), (9, 1100)]:          # smaller than the radius: multiple reflections
+        m = rng.random(shape).astype(np.float32)
+        assert np.max(np.abs(gauss(emu, m, 20.0) - ndimage.gaussian_filter(m.astype(np.float64), 20))) < 2e-6
+        assert np.max(np.abs(gauss(emu, m, 3.0) - ndimage.gaussian_filter(m.astype(np.float64), 3))) < 2e-6
+    x = (rng.random((13, 77)) * 5 - 2).astype(np.float32)
+    ref = (x - x.min()) / (x.max() - x.min())
+    assert emu.d4w_minmax_normalise_f32(vp(x), x.size, None) == 0
+    assert np.max(np.abs(x - ref)) < 1e-6
