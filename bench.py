@@ -34,29 +34,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PASS_NAMES = ["fk_passA_fwd", "fk_passC_fwd", "fk_passB_mid", "fk_passC_inv", "fk_passA_inv"]
 
 
-def classic_mask_shifted(nx, ns, step_dx, fs, device, cs_min=1400., cp_min=1450., cp_max=3400., cs_max=3500.):
-    """dsp.fk_filter_design's speed fan (reference dsp.py:140-161) evaluated with torch ops, row
-    blocks at a time -- bench set-up only (not timed, not the product's design path)."""
-    f = torch.fft.fftshift(torch.fft.fftfreq(ns, d=1.0 / fs, dtype=torch.float64, device=device))
-    k = torch.fft.fftshift(torch.fft.fftfreq(nx, d=step_dx, dtype=torch.float64, device=device))
-    out = torch.empty((nx, ns), dtype=torch.float32, device=device)
-    rb = max(1, (1 << 26) // ns)
-    for r0 in range(0, nx, rb):
-        kk = k[r0:r0 + rb, None]
-        s = (f[None, :] / kk).abs()
-        m = torch.ones_like(s)
-        up = (s >= cs_min) & (s <= cp_min)
-        m = torch.where(up, torch.sin(0.5 * np.pi * (s - cs_min) / (cp_min - cs_min)), m)
-        dn = (s >= cp_max) & (s <= cs_max)
-        m = torch.where(dn, 1.0 - torch.sin(0.5 * np.pi * (s - cp_max) / (cs_max - cp_max)), m)
-        m = torch.where(s >= cs_max, torch.zeros_like(m), m)
-        m = torch.where(s < cs_min, torch.zeros_like(m), m)
-        m = torch.where(kk.abs() < 0.005, torch.zeros_like(m), m)
-        m = torch.nan_to_num(m, nan=0.0)
-        out[r0:r0 + rb] = m.to(torch.float32)
-    return out
-
-
 def cpu_baseline(sample_nx, sample_ns, stages):
     """NumPy float64 restatement of the reference path (oracle) on a bounded sample: each stage is
     timed on its own sample and the per-sample times are added (same composition as a GPU step)."""
@@ -105,6 +82,7 @@ def main():
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="8000x24000")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask f-k timing")
     ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
     args = ap.parse_args()
     stages = [t for t in args.stages.split(",") if t]
@@ -132,8 +110,11 @@ def main():
     y = torch.empty_like(x)
     opts = [int(v) for v in args.plan.split(",")] if args.plan else None
     plan = dw.dsp.FkPlan(nx, ns, opts=opts, device=device)
-    mask = classic_mask_shifted(nx, ns, dx, fs, device)
+    # the mask of BASELINE's configs: dsp.fk_filter_design defaults (speed fan 1400/1450/3400/3500
+    # m/s), designed on the device by the product's own design kernel
+    mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)
     plan.set_mask(mask)
+    live_rows = plan.live_rows()
     del mask
     torch.cuda.empty_cache()
 
@@ -229,7 +210,22 @@ def main():
     if "fk" in stages:
         fk_gbs = 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9
         roofline.update({"fk_algorithmic_GBps": fk_gbs, "fk_algorithmic_frac": fk_gbs / HBM_PEAK_GBS,
-                         "fk_only_samples_per_s": samples / (float(acc.sum()) * 1e-3)})
+                         "fk_only_samples_per_s": samples / (float(acc.sum()) * 1e-3),
+                         "fk_live_wavenumber_rows": live_rows})
+        if live_rows < nx and not args.no_dense:
+            # the same filter with a fully dense mask (nothing skipped), for reference
+            dm = torch.rand((nx, ns), dtype=torch.float32, device=device, generator=gen)
+            plan.set_mask(dm)
+            del dm
+            accd = np.zeros(5)
+            plan.apply(x, out=y)
+            for _ in range(max(2, args.steps // 2)):
+                _, ms = plan.apply_timed(x, out=y)
+                accd += np.array(ms)
+            accd /= max(2, args.steps // 2)
+            roofline["fk_dense_mask"] = {"fk_filter_ms": float(accd.sum()),
+                                         "kernel_ms": {PASS_NAMES[i]: float(accd[i]) for i in range(5)},
+                                         "fk_algorithmic_frac": 24.0 * samples / (float(accd.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         out = {"metric": "channel-samples/sec through " + " + ".join(

@@ -37,7 +37,9 @@ struct FkFastCfg {
     // pass A: tile [C1][N1][TA] + double-buffered four-step twiddle strip [2][N1][TA]
     static constexpr size_t ldsA = (size_t)(C1 * N1 * TA + 2 * N1 * TA) * sizeof(float2);
     // pass C: tile [(C2A)(C2B + 1)][TC] (one pad row per C2B rows) + twiddles [C2A][C2B]
-    static constexpr size_t ldsC = (size_t)(C2A * (C2B + 1) * TC + (CTREE_ ? C2B : C2A * C2B)) * sizeof(float2);
+    static constexpr size_t ldsC = (size_t)(C2A * (C2B + 1) * TC + (CTREE_ ? C2B : C2A * C2B)) * sizeof(float2) +
+                                   (size_t)C1 * C2A * sizeof(unsigned);
+    static_assert(C2B_ <= 32, "pass C keeps one live bit per radix-C2B output in a 32-bit word");
     // pass B: two rows of N2 (+ one pad element per NC) + tw1 [NB*NC] + tw2 [NB][NC]
     static constexpr int ROWP = N2 + NA * NB;
     static constexpr size_t ldsB = (size_t)(2 * ROWP + 2 * NB * NC) * sizeof(float2);
@@ -52,6 +54,11 @@ struct FkFastDev {
     const float2* twC;    // [C2A][C2B]  W_C2^(j a)
     const float2* twB1;   // [NB*NC]     W_N2^j
     const float2* twB2;   // [NB][NC]    W_(NB*NC)^(j2 b)
+    // Dead-row pruning (exact): a wavenumber row whose folded mask is all zero, together with
+    // its Hermitian partner row, comes out of pass B as zeros whatever it held, so pass C does
+    // not write it, pass B skips its pairs and pass C' reads zeros instead of memory.
+    const unsigned* live; // [C1][C2A] bit b = row position q*C2 + g*C2B + b is live; NULL = all live
+    const int2* pairs;    // pass-B work list actually run (all pairs, or the live ones)
 };
 
 template <int R>
@@ -263,6 +270,9 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     const bool actB = hi < RA;                         // items of the radix-RB step
     // table layout [a][j]; row a = 1 is W_C2^j, all the tree variant needs
     for (int i = tid; i < (G::CTREE ? RB : RA * RB); i += G::THRC) twl[i] = F.twC[(G::CTREE ? RB : 0) + i];
+    // live-row bits of every (q, g) in LDS: no vector-memory load on the tile loop's critical path
+    unsigned* livel = reinterpret_cast<unsigned*>(twl + (G::CTREE ? RB : RA * RB));
+    for (int i = tid; i < G::C1 * RA; i += G::THRC) livel[i] = F.live ? F.live[i] : 0xFFFFFFFFu;
     __syncthreads();
     constexpr int NPF = INV ? RB : RA;
     // Two register sets: the loads of tile i+1 are issued at the TOP of iteration i (before the
@@ -278,9 +288,10 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 pf[a] = base[(size_t)(hi + a * RB) * G::M];
             });
         } else {
+            const unsigned bits = livel[q * RA + hi];       // dead rows are zeros by construction
             static_for<RB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                pf[b] = base[(size_t)(hi * RB + b) * G::M];
+                pf[b] = ((bits >> b) & 1u) ? base[(size_t)(hi * RB + b) * G::M] : make_float2(0.f, 0.f);
             });
         }
     };
@@ -340,9 +351,10 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
         if (act_second) {
             if constexpr (!INV) {
                 dft<RB>(v);
+                const unsigned bits = livel[q * RA + hi];   // dead rows are never read again
                 static_for<RB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    base[(size_t)(hi * RB + b) * G::M] = v[b];
+                    if ((bits >> b) & 1u) base[(size_t)(hi * RB + b) * G::M] = v[b];
                 });
             } else {
                 float2 pw[RA];
@@ -412,13 +424,13 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
     int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
     const int gstep = gridDim.x;
     int2 pr_cur = make_int2(0, 0), pr_nxt = make_int2(0, 0);
-    if (t < npairs) pr_cur = P.pairs[t];
-    if (t + gstep < npairs) pr_nxt = P.pairs[t + gstep];
+    if (t < npairs) pr_cur = F.pairs[t];
+    if (t + gstep < npairs) pr_nxt = F.pairs[t + gstep];
     if (t < npairs) issue(pr_cur);
     for (; t < npairs; t += gstep) {
         const int2 pr = pr_cur;
         int2 pr_nn = pr_cur;
-        if (t + 2 * gstep < npairs) pr_nn = P.pairs[t + 2 * gstep];
+        if (t + 2 * gstep < npairs) pr_nn = F.pairs[t + 2 * gstep];
         const bool same = (pr.x == pr.y);
         const int nrows = same ? 1 : 2;
         const int rpos = pr.x / G::N1, q1 = pr.x - rpos * G::N1;

@@ -375,6 +375,16 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* 
     }
 }
 
+// live[r] = 1 when the folded mask of row position r has any non-zero entry (incl. the Nyquist column)
+__global__ __launch_bounds__(kThreads) void fk_row_live(FkDims d, const float* __restrict__ mask,
+                                                         const float* __restrict__ nyq, int* __restrict__ live) {
+    const int r = blockIdx.x;
+    const float* row = mask + (size_t)r * d.M;
+    bool any = (threadIdx.x == 0) && (nyq[r] != 0.f);
+    for (int p = threadIdx.x; p < d.M; p += blockDim.x) any |= (row[p] != 0.f);
+    if (any) live[r] = 1;       // same value from every writer
+}
+
 __global__ __launch_bounds__(kThreads) void taper_rows(float* __restrict__ x, const float* __restrict__ win,
                                                         size_t total, int ns) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -554,6 +564,13 @@ struct d4w_fk_plan {
     int wg_per_cu = 2;
     const FkFastEntry* fast = nullptr;     // shape-specialised kernels, or nullptr = generic passes
     FkFastDev fdev;
+    // dead-row pruning of the specialised path (set per mask)
+    std::vector<int2> h_pairs;             // full pass-B work list (host copy)
+    int* d_live = nullptr;                 // [nx] scratch of fk_row_live
+    unsigned* d_livebits = nullptr;        // [C1][C2A]
+    int2* d_pairs_live = nullptr;          // [npairs] compacted list
+    int npairs_run = 0;                    // pairs the specialised pass B runs
+    int live_rows = 0;
     int wgA = 1, wgC = 1, wgB = 1;
 };
 
@@ -731,6 +748,20 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
             }
         pl->npairs = (int)pairs.size();
         D4W_TRY(upload(pl, pairs, &pl->dev.pairs));
+        pl->h_pairs = pairs;
+        pl->npairs_run = pl->npairs;
+        pl->live_rows = nx;
+        pl->fdev.pairs = pl->dev.pairs;
+        pl->fdev.live = nullptr;
+        if (fast) {
+            void* q = nullptr;
+            if (hipMalloc(&q, (size_t)nx * sizeof(int)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+            pl->allocs.push_back(q); pl->d_live = (int*)q;
+            if (hipMalloc(&q, (size_t)C1 * fast->C2A * sizeof(unsigned)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+            pl->allocs.push_back(q); pl->d_livebits = (unsigned*)q;
+            if (hipMalloc(&q, pairs.size() * sizeof(int2)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+            pl->allocs.push_back(q); pl->d_pairs_live = (int2*)q;
+        }
     }
     D4W_TRY(upload(pl, rowpart, &pl->dev.row_partner));
     D4W_TRY(upload(pl, q1part, &pl->dev.q1_partner));
@@ -849,8 +880,55 @@ int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* 
     D4W_LAUNCH(fk_fold_mask, grid, dim3(kThreads), 0, stream, d, mask_shifted, (const int*)pl->d_rowk,
                (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq);
     pl->has_mask = true;
+    pl->npairs_run = pl->npairs;
+    pl->live_rows = d.nx;
+    pl->fdev.pairs = pl->dev.pairs;
+    pl->fdev.live = nullptr;
+    const char* np = getenv("D4W_FK_NOPRUNE");
+    if (pl->fast && !(np && atoi(np) > 0)) {
+        // rows whose folded mask (and whose Hermitian partner's) is identically zero
+        hipStream_t st = (hipStream_t)stream;
+        D4W_HIP(hipMemsetAsync(pl->d_live, 0, (size_t)d.nx * sizeof(int), st));
+        D4W_LAUNCH(fk_row_live, dim3(d.nx), dim3(kThreads), 0, stream, d, (const float*)pl->d_mask,
+                   (const float*)pl->d_nyq, pl->d_live);
+        std::vector<int> live(d.nx);
+        D4W_HIP(hipMemcpyAsync(live.data(), pl->d_live, (size_t)d.nx * sizeof(int), hipMemcpyDeviceToHost, st));
+        D4W_HIP(hipStreamSynchronize(st));
+        const int N1 = d.N1;
+        std::vector<char> lv(d.nx, 0);
+        std::vector<int2> run;
+        run.reserve(pl->h_pairs.size());
+        for (const int2& pr : pl->h_pairs) {
+            const int ra = pr.x / N1, rb = pr.y / N1;
+            if (live[ra] || live[rb]) {
+                lv[ra] = lv[rb] = 1;
+                run.push_back(pr);
+            }
+        }
+        int nlive = 0;
+        for (int r = 0; r < d.nx; ++r) nlive += lv[r];
+        if (nlive < d.nx) {
+            const int RA = pl->fast->C2A, RB = pl->fast->C2B;
+            std::vector<unsigned> bits((size_t)d.C1 * RA, 0u);
+            for (int r = 0; r < d.nx; ++r)
+                if (lv[r]) {
+                    const int q = r / d.C2, p2 = r % d.C2;
+                    bits[(size_t)q * RA + p2 / RB] |= 1u << (p2 % RB);
+                }
+            D4W_HIP(hipMemcpyAsync(pl->d_livebits, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+            if (!run.empty())
+                D4W_HIP(hipMemcpyAsync(pl->d_pairs_live, run.data(), run.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+            D4W_HIP(hipStreamSynchronize(st));      // bits / run are host temporaries
+            pl->fdev.live = pl->d_livebits;
+            pl->fdev.pairs = pl->d_pairs_live;
+            pl->npairs_run = (int)run.size();
+            pl->live_rows = nlive;
+        }
+    }
     return D4W_OK;
 }
+
+int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
 
 static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev) {
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
@@ -870,7 +948,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         const FkFastEntry& F = *pl->fast;
         const int fA = (d.N2 / d.TA) * d.C2, fC = (d.M / d.TC) * d.C1;
         const dim3 gA(std::min(fA, pl->num_cu * pl->wgA)), gC(std::min(fC, pl->num_cu * pl->wgC)),
-            gB(std::min(ntB, pl->num_cu * pl->wgB));
+            gB(std::max(1, std::min(pl->npairs_run, pl->num_cu * pl->wgB)));
         int rc;
 #define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
         D4W_MARK(0);
@@ -878,7 +956,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         D4W_MARK(1);
         if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
         D4W_MARK(2);
-        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, ntB))) return rc;
+        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run))) return rc;
         D4W_MARK(3);
         if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
         D4W_MARK(4);
@@ -938,6 +1016,7 @@ int d4w_fk_debug_run_pass(d4w_fk_plan* pl, float* data, int pass, int t_begin, i
     const FkFastEntry& F = *pl->fast;
     const FkDev& P = pl->dev;
     float2* d2 = reinterpret_cast<float2*>(data);
+    if (pass == 2) t_end = std::min(t_end, pl->npairs_run);
     const int n = t_end - t_begin;
     if (n <= 0) return D4W_OK;
     switch (pass) {

@@ -37,6 +37,10 @@ class FkPlan:
         check(lib.d4w_fk_plan_info(self._h, v))
         return dict(zip(("nx", "ns", "C1", "C2", "N1", "N2", "TA", "TC"), list(v)))
 
+    def live_rows(self):
+        """Wavenumber rows the current mask keeps alive (nx = nothing is skipped), include/d4w.h."""
+        return int(lib.d4w_fk_plan_live_rows(self._h))
+
     def set_mask(self, fk_filter_matrix):
         """Dense ndarray (any order / float dtype), sparse.COO-like (.todense()) or CUDA tensor,
         on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return."""

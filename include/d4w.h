@@ -55,8 +55,16 @@ int d4w_fk_plan_info(const d4w_fk_plan* plan, int* info8_host);
 
 /* Mask as the reference hands it over: dense [nx][ns] float32 on the fftshift-ed (k, f) grid
  * (dsp.py:129-130,137).  Folds it to its Hermitian part M_h = (M(k,f)+M(-k,-f))/2 -- which is
- * what `.real` at dsp.py:756,786 keeps -- and stores it in the plan's internal order. */
+ * what `.real` at dsp.py:756,786 keeps -- and stores it in the plan's internal order.
+ * Synchronises `stream` (the row-liveness scan of the folded mask is read back by the host). */
 int d4w_fk_set_mask_dense_f32(d4w_fk_plan* plan, const float* mask_shifted, void* stream);
+
+/* Number of wavenumber rows (0..nx) the current mask keeps alive.  A row whose folded mask -- and
+ * whose Hermitian partner's -- is identically zero is multiplied by zero whatever it holds; the
+ * shape-specialised kernels skip such rows in the three middle passes (exact, the analogue of the
+ * reference's sparse.COO product at dsp.py:782).  nx = nothing is skipped (dense mask, or a shape
+ * that runs the generic kernels).  D4W_FK_NOPRUNE=1 in the environment disables the skipping. */
+int d4w_fk_plan_live_rows(const d4w_fk_plan* plan);
 
 /* x -> y (may alias).  taper != 0 multiplies x by tukey(ns, 0.03) first (dsp.taper_data,
  * dsp.py:705-722, fused into the first pass; x itself is not modified). */

@@ -83,3 +83,40 @@ def test_shape_specialised_kernels(emu, nx, ns):
     emu.d4w_fk_plan_info(plan, info)
     emu.d4w_fk_plan_destroy(plan)
     assert list(info)[:2] == [nx, ns]
+
+
+@pytest.mark.parametrize("nx,ns", [(18, 48), (100, 600)])
+def test_dead_row_pruning(emu, nx, ns):
+    """Masks with all-zero wavenumber rows: the specialised path skips those rows in passes C, B
+    and C' (exact: they would be multiplied by zero).  Same result as the unpruned run."""
+    rng = np.random.default_rng(5 * nx + ns)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    ks = np.fft.fftshift(np.arange(nx))               # shifted-grid row -> wavenumber index
+    kabs = np.minimum(ks, nx - ks)
+    m[kabs > nx // 5, :] = 0.0                        # keep low |k| only (what a speed fan does)
+    m[nx // 2 + 2, ns // 3] = 0.7                     # one-sided live entry: its partner row must stay live too
+    ref = orc.fk_filter_filt(x, m)
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+    mf = np.ascontiguousarray(m, dtype=np.float32)
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(xf)
+    assert emu.d4w_fk_set_mask_dense_f32(plan, vp(mf), None) == 0
+    live = emu.d4w_fk_plan_live_rows(plan)
+    assert 0 < live < nx
+    assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) == 0
+    assert rel(y, ref) < TOL
+    # all-zero mask: nothing is live, output is exactly zero
+    z = np.zeros_like(mf)
+    assert emu.d4w_fk_set_mask_dense_f32(plan, vp(z), None) == 0
+    assert emu.d4w_fk_plan_live_rows(plan) == 0
+    assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) == 0
+    assert np.all(y == 0)
+    # back to a dense mask on the same plan: pruning switches off again
+    md = np.ascontiguousarray(rng.random((nx, ns)), dtype=np.float32)
+    assert emu.d4w_fk_set_mask_dense_f32(plan, vp(md), None) == 0
+    assert emu.d4w_fk_plan_live_rows(plan) == nx
+    assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) == 0
+    assert rel(y, orc.fk_filter_filt(x, md)) < TOL
+    emu.d4w_fk_plan_destroy(plan)

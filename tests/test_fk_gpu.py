@@ -170,3 +170,18 @@ def test_full_size_properties(dw):
     err3 = float((y - yg).abs().max() / yg.abs().max())
     print("20000x120000 specialised vs generic kernels: %.3e" % err3)
     assert err3 < TOL
+    # dead-row skipping: the speed fan of fk_filter_design keeps ~30 % of the wavenumber rows; the
+    # pruned run must equal the generic (unpruned) kernels' result
+    del yg
+    fan = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419046878814697, 200.0)
+    plan.set_mask(fan)
+    live = plan.live_rows()
+    print("20000x120000 classic fan: %d of %d wavenumber rows live" % (live, nx))
+    assert 0 < live < nx
+    plan.apply(x, out=y)
+    plan_g.set_mask(fan)
+    del fan
+    yg = plan_g.apply(x)
+    err4 = float((y - yg).abs().max() / yg.abs().max())
+    print("20000x120000 pruned specialised vs generic, classic fan: %.3e" % err4)
+    assert err4 < TOL
