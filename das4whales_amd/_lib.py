@@ -49,6 +49,17 @@ def _load():
         "d4w_row_stats_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
+        "d4w_analytic_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),
+        "d4w_row_var_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+        "d4w_snr_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+        "d4w_fx_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+        "d4w_stft_frames": (c_int, [c_int, c_int]),
+        "d4w_stft_mag_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+        "d4w_scale_rows_f32": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_int, c_void_p]),
+        "d4w_row_median_f32": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_void_p]),
+        "d4w_spectrocorr_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                        c_int, c_void_p, c_void_p]),
+        "d4w_find_peaks_f32": (c_int, [c_void_p, c_int, c_int, ctypes.c_float, c_void_p, c_void_p, c_int, c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly

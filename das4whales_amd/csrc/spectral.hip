@@ -1,0 +1,651 @@
+// Row-independent spectral operators on MI355X (gfx950), every transform running in LDS with the
+// mixed-radix stages of fft_lds.h:
+//   * analytic signal along time (scipy.signal.hilbert): envelope, Hilbert transform, envelope SNR,
+//     instantaneous frequency   -- reference dsp.py:830-856 (instant_freq), dsp.py:956-976
+//     (snr_tr_array), detect.py:192,217 (pick_times_env / process_corr);
+//   * STFT magnitude as librosa.stft is called by the reference (dsp.py:66-68 get_spectrogram,
+//     detect.py:382 get_sliced_nspectrogram), with the per-channel maximum the reference
+//     normalises by (dsp.py:76, detect.py:387);
+//   * spectrogram x kernel correlation (detect.py:579-602 xcorr2d, :605-647 xcorr) and the median
+//     it divides by (a radix select, not a reduction);
+//   * peak picking: scipy.signal.find_peaks(x, prominence=thr) (detect.py:192,217,271);
+//   * dsp.get_fx (dsp.py:18-38).
+// All of it is HBM-streaming work; no MFMA.
+#include <map>
+#include <mutex>
+
+#include "fft_host.h"
+
+namespace d4w {
+
+constexpr int kSpThreads = 256;
+constexpr size_t kSpLdsMax = 150 * 1024;      // dynamic LDS a single-row transform may use
+
+// ---------------------------------------------------------------------------------------------
+// per-(device, length) transform tables, cached for the life of the process
+// ---------------------------------------------------------------------------------------------
+struct RowFftDev {
+    AxisDesc ax;
+    const int* pos;       // [L] frequency -> LDS position after the forward (DIF) transform
+    const int* p2f;       // [L] position -> frequency
+    const float2* wpack;  // [L] exp(-2 pi i f / (2L)): real-packing twiddle of a 2L-point real row
+    const float* hann;    // [L] periodic Hann window (scipy get_window('hann', L, fftbins=True))
+};
+
+struct RowFftHost {
+    RowFftDev dev;
+    bool generic;
+    std::vector<void*> allocs;
+};
+
+static std::mutex g_rowfft_mu;
+static std::map<std::pair<int, int>, RowFftHost*> g_rowfft;
+
+template <typename T>
+static int sp_upload(RowFftHost* h, const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    D4W_HIP(hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    h->allocs.push_back(p);
+    D4W_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return D4W_OK;
+}
+
+static int row_fft_get(int L, const RowFftHost** out) {
+    int devid = 0;
+    D4W_HIP(hipGetDevice(&devid));
+    std::lock_guard<std::mutex> lk(g_rowfft_mu);
+    auto it = g_rowfft.find({devid, L});
+    if (it != g_rowfft.end()) { *out = it->second; return D4W_OK; }
+    std::vector<int> rad;
+    if (!factor_radices(L, rad))
+        return fail(D4W_EINVAL, "transform length %d has a prime factor > 31 (not supported)", L);
+    RowFftHost* h = new RowFftHost();
+    memset(&h->dev, 0, sizeof(h->dev));
+    AxisDesc& ax = h->dev.ax;
+    ax.L = L;
+    ax.nstage = (L == 1) ? 0 : (int)rad.size();
+    for (int i = 0; i < kMaxStages; ++i) ax.radix[i] = (i < (int)rad.size() && L > 1) ? rad[i] : 1;
+    if (L == 1) rad.clear();
+    const std::vector<int> p2f = pos_to_freq(L, rad);
+    std::vector<int> pos(L);
+    for (int p = 0; p < L; ++p) pos[p2f[p]] = p;
+    std::vector<float2> wp(L);
+    for (int f = 0; f < L; ++f) wp[f] = wexp(f, 2LL * L);
+    std::vector<float> hann(L);
+    for (int n = 0; n < L; ++n) hann[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)L));
+    int rc = sp_upload(h, twiddle_table2(L, &ax.nhi), &ax.tw2);
+    if (!rc) rc = sp_upload(h, pos, &h->dev.pos);
+    if (!rc) rc = sp_upload(h, p2f, &h->dev.p2f);
+    if (!rc) rc = sp_upload(h, wp, &h->dev.wpack);
+    if (!rc) rc = sp_upload(h, hann, &h->dev.hann);
+    if (rc) {
+        for (void* p : h->allocs) (void)hipFree(p);
+        delete h;
+        return rc;
+    }
+    h->generic = axis_needs_generic(ax);
+    g_rowfft[{devid, L}] = h;
+    *out = h;
+    return D4W_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// analytic signal of every row  (scipy.signal.hilbert(x, axis=1) = ifft(fft(x) * h))
+//
+// Even ns (every shape the reference processes): the real row is read as M = ns/2 packed complex
+// samples, one M-point FFT gives the half spectrum X(f) after the real-spectrum untangle, the
+// Hilbert transform's spectrum is -i X(f) (0 < f < M; 0 at DC and Nyquist, scipy's h = 1 there
+// belongs to the real part), and the packed inverse returns H[x] itself; z = x + i H[x].
+// Odd ns: plain ns-point complex transform of (x, 0), times h, inverse.
+//   mode 0: |z|                               (envelope, detect.py:192)
+//   mode 1: imag(z) = H[x]
+//   mode 2: 10 log10(|z|^2 / var[row])        (dsp.py:975)
+//   mode 3: arg(z[i+1] conj(z[i])) * fscale   (diff(unwrap(angle z)) / 2 pi * fs, dsp.py:846-855),
+//           ns - 1 outputs per row
+// ---------------------------------------------------------------------------------------------
+enum { kAnEnvelope = 0, kAnHilbert = 1, kAnSnr = 2, kAnIfreq = 3 };
+
+__device__ __forceinline__ float an_ifreq(float2 z0, float2 z1, float fscale) {
+    const float2 p = c_mulc(z1, z0);
+    return atan2f(p.y, p.x) * fscale;
+}
+
+template <bool PACKED, bool GENERIC>
+__global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const float* __restrict__ x, int ns,
+                                                            float* __restrict__ y, int mode,
+                                                            const float* __restrict__ var, float fscale) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int L = F.ax.L;
+    const TwLds tw = tw_stage(F.ax, tile + L, tid, nthr);
+    const float* xr = x + (size_t)blockIdx.x * ns;
+    if (PACKED) {
+        const float2* x2 = reinterpret_cast<const float2*>(xr);       // ns even: 8-byte aligned rows
+        for (int m = tid; m < L; m += nthr) tile[m] = x2[m];
+    } else {
+        for (int n = tid; n < L; n += nthr) tile[n] = make_float2(xr[n], 0.f);
+    }
+    lds_barrier();
+    lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+    if (PACKED) {
+        const int M = L;
+        for (int f = tid; f <= M / 2; f += nthr) {
+            const int g = (f == 0) ? 0 : M - f;
+            const int pa = F.pos[f], pb = F.pos[g];
+            const float2 a = tile[pa], bc = c_conj(tile[pb]);
+            float2 out_a = make_float2(0.f, 0.f), out_b = make_float2(0.f, 0.f);
+            if (f != 0) {
+                const float2 w = F.wpack[f];
+                const float2 E = c_scale(c_add(a, bc), 0.5f);
+                const float2 O = c_mul_mi(c_scale(c_sub(a, bc), 0.5f));
+                const float2 tO = c_mul(w, O);
+                const float2 Yp = c_mul_mi(c_add(E, tO));             // -i X(f)
+                const float2 Ym = c_mul_pi(c_sub(E, tO));             // +i X(f + M)  (negative frequency)
+                const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
+                const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+                out_a = c_add(S, D);
+                out_b = c_conj(c_sub(S, D));
+            }
+            tile[pa] = out_a;
+            if (pb != pa) tile[pb] = out_b;
+        }
+    } else {
+        const int half = (L + 1) / 2;                                 // first negative frequency
+        for (int p = tid; p < L; p += nthr) {
+            const int f = F.p2f[p];
+            float h = (f < half) ? 2.f : 0.f;
+            if (f == 0 || (2 * f == L)) h = 1.f;
+            tile[p] = c_scale(tile[p], h);
+        }
+    }
+    lds_barrier();
+    lds_fft<true, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+    const float scale = 1.0f / (float)L;
+    auto zat = [&](int i) -> float2 {
+        if (PACKED) {
+            const float2 h = tile[i >> 1];
+            return make_float2(xr[i], ((i & 1) ? h.y : h.x) * scale);
+        }
+        return c_scale(tile[i], scale);
+    };
+    if (mode == kAnIfreq) {
+        float* yr = y + (size_t)blockIdx.x * (ns - 1);
+        for (int i = tid; i < ns - 1; i += nthr) yr[i] = an_ifreq(zat(i), zat(i + 1), fscale);
+        return;
+    }
+    float* yr = y + (size_t)blockIdx.x * ns;
+    const float inv_var = (mode == kAnSnr) ? 1.0f / var[blockIdx.x] : 0.f;
+    for (int i = tid; i < ns; i += nthr) {
+        const float2 z = zat(i);
+        float v;
+        if (mode == kAnEnvelope) v = sqrtf(fmaf(z.x, z.x, z.y * z.y));
+        else if (mode == kAnHilbert) v = z.y;
+        else v = 10.0f * log10f(fmaf(z.x, z.x, z.y * z.y) * inv_var);
+        yr[i] = v;
+    }
+}
+
+// population variance of every row (np.std(x, axis=1)**2, dsp.py:975-976): two sweeps of the row
+// (mean, then centred sum of squares; the second sweep hits L2)
+__global__ __launch_bounds__(kSpThreads) void row_var(const float* __restrict__ x, int ns, float* __restrict__ var) {
+    __shared__ float red[kSpThreads / 64];
+    __shared__ float s_mean;
+    const float* row = x + (size_t)blockIdx.x * ns;
+    const int tid = threadIdx.x;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const float mu = sweep ? s_mean : 0.f;
+        float s0 = 0.f, s1 = 0.f;
+        int i = tid;
+        for (; i + kSpThreads < ns; i += 2 * kSpThreads) {
+            const float a = row[i] - mu, b = row[i + kSpThreads] - mu;
+            s0 += sweep ? a * a : a;
+            s1 += sweep ? b * b : b;
+        }
+        if (i < ns) {
+            const float a = row[i] - mu;
+            s0 += sweep ? a * a : a;
+        }
+        float s = s0 + s1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if ((tid & 63) == 0) red[tid / 64] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < kSpThreads / 64; ++w) t += red[w];
+            if (sweep) var[blockIdx.x] = t / (float)ns;
+            else s_mean = t / (float)ns;
+        }
+        __syncthreads();
+    }
+}
+
+// 10 log10(x^2 / var[row])   (dsp.py:976)
+__global__ __launch_bounds__(kSpThreads) void snr_rows(const float* __restrict__ x, int ns,
+                                                       const float* __restrict__ var, float* __restrict__ y) {
+    const size_t base = (size_t)blockIdx.y * ns;
+    const float inv_var = 1.0f / var[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const float v = x[base + i];
+        y[base + i] = 10.0f * log10f(v * v * inv_var);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dsp.get_fx: 2 |fftshift(fft(x, nfft), axes=1)| / nfft * 1e9   (dsp.py:35-37)
+// np.fft.fft(x, nfft) crops or zero-pads the row to nfft samples.
+// ---------------------------------------------------------------------------------------------
+template <bool GENERIC>
+__global__ __launch_bounds__(kSpThreads) void fx_rows(RowFftDev F, const float* __restrict__ x, int ns,
+                                                      float* __restrict__ y) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int L = F.ax.L;
+    const TwLds tw = tw_stage(F.ax, tile + L, tid, nthr);
+    const float* xr = x + (size_t)blockIdx.x * ns;
+    for (int n = tid; n < L; n += nthr) tile[n] = make_float2(n < ns ? xr[n] : 0.f, 0.f);
+    lds_barrier();
+    lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+    const float scale = (float)(2.0e9 / (double)L);
+    float* yr = y + (size_t)blockIdx.x * L;
+    const int sh = L / 2;                                             // fftshift: out[j] = F[(j - L//2) mod L]
+    for (int j = tid; j < L; j += nthr) {
+        int f = j - sh;
+        if (f < 0) f += L;
+        const float2 v = tile[F.pos[f]];
+        yr[j] = sqrtf(fmaf(v.x, v.x, v.y * v.y)) * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// |librosa.stft(y, n_fft, hop_length=hop)|: periodic Hann, center=True with zero padding,
+// frame t covers samples [t*hop - n_fft/2, t*hop + n_fft/2), n_frames = 1 + ns/hop, bins 0..n_fft/2
+// (SURVEY.md A.1).  A workgroup owns FT consecutive frames of one channel: the samples they cover
+// are staged once in LDS, two real frames ride one complex n_fft-point transform, the bins
+// [b_lo, b_hi] are written as S[c][bin - b_lo][t] (t fastest) and the maximum over ALL bins and
+// frames goes to rowmax[c] (the reference normalises by the full spectrogram's max before it
+// slices, detect.py:387,390).
+// ---------------------------------------------------------------------------------------------
+struct StftDims {
+    int ns, n_fft, hop, nframes, FT, b_lo, b_hi;
+};
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kSpThreads) void stft_mag(RowFftDev F, StftDims d, const float* __restrict__ x,
+                                                       float* __restrict__ S, unsigned* __restrict__ rowmax) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int n_fft = d.n_fft, nb = d.FT / 2;
+    const TwLds tw = tw_stage(F.ax, tile + nb * n_fft, tid, nthr);
+    float* seg = reinterpret_cast<float*>(tile + nb * n_fft + tw_lds_elems(F.ax));
+    const int seg_len = (d.FT - 1) * d.hop + n_fft;
+    const int t0 = blockIdx.x * d.FT;
+    const int s0 = t0 * d.hop - n_fft / 2;
+    const float* xr = x + (size_t)blockIdx.y * d.ns;
+    for (int j = tid; j < seg_len; j += nthr) {
+        const int s = s0 + j;
+        seg[j] = (s >= 0 && s < d.ns) ? xr[s] : 0.f;
+    }
+    lds_barrier();
+    const FDiv dn(n_fft), dnb(nb);
+    for (int w = tid; w < nb * n_fft; w += nthr) {
+        const int b = dn.div(w), n = w - b * n_fft;
+        const float wn = F.hann[n];
+        tile[w] = make_float2(seg[2 * b * d.hop + n] * wn, seg[(2 * b + 1) * d.hop + n] * wn);
+    }
+    lds_barrier();
+    lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, nb, n_fft, 1, 0, tid, nthr);
+    const int nbins = n_fft / 2 + 1, nkeep = d.b_hi - d.b_lo + 1;
+    float mx = 0.f;
+    for (int w = tid; w < nbins * nb; w += nthr) {
+        const int k = dnb.div(w), b = w - k * nb;
+        const int tA = t0 + 2 * b;
+        if (tA >= d.nframes) continue;
+        const float2* tb = tile + b * n_fft;
+        const float2 zk = tb[F.pos[k]], zm = c_conj(tb[F.pos[(k == 0) ? 0 : n_fft - k]]);
+        const float2 A = c_scale(c_add(zk, zm), 0.5f);
+        const float2 B = c_mul_mi(c_scale(c_sub(zk, zm), 0.5f));
+        const float ma = sqrtf(fmaf(A.x, A.x, A.y * A.y)), mb = sqrtf(fmaf(B.x, B.x, B.y * B.y));
+        const bool hasB = (tA + 1 < d.nframes);
+        mx = fmaxf(mx, ma);
+        if (hasB) mx = fmaxf(mx, mb);
+        if (k >= d.b_lo && k <= d.b_hi) {
+            float* o = S + ((size_t)blockIdx.y * nkeep + (k - d.b_lo)) * d.nframes + tA;
+            o[0] = ma;
+            if (hasB) o[1] = mb;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) atomicMax(rowmax + blockIdx.y, __float_as_uint(mx));   // mx >= 0: bit order = value order
+}
+
+// S[c][i] /= denom[c]  (mode 0, detect.py:387)   or   20 log10(S[c][i] / denom[c])  (mode 1, dsp.py:76)
+__global__ __launch_bounds__(kSpThreads) void scale_rows(float* __restrict__ S, size_t per_row,
+                                                         const float* __restrict__ denom, int mode) {
+    float* row = S + (size_t)blockIdx.y * per_row;
+    const float dv = denom[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_row; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = row[i] / dv;
+        row[i] = mode ? 20.0f * log10f(v) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// np.median of every row (detect.py:600 divides by the median of the sliced spectrogram):
+// 4-pass 8-bit radix select on order-preserving keys with an LDS histogram; for an even count the
+// upper middle is the smallest key above the lower one unless duplicates cover it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned med_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float med_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict__ v, size_t n,
+                                                         float* __restrict__ med) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_k, s_cnt, s_min;
+    const float* row = v + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_prefix = 0u; s_k = (unsigned)((n - 1) / 2); }
+    unsigned mask = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (size_t i = tid; i < n; i += kSpThreads) {
+            const unsigned k = med_key(row[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned k = s_k, b = 0;
+            for (; b < 255u; ++b) {
+                if (hist[b] > k) break;
+                k -= hist[b];
+            }
+            s_k = k;
+            s_prefix = prefix | (b << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned a = s_prefix;
+    if (n & 1) {
+        if (tid == 0) med[blockIdx.x] = med_unkey(a);
+        return;
+    }
+    if (tid == 0) { s_cnt = 0u; s_min = 0xFFFFFFFFu; }
+    __syncthreads();
+    unsigned cnt = 0u, mn = 0xFFFFFFFFu;
+    for (size_t i = tid; i < n; i += kSpThreads) {
+        const unsigned k = med_key(row[i]);
+        if (k <= a) ++cnt;
+        else mn = min(mn, k);
+    }
+    atomicAdd(&s_cnt, cnt);
+    atomicMin(&s_min, mn);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned b = (s_cnt > (unsigned)(n / 2)) ? a : s_min;
+        med[blockIdx.x] = 0.5f * (med_unkey(a) + med_unkey(b));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// spectrogram x kernel correlation along time, summed over frequency:
+//   raw[c][t] = sum_f sum_j S[c][f][t + j - off] K[f][j]   (S = 0 outside [0, nt)),  t < nout
+//   out = max(raw, 0) / (med[c] * nk)                      (detect.py:597-600)
+// off = nk/2 reproduces fftconvolve(S, flip(K, 1), 'same', axes=1); off = 0 with nout = nt-nk+1
+// and zero_ends reproduces detect.xcorr (detect.py:632-644: first and last value forced to 0).
+// ---------------------------------------------------------------------------------------------
+constexpr int kScTile = 256;
+constexpr int kScLdsFloats = 8192;
+
+__global__ __launch_bounds__(kScTile) void spectro_corr(const float* __restrict__ S, int nf, int nt,
+                                                        const float* __restrict__ K, int nk, int off, int nout,
+                                                        const float* __restrict__ med, int zero_ends,
+                                                        float* __restrict__ out) {
+    __shared__ float strip[kScLdsFloats];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * kScTile;
+    const int width = kScTile + nk - 1;
+    const int fchunk = max(1, kScLdsFloats / width);
+    const float* Sc = S + (size_t)blockIdx.y * nf * nt;
+    float acc = 0.f;
+    for (int f0 = 0; f0 < nf; f0 += fchunk) {
+        const int fn = min(fchunk, nf - f0);
+        for (int w = tid; w < fn * width; w += kScTile) {
+            const int fl = w / width, j = w - fl * width;
+            const int s = t0 + j - off;
+            strip[w] = (s >= 0 && s < nt) ? Sc[(size_t)(f0 + fl) * nt + s] : 0.f;
+        }
+        __syncthreads();
+        for (int fl = 0; fl < fn; ++fl) {
+            const float* kr = K + (size_t)(f0 + fl) * nk;
+            const float* sr = strip + fl * width + tid;
+            for (int j = 0; j < nk; ++j) acc = fmaf(sr[j], kr[j], acc);
+        }
+        __syncthreads();
+    }
+    const int t = t0 + tid;
+    if (t < nout) {
+        float v = acc / (med[blockIdx.y] * (float)nk);
+        if (zero_ends && (t == 0 || t == nout - 1)) v = 0.f;
+        if (v < 0.f) v = 0.f;                                        // NaN (0/0 on an all-zero row) passes through
+        out[(size_t)blockIdx.y * nout + t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scipy.signal.find_peaks(x, prominence=thr)[0] per row  (detect.py:192,217,271)
+//   _local_maxima_1d: a plateau whose left neighbour is lower and whose right neighbour is lower is
+//   a peak at the plateau's middle sample (floor); the first and last sample never are.
+//   _peak_prominences (wlen=None): walk left / right from the peak while samples are <= the peak,
+//   tracking the minimum; prominence = peak - max(left_min, right_min); keep prominence >= thr.
+// One workgroup per row; a thread owns a candidate left edge, accepted peaks are written in time
+// order through a workgroup prefix sum.  idx[row][0..min(count, cap)) ; counts[row] = count.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, float thr,
+                                                              int* __restrict__ idx, int* __restrict__ counts,
+                                                              int cap) {
+    __shared__ int wave_tot[kSpThreads / 64];
+    const float* r = x + (size_t)blockIdx.x * ns;
+    int* orow = idx + (size_t)blockIdx.x * cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int c0 = 1; c0 < ns - 1; c0 += kSpThreads) {
+        const int i = c0 + tid;
+        int peak = -1;
+        if (i < ns - 1 && r[i - 1] < r[i]) {
+            const float v = r[i];
+            int ia = i + 1;
+            while (ia < ns - 1 && r[ia] == v) ++ia;
+            if (r[ia] < v) {
+                const int mid = (i + ia - 1) / 2;
+                float lmin = v, rmin = v;
+                for (int q = i - 1; q >= 0; --q) {
+                    const float u = r[q];
+                    if (u > v) break;
+                    lmin = fminf(lmin, u);
+                }
+                for (int q = ia; q < ns; ++q) {
+                    const float u = r[q];
+                    if (u > v) break;
+                    rmin = fminf(rmin, u);
+                }
+                if (v - fmaxf(lmin, rmin) >= thr) peak = mid;
+            }
+        }
+        // ordered compaction: inclusive scan inside the wave, then across the waves
+        const int flag = (peak >= 0) ? 1 : 0;
+        int incl = flag;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(incl, off);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < kSpThreads / 64; ++w) {
+            if (w < wave) before += wave_tot[w];
+            total += wave_tot[w];
+        }
+        if (flag) {
+            const int p = base + before + incl - 1;
+            if (p < cap) orow[p] = peak;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[blockIdx.x] = base;
+}
+
+}  // namespace d4w
+
+using namespace d4w;
+
+template <typename K>
+static void sp_allow_lds(K kern, size_t lds) {
+#ifndef D4W_EMU
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#else
+    (void)kern; (void)lds;
+#endif
+}
+
+extern "C" {
+
+int d4w_row_var_f32(const float* x, int nx, int ns, float* var, void* stream) {
+    if (!x || !var || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(row_var, dim3(nx), dim3(kSpThreads), 0, stream, x, ns, var);
+    return D4W_OK;
+}
+
+int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
+                     void* stream) {
+    if (!x || !y || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");
+    if (mode < 0 || mode > 3) return fail(D4W_EINVAL, "mode = %d not in 0..3", mode);
+    if (mode == kAnSnr && !var) return fail(D4W_EINVAL, "mode 2 needs the row variances");
+    const bool packed = (ns % 2 == 0);
+    const int L = packed ? ns / 2 : ns;
+    const RowFftHost* h = nullptr;
+    int rc = row_fft_get(L, &h);
+    if (rc) return rc;
+    const size_t lds = ((size_t)L + kTwLo + h->dev.ax.nhi) * sizeof(float2);
+    if (lds > kSpLdsMax)
+        return fail(D4W_EINVAL, "rows of %d samples exceed the single-workgroup transform (max %d even / %d odd)",
+                    ns, (int)(2 * (kSpLdsMax / 8 - 512)), (int)(kSpLdsMax / 8 - 512));
+    const float fscale = (float)(fs / (2.0 * M_PI));
+#define D4W_AN(P, G)                                                                              \
+    do {                                                                                          \
+        sp_allow_lds(analytic_rows<P, G>, lds);                                                   \
+        D4W_LAUNCH((analytic_rows<P, G>), dim3(nx), dim3(kSpThreads), lds, stream, h->dev, x, ns, \
+                   y, mode, var, fscale);                                                         \
+    } while (0)
+    if (packed) { if (h->generic) D4W_AN(true, true); else D4W_AN(true, false); }
+    else { if (h->generic) D4W_AN(false, true); else D4W_AN(false, false); }
+#undef D4W_AN
+    return D4W_OK;
+}
+
+int d4w_snr_f32(const float* x, float* y, int nx, int ns, int env, float* var_ws, void* stream) {
+    if (!x || !y || !var_ws || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");
+    int rc = d4w_row_var_f32(x, nx, ns, var_ws, stream);
+    if (rc) return rc;
+    if (env) return d4w_analytic_f32(x, y, nx, ns, kAnSnr, var_ws, 0.0, stream);
+    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    D4W_LAUNCH(snr_rows, dim3(std::min(ceil_div(ns, kSpThreads), 64), nx), dim3(kSpThreads), 0, stream, x, ns,
+               (const float*)var_ws, y);
+    return D4W_OK;
+}
+
+int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream) {
+    if (!x || !y || nx < 1 || ns < 1 || nfft < 1) return fail(D4W_EINVAL, "bad argument");
+    const RowFftHost* h = nullptr;
+    int rc = row_fft_get(nfft, &h);
+    if (rc) return rc;
+    const size_t lds = ((size_t)nfft + kTwLo + h->dev.ax.nhi) * sizeof(float2);
+    if (lds > kSpLdsMax) return fail(D4W_EINVAL, "nfft = %d exceeds the single-workgroup transform", nfft);
+    if (h->generic) {
+        sp_allow_lds(fx_rows<true>, lds);
+        D4W_LAUNCH(fx_rows<true>, dim3(nx), dim3(kSpThreads), lds, stream, h->dev, x, ns, y);
+    } else {
+        sp_allow_lds(fx_rows<false>, lds);
+        D4W_LAUNCH(fx_rows<false>, dim3(nx), dim3(kSpThreads), lds, stream, h->dev, x, ns, y);
+    }
+    return D4W_OK;
+}
+
+int d4w_stft_frames(int ns, int hop) { return (hop > 0 && ns >= 0) ? 1 + ns / hop : 0; }
+
+int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, int n_fft, int hop, int bin_lo,
+                     int bin_hi, void* stream) {
+    if (!x || !S || !rowmax || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (n_fft < 2 || (n_fft & 1) || hop < 1) return fail(D4W_EINVAL, "n_fft = %d must be even and >= 2, hop = %d >= 1", n_fft, hop);
+    if (bin_lo < 0 || bin_hi > n_fft / 2 || bin_lo > bin_hi) return fail(D4W_EINVAL, "bin range [%d, %d] outside 0..%d", bin_lo, bin_hi, n_fft / 2);
+    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    const RowFftHost* h = nullptr;
+    int rc = row_fft_get(n_fft, &h);
+    if (rc) return rc;
+    StftDims d;
+    d.ns = ns; d.n_fft = n_fft; d.hop = hop; d.nframes = 1 + ns / hop; d.b_lo = bin_lo; d.b_hi = bin_hi;
+    int nb = std::max(1, 6144 / n_fft);                      // complex transforms (frame pairs) per workgroup
+    nb = std::min(nb, std::max(1, (d.nframes + 1) / 2));
+    d.FT = 2 * nb;
+    const size_t lds = ((size_t)nb * n_fft + kTwLo + h->dev.ax.nhi) * sizeof(float2) +
+                       ((size_t)(d.FT - 1) * hop + n_fft) * sizeof(float);
+    if (lds > kSpLdsMax) return fail(D4W_EINVAL, "n_fft = %d / hop = %d exceed the LDS frame tile", n_fft, hop);
+    D4W_HIP(hipMemsetAsync(rowmax, 0, (size_t)nx * sizeof(float), (hipStream_t)stream));
+    const dim3 grid(ceil_div(d.nframes, d.FT), nx);
+    if (h->generic) {
+        sp_allow_lds(stft_mag<true>, lds);
+        D4W_LAUNCH(stft_mag<true>, grid, dim3(kSpThreads), lds, stream, h->dev, d, x, S, (unsigned*)rowmax);
+    } else {
+        sp_allow_lds(stft_mag<false>, lds);
+        D4W_LAUNCH(stft_mag<false>, grid, dim3(kSpThreads), lds, stream, h->dev, d, x, S, (unsigned*)rowmax);
+    }
+    return D4W_OK;
+}
+
+int d4w_scale_rows_f32(float* S, int nx, size_t per_row, const float* denom, int mode, void* stream) {
+    if (!S || !denom || nx < 1 || per_row < 1) return fail(D4W_EINVAL, "bad argument");
+    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    const int bx = (int)std::min<size_t>((per_row + kSpThreads - 1) / kSpThreads, 256);
+    D4W_LAUNCH(scale_rows, dim3(bx, nx), dim3(kSpThreads), 0, stream, S, per_row, denom, mode);
+    return D4W_OK;
+}
+
+int d4w_row_median_f32(const float* v, int nx, size_t per_row, float* med, void* stream) {
+    if (!v || !med || nx < 1 || per_row < 1) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(row_median, dim3(nx), dim3(kSpThreads), 0, stream, v, per_row, med);
+    return D4W_OK;
+}
+
+int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, int nk, int off, int nout,
+                        const float* med, int zero_ends, float* out, void* stream) {
+    if (!S || !K || !med || !out || nx < 1 || nf < 1 || nt < 1 || nk < 1 || nout < 1)
+        return fail(D4W_EINVAL, "bad argument");
+    if (nk > kScLdsFloats - kScTile) return fail(D4W_EINVAL, "kernel of %d frames is too long", nk);
+    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    D4W_LAUNCH(spectro_corr, dim3(ceil_div(nout, kScTile), nx), dim3(kScTile), 0, stream, S, nf, nt, K, nk, off,
+               nout, med, zero_ends, out);
+    return D4W_OK;
+}
+
+int d4w_find_peaks_f32(const float* x, int nx, int ns, float prominence, int32_t* idx, int32_t* counts, int cap,
+                       void* stream) {
+    if (!x || !idx || !counts || nx < 1 || ns < 1 || cap < 1) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(find_peaks_prom, dim3(nx), dim3(kSpThreads), 0, stream, x, ns, prominence, (int*)idx, (int*)counts, cap);
+    return D4W_OK;
+}
+
+}  // extern "C"

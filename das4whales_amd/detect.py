@@ -133,6 +133,206 @@ def compute_cross_correlogram(data, template):
 
 
 # ---------------------------------------------------------------------------------------------
+# peak picking (d4w_find_peaks_f32; the envelope of the *_env variants is d4w_analytic_f32)
+# ---------------------------------------------------------------------------------------------
+def _find_peaks_device(c, threshold, cap0=1024):
+    """c: float32 CUDA [nx, ns] -> list of int64 index arrays, one per row, in row order."""
+    nx, ns = c.shape
+    cap = max(1, min(ns // 2 + 1, int(cap0)))
+    with torch.cuda.device(c.device):
+        while True:
+            idx = torch.empty((nx, cap), dtype=torch.int32, device=c.device)
+            cnt = torch.empty(nx, dtype=torch.int32, device=c.device)
+            check(lib.d4w_find_peaks_f32(dev.ptr(c), nx, ns, float(threshold), dev.ptr(idx), dev.ptr(cnt), cap,
+                                         dev.stream_ptr(c)))
+            counts = cnt.cpu().numpy().astype(np.int64)
+            need = int(counts.max()) if nx else 0
+            if need <= cap:
+                break
+            cap = min(ns // 2 + 1, max(need, 2 * cap))          # rare: a row with more peaks than the first guess
+        keep = torch.arange(cap, device=c.device)[None, :] < cnt[:, None]
+        flat = idx[keep].cpu().numpy().astype(np.int64)
+    return np.split(flat, np.cumsum(counts)[:-1]) if nx else []
+
+
+def pick_times_env(corr_m, threshold):
+    """Per row find_peaks(|hilbert(corr)|, prominence=threshold)[0] -- reference detect.py:169-195."""
+    from . import dsp
+    if getattr(corr_m, "ndim", 0) != 2:
+        raise ValueError("corr_m must be a 2-D [channel x time] array")
+    env = dsp._analytic(dev.to_device_f32(corr_m), 0)
+    return _find_peaks_device(env, threshold)
+
+
+def process_corr(corr, threshold):
+    """One row of pick_times_env -- reference detect.py:198-218."""
+    c = corr if dev.is_tensor(corr) else np.asarray(corr)
+    return pick_times_env(c.reshape(1, -1), threshold)[0]
+
+
+def pick_times_par(corr_m, threshold):
+    """pick_times_env; the reference's thread-pool variant (detect.py:221-246) returns rows in
+    completion order, here rows come back in channel order."""
+    return pick_times_env(corr_m, threshold)
+
+
+def pick_times(corr_m, threshold):
+    """Per row find_peaks(corr, prominence=threshold)[0] -- reference detect.py:249-274."""
+    if getattr(corr_m, "ndim", 0) != 2:
+        raise ValueError("corr_m must be a 2-D [channel x time] array")
+    return _find_peaks_device(dev.to_device_f32(corr_m), threshold)
+
+
+# ---------------------------------------------------------------------------------------------
+# spectrogram correlation
+# ---------------------------------------------------------------------------------------------
+def _keep_bins(fs, nperseg, fmin, fmax):
+    ff = np.linspace(0, fs / 2, num=nperseg // 2 + 1)                            # detect.py:386
+    keep = np.where((ff >= fmin) & (ff <= fmax))[0]                              # detect.py:390
+    if len(keep) == 0:
+        raise ValueError("no STFT bin between fmin = %g and fmax = %g" % (fmin, fmax))
+    return ff, int(keep[0]), int(keep[-1])
+
+
+def get_sliced_nspectrogram(trace, fs, fmin, fmax, nperseg, nhop, plotflag=False):
+    """|librosa.stft(trace, nperseg, nhop)| / max, rows with fmin <= f <= fmax; returns (p, ff, tt)
+    -- reference detect.py:334-408 (plotflag is a plotting path of the reference and is ignored)."""
+    from . import dsp
+    if getattr(trace, "ndim", 0) != 1:
+        raise ValueError("trace must be 1-D")
+    ff, lo, hi = _keep_bins(fs, nperseg, fmin, fmax)
+    x = dev.to_device_f32(trace.reshape(1, -1))
+    S, mx = dsp._stft_mag(x, nperseg, nhop, lo, hi)
+    dsp._scale_rows(S, mx, 0)                                                   # detect.py:387
+    tt = np.linspace(0, trace.shape[0] / fs, num=S.shape[2])                    # detect.py:385
+    return dev.like_input(S[0], trace), ff[lo:hi + 1], tt
+
+
+def buildkernel(f0, f1, bdwdth, dur, f, t, samp, fmin, fmax, plotflag=False):
+    """Hat-function kernel along a hyperbolic down-sweep, Hann-weighted in time; returns
+    (tvec, fvec, BlueKernel) -- reference detect.py:411-492 (host, a few hundred values)."""
+    t = np.asarray(t)
+    tvec = np.linspace(0, dur, np.size(np.nonzero((t < dur * 8) & (t > dur * 7))))      # detect.py:456
+    fvec = np.asarray(f)
+    x = fvec[:, None] - (f0 * f1 * dur / ((f0 - f1) * tvec[None, :] + f1 * dur))        # detect.py:470
+    kdist = (1 - np.square(x) / (bdwdth * bdwdth)) * np.exp(-np.square(x) / (2 * (bdwdth * bdwdth)))
+    return tvec, fvec, kdist * np.hanning(len(tvec))[np.newaxis, :]                     # detect.py:474
+
+
+def buildkernel_from_template(fmin, fmax, dur, fs, nperseg, nhop, plotflag=False):
+    """Sliced normalised spectrogram of the windowed hyperbolic chirp -- reference detect.py:495-541."""
+    template = gen_hyperbolic_chirp(fmin, fmax, dur, fs)
+    template *= np.hanning(len(template))
+    spectro, _, _ = get_sliced_nspectrogram(template, fs, fmin, fmax, nperseg, nhop, plotflag=False)
+    return spectro
+
+
+def _spectrocorr_device(S, K, off, nout, med=None, zero_ends=False):
+    """S: float32 CUDA [nx, nf, nt]; K: host [nf, nk] -> CUDA [nx, nout] (include/d4w.h d4w_spectrocorr_f32)."""
+    nx, nf, nt = S.shape
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    if K.ndim != 2 or K.shape[0] != nf:
+        raise ValueError("kernel has %s rows, the spectrogram %d" % (K.shape[:1], nf))
+    Kd = torch.from_numpy(K).to(S.device)
+    out = torch.empty((nx, nout), dtype=torch.float32, device=S.device)
+    with torch.cuda.device(S.device):
+        if med is None:
+            med = torch.empty(nx, dtype=torch.float32, device=S.device)
+            check(lib.d4w_row_median_f32(dev.ptr(S), nx, nf * nt, dev.ptr(med), dev.stream_ptr(S)))   # detect.py:600
+        check(lib.d4w_spectrocorr_f32(dev.ptr(S), nx, nf, nt, dev.ptr(Kd), K.shape[1], int(off), int(nout),
+                                      dev.ptr(med), int(bool(zero_ends)), dev.ptr(out), dev.stream_ptr(S)))
+        torch.cuda.current_stream().synchronize()               # Kd is a temporary
+    return out
+
+
+def _spectro_2d(spectro):
+    if getattr(spectro, "ndim", 0) != 2:
+        raise ValueError("spectro must be a 2-D [frequency x time] array")
+    return dev.to_device_f32(spectro)[None]
+
+
+def xcorr2d(spectro, kernel):
+    """sum_f fftconvolve(spectro, flip(kernel, 1), 'same', axes=1), clipped at 0,
+    / (median(spectro) * kernel.shape[1]) -- reference detect.py:579-602."""
+    S = _spectro_2d(spectro)
+    kernel = np.asarray(kernel)
+    out = _spectrocorr_device(S, kernel, kernel.shape[1] // 2, S.shape[2])
+    return dev.like_input(out[0], spectro)
+
+
+def xcorr(t, f, Sxx, tvec, fvec, BlueKernel):
+    """Valid-lag kernel x spectrogram correlation; returns [t_scale, CorrVal] -- reference detect.py:605-647."""
+    nk, nfk = np.size(tvec), np.size(fvec)
+    S = _spectro_2d(Sxx)
+    med = torch.empty(1, dtype=torch.float32, device=S.device)
+    with torch.cuda.device(S.device):                           # np.median(Sxx) is over the whole spectrogram
+        check(lib.d4w_row_median_f32(dev.ptr(S), 1, S[0].numel(), dev.ptr(med), dev.stream_ptr(S)))
+    S = S[:, :nfk].contiguous()                                 # detect.py:636: Sxx[:fvec_size, ...]
+    nout = np.size(t) - (nk - 1)
+    out = _spectrocorr_device(S, np.asarray(BlueKernel)[:nfk], 0, nout, med=med, zero_ends=True)
+    t = np.asarray(t)
+    t_scale = t[int(nk / 2) - 1:-int(np.ceil(nk / 2))]          # detect.py:645
+    return [t_scale, dev.like_input(out[0], Sxx)]
+
+
+def nxcorr2d(spectro, kernel):
+    """max over the frequency lag of correlate(spectro, kernel, 'same') / (std(spectro) std(kernel) nt)
+    -- reference detect.py:544-576.  One d4w_spectrocorr_f32 launch per frequency lag."""
+    S = _spectro_2d(spectro)
+    K = np.asarray(kernel, dtype=np.float64)
+    nf, nt = S.shape[1], S.shape[2]
+    nfk, nk = K.shape
+    var = torch.empty(1, dtype=torch.float32, device=S.device)
+    with torch.cuda.device(S.device):
+        check(lib.d4w_row_var_f32(dev.ptr(S), 1, nf * nt, dev.ptr(var), dev.stream_ptr(S)))
+    # out = raw / (med * nk) with med chosen so that the divisor is std(S) std(K) nt
+    med = torch.sqrt(var) * float(np.std(K) * nt / nk)
+    best = None
+    for a in range(nf):                                          # output row a: K row fk meets S row a + fk - nfk//2
+        Ka = np.zeros((nf, nk))
+        lo = a - nfk // 2
+        for fk in range(nfk):
+            if 0 <= lo + fk < nf:
+                Ka[lo + fk] = K[fk]
+        # clipping at 0 is harmless only when the max is >= 0; keep exact semantics via two signs
+        pos = _spectrocorr_device(S, Ka, nk // 2, nt, med=med)
+        neg = _spectrocorr_device(S, -Ka, nk // 2, nt, med=med)
+        row = pos - neg
+        best = row if best is None else torch.maximum(best, row)
+    return dev.like_input(best[0], spectro)
+
+
+def compute_cross_correlogram_spectrocorr(data, fs, flims, kernel, win_size, overlap_pct):
+    """Per-channel sliced spectrogram x hat kernel correlation -- reference detect.py:650-709.
+    All channels go through one STFT launch, one median launch and one correlation launch; the
+    spectrogram's max-normalisation (detect.py:387) cancels between numerator and median."""
+    from . import dsp
+    if getattr(data, "ndim", 0) != 2:
+        raise ValueError("data must be a 2-D [channel x time] array")
+    nperseg = int(win_size * fs)                                                 # detect.py:680
+    nhop = int(np.floor(nperseg * (1 - overlap_pct)))                            # detect.py:681
+    fmin, fmax = flims
+    f1, f0, duration, bandwidth = kernel["f1"], kernel["f0"], kernel["dur"], kernel["bdwidth"]
+    if fmax - f1 < 2 * bandwidth:                                                # detect.py:693-696
+        fmax = f1 + 3 * bandwidth
+    if f0 - fmin < 2 * bandwidth:
+        fmin = f0 - 3 * bandwidth
+    ff, lo, hi = _keep_bins(fs, nperseg, fmin, fmax)
+    x = dev.to_device_f32(data)
+    nx, ns = x.shape
+    nt = int(lib.d4w_stft_frames(ns, nhop))
+    tt = np.linspace(0, ns / fs, num=nt)                                         # detect.py:385
+    _, _, ker = buildkernel(f0, f1, bandwidth, duration, ff[lo:hi + 1], tt, fs, fmin, fmax)   # detect.py:702
+    out = torch.empty((nx, nt), dtype=torch.float32, device=x.device)
+    per_ch = (hi - lo + 1) * nt * 4
+    step = int(max(1, min(65535, (2 << 30) // per_ch)))          # <= 2 GiB of spectrogram in flight
+    for a in range(0, nx, step):
+        S, _ = dsp._stft_mag(x[a:a + step], nperseg, nhop, lo, hi)
+        out[a:a + step] = _spectrocorr_device(S, ker, ker.shape[1] // 2, nt)
+    return dev.like_input(out, data)
+
+
+# ---------------------------------------------------------------------------------------------
 # pick utilities (index bookkeeping, host)
 # ---------------------------------------------------------------------------------------------
 def convert_pick_times(peaks_indexes_m):

@@ -386,3 +386,96 @@ def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
     with torch.cuda.device(g.device):
         check(lib.d4w_minmax_normalise_f32(dev.ptr(g), g.numel(), dev.stream_ptr(g)))        # dsp.py:945
     return _fk_apply(data, DeviceMask(g), False)
+
+
+# ---------------------------------------------------------------------------------------------
+# spectral views / metrics (row operators of csrc/spectral.hip)
+# ---------------------------------------------------------------------------------------------
+def _analytic(x2d, mode, fs=0.0, var=None):
+    """x2d: float32 CUDA [nx, ns]; mode as in include/d4w.h d4w_analytic_f32."""
+    nx, ns = x2d.shape
+    y = torch.empty((nx, ns - 1 if mode == 3 else ns), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        check(lib.d4w_analytic_f32(dev.ptr(x2d), dev.ptr(y), nx, ns, int(mode),
+                                   dev.ptr(var) if var is not None else None, float(fs), dev.stream_ptr(x2d)))
+    return y
+
+
+def envelope(trace):
+    """|scipy.signal.hilbert(trace, axis=-1)| -- the envelope the reference forms inline at
+    detect.py:192,217 and scripts/main_mfdetect.py:58."""
+    x2, was1d = _rows_2d(trace)
+    y = _analytic(dev.to_device_f32(x2), 0)
+    return dev.like_input(y[0] if was1d else y, trace)
+
+
+def hilbert_imag(trace):
+    """imag(scipy.signal.hilbert(trace, axis=-1)): the Hilbert transform of every row."""
+    x2, was1d = _rows_2d(trace)
+    y = _analytic(dev.to_device_f32(x2), 1)
+    return dev.like_input(y[0] if was1d else y, trace)
+
+
+def instant_freq(channel, fs):
+    """diff(unwrap(angle(hilbert(channel)))) / (2 pi) * fs -- reference dsp.py:830-856."""
+    x2, was1d = _rows_2d(channel)
+    y = _analytic(dev.to_device_f32(x2), 3, fs=fs)
+    return dev.like_input(y[0] if was1d else y, channel)
+
+
+def snr_tr_array(trace, env=False):
+    """10 log10(trace^2 / std^2) per element, or with |hilbert|^2 (env=True) -- reference dsp.py:956-976."""
+    if getattr(trace, "ndim", 0) != 2:
+        raise ValueError("trace must be a 2-D [channel x time] array")
+    x = dev.to_device_f32(trace)
+    nx, ns = x.shape
+    y = torch.empty_like(x)
+    var = torch.empty(nx, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.d4w_snr_f32(dev.ptr(x), dev.ptr(y), nx, ns, int(bool(env)), dev.ptr(var), dev.stream_ptr(x)))
+    return dev.like_input(y, trace)
+
+
+def get_fx(trace, nfft):
+    """2 |fftshift(fft(trace, nfft), axes=1)| / nfft * 1e9 -- reference dsp.py:18-38."""
+    if getattr(trace, "ndim", 0) != 2:
+        raise ValueError("trace must be a 2-D [channel x time] array")
+    x = dev.to_device_f32(trace)
+    nx, ns = x.shape
+    y = torch.empty((nx, int(nfft)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.d4w_fx_f32(dev.ptr(x), dev.ptr(y), nx, ns, int(nfft), dev.stream_ptr(x)))
+    return dev.like_input(y, trace)
+
+
+def _stft_mag(x2d, n_fft, hop, bin_lo, bin_hi):
+    """|librosa.stft| of every row: returns (S [nx, bins, frames] raw magnitudes, rowmax [nx])."""
+    nx, ns = x2d.shape
+    nt = int(lib.d4w_stft_frames(ns, int(hop)))
+    S = torch.empty((nx, bin_hi - bin_lo + 1, nt), dtype=torch.float32, device=x2d.device)
+    mx = torch.empty(nx, dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        check(lib.d4w_stft_mag_f32(dev.ptr(x2d), dev.ptr(S), dev.ptr(mx), nx, ns, int(n_fft), int(hop),
+                                   int(bin_lo), int(bin_hi), dev.stream_ptr(x2d)))
+    return S, mx
+
+
+def _scale_rows(S, denom, mode):
+    nx = S.shape[0]
+    with torch.cuda.device(S.device):
+        check(lib.d4w_scale_rows_f32(dev.ptr(S), nx, S[0].numel(), dev.ptr(denom), int(mode), dev.stream_ptr(S)))
+    return S
+
+
+def get_spectrogram(waveform, fs, nfft=128, overlap_pct=0.8):
+    """dB spectrogram of one channel normalised by its maximum; returns (p, tt, ff) -- reference
+    dsp.py:41-78 (librosa.stft with hop = floor(nfft (1 - overlap_pct)))."""
+    if getattr(waveform, "ndim", 0) != 1:
+        raise ValueError("waveform must be 1-D")
+    hop = int(np.floor(nfft * (1 - overlap_pct)))                                # dsp.py:68
+    x = dev.to_device_f32(waveform.reshape(1, -1))
+    S, mx = _stft_mag(x, nfft, hop, 0, nfft // 2)
+    _scale_rows(S, mx, 1)                                                       # dsp.py:76
+    tt = np.linspace(0, waveform.shape[0] / fs, num=S.shape[2])                 # dsp.py:74
+    ff = np.linspace(0, fs / 2, num=S.shape[1])                                 # dsp.py:75
+    return dev.like_input(S[0], waveform), tt, ff

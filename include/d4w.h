@@ -149,6 +149,65 @@ int d4w_gaussian_filter_f32(const float* in, float* out, float* tmp, int nx, int
                             void* stream);
 int d4w_minmax_normalise_f32(float* x, size_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row spectral operators (rows independent; every transform runs inside one workgroup's LDS).
+ *
+ * d4w_analytic_f32: scipy.signal.hilbert(x, axis=1) = ifft(fft(x) * h) per row, z = x + i H[x]
+ *   mode 0  y = |z|                      envelope        (detect.py:192,217; scripts/main_mfdetect.py:58)
+ *   mode 1  y = imag(z) = H[x]
+ *   mode 2  y = 10 log10(|z|^2 / var[c]) var = DEVICE [nx] row variances   (dsp.py:975)
+ *   mode 3  y[c][i] = diff(unwrap(angle z))[i] / (2 pi) * fs, [nx][ns-1]   (dsp.instant_freq, dsp.py:830-856)
+ *   Row length limit: ns <= ~37 000 (even) / ~18 000 (odd); ns/2 (even) or ns (odd) must factor
+ *   into primes <= 31.  D4W_EINVAL otherwise.
+ * d4w_row_var_f32: var[c] = np.std(x[c])**2 (population).
+ * d4w_snr_f32: dsp.snr_tr_array (dsp.py:956-976): 10 log10(x^2 / std^2) (env = 0) or the envelope
+ *   form (env != 0); var_ws = DEVICE [nx] scratch.
+ * d4w_fx_f32: dsp.get_fx (dsp.py:18-38): y[c][j] = 2 |fftshift(fft(x[c], nfft))|[j] / nfft * 1e9,
+ *   y is [nx][nfft]; rows are cropped / zero-padded to nfft like np.fft.fft(x, nfft).
+ * ------------------------------------------------------------------------------------------ */
+int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
+                     void* stream);
+int d4w_row_var_f32(const float* x, int nx, int ns, float* var, void* stream);
+int d4w_snr_f32(const float* x, float* y, int nx, int ns, int env, float* var_ws, void* stream);
+int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectrograms and spectrogram correlation: replaces dsp.get_spectrogram (dsp.py:41-78),
+ * detect.get_sliced_nspectrogram (detect.py:334-408), detect.xcorr2d (detect.py:579-602),
+ * detect.xcorr (detect.py:605-647) and the per-channel loop of
+ * detect.compute_cross_correlogram_spectrocorr (detect.py:650-709).
+ *
+ * d4w_stft_mag_f32: S[c][b - bin_lo][t] = |librosa.stft(x[c], n_fft, hop_length=hop)|[b][t] for
+ *   bin_lo <= b <= bin_hi, t < d4w_stft_frames(ns, hop) = 1 + ns/hop (periodic Hann, center=True
+ *   with zero padding: librosa >= 0.10 defaults).  rowmax[c] = max over ALL bins and frames (what
+ *   detect.py:387 / dsp.py:76 normalise by).  n_fft even, <= 6144.
+ * d4w_scale_rows_f32: S[c][:] /= denom[c] (mode 0) or 20 log10(S[c][:] / denom[c]) (mode 1).
+ * d4w_row_median_f32: med[c] = np.median(v[c][0:per_row]).
+ * d4w_spectrocorr_f32:
+ *   raw[c][t] = sum_f sum_j S[c][f][t + j - off] K[f][j]  (zero outside the spectrogram), t < nout
+ *   out[c][t] = max(raw, 0) / (med[c] * nk);  zero_ends != 0 also forces out[c][0] = out[c][nout-1] = 0.
+ *   off = nk/2, nout = nt: detect.xcorr2d;  off = 0, nout = nt-nk+1, zero_ends: detect.xcorr.
+ *   S [nx][nf][nt], K [nf][nk], med [nx], out [nx][nout], all DEVICE float32.
+ * ------------------------------------------------------------------------------------------ */
+int d4w_stft_frames(int ns, int hop);
+int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, int n_fft, int hop,
+                     int bin_lo, int bin_hi, void* stream);
+int d4w_scale_rows_f32(float* S, int nx, size_t per_row, const float* denom, int mode, void* stream);
+int d4w_row_median_f32(const float* v, int nx, size_t per_row, float* med, void* stream);
+int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, int nk, int off,
+                        int nout, const float* med, int zero_ends, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Peak picking: scipy.signal.find_peaks(x[c], prominence=thr)[0] per row, replaces the loops of
+ * detect.pick_times / pick_times_env / process_corr / pick_times_par (detect.py:169-274; the
+ * envelope of the *_env variants is d4w_analytic_f32 mode 0).  Strict local maxima with plateaus
+ * reported at their middle sample, prominence with wlen=None, kept when prominence >= thr.
+ *   idx [nx][cap] int32: the first min(counts[c], cap) peak positions of row c in time order;
+ *   counts[c] = number of peaks found (may exceed cap: call again with a larger cap; ns/2 always suffices).
+ * ------------------------------------------------------------------------------------------ */
+int d4w_find_peaks_f32(const float* x, int nx, int ns, float prominence, int32_t* idx,
+                       int32_t* counts, int cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -558,6 +558,46 @@ def xcorr2d(spectro, kernel):
     return c / (np.median(S) * nk)                                              # detect.py:600
 
 
+def nxcorr2d(spectro, kernel):
+    """max over the frequency lag of the 2-D 'same' correlation / (std(S) std(K) n_t) -- detect.py:544-576.
+
+    scipy.signal.correlate(S, K, 'same')[a, t] = sum_{fk, j} S[a + fk - nfk//2, t + j - nk//2] K[fk, j].
+    """
+    S = np.asarray(spectro, dtype=float)
+    K = np.asarray(kernel, dtype=float)
+    nf, nt = S.shape
+    nfk, nk = K.shape
+    Sp = np.zeros((nf + nfk, nt + nk))
+    Sp[nfk // 2:nfk // 2 + nf, nk // 2:nk // 2 + nt] = S
+    corr = np.zeros((nf, nt))
+    for fk in range(nfk):
+        for j in range(nk):
+            corr += Sp[fk:fk + nf, j:j + nt] * K[fk, j]
+    corr /= np.std(S) * np.std(K) * nt                                          # detect.py:573
+    return np.max(corr, axis=0)
+
+
+def xcorr(t, f, Sxx, tvec, fvec, BlueKernel):
+    """Valid-lag correlation of the kernel with the spectrogram -- detect.py:605-647."""
+    nk, nfk = np.size(tvec), np.size(fvec)
+    S = np.asarray(Sxx, dtype=float)
+    K = np.asarray(BlueKernel, dtype=float)
+    n = np.size(t) - (nk - 1)
+    c = np.array([np.sum(K * S[:nfk, i:i + nk]) for i in range(n)])             # detect.py:634-638
+    c /= np.median(S) * nk
+    c[0] = 0
+    c[-1] = 0
+    c[c < 0] = 0
+    return [np.asarray(t)[int(nk / 2) - 1:-int(np.ceil(nk / 2))], c]
+
+
+def buildkernel_from_template(fmin, fmax, dur, fs, nperseg, nhop):
+    """Sliced normalised spectrogram of the windowed hyperbolic chirp -- detect.py:495-541."""
+    tpl = gen_hyperbolic_chirp(fmin, fmax, dur, fs)
+    tpl = tpl * np.hanning(len(tpl))
+    return get_sliced_nspectrogram(tpl, fs, fmin, fmax, nperseg, nhop)[0]
+
+
 def spectrocorr_params(fs, flims, kernel, win_size, overlap_pct):
     """Parameter derivation of compute_cross_correlogram_spectrocorr -- detect.py:680-696."""
     nperseg = int(win_size * fs)

@@ -119,6 +119,10 @@ def main():
         det["spectrocorr"] = dw.detect.compute_cross_correlogram_spectrocorr(
             x3, FS, [14., 30.], {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}, 0.8, 0.95)
     det["xcorr2d"] = dw.detect.xcorr2d(sp_s, ker)
+    det["nxcorr2d"] = dw.detect.nxcorr2d(sp_s, ker)
+    xs, xv = dw.detect.xcorr(stt, sff, sp_s, tvec, fvec, ker)
+    det["xcorr_t"], det["xcorr_v"] = np.asarray(xs), np.asarray(xv)
+    det["ker_tpl"] = dw.detect.buildkernel_from_template(17., 27., 0.8, FS, 160, 8)
     np.savez_compressed(os.path.join(HERE, "detect_12x2000.npz"), **det)
 
     # ------------------------------------------------------------------ reference's own pinned vectors

@@ -1,0 +1,248 @@
+"""Row spectral operator LOGIC (analytic signal, STFT magnitude, median select, spectrogram
+correlation, peak picking, get_fx) on the CPU emulator build: same HIP sources, same C ABI, host
+pointers, checked against the reference's golden outputs and the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.signal as sps
+
+from oracle import d4w_oracle as orc
+from tests.emu_util import load_emu, vp
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return load_emu()
+
+
+def rel(y, ref):
+    return np.max(np.abs(y - ref)) / np.max(np.abs(ref))
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.d4w_last_error()
+
+
+def analytic(lib, x, mode, fs=0.0, var=None):
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    y = np.empty((nx, ns - 1 if mode == 3 else ns), dtype=np.float32)
+    ok(lib, lib.d4w_analytic_f32(vp(xf), vp(y), nx, ns, mode, vp(var) if var is not None else None,
+                                 ctypes.c_double(fs), None))
+    return y
+
+
+@pytest.mark.parametrize("ns", [480, 360, 250, 77, 2 * 19 * 7])      # packed (even) and complex (odd) paths
+def test_envelope_and_hilbert(emu, ns):
+    rng = np.random.default_rng(ns)
+    x = rng.standard_normal((5, ns)) + 0.3
+    z = orc.hilbert(x)
+    assert rel(analytic(emu, x, 0), np.abs(z)) < TOL
+    assert rel(analytic(emu, x, 1), z.imag) < TOL
+    assert np.allclose(np.abs(z), np.abs(sps.hilbert(x, axis=1)))
+
+
+def test_snr_golden(emu, golden):
+    g = golden("fk_40x480.npz")
+    x = np.ascontiguousarray(g["x"], dtype=np.float32)
+    nx, ns = x.shape
+    var = np.empty(nx, dtype=np.float32)
+    for env, key in ((0, "snr"), (1, "snr_env")):
+        y = np.empty_like(x)
+        ok(emu, emu.d4w_snr_f32(vp(x), vp(y), nx, ns, env, vp(var), None))
+        ref = g[key]
+        fin = np.isfinite(ref) & (ref > -60)
+        assert np.max(np.abs(y[fin] - ref[fin])) < 2e-3            # dB; 1e-5 relative on the power ratio is 4e-5 dB
+    assert rel(var, np.var(g["x"], axis=1)) < TOL
+    # the reference's own value-pinning test (tests/test_dsp.py:136-141)
+    r = golden("ref_test_vectors.npz")
+    xi = np.ascontiguousarray(r["snr_in"], dtype=np.float32)
+    y = np.empty_like(xi)
+    v2 = np.empty(2, dtype=np.float32)
+    ok(emu, emu.d4w_snr_f32(vp(xi), vp(y), 2, 5, 0, vp(v2), None))
+    assert np.allclose(y, r["snr_expected"], atol=1e-4)
+
+
+def test_instant_freq_golden(emu, golden):
+    g = golden("fk_40x480.npz")
+    fs = float(g["fs"])
+    y = analytic(emu, g["x"][3:4], 3, fs=fs)[0]
+    ref = g["ifreq"]
+    assert y.shape == ref.shape
+    # wrapped phase increments: compare modulo fs (a +-pi increment may resolve to either sign)
+    d = np.abs(y - ref)
+    d = np.minimum(d, np.abs(d - fs))
+    assert np.max(d) < 2e-3 * fs / 2
+
+
+def test_get_fx_golden(emu, golden):
+    g = golden("fk_40x480.npz")
+    x = np.ascontiguousarray(g["x"][:, :400], dtype=np.float32)
+    nx, ns = x.shape
+    for nfft in (512, 300):
+        y = np.empty((nx, nfft), dtype=np.float32)
+        ok(emu, emu.d4w_fx_f32(vp(x), vp(y), nx, ns, nfft, None))
+        ref = g["fx"] if nfft == 512 else orc.get_fx(g["x"][:, :400], nfft)
+        assert rel(y, ref) < TOL
+
+
+def stft(lib, x, n_fft, hop, lo, hi):
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    nt = lib.d4w_stft_frames(ns, hop)
+    S = np.full((nx, hi - lo + 1, nt), np.nan, dtype=np.float32)
+    mx = np.empty(nx, dtype=np.float32)
+    ok(lib, lib.d4w_stft_mag_f32(vp(xf), vp(S), vp(mx), nx, ns, n_fft, hop, lo, hi, None))
+    return S, mx
+
+
+@pytest.mark.parametrize("n_fft,hop,ns", [(160, 8, 2000), (256, 12, 2000), (128, 25, 999), (64, 3, 130)])
+def test_stft_magnitude(emu, n_fft, hop, ns):
+    rng = np.random.default_rng(n_fft + hop)
+    x = rng.standard_normal((3, ns))
+    S, mx = stft(emu, x, n_fft, hop, 0, n_fft // 2)
+    for c in range(3):
+        ref = np.abs(orc.librosa_stft(x[c], n_fft=n_fft, hop_length=hop))
+        assert S[c].shape == ref.shape
+        assert rel(S[c], ref) < TOL
+        assert abs(mx[c] - ref.max()) < TOL * ref.max()
+    S2, mx2 = stft(emu, x, n_fft, hop, 5, 17)                       # sliced bins, max still over all bins
+    assert np.array_equal(S2, S[:, 5:18]) and np.array_equal(mx2, mx)
+
+
+def test_spectrogram_and_nspectrogram_golden(emu, golden):
+    g = golden("detect_12x2000.npz")
+    x, fs = g["x"], float(g["fs"])
+    # dsp.get_spectrogram(x[0], fs, nfft=256, overlap_pct=0.95) -> hop 12
+    S, mx = stft(emu, x[5:6], 256, 12, 0, 128)
+    per = S[0].size
+    ok(emu, emu.d4w_scale_rows_f32(vp(S), 1, ctypes.c_size_t(per), vp(mx), 1, None))
+    ref = g["spec_p"]
+    assert S[0].shape == ref.shape
+    # dB values: 1e-5 of the maximum in the linear domain (the tolerance of the magnitudes themselves)
+    assert np.max(np.abs(10.0 ** (S[0].astype(np.float64) / 20) - 10.0 ** (ref / 20))) < TOL
+    top = ref > -40
+    assert np.max(np.abs(S[0][top] - ref[top])) < 1e-3
+    # detect.get_sliced_nspectrogram(x[0], fs, 14, 30, 160, 8)
+    ff = np.linspace(0, fs / 2, 81)
+    keep = np.where((ff >= g["nspec_ff"][0] - 1e-9) & (ff <= g["nspec_ff"][-1] + 1e-9))[0]
+    S, mx = stft(emu, x[5:6], 160, 8, int(keep[0]), int(keep[-1]))
+    ok(emu, emu.d4w_scale_rows_f32(vp(S), 1, ctypes.c_size_t(S[0].size), vp(mx), 0, None))
+    assert rel(S[0], g["nspec"]) < TOL
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 4096, 19513, 1000])
+def test_row_median(emu, n):
+    rng = np.random.default_rng(n)
+    v = rng.standard_normal((3, n)).astype(np.float32)
+    v[1] = np.abs(v[1])
+    v[2] = np.round(v[2] * 2) / 2                                    # many duplicates
+    med = np.empty(3, dtype=np.float32)
+    ok(emu, emu.d4w_row_median_f32(vp(v), 3, ctypes.c_size_t(n), vp(med), None))
+    assert np.allclose(med, np.median(v.astype(np.float64), axis=1), rtol=1e-6, atol=0)
+
+
+def spectrocorr(lib, S, K, off, nout, zero_ends=0):
+    Sf = np.ascontiguousarray(S, dtype=np.float32)
+    Kf = np.ascontiguousarray(K, dtype=np.float32)
+    nx, nf, nt = Sf.shape
+    med = np.empty(nx, dtype=np.float32)
+    ok(lib, lib.d4w_row_median_f32(vp(Sf), nx, ctypes.c_size_t(nf * nt), vp(med), None))
+    out = np.empty((nx, nout), dtype=np.float32)
+    ok(lib, lib.d4w_spectrocorr_f32(vp(Sf), nx, nf, nt, vp(Kf), Kf.shape[1], off, nout, vp(med), zero_ends,
+                                    vp(out), None))
+    return out
+
+
+def test_xcorr2d_and_spectrocorr_golden(emu, golden):
+    g = golden("detect_12x2000.npz")
+    K = g["ker"]
+    nk = K.shape[1]
+    out = spectrocorr(emu, g["nspec"][None], K, nk // 2, g["nspec"].shape[1])
+    assert rel(out[0], g["xcorr2d"]) < TOL
+    # whole pipeline per channel: STFT (raw, sliced) -> median -> correlation; the max cancels
+    x, fs = g["x"], float(g["fs"])
+    ff = np.linspace(0, fs / 2, 81)
+    keep = np.where((ff >= g["nspec_ff"][0] - 1e-9) & (ff <= g["nspec_ff"][-1] + 1e-9))[0]
+    S, _ = stft(emu, x, 160, 8, int(keep[0]), int(keep[-1]))
+    out = spectrocorr(emu, S, K, nk // 2, S.shape[2])
+    assert rel(out, g["spectrocorr"]) < TOL
+    # odd kernel length and a wide (chunked over f) spectrogram vs the oracle
+    rng = np.random.default_rng(0)
+    S3 = np.abs(rng.standard_normal((2, 40, 700)))
+    K3 = rng.standard_normal((40, 24))
+    out = spectrocorr(emu, S3, K3, 24 // 2, 700)
+    for c in range(2):
+        assert rel(out[c], orc.xcorr2d(S3[c], K3)) < TOL
+
+
+def test_xcorr_valid_mode_golden(emu, golden):
+    """detect.xcorr (detect.py:605-647): valid lags, first / last value forced to zero."""
+    g = golden("detect_12x2000.npz")
+    K = g["ker"]
+    nk = K.shape[1]
+    nt = g["nspec"].shape[1]
+    out = spectrocorr(emu, g["nspec"][None], K, 0, nt - nk + 1, zero_ends=1)
+    assert out.shape[1] == g["xcorr_v"].shape[0]
+    assert rel(out[0], g["xcorr_v"]) < TOL and out[0, 0] == 0 and out[0, -1] == 0
+
+
+def test_find_peaks_matches_scipy(emu):
+    rng = np.random.default_rng(5)
+    nx, ns = 6, 1500
+    x = rng.standard_normal((nx, ns)).astype(np.float32)
+    x[1] = np.round(x[1] * 3) / 3                                    # plateaus
+    x[2, :] = 0.0                                                    # flat row: no peaks
+    x[3] = np.sin(np.arange(ns) * 0.05).astype(np.float32) + 0.01 * x[3]
+    x[4, -1] = 10.0                                                  # maximum on the edge
+    x[5, 0] = 10.0
+    for thr in (0.0, 0.8, 2.5):
+        cap = ns // 2 + 1
+        idx = np.full((nx, cap), -1, dtype=np.int32)
+        cnt = np.empty(nx, dtype=np.int32)
+        ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_float(thr), vp(idx), vp(cnt), cap, None))
+        for c in range(nx):
+            ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+            assert cnt[c] == len(ref), (thr, c)
+            assert np.array_equal(idx[c, :cnt[c]], ref)
+            if thr == 0.8 and c < 2:
+                assert np.array_equal(orc.find_peaks_prominence(x[c], thr), ref)
+    # capacity overflow reports the true count and writes only `cap` entries
+    idx = np.full((nx, 4), -1, dtype=np.int32)
+    cnt = np.empty(nx, dtype=np.int32)
+    ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_float(0.0), vp(idx), vp(cnt), 4, None))
+    ref0 = sps.find_peaks(x[0].astype(np.float64), prominence=0.0)[0]
+    assert cnt[0] == len(ref0) and np.array_equal(idx[0], ref0[:4])
+
+
+def test_pick_times_golden(emu, golden):
+    g = golden("detect_12x2000.npz")
+    thr = float(g["thr"])
+    for key, env in (("picks", False), ("picks_env", True)):
+        c = np.ascontiguousarray(g["corr_hf"], dtype=np.float32)
+        if env:
+            c = analytic(emu, c, 0)
+        nx, ns = c.shape
+        cap = ns // 2 + 1
+        idx = np.empty((nx, cap), dtype=np.int32)
+        cnt = np.empty(nx, dtype=np.int32)
+        ok(emu, emu.d4w_find_peaks_f32(vp(c), nx, ns, ctypes.c_float(thr), vp(idx), vp(cnt), cap, None))
+        got = np.asarray([(r, t) for r in range(nx) for t in idx[r, :cnt[r]]], dtype=np.int64).T.reshape(2, -1)
+        ref = g[key]
+        a = set(map(tuple, got.T.tolist()))
+        b = set(map(tuple, ref.T.tolist()))
+        # parity rule: identical except peaks whose prominence is within 1e-4*thr of thr
+        assert len(a ^ b) <= max(1, len(b) // 100), (key, sorted(a ^ b))
+
+
+def test_argument_errors(emu):
+    x = np.zeros((2, 64), dtype=np.float32)
+    y = np.zeros((2, 64), dtype=np.float32)
+    assert emu.d4w_analytic_f32(vp(x), vp(y), 2, 64, 7, None, ctypes.c_double(0), None) == -1
+    assert emu.d4w_analytic_f32(vp(x), vp(y), 2, 2 * 37, 0, None, ctypes.c_double(0), None) == -1   # prime 37
+    assert b"prime" in emu.d4w_last_error()
+    assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 15, 4, 0, 7, None) == -1                # odd n_fft
+    assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 16, 4, 0, 9, None) == -1                # bin range

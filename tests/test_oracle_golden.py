@@ -138,3 +138,14 @@ def test_spectro(d):
     assert rel(orc.xcorr2d(S, ker), d["xcorr2d"]) < 1e-12
     sc = orc.compute_cross_correlogram_spectrocorr(x, fs, [14., 30.], {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}, 0.8, 0.95)
     assert rel(sc, d["spectrocorr"]) < 1e-12
+
+
+def test_spectro_alternatives(d):
+    """The reference's unused correlation variants (detect.py:495-576,605-647)."""
+    fs = float(d["fs"])
+    S, sff, stt = d["nspec"], d["nspec_ff"], d["nspec_tt"]
+    ker, tvec = d["ker"], d["ker_tvec"]
+    assert rel(orc.nxcorr2d(S, ker), d["nxcorr2d"]) < 1e-11
+    ts, cv = orc.xcorr(stt, sff, S, tvec, sff, ker)
+    assert np.allclose(ts, d["xcorr_t"]) and rel(cv, d["xcorr_v"]) < 1e-12
+    assert rel(orc.buildkernel_from_template(17., 27., 0.8, fs, 160, 8), d["ker_tpl"]) < 1e-12

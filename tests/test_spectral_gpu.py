@@ -1,0 +1,161 @@
+"""GPU parity tests of the row spectral operators through the Python mirror of the reference
+namespace (which calls the C ABI): analytic signal / SNR / instantaneous frequency / get_fx,
+spectrograms, spectrogram correlation and peak picking, vs the reference's golden outputs
+(tests/golden/*.npz) and the CPU oracle.
+
+Tolerance (north star): max|y - y_ref| <= 1e-5 * max|y_ref| with float32 arithmetic; picks must be
+the identical index sets except peaks whose prominence is within 1e-4 * threshold of the threshold."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+FS = 200.0
+KERNEL = {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}
+
+
+def rel(y, ref):
+    return float(np.max(np.abs(np.asarray(y, dtype=np.float64) - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import das4whales_amd as dw_
+    return dw_
+
+
+def test_snr_fx_ifreq_golden(dw, golden):
+    g = golden("fk_40x480.npz")
+    x = g["x"]
+    for env, key in ((False, "snr"), (True, "snr_env")):
+        y = dw.dsp.snr_tr_array(x, env=env)
+        assert y.shape == x.shape and y.dtype == np.float64
+        lin, ref = 10.0 ** (y / 10), 10.0 ** (g[key] / 10)          # power ratios: the quantity under the log
+        assert np.max(np.abs(lin - ref)) / np.max(ref) < TOL
+        top = g[key] > -40
+        assert np.max(np.abs(y[top] - g[key][top])) < 1e-3
+    r = golden("ref_test_vectors.npz")                              # reference tests/test_dsp.py:136-141
+    assert np.allclose(dw.dsp.snr_tr_array(r["snr_in"]), r["snr_expected"], atol=1e-4)
+    assert rel(dw.dsp.get_fx(x[:, :400], 512), g["fx"]) < TOL
+    fi = dw.dsp.instant_freq(x[3], FS)
+    assert fi.shape == g["ifreq"].shape
+    d = np.abs(fi - g["ifreq"])
+    d = np.minimum(d, np.abs(d - FS))                               # a +-pi phase step may take either sign
+    assert np.max(d) < 2e-3 * FS / 2
+    z = orc.hilbert(x)
+    assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL
+    assert rel(dw.dsp.hilbert_imag(x[7]), z[7].imag) < TOL
+    xo = x[:, :479]                                                 # odd length: full complex transform
+    assert rel(dw.dsp.envelope(xo), np.abs(orc.hilbert(xo))) < TOL
+
+
+def test_envelope_config1_rows(dw):
+    """12 000-sample rows (BASELINE configs[1] geometry), CUDA tensor in -> CUDA tensor out."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((300, 12000))
+    xt = torch.from_numpy(x).cuda().float()
+    e = dw.dsp.envelope(xt)
+    assert e.is_cuda and e.dtype == torch.float32
+    ref = orc.envelope(x[:40])
+    assert rel(e[:40].cpu().numpy(), ref) < TOL
+    with pytest.raises(ValueError, match="single-workgroup"):
+        dw.dsp.envelope(torch.zeros((2, 120000), device="cuda"))
+
+
+def test_spectrograms_golden(dw, golden):
+    g = golden("detect_12x2000.npz")
+    x = g["x"]
+    p, tt, ff = dw.dsp.get_spectrogram(x[5], FS, nfft=256, overlap_pct=0.95)
+    assert p.shape == g["spec_p"].shape
+    assert np.allclose(tt, g["spec_tt"]) and np.allclose(ff, g["spec_ff"])
+    assert np.max(np.abs(10.0 ** (p / 20) - 10.0 ** (g["spec_p"] / 20))) < TOL
+    S, sff, stt = dw.detect.get_sliced_nspectrogram(x[5], FS, 14., 30., 160, 8)
+    assert rel(S, g["nspec"]) < TOL
+    assert np.allclose(sff, g["nspec_ff"]) and np.allclose(stt, g["nspec_tt"])
+    tvec, fvec, ker = dw.detect.buildkernel(27., 17., 4., 0.8, sff, stt, FS, 14., 30.)
+    assert np.allclose(ker, g["ker"], rtol=1e-13, atol=1e-15) and np.allclose(tvec, g["ker_tvec"])
+    assert rel(dw.detect.buildkernel_from_template(17., 27., 0.8, FS, 160, 8), g["ker_tpl"]) < TOL
+
+
+def test_spectrocorr_golden(dw, golden):
+    g = golden("detect_12x2000.npz")
+    assert rel(dw.detect.xcorr2d(g["nspec"], g["ker"]), g["xcorr2d"]) < TOL
+    sc = dw.detect.compute_cross_correlogram_spectrocorr(g["x"], FS, [14., 30.], KERNEL, 0.8, 0.95)
+    assert sc.shape == g["spectrocorr"].shape
+    assert rel(sc, g["spectrocorr"]) < TOL
+    ts, cv = dw.detect.xcorr(g["nspec_tt"], g["nspec_ff"], g["nspec"], g["ker_tvec"], g["nspec_ff"], g["ker"])
+    assert np.allclose(ts, g["xcorr_t"]) and rel(cv, g["xcorr_v"]) < TOL
+    assert rel(dw.detect.nxcorr2d(g["nspec"], g["ker"]), g["nxcorr2d"]) < TOL
+
+
+def test_spectrocorr_config1_block(dw):
+    """4000 x 12000 block (detector settings of scripts/main_spectrodetect.py): all channels in one
+    STFT / median / correlation launch vs the per-channel oracle on a row subset."""
+    nx, ns = 4000, 12000
+    x = orc.synth_block(nx, ns, fs=FS, step=4, seed=1234, n_calls=6, n_waves=10) * 1e9
+    sc = dw.detect.compute_cross_correlogram_spectrocorr(x, FS, [14., 30.], KERNEL, 0.8, 0.95)
+    assert sc.shape == (nx, 1 + ns // 8)
+    rows = [0, 1, 777, 2048, 3999]
+    ref = orc.compute_cross_correlogram_spectrocorr(x[rows], FS, [14., 30.], KERNEL, 0.8, 0.95)
+    err = rel(sc[rows], ref)
+    print("spectrocorr 4000x12000 (5 rows): rel err %.3e" % err)
+    assert err < TOL
+
+
+def _sets(picks):
+    return set((int(r), int(t)) for r, row in enumerate(picks) for t in row)
+
+
+def test_picks_golden(dw, golden):
+    g = golden("detect_12x2000.npz")
+    thr = float(g["thr"])
+    pk = dw.detect.pick_times(g["corr_hf"], thr)
+    pe = dw.detect.pick_times_env(g["corr_hf"], thr)
+    assert len(pk) == 12 and all(p.dtype == np.int64 for p in pk)
+    assert np.array_equal(dw.detect.convert_pick_times(pk), g["picks"])
+    assert np.array_equal(dw.detect.convert_pick_times(pe), g["picks_env"])
+    assert np.array_equal(dw.detect.process_corr(g["corr_hf"][4], thr), pe[4])
+    par = dw.detect.pick_times_par(g["corr_hf"], thr)
+    assert all(np.array_equal(a, b) for a, b in zip(par, pe))
+    sel = dw.detect.select_picked_times(dw.detect.convert_pick_times(pe), 1.0, 8.0, FS)
+    assert np.array_equal(sel[0], g["picks_env_sel0"]) and np.array_equal(sel[1], g["picks_env_sel1"])
+
+
+def test_picks_random_rows_vs_scipy(dw):
+    """Noise rows, plateaus, flat rows, edge maxima; also more peaks than the first capacity guess."""
+    import scipy.signal as sps
+    rng = np.random.default_rng(5)
+    nx, ns = 64, 12000
+    x = rng.standard_normal((nx, ns)).astype(np.float32)
+    x[1] = np.round(x[1] * 3) / 3
+    x[2] = 0.0
+    x[4, -1] = 10.0
+    x[5, 0] = 10.0
+    for thr in (0.0, 1.5, 4.0):
+        got = dw.detect.pick_times(x, thr)
+        for c in range(nx):
+            ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+            assert np.array_equal(got[c], ref), (thr, c)
+
+
+def test_pick_pipeline_config1(dw):
+    """f-k -> matched filter -> envelope picks on a 1000 x 12000 synthetic block: same picks as the
+    float64 oracle pipeline except at prominences within 1e-4 of the threshold."""
+    nx, ns = 1000, 12000
+    x = orc.synth_block(nx, ns, fs=FS, step=4, seed=99, n_calls=5, n_waves=6) * 1e9
+    x = orc.bp_filt(x, FS, 14, 30)
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    ref_c = orc.compute_cross_correlogram(x, hf)
+    thr = 0.45 * float(np.max(ref_c))
+    ref_p = orc.pick_times_env(ref_c, thr)
+    c = dw.detect.compute_cross_correlogram(x, hf)
+    got = dw.detect.pick_times_env(c, thr)
+    a, b = _sets(got), _sets(ref_p)
+    print("picks: %d vs %d reference, symmetric difference %d" % (len(a), len(b), len(a ^ b)))
+    assert len(b) > 50
+    assert len(a ^ b) <= max(2, len(b) // 200)
