@@ -59,7 +59,7 @@ def _load():
         "d4w_row_median_f32": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_void_p]),
         "d4w_spectrocorr_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_int, c_void_p, c_void_p]),
-        "d4w_find_peaks_f32": (c_int, [c_void_p, c_int, c_int, ctypes.c_float, c_void_p, c_void_p, c_int, c_void_p]),
+        "d4w_find_peaks_f32": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_int, c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kScTile) void spectro_corr(const float* __restrict_
 // One workgroup per row; a thread owns a candidate left edge, accepted peaks are written in time
 // order through a workgroup prefix sum.  idx[row][0..min(count, cap)) ; counts[row] = count.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, float thr,
+__global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
                                                               int* __restrict__ idx, int* __restrict__ counts,
                                                               int cap) {
     __shared__ int wave_tot[kSpThreads / 64];
@@ -481,7 +481,8 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
                     if (u > v) break;
                     rmin = fminf(rmin, u);
                 }
-                if (v - fmaxf(lmin, rmin) >= thr) peak = mid;
+                // float64 like scipy: float32 samples are exact in float64, a float32 subtraction is not
+                if ((double)v - (double)fmaxf(lmin, rmin) >= thr) peak = mid;
             }
         }
         // ordered compaction: inclusive scan inside the wave, then across the waves
@@ -641,7 +642,7 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
     return D4W_OK;
 }
 
-int d4w_find_peaks_f32(const float* x, int nx, int ns, float prominence, int32_t* idx, int32_t* counts, int cap,
+int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx, int32_t* counts, int cap,
                        void* stream) {
     if (!x || !idx || !counts || nx < 1 || ns < 1 || cap < 1) return fail(D4W_EINVAL, "bad argument");
     D4W_LAUNCH(find_peaks_prom, dim3(nx), dim3(kSpThreads), 0, stream, x, ns, prominence, (int*)idx, (int*)counts, cap);

@@ -201,11 +201,12 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
  * Peak picking: scipy.signal.find_peaks(x[c], prominence=thr)[0] per row, replaces the loops of
  * detect.pick_times / pick_times_env / process_corr / pick_times_par (detect.py:169-274; the
  * envelope of the *_env variants is d4w_analytic_f32 mode 0).  Strict local maxima with plateaus
- * reported at their middle sample, prominence with wlen=None, kept when prominence >= thr.
+ * reported at their middle sample, prominence with wlen=None, kept when prominence >= thr
+ * (compared in float64, as SciPy does on the float64 view of the same samples).
  *   idx [nx][cap] int32: the first min(counts[c], cap) peak positions of row c in time order;
  *   counts[c] = number of peaks found (may exceed cap: call again with a larger cap; ns/2 always suffices).
  * ------------------------------------------------------------------------------------------ */
-int d4w_find_peaks_f32(const float* x, int nx, int ns, float prominence, int32_t* idx,
+int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx,
                        int32_t* counts, int cap, void* stream);
 
 #ifdef __cplusplus

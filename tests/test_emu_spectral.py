@@ -199,11 +199,11 @@ def test_find_peaks_matches_scipy(emu):
     x[3] = np.sin(np.arange(ns) * 0.05).astype(np.float32) + 0.01 * x[3]
     x[4, -1] = 10.0                                                  # maximum on the edge
     x[5, 0] = 10.0
-    for thr in (0.0, 0.8, 2.5):
+    for thr in (0.0, 0.8, 2.5, 4.0 / 3.0, 2.0):                     # the last two sit exactly on plateau prominences
         cap = ns // 2 + 1
         idx = np.full((nx, cap), -1, dtype=np.int32)
         cnt = np.empty(nx, dtype=np.int32)
-        ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_float(thr), vp(idx), vp(cnt), cap, None))
+        ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
         for c in range(nx):
             ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
             assert cnt[c] == len(ref), (thr, c)
@@ -213,7 +213,7 @@ def test_find_peaks_matches_scipy(emu):
     # capacity overflow reports the true count and writes only `cap` entries
     idx = np.full((nx, 4), -1, dtype=np.int32)
     cnt = np.empty(nx, dtype=np.int32)
-    ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_float(0.0), vp(idx), vp(cnt), 4, None))
+    ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(0.0), vp(idx), vp(cnt), 4, None))
     ref0 = sps.find_peaks(x[0].astype(np.float64), prominence=0.0)[0]
     assert cnt[0] == len(ref0) and np.array_equal(idx[0], ref0[:4])
 
@@ -229,7 +229,7 @@ def test_pick_times_golden(emu, golden):
         cap = ns // 2 + 1
         idx = np.empty((nx, cap), dtype=np.int32)
         cnt = np.empty(nx, dtype=np.int32)
-        ok(emu, emu.d4w_find_peaks_f32(vp(c), nx, ns, ctypes.c_float(thr), vp(idx), vp(cnt), cap, None))
+        ok(emu, emu.d4w_find_peaks_f32(vp(c), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
         got = np.asarray([(r, t) for r in range(nx) for t in idx[r, :cnt[r]]], dtype=np.int64).T.reshape(2, -1)
         ref = g[key]
         a = set(map(tuple, got.T.tolist()))
