@@ -49,6 +49,8 @@ def _load():
         "d4w_row_stats_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
+        "d4w_xcorr_lens_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
         "d4w_analytic_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_row_var_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
         "d4w_snr_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

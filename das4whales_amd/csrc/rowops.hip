@@ -4,6 +4,7 @@
 // detect.shift_xcorr, reference detect.py:96-166).  See DESIGN.md "band-pass" and
 // "matched filter" for the data layout and the roofline that bounds each kernel.
 #include <algorithm>
+#include <cstdlib>
 
 #include "d4w_internal.h"
 
@@ -178,35 +179,50 @@ __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restric
 // =============================================================================================
 // matched filter: direct-form correlation, NT templates fused over one read of x
 //   y_t[c][k] = g[c] * sum_n (x[c][n+k] - m[c]) * taps[t][n]
-// VALU-bound (2*(L_0 + L_1) flop per 4 + 4*NT bytes), and on gfx950 a scalar
-// v_fma_f32 costs the same 4 issue cycles as a packed v_pk_fma_f32 (measured: VALU 100 % busy at
-// 4 cycles per instruction), so the kernel is built around packed FMAs:
-//   * a workgroup owns TWO rows x kXcTile lags; the de-meaned pieces sit in LDS interleaved as
+// VALU-bound (2*(L_0 + L_1) flop per 4 + 4*NT bytes).  On gfx950 a v_pk_fma_f32 issues
+// in the same 4 cycles as a scalar v_fma_f32, so the kernel is built around packed FMAs, and a
+// ds_read_b128 of a full wave occupies the CU's LDS pipe for 8 cycles, so the register blocking is
+// chosen to keep LDS traffic far below the FMA issue rate:
+//   * a workgroup owns TWO rows x (256 R) lags; the de-meaned pieces sit in LDS interleaved as
 //     (xA[j], xB[j]) pairs, so every v_pk_fma_f32 advances the same lag of both rows and the tap is
 //     one broadcast SGPR (taps are wave-uniform scalar loads);
-//   * a thread keeps two groups of 2 consecutive lags (kXcTile/2 apart) in registers and slides a
-//     16-byte window over the taps: one conflict-free ds_read_b128 (lane stride 16 B) per group
-//     per two taps, i.e. per 4*NT packed FMAs.
+//   * a thread owns R CONSECUTIVE lags and slides an (R + 2)-sample register window over the taps:
+//     one ds_read_b128 (two new samples of both rows) per 2 taps = per 2 R NT packed FMAs
+//     (R = 8, NT = 2: 32 FMAs, i.e. 128 issue cycles per 8 LDS cycles);
+//   * the window of thread t starts at float4 index (R/2) t, a 16 R-byte lane stride that would be
+//     an (R/2)-way bank conflict; the tile is therefore stored residue-major: float4 index
+//     f = (R/2) q + r lives at r * PITCH + q, which turns every window read into consecutive
+//     lanes -> consecutive 16-byte words (PITCH = 4 mod 16 keeps the staging writes conflict-free);
+//   * the two templates may have different supports: taps beyond the shorter one are only
+//     applied to the longer one (HF 136 / LF 156 taps: 6 % fewer FMAs than padding both to 156).
 // =============================================================================================
 constexpr int kXcThreads = 256;
-constexpr int kXcGroups = 2;
-constexpr int kXcTile = kXcThreads * 2 * kXcGroups;   // lags per workgroup (1024)
 constexpr int kXcTapBlock = 256;                      // taps per LDS staging round
 
-template <int NT>
+template <int R>
+struct XcGeom {
+    static constexpr int H = R / 2;                                   // float4 per R samples
+    static constexpr int TILE = kXcThreads * R;                       // lags per workgroup
+    static constexpr int NQ = kXcThreads + kXcTapBlock / R + 1;       // float4 columns per residue row
+    static constexpr int PITCH = ((NQ + 15) / 16) * 16 + 4;
+};
+
+template <int NT, int R>
 __global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict__ x, int nx, int ns,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ maxabs,
-                                                        const float* __restrict__ taps, int ltaps,
+                                                        const float* __restrict__ taps0,
+                                                        const float* __restrict__ taps1, int l_both, int l_long,
                                                         float* __restrict__ y0, float* __restrict__ y1) {
-    // xs4[f] = (xA[2f], xB[2f], xA[2f+1], xB[2f+1])
-    __shared__ float4 xs4[(kXcTile + kXcTapBlock) / 2 + 2];
+    typedef XcGeom<R> G;
+    constexpr int H = G::H, PITCH = G::PITCH;
+    __shared__ float4 xs4[H * PITCH];
     float2* xs2 = reinterpret_cast<float2*>(xs4);
     const int tid = threadIdx.x;
     const int rowA = 2 * blockIdx.y;
     const bool hasB = (rowA + 1 < nx);
     const int rowB = hasB ? rowA + 1 : rowA;
-    const int k0 = blockIdx.x * kXcTile;
+    const int k0 = blockIdx.x * G::TILE;
     const float* pa = x + (size_t)rowA * ns;
     const float* pb = x + (size_t)rowB * ns;
     const float ma = mean ? mean[rowA] : 0.f, mb = mean ? mean[rowB] : 0.f;
@@ -216,70 +232,100 @@ __global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict_
         ga = (a > 0.f) ? 1.0f / a : 0.f;
         gb = (b > 0.f) ? 1.0f / b : 0.f;
     }
-    v2f acc[NT][kXcGroups][2];
+    v2f acc[NT][R];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < kXcGroups; ++g) acc[t][g][0] = acc[t][g][1] = v2_make(0.f, 0.f);
+        for (int r = 0; r < R; ++r) acc[t][r] = v2_make(0.f, 0.f);
 
-    for (int n0 = 0; n0 < ltaps; n0 += kXcTapBlock) {
-        const int nb = min(kXcTapBlock, ltaps - n0);          // taps in this round (multiple of 4)
-        const int need = kXcTile + nb;                        // samples k0+n0 .. k0+n0+need-1
+    const int ltot = (NT == 2) ? l_long : l_both;
+    for (int n0 = 0; n0 < ltot; n0 += kXcTapBlock) {
+        const int nb = min(kXcTapBlock, ltot - n0);           // taps in this round (even)
+        const int need = G::TILE + nb;                        // samples k0+n0 .. k0+n0+need-1
         for (int j = tid; j < need; j += kXcThreads) {
             const int i = k0 + n0 + j;
             float2 v = make_float2(0.f, 0.f);                 // beyond the row: zero padding
             if (i < ns) v = make_float2(pa[i] - ma, pb[i] - mb);
-            xs2[j] = v;
+            const int f = j >> 1, q = f / H, rr = f - q * H;
+            xs2[2 * (rr * PITCH + q) + (j & 1)] = v;
         }
         __syncthreads();
-        const float4* win[kXcGroups];
-        float4 cur[kXcGroups];
+        v2f w[R + 2];
 #pragma unroll
-        for (int g = 0; g < kXcGroups; ++g) {
-            win[g] = xs4 + tid + g * (kXcTile / (2 * kXcGroups));
-            cur[g] = lds_read4(win[g]);
+        for (int s = 0; s < H; ++s) {
+            const float4 c = lds_read4(xs4 + s * PITCH + tid);
+            w[2 * s] = v2_make(c.x, c.y);
+            w[2 * s + 1] = v2_make(c.z, c.w);
         }
-        for (int tb = 0; tb < nb / 2; ++tb) {                 // two taps per step
-            float c[NT][2];
+        const float4* wbase = xs4 + tid;
+        const int steps = nb / 2;
+        const int steps_both = (NT == 2) ? max(0, min(nb, l_both - n0)) / 2 : steps;
+        // one step = two taps: fetch the two samples that enter the window, 2 R FMAs per template
+        auto fetch = [&](int st) {
+            const int s = H + st;
+            const float4 c = lds_read4(wbase + (s % H) * PITCH + s / H);
+            w[R] = v2_make(c.x, c.y);
+            w[R + 1] = v2_make(c.z, c.w);
+        };
+        auto slide = [&]() {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                c[t][0] = taps[(size_t)t * ltaps + n0 + 2 * tb];
-                c[t][1] = taps[(size_t)t * ltaps + n0 + 2 * tb + 1];
-            }
+            for (int i = 0; i < R; ++i) w[i] = w[i + 2];
+        };
+        int st = 0;
+#pragma unroll R / 2 + 1
+        for (; st < steps_both; ++st) {
+            fetch(st);
+            const float a0 = taps0[n0 + 2 * st], a1 = taps0[n0 + 2 * st + 1];
+            float b0 = 0.f, b1 = 0.f;
+            if (NT == 2) { b0 = taps1[n0 + 2 * st]; b1 = taps1[n0 + 2 * st + 1]; }
 #pragma unroll
-            for (int g = 0; g < kXcGroups; ++g) {
-                const float4 nxt = lds_read4(win[g] + tb + 1);
-                const v2f w0 = v2_make(cur[g].x, cur[g].y), w1 = v2_make(cur[g].z, cur[g].w),
-                          w2 = v2_make(nxt.x, nxt.y);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t][g][0] = v2_fma(w0, c[t][0], acc[t][g][0]);
-                    acc[t][g][1] = v2_fma(w1, c[t][0], acc[t][g][1]);
-                    acc[t][g][0] = v2_fma(w1, c[t][1], acc[t][g][0]);
-                    acc[t][g][1] = v2_fma(w2, c[t][1], acc[t][g][1]);
+            for (int r = 0; r < R; ++r) {
+                acc[0][r] = v2_fma(w[r], a0, acc[0][r]);
+                acc[0][r] = v2_fma(w[r + 1], a1, acc[0][r]);
+                if (NT == 2) {
+                    acc[NT - 1][r] = v2_fma(w[r], b0, acc[NT - 1][r]);
+                    acc[NT - 1][r] = v2_fma(w[r + 1], b1, acc[NT - 1][r]);
                 }
-                cur[g] = nxt;
+            }
+            slide();
+        }
+        if (NT == 2) {
+#pragma unroll R / 2 + 1
+            for (; st < steps; ++st) {                        // the longer template's extra taps
+                fetch(st);
+                const float b0 = taps1[n0 + 2 * st], b1 = taps1[n0 + 2 * st + 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[NT - 1][r] = v2_fma(w[r], b0, acc[NT - 1][r]);
+                    acc[NT - 1][r] = v2_fma(w[r + 1], b1, acc[NT - 1][r]);
+                }
+                slide();
             }
         }
         __syncthreads();
     }
+    const int k = k0 + R * tid;
+    if (k >= ns) return;
 #pragma unroll
-    for (int g = 0; g < kXcGroups; ++g) {
-        const int k = k0 + g * (kXcTile / kXcGroups) + 2 * tid;
-        if (k >= ns) continue;
+    for (int t = 0; t < NT; ++t) {
+        float* base = (t == 0 ? y0 : y1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float* base = (t == 0 ? y0 : y1);
-            const float a0 = v2_x(acc[t][g][0]) * ga, a1 = v2_x(acc[t][g][1]) * ga;
-            const float b0 = v2_y(acc[t][g][0]) * gb, b1 = v2_y(acc[t][g][1]) * gb;
-            float* oa = base + (size_t)rowA * ns + k;
-            float* ob = base + (size_t)rowB * ns + k;
-            const bool pair = (k + 1 < ns);
-            if (pair && ((((size_t)rowA * ns + k) & 1) == 0)) *reinterpret_cast<float2*>(oa) = make_float2(a0, a1);
-            else { oa[0] = a0; if (pair) oa[1] = a1; }
-            if (hasB) {
-                if (pair && ((((size_t)rowB * ns + k) & 1) == 0)) *reinterpret_cast<float2*>(ob) = make_float2(b0, b1);
-                else { ob[0] = b0; if (pair) ob[1] = b1; }
+        for (int rowsel = 0; rowsel < 2; ++rowsel) {
+            if (rowsel == 1 && !hasB) break;
+            const size_t off = (size_t)(rowsel ? rowB : rowA) * ns + k;
+            const float g = rowsel ? gb : ga;
+            float o[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) o[r] = (rowsel ? v2_y(acc[t][r]) : v2_x(acc[t][r])) * g;
+            float* dst = base + off;
+            if (k + R <= ns && (off & 3) == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r += 4)
+                    *reinterpret_cast<float4*>(dst + r) = make_float4(o[r], o[r + 1], o[r + 2], o[r + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (k + r < ns) dst[r] = o[r];
             }
         }
     }
@@ -306,6 +352,20 @@ static int sos_launch(int nsec, dim3 grid, void* stream, const SosArgs& A, const
             return fail(D4W_EINVAL, "nsec = %d not in 1..%d", nsec, kSosMaxSec);
     }
     D4W_HIP(hipGetLastError());
+    return D4W_OK;
+}
+
+template <int R>
+static int xcorr_launch(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps0,
+                        const float* taps1, int ntpl, int l_both, int l_long, float* y0, float* y1, void* stream) {
+    const dim3 grid(ceil_div(ns, XcGeom<R>::TILE), ceil_div(nx, 2));
+    if (grid.y > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
+    if (ntpl == 1)
+        D4W_LAUNCH((xcorr_fir<1, R>), grid, dim3(kXcThreads), 0, stream, x, nx, ns, mean, maxabs, taps0, taps1, l_both,
+                   l_long, y0, y1);
+    else
+        D4W_LAUNCH((xcorr_fir<2, R>), grid, dim3(kXcThreads), 0, stream, x, nx, ns, mean, maxabs, taps0, taps1, l_both,
+                   l_long, y0, y1);
     return D4W_OK;
 }
 
@@ -350,18 +410,28 @@ int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs
     return D4W_OK;
 }
 
-int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
-                  int ntpl, int ltaps, float* y0, float* y1, void* stream) {
+int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
+                       int ntpl, int ltaps, int len0, int len1, float* y0, float* y1, void* stream) {
     if (!x || !taps || !y0 || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
     if (ltaps < 4 || (ltaps & 3)) return fail(D4W_EINVAL, "ltaps = %d must be a positive multiple of 4", ltaps);
-    const dim3 grid(ceil_div(ns, kXcTile), ceil_div(nx, 2));
-    if (grid.y > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
-    if (ntpl == 1)
-        D4W_LAUNCH(xcorr_fir<1>, grid, dim3(kXcThreads), 0, stream, x, nx, ns, mean, maxabs, taps, ltaps, y0, y1);
-    else
-        D4W_LAUNCH(xcorr_fir<2>, grid, dim3(kXcThreads), 0, stream, x, nx, ns, mean, maxabs, taps, ltaps, y0, y1);
-    return D4W_OK;
+    if (len0 < 1 || len0 > ltaps || (ntpl == 2 && (len1 < 1 || len1 > ltaps)))
+        return fail(D4W_EINVAL, "template supports (%d, %d) must lie in 1..ltaps = %d", len0, len1, ltaps);
+    // taps are zero padded to ltaps (a multiple of 4), so rounding a support up to even stays in range
+    int l0 = (len0 + 1) & ~1, l1 = (len1 + 1) & ~1;
+    const float *t0 = taps, *t1 = taps + ltaps;
+    if (ntpl == 1) { l1 = l0; t1 = t0; }
+    else if (l0 > l1) {                                   // kernel convention: template 0 is the shorter one
+        std::swap(l0, l1); std::swap(t0, t1); std::swap(y0, y1);
+    }
+    static const int r_env = [] { const char* v = getenv("D4W_XC_R"); return v ? atoi(v) : 0; }();   // tuning knob
+    if (r_env == 4) return xcorr_launch<4>(x, nx, ns, mean, maxabs, t0, t1, ntpl, l0, l1, y0, y1, stream);
+    return xcorr_launch<8>(x, nx, ns, mean, maxabs, t0, t1, ntpl, l0, l1, y0, y1, stream);
+}
+
+int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
+                  int ntpl, int ltaps, float* y0, float* y1, void* stream) {
+    return d4w_xcorr_lens_f32(x, nx, ns, mean, maxabs, taps, ntpl, ltaps, ltaps, ltaps, y0, y1, stream);
 }
 
 }  // extern "C"

@@ -70,10 +70,11 @@ def _xcorr_device(x, taps_list, normalize):
             grp = taps_list[i:i + 2]
             taps, lt = _taps_tensor(grp, x.device)
             ys = [torch.empty_like(x) for _ in grp]
-            check(lib.d4w_xcorr_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
-                                    dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
-                                    dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
-                                    dev.stream_ptr(x)))
+            check(lib.d4w_xcorr_lens_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
+                                         dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
+                                         len(grp[0]), len(grp[-1]),
+                                         dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
+                                         dev.stream_ptr(x)))
             outs.extend(ys)
     return outs
 

@@ -123,6 +123,11 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
 int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream);
 int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
                   const float* taps, int ntpl, int ltaps, float* y0, float* y1, void* stream);
+/* Same, with the true support of each template (len_t <= ltaps, taps[t][len_t..ltaps) == 0): taps
+ * beyond the shorter support are only applied to the longer template (HF 136 / LF 156 samples). */
+int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+                       const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
+                       float* y1, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * f-k mask design on the device (one-off per shape), float32 masks on the fftshift-ed (k, f)

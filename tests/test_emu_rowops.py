@@ -74,7 +74,7 @@ def test_sosfiltfilt_errors(emu):
     assert rc == -1 and b"padlen, which is 51" in emu.d4w_last_error()
 
 
-def xcorr_emu(lib, x, taps_list, normalize=True):
+def xcorr_emu(lib, x, taps_list, normalize=True, lens=True):
     xf = np.ascontiguousarray(x, dtype=np.float32)
     nx, ns = xf.shape
     lt = max(4, -(-max(len(t) for t in taps_list) // 4) * 4)
@@ -86,8 +86,13 @@ def xcorr_emu(lib, x, taps_list, normalize=True):
     if normalize:
         assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
     ys = [np.empty_like(xf) for _ in taps_list]
-    rc = lib.d4w_xcorr_f32(vp(xf), nx, ns, vp(mean) if normalize else None, vp(mx) if normalize else None,
-                           vp(taps), len(taps_list), lt, vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None, None)
+    if lens:
+        rc = lib.d4w_xcorr_lens_f32(vp(xf), nx, ns, vp(mean) if normalize else None, vp(mx) if normalize else None,
+                                    vp(taps), len(taps_list), lt, len(taps_list[0]), len(taps_list[-1]),
+                                    vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None, None)
+    else:
+        rc = lib.d4w_xcorr_f32(vp(xf), nx, ns, vp(mean) if normalize else None, vp(mx) if normalize else None,
+                               vp(taps), len(taps_list), lt, vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None, None)
     assert rc == 0, lib.d4w_last_error()
     return ys, mean, mx
 
@@ -108,6 +113,24 @@ def test_cross_correlogram_golden(emu, golden):
     assert rel(yl, d["corr_lf"]) < TOL
     (y1,), _, _ = xcorr_emu(emu, d["x"], [norm_taps(d["hf"])])
     assert np.array_equal(y1, yh)                       # fused and single-template paths agree bit for bit
+    # longer template first (the kernel orders them itself), and the padded-length entry point
+    (zl, zh), _, _ = xcorr_emu(emu, d["x"], [norm_taps(d["lf"]), norm_taps(d["hf"])])
+    assert np.array_equal(zl, yl) and np.array_equal(zh, yh)
+    (ph, pl), _, _ = xcorr_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])], lens=False)
+    assert np.array_equal(ph, yh) and np.array_equal(pl, yl)
+
+
+@pytest.mark.parametrize("nx,ns,l0,l1", [(3, 2100, 7, 300), (2, 4097, 136, 156), (5, 999, 33, 1), (1, 64, 64, 10)])
+def test_xcorr_ragged_shapes(emu, nx, ns, l0, l1):
+    """Odd row counts (row pairs), rows that are not a multiple of the lag tile or of 4, supports that
+    are odd / longer than one tap round / longer than the tile remainder, both environment tilings."""
+    rng = np.random.default_rng(ns + l0)
+    x = rng.standard_normal((nx, ns))
+    t0, t1 = rng.standard_normal(l0), rng.standard_normal(l1)
+    (y0, y1), _, _ = xcorr_emu(emu, x, [t0, t1], normalize=False)
+    for c in range(nx):
+        assert rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - l0)))) < TOL
+        assert rel(y1[c], orc.shift_xcorr(x[c], np.pad(t1, (0, ns - l1)))) < TOL
 
 
 def test_shift_xcorr_long_template(emu, golden):
