@@ -72,6 +72,70 @@ def cpu_baseline(sample_nx, sample_ns, stages):
             "sample": "oracle (numpy.fft / scipy float64, single thread): " + "; ".join(notes)}
 
 
+def bench_channel_sharded(args, stages, world, rank, device, dist):
+    """BASELINE configs[3]: ONE nx x ns block sharded by contiguous channel block over the ranks; a step
+    is the exact distributed f-k filter (time phase, all-to-all, channel phase, all-to-all, inverse
+    time phase), the HF+LF matched filter on the local rows and, with --gather, the RCCL all-gather
+    of the filtered t-x matrix.  Strong scaling: value = nx * ns / step time."""
+    import das4whales_amd as dw
+    from das4whales_amd import shard, detect as ddet
+    nx, ns = args.nx, args.ns
+    fs, dx = 200.0, 2.0419046878814697
+    a, b = shard.channel_block(nx, world, rank)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    x_loc = torch.randn((b - a, ns), dtype=torch.float32, device=device, generator=gen)
+    plan = shard.ShardedFkPlan(nx, ns)
+    mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)          # every rank designs the same mask
+    plan.set_mask(mask.tensor)
+    del mask
+    torch.cuda.empty_cache()
+    time_ax = np.arange(ns) / fs
+    tpl = [ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 17.8, 28.8, 0.68)),
+           ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 14.7, 21.8, 0.78))]
+
+    def step():
+        y = plan.apply(x_loc) if "fk" in stages else x_loc
+        out = ddet._xcorr_device(y, tpl, normalize=True) if "mf" in stages else None
+        if args.gather:
+            shard.all_gather_rows(y, nx)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        samples = float(nx) * ns
+        ms = dt / args.steps * 1e3
+        gbs = 24.0 * samples / (ms * 1e-3) / 1e9 / world           # per-GPU algorithmic f-k bytes over the whole step
+        out = {"metric": "channel-samples/sec through f-k filter + matched-filter", "value": samples / (dt / args.steps),
+               "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": "ONE %d channels x %d samples float32 block sharded by channel block over %d GPU(s), "
+                                      "classic f-k fan mask, stages %s%s" % (nx, ns, world, "+".join(stages),
+                                                                             ", all-gather of the t-x output" if args.gather else ""),
+                          "plan": {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq},
+                          "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
+               "roofline": {"bound": "hbm", "kernel": "distributed step (generic pass kernels + exchange)",
+                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "traffic": None}}
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +148,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask f-k timing")
     ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
+    ap.add_argument("--shard", type=str, default="replicas", choices=["replicas", "channel"],
+                    help="N > 1: 'replicas' = one independent block per GPU (default, weak scaling); 'channel' = ONE "
+                         "block sharded by channel block, exact distributed f-k filter (two all-to-alls), strong scaling")
+    ap.add_argument("--gather", action="store_true", help="--shard channel: all-gather the filtered t-x matrix each step")
     args = ap.parse_args()
     stages = [t for t in args.stages.split(",") if t]
     assert set(stages) <= {"bp", "fk", "mf"} and stages, "--stages: comma list of bp, fk, mf"
@@ -96,10 +164,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.shard == "channel":
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    if args.shard == "channel":
+        return bench_channel_sharded(args, stages, world, rank, device, dist)
 
     import das4whales_amd as dw
     nx, ns = args.nx, args.ns

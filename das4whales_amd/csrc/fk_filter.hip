@@ -969,3 +969,388 @@ int d4w_taper_f32(float* x, int nx, int ns, void* stream) {
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Distributed f-k filter (one channel block per GPU): pencil decomposition with ONE exchange each
+// way.  The packed 2-D transform factorises per axis, so the five passes regroup as
+//   time phase   (local rows)        : n1 sub-FFT + four-step twiddle (pass A with C1 = 1), then the
+//                                      contiguous n2 sub-FFT of every sub-row            [fkd_rows_n2]
+//   all-to-all                       : re-shard by n1-position q1 (sub-rows of N2 bins); a q1 and its
+//                                      Hermitian partner q1' always travel to the same rank
+//   channel phase (all nx channels   : c1 sub-FFT + twiddle (pass A with N1 = 1), c2 sub-FFT (pass C),
+//                  of the owned q1s)   real-spectrum pair op x folded mask                [fkd_pair_slab],
+//                                      inverse c2, inverse c1 (x 1/(nx M))
+//   all-to-all back, inverse time phase.
+// The generic pass kernels are reused unchanged through two FkDev descriptors with a degenerate
+// axis each.  Host plumbing (pack, RCCL all_to_all_single, unpack) lives in das4whales_amd/shard.py.
+// =============================================================================================
+namespace d4w {
+
+// contiguous n2 sub-FFT of every sub-row (forward: natural -> digit-reversed; inverse: back)
+template <bool INV, bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_rows_n2(FkDev P, float2* __restrict__ data, int nsub) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N2 = P.d.N2;
+    const TwLds tw = tw_stage(P.ax_n2, tile + N2, tid, nthr);
+    for (int t = blockIdx.x; t < nsub; t += gridDim.x) {
+        float2* row = data + (size_t)t * N2;
+        for (int w = tid; w < N2; w += nthr) tile[w] = row[w];
+        lds_barrier();
+        lds_fft<INV, false, GENERIC>(tile, P.ax_n2, tw, 1, 1, 0, 1, 0, tid, nthr);
+        for (int w = tid; w < N2; w += nthr) row[w] = tile[w];
+        lds_barrier();
+    }
+}
+
+struct FkdSlab {
+    int nx, nq, N2;           // slab [nx row positions][nq owned q1][N2 positions]
+    const int* q1_of;         // [nq] n1-position of local column block jq
+    const int* jq_partner;    // [nq] local index of the Hermitian partner q1
+    const int* row_partner;   // [nx]
+    const int* mirror0;       // [N2]
+    const float2* wrow;       // [N1] indexed by q1
+    const float2* wcol;       // [N2]
+    const float* mask;        // [nx][nq][N2] folded mask of the owned sub-rows
+    const float* nyq;         // [nx]
+};
+
+// pair op of fk_passB on the slab layout (see the algebra there); one thread per Hermitian pair
+__global__ __launch_bounds__(kThreads) void fkd_pair_slab(FkdSlab S, float2* __restrict__ slab) {
+    const int jq = blockIdx.z, r = blockIdx.y;
+    const int rp = S.row_partner[r], jp = S.jq_partner[jq];
+    const long keyA = (long)r * S.nq + jq, keyB = (long)rp * S.nq + jp;
+    if (keyB < keyA) return;
+    const bool same = (keyA == keyB);
+    const bool k1zero = (S.q1_of[jq] == 0);
+    float2* A = slab + (size_t)keyA * S.N2;
+    float2* B = slab + (size_t)keyB * S.N2;
+    const float* mA = S.mask + (size_t)keyA * S.N2;
+    const float* mB = S.mask + (size_t)keyB * S.N2;
+    const float2 wr = S.wrow[S.q1_of[jq]];
+    const float nyq = S.nyq[r];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.N2; i += gridDim.x * blockDim.x) {
+        const int j = k1zero ? S.mirror0[i] : (S.N2 - 1 - i);
+        if (same && j < i) continue;
+        const float2 a = A[i];
+        const float2 Bc = c_conj(B[j]);
+        const float ma = mA[i];
+        const float mb = (k1zero && i == 0) ? nyq : mB[j];
+        const float2 w = c_mul(wr, S.wcol[i]);
+        const float2 E = c_scale(c_add(a, Bc), 0.5f);
+        const float2 O = c_mul_mi(c_scale(c_sub(a, Bc), 0.5f));
+        const float2 tO = c_mul(w, O);
+        const float2 Yp = c_scale(c_add(E, tO), ma);
+        const float2 Ym = c_scale(c_sub(E, tO), mb);
+        const float2 Sm = c_scale(c_add(Yp, Ym), 0.5f);
+        const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+        A[i] = c_add(Sm, D);
+        B[j] = c_conj(c_sub(Sm, D));
+    }
+}
+
+// folded mask of the owned sub-rows (fk_fold_mask restricted to a q1 subset)
+__global__ __launch_bounds__(kThreads) void fkd_fold_mask(int nx, int ns, int N1, int N2, int nq,
+                                                           const float* __restrict__ ms,
+                                                           const int* __restrict__ rowk,
+                                                           const int* __restrict__ q1_of,
+                                                           const int* __restrict__ k1_of_q1,
+                                                           const int* __restrict__ k2_of_i,
+                                                           float* __restrict__ mask, float* __restrict__ nyq) {
+    const int r = blockIdx.y;
+    const int k = rowk[r];
+    const int km = (nx - k) % nx;
+    const int sx = nx / 2, st = ns / 2, M = ns / 2;
+    const size_t rowp = (size_t)((k + sx) % nx) * ns;
+    const size_t rowm = (size_t)((km + sx) % nx) * ns;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nq * N2; p += gridDim.x * blockDim.x) {
+        const int jq = p / N2, i = p - jq * N2;
+        const int f = k1_of_q1[q1_of[jq]] + N1 * k2_of_i[i];
+        const int fm = (ns - f) % ns;
+        mask[(size_t)r * nq * N2 + p] = 0.5f * (ms[rowp + (f + st) % ns] + ms[rowm + (fm + st) % ns]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        nyq[r] = 0.5f * (ms[rowp + (M + st) % ns] + ms[rowm + ((ns - M) + st) % ns]);
+}
+
+}  // namespace d4w
+
+struct d4w_fkd_plan {
+    int nx = 0, ns = 0, M = 0, world = 1, rank = 0;
+    int row_begin = 0, row_end = 0;      // this rank's channel block
+    int N1 = 1, N2 = 1, C1 = 1, C2 = 1, TA_t = 1, TA_c = 1, TC = 1;
+    std::vector<int> owner;              // [N1] rank owning each n1-position
+    std::vector<int> myq;                // owned n1-positions, ascending
+    d4w_fk_plan tp, cp;                  // time-phase / channel-phase descriptors (tables owned here)
+    FkdSlab slab;
+    size_t lds_t = 0, lds_c1 = 0, lds_c2 = 0, lds_n2 = 0;
+    bool gen_t = false, gen_n2 = false, gen_c1 = false, gen_c2 = false;
+    int* d_rowk = nullptr; int* d_k1 = nullptr; int* d_k2 = nullptr; int* d_q1of = nullptr;
+    float* d_mask = nullptr; float* d_nyq = nullptr;
+    bool has_mask = false;
+    int num_cu = 256;
+};
+
+static void fkd_block(int nx, int world, int r, int* a, int* b) {
+    const int base = nx / world, extra = nx % world;
+    *a = r * base + std::min(r, extra);
+    *b = *a + base + (r < extra ? 1 : 0);
+}
+
+extern "C" {
+
+int d4w_fkd_plan_destroy(d4w_fkd_plan* pl) {
+    if (!pl) return D4W_OK;
+    for (void* p : pl->tp.allocs) (void)hipFree(p);
+    for (void* p : pl->cp.allocs) (void)hipFree(p);
+    delete pl;
+    return D4W_OK;
+}
+
+int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out) {
+    if (!out) return fail(D4W_EINVAL, "plan pointer is NULL");
+    *out = nullptr;
+    if (nx < 1 || ns < 2 || (ns & 1)) return fail(D4W_EINVAL, "bad shape %d x %d (ns must be even)", nx, ns);
+    if (world < 1 || rank < 0 || rank >= world || world > nx) return fail(D4W_EINVAL, "bad world %d / rank %d", world, rank);
+    const int M = ns / 2;
+    // time axis M = N1 * N2: N2 in one LDS row, and enough n1-positions (Hermitian classes) to balance the ranks
+    int N1 = 0;
+    for (int cand = 1; cand <= M; ++cand) {
+        if (M % cand) continue;
+        if (M / cand > kMaxTile / 2) continue;
+        if (N1 == 0) N1 = cand;                              // smallest admissible
+        if (cand >= 4 * world && cand <= 512) { N1 = cand; break; }
+        if (cand > 512) break;
+    }
+    if (N1 == 0) return fail(D4W_EINVAL, "ns/2 = %d has no factorisation with N2 <= %d", M, kMaxTile / 2);
+    const int N2 = M / N1;
+    int C2 = largest_divisor_le(nx, kMaxTile / 8);
+    int C1 = nx / C2;
+    if (C1 > kMaxTile) return fail(D4W_EINVAL, "nx = %d does not factor into C1 <= %d, C2 <= %d", nx, kMaxTile, kMaxTile / 8);
+    d4w_fkd_plan* pl = new d4w_fkd_plan();
+    pl->nx = nx; pl->ns = ns; pl->M = M; pl->world = world; pl->rank = rank;
+    fkd_block(nx, world, rank, &pl->row_begin, &pl->row_end);
+    pl->N1 = N1; pl->N2 = N2; pl->C1 = C1; pl->C2 = C2;
+    const int nxl = pl->row_end - pl->row_begin;
+    int rc;
+#define D4W_TRY(x) do { rc = (x); if (rc != D4W_OK) { d4w_fkd_plan_destroy(pl); return rc; } } while (0)
+    // ---------------- time-phase descriptor: C1 = 1, C2 = local rows
+    d4w_fk_plan& tp = pl->tp;
+    memset(&tp.dev, 0, sizeof(tp.dev));
+    int TA = 16;
+    while (TA > 1 && (long)N1 * TA > kMaxTile) TA /= 2;
+    if ((long)N1 * TA > kMaxTile) { d4w_fkd_plan_destroy(pl); return fail(D4W_EINVAL, "N1 = %d exceeds the LDS tile", N1); }
+    pl->TA_t = TA;
+    tp.dev.d = FkDims{nxl, ns, M, 1, nxl, N1, N2, TA, 1};
+    tp.dev.scale = 1.0f;
+    std::vector<int> f_one, f_n1, f_n2, f_c1, f_c2;
+    D4W_TRY(make_axis(&tp, 1, &tp.dev.ax_c1, &f_one));
+    D4W_TRY(make_axis(&tp, 1, &tp.dev.ax_c2, &f_one));
+    D4W_TRY(make_axis(&tp, N1, &tp.dev.ax_n1, &f_n1));
+    D4W_TRY(make_axis(&tp, N2, &tp.dev.ax_n2, &f_n2));
+    {
+        std::vector<float2> ones((size_t)nxl, make_float2(1.f, 0.f)), twt((size_t)N1 * N2);
+        for (int q1 = 0; q1 < N1; ++q1)
+            for (int b = 0; b < N2; ++b) twt[(size_t)q1 * N2 + b] = wexp((long long)b * f_n1[q1], M);
+        D4W_TRY(upload(&tp, ones, &tp.dev.twc));
+        D4W_TRY(upload(&tp, twt, &tp.dev.twt));
+        std::vector<float> win = tukey_window(ns, 0.03);
+        std::vector<float2> winp(M);
+        for (int m = 0; m < M; ++m) winp[m] = make_float2(win[2 * m], win[2 * m + 1]);
+        D4W_TRY(upload(&tp, winp, &tp.dev.win));
+    }
+    pl->gen_t = axis_needs_generic(tp.dev.ax_n1);
+    pl->gen_n2 = axis_needs_generic(tp.dev.ax_n2);
+    pl->lds_t = ((size_t)N1 * TA + 2 * kTwLo + tp.dev.ax_c1.nhi + tp.dev.ax_n1.nhi) * sizeof(float2);
+    pl->lds_n2 = ((size_t)N2 + kTwLo + tp.dev.ax_n2.nhi) * sizeof(float2);
+
+    // ---------------- ownership of the n1-positions: Hermitian classes {q1, q1'} dealt round-robin
+    std::vector<int> p_n1(N1), q1part(N1);
+    for (int p = 0; p < N1; ++p) p_n1[f_n1[p]] = p;
+    for (int q1 = 0; q1 < N1; ++q1) q1part[q1] = p_n1[(N1 - f_n1[q1]) % N1];
+    pl->owner.assign(N1, -1);
+    {
+        std::vector<int> load(world, 0);
+        for (int q1 = 0; q1 < N1; ++q1) {
+            if (pl->owner[q1] >= 0) continue;
+            int best = 0;
+            for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+            pl->owner[q1] = best; ++load[best];
+            if (q1part[q1] != q1) { pl->owner[q1part[q1]] = best; ++load[best]; }
+        }
+    }
+    for (int q1 = 0; q1 < N1; ++q1) if (pl->owner[q1] == rank) pl->myq.push_back(q1);
+    const int nq = (int)pl->myq.size();
+    const int W = std::max(nq, 1) * N2;                       // slab width (complex columns)
+
+    // ---------------- channel-phase descriptor: N1 = 1, "N2" = slab width
+    d4w_fk_plan& cp = pl->cp;
+    memset(&cp.dev, 0, sizeof(cp.dev));
+    int TC = 16, TAc = 16;
+    while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
+    while (TAc > 1 && ((long)C1 * TAc > kMaxTile)) TAc /= 2;
+    pl->TC = TC; pl->TA_c = TAc;
+    cp.dev.d = FkDims{nx, 2 * W, W, C1, C2, 1, W, TAc, TC};
+    cp.dev.scale = (float)(1.0 / ((double)nx * (double)M));
+    D4W_TRY(make_axis(&cp, C1, &cp.dev.ax_c1, &f_c1));
+    D4W_TRY(make_axis(&cp, C2, &cp.dev.ax_c2, &f_c2));
+    D4W_TRY(make_axis(&cp, 1, &cp.dev.ax_n1, &f_one));
+    D4W_TRY(make_axis(&cp, 1, &cp.dev.ax_n2, &f_one));
+    {
+        std::vector<float2> twc((size_t)C1 * C2), ones((size_t)W, make_float2(1.f, 0.f));
+        for (int q = 0; q < C1; ++q)
+            for (int c2 = 0; c2 < C2; ++c2) twc[(size_t)q * C2 + c2] = wexp((long long)c2 * f_c1[q], nx);
+        D4W_TRY(upload(&cp, twc, &cp.dev.twc));
+        D4W_TRY(upload(&cp, ones, &cp.dev.twt));
+    }
+    pl->gen_c1 = axis_needs_generic(cp.dev.ax_c1);
+    pl->gen_c2 = axis_needs_generic(cp.dev.ax_c2);
+    pl->lds_c1 = ((size_t)C1 * TAc + 2 * kTwLo + cp.dev.ax_c1.nhi + cp.dev.ax_n1.nhi) * sizeof(float2);
+    pl->lds_c2 = ((size_t)C2 * TC + kTwLo + cp.dev.ax_c2.nhi) * sizeof(float2);
+
+    // ---------------- pair-op tables
+    std::vector<int> p_c1(C1), p_c2(C2), p_n2(N2), rowk(nx), rowpart(nx), mirror0(N2), jqpart(std::max(nq, 1), 0);
+    for (int p = 0; p < C1; ++p) p_c1[f_c1[p]] = p;
+    for (int p = 0; p < C2; ++p) p_c2[f_c2[p]] = p;
+    for (int p = 0; p < N2; ++p) p_n2[f_n2[p]] = p;
+    for (int q = 0; q < C1; ++q)
+        for (int p2 = 0; p2 < C2; ++p2) rowk[q * C2 + p2] = f_c1[q] + C1 * f_c2[p2];
+    for (int r = 0; r < nx; ++r) {
+        const int km = (nx - rowk[r]) % nx;
+        rowpart[r] = p_c1[km % C1] * C2 + p_c2[km / C1];
+    }
+    for (int i = 0; i < N2; ++i) mirror0[i] = p_n2[(N2 - f_n2[i]) % N2];
+    for (int j = 0; j < nq; ++j)
+        for (int j2 = 0; j2 < nq; ++j2)
+            if (pl->myq[j2] == q1part[pl->myq[j]]) jqpart[j] = j2;
+    std::vector<float2> wrow(N1), wcol(N2);
+    for (int q1 = 0; q1 < N1; ++q1) wrow[q1] = wexp(f_n1[q1], ns);
+    for (int i = 0; i < N2; ++i) wcol[i] = wexp((long long)N1 * f_n2[i], ns);
+    std::vector<int> myq = pl->myq;
+    if (myq.empty()) myq.push_back(0);
+    const int *c_rowk, *c_k1, *c_k2, *c_q1of;
+    FkdSlab& S = pl->slab;
+    S.nx = nx; S.nq = nq; S.N2 = N2;
+    D4W_TRY(upload(&cp, myq, &c_q1of));
+    D4W_TRY(upload(&cp, jqpart, &S.jq_partner));
+    D4W_TRY(upload(&cp, rowpart, &S.row_partner));
+    D4W_TRY(upload(&cp, mirror0, &S.mirror0));
+    D4W_TRY(upload(&cp, wrow, &S.wrow));
+    D4W_TRY(upload(&cp, wcol, &S.wcol));
+    D4W_TRY(upload(&cp, rowk, &c_rowk));
+    D4W_TRY(upload(&cp, f_n1, &c_k1));
+    D4W_TRY(upload(&cp, f_n2, &c_k2));
+    S.q1_of = c_q1of;
+    pl->d_rowk = const_cast<int*>(c_rowk); pl->d_k1 = const_cast<int*>(c_k1); pl->d_k2 = const_cast<int*>(c_k2);
+    pl->d_q1of = const_cast<int*>(c_q1of);
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)nx * W * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc of the slab mask failed"); }
+    cp.allocs.push_back(p); pl->d_mask = (float*)p;
+    if (hipMalloc(&p, (size_t)nx * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+    cp.allocs.push_back(p); pl->d_nyq = (float*)p;
+    S.mask = pl->d_mask; S.nyq = pl->d_nyq;
+#undef D4W_TRY
+#ifndef D4W_EMU
+    {
+        int devid = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess)
+            pl->num_cu = prop.multiProcessorCount;
+        const void* fns[] = {
+            (const void*)fk_passA_fwd<true, true>, (const void*)fk_passA_fwd<true, false>,
+            (const void*)fk_passA_fwd<false, true>, (const void*)fk_passA_fwd<false, false>,
+            (const void*)fk_passA_inv<true>, (const void*)fk_passA_inv<false>,
+            (const void*)fk_passC<false, true>, (const void*)fk_passC<false, false>,
+            (const void*)fk_passC<true, true>, (const void*)fk_passC<true, false>,
+            (const void*)fkd_rows_n2<false, true>, (const void*)fkd_rows_n2<false, false>,
+            (const void*)fkd_rows_n2<true, true>, (const void*)fkd_rows_n2<true, false>};
+        for (const void* f : fns)
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    }
+#else
+    pl->num_cu = 3;
+#endif
+    *out = pl;
+    return D4W_OK;
+}
+
+/* info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq_local, C1, C2, 0} */
+int d4w_fkd_plan_info(const d4w_fkd_plan* pl, int* info) {
+    if (!pl || !info) return fail(D4W_EINVAL, "NULL argument");
+    const int v[12] = {pl->nx, pl->ns, pl->world, pl->rank, pl->row_begin, pl->row_end, pl->N1, pl->N2,
+                       (int)pl->myq.size(), pl->C1, pl->C2, 0};
+    memcpy(info, v, sizeof(v));
+    return D4W_OK;
+}
+
+int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* pl, int* owner) {
+    if (!pl || !owner) return fail(D4W_EINVAL, "NULL argument");
+    memcpy(owner, pl->owner.data(), pl->owner.size() * sizeof(int));
+    return D4W_OK;
+}
+
+int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
+    if (!pl || !mask_shifted) return fail(D4W_EINVAL, "NULL argument");
+    const int nq = (int)pl->myq.size();
+    if (nq > 0) {
+        dim3 grid(std::min(ceil_div(nq * pl->N2, kThreads), 64), pl->nx);
+        D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, pl->nx, pl->ns, pl->N1, pl->N2, nq, mask_shifted,
+                   (const int*)pl->d_rowk, (const int*)pl->d_q1of, (const int*)pl->d_k1, (const int*)pl->d_k2,
+                   pl->d_mask, pl->d_nyq);
+    }
+    pl->has_mask = true;
+    return D4W_OK;
+}
+
+int d4w_fkd_time_fwd_f32(d4w_fkd_plan* pl, const float* x_loc, float* z_loc, int taper, void* stream) {
+    if (!pl || !x_loc || !z_loc) return fail(D4W_EINVAL, "NULL argument");
+    const FkDev& P = pl->tp.dev;
+    const int nxl = P.d.nx;
+    const int ntA = ceil_div(P.d.N2, P.d.TA) * nxl, nsub = nxl * pl->N1;
+    const int persist = pl->num_cu * 4;
+    const float2* src = reinterpret_cast<const float2*>(x_loc);
+    float2* dst = reinterpret_cast<float2*>(z_loc);
+    const dim3 blk(kMaxThreads);
+    int rc;
+    if (taper) rc = launch_k(pl->gen_t ? fk_passA_fwd<true, true> : fk_passA_fwd<true, false>, dim3(std::min(ntA, persist)), blk, pl->lds_t, stream, P, src, dst, ntA);
+    else rc = launch_k(pl->gen_t ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, dim3(std::min(ntA, persist)), blk, pl->lds_t, stream, P, src, dst, ntA);
+    if (rc) return rc;
+    return launch_k(pl->gen_n2 ? fkd_rows_n2<false, true> : fkd_rows_n2<false, false>, dim3(std::min(nsub, persist)), blk, pl->lds_n2, stream, P, dst, nsub);
+}
+
+int d4w_fkd_time_inv_f32(d4w_fkd_plan* pl, float* z_loc, void* stream) {
+    if (!pl || !z_loc) return fail(D4W_EINVAL, "NULL argument");
+    const FkDev& P = pl->tp.dev;
+    const int nxl = P.d.nx;
+    const int ntA = ceil_div(P.d.N2, P.d.TA) * nxl, nsub = nxl * pl->N1;
+    const int persist = pl->num_cu * 4;
+    float2* d2 = reinterpret_cast<float2*>(z_loc);
+    const dim3 blk(kMaxThreads);
+    int rc = launch_k(pl->gen_n2 ? fkd_rows_n2<true, true> : fkd_rows_n2<true, false>, dim3(std::min(nsub, persist)), blk, pl->lds_n2, stream, P, d2, nsub);
+    if (rc) return rc;
+    return launch_k(pl->gen_t ? fk_passA_inv<true> : fk_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_t, stream, P, d2, ntA);
+}
+
+int d4w_fkd_chan_apply_f32(d4w_fkd_plan* pl, float* slab, void* stream) {
+    if (!pl || (!slab && !pl->myq.empty())) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl->has_mask) return fail(D4W_EINVAL, "no mask set on this plan");
+    const int nq = (int)pl->myq.size();
+    if (nq == 0) return D4W_OK;
+    const FkDev& P = pl->cp.dev;
+    const FkDims& d = P.d;
+    const int ntA = ceil_div(d.N2, d.TA) * d.C2, ntC = ceil_div(d.M, d.TC) * d.C1;
+    const int persist = pl->num_cu * 4;
+    float2* d2 = reinterpret_cast<float2*>(slab);
+    const dim3 blk(kMaxThreads);
+    int rc;
+    if ((rc = launch_k(pl->gen_c1 ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, (const float2*)d2, d2, ntA))) return rc;
+    if ((rc = launch_k(pl->gen_c2 ? fk_passC<false, true> : fk_passC<false, false>, dim3(std::min(ntC, persist)), blk, pl->lds_c2, stream, P, d2, ntC))) return rc;
+    if (pl->nx > 65535 || nq > 65535) return fail(D4W_EINVAL, "slab %d x %d exceeds the pair-op grid", pl->nx, nq);
+    if ((rc = launch_k(fkd_pair_slab, dim3(std::min(ceil_div(pl->N2, kThreads), 8), pl->nx, nq), dim3(kThreads), 0,
+                       stream, pl->slab, d2))) return rc;
+    if ((rc = launch_k(pl->gen_c2 ? fk_passC<true, true> : fk_passC<true, false>, dim3(std::min(ntC, persist)), blk, pl->lds_c2, stream, P, d2, ntC))) return rc;
+    return launch_k(pl->gen_c1 ? fk_passA_inv<true> : fk_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, d2, ntA);
+}
+
+}  // extern "C"

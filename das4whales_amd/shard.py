@@ -49,3 +49,143 @@ def map_channel_blocks(fn, x_full, gather=True, group=None):
     a, b = channel_block(x_full.shape[0], world, rank)
     y = fn(x_full[a:b])
     return all_gather_rows(y, x_full.shape[0], group=group) if gather else y
+
+
+# ---------------------------------------------------------------------------------------------
+# exact f-k filter of ONE block sharded by channel block (pencil decomposition, two all-to-alls)
+# ---------------------------------------------------------------------------------------------
+def _native():
+    from ._lib import lib, check
+    return lib, check
+
+
+def _sptr(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+class ShardedFkPlan:
+    """Per-rank plan of the distributed f-k filter (include/d4w.h, d4w_fkd_*): this rank's channel
+    block, the owner of every time-axis sub-row q1, and the folded mask of the sub-rows it owns.
+    `native` = (lib, check) lets the CPU tests drive the same code with the emulator build."""
+
+    def __init__(self, nx, ns, group=None, native=None):
+        import ctypes
+        self._ct = ctypes
+        self.lib, self.check = native if native is not None else _native()
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self._h = ctypes.c_void_p()
+        self.check(self.lib.d4w_fkd_plan_create(int(nx), int(ns), self.world, self.rank, ctypes.byref(self._h)))
+        info = (ctypes.c_int * 12)()
+        self.check(self.lib.d4w_fkd_plan_info(self._h, info))
+        (self.nx, self.ns, _, _, self.row_begin, self.row_end, self.N1, self.N2, self.nq, _, _, _) = list(info)
+        own = (ctypes.c_int * self.N1)()
+        self.check(self.lib.d4w_fkd_plan_q1_owner(self._h, own))
+        owner = torch.tensor(list(own), dtype=torch.int64)
+        self.qidx = [torch.nonzero(owner == s).flatten() for s in range(self.world)]
+        self.blocks = [channel_block(self.nx, self.world, r) for r in range(self.world)]
+        assert self.blocks[self.rank] == (self.row_begin, self.row_end)
+
+    def set_mask(self, mask):
+        """mask: dense float32 [nx, ns] tensor on this rank's device, fftshift-ed grid (what the
+        reference designers return; every rank designs or loads the same mask)."""
+        if tuple(mask.shape) != (self.nx, self.ns):
+            raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s"
+                             % (self.nx, self.ns, tuple(mask.shape)))
+        m = mask.to(torch.float32).contiguous()
+        self.check(self.lib.d4w_fkd_set_mask_dense_f32(self._h, m.data_ptr(), _sptr(m)))
+        if m.is_cuda:
+            torch.cuda.current_stream(m.device).synchronize()
+
+    # elements per collective call: RCCL / gloo counts are 32-bit safe well below this, and the
+    # chunking also bounds the size of the packed send / receive staging buffers
+    MAX_CALL_ELEMS = 1 << 29
+
+    def _chunk_rows(self, r, j, nch):
+        """Global row range of chunk j (of nch) of rank r's channel block."""
+        a, b = self.blocks[r]
+        n = b - a
+        return a + (n * j) // nch, a + (n * (j + 1)) // nch
+
+    def _all_to_all(self, recv, send, out_splits, in_splits):
+        if self.world == 1:
+            recv.copy_(send)
+        else:
+            dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+
+    def apply(self, x_loc, taper=False):
+        """x_loc: float32 [rows of this rank, ns] -> filtered rows of this rank (same shape)."""
+        nxl = self.row_end - self.row_begin
+        if tuple(x_loc.shape) != (nxl, self.ns):
+            raise ValueError("local block has shape %s, expected (%d, %d)" % (tuple(x_loc.shape), nxl, self.ns))
+        x_loc = x_loc.to(torch.float32).contiguous()
+        per = self.N2 * 2                                        # floats per sub-row
+        z = torch.empty((nxl, self.N1, per), dtype=torch.float32, device=x_loc.device)
+        self.check(self.lib.d4w_fkd_time_fwd_f32(self._h, x_loc.data_ptr(), z.data_ptr(), int(bool(taper)), _sptr(z)))
+        qidx = [q.to(z.device) for q in self.qidx]
+        nql = [len(q) for q in self.qidx]
+        biggest = max(b - a for a, b in self.blocks) * self.N1 * per
+        nch = max(1, -(-biggest // self.MAX_CALL_ELEMS))          # same on every rank
+        slab = torch.empty((self.nx, self.nq * per), dtype=torch.float32, device=z.device)   # [nx][nq][N2] complex
+        # exchange 1: sub-row q1 of every local channel -> rank owner[q1], in row chunks
+        for j in range(nch):
+            g0, g1 = self._chunk_rows(self.rank, j, nch)
+            l0, l1 = g0 - self.row_begin, g1 - self.row_begin
+            send = torch.cat([z[l0:l1].index_select(1, qidx[s]).reshape(-1) for s in range(self.world)])
+            to_peer = [(l1 - l0) * nql[s] * per for s in range(self.world)]
+            rows = [self._chunk_rows(r, j, nch) for r in range(self.world)]
+            from_peer = [(b - a) * self.nq * per for a, b in rows]
+            recv = slab.view(-1) if nch == 1 else torch.empty(sum(from_peer), dtype=torch.float32, device=z.device)
+            self._all_to_all(recv, send, from_peer, to_peer)
+            if nch > 1:
+                off = 0
+                for (a, b), n in zip(rows, from_peer):
+                    slab[a:b] = recv[off:off + n].view(b - a, self.nq * per)
+                    off += n
+            del send, recv
+        self.check(self.lib.d4w_fkd_chan_apply_f32(self._h, slab.data_ptr() if self.nq else None, _sptr(slab)))
+        # exchange 2: the exact reverse
+        for j in range(nch):
+            g0, g1 = self._chunk_rows(self.rank, j, nch)
+            l0, l1 = g0 - self.row_begin, g1 - self.row_begin
+            rows = [self._chunk_rows(r, j, nch) for r in range(self.world)]
+            to_peer = [(b - a) * self.nq * per for a, b in rows]
+            from_peer = [(l1 - l0) * nql[s] * per for s in range(self.world)]
+            send = slab.view(-1) if nch == 1 else torch.cat([slab[a:b].reshape(-1) for a, b in rows])
+            back = torch.empty(sum(from_peer), dtype=torch.float32, device=z.device)
+            self._all_to_all(back, send, from_peer, to_peer)
+            off = 0
+            for s in range(self.world):
+                n = from_peer[s]
+                if n:
+                    z[l0:l1].index_copy_(1, qidx[s], back[off:off + n].view(l1 - l0, nql[s], per))
+                off += n
+            del send, back
+        del slab
+        self.check(self.lib.d4w_fkd_time_inv_f32(self._h, z.data_ptr(), _sptr(z)))
+        return z.view(nxl, self.ns)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.d4w_fkd_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def fk_filter_sharded(x_loc, fk_filter_matrix, nx_total, tapering=False, gather=False, group=None, plan=None):
+    """dsp.fk_filter_filt (reference dsp.py:725-756) of ONE [nx_total, ns] block whose rows are
+    sharded by contiguous channel block (channel_block) over the ranks of `group`.  Returns this
+    rank's filtered rows, or the whole filtered matrix on every rank after a single all-gather
+    when gather=True (north star: RCCL all-gather of the t-x output)."""
+    if plan is None:
+        plan = ShardedFkPlan(nx_total, x_loc.shape[1], group=group)
+        m = fk_filter_matrix.tensor if hasattr(fk_filter_matrix, "tensor") else fk_filter_matrix
+        if not isinstance(m, torch.Tensor):
+            import numpy as np
+            m = torch.from_numpy(np.ascontiguousarray(np.asarray(m.todense() if hasattr(m, "todense") else m),
+                                                      dtype=np.float32))
+        plan.set_mask(m.to(x_loc.device))
+    y = plan.apply(x_loc, taper=tapering)
+    return all_gather_rows(y, nx_total, group=group) if gather else y

@@ -76,6 +76,38 @@ int d4w_fk_apply_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, voi
 int d4w_fk_apply_timed_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, void* stream,
                            float* ms5_host);
 
+/* ------------------------------------------------------------------------------------------
+ * Distributed f-k filter: ONE [nx][ns] block sharded by contiguous channel block over `world`
+ * GPUs (rank r owns rows [row_begin, row_end), balanced like np.array_split).  Exactly the same
+ * filter as d4w_fk_apply_f32 -- the 2-D transform couples all channels, so the packed spectrum is
+ * re-sharded once each way (pencil decomposition):
+ *
+ *   d4w_fkd_time_fwd_f32   local rows: x_loc [nxl][ns] real -> z_loc [nxl][N1][N2] complex
+ *                          (time-axis transform of the packed rows; q1-major sub-rows of N2 bins)
+ *   -- all-to-all: sub-row q1 of every channel goes to rank owner[q1] (d4w_fkd_plan_q1_owner);
+ *      the receiver concatenates the senders' pieces in rank order = channel order, which gives
+ *      slab [nx][nq][N2] (nq = sub-rows owned, in ascending q1)
+ *   d4w_fkd_chan_apply_f32 channel-axis transform, real-spectrum pair op x folded mask, inverse
+ *                          channel-axis transform (x 1/(nx ns/2)), in place on the slab
+ *   -- all-to-all back (the exact reverse)
+ *   d4w_fkd_time_inv_f32   z_loc -> filtered rows, in place (read the buffer as float [nxl][ns])
+ *
+ * The exchange itself (RCCL all_to_all_single over xGMI, gloo in the CPU tests) is host plumbing:
+ * das4whales_amd/shard.py fk_filter_sharded.  All buffers are DEVICE float32 (complex = 2 floats).
+ * info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq, C1, C2, 0}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct d4w_fkd_plan d4w_fkd_plan;
+int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** plan);
+int d4w_fkd_plan_destroy(d4w_fkd_plan* plan);
+int d4w_fkd_plan_info(const d4w_fkd_plan* plan, int* info12_host);
+int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* plan, int* owner_host /* [N1] */);
+/* mask: the full dense [nx][ns] float32 mask on the fftshift-ed grid (as d4w_fk_set_mask_dense_f32);
+ * only the owned sub-rows are folded and kept */
+int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* plan, const float* mask_shifted, void* stream);
+int d4w_fkd_time_fwd_f32(d4w_fkd_plan* plan, const float* x_loc, float* z_loc, int taper, void* stream);
+int d4w_fkd_chan_apply_f32(d4w_fkd_plan* plan, float* slab, void* stream);
+int d4w_fkd_time_inv_f32(d4w_fkd_plan* plan, float* z_loc, void* stream);
+
 /* dsp.taper_data (dsp.py:705-722): x *= tukey(ns, 0.03) in place, every row */
 int d4w_taper_f32(float* x, int nx, int ns, void* stream);
 

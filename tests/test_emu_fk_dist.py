@@ -1,0 +1,121 @@
+"""Distributed f-k filter LOGIC on the CPU emulator build: the per-rank C-ABI phases
+(d4w_fkd_time_fwd / chan_apply / time_inv) of every rank run in ONE process and the two all-to-all
+exchanges are played by NumPy, exactly as include/d4w.h describes them.  Parity vs the reference
+goldens and the oracle.  (tests/test_shard_gloo.py runs the real exchange with gloo.)"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import d4w_oracle as orc
+from tests.emu_util import load_emu, vp
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return load_emu()
+
+
+def rel(y, ref):
+    return np.max(np.abs(y - ref)) / np.max(np.abs(ref))
+
+
+class Rank:
+    def __init__(self, lib, nx, ns, world, rank):
+        self.lib = lib
+        self.h = ctypes.c_void_p()
+        assert lib.d4w_fkd_plan_create(nx, ns, world, rank, ctypes.byref(self.h)) == 0, lib.d4w_last_error()
+        info = (ctypes.c_int * 12)()
+        assert lib.d4w_fkd_plan_info(self.h, info) == 0
+        (_, _, _, _, self.a, self.b, self.N1, self.N2, self.nq, self.C1, self.C2, _) = list(info)
+        own = (ctypes.c_int * self.N1)()
+        assert lib.d4w_fkd_plan_q1_owner(self.h, own) == 0
+        self.owner = np.array(list(own))
+
+    def close(self):
+        self.lib.d4w_fkd_plan_destroy(self.h)
+
+
+def fk_sharded_emu(lib, x, mask, world, taper=False):
+    nx, ns = x.shape
+    M = ns // 2
+    ranks = [Rank(lib, nx, ns, world, r) for r in range(world)]
+    N1, N2 = ranks[0].N1, ranks[0].N2
+    owner = ranks[0].owner
+    assert all(np.array_equal(rk.owner, owner) for rk in ranks)          # every rank derives the same map
+    assert ranks[0].a == 0 and ranks[-1].b == nx and all(ranks[i].b == ranks[i + 1].a for i in range(world - 1))
+    assert sorted(owner.tolist()) == sorted(sum(([r] * ranks[r].nq for r in range(world)), []))
+    mf = np.ascontiguousarray(mask, dtype=np.float32)
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    z = []
+    for rk in ranks:
+        assert lib.d4w_fkd_set_mask_dense_f32(rk.h, vp(mf), None) == 0
+        xl = np.ascontiguousarray(xf[rk.a:rk.b])
+        zl = np.empty((rk.b - rk.a, N1, N2, 2), dtype=np.float32)
+        assert lib.d4w_fkd_time_fwd_f32(rk.h, vp(xl), vp(zl), int(taper), None) == 0, lib.d4w_last_error()
+        z.append(zl)
+    # all-to-all: sub-row q1 of every channel -> rank owner[q1]; receiver concatenates in rank order
+    qidx = [np.nonzero(owner == s)[0] for s in range(world)]
+    slabs = [np.ascontiguousarray(np.concatenate([z[r][:, qidx[s]] for r in range(world)], axis=0))
+             for s in range(world)]
+    for s, rk in enumerate(ranks):
+        assert slabs[s].shape == (nx, rk.nq, N2, 2)
+        assert lib.d4w_fkd_chan_apply_f32(rk.h, vp(slabs[s]) if rk.nq else None, None) == 0, lib.d4w_last_error()
+    # all-to-all back
+    y = np.empty((nx, ns), dtype=np.float32)
+    for r, rk in enumerate(ranks):
+        zl = z[r]
+        for s in range(world):
+            zl[:, qidx[s]] = slabs[s][rk.a:rk.b]
+        assert lib.d4w_fkd_time_inv_f32(rk.h, vp(zl), None) == 0, lib.d4w_last_error()
+        y[rk.a:rk.b] = zl.reshape(rk.b - rk.a, ns)
+    for rk in ranks:
+        rk.close()
+    assert M == N1 * N2
+    return y
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_dist_golden_40x480(emu, golden, world):
+    g = golden("fk_40x480.npz")
+    assert rel(fk_sharded_emu(emu, g["x"], g["m_ninf"], world), g["y_ninf"]) < TOL       # non-Hermitian design
+    assert rel(fk_sharded_emu(emu, g["x"], g["m_classic"], world), g["y_classic"]) < TOL
+    if world == 2:
+        assert rel(fk_sharded_emu(emu, g["x"], g["m_classic"], world, taper=True), g["y_classic_taper"]) < TOL
+
+
+def test_dist_uneven_blocks_and_primes(emu, golden):
+    g = golden("fk_30x360.npz")                         # 30 channels over 4 ranks: blocks of 8, 8, 7, 7
+    assert rel(fk_sharded_emu(emu, g["x"], g["m_ninf"], 4), g["y_ninf"]) < TOL
+    rng = np.random.default_rng(2)
+    nx, ns = 2 * 19, 2 * 7 * 11 * 3                     # loop-based prime radices on both axes
+    x = rng.standard_normal((nx, ns))
+    m = rng.uniform(0, 1, (nx, ns))
+    assert rel(fk_sharded_emu(emu, x, m, 3), orc.fk_filter_filt(x, m)) < TOL
+
+
+def test_dist_matches_single_gpu_path(emu):
+    """Same answer as the single-device plan (d4w_fk_apply_f32) to rounding, more ranks than classes."""
+    rng = np.random.default_rng(4)
+    nx, ns = 24, 96
+    x = rng.standard_normal((nx, ns)).astype(np.float32)
+    m = rng.uniform(0, 1, (nx, ns)).astype(np.float32)
+    h = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(h)) == 0
+    assert emu.d4w_fk_set_mask_dense_f32(h, vp(m), None) == 0
+    y1 = np.empty_like(x)
+    assert emu.d4w_fk_apply_f32(h, vp(x), vp(y1), 0, None) == 0
+    emu.d4w_fk_plan_destroy(h)
+    for world in (2, 8):
+        y = fk_sharded_emu(emu, x, m, world)
+        assert rel(y, y1.astype(np.float64)) < 2e-6
+        assert rel(y, orc.fk_filter_filt(x, m)) < TOL
+
+
+def test_dist_plan_errors(emu):
+    h = ctypes.c_void_p()
+    assert emu.d4w_fkd_plan_create(40, 481, 2, 0, ctypes.byref(h)) == -1
+    assert emu.d4w_fkd_plan_create(40, 480, 2, 2, ctypes.byref(h)) == -1
+    assert emu.d4w_fkd_plan_create(4, 480, 8, 0, ctypes.byref(h)) == -1       # more ranks than channels
