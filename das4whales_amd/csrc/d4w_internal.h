@@ -53,10 +53,39 @@ inline int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------
 namespace d4w {
 __device__ __forceinline__ float2 c_make(float re, float im) { return make_float2(re, im); }
+__device__ __forceinline__ float2 c_conj(float2 a) { return make_float2(a.x, -a.y); }
+// multiply by -i : (x, y) -> (y, -x)
+__device__ __forceinline__ float2 c_mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+// multiply by +i : (x, y) -> (-y, x)
+__device__ __forceinline__ float2 c_mul_pi(float2 a) { return make_float2(-a.y, a.x); }
+#if defined(D4W_PKMATH) && !defined(D4W_EMU)
+// Packed-math variant: a complex value is one 64-bit VGPR pair and add / sub / scale / multiply are
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 (half the VALU issue slots of the scalar forms; the FFT
+// butterflies are add-dominated and VALU-bound).
+typedef float d4w_pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d4w_pk2 pk_(float2 a) { d4w_pk2 r; r.x = a.x; r.y = a.y; return r; }
+__device__ __forceinline__ float2 unpk_(d4w_pk2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return unpk_(pk_(a) + pk_(b)); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return unpk_(pk_(a) - pk_(b)); }
+__device__ __forceinline__ float2 c_scale(float2 a, float s) { d4w_pk2 sv; sv.x = s; sv.y = s; return unpk_(pk_(a) * sv); }
+// a * b = (a.x, a.x) * b + (-a.y, a.y) * (b.y, b.x)
+__device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
+    d4w_pk2 ax; ax.x = a.x; ax.y = a.x;
+    d4w_pk2 ay; ay.x = -a.y; ay.y = a.y;
+    d4w_pk2 bs; bs.x = b.y; bs.y = b.x;
+    return unpk_(__builtin_elementwise_fma(ax, pk_(b), ay * bs));
+}
+// a * conj(b) = (b.x, b.x) * a + (a.y, -a.x) * (b.y, b.y)
+__device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {
+    d4w_pk2 bx; bx.x = b.x; bx.y = b.x;
+    d4w_pk2 by; by.x = b.y; by.y = b.y;
+    d4w_pk2 as; as.x = a.y; as.y = -a.x;
+    return unpk_(__builtin_elementwise_fma(bx, pk_(a), as * by));
+}
+#else
 __device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 c_scale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
-__device__ __forceinline__ float2 c_conj(float2 a) { return make_float2(a.x, -a.y); }
 // a * b
 __device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
     return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
@@ -65,10 +94,7 @@ __device__ __forceinline__ float2 c_mul(float2 a, float2 b) {
 __device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {
     return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
 }
-// multiply by -i : (x, y) -> (y, -x)
-__device__ __forceinline__ float2 c_mul_mi(float2 a) { return make_float2(a.y, -a.x); }
-// multiply by +i : (x, y) -> (-y, x)
-__device__ __forceinline__ float2 c_mul_pi(float2 a) { return make_float2(-a.y, a.x); }
+#endif
 
 // 24-bit integer multiply (full-rate v_mul_i32_i24; v_mul_lo_u32 is quarter rate) and fast reciprocal
 #ifdef D4W_EMU

@@ -56,10 +56,13 @@ def _taps_tensor(taps_list, device):
     return torch.from_numpy(taps).to(device), lt
 
 
-def _xcorr_device(x, taps_list, normalize):
-    """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors."""
+def _xcorr_device(x, taps_list, normalize, method="auto"):
+    """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
+    method: "fft" (overlap-save, supports <= 161 samples), "direct", or "auto" (fft when it applies)."""
     nx, ns = x.shape
     outs = []
+    use_fft = method == "fft" or (method == "auto" and ns >= 1024
+                                  and max(len(t) for t in taps_list) <= int(lib.d4w_xcorr_fft_max_support()))
     with torch.cuda.device(x.device):
         mean = mx = None
         if normalize:
@@ -70,6 +73,15 @@ def _xcorr_device(x, taps_list, normalize):
             grp = taps_list[i:i + 2]
             taps, lt = _taps_tensor(grp, x.device)
             ys = [torch.empty_like(x) for _ in grp]
+            if use_fft:
+                ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
+                check(lib.d4w_xcorr_fft_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
+                                            dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
+                                            len(grp[0]), len(grp[-1]),
+                                            dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
+                                            dev.ptr(ws), dev.stream_ptr(x)))
+                outs.extend(ys)
+                continue
             check(lib.d4w_xcorr_lens_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
                                          dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
                                          len(grp[0]), len(grp[-1]),

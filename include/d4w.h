@@ -161,6 +161,18 @@ int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const 
                        const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                        float* y1, void* stream);
 
+/* Overlap-save FFT form of the same correlation for short templates (support <=
+ * d4w_xcorr_fft_max_support() = 161 samples; the fin-whale templates have 136 / 156): blocks of
+ * 4096 samples, one forward transform per block and one inverse per template, ~5x fewer flops than
+ * the direct form, bound by HBM instead of the vector ALUs.  Same arguments and result as
+ * d4w_xcorr_lens_f32 (agreement to float32 rounding); ws = DEVICE scratch of
+ * d4w_xcorr_fft_ws_bytes() bytes (template spectra, rebuilt per call on `stream`). */
+int d4w_xcorr_fft_max_support(void);
+size_t d4w_xcorr_fft_ws_bytes(void);
+int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+                      const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
+                      float* y1, void* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * f-k mask design on the device (one-off per shape), float32 masks on the fftshift-ed (k, f)
  * grid, row-major [nx][ns] -- what d4w_fk_set_mask_dense_f32 takes.  Closed forms of the

@@ -144,3 +144,52 @@ def test_shift_xcorr_long_template(emu, golden):
     d = golden("detect_12x2000.npz")
     (c2,), _, _ = xcorr_emu(emu, d["x"][2:3], [d["hf"][:137]], normalize=False)
     assert rel(c2[0], d["xc"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------
+# overlap-save FFT matched filter (csrc/xcorr_fft.hip)
+# ------------------------------------------------------------------------------------------
+def xcorr_fft_emu(lib, x, taps_list, normalize=True):
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    lt = max(4, -(-max(len(t) for t in taps_list) // 4) * 4)
+    taps = np.zeros((len(taps_list), lt), dtype=np.float32)
+    for i, t in enumerate(taps_list):
+        taps[i, :len(t)] = t
+    mean = np.empty(nx, dtype=np.float32)
+    mx = np.empty(nx, dtype=np.float32)
+    if normalize:
+        assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
+    lib.d4w_xcorr_fft_ws_bytes.restype = ctypes.c_size_t
+    ws = np.empty(lib.d4w_xcorr_fft_ws_bytes(), dtype=np.uint8)
+    ys = [np.full_like(xf, np.nan) for _ in taps_list]
+    rc = lib.d4w_xcorr_fft_f32(vp(xf), nx, ns, vp(mean) if normalize else None, vp(mx) if normalize else None,
+                               vp(taps), len(taps_list), lt, len(taps_list[0]), len(taps_list[-1]),
+                               vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None, vp(ws), None)
+    assert rc == 0, lib.d4w_last_error()
+    return ys
+
+
+def test_xcorr_fft_golden(emu, golden):
+    d = golden("detect_12x2000.npz")
+    yh, yl = xcorr_fft_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])])
+    assert rel(yh, d["corr_hf"]) < TOL                  # reference detect.compute_cross_correlogram
+    assert rel(yl, d["corr_lf"]) < TOL
+    (y1,) = xcorr_fft_emu(emu, d["x"], [norm_taps(d["lf"])])
+    assert rel(y1, d["corr_lf"]) < TOL
+    (yd, _), _, _ = xcorr_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])])
+    assert rel(yh, yd.astype(np.float64)) < 3e-6        # FFT and direct forms agree to rounding
+
+
+@pytest.mark.parametrize("nx,ns,l0,l1", [(3, 9001, 161, 7), (2, 4096, 136, 156), (1, 3937, 1, 160), (4, 1300, 50, 50)])
+def test_xcorr_fft_ragged(emu, nx, ns, l0, l1):
+    """Odd row counts, odd row lengths (unaligned row pairs), several blocks with a ragged tail, a
+    single block shorter than the transform, the maximum support."""
+    rng = np.random.default_rng(ns + l0)
+    x = rng.standard_normal((nx, ns)) + 0.5
+    t0, t1 = rng.standard_normal(l0), rng.standard_normal(l1)
+    y0, y1 = xcorr_fft_emu(emu, x, [t0, t1], normalize=False)
+    for c in range(nx):
+        assert rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - l0)))) < TOL
+        assert rel(y1[c], orc.shift_xcorr(x[c], np.pad(t1, (0, ns - l1)))) < TOL
+    assert emu.d4w_xcorr_fft_max_support() == 161
