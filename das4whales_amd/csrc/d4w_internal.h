@@ -138,6 +138,12 @@ __device__ __forceinline__ float v2_x(v2f a) { return a.x; }
 __device__ __forceinline__ float v2_y(v2f a) { return a.y; }
 // a * s + c  (s broadcast)
 __device__ __forceinline__ v2f v2_fma(v2f a, float s, v2f c) { return v2f{fmaf(a.x, s, c.x), fmaf(a.y, s, c.y)}; }
+__device__ __forceinline__ v2f v2_fnma(v2f a, float s, v2f c) { return v2f{fmaf(-a.x, s, c.x), fmaf(-a.y, s, c.y)}; }
+__device__ __forceinline__ v2f v2_add(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f v2_sub(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f v2_mul(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f v2_muls(v2f a, float s) { return v2f{a.x * s, a.y * s}; }
+__device__ __forceinline__ v2f v2_neg(v2f a) { return v2f{-a.x, -a.y}; }
 #else
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f v2_make(float x, float y) { v2f r; r.x = x; r.y = y; return r; }
@@ -147,6 +153,16 @@ __device__ __forceinline__ v2f v2_fma(v2f a, float s, v2f c) {
     v2f sv; sv.x = s; sv.y = s;
     return __builtin_elementwise_fma(a, sv, c);
 }
+// c - a * s
+__device__ __forceinline__ v2f v2_fnma(v2f a, float s, v2f c) {
+    v2f sv; sv.x = -s; sv.y = -s;
+    return __builtin_elementwise_fma(a, sv, c);
+}
+__device__ __forceinline__ v2f v2_add(v2f a, v2f b) { return a + b; }
+__device__ __forceinline__ v2f v2_sub(v2f a, v2f b) { return a - b; }
+__device__ __forceinline__ v2f v2_mul(v2f a, v2f b) { return a * b; }
+__device__ __forceinline__ v2f v2_muls(v2f a, float s) { v2f sv; sv.x = s; sv.y = s; return a * sv; }
+__device__ __forceinline__ v2f v2_neg(v2f a) { return -a; }
 #endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

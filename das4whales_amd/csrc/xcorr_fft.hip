@@ -14,16 +14,16 @@
 //     applied to the registers the global loads landed in, the last one feeds the global stores, the
 //     middle item does [radix 8 | pair op x 2 templates | inverse radix 8] for a group of 8
 //     positions and its Hermitian partner group;
-//   * a workgroup transforms the same block of TWO adjacent rows (every middle item then has work
-//     for all 256 threads, and the template spectra are read once per row pair).
+//   * a workgroup (128 threads) transforms the same block of TWO adjacent rows at once, the two rows
+//     riding the two halves of packed registers (fft_pair.h): every butterfly add / multiply is one
+//     v_pk_* instruction for both rows -- the kernel is VALU-bound, and add-dominated scalar FFT
+//     code runs the vector ALUs at a quarter of their packed-FMA rate;
+//   * the item's two groups of the block spectrum stay in registers for every template, so each
+//     template's correlation overwrites the row buffer in place (37 KiB of LDS per workgroup).
 // Spectra tables are built per call by xcf_spectra (a few hundred microseconds of a 4096 x 161 DFT).
 #include <cstdlib>
 
-// complex arithmetic as v_pk_* on 64-bit register pairs in this translation unit: the kernel is
-// VALU-bound and add-dominated (measured 13.2 -> 11.1 ms at 20000 x 120000); the f-k pass kernels
-// lose a few percent with it (register pairs / swizzle moves) and keep the scalar forms
-#define D4W_PKMATH 1
-#include "fft_radix.h"
+#include "fft_pair.h"
 
 namespace d4w {
 
@@ -33,7 +33,7 @@ constexpr int kXfM1 = kXfNB * kXfNC;               // 128
 constexpr int kXfNG = kXfNA * kXfNB;               // 256 groups of NC positions
 constexpr int kXfPad = 160;                        // lags lost per block = max support - 1
 constexpr int kXfStep = kXfB - kXfPad;             // 3936 lags per block
-constexpr int kXfThreads = 256;
+constexpr int kXfThreads = 128;               // one item per thread in every stage
 constexpr int kXfRowP = kXfMB + kXfNG;             // LDS row pitch: one pad element per group
 
 __host__ __device__ constexpr int xf_ad(int e) { return e + e / kXfNC; }
@@ -101,57 +101,71 @@ __global__ __launch_bounds__(256) void xcf_spectra(const float* __restrict__ tap
     }
 }
 
-// pair op for one frequency pair: A = Z[f], Bc = conj(Z[MB - f]), w = W_B^f, gf = conj(T(f)),
-// gmc = conj(T(f + MB)) = conj(conj(T(MB - f)))^* ... passed already conjugated (see call sites)
-__device__ __forceinline__ void xf_pair(float2 A, float2 Bs, float2 w, float2 gf, float2 gm, float2& na, float2& nb) {
-    const float2 Bc = c_conj(Bs);
-    const float2 E = c_scale(c_add(A, Bc), 0.5f);
-    const float2 O = c_mul_mi(c_scale(c_sub(A, Bc), 0.5f));
-    const float2 tO = c_mul(w, O);
-    const float2 Yp = c_mul(c_add(E, tO), gf);            // X(f)      conj(T(f))
-    const float2 Ym = c_mulc(c_sub(E, tO), gm);           // X(f + MB) conj(T(f + MB)),  conj(T(f+MB)) = conj(gm)
-    const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
-    const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
-    na = c_add(S, D);
-    nb = c_conj(c_sub(S, D));
+// pair op for one frequency pair of both rows: A = Z[f], Bs = Z[MB - f], w = W_B^f, gf = conj(T(f)),
+// gm = conj(T(MB - f)) (so that conj(T(f + MB)) = conj(gm)); na -> position of f, nb -> position of MB - f
+__device__ __forceinline__ void xf_pair(c2 A, c2 Bs, float2 w, float2 gf, float2 gm, c2& na, c2& nb) {
+    const c2 Bc = c2_conj(Bs);
+    const c2 E = c2_scale(c2_add(A, Bc), 0.5f);
+    const c2 O = c2_mul_mi(c2_scale(c2_sub(A, Bc), 0.5f));
+    const c2 tO = c2_mulw(O, w);
+    const c2 Yp = c2_mulw(c2_add(E, tO), gf);             // X(f)      conj(T(f))
+    const c2 Ym = c2_mulwc(c2_sub(E, tO), gm);            // X(f + MB) conj(T(f + MB))
+    const c2 S = c2_scale(c2_add(Yp, Ym), 0.5f);
+    const c2 D = c2_mul_pi(c2_mulwc(c2_scale(c2_sub(Yp, Ym), 0.5f), w));
+    na = c2_add(S, D);
+    nb = c2_conj(c2_sub(S, D));
 }
 
-template <int NT, int WAVES>
-__global__ __launch_bounds__(kXfThreads, WAVES) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
+// LDS element: (re_A, re_B, im_A, im_B)
+__device__ __forceinline__ c2 xf_ld(const float4* p) {
+    const float4 v = lds_read4(p);
+    return c2{v2_make(v.x, v.y), v2_make(v.z, v.w)};
+}
+__device__ __forceinline__ void xf_st(float4* p, c2 v) {
+    *p = make_float4(v2_x(v.re), v2_y(v.re), v2_x(v.im), v2_y(v.im));
+}
+
+template <int NT>
+__global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
                                                                   int ns, const float* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1) {
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
     D4W_DYN_LDS(smem_raw);
-    float2* bufA = reinterpret_cast<float2*>(smem_raw);        // [2 rows][ROWP]: block spectra, then each template's correlation
-    float2* tw1 = bufA + 2 * ROWP;                              // [M1]
+    float4* buf = reinterpret_cast<float4*>(smem_raw);          // [ROWP] block spectra of both rows, then each template's correlation
+    float2* tw1 = reinterpret_cast<float2*>(buf + ROWP);        // [M1]
     float2* tw2 = tw1 + M1;                                     // [NB][NC]
     const int tid = threadIdx.x;
-    if (tid < M1) {
-        tw1[tid] = T.tw1[tid];
-        tw2[tid] = T.tw2[tid];
-    }
-    const int r = tid >> 7, rem = tid & 127;                    // row of the pair, item within the row
-    const int row = 2 * blockIdx.y + r;
-    const bool live = row < nx;
+    tw1[tid] = T.tw1[tid];
+    tw2[tid] = T.tw2[tid];
+    const int rowA = 2 * blockIdx.y;
+    const bool hasB = rowA + 1 < nx;
+    const int rowB = hasB ? rowA + 1 : rowA;
     const int k0 = blockIdx.x * kXfStep;                        // first lag / first sample of the block
-    const float* xr = x + (size_t)(live ? row : 0) * ns;
-    const float mu = (mean && live) ? mean[row] : 0.f;
-    float gain = 1.f;
-    if (maxabs && live) {
-        const float a = maxabs[row];
-        gain = (a > 0.f) ? 1.0f / a : 0.f;
+    const float* xa = x + (size_t)rowA * ns;
+    const float* xb = x + (size_t)rowB * ns;
+    const float mua = mean ? mean[rowA] : 0.f, mub = mean ? mean[rowB] : 0.f;
+    float ga_ = 1.f, gb_ = 1.f;
+    if (maxabs) {
+        const float a = maxabs[rowA], b = maxabs[rowB];
+        ga_ = (a > 0.f) ? 1.0f / a : 0.f;
+        gb_ = (b > 0.f) ? 1.0f / b : 0.f;
     }
-    // ---------------- S1: radix NA on the packed samples z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = j1 + a M1
-    float2 pf[NA];
-    {
-        const int j1 = rem;
-        const bool vec = ((((size_t)row * ns + k0) & 1) == 0);  // 8-byte aligned pairs
-        static_for<NA>([&](auto aa) {
-            constexpr int a = decltype(aa)::value;
-            const int i = k0 + 2 * (j1 + a * M1);
-            float2 v = make_float2(0.f, 0.f);
-            if (live) {
+    const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
+    const bool veca = ((((size_t)rowA * ns + k0) & 1) == 0), vecb = ((((size_t)rowB * ns + k0) & 1) == 0);
+    const bool interior = (k0 + kXfB <= ns) && veca && vecb;   // whole block inside both rows, 8-byte aligned pairs
+    // NT templates per launch: the host launches NT = 1 once per template.  Measured at 20000 x 120000
+    // (HF + LF): two NT = 1 launches 9.1 ms; one NT = 2 launch 11.2 ms (57 KiB of straight-line code
+    // against a 64 KiB instruction cache shared by two CUs), 11.6 ms when the block spectrum is kept
+    // in registers across the templates instead (VGPR spills).
+    static_for<NT>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        // ---------------- S1: radix NA on the packed samples z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = j1 + a M1
+        c2 pf[NA];
+        {
+            const int j1 = tid;
+            auto fetch = [&](const float* xr, float mu, bool vec, int i) -> float2 {
+                float2 v = make_float2(0.f, 0.f);
                 if (vec && i + 1 < ns) {
                     v = *reinterpret_cast<const float2*>(xr + i);
                     v.x -= mu;
@@ -160,72 +174,79 @@ __global__ __launch_bounds__(kXfThreads, WAVES) void xcorr_fft_blocks(XfTables T
                     if (i < ns) v.x = xr[i] - mu;
                     if (i + 1 < ns) v.y = xr[i + 1] - mu;
                 }
+                return v;
+            };
+            if (interior) {
+                const float2* pa = reinterpret_cast<const float2*>(xa + k0) + j1;
+                const float2* pb = reinterpret_cast<const float2*>(xb + k0) + j1;
+                const v2f mu2 = v2_make(mua, mub);
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const float2 va = pa[a * M1], vb = pb[a * M1];
+                    pf[a] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+                });
+            } else {
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const int i = k0 + 2 * (j1 + a * M1);
+                    pf[a] = c2_make(fetch(xa, mua, veca, i), fetch(xb, mub, vecb, i));
+                });
             }
-            pf[a] = v;
-        });
-    }
-    __syncthreads();                                            // twiddle tables visible
-    {
-        const int j1 = rem;
-        dft<NA>(pf);
-        float2 pw[NA];
-        xf_pw_tree<NA>(tw1[j1], pw);
-        float2* rowp = bufA + r * ROWP;
-        static_for<NA>([&](auto aa) {
-            constexpr int a = decltype(aa)::value;
-            rowp[xf_ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
-        });
-    }
-    lds_barrier();
-    // ---------------- S2: radix NB in place, x W_M1^(j2 b')
-    {
-        const int g = rem >> 3, j2 = rem & 7;
-        float2* rowp = bufA + r * ROWP;
-        float2 v[NB];
-        static_for<NB>([&](auto bb) {
-            constexpr int b = decltype(bb)::value;
-            v[b] = rowp[xf_ad(g * M1 + j2 + b * NC)];
-        });
-        dft<NB>(v);
-        static_for<NB>([&](auto bb) {
-            constexpr int b = decltype(bb)::value;
-            rowp[xf_ad(g * M1 + j2 + b * NC)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
-        });
-    }
-    lds_barrier();
-    // ---------------- per template: MID (radix NC on a group and its Hermitian partner group, pair op,
-    //                  inverse radix NC), S2' and S1'.  Item p < 127: a proper pair (Gi < PG); p = 127: the
-    //                  two self-paired groups 0 (digit partner (NC - d) % NC, f = 0 pairs with the Nyquist
-    //                  bin) and NB / 2.
-    int Gi, PG;
-    {
-        const int p = rem;
-        if (p < 112) { const int g = 1 + (p >> 4), b = p & 15; Gi = g * NB + b; PG = (NA - g) * NB + (NB - 1 - b); }
-        else if (p < 120) { const int b = p - 112; Gi = (NA / 2) * NB + b; PG = (NA / 2) * NB + (NB - 1 - b); }
-        else if (p < 127) { const int b = p - 119; Gi = b; PG = NB - b; }
-        else { Gi = 0; PG = NB / 2; }
-    }
-    const bool selfitem = (rem == 127);
-    const float sc = gain / (float)MB;
-    // the item's two groups of the block spectrum stay in registers for every template, so the
-    // correlation of each template can overwrite the row buffer in place (37 KiB of LDS per
-    // workgroup = four workgroups per CU)
-    float2 a[NC], b[NC];
-    {
-        const float2* rowp = bufA + r * ROWP;
-        const float2* ga = rowp + xf_ad(Gi * NC);
-        const float2* gb = rowp + xf_ad(PG * NC);
-        static_for<NC>([&](auto dd) {
-            constexpr int d = decltype(dd)::value;
-            a[d] = ga[d];
-            b[d] = gb[d];
-        });
-        dft<NC>(a);
-        dft<NC>(b);
-    }
-    const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];       // W_B^f, f = f0(G) + 256 d: W_B^(256 d) are literals
-    static_for<NT>([&](auto tt) {
-        constexpr int t = decltype(tt)::value;
+        }
+        if (t == 0) __syncthreads();                                // twiddle tables visible
+        {
+            const int j1 = tid;
+            dftp<NA>(pf);
+            float2 pw[NA];
+            xf_pw_tree<NA>(tw1[j1], pw);
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                xf_st(buf + xf_ad(j1 + a * M1), (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]));
+            });
+        }
+        lds_barrier();
+        // ---------------- S2: radix NB in place, x W_M1^(j2 b')
+        {
+            const int g = tid >> 3, j2 = tid & 7;
+            c2 v[NB];
+            static_for<NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                v[b] = xf_ld(buf + xf_ad(g * M1 + j2 + b * NC));
+            });
+            dftp<NB>(v);
+            static_for<NB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                xf_st(buf + xf_ad(g * M1 + j2 + b * NC), (b == 0) ? v[0] : c2_mulw(v[b], tw2[b * NC + j2]));
+            });
+        }
+        lds_barrier();
+        // ---------------- per template: MID (radix NC on a group and its Hermitian partner group, pair op,
+        //                  inverse radix NC), S2' and S1'.  Item p < 127: a proper pair (Gi < PG); p = 127: the
+        //                  two self-paired groups 0 (digit partner (NC - d) % NC, f = 0 pairs with the Nyquist
+        //                  bin) and NB / 2.
+        int Gi, PG;
+        {
+            const int p = tid;
+            if (p < 112) { const int g = 1 + (p >> 4), b = p & 15; Gi = g * NB + b; PG = (NA - g) * NB + (NB - 1 - b); }
+            else if (p < 120) { const int b = p - 112; Gi = (NA / 2) * NB + b; PG = (NA / 2) * NB + (NB - 1 - b); }
+            else if (p < 127) { const int b = p - 119; Gi = b; PG = NB - b; }
+            else { Gi = 0; PG = NB / 2; }
+        }
+        const bool selfitem = (tid == 127);
+        // the item's two groups of the block spectrum stay in registers for every template
+        c2 a[NC], b[NC];
+        {
+            const float4* ga = buf + xf_ad(Gi * NC);
+            const float4* gb = buf + xf_ad(PG * NC);
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                a[d] = xf_ld(ga + d);
+                b[d] = xf_ld(gb + d);
+            });
+            dftp<NC>(a);
+            dftp<NC>(b);
+        }
+        const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];       // W_B^f, f = f0(G) + 256 d: W_B^(256 d) are literals
         {
             const float2* gpa = T.gp + (size_t)t * MB + Gi * NC;
             const float2* gpb = T.gp + (size_t)t * MB + PG * NC;
@@ -236,100 +257,99 @@ __global__ __launch_bounds__(kXfThreads, WAVES) void xcorr_fft_blocks(XfTables T
                 GB[d] = gpb[d];
             });
             const float gny = T.gn[t];
-            float2 ra[NC], rb[NC];
+            c2 ra[NC], rb[NC];
             if (!selfitem) {
-                float2 nb[NC];
                 static_for<NC>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     constexpr int pn = NC - 1 - d;
-                    xf_pair(a[d], b[pn], rot_const<d, 16>(wa0), GA[d], GB[pn], ra[d], nb[d]);
-                });
-                static_for<NC>([&](auto dd) {
-                    constexpr int e = decltype(dd)::value;
-                    rb[e] = nb[NC - 1 - e];
+                    xf_pair(a[d], b[pn], rot_const<d, 16>(wa0), GA[d], GB[pn], ra[d], rb[pn]);
                 });
             } else {
-                // group 0 (array a): partner digit (NC - d) % NC; d = 0 pairs X(0) with the Nyquist bin
-                float2 na[NC], nb[NC];
-                static_for<NC>([&](auto dd) {
+                // group 0 (array a): partner digit (NC - d) % NC; d = 0 pairs X(0) with the Nyquist bin,
+                // d = 0 and d = NC / 2 are their own partners (the partner-side value is kept)
+                static_for<NC / 2 + 1>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     constexpr int pz = (NC - d) % NC;
                     const float2 gm = (d == 0) ? make_float2(gny, 0.f) : GA[pz];
-                    xf_pair(a[d], a[pz], rot_const<d, 16>(wa0), GA[d], gm, na[d], nb[d]);
-                });
-                static_for<NC>([&](auto dd) {
-                    constexpr int e = decltype(dd)::value;
-                    constexpr int pz = (NC - e) % NC;
-                    ra[e] = (e < pz) ? na[e] : nb[pz];
+                    c2 na;
+                    xf_pair(a[d], a[pz], rot_const<d, 16>(wa0), GA[d], gm, na, ra[pz]);
+                    if constexpr (pz != d) ra[d] = na;
                 });
                 // group NB / 2 (array b): partner digit NC - 1 - d, no self-paired position
-                static_for<NC>([&](auto dd) {
+                static_for<NC / 2>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     constexpr int pn = NC - 1 - d;
-                    xf_pair(b[d], b[pn], rot_const<d, 16>(wb0), GB[d], GB[pn], na[d], nb[d]);
-                });
-                static_for<NC>([&](auto dd) {
-                    constexpr int e = decltype(dd)::value;
-                    constexpr int pn = NC - 1 - e;
-                    rb[e] = (e < pn) ? na[e] : nb[pn];
+                    xf_pair(b[d], b[pn], rot_const<d, 16>(wb0), GB[d], GB[pn], rb[d], rb[pn]);
                 });
             }
-            idft<NC>(ra);
-            idft<NC>(rb);
-            float2* outp = bufA + r * ROWP;
-            float2* oa = outp + xf_ad(Gi * NC);
-            float2* ob = outp + xf_ad(PG * NC);
+            idftp<NC>(ra);
+            idftp<NC>(rb);
+            float4* oa = buf + xf_ad(Gi * NC);
+            float4* ob = buf + xf_ad(PG * NC);
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
-                oa[d] = ra[d];
-                ob[d] = rb[d];
+                xf_st(oa + d, ra[d]);
+                xf_st(ob + d, rb[d]);
             });
         }
         lds_barrier();
         // ---------------- S2': inverse radix NB
         {
-            const int g = rem >> 3, j2 = rem & 7;
-            float2* rowp = bufA + r * ROWP;
-            float2 v[NB];
+            const int g = tid >> 3, j2 = tid & 7;
+            c2 v[NB];
             static_for<NB>([&](auto bb) {
-                constexpr int b = decltype(bb)::value;
-                const float2 xv = rowp[xf_ad(g * M1 + j2 + b * NC)];
-                v[b] = (b == 0) ? xv : c_mulc(xv, tw2[b * NC + j2]);
+                constexpr int bq = decltype(bb)::value;
+                const c2 xv = xf_ld(buf + xf_ad(g * M1 + j2 + bq * NC));
+                v[bq] = (bq == 0) ? xv : c2_mulwc(xv, tw2[bq * NC + j2]);
             });
-            idft<NB>(v);
+            idftp<NB>(v);
             static_for<NB>([&](auto bb) {
-                constexpr int b = decltype(bb)::value;
-                rowp[xf_ad(g * M1 + j2 + b * NC)] = v[b];
+                constexpr int bq = decltype(bb)::value;
+                xf_st(buf + xf_ad(g * M1 + j2 + bq * NC), v[bq]);
             });
         }
         lds_barrier();
         // ---------------- S1': inverse radix NA -> lags k0 + 2m, k0 + 2m + 1 (m = j1 + a M1), the first S of them
         {
-            const int j1 = rem;
+            const int j1 = tid;
             float2 pw[NA];
             xf_pw_tree<NA>(tw1[j1], pw);
-            const float2* rowp = bufA + r * ROWP;
-            float2 v[NA];
+            c2 v[NA];
             static_for<NA>([&](auto aa) {
-                constexpr int a = decltype(aa)::value;
-                const float2 xv = rowp[xf_ad(j1 + a * M1)];
-                v[a] = (a == 0) ? xv : c_mulc(xv, pw[a]);
+                constexpr int aq = decltype(aa)::value;
+                const c2 xv = xf_ld(buf + xf_ad(j1 + aq * M1));
+                v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pw[aq]);
             });
-            idft<NA>(v);
-            if (live) {
-                float* yr = (t == 0 ? y0 : y1) + (size_t)row * ns;
-                const bool vec = ((((size_t)row * ns + k0) & 1) == 0);
+            idftp<NA>(v);
+            float* ya = (t == 0 ? y0 : y1) + (size_t)rowA * ns;
+            float* yb = (t == 0 ? y0 : y1) + (size_t)rowB * ns;
+            if (interior) {
+                float2* oa = reinterpret_cast<float2*>(ya + k0) + j1;
+                float2* ob = reinterpret_cast<float2*>(yb + k0) + j1;
                 static_for<NA>([&](auto aa) {
-                    constexpr int a = decltype(aa)::value;
-                    const int m = j1 + a * M1;
-                    const int k = k0 + 2 * m;
-                    if (2 * m < kXfStep && k < ns) {
-                        const float2 o = c_scale(v[a], sc);
-                        if (vec && k + 1 < ns) *reinterpret_cast<float2*>(yr + k) = o;
-                        else {
-                            yr[k] = o.x;
-                            if (k + 1 < ns) yr[k + 1] = o.y;
-                        }
+                    constexpr int aq = decltype(aa)::value;
+                    if (2 * (j1 + aq * M1) < kXfStep) {
+                        const c2 o = c2_scale2(v[aq], sc);
+                        oa[aq * M1] = c2_a(o);
+                        if (hasB) ob[aq * M1] = c2_b(o);
+                    }
+                });
+            } else {
+                auto put = [&](float* yr, bool vec, int k, float2 o) {
+                    if (k >= ns) return;
+                    if (vec && k + 1 < ns) *reinterpret_cast<float2*>(yr + k) = o;
+                    else {
+                        yr[k] = o.x;
+                        if (k + 1 < ns) yr[k + 1] = o.y;
+                    }
+                };
+                static_for<NA>([&](auto aa) {
+                    constexpr int aq = decltype(aa)::value;
+                    const int m = j1 + aq * M1;
+                    if (2 * m < kXfStep) {
+                        const c2 o = c2_scale2(v[aq], sc);
+                        put(ya, veca, k0 + 2 * m, c2_a(o));
+                        if (hasB) put(yb, vecb, k0 + 2 * m, c2_b(o));
                     }
                 });
             }
@@ -369,17 +389,21 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
     D4W_LAUNCH(xcf_spectra, dim3(ceil_div(ntpl * kXfMB, 256)), dim3(256), 0, stream, taps, ntpl, ltaps, len0, len1, gp, gn,
                tw1, tw2, wg);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
-    const size_t lds = ((size_t)2 * kXfRowP + 2 * kXfM1) * sizeof(float2);
-    // register budget: 4 waves per SIMD (128 VGPRs) spills the two-template kernel; 3 (168 VGPRs) does not
-    static const int waves = [] { const char* v = getenv("D4W_XF_WAVES"); return v ? atoi(v) : 3; }();
-#define D4W_XF_LAUNCH(NT, WV)                                                                                   \
-    do {                                                                                                        \
-        D4W_LAUNCH((xcorr_fft_blocks<NT, WV>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, mean, maxabs, \
-                   y0, y1);                                                                                     \
-    } while (0)
-    if (ntpl == 1) { if (waves == 4) D4W_XF_LAUNCH(1, 4); else D4W_XF_LAUNCH(1, 3); }
-    else { if (waves == 4) D4W_XF_LAUNCH(2, 4); else if (waves == 2) D4W_XF_LAUNCH(2, 2); else D4W_XF_LAUNCH(2, 3); }
-#undef D4W_XF_LAUNCH
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+#ifndef D4W_EMU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+#endif
+    for (int t = 0; t < ntpl; ++t) {
+        XfTables Tt = T;
+        Tt.gp = gp + (size_t)t * kXfMB;
+        Tt.gn = gn + t;
+        D4W_LAUNCH(xcorr_fft_blocks<1>, grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
+                   t == 0 ? y0 : y1, (float*)nullptr);
+    }
     return D4W_OK;
 }
 

@@ -20,3 +20,9 @@ for method in ("fft", "direct"):
 yf = ddet._xcorr_device(x[:64], tpl, True, "fft"); yd = ddet._xcorr_device(x[:64], tpl, True, "direct")
 out["fft_vs_direct_rel"] = float((yf[0] - yd[0]).abs().max() / yd[0].abs().max())
 print(json.dumps(out))
+ts = []
+for i in range(6):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); y0 = ddet._xcorr_device(x, tpl[:1], normalize=False, method="fft"); y1 = ddet._xcorr_device(x, tpl[1:], normalize=False, method="fft"); b.record(); b.synchronize()
+    ts.append(a.elapsed_time(b)); del y0, y1
+print(json.dumps({"fft_two_single_template_launches": float(np.median(ts[1:]))}))
