@@ -242,6 +242,7 @@ def main():
 
     stage_ms = {}
     acc = np.zeros(5)
+    mf_k = {"mf_row_stats": 0.0, "mf_xcorr_fft_blocks": 0.0}
     for _ in range(args.steps):
         if "bp" in stages:
             stage_ms["bp_sosfiltfilt"] = stage_ms.get("bp_sosfiltfilt", 0.0) + ev_time(
@@ -250,20 +251,35 @@ def main():
             _, ms = plan.apply_timed(x, out=y)
             acc += np.array(ms)
         if "mf" in stages:
+            src = y if "fk" in stages else x
             stage_ms["mf_rowstats_xcorr"] = stage_ms.get("mf_rowstats_xcorr", 0.0) + ev_time(
-                lambda: ddet._xcorr_device(y if "fk" in stages else x, tpl, normalize=True))
+                lambda: ddet._xcorr_device(src, tpl, normalize=True))
+            # the stage's kernels one by one: row_stats, then one xcorr_fft_blocks launch per template
+            # (each call below = the 30-microsecond spectra kernel + ONE block-transform launch)
+            mean = torch.empty(nx, dtype=torch.float32, device=device)
+            mx = torch.empty(nx, dtype=torch.float32, device=device)
+            mf_k["mf_row_stats"] += ev_time(lambda: dw._lib.check(dw._lib.lib.d4w_row_stats_f32(
+                src.data_ptr(), nx, ns, mean.data_ptr(), mx.data_ptr(), torch.cuda.current_stream().cuda_stream)))
+            one = 0.0
+            for tp in tpl:
+                one += ev_time(lambda: ddet._xcorr_device(src, [tp], normalize=False, method="fft"))
+            mf_k["mf_xcorr_fft_blocks"] += one / len(tpl)
     acc /= args.steps
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
     kernel_ms = {PASS_NAMES[i]: float(acc[i]) for i in range(5)} if "fk" in stages else {}
     if "fk" in stages:
         stage_ms["fk_filter"] = float(acc.sum())
     # algorithmic bytes per launch: an f-k pass reads and writes the block once
-    # (8 B/sample); band-pass 2 x (4+4) B/sample; matched filter 4 + 4 (stats) + 8 B/sample
+    # (8 B/sample); row_stats reads it once (4 B/sample); one xcorr_fft_blocks launch reads it and
+    # writes one correlogram (8 B/sample); band-pass stage 2 x (4+4) B/sample
     alg_bytes = {n: 8.0 * samples for n in PASS_NAMES}
     cand = dict(kernel_ms)
     if "mf" in stages:
-        cand["mf_rowstats_xcorr"] = stage_ms["mf_rowstats_xcorr"]
-        alg_bytes["mf_rowstats_xcorr"] = 16.0 * samples
+        for k in mf_k:
+            kernel_ms[k] = mf_k[k] / args.steps
+            cand[k] = kernel_ms[k]
+        alg_bytes["mf_row_stats"] = 4.0 * samples
+        alg_bytes["mf_xcorr_fft_blocks"] = 8.0 * samples
     if "bp" in stages:
         cand["bp_sosfiltfilt"] = stage_ms["bp_sosfiltfilt"]
         alg_bytes["bp_sosfiltfilt"] = 16.0 * samples
@@ -271,13 +287,15 @@ def main():
     achieved = alg_bytes[dom] / (cand[dom] * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by scripts/pmc_summary.py
+    tkey = {"mf_row_stats": "row_stats", "mf_xcorr_fft_blocks": "xcorr_fft_blocks"}.get(dom, dom)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes[dom],
                 "kernel_ms": kernel_ms, "stage_ms": stage_ms}
     if "fk" in stages:
         fk_gbs = 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9
