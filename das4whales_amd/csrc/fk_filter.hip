@@ -1138,8 +1138,9 @@ int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out)
     // ---------------- time-phase descriptor: C1 = 1, C2 = local rows
     d4w_fk_plan& tp = pl->tp;
     memset(&tp.dev, 0, sizeof(tp.dev));
-    int TA = 16;
-    while (TA > 1 && (long)N1 * TA > kMaxTile) TA /= 2;
+    // one degenerate axis leaves the whole LDS tile to the other: long contiguous strips
+    int TA = 512;
+    while (TA > 1 && ((long)N1 * TA > kMaxTile || TA > N2)) TA /= 2;
     if ((long)N1 * TA > kMaxTile) { d4w_fkd_plan_destroy(pl); return fail(D4W_EINVAL, "N1 = %d exceeds the LDS tile", N1); }
     pl->TA_t = TA;
     tp.dev.d = FkDims{nxl, ns, M, 1, nxl, N1, N2, TA, 1};
@@ -1187,9 +1188,9 @@ int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out)
     // ---------------- channel-phase descriptor: N1 = 1, "N2" = slab width
     d4w_fk_plan& cp = pl->cp;
     memset(&cp.dev, 0, sizeof(cp.dev));
-    int TC = 16, TAc = 16;
+    int TC = 16, TAc = 512;
     while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
-    while (TAc > 1 && ((long)C1 * TAc > kMaxTile)) TAc /= 2;
+    while (TAc > 1 && ((long)C1 * TAc > kMaxTile || TAc > W)) TAc /= 2;
     pl->TC = TC; pl->TA_c = TAc;
     cp.dev.d = FkDims{nx, 2 * W, W, C1, C2, 1, W, TAc, TC};
     cp.dev.scale = (float)(1.0 / ((double)nx * (double)M));

@@ -107,6 +107,14 @@ class ShardedFkPlan:
         n = b - a
         return a + (n * j) // nch, a + (n * (j + 1)) // nch
 
+    def _scratch(self, name, numel, device):
+        """Persistent staging buffers (allocated once per plan: multi-GB temporaries churn the allocator)."""
+        pool = self.__dict__.setdefault("_pool", {})
+        t = pool.get(name)
+        if t is None or t.numel() < numel or t.device != device:
+            t = pool[name] = torch.empty(int(numel), dtype=torch.float32, device=device)
+        return t[:numel]
+
     def _all_to_all(self, recv, send, out_splits, in_splits):
         if self.world == 1:
             recv.copy_(send)
@@ -120,29 +128,33 @@ class ShardedFkPlan:
             raise ValueError("local block has shape %s, expected (%d, %d)" % (tuple(x_loc.shape), nxl, self.ns))
         x_loc = x_loc.to(torch.float32).contiguous()
         per = self.N2 * 2                                        # floats per sub-row
-        z = torch.empty((nxl, self.N1, per), dtype=torch.float32, device=x_loc.device)
+        z = torch.empty((nxl, self.N1, per), dtype=torch.float32, device=x_loc.device)     # returned to the caller
         self.check(self.lib.d4w_fkd_time_fwd_f32(self._h, x_loc.data_ptr(), z.data_ptr(), int(bool(taper)), _sptr(z)))
         qidx = [q.to(z.device) for q in self.qidx]
         nql = [len(q) for q in self.qidx]
         biggest = max(b - a for a, b in self.blocks) * self.N1 * per
         nch = max(1, -(-biggest // self.MAX_CALL_ELEMS))          # same on every rank
-        slab = torch.empty((self.nx, self.nq * per), dtype=torch.float32, device=z.device)   # [nx][nq][N2] complex
+        slab = self._scratch("slab", self.nx * self.nq * per, z.device).view(self.nx, self.nq * per)   # [nx][nq][N2] complex
         # exchange 1: sub-row q1 of every local channel -> rank owner[q1], in row chunks
         for j in range(nch):
             g0, g1 = self._chunk_rows(self.rank, j, nch)
             l0, l1 = g0 - self.row_begin, g1 - self.row_begin
-            send = torch.cat([z[l0:l1].index_select(1, qidx[s]).reshape(-1) for s in range(self.world)])
             to_peer = [(l1 - l0) * nql[s] * per for s in range(self.world)]
+            send = self._scratch("send", sum(to_peer), z.device)
+            off = 0
+            for s in range(self.world):
+                if to_peer[s]:
+                    torch.index_select(z[l0:l1], 1, qidx[s], out=send[off:off + to_peer[s]].view(l1 - l0, nql[s], per))
+                off += to_peer[s]
             rows = [self._chunk_rows(r, j, nch) for r in range(self.world)]
             from_peer = [(b - a) * self.nq * per for a, b in rows]
-            recv = slab.view(-1) if nch == 1 else torch.empty(sum(from_peer), dtype=torch.float32, device=z.device)
+            recv = slab.view(-1) if nch == 1 else self._scratch("recv", sum(from_peer), z.device)
             self._all_to_all(recv, send, from_peer, to_peer)
             if nch > 1:
                 off = 0
                 for (a, b), n in zip(rows, from_peer):
                     slab[a:b] = recv[off:off + n].view(b - a, self.nq * per)
                     off += n
-            del send, recv
         self.check(self.lib.d4w_fkd_chan_apply_f32(self._h, slab.data_ptr() if self.nq else None, _sptr(slab)))
         # exchange 2: the exact reverse
         for j in range(nch):
@@ -151,8 +163,15 @@ class ShardedFkPlan:
             rows = [self._chunk_rows(r, j, nch) for r in range(self.world)]
             to_peer = [(b - a) * self.nq * per for a, b in rows]
             from_peer = [(l1 - l0) * nql[s] * per for s in range(self.world)]
-            send = slab.view(-1) if nch == 1 else torch.cat([slab[a:b].reshape(-1) for a, b in rows])
-            back = torch.empty(sum(from_peer), dtype=torch.float32, device=z.device)
+            if nch == 1:
+                send = slab.view(-1)
+            else:
+                send = self._scratch("recv", sum(to_peer), z.device)
+                off = 0
+                for (a, b), n in zip(rows, to_peer):
+                    send[off:off + n].view(b - a, self.nq * per).copy_(slab[a:b])
+                    off += n
+            back = self._scratch("send", sum(from_peer), z.device)
             self._all_to_all(back, send, from_peer, to_peer)
             off = 0
             for s in range(self.world):
@@ -160,8 +179,6 @@ class ShardedFkPlan:
                 if n:
                     z[l0:l1].index_copy_(1, qidx[s], back[off:off + n].view(l1 - l0, nql[s], per))
                 off += n
-            del send, back
-        del slab
         self.check(self.lib.d4w_fkd_time_inv_f32(self._h, z.data_ptr(), _sptr(z)))
         return z.view(nxl, self.ns)
 
