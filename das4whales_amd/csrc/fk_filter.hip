@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <tuple>
 
 #include "fft_lds.h"
 #include "fft_host.h"
@@ -1014,35 +1016,45 @@ struct FkdSlab {
     const float2* wcol;       // [N2]
     const float* mask;        // [nx][nq][N2] folded mask of the owned sub-rows
     const float* nyq;         // [nx]
+    int hilbert;              // 0: x folded mask (f-k filter); 1: x (-i sign(f)), rows self-paired (analytic signal)
 };
 
 // pair op of fk_passB on the slab layout (see the algebra there); one thread per Hermitian pair
 __global__ __launch_bounds__(kThreads) void fkd_pair_slab(FkdSlab S, float2* __restrict__ slab) {
     const int jq = blockIdx.z, r = blockIdx.y;
-    const int rp = S.row_partner[r], jp = S.jq_partner[jq];
+    const int rp = S.hilbert ? r : S.row_partner[r], jp = S.jq_partner[jq];
     const long keyA = (long)r * S.nq + jq, keyB = (long)rp * S.nq + jp;
     if (keyB < keyA) return;
     const bool same = (keyA == keyB);
     const bool k1zero = (S.q1_of[jq] == 0);
     float2* A = slab + (size_t)keyA * S.N2;
     float2* B = slab + (size_t)keyB * S.N2;
-    const float* mA = S.mask + (size_t)keyA * S.N2;
-    const float* mB = S.mask + (size_t)keyB * S.N2;
+    const float* mA = S.hilbert ? nullptr : S.mask + (size_t)keyA * S.N2;
+    const float* mB = S.hilbert ? nullptr : S.mask + (size_t)keyB * S.N2;
     const float2 wr = S.wrow[S.q1_of[jq]];
-    const float nyq = S.nyq[r];
+    const float nyq = S.hilbert ? 0.f : S.nyq[r];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S.N2; i += gridDim.x * blockDim.x) {
         const int j = k1zero ? S.mirror0[i] : (S.N2 - 1 - i);
         if (same && j < i) continue;
         const float2 a = A[i];
         const float2 Bc = c_conj(B[j]);
-        const float ma = mA[i];
-        const float mb = (k1zero && i == 0) ? nyq : mB[j];
         const float2 w = c_mul(wr, S.wcol[i]);
         const float2 E = c_scale(c_add(a, Bc), 0.5f);
         const float2 O = c_mul_mi(c_scale(c_sub(a, Bc), 0.5f));
         const float2 tO = c_mul(w, O);
-        const float2 Yp = c_scale(c_add(E, tO), ma);
-        const float2 Ym = c_scale(c_sub(E, tO), mb);
+        float2 Yp, Ym;
+        if (S.hilbert) {
+            // spectrum of the Hilbert transform: -i X(f) for 0 < f < M, +i X(f) for the negative
+            // frequencies f + M, zero at DC and Nyquist (scipy's h = 1 there belongs to the real part)
+            const bool dc = k1zero && i == 0;
+            Yp = dc ? make_float2(0.f, 0.f) : c_mul_mi(c_add(E, tO));
+            Ym = dc ? make_float2(0.f, 0.f) : c_mul_pi(c_sub(E, tO));
+        } else {
+            const float ma = mA[i];
+            const float mb = (k1zero && i == 0) ? nyq : mB[j];
+            Yp = c_scale(c_add(E, tO), ma);
+            Ym = c_scale(c_sub(E, tO), mb);
+        }
         const float2 Sm = c_scale(c_add(Yp, Ym), 0.5f);
         const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
         A[i] = c_add(Sm, D);
@@ -1108,7 +1120,7 @@ int d4w_fkd_plan_destroy(d4w_fkd_plan* pl) {
     return D4W_OK;
 }
 
-int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out) {
+static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d4w_fkd_plan** out) {
     if (!out) return fail(D4W_EINVAL, "plan pointer is NULL");
     *out = nullptr;
     if (nx < 1 || ns < 2 || (ns & 1)) return fail(D4W_EINVAL, "bad shape %d x %d (ns must be even)", nx, ns);
@@ -1245,11 +1257,14 @@ int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out)
     S.q1_of = c_q1of;
     pl->d_rowk = const_cast<int*>(c_rowk); pl->d_k1 = const_cast<int*>(c_k1); pl->d_k2 = const_cast<int*>(c_k2);
     pl->d_q1of = const_cast<int*>(c_q1of);
-    void* p = nullptr;
-    if (hipMalloc(&p, (size_t)nx * W * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc of the slab mask failed"); }
-    cp.allocs.push_back(p); pl->d_mask = (float*)p;
-    if (hipMalloc(&p, (size_t)nx * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
-    cp.allocs.push_back(p); pl->d_nyq = (float*)p;
+    S.hilbert = 0;
+    if (want_mask) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)nx * W * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc of the slab mask failed"); }
+        cp.allocs.push_back(p); pl->d_mask = (float*)p;
+        if (hipMalloc(&p, (size_t)nx * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        cp.allocs.push_back(p); pl->d_nyq = (float*)p;
+    }
     S.mask = pl->d_mask; S.nyq = pl->d_nyq;
 #undef D4W_TRY
 #ifndef D4W_EMU
@@ -1276,6 +1291,10 @@ int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out)
     return D4W_OK;
 }
 
+int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out) {
+    return fkd_plan_build(nx, ns, world, rank, true, out);
+}
+
 /* info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq_local, C1, C2, 0} */
 int d4w_fkd_plan_info(const d4w_fkd_plan* pl, int* info) {
     if (!pl || !info) return fail(D4W_EINVAL, "NULL argument");
@@ -1292,7 +1311,7 @@ int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* pl, int* owner) {
 }
 
 int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
-    if (!pl || !mask_shifted) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     const int nq = (int)pl->myq.size();
     if (nq > 0) {
         dim3 grid(std::min(ceil_div(nq * pl->N2, kThreads), 64), pl->nx);
@@ -1352,6 +1371,80 @@ int d4w_fkd_chan_apply_f32(d4w_fkd_plan* pl, float* slab, void* stream) {
                        stream, pl->slab, d2))) return rc;
     if ((rc = launch_k(pl->gen_c2 ? fk_passC<true, true> : fk_passC<true, false>, dim3(std::min(ntC, persist)), blk, pl->lds_c2, stream, P, d2, ntC))) return rc;
     return launch_k(pl->gen_c1 ? fk_passA_inv<true> : fk_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, d2, ntA);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Analytic signal of rows too long for one workgroup's LDS (e.g. 120 000 samples): the four-step
+ * time phase of the distributed plan over ALL rows (world = 1), the Hilbert pair op on the packed
+ * spectrum, the inverse time phase, and one elementwise combine with x.  Same modes as
+ * d4w_analytic_f32 (spectral.hip).  ws: [nx][ns] float32 scratch.
+ * ------------------------------------------------------------------------------------------ */
+}  // extern "C"
+
+namespace d4w {
+__global__ __launch_bounds__(kThreads) void analytic_combine(const float* __restrict__ x, const float* __restrict__ h,
+                                                              float* __restrict__ y, int ns, int mode,
+                                                              const float* __restrict__ var, float fscale) {
+    const size_t base = (size_t)blockIdx.y * ns;
+    const int nout = (mode == 3) ? ns - 1 : ns;
+    float* yr = y + (size_t)blockIdx.y * nout;
+    const float inv_var = (mode == 2) ? 1.0f / var[blockIdx.y] : 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += gridDim.x * blockDim.x) {
+        const float re = x[base + i], im = h[base + i];
+        float v;
+        if (mode == 0) v = sqrtf(fmaf(re, re, im * im));
+        else if (mode == 1) v = im;
+        else if (mode == 2) v = 10.0f * log10f(fmaf(re, re, im * im) * inv_var);
+        else {
+            const float2 p = c_mulc(make_float2(x[base + i + 1], h[base + i + 1]), make_float2(re, im));
+            v = atan2f(p.y, p.x) * fscale;
+        }
+        yr[i] = v;
+    }
+}
+}  // namespace d4w
+
+static std::mutex g_long_mu;
+static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_plans;
+
+extern "C" {
+
+size_t d4w_analytic_long_ws_bytes(int nx, int ns) { return (nx > 0 && ns > 0) ? (size_t)nx * ns * sizeof(float) : 0; }
+
+int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
+                          void* ws, void* stream) {
+    if (!x || !y || !ws || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");
+    if (ns & 1) return fail(D4W_EINVAL, "ns = %d must be even on the long-row path", ns);
+    if (mode < 0 || mode > 3) return fail(D4W_EINVAL, "mode = %d not in 0..3", mode);
+    if (mode == 2 && !var) return fail(D4W_EINVAL, "mode 2 needs the row variances");
+    if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
+    int devid = 0;
+    D4W_HIP(hipGetDevice(&devid));
+    d4w_fkd_plan* pl = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_long_mu);
+        auto key = std::make_tuple(devid, nx, ns);
+        auto it = g_long_plans.find(key);
+        if (it == g_long_plans.end()) {
+            int rc = fkd_plan_build(nx, ns, 1, 0, false, &pl);
+            if (rc) return rc;
+            pl->slab.hilbert = 1;
+            pl->tp.dev.scale = (float)(1.0 / (double)pl->M);     // forward / inverse pair of the packed rows
+            g_long_plans[key] = pl;
+        } else {
+            pl = it->second;
+        }
+    }
+    float* h = (float*)ws;
+    int rc = d4w_fkd_time_fwd_f32(pl, x, h, 0, stream);
+    if (rc) return rc;
+    if ((rc = launch_k(fkd_pair_slab, dim3(std::min(ceil_div(pl->N2, kThreads), 8), nx, pl->N1), dim3(kThreads), 0, stream,
+                       pl->slab, reinterpret_cast<float2*>(h)))) return rc;
+    if ((rc = d4w_fkd_time_inv_f32(pl, h, stream))) return rc;
+    const float fscale = (float)(fs / (2.0 * M_PI));
+    D4W_LAUNCH(analytic_combine, dim3(std::min(ceil_div(ns, kThreads), 128), nx), dim3(kThreads), 0, stream, x,
+               (const float*)h, y, ns, mode, var, fscale);
+    return D4W_OK;
 }
 
 }  // extern "C"

@@ -531,6 +531,12 @@ int d4w_row_var_f32(const float* x, int nx, int ns, float* var, void* stream) {
     return D4W_OK;
 }
 
+int d4w_analytic_row_fits_lds(int ns) {
+    if (ns < 2) return 0;
+    const int L = (ns % 2 == 0) ? ns / 2 : ns;
+    return ((size_t)L + kTwLo + (size_t)(L + kTwLo - 1) / kTwLo) * sizeof(float2) <= kSpLdsMax ? 1 : 0;
+}
+
 int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
                      void* stream) {
     if (!x || !y || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");

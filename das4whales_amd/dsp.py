@@ -396,8 +396,16 @@ def _analytic(x2d, mode, fs=0.0, var=None):
     nx, ns = x2d.shape
     y = torch.empty((nx, ns - 1 if mode == 3 else ns), dtype=torch.float32, device=x2d.device)
     with torch.cuda.device(x2d.device):
-        check(lib.d4w_analytic_f32(dev.ptr(x2d), dev.ptr(y), nx, ns, int(mode),
-                                   dev.ptr(var) if var is not None else None, float(fs), dev.stream_ptr(x2d)))
+        if lib.d4w_analytic_row_fits_lds(ns) or ns % 2:
+            check(lib.d4w_analytic_f32(dev.ptr(x2d), dev.ptr(y), nx, ns, int(mode),
+                                       dev.ptr(var) if var is not None else None, float(fs), dev.stream_ptr(x2d)))
+        else:                                        # long rows: four-step time-axis transform through HBM
+            for a in range(0, nx, 65535):
+                xb, yb = x2d[a:a + 65535], y[a:a + 65535]
+                ws = torch.empty(int(lib.d4w_analytic_long_ws_bytes(xb.shape[0], ns)), dtype=torch.uint8, device=x2d.device)
+                check(lib.d4w_analytic_long_f32(dev.ptr(xb), dev.ptr(yb), xb.shape[0], ns, int(mode),
+                                                dev.ptr(var[a:a + 65535]) if var is not None else None, float(fs),
+                                                dev.ptr(ws), dev.stream_ptr(x2d)))
     return y
 
 
@@ -432,7 +440,11 @@ def snr_tr_array(trace, env=False):
     y = torch.empty_like(x)
     var = torch.empty(nx, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.d4w_snr_f32(dev.ptr(x), dev.ptr(y), nx, ns, int(bool(env)), dev.ptr(var), dev.stream_ptr(x)))
+        if env and not (lib.d4w_analytic_row_fits_lds(ns) or ns % 2):
+            check(lib.d4w_row_var_f32(dev.ptr(x), nx, ns, dev.ptr(var), dev.stream_ptr(x)))
+            y = _analytic(x, 2, var=var)
+        else:
+            check(lib.d4w_snr_f32(dev.ptr(x), dev.ptr(y), nx, ns, int(bool(env)), dev.ptr(var), dev.stream_ptr(x)))
     return dev.like_input(y, trace)
 
 

@@ -216,6 +216,14 @@ int d4w_minmax_normalise_f32(float* x, size_t n, void* stream);
  * ------------------------------------------------------------------------------------------ */
 int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
                      void* stream);
+/* Rows too long for one workgroup's LDS (d4w_analytic_row_fits_lds(ns) == 0, e.g. 120 000 samples):
+ * same modes through the four-step time-axis transform of the distributed f-k plan (two passes
+ * each way over HBM) + the Hilbert pair op + one combine pass; ns even; ws = DEVICE scratch of
+ * d4w_analytic_long_ws_bytes(nx, ns) bytes. */
+int d4w_analytic_row_fits_lds(int ns);
+size_t d4w_analytic_long_ws_bytes(int nx, int ns);
+int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
+                          void* ws, void* stream);
 int d4w_row_var_f32(const float* x, int nx, int ns, float* var, void* stream);
 int d4w_snr_f32(const float* x, float* y, int nx, int ns, int env, float* var_ws, void* stream);
 int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream);

@@ -246,3 +246,31 @@ def test_argument_errors(emu):
     assert b"prime" in emu.d4w_last_error()
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 15, 4, 0, 7, None) == -1                # odd n_fft
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 16, 4, 0, 9, None) == -1                # bin range
+
+
+@pytest.mark.parametrize("nx,ns", [(3, 480), (2, 2 * 3 * 5 * 7 * 11), (5, 96)])
+def test_analytic_long_row_path(emu, nx, ns):
+    """The HBM four-step path (used for rows beyond one workgroup's LDS) on small rows: all four
+    modes agree with the single-workgroup kernel and the oracle."""
+    rng = np.random.default_rng(ns)
+    x = (rng.standard_normal((nx, ns)) + 0.2).astype(np.float32)
+    emu.d4w_analytic_long_ws_bytes.restype = ctypes.c_size_t
+    ws = np.empty(emu.d4w_analytic_long_ws_bytes(nx, ns), dtype=np.uint8)
+    var = np.var(x.astype(np.float64), axis=1).astype(np.float32)
+    z = orc.hilbert(x)
+    for mode in range(4):
+        y = np.empty((nx, ns - 1 if mode == 3 else ns), dtype=np.float32)
+        ok(emu, emu.d4w_analytic_long_f32(vp(x), vp(y), nx, ns, mode, vp(var), ctypes.c_double(200.0), vp(ws), None))
+        y_short = analytic(emu, x, mode, fs=200.0, var=var)
+        if mode == 0:
+            assert rel(y, np.abs(z)) < TOL
+        elif mode == 1:
+            assert rel(y, z.imag) < TOL
+        elif mode == 2:
+            lin, ref = 10.0 ** (y.astype(np.float64) / 10), np.abs(z) ** 2 / var[:, None]
+            assert np.max(np.abs(lin - ref)) / np.max(ref) < TOL
+        else:
+            d = np.abs(y - y_short)
+            assert np.max(np.minimum(d, np.abs(d - 200.0))) < 0.5      # noise rows: |z| ~ 0 samples are ill-conditioned
+            assert np.median(d) < 1e-3
+    assert emu.d4w_analytic_row_fits_lds(12000) == 1 and emu.d4w_analytic_row_fits_lds(120000) == 0

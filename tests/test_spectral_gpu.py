@@ -62,8 +62,29 @@ def test_envelope_config1_rows(dw):
     assert e.is_cuda and e.dtype == torch.float32
     ref = orc.envelope(x[:40])
     assert rel(e[:40].cpu().numpy(), ref) < TOL
-    with pytest.raises(ValueError, match="single-workgroup"):
-        dw.dsp.envelope(torch.zeros((2, 120000), device="cuda"))
+
+
+def test_envelope_long_rows(dw):
+    """120 000-sample rows (BASELINE configs[2] row length) do not fit one workgroup's LDS: the
+    four-step time-axis path through HBM (d4w_analytic_long_f32) gives the same envelope, SNR and picks."""
+    import scipy.signal as sps
+    rng = np.random.default_rng(8)
+    nx, ns = 70, 120000
+    x = rng.standard_normal((nx, ns))
+    xt = torch.from_numpy(x).cuda().float()
+    e = dw.dsp.envelope(xt)
+    ref = orc.envelope(x[:6])
+    err = rel(e[:6].cpu().numpy(), ref)
+    print("envelope 70 x 120000 (6 rows): rel err %.3e" % err)
+    assert err < TOL
+    s = dw.dsp.snr_tr_array(x[:4], env=True)
+    lin, lref = 10.0 ** (s / 10), np.abs(orc.hilbert(x[:4])) ** 2 / np.var(x[:4], axis=1, keepdims=True)
+    assert np.max(np.abs(lin - lref)) / np.max(lref) < TOL
+    thr = 3.0
+    got = dw.detect.pick_times_env(x[:3], thr)
+    for c in range(3):
+        refp = sps.find_peaks(orc.envelope(x[c]), prominence=thr)[0]
+        assert len(set(got[c]) ^ set(refp)) <= max(1, len(refp) // 200)
 
 
 def test_spectrograms_golden(dw, golden):
