@@ -8,5 +8,6 @@ C ABI in include/d4w.h; PyTorch-ROCm is used only for device memory, streams and
 from . import _lib  # noqa: F401  (fails loudly if the native library is missing)
 from . import dsp  # noqa: F401
 from . import detect  # noqa: F401
+from . import data_handle  # noqa: F401
 
-__all__ = ["dsp", "detect"]
+__all__ = ["dsp", "detect", "data_handle"]

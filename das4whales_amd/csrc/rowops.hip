@@ -177,6 +177,35 @@ __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restric
 }
 
 // =============================================================================================
+// fused ingest: data_handle.load_das_data + raw2strain (data_handle.py:157-176,
+// 213-214): select channels c0 + r * cstep of the raw [nch][ns] matrix, convert to floating point,
+// remove each channel's mean, multiply by scale_factor -- one kernel, the raw row is read from HBM
+// once (the second sweep hits L2), float64 accumulation and subtraction, float32 result.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(kStatThreads) void raw2strain_rows(const T* __restrict__ raw, int ns, int c0, int cstep,
+                                                                double scale, float* __restrict__ y) {
+    __shared__ double red[kStatThreads / 64];
+    __shared__ double s_mean;
+    const T* row = raw + ((size_t)c0 + (size_t)blockIdx.x * cstep) * ns;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ns; i += kStatThreads) s += (double)row[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x / 64] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kStatThreads / 64; ++w) t += red[w];
+        s_mean = t / (double)ns;
+    }
+    __syncthreads();
+    const double mu = s_mean;
+    float* out = y + (size_t)blockIdx.x * ns;
+    for (int i = threadIdx.x; i < ns; i += kStatThreads) out[i] = (float)(((double)row[i] - mu) * scale);
+}
+
+// =============================================================================================
 // matched filter: direct-form correlation, NT templates fused over one read of x
 //   y_t[c][k] = g[c] * sum_n (x[c][n+k] - m[c]) * taps[t][n]
 // VALU-bound (2*(L_0 + L_1) flop per 4 + 4*NT bytes).  On gfx950 a v_pk_fma_f32 issues
@@ -402,6 +431,19 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     int rc = sos_launch<false>(nsec, grid, stream, A, x, nullptr, t, edge, nx, ns, padlen, S, W);
     if (rc) return rc;
     return sos_launch<true>(nsec, grid, stream, A, t, edge, y, nullptr, nx, ns, padlen, S, W);
+}
+
+int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep, int nx_out, double scale_factor,
+                       float* y, void* stream) {
+    if (!raw || !y || ns < 1 || nx_out < 1 || c0 < 0 || cstep < 1) return fail(D4W_EINVAL, "bad argument");
+    switch (raw_dtype) {
+        case 0: D4W_LAUNCH(raw2strain_rows<int32_t>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const int32_t*)raw, ns, c0, cstep, scale_factor, y); break;
+        case 1: D4W_LAUNCH(raw2strain_rows<int16_t>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const int16_t*)raw, ns, c0, cstep, scale_factor, y); break;
+        case 2: D4W_LAUNCH(raw2strain_rows<float>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const float*)raw, ns, c0, cstep, scale_factor, y); break;
+        case 3: D4W_LAUNCH(raw2strain_rows<double>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const double*)raw, ns, c0, cstep, scale_factor, y); break;
+        default: return fail(D4W_EINVAL, "raw_dtype = %d (0 int32, 1 int16, 2 float32, 3 float64)", raw_dtype);
+    }
+    return D4W_OK;
 }
 
 int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream) {

@@ -138,6 +138,16 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
                         void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused ingest (the step in front of the path): data_handle.load_das_data's channel selection and
+ * float conversion + data_handle.raw2strain (data_handle.py:157-176,213-214):
+ *   y[r][:] = (float64(raw[c0 + r*cstep][:]) - mean_r) * scale_factor,   r < nx_out
+ * raw: DEVICE [nch][ns] row-major of raw_dtype 0 = int32 (OptaSense RawData), 1 = int16,
+ * 2 = float32, 3 = float64; y: float32 [nx_out][ns].  One read of the selected raw rows, one write.
+ * ------------------------------------------------------------------------------------------ */
+int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep, int nx_out,
+                       double scale_factor, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Matched filter (time-domain cross-correlation, positive lags), rows independent:
  * replaces detect.compute_cross_correlogram (detect.py:140-166), detect.shift_xcorr
  * (detect.py:96-112) and the numerator of detect.shift_nxcorr (detect.py:115-137).

@@ -193,3 +193,25 @@ def test_xcorr_fft_ragged(emu, nx, ns, l0, l1):
         assert rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - l0)))) < TOL
         assert rel(y1[c], orc.shift_xcorr(x[c], np.pad(t1, (0, ns - l1)))) < TOL
     assert emu.d4w_xcorr_fft_max_support() == 161
+
+
+def test_raw2strain_ingest(emu):
+    """data_handle.load_das_data channel selection + raw2strain (data_handle.py:157-176,213-214)."""
+    rng = np.random.default_rng(9)
+    nch, ns = 23, 1001
+    raw = (rng.standard_normal((nch, ns)) * 3e4 + 1.5e5).astype(np.int32)
+    scale = 2.3e-11
+    c0, c1, step = 3, 21, 4
+    ref = raw[c0:c1:step].astype(np.float64)
+    ref -= ref.mean(axis=1, keepdims=True)                      # raw2strain
+    ref *= scale
+    nx = ref.shape[0]
+    for dt, code in ((np.int32, 0), (np.int16, 1), (np.float32, 2), (np.float64, 3)):
+        r = (raw // 8).astype(dt) if dt == np.int16 else raw.astype(dt)
+        rr = r[c0:c1:step].astype(np.float64)
+        rr = (rr - rr.mean(axis=1, keepdims=True)) * scale
+        y = np.empty((nx, ns), dtype=np.float32)
+        rc = emu.d4w_raw2strain_f32(vp(np.ascontiguousarray(r)), code, ns, c0, step, nx, ctypes.c_double(scale), vp(y), None)
+        assert rc == 0, emu.d4w_last_error()
+        assert rel(y, rr) < 1e-6
+    assert emu.d4w_raw2strain_f32(vp(raw), 7, ns, 0, 1, 2, ctypes.c_double(1.0), vp(y), None) == -1

@@ -162,3 +162,27 @@ def test_correlogram_full_size_rows_vs_oracle(dw):
     e2 = rel(c_lf[rows].cpu().numpy(), orc.compute_cross_correlogram(xr, lf))
     print("correlogram 20000x120000 (5 rows): rel err HF %.3e LF %.3e" % (e1, e2))
     assert e1 < TOL and e2 < TOL
+
+
+# ------------------------------------------------------------------------------------------
+# fused ingest
+# ------------------------------------------------------------------------------------------
+def test_raw2strain_and_channel_selection(dw):
+    """data_handle.raw2strain (data_handle.py:157-176) and the array part of load_das_data
+    (data_handle.py:213-228) on an int32 'RawData' matrix."""
+    rng = np.random.default_rng(21)
+    nch, ns = 300, 12000
+    raw = (rng.standard_normal((nch, ns)) * 4e4 + 2e5).astype(np.int32)
+    meta = {"scale_factor": 1.7e-11, "fs": 200.0, "dx": 2.0419046878814697}
+    sel = [10, 290, 4]
+    ref = raw[sel[0]:sel[1]:sel[2]].astype(np.float64)
+    ref -= np.mean(ref, axis=1, keepdims=True)
+    ref *= meta["scale_factor"]
+    y, tx, dist = dw.data_handle.load_das_data_array(raw, sel, meta)
+    assert y.is_cuda and tuple(y.shape) == ref.shape
+    assert rel(y.cpu().numpy(), ref) < 1e-6
+    assert np.allclose(tx, np.arange(ns) / 200.0) and np.allclose(dist, (np.arange(ref.shape[0]) * 4 + 10) * meta["dx"])
+    tr = raw[:50].astype(np.float64)
+    out = dw.data_handle.raw2strain(tr.copy(), meta)
+    exp = (tr - tr.mean(axis=1, keepdims=True)) * meta["scale_factor"]
+    assert out.dtype == np.float64 and rel(out, exp) < 1e-6
