@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask f-k timing")
     ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
+    ap.add_argument("--no-fused-stats", action="store_true",
+                    help="matched-filter row statistics by a separate pass over the filtered block instead of the f-k epilogue")
     ap.add_argument("--shard", type=str, default="replicas", choices=["replicas", "channel"],
                     help="N > 1: 'replicas' = one independent block per GPU (default, weak scaling); 'channel' = ONE "
                          "block sharded by channel block, exact distributed f-k filter (two all-to-alls), strong scaling")
@@ -201,11 +203,17 @@ def main():
         cur = x
         if "bp" in stages:
             cur = ddsp._sosfiltfilt_device(cur, sos_bp, 51)
+        st = None
         if "fk" in stages:
-            plan.apply(cur, out=y)
+            if "mf" in stages and not args.no_fused_stats:
+                # row mean / max|.| of the filtered block come out of the f-k filter's last pass
+                _, mean, mx = plan.apply_stats(cur, out=y)
+                st = (mean, mx)
+            else:
+                plan.apply(cur, out=y)
             cur = y
         if "mf" in stages:
-            return ddet._xcorr_device(cur, tpl, normalize=True)
+            return ddet._xcorr_device(cur, tpl, normalize=True, stats=st)
         return cur
 
     for _ in range(args.warmup):
@@ -247,13 +255,20 @@ def main():
         if "bp" in stages:
             stage_ms["bp_sosfiltfilt"] = stage_ms.get("bp_sosfiltfilt", 0.0) + ev_time(
                 lambda: ddsp._sosfiltfilt_device(x, sos_bp, 51))
+        fused = "fk" in stages and "mf" in stages and not args.no_fused_stats
+        st = None
         if "fk" in stages:
-            _, ms = plan.apply_timed(x, out=y)
+            if fused:
+                _, mean_f, mx_f, ms = plan.apply_stats(x, out=y, timed=True)
+                st = (mean_f, mx_f)
+            else:
+                _, ms = plan.apply_timed(x, out=y)
             acc += np.array(ms)
         if "mf" in stages:
             src = y if "fk" in stages else x
-            stage_ms["mf_rowstats_xcorr"] = stage_ms.get("mf_rowstats_xcorr", 0.0) + ev_time(
-                lambda: ddet._xcorr_device(src, tpl, normalize=True))
+            stage_ms["mf_xcorr" if fused else "mf_rowstats_xcorr"] = stage_ms.get(
+                "mf_xcorr" if fused else "mf_rowstats_xcorr", 0.0) + ev_time(
+                lambda: ddet._xcorr_device(src, tpl, normalize=True, stats=st))
             # the stage's kernels one by one: row_stats, then one xcorr_fft_blocks launch per template
             # (each call below = the 30-microsecond spectra kernel + ONE block-transform launch)
             mean = torch.empty(nx, dtype=torch.float32, device=device)
@@ -277,6 +292,8 @@ def main():
     if "mf" in stages:
         for k in mf_k:
             kernel_ms[k] = mf_k[k] / args.steps
+            if k == "mf_row_stats" and "fk" in stages and not args.no_fused_stats:
+                continue                     # not part of the step: statistics come from the f-k epilogue
             cand[k] = kernel_ms[k]
         alg_bytes["mf_row_stats"] = 4.0 * samples
         alg_bytes["mf_xcorr_fft_blocks"] = 8.0 * samples

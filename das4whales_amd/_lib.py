@@ -45,6 +45,9 @@ def _load():
         "d4w_fkd_time_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fkd_chan_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
         "d4w_fkd_time_inv_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
+        "d4w_fk_apply_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+        "d4w_fk_apply_timed_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                 P(ctypes.c_float)]),
         "d4w_taper_f32": (c_int, [c_void_p, c_int, c_int, c_void_p]),
         "d4w_sosfiltfilt_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
         "d4w_sosfiltfilt_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, P(ctypes.c_double), P(ctypes.c_double),

@@ -250,6 +250,120 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
     }
 }
 
+// pass A inverse with the row statistics of the filtered block in its epilogue (what the matched filter
+// normalises by, detect.py:157: mean and max|.| of every output row), so the consumer does not re-read
+// the block for them.  A thread's S2' item holds one packed sample of every c1 row; the tile order is
+// cut into RUNS of `run` consecutive tiles (same c2, i.e. the same C1 rows) that one workgroup walks in
+// order, accumulating per-thread partial sums / maxima in registers and reducing them once per run
+// (wave shuffle + one float atomicAdd / integer atomicMax per row and wave).
+template <class G>
+__global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* __restrict__ data, int run, int nruns,
+                                                               float* __restrict__ rowmean,
+                                                               unsigned* __restrict__ rowmaxbits) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = tile + G::C1 * G::N1 * G::TA;
+    constexpr int NBX = G::N2 / G::TA;
+    constexpr int STRIP = G::N1 * G::TA;
+    const int tid = threadIdx.x;
+    const int hi = tid / G::TA, tt = tid % G::TA;
+    const bool act1 = hi < G::C1, act2 = hi < G::N1;
+    const int myruns = (nruns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nseq = max(myruns, 0) * run;              // tiles this workgroup walks, in order
+    auto tile_of = [&](int sq) {
+        const int k = sq / run, j = sq - k * run;
+        return ((int)blockIdx.x + k * (int)gridDim.x) * run + j;
+    };
+    typedef FkPrefetchA<G::N1> Pre;
+    Pre A, B;
+    auto issue = [&](Pre& R, int t) {
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
+        if (act1) {
+            const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+            static_for<G::N1>([&](auto kk) {
+                constexpr int q1 = decltype(kk)::value;
+                R.pf[q1] = p[q1 * G::N2];
+            });
+            R.tc = P.twc[hi * G::C2 + c2];
+        }
+    };
+    float asum[G::C1], amax[G::C1];
+    static_for<G::C1>([&](auto cc) { asum[decltype(cc)::value] = 0.f; amax[decltype(cc)::value] = 0.f; });
+    const float inv_ns = 1.0f / (float)P.d.ns;
+    int par = 0;
+    auto body = [&](Pre& R, Pre& Rn, int sq, bool first) {
+        const int t = tile_of(sq);
+        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const float2* tw_cur = twl + par * STRIP;
+        const bool more = (sq + 1 < nseq);
+        if (first) {
+            if (act2) twl[par * STRIP + hi * G::TA + tt] = R.tw;
+            __syncthreads();
+        }
+        if (more && act2) twl[(par ^ 1) * STRIP + hi * G::TA + tt] = Rn.tw;
+        if (act1) {
+            static_for<G::N1>([&](auto kk) {
+                constexpr int q1 = decltype(kk)::value;
+                R.pf[q1] = c_mulc(R.pf[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
+            });
+            idft<G::N1>(R.pf);
+            static_for<G::N1>([&](auto kk) {
+                constexpr int n1 = decltype(kk)::value;
+                tile[(hi * G::N1 + n1) * G::TA + tt] = R.pf[n1];
+            });
+        }
+        lds_barrier();
+        if (sq + 2 < nseq) issue(R, tile_of(sq + 2));
+        float2 v[G::C1];
+        if (act2) {
+            static_for<G::C1>([&](auto cc) {
+                constexpr int q = decltype(cc)::value;
+                v[q] = tile[(q * G::N1 + hi) * G::TA + tt];
+            });
+        }
+        lds_barrier();
+        if (act2) {
+            idft<G::C1>(v);
+            float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                const float2 y2 = c_scale(v[c1], P.scale);
+                o[(size_t)c1 * G::C2 * G::M] = y2;
+                asum[c1] += y2.x + y2.y;
+                amax[c1] = fmaxf(amax[c1], fmaxf(fabsf(y2.x), fabsf(y2.y)));
+            });
+        }
+        if ((sq % run) == run - 1) {                     // end of a run: its C1 rows are complete for these columns
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                float sv = asum[c1], mv = amax[c1];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    sv += __shfl_xor(sv, off);
+                    mv = fmaxf(mv, __shfl_xor(mv, off));
+                }
+                if ((tid & 63) == 0) {
+                    const size_t row = (size_t)c1 * G::C2 + c2;
+                    atomicAdd(rowmean + row, sv * inv_ns);
+                    atomicMax(rowmaxbits + row, __float_as_uint(mv));      // mv >= 0: bit order = value order
+                }
+                asum[c1] = 0.f;
+                amax[c1] = 0.f;
+            });
+        }
+        par ^= 1;
+    };
+    if (nseq > 0) issue(A, tile_of(0));
+    if (nseq > 1) issue(B, tile_of(1));
+    bool first = true;
+    for (int sq = 0; sq < nseq; sq += 2) {
+        body(A, B, sq, first);
+        first = false;
+        if (sq + 1 < nseq) body(B, A, sq + 1, false);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass C: FFT over c2 = C2A x C2B for TC contiguous columns of one c1-position q.
 //   forward : S1 item (j < C2B, tt): radix C2A over rows j + a C2B, x W_C2^(j a') -> LDS

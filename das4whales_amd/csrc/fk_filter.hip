@@ -425,6 +425,7 @@ struct FkFastEntry {
     void (*A_fwd)(FkDev, const float2*, float2*, int, int);
     void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int);
     void (*A_inv)(FkDev, float2*, int, int);
+    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*);
     void (*C_fwd)(FkDev, FkFastDev, float2*, int, int);
     void (*C_inv)(FkDev, FkFastDev, float2*, int, int);
     void (*B_mid)(FkDev, FkFastDev, float2*, int, int);
@@ -442,6 +443,7 @@ static FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0) {
     e.A_fwd = fkf_passA_fwd<G, false>;
     e.A_fwd_taper = fkf_passA_fwd<G, true>;
     e.A_inv = fkf_passA_inv<G>;
+    e.A_inv_stats = fkf_passA_inv_stats<G>;
     e.C_fwd = fkf_passC<G, false>;
     e.C_inv = fkf_passC<G, true>;
     e.B_mid = fkf_passB<G>;
@@ -760,6 +762,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
             (void)hipFuncSetAttribute((const void*)fast->A_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
             (void)hipFuncSetAttribute((const void*)fast->A_fwd_taper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
             (void)hipFuncSetAttribute((const void*)fast->A_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
+            (void)hipFuncSetAttribute((const void*)fast->A_inv_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
             (void)hipFuncSetAttribute((const void*)fast->C_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->C_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->B_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
@@ -853,8 +856,10 @@ int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* 
 
 int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
 
-static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev) {
+static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev,
+                         float* row_mean = nullptr, float* row_maxabs = nullptr) {
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
+    if ((row_mean == nullptr) != (row_maxabs == nullptr)) return fail(D4W_EINVAL, "row_mean and row_maxabs go together");
     if (!pl->has_mask) return fail(D4W_EINVAL, "no mask set on this plan");
     const FkDev& P = pl->dev;
     const FkDims& d = P.d;
@@ -883,7 +888,19 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         D4W_MARK(3);
         if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
         D4W_MARK(4);
-        if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA))) return rc;
+        if (row_mean) {
+            // row statistics in the epilogue of the last pass: tiles walked in runs of `run` (a divisor of
+            // the tiles per c2, so that a run stays on the same C1 rows)
+            const int nbx = d.N2 / d.TA;
+            static const int run_env = [] { const char* v = getenv("D4W_FK_RUN_A"); return v ? atoi(v) : 30; }();
+            int run = 1;
+            for (int r = 1; r <= nbx && r <= std::max(run_env, 1); ++r) if (nbx % r == 0) run = r;
+            const int nruns = fA / run;
+            D4W_HIP(hipMemsetAsync(row_mean, 0, (size_t)d.nx * sizeof(float), st));
+            D4W_HIP(hipMemsetAsync(row_maxabs, 0, (size_t)d.nx * sizeof(float), st));
+            if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
+                               dst, run, nruns, row_mean, (unsigned*)row_maxabs))) return rc;
+        } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA))) return rc;
         D4W_MARK(5);
 #undef D4W_MARK
         return D4W_OK;
@@ -906,6 +923,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     if ((rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC))) return rc;
     D4W_MARK(4);
     if ((rc = launch_k(gA ? fk_passA_inv<true> : fk_passA_inv<false>, gridA, blk, pl->ldsA, stream, P, dst, ntA))) return rc;
+    if (row_mean && (rc = d4w_row_stats_f32(y, d.nx, d.ns, row_mean, row_maxabs, stream))) return rc;   // generic kernels: separate pass
     D4W_MARK(5);
 #undef D4W_MARK
     return D4W_OK;
@@ -915,11 +933,25 @@ int d4w_fk_apply_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void*
     return fk_apply_impl(pl, x, y, taper, stream, nullptr);
 }
 
+int d4w_fk_apply_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, float* row_mean, float* row_maxabs,
+                           void* stream) {
+    if (!row_mean || !row_maxabs) return fail(D4W_EINVAL, "NULL argument");
+    return fk_apply_impl(pl, x, y, taper, stream, nullptr, row_mean, row_maxabs);
+}
+
+int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, float* row_mean,
+                                 float* row_maxabs, void* stream, float* ms5);
+
 int d4w_fk_apply_timed_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, float* ms5) {
+    return d4w_fk_apply_timed_stats_f32(pl, x, y, taper, nullptr, nullptr, stream, ms5);
+}
+
+int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, float* row_mean,
+                                 float* row_maxabs, void* stream, float* ms5) {
     if (!ms5) return fail(D4W_EINVAL, "NULL argument");
     hipEvent_t ev[6];
     for (int i = 0; i < 6; ++i) D4W_HIP(hipEventCreate(&ev[i]));
-    int rc = fk_apply_impl(pl, x, y, taper, stream, ev);
+    int rc = fk_apply_impl(pl, x, y, taper, stream, ev, row_mean, row_maxabs);
     if (rc == D4W_OK) {
         hipError_t e = hipEventSynchronize(ev[5]);
         if (e != hipSuccess) rc = fail(D4W_EHIP, "hipEventSynchronize: %s", hipGetErrorString(e));

@@ -56,16 +56,19 @@ def _taps_tensor(taps_list, device):
     return torch.from_numpy(taps).to(device), lt
 
 
-def _xcorr_device(x, taps_list, normalize, method="auto"):
+def _xcorr_device(x, taps_list, normalize, method="auto", stats=None):
     """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
-    method: "fft" (overlap-save, supports <= 161 samples), "direct", or "auto" (fft when it applies)."""
+    method: "fft" (overlap-save, supports <= 161 samples), "direct", or "auto" (fft when it applies).
+    stats: optional (mean, maxabs) CUDA tensors of the rows, e.g. from FkPlan.apply_stats."""
     nx, ns = x.shape
     outs = []
     use_fft = method == "fft" or (method == "auto" and ns >= 1024
                                   and max(len(t) for t in taps_list) <= int(lib.d4w_xcorr_fft_max_support()))
     with torch.cuda.device(x.device):
         mean = mx = None
-        if normalize:
+        if normalize and stats is not None:
+            mean, mx = stats
+        elif normalize:
             mean = torch.empty(nx, dtype=torch.float32, device=x.device)
             mx = torch.empty(nx, dtype=torch.float32, device=x.device)
             check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))

@@ -78,6 +78,26 @@ class FkPlan:
             check(lib.d4w_fk_apply_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.stream_ptr(x)))
         return out
 
+    def apply_stats(self, x, out=None, taper=False, timed=False):
+        """apply() that also returns (mean, maxabs) of every filtered row -- what
+        detect.compute_cross_correlogram normalises by -- formed in the last pass's epilogue.
+        timed=True additionally returns the five pass times in ms."""
+        if tuple(x.shape) != (self.nx, self.ns):
+            raise ValueError("trace shape %s does not match the plan (%d, %d)" % (tuple(x.shape), self.nx, self.ns))
+        if out is None:
+            out = torch.empty_like(x)
+        mean = torch.empty(self.nx, dtype=torch.float32, device=x.device)
+        mx = torch.empty(self.nx, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(self.device):
+            if timed:
+                ms = (ctypes.c_float * 5)()
+                check(lib.d4w_fk_apply_timed_stats_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.ptr(mean),
+                                                       dev.ptr(mx), dev.stream_ptr(x), ms))
+                return out, mean, mx, list(ms)
+            check(lib.d4w_fk_apply_stats_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.ptr(mean),
+                                             dev.ptr(mx), dev.stream_ptr(x)))
+        return out, mean, mx
+
     def apply_timed(self, x, out=None, taper=False):
         """Like apply() but returns (out, [ms per pass A, C, B, C', A']) via HIP events."""
         if out is None:

@@ -70,11 +70,21 @@ int d4w_fk_plan_live_rows(const d4w_fk_plan* plan);
  * dsp.py:705-722, fused into the first pass; x itself is not modified). */
 int d4w_fk_apply_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, void* stream);
 
+/* d4w_fk_apply_f32 that also returns what the matched filter normalises the filtered rows by
+ * (detect.py:157): row_mean[c] = mean(y[c,:]), row_maxabs[c] = max|y[c,:]|, DEVICE float32 [nx].
+ * The shape-specialised kernels form them in the epilogue of the last pass (no extra read of y);
+ * other shapes run d4w_row_stats_f32 afterwards.  Feed them to d4w_xcorr_fft_f32 / d4w_xcorr_lens_f32. */
+int d4w_fk_apply_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, float* row_mean,
+                           float* row_maxabs, void* stream);
+
 /* Same as d4w_fk_apply_f32 but brackets each of the five passes (A, C, B, C', A') with HIP events
  * on `stream`, synchronises, and returns their durations in milliseconds in ms5_host[0..4].
  * Measurement aid for bench.py's roofline report; not for production loops. */
 int d4w_fk_apply_timed_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, void* stream,
                            float* ms5_host);
+/* timed variant of d4w_fk_apply_stats_f32 (row_mean / row_maxabs may both be NULL) */
+int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, float* row_mean,
+                                 float* row_maxabs, void* stream, float* ms5_host);
 
 /* ------------------------------------------------------------------------------------------
  * Distributed f-k filter: ONE [nx][ns] block sharded by contiguous channel block over `world`

@@ -120,3 +120,26 @@ def test_dead_row_pruning(emu, nx, ns):
     assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) == 0
     assert rel(y, orc.fk_filter_filt(x, md)) < TOL
     emu.d4w_fk_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("nx,ns,opts", [(18, 48, None), (8, 480, None), (100, 600, None), (40, 480, None), (100, 600, [-1, 0, 0, 0, 0, 0])])
+def test_apply_with_row_statistics(emu, nx, ns, opts):
+    """d4w_fk_apply_stats_f32: mean / max|.| of every filtered row from the last pass's epilogue
+    (shape-specialised kernels, several tiles per run) or from the separate row pass (generic)."""
+    rng = np.random.default_rng(nx * ns)
+    x = (rng.standard_normal((nx, ns)) + 0.7).astype(np.float32)
+    m = np.ascontiguousarray(rng.random((nx, ns)), dtype=np.float32)
+    plan = ctypes.c_void_p()
+    o = (ctypes.c_int * 6)(*opts) if opts else None
+    assert emu.d4w_fk_plan_create_ex(nx, ns, o, ctypes.byref(plan)) == 0, emu.d4w_last_error()
+    assert emu.d4w_fk_set_mask_dense_f32(plan, vp(m), None) == 0
+    y0, y1 = np.empty_like(x), np.empty_like(x)
+    mean = np.full(nx, np.nan, dtype=np.float32)
+    mx = np.full(nx, np.nan, dtype=np.float32)
+    assert emu.d4w_fk_apply_f32(plan, vp(x), vp(y0), 0, None) == 0
+    assert emu.d4w_fk_apply_stats_f32(plan, vp(x), vp(y1), 0, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
+    emu.d4w_fk_plan_destroy(plan)
+    assert np.array_equal(y0, y1)                       # same filter output, bit for bit
+    y64 = y1.astype(np.float64)
+    assert np.allclose(mx, np.abs(y64).max(axis=1), rtol=1e-6)
+    assert np.max(np.abs(mean - y64.mean(axis=1))) < 1e-6 * np.abs(y64).max()

@@ -185,3 +185,33 @@ def test_full_size_properties(dw):
     err4 = float((y - yg).abs().max() / yg.abs().max())
     print("20000x120000 pruned specialised vs generic, classic fan: %.3e" % err4)
     assert err4 < TOL
+
+
+def test_apply_stats_bench_shape(dw):
+    """20 000 x 120 000: the row mean / max|.| formed in the last pass's epilogue equal the statistics of
+    the filtered block (what detect.compute_cross_correlogram normalises by), the filter output is
+    unchanged, and the matched filter fed with them matches the one that computes its own."""
+    import torch
+    nx, ns = 20000, 120000
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((nx, ns), device="cuda", generator=gen) + 0.25
+    plan = dw.dsp.get_fk_plan(nx, ns)
+    mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419046878814697, 200.0)
+    plan.set_mask(mask)
+    del mask
+    y0 = plan.apply(x)
+    y1, mean, mx = plan.apply_stats(x)
+    assert torch.equal(y0, y1)
+    ref_mean = y1.double().mean(dim=1)
+    ref_max = y1.abs().amax(dim=1)
+    scale = float(ref_max.max())
+    assert float((mean.double() - ref_mean).abs().max()) < 1e-6 * scale
+    assert torch.allclose(mx, ref_max, rtol=1e-6, atol=0)
+    import numpy as np
+    t = np.arange(ns) / 200.0
+    hf = dw.detect.gen_template_fincall(t, 200.0, 17.8, 28.8, 0.68)
+    taps = [dw.detect._normalised_support(hf)]
+    rows = y1[:256].contiguous()
+    c_own = dw.detect._xcorr_device(rows, taps, normalize=True)[0]
+    c_fed = dw.detect._xcorr_device(rows, taps, normalize=True, stats=(mean[:256].contiguous(), mx[:256].contiguous()))[0]
+    assert float((c_own - c_fed).abs().max()) < 2e-6 * float(c_own.abs().max())
