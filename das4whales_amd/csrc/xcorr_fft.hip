@@ -358,6 +358,234 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two templates, one row per workgroup: the block is read ONCE, its forward transform runs in scalar
+// complex arithmetic, and the two correlations ride the halves of packed registers through the pair
+// op and ONE inverse transform (fft_pair.h with the pair = the two templates).  Same VALU work as
+// two row-pair launches, 12 instead of 16 bytes of HBM traffic per sample.
+//   forward S1, S2 (float2 LDS elements) -> every item reads its two groups into registers, radix 8
+//   -> barrier -> pair op for both templates -> inverse radix 8 -> (float4 LDS elements, in place)
+//   -> S2', S1' packed -> y0 and y1.
+// ---------------------------------------------------------------------------------------------
+// conj(a) * w for packed a and one complex scalar w
+__device__ __forceinline__ c2 c2_cmulw(c2 a, float2 w) {
+    return c2{v2_fma(a.im, w.y, v2_muls(a.re, w.x)), v2_fnma(a.im, w.x, v2_muls(a.re, w.y))};
+}
+
+// A = Z[f], Bs = Z[MB - f] (scalars); gf = (conj T0(f), conj T1(f)), gm = the same at MB - f
+__device__ __forceinline__ void xf_tpair(float2 A, float2 Bs, float2 w, c2 gf, c2 gm, c2& na, c2& nb) {
+    const float2 Bc = c_conj(Bs);
+    const float2 E = c_scale(c_add(A, Bc), 0.5f);
+    const float2 O = c_mul_mi(c_scale(c_sub(A, Bc), 0.5f));
+    const float2 tO = c_mul(w, O);
+    const c2 Yp = c2_mulw(gf, c_add(E, tO));              // X(f)      conj(T_t(f))
+    const c2 Ym = c2_cmulw(gm, c_sub(E, tO));             // X(f + MB) conj(T_t(f + MB)) = X(f + MB) conj(gm)
+    const c2 S = c2_scale(c2_add(Yp, Ym), 0.5f);
+    const c2 D = c2_mul_pi(c2_mulwc(c2_scale(c2_sub(Yp, Ym), 0.5f), w));
+    na = c2_add(S, D);
+    nb = c2_conj(c2_sub(S, D));
+}
+
+__global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, const float* __restrict__ x, int ns,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ maxabs,
+                                                                 float* __restrict__ y0, float* __restrict__ y1) {
+    constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
+    D4W_DYN_LDS(smem_raw);
+    float4* buf = reinterpret_cast<float4*>(smem_raw);          // [ROWP] packed correlations of the two templates
+    float2* bufs = reinterpret_cast<float2*>(smem_raw);         // the same memory as float2: the block spectrum
+    float2* tw1 = reinterpret_cast<float2*>(buf + ROWP);        // [M1]
+    float2* tw2 = tw1 + M1;                                     // [NB][NC]
+    const int tid = threadIdx.x;
+    tw1[tid] = T.tw1[tid];
+    tw2[tid] = T.tw2[tid];
+    const int row = blockIdx.y;
+    const int k0 = blockIdx.x * kXfStep;
+    const float* xr = x + (size_t)row * ns;
+    const float mu = mean ? mean[row] : 0.f;
+    float gain = 1.f;
+    if (maxabs) {
+        const float a = maxabs[row];
+        gain = (a > 0.f) ? 1.0f / a : 0.f;
+    }
+    const float sc = gain / (float)MB;
+    const bool vec = ((((size_t)row * ns + k0) & 1) == 0);
+    const bool interior = (k0 + kXfB <= ns) && vec;
+    // ---------------- S1 (scalar): radix NA on z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = j1 + a M1
+    {
+        const int j1 = tid;
+        float2 pf[NA];
+        if (interior) {
+            const float2* pa = reinterpret_cast<const float2*>(xr + k0) + j1;
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                const float2 v = pa[a * M1];
+                pf[a] = make_float2(v.x - mu, v.y - mu);
+            });
+        } else {
+            static_for<NA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                const int i = k0 + 2 * (j1 + a * M1);
+                float2 v = make_float2(0.f, 0.f);
+                if (i < ns) v.x = xr[i] - mu;
+                if (i + 1 < ns) v.y = xr[i + 1] - mu;
+                pf[a] = v;
+            });
+        }
+        __syncthreads();                                        // twiddle tables visible
+        dft<NA>(pf);
+        float2 pw[NA];
+        xf_pw_tree<NA>(tw1[j1], pw);
+        static_for<NA>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            bufs[xf_ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+        });
+    }
+    lds_barrier();
+    // ---------------- S2 (scalar): radix NB in place, x W_M1^(j2 b')
+    {
+        const int g = tid >> 3, j2 = tid & 7;
+        float2 v[NB];
+        static_for<NB>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            v[b] = bufs[xf_ad(g * M1 + j2 + b * NC)];
+        });
+        dft<NB>(v);
+        static_for<NB>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            bufs[xf_ad(g * M1 + j2 + b * NC)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
+        });
+    }
+    lds_barrier();
+    // ---------------- MID: the item's two groups (see xcorr_fft_blocks for the item list)
+    int Gi, PG;
+    {
+        const int p = tid;
+        if (p < 112) { const int g = 1 + (p >> 4), b = p & 15; Gi = g * NB + b; PG = (NA - g) * NB + (NB - 1 - b); }
+        else if (p < 120) { const int b = p - 112; Gi = (NA / 2) * NB + b; PG = (NA / 2) * NB + (NB - 1 - b); }
+        else if (p < 127) { const int b = p - 119; Gi = b; PG = NB - b; }
+        else { Gi = 0; PG = NB / 2; }
+    }
+    const bool selfitem = (tid == 127);
+    {
+        float2 a[NC], b[NC];
+        {
+            const float2* ga = bufs + xf_ad(Gi * NC);
+            const float2* gb = bufs + xf_ad(PG * NC);
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                a[d] = ga[d];
+                b[d] = gb[d];
+            });
+        }
+        // template spectra of both groups, packed over the two templates
+        c2 GA[NC], GB[NC];
+        {
+            const float2* g0a = T.gp + Gi * NC;
+            const float2* g0b = T.gp + PG * NC;
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                GA[d] = c2_make(g0a[d], g0a[MB + d]);
+                GB[d] = c2_make(g0b[d], g0b[MB + d]);
+            });
+        }
+        const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];
+        const c2 gny = c2{v2_make(T.gn[0], T.gn[1]), v2_make(0.f, 0.f)};
+        lds_barrier();                                          // every item has its groups: the buffer may be overwritten
+        dft<NC>(a);
+        dft<NC>(b);
+        c2 ra[NC], rb[NC];
+        if (!selfitem) {
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pn = NC - 1 - d;
+                xf_tpair(a[d], b[pn], rot_const<d, 16>(wa0), GA[d], GB[pn], ra[d], rb[pn]);
+            });
+        } else {
+            static_for<NC / 2 + 1>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pz = (NC - d) % NC;
+                c2 na;
+                xf_tpair(a[d], a[pz], rot_const<d, 16>(wa0), GA[d], (d == 0) ? gny : GA[pz], na, ra[pz]);
+                if constexpr (pz != d) ra[d] = na;
+            });
+            static_for<NC / 2>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pn = NC - 1 - d;
+                xf_tpair(b[d], b[pn], rot_const<d, 16>(wb0), GB[d], GB[pn], rb[d], rb[pn]);
+            });
+        }
+        idftp<NC>(ra);
+        idftp<NC>(rb);
+        float4* oa = buf + xf_ad(Gi * NC);
+        float4* ob = buf + xf_ad(PG * NC);
+        static_for<NC>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;
+            xf_st(oa + d, ra[d]);
+            xf_st(ob + d, rb[d]);
+        });
+    }
+    lds_barrier();
+    // ---------------- S2' (packed over the templates)
+    {
+        const int g = tid >> 3, j2 = tid & 7;
+        c2 v[NB];
+        static_for<NB>([&](auto bb) {
+            constexpr int bq = decltype(bb)::value;
+            const c2 xv = xf_ld(buf + xf_ad(g * M1 + j2 + bq * NC));
+            v[bq] = (bq == 0) ? xv : c2_mulwc(xv, tw2[bq * NC + j2]);
+        });
+        idftp<NB>(v);
+        static_for<NB>([&](auto bb) {
+            constexpr int bq = decltype(bb)::value;
+            xf_st(buf + xf_ad(g * M1 + j2 + bq * NC), v[bq]);
+        });
+    }
+    lds_barrier();
+    // ---------------- S1' -> y0, y1
+    {
+        const int j1 = tid;
+        float2 pw[NA];
+        xf_pw_tree<NA>(tw1[j1], pw);
+        c2 v[NA];
+        static_for<NA>([&](auto aa) {
+            constexpr int aq = decltype(aa)::value;
+            const c2 xv = xf_ld(buf + xf_ad(j1 + aq * M1));
+            v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pw[aq]);
+        });
+        idftp<NA>(v);
+        float* ya = y0 + (size_t)row * ns;
+        float* yb = y1 + (size_t)row * ns;
+        if (interior) {
+            float2* oa = reinterpret_cast<float2*>(ya + k0) + j1;
+            float2* ob = reinterpret_cast<float2*>(yb + k0) + j1;
+            static_for<NA>([&](auto aa) {
+                constexpr int aq = decltype(aa)::value;
+                if (2 * (j1 + aq * M1) < kXfStep) {
+                    const c2 o = c2_scale(v[aq], sc);
+                    oa[aq * M1] = c2_a(o);
+                    ob[aq * M1] = c2_b(o);
+                }
+            });
+        } else {
+            auto put = [&](float* yr, int k, float2 o) {
+                if (k >= ns) return;
+                yr[k] = o.x;
+                if (k + 1 < ns) yr[k + 1] = o.y;
+            };
+            static_for<NA>([&](auto aa) {
+                constexpr int aq = decltype(aa)::value;
+                const int m = j1 + aq * M1;
+                if (2 * m < kXfStep) {
+                    const c2 o = c2_scale(v[aq], sc);
+                    put(ya, k0 + 2 * m, c2_a(o));
+                    put(yb, k0 + 2 * m, c2_b(o));
+                }
+            });
+        }
+    }
+}
+
 constexpr size_t kXfWsFloats = 2 * 2 * kXfMB + 8 + 2 * kXfM1 * 2 + 2 * kXfNG;
 
 }  // namespace d4w
@@ -397,6 +625,23 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
         attr_done = true;
     }
 #endif
+    // D4W_XF_TPAIR=1: both templates off ONE read of x (one row per workgroup, the two correlations
+    // packed through one inverse transform).  Measured at 20000 x 120000: 8.96 ms against 8.93 ms for the
+    // two row-pair launches -- both forms are bound by VALU issue (~2000 packed instructions per row
+    // block), not by the 12 vs 16 bytes per sample they move -- so the default stays with the kernel
+    // that has the simpler forward stage.
+    static const int pairmode = [] { const char* v = getenv("D4W_XF_TPAIR"); return v ? atoi(v) : 0; }();
+    if (ntpl == 2 && pairmode && nx <= 65535) {
+#ifndef D4W_EMU
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_tpair, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            attr2 = true;
+        }
+#endif
+        D4W_LAUNCH(xcorr_fft_tpair, dim3(grid.x, nx), dim3(kXfThreads), lds, stream, T, x, ns, mean, maxabs, y0, y1);
+        return D4W_OK;
+    }
     for (int t = 0; t < ntpl; ++t) {
         XfTables Tt = T;
         Tt.gp = gp + (size_t)t * kXfMB;

@@ -170,6 +170,27 @@ def xcorr_fft_emu(lib, x, taps_list, normalize=True):
     return ys
 
 
+def test_xcorr_fft_template_pair_kernel(golden):
+    """The one-read two-template kernel (D4W_XF_TPAIR=1; the library reads the switch once per
+    process, hence the subprocess) gives the same correlograms."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); import tests.test_emu_rowops as t; "
+            "from tests.emu_util import load_emu; emu = load_emu(); "
+            "d = np.load(%r); yh, yl = t.xcorr_fft_emu(emu, d['x'], [t.norm_taps(d['hf']), t.norm_taps(d['lf'])]); "
+            "assert t.rel(yh, d['corr_hf']) < 1e-5 and t.rel(yl, d['corr_lf']) < 1e-5; "
+            "rng = np.random.default_rng(1); x = rng.standard_normal((3, 9001)); a, b = rng.standard_normal(161), rng.standard_normal(7); "
+            "y0, y1 = t.xcorr_fft_emu(emu, x, [a, b], normalize=False); "
+            "assert t.rel(y0[2], t.orc.shift_xcorr(x[2], np.pad(a, (0, 9001 - 161)))) < 1e-5; "
+            "assert t.rel(y1[1], t.orc.shift_xcorr(x[1], np.pad(b, (0, 9001 - 7)))) < 1e-5; print('ok')"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detect_12x2000.npz")))
+    env = dict(os.environ, D4W_XF_TPAIR="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_xcorr_fft_golden(emu, golden):
     d = golden("detect_12x2000.npz")
     yh, yl = xcorr_fft_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])])
