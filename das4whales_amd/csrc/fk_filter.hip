@@ -453,6 +453,10 @@ static FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0) {
 //                 C1  C2A C2B  N1  NA  NB  NC  TA  TC  thrA thrC thrB
 // 20000 x 120000: 128-byte column strips in pass C (TC = 16) are worth 3.8 vs 6.9 ms per pass over 64-byte ones
 using FkShapeBench = FkFastCfg<25, 25, 32, 25, 20, 12, 10, 16, 16, 448, 512, 256>;
+// BASELINE configs[0..1] geometry and the real OOI RAPID channel count (11020 = 20 x 19 x 29: the two
+// primes are register butterflies of the c2 axis)
+using FkShapeC1 = FkFastCfg<20, 10, 20, 5, 10, 12, 10, 16, 16, 320, 320, 256>;      // 4000 x 12000
+using FkShapeOOI = FkFastCfg<20, 19, 29, 5, 10, 12, 10, 16, 16, 320, 464, 256>;     // 11020 x 12000
 using FkShapeT1 = FkFastCfg<3, 2, 3, 2, 2, 3, 2, 2, 2, 64, 64, 64>;                 // 18 x 48    (tests)
 using FkShapeT2 = FkFastCfg<2, 2, 2, 2, 8, 3, 5, 2, 2, 64, 64, 64>;                 // 8 x 480    (tests)
 using FkShapeT3 = FkFastCfg<5, 4, 5, 5, 4, 3, 5, 4, 4, 64, 64, 64>;                 // 100 x 600  (tests)
@@ -460,6 +464,8 @@ using FkShapeT3 = FkFastCfg<5, 4, 5, 5, 4, 3, 5, 4, 4, 64, 64, 64>;             
 static const std::vector<FkFastEntry>& fast_shapes() {
     static const std::vector<FkFastEntry> v = {
         fast_entry<FkShapeBench>(1, 1, 2),
+        fast_entry<FkShapeC1>(2, 2, 2),
+        fast_entry<FkShapeOOI>(2, 2, 2),
         fast_entry<FkShapeT1>(2, 2, 2),
         fast_entry<FkShapeT2>(2, 2, 2),
         fast_entry<FkShapeT3>(2, 2, 2),

@@ -199,6 +199,27 @@ def _sos_decay_samples(sos, tol=1e-9, nmax=1 << 17):
         n *= 2
 
 
+def _sos_segment_length(nx, ns, warm, slots=None):
+    """Time-segment length of the recursive filter.  A wave owns 64 rows x one segment and walks
+    seg_len + warm samples of a latency-bound recursion, so the run time is about
+    (ns / nseg + warm) * ceil(groups * nseg / slots) for `slots` concurrently resident waves (1024
+    SIMDs x 4 waves that interleave their dependent chains): pick the nseg that minimises it.
+    Short blocks (4000 x 12000) want many short segments although most of their work is warm-up."""
+    import os
+    if slots is None:
+        slots = int(os.environ.get("D4W_SOS_SLOTS", 4096))
+    groups = -(-nx // 64)
+    best, best_cost = 0, float(ns + 2 * warm)        # nseg = 1: exact single segment
+    for nseg in range(2, max(2, ns // 64) + 1):
+        seg = -(-(-(-ns // nseg)) // 32) * 32
+        if seg + 2 * warm >= ns:
+            continue
+        cost = (seg + warm) * max(1.0, groups * nseg / float(slots))
+        if cost < best_cost:
+            best, best_cost = seg, cost
+    return best
+
+
 def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
     """x: float32 CUDA tensor [nx, ns] -> filtered tensor (new)."""
     import scipy.signal as sp
@@ -212,10 +233,8 @@ def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
     if warm is None:
         warm = -(-int(1.5 * _sos_decay_samples(sos)) // 32) * 32
     if seg_len is None:
-        groups = -(-nx // 64)
-        want = -(-2048 // groups)                    # ~8 waves per CU
-        seg_len = max(8 * warm, -(-(-(-ns // want)) // 32) * 32)
-    if seg_len + 2 * warm >= ns:
+        seg_len = _sos_segment_length(nx, ns, warm)
+    if seg_len <= 0 or seg_len + 2 * warm >= ns:
         seg_len, warm = 0, 0                         # one exact segment per row
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):

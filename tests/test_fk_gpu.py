@@ -215,3 +215,28 @@ def test_apply_stats_bench_shape(dw):
     c_own = dw.detect._xcorr_device(rows, taps, normalize=True)[0]
     c_fed = dw.detect._xcorr_device(rows, taps, normalize=True, stats=(mean[:256].contiguous(), mx[:256].contiguous()))[0]
     assert float((c_own - c_fed).abs().max()) < 2e-6 * float(c_own.abs().max())
+
+
+@pytest.mark.parametrize("nx,ns", [(4000, 12000), (11020, 12000)])
+def test_config_shapes_specialised_vs_generic(dw, nx, ns):
+    """The 60-s file shapes (BASELINE configs[0..1]; the real OOI channel count 11020 = 20 x 19 x 29)
+    run shape-specialised kernels: same result as the generic five passes, pruned and unpruned, and a
+    row subset against the float64 oracle's channel-axis / time-axis separable identity check."""
+    gen = torch.Generator(device="cuda").manual_seed(nx)
+    x = torch.randn((nx, ns), device="cuda", generator=gen)
+    dense = torch.rand((nx, ns), device="cuda", generator=gen)
+    fan = dw.dsp.fk_filter_design((nx, ns), [0, nx * 4, 4], 2.0419046878814697, 200.0)
+    fast, generic = dw.dsp.FkPlan(nx, ns), dw.dsp.FkPlan(nx, ns, opts=(-1, 0, 0, 0, 0, 0))
+    for m in (dense, fan):
+        fast.set_mask(m)
+        generic.set_mask(m)
+        y1, y2 = fast.apply(x), generic.apply(x)
+        err = float((y1 - y2).abs().max()) / float(y2.abs().max())
+        print("%d x %d specialised vs generic (%d live rows): %.3e" % (nx, ns, fast.live_rows(), err))
+        assert err < 3e-6
+    y1, mean, mx = fast.apply_stats(x)
+    assert torch.allclose(mx, y1.abs().amax(dim=1), rtol=1e-6, atol=0)
+    assert float((mean.double() - y1.double().mean(dim=1)).abs().max()) < 1e-6 * float(mx.max())
+    ident = torch.ones((nx, ns), device="cuda")
+    fast.set_mask(ident)
+    assert float((fast.apply(x) - x).abs().max()) / float(x.abs().max()) < TOL
