@@ -74,22 +74,55 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgs A, const float* __r
         s1[s] = A.s[s].z1 * x0;
         s2[s] = A.s[s].z2 * x0;
     }
+    // A chunk is INTERIOR when its 32 samples lie inside the row proper (no extension, no edge buffer)
+    // and inside this segment's walk: its loads are then branch-free, all 32 of a lane in flight at
+    // once, and issued one chunk ahead (the branchy edge fetch serialises its loads and is kept for
+    // the few chunks that touch a row end).
+    const bool full_rows = (row0 + kSosRows <= nx);
+    auto interior = [&](int m0) {
+        if (m0 + kSosChunk > count) return false;
+        const int lo = REV ? i_start - m0 - (kSosChunk - 1) : i_start + m0;
+        return lo >= 0 && lo + kSosChunk <= ns;
+    };
+    float pre[kSosChunk];
+    auto issue = [&](int m0) {
+#pragma unroll
+        for (int k = 0; k < kSosChunk; ++k) {
+            const int e = lane + k * kSosRows;
+            const int rl = e / kSosChunk, ml = e % kSosChunk;
+            const int row = min(row0 + rl, nx - 1);
+            const int i = REV ? i_start - (m0 + ml) : i_start + m0 + ml;
+            pre[k] = src[(size_t)row * ns + i];
+        }
+    };
+    int pre_for = -1;
+    if (count > 0 && interior(0)) { issue(0); pre_for = 0; }
     for (int m0 = 0; m0 < count; m0 += kSosChunk) {
         // ---- stage in: lanes walk time within a row (coalesced), two rows per wave instruction
-#pragma unroll 4
-        for (int e = lane; e < kSosRows * kSosChunk; e += kSosRows) {
-            const int rl = e / kSosChunk, ml = e % kSosChunk;
-            const int m = m0 + ml;
-            const int row = min(row0 + rl, nx - 1);
-            float v = 0.f;
-            if (m < count) {
-                const int i = REV ? i_start - m : i_start + m;
-                const float* r = src + (size_t)row * ns;
-                v = REV ? sos_fetch_bwd(r, edge_in + (size_t)row * padlen, ns, i) : sos_fetch_fwd(r, ns, i);
+        if (pre_for == m0) {
+#pragma unroll
+            for (int k = 0; k < kSosChunk; ++k) {
+                const int e = lane + k * kSosRows;
+                tile[(e / kSosChunk) * kSosPitch + (e % kSosChunk)] = pre[k];
             }
-            tile[rl * kSosPitch + ml] = v;
+        } else {
+#pragma unroll 4
+            for (int e = lane; e < kSosRows * kSosChunk; e += kSosRows) {
+                const int rl = e / kSosChunk, ml = e % kSosChunk;
+                const int m = m0 + ml;
+                const int row = min(row0 + rl, nx - 1);
+                float v = 0.f;
+                if (m < count) {
+                    const int i = REV ? i_start - m : i_start + m;
+                    const float* r = src + (size_t)row * ns;
+                    v = REV ? sos_fetch_bwd(r, edge_in + (size_t)row * padlen, ns, i) : sos_fetch_fwd(r, ns, i);
+                }
+                tile[rl * kSosPitch + ml] = v;
+            }
         }
         __syncthreads();
+        const int nextm = m0 + kSosChunk;
+        if (nextm < count && interior(nextm)) { issue(nextm); pre_for = nextm; }
         // ---- recursion: lane = row, 4 samples per LDS access
         float4* mine = reinterpret_cast<float4*>(tile + lane * kSosPitch);
 #pragma unroll 2
@@ -114,16 +147,27 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgs A, const float* __r
         __syncthreads();
         // ---- stage out (only this segment's own samples; the last forward segment also feeds
         //      the right-extension outputs to the edge buffer for the backward pass)
+        const int lo = REV ? i_start - m0 - (kSosChunk - 1) : i_start + m0;
+        if (full_rows && m0 + kSosChunk <= count && lo >= a && lo + kSosChunk <= b) {
+#pragma unroll
+            for (int k = 0; k < kSosChunk; ++k) {
+                const int e = lane + k * kSosRows;
+                const int rl = e / kSosChunk, ml = e % kSosChunk;
+                const int i = REV ? i_start - (m0 + ml) : i_start + m0 + ml;
+                dst[(size_t)(row0 + rl) * ns + i] = tile[rl * kSosPitch + ml];
+            }
+        } else {
 #pragma unroll 4
-        for (int e = lane; e < kSosRows * kSosChunk; e += kSosRows) {
-            const int rl = e / kSosChunk, ml = e % kSosChunk;
-            const int m = m0 + ml;
-            const int row = row0 + rl;
-            if (m < count && row < nx) {
-                const int i = REV ? i_start - m : i_start + m;
-                const float v = tile[rl * kSosPitch + ml];
-                if (i >= a && i < b) dst[(size_t)row * ns + i] = v;
-                else if (!REV && i >= ns) edge_out[(size_t)row * padlen + (i - ns)] = v;
+            for (int e = lane; e < kSosRows * kSosChunk; e += kSosRows) {
+                const int rl = e / kSosChunk, ml = e % kSosChunk;
+                const int m = m0 + ml;
+                const int row = row0 + rl;
+                if (m < count && row < nx) {
+                    const int i = REV ? i_start - m : i_start + m;
+                    const float v = tile[rl * kSosPitch + ml];
+                    if (i >= a && i < b) dst[(size_t)row * ns + i] = v;
+                    else if (!REV && i >= ns) edge_out[(size_t)row * padlen + (i - ns)] = v;
+                }
             }
         }
         __syncthreads();

@@ -199,22 +199,23 @@ def _sos_decay_samples(sos, tol=1e-9, nmax=1 << 17):
         n *= 2
 
 
-def _sos_segment_length(nx, ns, warm, slots=None):
+def _sos_segment_length(nx, ns, warm, half_waves=None):
     """Time-segment length of the recursive filter.  A wave owns 64 rows x one segment and walks
-    seg_len + warm samples of a latency-bound recursion, so the run time is about
-    (ns / nseg + warm) * ceil(groups * nseg / slots) for `slots` concurrently resident waves (1024
-    SIMDs x 4 waves that interleave their dependent chains): pick the nseg that minimises it.
-    Short blocks (4000 x 12000) want many short segments although most of their work is warm-up."""
+    seg_len + warm samples; the GPU's rate of wave-steps saturates with the number of waves like
+    waves / (waves + W_h) (measured on MI355X: W_h ~ 1000, 4.3 M wave-steps/ms when saturated), so
+    the run time is about (seg_len + warm) * (groups * nseg + W_h): pick the nseg that minimises it.
+    Short blocks (4000 x 12000) run a few dozen warm-started segments per row, long ones
+    (20000 x 120000) ~26."""
     import os
-    if slots is None:
-        slots = int(os.environ.get("D4W_SOS_SLOTS", 4096))
+    if half_waves is None:
+        half_waves = int(os.environ.get("D4W_SOS_WH", 1024))
     groups = -(-nx // 64)
-    best, best_cost = 0, float(ns + 2 * warm)        # nseg = 1: exact single segment
+    best, best_cost = 0, float(ns + 2 * warm) * (groups + half_waves)      # nseg = 1: exact single segment
     for nseg in range(2, max(2, ns // 64) + 1):
         seg = -(-(-(-ns // nseg)) // 32) * 32
         if seg + 2 * warm >= ns:
             continue
-        cost = (seg + warm) * max(1.0, groups * nseg / float(slots))
+        cost = float(seg + warm) * (groups * nseg + half_waves)
         if cost < best_cost:
             best, best_cost = seg, cost
     return best
