@@ -43,12 +43,24 @@ __host__ __device__ constexpr int xf_freq(int e) {
 }
 
 struct XfTables {
-    const float2* gp;     // [ntpl][MB] conj(T_t(f)) at position e (f = xf_freq(e))
-    const float* gn;      // [ntpl]     conj(T_t(MB)) (real)
+    const float2* gp;     // [ntpl][MB] conj(T_t(f)) / 4 at position e (f = xf_freq(e))
+    const float* gn;      // [ntpl]     conj(T_t(MB)) / 4 (real)
     const float2* tw1;    // [M1]       W_MB^j
     const float2* tw2;    // [NB][NC]   W_M1^(j2 b)
     const float2* wg;     // [NG]       W_B^(a' + NA b') : untangle twiddle of a group's first frequency
+    const float2* twa;    // [NA][M1]   W_MB^(j a): stage-1 twiddles (a table read costs no VALU slot; the
+                          //            power tree it replaces was 56 scalar multiplies per stage)
 };
+
+// stage-1 twiddles of item j1: loads issued early, consumed after the butterfly
+template <int R>
+__device__ __forceinline__ void xf_pw_load(const float2* __restrict__ twa, int j1, float2 (&pw)[R]) {
+    pw[0] = make_float2(1.f, 0.f);
+    static_for<R - 1>([&](auto qq) {
+        constexpr int q = decltype(qq)::value + 1;
+        pw[q] = twa[q * kXfM1 + j1];
+    });
+}
 
 template <int R>
 __device__ __forceinline__ void xf_pw_tree(float2 w1, float2 (&pw)[R]) {
@@ -64,7 +76,8 @@ __device__ __forceinline__ void xf_pw_tree(float2 w1, float2 (&pw)[R]) {
 __global__ __launch_bounds__(256) void xcf_spectra(const float* __restrict__ taps, int ntpl, int ltaps,
                                                    int len0, int len1, float2* __restrict__ gp,
                                                    float* __restrict__ gn, float2* __restrict__ tw1,
-                                                   float2* __restrict__ tw2, float2* __restrict__ wg) {
+                                                   float2* __restrict__ tw2, float2* __restrict__ wg,
+                                                   float2* __restrict__ twa) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ntpl * kXfMB) {
         const int t = i / kXfMB, e = i - t * kXfMB;
@@ -77,13 +90,13 @@ __global__ __launch_bounds__(256) void xcf_spectra(const float* __restrict__ tap
             re += (double)tp[n] * c;
             im += (double)tp[n] * s;                   // conj(T(f)) = sum t[n] exp(+2 pi i f n / B)
         }
-        gp[i] = make_float2((float)re, (float)im);
+        gp[i] = make_float2((float)(0.25 * re), (float)(0.25 * im));   // 1/4: the pair op's factors 1/2, folded
     }
     if (i < ntpl) {
         const int L = i ? len1 : len0;
         double s = 0.0;
         for (int n = 0; n < L; ++n) s += (n & 1) ? -(double)taps[(size_t)i * ltaps + n] : (double)taps[(size_t)i * ltaps + n];
-        gn[i] = (float)s;
+        gn[i] = (float)(0.25 * s);
     }
     if (i < kXfM1) {
         float s, c;
@@ -92,6 +105,12 @@ __global__ __launch_bounds__(256) void xcf_spectra(const float* __restrict__ tap
         const int b = i / kXfNC, j2 = i % kXfNC;
         sincospif(-2.0f * (float)((j2 * b) % kXfM1) / (float)kXfM1, &s, &c);
         tw2[i] = make_float2(c, s);
+    }
+    if (i < kXfNA * kXfM1) {
+        const int a = i / kXfM1, j = i % kXfM1;
+        float sn, cs;
+        sincospif(-2.0f * (float)((a * j) % kXfMB) / (float)kXfMB, &sn, &cs);
+        twa[i] = make_float2(cs, sn);
     }
     if (i < kXfNG) {
         const int f0 = (i / kXfNB) + kXfNA * (i % kXfNB);
@@ -104,14 +123,15 @@ __global__ __launch_bounds__(256) void xcf_spectra(const float* __restrict__ tap
 // pair op for one frequency pair of both rows: A = Z[f], Bs = Z[MB - f], w = W_B^f, gf = conj(T(f)),
 // gm = conj(T(MB - f)) (so that conj(T(f + MB)) = conj(gm)); na -> position of f, nb -> position of MB - f
 __device__ __forceinline__ void xf_pair(c2 A, c2 Bs, float2 w, float2 gf, float2 gm, c2& na, c2& nb) {
+    // the four factors 1/2 of the untangle / re-tangle algebra are folded into the tables (gf, gm = G / 4)
     const c2 Bc = c2_conj(Bs);
-    const c2 E = c2_scale(c2_add(A, Bc), 0.5f);
-    const c2 O = c2_mul_mi(c2_scale(c2_sub(A, Bc), 0.5f));
+    const c2 E = c2_add(A, Bc);                            // 2 E
+    const c2 O = c2_mul_mi(c2_sub(A, Bc));                 // 2 O
     const c2 tO = c2_mulw(O, w);
-    const c2 Yp = c2_mulw(c2_add(E, tO), gf);             // X(f)      conj(T(f))
-    const c2 Ym = c2_mulwc(c2_sub(E, tO), gm);            // X(f + MB) conj(T(f + MB))
-    const c2 S = c2_scale(c2_add(Yp, Ym), 0.5f);
-    const c2 D = c2_mul_pi(c2_mulwc(c2_scale(c2_sub(Yp, Ym), 0.5f), w));
+    const c2 Yp = c2_mulw(c2_add(E, tO), gf);             // X(f)      conj(T(f))      / 2
+    const c2 Ym = c2_mulwc(c2_sub(E, tO), gm);            // X(f + MB) conj(T(f + MB)) / 2
+    const c2 S = c2_add(Yp, Ym);
+    const c2 D = c2_mul_pi(c2_mulwc(c2_sub(Yp, Ym), w));
     na = c2_add(S, D);
     nb = c2_conj(c2_sub(S, D));
 }
@@ -193,12 +213,12 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
                 });
             }
         }
+        float2 pw[NA];
+        xf_pw_load<NA>(T.twa, tid, pw);                             // in flight together with the samples
         if (t == 0) __syncthreads();                                // twiddle tables visible
         {
             const int j1 = tid;
             dftp<NA>(pf);
-            float2 pw[NA];
-            xf_pw_tree<NA>(tw1[j1], pw);
             static_for<NA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
                 xf_st(buf + xf_ad(j1 + a * M1), (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]));
@@ -293,6 +313,8 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
             });
         }
         lds_barrier();
+        float2 pwi[NA];
+        xf_pw_load<NA>(T.twa, tid, pwi);                            // for S1', in flight across S2'
         // ---------------- S2': inverse radix NB
         {
             const int g = tid >> 3, j2 = tid & 7;
@@ -312,13 +334,11 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
         // ---------------- S1': inverse radix NA -> lags k0 + 2m, k0 + 2m + 1 (m = j1 + a M1), the first S of them
         {
             const int j1 = tid;
-            float2 pw[NA];
-            xf_pw_tree<NA>(tw1[j1], pw);
             c2 v[NA];
             static_for<NA>([&](auto aa) {
                 constexpr int aq = decltype(aa)::value;
                 const c2 xv = xf_ld(buf + xf_ad(j1 + aq * M1));
-                v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pw[aq]);
+                v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pwi[aq]);
             });
             idftp<NA>(v);
             float* ya = (t == 0 ? y0 : y1) + (size_t)rowA * ns;
@@ -375,13 +395,13 @@ __device__ __forceinline__ c2 c2_cmulw(c2 a, float2 w) {
 // A = Z[f], Bs = Z[MB - f] (scalars); gf = (conj T0(f), conj T1(f)), gm = the same at MB - f
 __device__ __forceinline__ void xf_tpair(float2 A, float2 Bs, float2 w, c2 gf, c2 gm, c2& na, c2& nb) {
     const float2 Bc = c_conj(Bs);
-    const float2 E = c_scale(c_add(A, Bc), 0.5f);
-    const float2 O = c_mul_mi(c_scale(c_sub(A, Bc), 0.5f));
+    const float2 E = c_add(A, Bc);                          // 2 E (the factors 1/2 live in the tables)
+    const float2 O = c_mul_mi(c_sub(A, Bc));
     const float2 tO = c_mul(w, O);
-    const c2 Yp = c2_mulw(gf, c_add(E, tO));              // X(f)      conj(T_t(f))
-    const c2 Ym = c2_cmulw(gm, c_sub(E, tO));             // X(f + MB) conj(T_t(f + MB)) = X(f + MB) conj(gm)
-    const c2 S = c2_scale(c2_add(Yp, Ym), 0.5f);
-    const c2 D = c2_mul_pi(c2_mulwc(c2_scale(c2_sub(Yp, Ym), 0.5f), w));
+    const c2 Yp = c2_mulw(gf, c_add(E, tO));              // X(f)      conj(T_t(f))      / 2
+    const c2 Ym = c2_cmulw(gm, c_sub(E, tO));             // X(f + MB) conj(T_t(f + MB)) / 2
+    const c2 S = c2_add(Yp, Ym);
+    const c2 D = c2_mul_pi(c2_mulwc(c2_sub(Yp, Ym), w));
     na = c2_add(S, D);
     nb = c2_conj(c2_sub(S, D));
 }
@@ -435,7 +455,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, con
         __syncthreads();                                        // twiddle tables visible
         dft<NA>(pf);
         float2 pw[NA];
-        xf_pw_tree<NA>(tw1[j1], pw);
+        xf_pw_load<NA>(T.twa, j1, pw);
         static_for<NA>([&](auto aa) {
             constexpr int a = decltype(aa)::value;
             bufs[xf_ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, con
     {
         const int j1 = tid;
         float2 pw[NA];
-        xf_pw_tree<NA>(tw1[j1], pw);
+        xf_pw_load<NA>(T.twa, j1, pw);
         c2 v[NA];
         static_for<NA>([&](auto aa) {
             constexpr int aq = decltype(aa)::value;
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, con
     }
 }
 
-constexpr size_t kXfWsFloats = 2 * 2 * kXfMB + 8 + 2 * kXfM1 * 2 + 2 * kXfNG;
+constexpr size_t kXfWsFloats = 2 * 2 * kXfMB + 8 + 2 * kXfM1 * 2 + 2 * kXfNG + 2 * kXfNA * kXfM1;
 
 }  // namespace d4w
 
@@ -613,9 +633,10 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
     float2* tw1 = (float2*)(gn + 8);
     float2* tw2 = tw1 + kXfM1;
     float2* wg = tw2 + kXfM1;
-    T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg;
-    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(ntpl * kXfMB, 256)), dim3(256), 0, stream, taps, ntpl, ltaps, len0, len1, gp, gn,
-               tw1, tw2, wg);
+    float2* twa = wg + kXfNG;
+    T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg; T.twa = twa;
+    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(ntpl * kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, ntpl,
+               ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
 #ifndef D4W_EMU
