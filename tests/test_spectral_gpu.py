@@ -180,3 +180,35 @@ def test_pick_pipeline_config1(dw):
     print("picks: %d vs %d reference, symmetric difference %d" % (len(a), len(b), len(a ^ b)))
     assert len(b) > 50
     assert len(a ^ b) <= max(2, len(b) // 200)
+
+
+def test_detectors_on_long_rows(dw):
+    """BASELINE configs[2] row length (120 000 samples) through the detector rows of SURVEY 8(a): matched
+    filter -> envelope picks, spectrogram correlation, SNR; a few rows against the float64 oracle."""
+    import scipy.signal as sps
+    nx, ns = 600, 120000
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((nx, ns))
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    for r in (0, 1, 599):                                   # a few calls so that picks exist
+        for k in (5000, 60000, 110000):
+            x[r, k:k + 136] += 6.0 * hf[:136]
+    xt = torch.from_numpy(x).cuda().float()
+    c = dw.detect.compute_cross_correlogram(xt, hf)
+    rows = [0, 1, 599]
+    ref_c = orc.compute_cross_correlogram(x[rows], hf)
+    assert rel(c[rows].cpu().numpy(), ref_c) < TOL
+    thr = 0.5 * float(ref_c.max())
+    picks = dw.detect.pick_times_env(c, thr)
+    assert len(picks) == nx
+    for i, r in enumerate(rows):
+        refp = sps.find_peaks(orc.envelope(ref_c[i]), prominence=thr)[0]
+        assert len(refp) >= 3 and len(set(picks[r]) ^ set(refp)) <= 1
+    sc = dw.detect.compute_cross_correlogram_spectrocorr(xt, FS, [14., 30.], KERNEL, 0.8, 0.95)
+    assert tuple(sc.shape) == (nx, 1 + ns // 8)
+    ref_sc = orc.compute_cross_correlogram_spectrocorr(x[rows], FS, [14., 30.], KERNEL, 0.8, 0.95)
+    assert rel(sc[rows].cpu().numpy(), ref_sc) < TOL
+    s = dw.dsp.snr_tr_array(xt[:8])
+    ref_s = orc.snr_tr_array(x[:8])
+    assert np.max(np.abs(10.0 ** (s.cpu().numpy() / 10) - 10.0 ** (ref_s / 10))) / np.max(10.0 ** (ref_s / 10)) < TOL
