@@ -228,6 +228,29 @@ def fk_filter_filt_half(trace, fk_filter_matrix):
     return np.fft.irfft2(np.fft.rfft2(x) * Mh, s=x.shape)
 
 
+def fk_filter_filt_best_effort(trace32, mask_half32, workers=-1):
+    """Best-effort CPU form of the same filter (NOT what the reference runs; bench.py's second CPU
+    column): float32, half spectrum with the pre-folded mask, scipy.fft with all cores."""
+    import scipy.fft as sfft
+    F = sfft.rfft2(trace32, workers=workers)
+    F *= mask_half32
+    return sfft.irfft2(F, s=trace32.shape, workers=workers)
+
+
+def compute_cross_correlogram_best_effort(x32, templates, workers=-1):
+    """Best-effort CPU matched filter: float32, one batched rfft of the block shared by all templates,
+    scipy.fft with all cores (the reference re-transforms the row per template, detect.py:163-164)."""
+    import scipy.fft as sfft
+    x = (x32 - x32.mean(axis=1, keepdims=True)) / np.max(np.abs(x32), axis=1, keepdims=True)
+    n = sfft.next_fast_len(x.shape[1] + max(len(t) for t in templates) - 1, real=True)
+    X = sfft.rfft(x, n, axis=1, workers=workers)
+    outs = []
+    for t in templates:
+        T = np.conj(sfft.rfft(np.asarray(t, dtype=np.float32), n))
+        outs.append(sfft.irfft(X * T[None, :], n, axis=1, workers=workers)[:, : x.shape[1]])
+    return outs
+
+
 def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
     """Self-designing Gaussian-tapered speed band -- dsp.py:883-953."""
     x = np.asarray(data, dtype=float)
