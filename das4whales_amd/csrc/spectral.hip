@@ -453,41 +453,119 @@ __global__ __launch_bounds__(kScTile) void spectro_corr(const float* __restrict_
 // One workgroup per row; a thread owns a candidate left edge, accepted peaks are written in time
 // order through a workgroup prefix sum.  idx[row][0..min(count, cap)) ; counts[row] = count.
 // ---------------------------------------------------------------------------------------------
+// Prominence walks use per-block (max, min) summaries of the whole row held in LDS: a walk steps sample
+// by sample only to the edge of its block, then over whole blocks while their maximum does not exceed
+// the peak, and descends into the one block that stops it -- O(block + row / block) instead of O(row)
+// dependent loads (a smooth envelope of 120 000 samples has walks of thousands of samples).  Rows of
+// up to kFpRowLds samples are staged in LDS once (the sample steps are LDS reads); longer rows are read
+// in place (L2-resident after the summary sweep).  Candidates are processed without barriers (a thread
+// strides the row and marks its accepted peaks in an LDS bitmap); the time-ordered index list is
+// produced at the end by a popcount prefix sum over the bitmap.
+constexpr int kFpMaxBlocks = 4096;
+constexpr int kFpRowLds = 16384;
+
+template <bool STAGED>
 __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
-                                                              int* __restrict__ idx, int* __restrict__ counts,
-                                                              int cap) {
+                                                              int bshift, int* __restrict__ idx,
+                                                              int* __restrict__ counts, int cap) {
+    D4W_DYN_LDS(smem_raw);
     __shared__ int wave_tot[kSpThreads / 64];
-    const float* r = x + (size_t)blockIdx.x * ns;
+    const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift;
+    const int nwords = (ns + 31) >> 5;
+    float* bmax = reinterpret_cast<float*>(smem_raw);
+    float* bmin = bmax + nb;
+    unsigned* bits = reinterpret_cast<unsigned*>(bmin + nb);   // [nwords] accepted peaks
+    float* rowl = reinterpret_cast<float*>(bits + nwords);     // [ns] when STAGED
+    const float* rg = x + (size_t)blockIdx.x * ns;
     int* orow = idx + (size_t)blockIdx.x * cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int base = 0;
-    for (int c0 = 1; c0 < ns - 1; c0 += kSpThreads) {
-        const int i = c0 + tid;
-        int peak = -1;
-        if (i < ns - 1 && r[i - 1] < r[i]) {
-            const float v = r[i];
-            int ia = i + 1;
-            while (ia < ns - 1 && r[ia] == v) ++ia;
-            if (r[ia] < v) {
-                const int mid = (i + ia - 1) / 2;
-                float lmin = v, rmin = v;
-                for (int q = i - 1; q >= 0; --q) {
-                    const float u = r[q];
-                    if (u > v) break;
-                    lmin = fminf(lmin, u);
-                }
-                for (int q = ia; q < ns; ++q) {
-                    const float u = r[q];
-                    if (u > v) break;
-                    rmin = fminf(rmin, u);
-                }
-                // float64 like scipy: float32 samples are exact in float64, a float32 subtraction is not
-                if ((double)v - (double)fmaxf(lmin, rmin) >= thr) peak = mid;
-            }
+    for (int w = tid; w < nwords; w += kSpThreads) bits[w] = 0u;
+    // ---- block summaries: one block per wave iteration, lanes stride the block
+    for (int bk = wave; bk < nb; bk += kSpThreads / 64) {
+        float mx = -INFINITY, mn = INFINITY;
+        const int lo = bk << bshift, hi = min(lo + BS, ns);
+        for (int i = lo + lane; i < hi; i += 64) {
+            const float u = rg[i];
+            mx = fmaxf(mx, u);
+            mn = fminf(mn, u);
         }
-        // ordered compaction: inclusive scan inside the wave, then across the waves
-        const int flag = (peak >= 0) ? 1 : 0;
-        int incl = flag;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+            mn = fminf(mn, __shfl_xor(mn, off));
+        }
+        if (lane == 0) { bmax[bk] = mx; bmin[bk] = mn; }
+    }
+    if (STAGED)
+        for (int i = tid; i < ns; i += kSpThreads) rowl[i] = rg[i];
+    __syncthreads();
+    {
+        const float* r = STAGED ? rowl : rg;
+        auto rd = [&](int q) { return r[q]; };
+        for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
+            const float v = rd(i);
+            if (!(rd(i - 1) < v)) continue;
+            int ia = i + 1;
+            while (ia < ns - 1 && rd(ia) == v) ++ia;
+            if (!(rd(ia) < v)) continue;
+            const int mid = (i + ia - 1) / 2;
+            float lmin = v, rmin = v;
+            {   // left of the plateau: stop at the first sample > v
+                int q = i - 1;
+                bool stopped = false;
+                while (q >= 0 && (q & (BS - 1)) != BS - 1) {                   // to the end of the previous block
+                    const float u = rd(q);
+                    if (u > v) { stopped = true; break; }
+                    lmin = fminf(lmin, u);
+                    --q;
+                }
+                if (!stopped) {
+                    while (q >= 0 && !(bmax[q >> bshift] > v)) {               // whole blocks
+                        lmin = fminf(lmin, bmin[q >> bshift]);
+                        q -= BS;
+                    }
+                    while (q >= 0) {                                           // inside the stopping block
+                        const float u = rd(q);
+                        if (u > v) break;
+                        lmin = fminf(lmin, u);
+                        --q;
+                    }
+                }
+            }
+            {   // right of the plateau
+                int q = ia;
+                bool stopped = false;
+                while (q < ns && (q & (BS - 1)) != 0) {                        // to the start of the next block
+                    const float u = rd(q);
+                    if (u > v) { stopped = true; break; }
+                    rmin = fminf(rmin, u);
+                    ++q;
+                }
+                if (!stopped) {
+                    while (q < ns && !(bmax[q >> bshift] > v)) {
+                        rmin = fminf(rmin, bmin[q >> bshift]);
+                        q += BS;
+                    }
+                    while (q < ns) {
+                        const float u = rd(q);
+                        if (u > v) break;
+                        rmin = fminf(rmin, u);
+                        ++q;
+                    }
+                }
+            }
+            // float64 like scipy: float32 samples are exact in float64, a float32 subtraction is not
+            if ((double)v - (double)fmaxf(lmin, rmin) >= thr) atomicOr(&bits[mid >> 5], 1u << (mid & 31));
+        }
+    }
+    __syncthreads();
+    // ---- time-ordered index list: popcount prefix sum over the bitmap, kSpThreads words per round
+    int base = 0;
+    for (int w0 = 0; w0 < nwords; w0 += kSpThreads) {
+        const int w = w0 + tid;
+        unsigned word = (w < nwords) ? bits[w] : 0u;
+        const int cnt = __popc(word);
+        int incl = cnt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int n = __shfl_up(incl, off);
@@ -496,13 +574,16 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         int before = 0, total = 0;
-        for (int w = 0; w < kSpThreads / 64; ++w) {
-            if (w < wave) before += wave_tot[w];
-            total += wave_tot[w];
+        for (int k = 0; k < kSpThreads / 64; ++k) {
+            if (k < wave) before += wave_tot[k];
+            total += wave_tot[k];
         }
-        if (flag) {
-            const int p = base + before + incl - 1;
-            if (p < cap) orow[p] = peak;
+        int p = base + before + incl - cnt;
+        while (word) {
+            const int bit = __builtin_ctz(word);
+            word &= word - 1u;
+            if (p < cap) orow[p] = (w << 5) + bit;
+            ++p;
         }
         base += total;
         __syncthreads();
@@ -651,7 +732,21 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
 int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx, int32_t* counts, int cap,
                        void* stream) {
     if (!x || !idx || !counts || nx < 1 || ns < 1 || cap < 1) return fail(D4W_EINVAL, "bad argument");
-    D4W_LAUNCH(find_peaks_prom, dim3(nx), dim3(kSpThreads), 0, stream, x, ns, prominence, (int*)idx, (int*)counts, cap);
+    int bshift = 5;                                            // 32-sample blocks, larger for very long rows
+    while (((ns + (1 << bshift) - 1) >> bshift) > kFpMaxBlocks) ++bshift;
+    const int nb = (ns + (1 << bshift) - 1) >> bshift;
+    const bool staged = (ns <= kFpRowLds);
+    const size_t lds = ((size_t)2 * nb + (size_t)((ns + 31) >> 5) + (staged ? (size_t)ns : 0)) * sizeof(float);
+    if (lds > kSpLdsMax) return fail(D4W_EINVAL, "rows of %d samples exceed the peak-picking LDS tables", ns);
+    if (staged) {
+        sp_allow_lds(find_peaks_prom<true>, lds);
+        D4W_LAUNCH(find_peaks_prom<true>, dim3(nx), dim3(kSpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
+                   (int*)counts, cap);
+    } else {
+        sp_allow_lds(find_peaks_prom<false>, lds);
+        D4W_LAUNCH(find_peaks_prom<false>, dim3(nx), dim3(kSpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
+                   (int*)counts, cap);
+    }
     return D4W_OK;
 }
 

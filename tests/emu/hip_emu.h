@@ -257,6 +257,8 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

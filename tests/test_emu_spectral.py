@@ -274,3 +274,24 @@ def test_analytic_long_row_path(emu, nx, ns):
             assert np.max(np.minimum(d, np.abs(d - 200.0))) < 0.5      # noise rows: |z| ~ 0 samples are ill-conditioned
             assert np.median(d) < 1e-3
     assert emu.d4w_analytic_row_fits_lds(12000) == 1 and emu.d4w_analytic_row_fits_lds(120000) == 0
+
+
+@pytest.mark.parametrize("ns", [20000, 270000])
+def test_find_peaks_long_rows_block_walks(emu, ns):
+    """Rows beyond the LDS staging limit (global-memory walks) and beyond 4096 blocks of 64 (larger
+    blocks): smooth rows whose prominence walks span many blocks, plus noise, vs SciPy."""
+    rng = np.random.default_rng(ns)
+    t = np.arange(ns)
+    rows = [np.sin(t * 0.0007) + 0.3 * np.sin(t * 0.013) + 0.001 * rng.standard_normal(ns),
+            np.abs(sps.hilbert(rng.standard_normal(ns))),
+            np.linspace(-1, 1, ns) + 0.05 * np.sin(t * 0.05)]
+    x = np.ascontiguousarray(np.stack(rows), dtype=np.float32)
+    for thr in (0.0, 0.3, 1.2):
+        cap = ns // 2 + 1
+        idx = np.empty((3, cap), dtype=np.int32)
+        cnt = np.empty(3, dtype=np.int32)
+        ok(emu, emu.d4w_find_peaks_f32(vp(x), 3, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
+        for c in range(3):
+            ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+            assert cnt[c] == len(ref), (thr, c, cnt[c], len(ref))
+            assert np.array_equal(idx[c, :cnt[c]], ref)
