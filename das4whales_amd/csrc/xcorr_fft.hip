@@ -3,24 +3,23 @@
 // detect.shift_xcorr (reference detect.py:96-166) for templates of short support (the fin-whale
 // call templates have 136 / 156 non-zero samples).
 //
-// The direct form (rowops.hip: xcorr_fir) is VALU-bound at 2 (L0 + L1) = 584 flop per sample; this
-// kernel spends ~110 flop per sample and streams: one read of x, one write per template.
+// The direct form (rowops.hip: xcorr_fir) spends 2 (L0 + L1) = 584 flop per sample; this kernel ~90.
 //   * a row is cut into blocks of B = 4096 samples that advance by S = B - 160 lags; the circular
 //     correlation of a block is exact for its first S lags (support <= 161);
 //   * a block is read as MB = 2048 packed complex samples; ONE complex FFT gives the block's real
-//     spectrum after the untangle, which is multiplied by conj(T_t(f)) for each template t and
-//     re-tangled, and one inverse FFT per template returns 2 lags per complex output;
+//     spectrum after the untangle, which is multiplied by conj(T(f)) and re-tangled, and one inverse
+//     FFT returns 2 lags per complex output;
 //   * MB = 16 x 16 x 8 "fat" register stages exactly as in fk_fast.h (pass B): the first radix-16 is
 //     applied to the registers the global loads landed in, the last one feeds the global stores, the
-//     middle item does [radix 8 | pair op x 2 templates | inverse radix 8] for a group of 8
-//     positions and its Hermitian partner group;
+//     middle item does [radix 8 | pair op | inverse radix 8] for a group of 8 positions and its
+//     Hermitian partner group;
 //   * a workgroup (128 threads) transforms the same block of TWO adjacent rows at once, the two rows
 //     riding the two halves of packed registers (fft_pair.h): every butterfly add / multiply is one
-//     v_pk_* instruction for both rows -- the kernel is VALU-bound, and add-dominated scalar FFT
-//     code runs the vector ALUs at a quarter of their packed-FMA rate;
-//   * the item's two groups of the block spectrum stay in registers for every template, so each
-//     template's correlation overwrites the row buffer in place (37 KiB of LDS per workgroup).
-// Spectra tables are built per call by xcf_spectra (a few hundred microseconds of a 4096 x 161 DFT).
+//     v_pk_* instruction for both rows;
+//   * one launch per template (xcorr_fft_blocks); xcorr_fft_tpair is the one-read alternative that
+//     packs the two TEMPLATES of one row through a single inverse transform (D4W_XF_TPAIR=1).
+// Spectra and twiddle tables are built per call by xcf_spectra (~30 us).  DESIGN.md 3.3 has the
+// measurements and the variants that were tried.
 #include <cstdlib>
 
 #include "fft_pair.h"
@@ -59,16 +58,6 @@ __device__ __forceinline__ void xf_pw_load(const float2* __restrict__ twa, int j
     static_for<R - 1>([&](auto qq) {
         constexpr int q = decltype(qq)::value + 1;
         pw[q] = twa[q * kXfM1 + j1];
-    });
-}
-
-template <int R>
-__device__ __forceinline__ void xf_pw_tree(float2 w1, float2 (&pw)[R]) {
-    pw[0] = make_float2(1.f, 0.f);
-    pw[1] = w1;
-    static_for<R - 2>([&](auto qq) {
-        constexpr int q = decltype(qq)::value + 2;
-        pw[q] = c_mul(pw[q / 2], pw[q - q / 2]);
     });
 }
 
