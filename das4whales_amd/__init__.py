@@ -9,5 +9,6 @@ from . import _lib  # noqa: F401  (fails loudly if the native library is missing
 from . import dsp  # noqa: F401
 from . import detect  # noqa: F401
 from . import data_handle  # noqa: F401
+from . import stream  # noqa: F401
 
-__all__ = ["dsp", "detect", "data_handle"]
+__all__ = ["dsp", "detect", "data_handle", "stream"]

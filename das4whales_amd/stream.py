@@ -1,0 +1,114 @@
+"""stream -- consecutive files of one cable processed as one continuous record (SURVEY.md 8f row f4,
+BASELINE configs[4]).  No reference counterpart: the reference's scripts process one 60-s file at a
+time (scripts/main_mfdetect.py:112-123), so every file starts and ends with filter transients and
+the last L-1 lags of every correlogram are cut short.
+
+What is carried across file boundaries
+  * zero-phase band-pass (dsp.bp_filt): file i is filtered together with `halo` samples of file i-1
+    and of file i+1.  The filter's two-sided impulse response decays below 1e-9 of its peak within
+    ~650 samples, so with halo >= 1024 the kept part equals dsp.bp_filt of the
+    CONCATENATED record to float32 rounding (parity target: the reference run on the concatenation);
+  * matched filter (detect.compute_cross_correlogram): the lags ns-L+1 .. ns-1 of file i are
+    completed with the first L-1 filtered samples of file i+1; normalisation stays per file (row mean
+    and max|.| of file i, detect.py:157), as in the reference's per-file runs.
+The f-k filter stays per file: it is a circular 2-D transform of one file in the reference
+(dsp.py:748), and a transform over the concatenation would be a different filter.
+
+Latency: the band-passed file i is complete when file i+1 has arrived, its correlograms when the
+band-passed and f-k filtered file i+1 exists, i.e. when file i+2 has arrived.  push() returns the
+results that became final; flush() closes the stream (the last file ends like a stand-alone file).
+All arithmetic runs in the HIP library through dsp / detect; this module only moves halos around.
+"""
+import numpy as np
+import torch
+
+from . import _device as dev
+from . import detect, dsp
+
+
+class FileStream:
+    def __init__(self, fs, fmin, fmax, templates=(), fk_mask=None, halo=1024):
+        """fs, fmin, fmax: band-pass (dsp.bp_filt arguments); templates: full-length or support-only
+        template vectors (detect.gen_template_fincall output) for the matched filter; fk_mask: f-k mask
+        for one file's shape (any form dsp.fk_filter_filt accepts) or None to skip the f-k filter."""
+        self.fs, self.fmin, self.fmax = float(fs), float(fmin), float(fmax)
+        self.halo = int(halo)
+        self.taps = [detect._normalised_support(t) for t in templates]
+        self.lmax = max((len(t) for t in self.taps), default=1)
+        self.fk_mask = fk_mask
+        self._raw = []          # raw files waiting for their right halo: [(index, tensor)]
+        self._prev_tail = None  # last `halo` raw samples of the file before self._raw[0]
+        self._filt = []         # filtered (band-pass [+ f-k]) files waiting for the next file's head
+        self._n = 0
+        self._sos = None
+
+    # ------------------------------------------------------------------------------------------
+    def _bandpass(self, left, cur, right):
+        """dsp.bp_filt of [left | cur | right], the part belonging to `cur`."""
+        import scipy.signal as sp
+        if self._sos is None:
+            self._sos = sp.butter(8, [self.fmin / (self.fs / 2), self.fmax / (self.fs / 2)], "bp", output="sos")
+        parts = [p for p in (left, cur, right) if p is not None]
+        ext = torch.cat(parts, dim=1) if len(parts) > 1 else cur
+        y = dsp._sosfiltfilt_device(ext.contiguous(), self._sos, 51)
+        a = left.shape[1] if left is not None else 0
+        return y[:, a:a + cur.shape[1]].contiguous()
+
+    def _finish_bandpass(self, right_head):
+        """The oldest waiting raw file now has its right halo (or the stream ends): filter it."""
+        idx, cur = self._raw.pop(0)
+        y = self._bandpass(self._prev_tail, cur, right_head)
+        self._prev_tail = cur[:, -self.halo:].contiguous() if self.halo > 0 else None
+        if self.fk_mask is not None:
+            y = dsp.fk_filter_filt(y, self.fk_mask)
+        return idx, y
+
+    def _correlate(self, idx, y, next_head):
+        """Correlograms of filtered file `y`, its last lags completed with `next_head` (or cut short)."""
+        out = {"index": idx, "filtered": y}
+        if not self.taps:
+            return out
+        nx, ns = y.shape
+        with torch.cuda.device(y.device):
+            mean = torch.empty(nx, dtype=torch.float32, device=y.device)
+            mx = torch.empty(nx, dtype=torch.float32, device=y.device)
+            from ._lib import lib, check
+            check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
+        if next_head is not None and self.lmax > 1:
+            # rows continue into the next file; the padding must enter de-meaned like the file's own
+            # samples (the kernel subtracts the mean from every sample it reads)
+            ext = torch.cat((y, next_head[:, :self.lmax - 1]), dim=1).contiguous()
+        else:
+            ext = y
+        cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
+        out["correlograms"] = [c[:, :ns].contiguous() for c in cs]
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def push(self, block):
+        """Next file ([channel x time], NumPy or CUDA tensor).  Returns the list of results that became
+        final (dicts with "index", "filtered" and "correlograms"), possibly empty."""
+        x = dev.to_device_f32(block)
+        self._raw.append((self._n, x))
+        self._n += 1
+        done = []
+        if len(self._raw) >= 2:                               # the older raw file has its right halo now
+            head = x[:, :self.halo].contiguous() if self.halo > 0 else None
+            self._filt.append(self._finish_bandpass(head))
+        if len(self._filt) >= 2:                              # the older filtered file has its successor
+            idx, y = self._filt.pop(0)
+            done.append(self._correlate(idx, y, self._filt[0][1]))
+        return done
+
+    def flush(self):
+        """End of the stream: finish the files still waiting (their right edge is a true record end)."""
+        done = []
+        while self._raw:
+            self._filt.append(self._finish_bandpass(None))
+            while len(self._filt) >= 2:
+                idx, y = self._filt.pop(0)
+                done.append(self._correlate(idx, y, self._filt[0][1]))
+        while self._filt:
+            idx, y = self._filt.pop(0)
+            done.append(self._correlate(idx, y, self._filt[0][1] if self._filt else None))
+        return done
