@@ -167,6 +167,17 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
     // (HF + LF): two NT = 1 launches 9.1 ms; one NT = 2 launch 11.2 ms (57 KiB of straight-line code
     // against a 64 KiB instruction cache shared by two CUs), 11.6 ms when the block spectrum is kept
     // in registers across the templates instead (VGPR spills).
+    // middle-stage item of this thread: p < 127 a proper pair of groups (Gi < PG), p = 127 the two
+    // self-paired groups 0 and NB / 2 (see the MID stage)
+    int Gi, PG;
+    {
+        const int p = tid;
+        if (p < 112) { const int g = 1 + (p >> 4), b = p & 15; Gi = g * NB + b; PG = (NA - g) * NB + (NB - 1 - b); }
+        else if (p < 120) { const int b = p - 112; Gi = (NA / 2) * NB + b; PG = (NA / 2) * NB + (NB - 1 - b); }
+        else if (p < 127) { const int b = p - 119; Gi = b; PG = NB - b; }
+        else { Gi = 0; PG = NB / 2; }
+    }
+    const bool selfitem = (tid == 127);
     static_for<NT>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
         // ---------------- S1: radix NA on the packed samples z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = j1 + a M1
@@ -213,6 +224,19 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
                 xf_st(buf + xf_ad(j1 + a * M1), (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]));
             });
         }
+        // the middle stage's table operands: issued here, in flight across S2
+        float2 GA[NC], GB[NC];
+        {
+            const float2* gpa = T.gp + (size_t)t * MB + Gi * NC;
+            const float2* gpb = T.gp + (size_t)t * MB + PG * NC;
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                GA[d] = gpa[d];
+                GB[d] = gpb[d];
+            });
+        }
+        const float gny = T.gn[t];
+        const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];       // W_B^f, f = f0(G) + 256 d: W_B^(256 d) are literals
         lds_barrier();
         // ---------------- S2: radix NB in place, x W_M1^(j2 b')
         {
@@ -233,16 +257,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
         //                  inverse radix NC), S2' and S1'.  Item p < 127: a proper pair (Gi < PG); p = 127: the
         //                  two self-paired groups 0 (digit partner (NC - d) % NC, f = 0 pairs with the Nyquist
         //                  bin) and NB / 2.
-        int Gi, PG;
-        {
-            const int p = tid;
-            if (p < 112) { const int g = 1 + (p >> 4), b = p & 15; Gi = g * NB + b; PG = (NA - g) * NB + (NB - 1 - b); }
-            else if (p < 120) { const int b = p - 112; Gi = (NA / 2) * NB + b; PG = (NA / 2) * NB + (NB - 1 - b); }
-            else if (p < 127) { const int b = p - 119; Gi = b; PG = NB - b; }
-            else { Gi = 0; PG = NB / 2; }
-        }
-        const bool selfitem = (tid == 127);
-        // the item's two groups of the block spectrum stay in registers for every template
+        // the item's two groups of the block spectrum
         c2 a[NC], b[NC];
         {
             const float4* ga = buf + xf_ad(Gi * NC);
@@ -255,17 +270,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
             dftp<NC>(a);
             dftp<NC>(b);
         }
-        const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];       // W_B^f, f = f0(G) + 256 d: W_B^(256 d) are literals
         {
-            const float2* gpa = T.gp + (size_t)t * MB + Gi * NC;
-            const float2* gpb = T.gp + (size_t)t * MB + PG * NC;
-            float2 GA[NC], GB[NC];
-            static_for<NC>([&](auto dd) {
-                constexpr int d = decltype(dd)::value;
-                GA[d] = gpa[d];
-                GB[d] = gpb[d];
-            });
-            const float gny = T.gn[t];
             c2 ra[NC], rb[NC];
             if (!selfitem) {
                 static_for<NC>([&](auto dd) {
