@@ -453,16 +453,96 @@ __global__ __launch_bounds__(kScTile) void spectro_corr(const float* __restrict_
 // One workgroup per row; a thread owns a candidate left edge, accepted peaks are written in time
 // order through a workgroup prefix sum.  idx[row][0..min(count, cap)) ; counts[row] = count.
 // ---------------------------------------------------------------------------------------------
-// Prominence walks use per-block (max, min) summaries of the whole row held in LDS: a walk steps sample
-// by sample only to the edge of its block, then over whole blocks while their maximum does not exceed
-// the peak, and descends into the one block that stops it -- O(block + row / block) instead of O(row)
-// dependent loads (a smooth envelope of 120 000 samples has walks of thousands of samples).  Rows of
-// up to kFpRowLds samples are staged in LDS once (the sample steps are LDS reads); longer rows are read
-// in place (L2-resident after the summary sweep).  Candidates are processed without barriers (a thread
-// strides the row and marks its accepted peaks in an LDS bitmap); the time-ordered index list is
-// produced at the end by a popcount prefix sum over the bitmap.
+// Prominence walks use a two-level (max, min) summary of the whole row held in LDS (blocks of 2^b
+// samples and super-blocks of 32 blocks): a walk steps sample by sample only to the edge of its block,
+// block by block to the edge of its super-block, then over super-blocks while their maximum does not
+// exceed the peak, and descends into the one block that stops it -- a few dozen dependent LDS reads
+// instead of O(row) dependent loads (a smooth envelope of 120 000 samples has walks of thousands of
+// samples, and in SIMT the longest walk of a wave is what every lane pays).  Rows of up to kFpRowLds
+// samples are staged in LDS once (the sample steps are LDS reads); longer rows are read in place
+// (L2-resident after the summary sweep).  Candidates are processed without barriers (a thread strides
+// the row and marks its accepted peaks in an LDS bitmap); the time-ordered index list is produced at
+// the end by a popcount prefix sum over the bitmap.
 constexpr int kFpMaxBlocks = 4096;
 constexpr int kFpRowLds = 16384;
+constexpr int kFpFan = 32;                      // blocks per super-block (the walk code shifts by 5)
+static_assert(kFpFan == 32, "fp_walk shifts by 5");
+
+// min over the walk from q in direction DIR until the first sample > v (exclusive) or the row end.
+// Every phase reads a BATCH of operands with independent loads before it looks at them: a walk is a
+// chain of dependent decisions, and one LDS round trip per step is what it would otherwise cost.
+constexpr int kFpBatch = 8;
+
+// scan `n` samples from q in direction DIR; returns true (and leaves lmin) when a sample > v stopped it
+template <int DIR>
+__device__ __forceinline__ bool fp_scan_samples(const float* __restrict__ r, int ns, int& q, int n, float v,
+                                                float& lmin) {
+    for (int done = 0; done < n; done += kFpBatch) {
+        float u[kFpBatch];
+#pragma unroll
+        for (int k = 0; k < kFpBatch; ++k) u[k] = r[min(max(q + DIR * k, 0), ns - 1)];   // clamped: speculative tail
+        const int m = min(kFpBatch, n - done);
+#pragma unroll
+        for (int k = 0; k < kFpBatch; ++k) {
+            if (k < m) {
+                if (u[k] > v) { q += DIR * k; return true; }
+                lmin = fminf(lmin, u[k]);
+            }
+        }
+        q += DIR * m;
+    }
+    return false;
+}
+
+// scan `n` summary entries (stride `step` samples each) from q; true when an entry's max > v stopped it
+template <int DIR>
+__device__ __forceinline__ bool fp_scan_blocks(const float2* __restrict__ sm, int nent, int shift, int& q, int n,
+                                               int step, float v, float& lmin) {
+    for (int done = 0; done < n; done += 4) {
+        float2 e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = sm[min(max((q + DIR * k * step) >> shift, 0), nent - 1)];
+        const int m = min(4, n - done);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < m) {
+                if (e[k].x > v) { q += DIR * k * step; return true; }
+                lmin = fminf(lmin, e[k].y);
+            }
+        }
+        q += DIR * m * step;
+    }
+    return false;
+}
+
+template <int DIR>
+__device__ __forceinline__ float fp_walk(const float* __restrict__ r, const float2* __restrict__ s1,
+                                         const float2* __restrict__ s2, int ns, int nb, int nb2, int bshift, int q,
+                                         float v, float lmin) {
+    const int BS = 1 << bshift, SB = BS * kFpFan;
+    // samples to the edge of the block (for DIR < 0 the block's first sample is included)
+    int n = (DIR < 0) ? ((q + 1) & (BS - 1)) : ((BS - (q & (BS - 1))) & (BS - 1));
+    if (DIR > 0) n = min(n, ns - q);
+    if (fp_scan_samples<DIR>(r, ns, q, n, v, lmin)) return lmin;
+    if ((DIR < 0) ? (q < 0) : (q >= ns)) return lmin;
+    // blocks to the edge of the super-block
+    const int blk = q >> bshift;
+    n = (DIR < 0) ? ((blk + 1) & (kFpFan - 1)) : ((kFpFan - (blk & (kFpFan - 1))) & (kFpFan - 1));
+    if (DIR > 0) n = min(n, nb - blk);
+    bool in_block = fp_scan_blocks<DIR>(s1, nb, bshift, q, n, BS, v, lmin);
+    if (!in_block) {
+        if ((DIR < 0) ? (q < 0) : (q >= ns)) return lmin;
+        // super-blocks to the row end
+        const int sb = q >> (bshift + 5);
+        n = (DIR < 0) ? sb + 1 : nb2 - sb;
+        if (!fp_scan_blocks<DIR>(s2, nb2, bshift + 5, q, n, SB, v, lmin)) return lmin;
+        // blocks of the stopping super-block (one of them has a larger sample)
+        (void)fp_scan_blocks<DIR>(s1, nb, bshift, q, kFpFan, BS, v, lmin);
+    }
+    // samples of the stopping block
+    (void)fp_scan_samples<DIR>(r, ns, q, BS, v, lmin);
+    return lmin;
+}
 
 template <bool STAGED>
 __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
@@ -470,90 +550,70 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
                                                               int* __restrict__ counts, int cap) {
     D4W_DYN_LDS(smem_raw);
     __shared__ int wave_tot[kSpThreads / 64];
-    const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift;
+    const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
     const int nwords = (ns + 31) >> 5;
-    float* bmax = reinterpret_cast<float*>(smem_raw);
-    float* bmin = bmax + nb;
-    unsigned* bits = reinterpret_cast<unsigned*>(bmin + nb);   // [nwords] accepted peaks
+    float2* s1 = reinterpret_cast<float2*>(smem_raw);          // [nb]  (max, min) of every block
+    float2* s2 = s1 + nb;                                      // [nb2] (max, min) of every super-block
+    unsigned* bits = reinterpret_cast<unsigned*>(s2 + nb2);    // [nwords] accepted peaks
     float* rowl = reinterpret_cast<float*>(bits + nwords);     // [ns] when STAGED
     const float* rg = x + (size_t)blockIdx.x * ns;
     int* orow = idx + (size_t)blockIdx.x * cap;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int w = tid; w < nwords; w += kSpThreads) bits[w] = 0u;
-    // ---- block summaries: one block per wave iteration, lanes stride the block
-    for (int bk = wave; bk < nb; bk += kSpThreads / 64) {
-        float mx = -INFINITY, mn = INFINITY;
-        const int lo = bk << bshift, hi = min(lo + BS, ns);
-        for (int i = lo + lane; i < hi; i += 64) {
-            const float u = rg[i];
-            mx = fmaxf(mx, u);
-            mn = fminf(mn, u);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, off));
-            mn = fminf(mn, __shfl_xor(mn, off));
-        }
-        if (lane == 0) { bmax[bk] = mx; bmin[bk] = mn; }
-    }
-    if (STAGED)
+    if (STAGED) {
         for (int i = tid; i < ns; i += kSpThreads) rowl[i] = rg[i];
+        __syncthreads();
+    }
+    // ---- block summaries: eight blocks per wave iteration (their loads are independent and in flight
+    //      together), lanes stride a block, wave shuffle reduction
+    {
+        const float* r = STAGED ? rowl : rg;
+        constexpr int kBatch = 8;
+        for (int bk0 = wave * kBatch; bk0 < nb; bk0 += (kSpThreads / 64) * kBatch) {
+            float mx[kBatch], mn[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                mx[j] = -INFINITY;
+                mn[j] = INFINITY;
+                const int lo = (bk0 + j) << bshift, hi = min(lo + BS, ns);
+                for (int i = lo + lane; i < hi; i += 64) {
+                    const float u = r[i];
+                    mx[j] = fmaxf(mx[j], u);
+                    mn[j] = fminf(mn[j], u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], off));
+                    mn[j] = fminf(mn[j], __shfl_xor(mn[j], off));
+                }
+                if (lane == 0 && bk0 + j < nb) s1[bk0 + j] = make_float2(mx[j], mn[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int b2 = tid; b2 < nb2; b2 += kSpThreads) {
+        float mx = -INFINITY, mn = INFINITY;
+        for (int k = b2 * kFpFan; k < min((b2 + 1) * kFpFan, nb); ++k) {
+            mx = fmaxf(mx, s1[k].x);
+            mn = fminf(mn, s1[k].y);
+        }
+        s2[b2] = make_float2(mx, mn);
+    }
     __syncthreads();
     {
         const float* r = STAGED ? rowl : rg;
-        auto rd = [&](int q) { return r[q]; };
         for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
-            const float v = rd(i);
-            if (!(rd(i - 1) < v)) continue;
+            const float v = r[i];
+            if (!(r[i - 1] < v)) continue;
             int ia = i + 1;
-            while (ia < ns - 1 && rd(ia) == v) ++ia;
-            if (!(rd(ia) < v)) continue;
+            while (ia < ns - 1 && r[ia] == v) ++ia;
+            if (!(r[ia] < v)) continue;
             const int mid = (i + ia - 1) / 2;
-            float lmin = v, rmin = v;
-            {   // left of the plateau: stop at the first sample > v
-                int q = i - 1;
-                bool stopped = false;
-                while (q >= 0 && (q & (BS - 1)) != BS - 1) {                   // to the end of the previous block
-                    const float u = rd(q);
-                    if (u > v) { stopped = true; break; }
-                    lmin = fminf(lmin, u);
-                    --q;
-                }
-                if (!stopped) {
-                    while (q >= 0 && !(bmax[q >> bshift] > v)) {               // whole blocks
-                        lmin = fminf(lmin, bmin[q >> bshift]);
-                        q -= BS;
-                    }
-                    while (q >= 0) {                                           // inside the stopping block
-                        const float u = rd(q);
-                        if (u > v) break;
-                        lmin = fminf(lmin, u);
-                        --q;
-                    }
-                }
-            }
-            {   // right of the plateau
-                int q = ia;
-                bool stopped = false;
-                while (q < ns && (q & (BS - 1)) != 0) {                        // to the start of the next block
-                    const float u = rd(q);
-                    if (u > v) { stopped = true; break; }
-                    rmin = fminf(rmin, u);
-                    ++q;
-                }
-                if (!stopped) {
-                    while (q < ns && !(bmax[q >> bshift] > v)) {
-                        rmin = fminf(rmin, bmin[q >> bshift]);
-                        q += BS;
-                    }
-                    while (q < ns) {
-                        const float u = rd(q);
-                        if (u > v) break;
-                        rmin = fminf(rmin, u);
-                        ++q;
-                    }
-                }
-            }
+            const float lmin = fp_walk<-1>(r, s1, s2, ns, nb, nb2, bshift, i - 1, v, v);
+            const float rmin = fp_walk<+1>(r, s1, s2, ns, nb, nb2, bshift, ia, v, v);
             // float64 like scipy: float32 samples are exact in float64, a float32 subtraction is not
             if ((double)v - (double)fmaxf(lmin, rmin) >= thr) atomicOr(&bits[mid >> 5], 1u << (mid & 31));
         }
@@ -736,7 +796,8 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
     while (((ns + (1 << bshift) - 1) >> bshift) > kFpMaxBlocks) ++bshift;
     const int nb = (ns + (1 << bshift) - 1) >> bshift;
     const bool staged = (ns <= kFpRowLds);
-    const size_t lds = ((size_t)2 * nb + (size_t)((ns + 31) >> 5) + (staged ? (size_t)ns : 0)) * sizeof(float);
+    const int nb2 = (nb + kFpFan - 1) / kFpFan;
+    const size_t lds = ((size_t)2 * (nb + nb2) + (size_t)((ns + 31) >> 5) + (staged ? (size_t)ns : 0)) * sizeof(float);
     if (lds > kSpLdsMax) return fail(D4W_EINVAL, "rows of %d samples exceed the peak-picking LDS tables", ns);
     if (staged) {
         sp_allow_lds(find_peaks_prom<true>, lds);

@@ -1,0 +1,91 @@
+"""End-to-end detection pipeline on consecutive 60-s files (BASELINE configs[4] style, one GPU):
+raw int32 -> strain (fused ingest) -> band-pass (streamed across files) -> f-k filter -> HF+LF matched
+filter -> envelope picks, and the spectrogram-correlation detector on the same filtered files.
+Prints one JSON line with per-stage times (HIP events, median over files) and files / s.
+
+    python scripts/pipeline_bench.py [--nx 11020] [--ns 12000] [--files 8]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import das4whales_amd as dw  # noqa: E402
+from das4whales_amd import data_handle, detect, dsp, stream  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=11020)
+    ap.add_argument("--ns", type=int, default=12000)
+    ap.add_argument("--files", type=int, default=8)
+    args = ap.parse_args()
+    nx, ns, fs, dx = args.nx, args.ns, 200.0, 2.0419046878814697
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    raws = [(torch.randn((nx, ns), device=dev, generator=gen) * 3e4).to(torch.int32) for _ in range(args.files)]
+    meta = {"scale_factor": 1.7e-11, "fs": fs, "dx": dx}
+    sel = [0, nx, 1]
+    mask = dsp.hybrid_ninf_filter_design((nx, ns), [0, nx, 1], dx, fs, cs_min=1350., cp_min=1450., cp_max=3300,
+                                         cs_max=3450, fmin=14., fmax=30.)
+    t = np.arange(ns) / fs
+    hf = detect.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)
+    lf = detect.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)
+    kernel = {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def run(timed):
+        st = stream.FileStream(fs, 14, 30, templates=[hf, lf], fk_mask=mask, halo=1024)
+        acc = {k: [] for k in ("ingest", "stream(bp+fk+mf)", "picks_env x2", "spectrocorr")}
+        npicks = 0
+        for raw in raws + [None]:
+            e0 = ev()
+            if raw is not None:
+                x, _, _ = data_handle.load_das_data_array(raw, sel, meta)
+                x = x * 1e9
+                e1 = ev()
+                done = st.push(x)
+            else:
+                e1 = ev()
+                done = st.flush()
+            e2 = ev()
+            for r in done:
+                thr = 0.45 * float(r["correlograms"][0].max())
+                for c in r["correlograms"]:
+                    npicks += sum(len(p) for p in detect.pick_times_env(c, thr))
+            e3 = ev()
+            for r in done:
+                detect.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)
+            e4 = ev()
+            e4.synchronize()
+            if timed:
+                n = max(len(done), 1)
+                acc["ingest"].append(e0.elapsed_time(e1))
+                acc["stream(bp+fk+mf)"].append(e1.elapsed_time(e2))
+                acc["picks_env x2"].append(e2.elapsed_time(e3) / n)
+                acc["spectrocorr"].append(e3.elapsed_time(e4) / n)
+        return acc, npicks
+
+    run(False)                                              # warm-up: plans, tables, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc, npicks = run(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"shape": [nx, ns], "files": args.files, "wall_s": dt, "files_per_s": args.files / dt,
+           "channel_samples_per_s": args.files * nx * ns / dt, "picks": npicks,
+           "stage_ms_per_file(median)": {k: float(np.median(v)) for k, v in acc.items() if v}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
