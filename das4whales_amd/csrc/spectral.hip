@@ -473,10 +473,14 @@ static_assert(kFpFan == 32, "fp_walk shifts by 5");
 // chain of dependent decisions, and one LDS round trip per step is what it would otherwise cost.
 constexpr int kFpBatch = 8;
 
-// scan `n` samples from q in direction DIR; returns true (and leaves lmin) when a sample > v stopped it
+// Only the decision prominence >= thr is needed, not the prominence itself: a side is SATISFIED as soon
+// as the running minimum reaches lim = the largest float <= v - thr, and the walk may stop there
+// (the minimum can only decrease further).  Prominent peaks therefore walk only to their first deep
+// dip and small ones to the next higher sample -- nobody walks across the row.
+// scan `n` samples from q in direction DIR: 1 = a sample > v stopped it, 2 = satisfied, 0 = ran out
 template <int DIR>
-__device__ __forceinline__ bool fp_scan_samples(const float* __restrict__ r, int ns, int& q, int n, float v,
-                                                float& lmin) {
+__device__ __forceinline__ int fp_scan_samples(const float* __restrict__ r, int ns, int& q, int n, float v, float lim,
+                                               float& lmin) {
     for (int done = 0; done < n; done += kFpBatch) {
         float u[kFpBatch];
 #pragma unroll
@@ -485,19 +489,21 @@ __device__ __forceinline__ bool fp_scan_samples(const float* __restrict__ r, int
 #pragma unroll
         for (int k = 0; k < kFpBatch; ++k) {
             if (k < m) {
-                if (u[k] > v) { q += DIR * k; return true; }
+                if (u[k] > v) { q += DIR * k; return 1; }
                 lmin = fminf(lmin, u[k]);
+                if (lmin <= lim) return 2;
             }
         }
         q += DIR * m;
     }
-    return false;
+    return 0;
 }
 
-// scan `n` summary entries (stride `step` samples each) from q; true when an entry's max > v stopped it
+// scan `n` summary entries (stride `step` samples each) from q: 1 = an entry's max > v stopped it (q at
+// that entry), 2 = satisfied, 0 = ran out
 template <int DIR>
-__device__ __forceinline__ bool fp_scan_blocks(const float2* __restrict__ sm, int nent, int shift, int& q, int n,
-                                               int step, float v, float& lmin) {
+__device__ __forceinline__ int fp_scan_blocks(const float2* __restrict__ sm, int nent, int shift, int& q, int n,
+                                              int step, float v, float lim, float& lmin) {
     for (int done = 0; done < n; done += 4) {
         float2 e[4];
 #pragma unroll
@@ -506,41 +512,46 @@ __device__ __forceinline__ bool fp_scan_blocks(const float2* __restrict__ sm, in
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < m) {
-                if (e[k].x > v) { q += DIR * k * step; return true; }
+                if (e[k].x > v) { q += DIR * k * step; return 1; }
                 lmin = fminf(lmin, e[k].y);
+                if (lmin <= lim) return 2;
             }
         }
         q += DIR * m * step;
     }
-    return false;
+    return 0;
 }
 
+// running minimum of the walk from q in direction DIR up to the first sample > v, the row end, or the
+// point where it reaches lim (whichever comes first)
 template <int DIR>
 __device__ __forceinline__ float fp_walk(const float* __restrict__ r, const float2* __restrict__ s1,
                                          const float2* __restrict__ s2, int ns, int nb, int nb2, int bshift, int q,
-                                         float v, float lmin) {
+                                         float v, float lim) {
     const int BS = 1 << bshift, SB = BS * kFpFan;
+    float lmin = v;
     // samples to the edge of the block (for DIR < 0 the block's first sample is included)
     int n = (DIR < 0) ? ((q + 1) & (BS - 1)) : ((BS - (q & (BS - 1))) & (BS - 1));
     if (DIR > 0) n = min(n, ns - q);
-    if (fp_scan_samples<DIR>(r, ns, q, n, v, lmin)) return lmin;
+    if (fp_scan_samples<DIR>(r, ns, q, n, v, lim, lmin)) return lmin;
     if ((DIR < 0) ? (q < 0) : (q >= ns)) return lmin;
     // blocks to the edge of the super-block
     const int blk = q >> bshift;
     n = (DIR < 0) ? ((blk + 1) & (kFpFan - 1)) : ((kFpFan - (blk & (kFpFan - 1))) & (kFpFan - 1));
     if (DIR > 0) n = min(n, nb - blk);
-    bool in_block = fp_scan_blocks<DIR>(s1, nb, bshift, q, n, BS, v, lmin);
-    if (!in_block) {
+    int st = fp_scan_blocks<DIR>(s1, nb, bshift, q, n, BS, v, lim, lmin);
+    if (st == 2) return lmin;
+    if (st == 0) {
         if ((DIR < 0) ? (q < 0) : (q >= ns)) return lmin;
         // super-blocks to the row end
         const int sb = q >> (bshift + 5);
         n = (DIR < 0) ? sb + 1 : nb2 - sb;
-        if (!fp_scan_blocks<DIR>(s2, nb2, bshift + 5, q, n, SB, v, lmin)) return lmin;
+        if (fp_scan_blocks<DIR>(s2, nb2, bshift + 5, q, n, SB, v, lim, lmin) != 1) return lmin;
         // blocks of the stopping super-block (one of them has a larger sample)
-        (void)fp_scan_blocks<DIR>(s1, nb, bshift, q, kFpFan, BS, v, lmin);
+        if (fp_scan_blocks<DIR>(s1, nb, bshift, q, kFpFan, BS, v, lim, lmin) == 2) return lmin;
     }
     // samples of the stopping block
-    (void)fp_scan_samples<DIR>(r, ns, q, BS, v, lmin);
+    (void)fp_scan_samples<DIR>(r, ns, q, BS, v, lim, lmin);
     return lmin;
 }
 
@@ -612,10 +623,14 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
             while (ia < ns - 1 && r[ia] == v) ++ia;
             if (!(r[ia] < v)) continue;
             const int mid = (i + ia - 1) / 2;
-            const float lmin = fp_walk<-1>(r, s1, s2, ns, nb, nb2, bshift, i - 1, v, v);
-            const float rmin = fp_walk<+1>(r, s1, s2, ns, nb, nb2, bshift, ia, v, v);
-            // float64 like scipy: float32 samples are exact in float64, a float32 subtraction is not
-            if ((double)v - (double)fmaxf(lmin, rmin) >= thr) atomicOr(&bits[mid >> 5], 1u << (mid & 31));
+            // float64 like scipy (float32 samples are exact in float64, a float32 subtraction is not):
+            // lim = the largest float u with (double)v - (double)u >= thr
+            const double dl = (double)v - thr;
+            float lim = (float)dl;
+            if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
+            if (fp_walk<-1>(r, s1, s2, ns, nb, nb2, bshift, i - 1, v, lim) > lim) continue;   // left base too high
+            if (fp_walk<+1>(r, s1, s2, ns, nb, nb2, bshift, ia, v, lim) > lim) continue;
+            atomicOr(&bits[mid >> 5], 1u << (mid & 31));
         }
     }
     __syncthreads();
