@@ -24,12 +24,20 @@ constexpr int kSosChunk = 32;    // time samples staged per LDS round trip
 constexpr int kSosPitch = kSosChunk + 4;
 constexpr int kSosMaxSec = 10;
 
-struct SosCoef {
-    float b0, b1, b2, a1, a2, z1, z2, pad;
+template <typename T>
+struct SosCoefT {
+    T b0, b1, b2, a1, a2, z1, z2, pad;
 };
-struct SosArgs {
-    SosCoef s[kSosMaxSec];
+template <typename T>
+struct SosArgsT {
+    SosCoefT<T> s[kSosMaxSec];
 };
+typedef SosCoefT<float> SosCoef;
+typedef SosArgsT<float> SosArgs;
+
+// fused multiply-add in the recursion's precision
+__device__ __forceinline__ float sos_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double sos_fma(double a, double b, double c) { return fma(a, b, c); }
 
 // forward pass input: scipy odd extension of the row, virtual index i in [-padlen, ns + padlen)
 __device__ __forceinline__ float sos_fetch_fwd(const float* __restrict__ row, int ns, int i) {
@@ -43,11 +51,22 @@ __device__ __forceinline__ float sos_fetch_bwd(const float* __restrict__ row, co
     return (i >= ns) ? edge[i - ns] : row[i];
 }
 
-template <int NSEC, bool REV>
-__global__ __launch_bounds__(kSosRows) void sos_pass(SosArgs A, const float* __restrict__ src,
+__global__ __launch_bounds__(256) void sos_first_samples(const float* __restrict__ x, int nx, int ns,
+                                                         float* __restrict__ first) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nx) first[r] = x[(size_t)r * ns];
+}
+
+// T = float for well-conditioned cascades; T = double (states and arithmetic, float32 I/O) when poles
+// sit close to the unit circle: the float32 recursion's rounding noise grows like 1 / (1 - |pole|)^2
+// (5 Hz band edge at 200 Hz: 2e-5 of the output, above the 1e-5 budget; 14-30 Hz: 1.5e-6)
+template <int NSEC, bool REV, typename T>
+__global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float* __restrict__ src,
                                                      const float* __restrict__ edge_in,
                                                      float* __restrict__ dst, float* __restrict__ edge_out,
-                                                     int nx, int ns, int padlen, int S, int W) {
+                                                     int nx, int ns, int padlen, int S, int W,
+                                                     const float* __restrict__ xorig /* [nx] first samples */,
+                                                     float dc_gain2) {
     __shared__ __attribute__((aligned(16))) float tile[kSosRows * kSosPitch];
     const int lane = threadIdx.x;
     const int row0 = blockIdx.x * kSosRows;
@@ -66,13 +85,19 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgs A, const float* __r
     }
     const int my_row = min(row0 + lane, nx - 1);
     const float* my_src = src + (size_t)my_row * ns;
-    const float x0 = REV ? sos_fetch_bwd(my_src, edge_in + (size_t)my_row * padlen, ns, i_start)
-                         : sos_fetch_fwd(my_src, ns, i_start);
-    float s1[NSEC], s2[NSEC];
+    // The row's first sample c is taken out before the forward recursion and c |H(1)|^2 put back after
+    // the backward one: filtfilt of a constant is exactly that constant times the squared DC gain (odd
+    // extension and steady-state initial conditions keep a constant in steady state), and a large offset
+    // in front of a band-pass would otherwise sit in the float32 states and drown the output's low bits.
+    const float c_row = xorig[my_row];
+    const float c_sub = REV ? 0.f : c_row, c_add = REV ? c_row * dc_gain2 : 0.f;
+    const float x0 = (REV ? sos_fetch_bwd(my_src, edge_in + (size_t)my_row * padlen, ns, i_start)
+                          : sos_fetch_fwd(my_src, ns, i_start)) - c_sub;
+    T s1[NSEC], s2[NSEC];
 #pragma unroll
     for (int s = 0; s < NSEC; ++s) {
-        s1[s] = A.s[s].z1 * x0;
-        s2[s] = A.s[s].z2 * x0;
+        s1[s] = A.s[s].z1 * (T)x0;
+        s2[s] = A.s[s].z2 * (T)x0;
     }
     // A chunk is INTERIOR when its 32 samples lie inside the row proper (no extension, no edge buffer)
     // and inside this segment's walk: its loads are then branch-free, all 32 of a lane in flight at
@@ -131,16 +156,16 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgs A, const float* __r
             float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float x = v[j];
+                T x = (T)(v[j] - c_sub);
 #pragma unroll
                 for (int s = 0; s < NSEC; ++s) {
-                    const SosCoef& c = A.s[s];
-                    const float y = fmaf(c.b0, x, s1[s]);
-                    s1[s] = fmaf(c.b1, x, fmaf(-c.a1, y, s2[s]));
-                    s2[s] = fmaf(c.b2, x, -c.a2 * y);
+                    const SosCoefT<T>& c = A.s[s];
+                    const T y = sos_fma(c.b0, x, s1[s]);
+                    s1[s] = sos_fma(c.b1, x, sos_fma(-c.a1, y, s2[s]));
+                    s2[s] = sos_fma(c.b2, x, -c.a2 * y);
                     x = y;
                 }
-                v[j] = x;
+                v[j] = (float)x + c_add;
             }
             mine[g] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -247,6 +272,64 @@ __global__ __launch_bounds__(kStatThreads) void raw2strain_rows(const T* __restr
     const double mu = s_mean;
     float* out = y + (size_t)blockIdx.x * ns;
     for (int i = threadIdx.x; i < ns; i += kStatThreads) out[i] = (float)(((double)row[i] - mu) * scale);
+}
+
+// =============================================================================================
+// DC tail of the de-meaned zero-padded template (detect.py:158): the reference normalises the template
+// over its zero-padded length, which leaves the constant -mean(t)/max|t| on the padded part.  Its
+// contribution to lag k is  coef * sum_{n >= L, n + k < ns} xh[n + k]  with xh the normalised row; as the
+// de-meaned row sums to zero this equals  -coef * P[k + L],  P[j] = sum_{i < j} xh[i]  (zero for
+// k + L >= ns), and with coef = -mean(t)/max|t|:   y[k] += (mean(t)/max|t|) * g * sum_{i < k+L} (x[i] - m).
+// One workgroup walks a row in order (chunks of 1024 samples, workgroup prefix sum, float64 carry).
+// Negligible for the fin-whale templates (|coef| ~ 5e-7) and applied by the host only when it matters.
+// =============================================================================================
+__global__ __launch_bounds__(kStatThreads) void xcorr_dc_tail(const float* __restrict__ x, int ns,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ maxabs, float coef, int L,
+                                                              float* __restrict__ y) {
+    __shared__ float wsum[kStatThreads / 64];
+    const float* row = x + (size_t)blockIdx.x * ns;
+    float* out = y + (size_t)blockIdx.x * ns;
+    const float m = mean ? mean[blockIdx.x] : 0.f;
+    float g = 1.f;
+    if (maxabs) {
+        const float a = maxabs[blockIdx.x];
+        g = (a > 0.f) ? 1.0f / a : 0.f;
+    }
+    const float cg = coef * g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double carry = 0.0;                                      // sum of (x - m) over all earlier chunks
+    for (int j0 = 0; j0 < ns; j0 += 4 * kStatThreads) {
+        float v[4], loc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + 4 * tid + k;
+            v[k] = (j < ns) ? row[j] - m : 0.f;
+            loc += v[k];
+        }
+        float incl = loc;                                    // inclusive scan of the threads' sums
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float n = __shfl_up(incl, off);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        float before = 0.f, total = 0.f;
+        for (int w = 0; w < kStatThreads / 64; ++w) {
+            if (w < wave) before += wsum[w];
+            total += wsum[w];
+        }
+        float pre = (float)carry + before + incl - loc;      // P[j0 + 4 tid]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + 4 * tid + k;                  // P[j] belongs to lag j - L
+            if (j >= L && j < ns) out[j - L] += cg * pre;
+            pre += v[k];
+        }
+        carry += (double)total;
+        __syncthreads();
+    }
 }
 
 // =============================================================================================
@@ -408,15 +491,15 @@ __global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict_
 
 using namespace d4w;
 
-template <bool REV>
-static int sos_launch(int nsec, dim3 grid, void* stream, const SosArgs& A, const float* src,
+template <bool REV, typename T>
+static int sos_launch(int nsec, dim3 grid, void* stream, const SosArgsT<T>& A, const float* src,
                       const float* edge_in, float* dst, float* edge_out, int nx, int ns, int padlen,
-                      int S, int W) {
+                      int S, int W, const float* xorig, float dc_gain2) {
     switch (nsec) {
 #define D4W_SOS_CASE(N)                                                                               \
     case N:                                                                                           \
-        hipLaunchKernelGGL((sos_pass<N, REV>), grid, dim3(kSosRows), 0, (hipStream_t)stream, A, src,  \
-                           edge_in, dst, edge_out, nx, ns, padlen, S, W);                             \
+        hipLaunchKernelGGL((sos_pass<N, REV, T>), grid, dim3(kSosRows), 0, (hipStream_t)stream, A, src, \
+                           edge_in, dst, edge_out, nx, ns, padlen, S, W, xorig, dc_gain2);            \
         break;
         D4W_SOS_CASE(1) D4W_SOS_CASE(2) D4W_SOS_CASE(3) D4W_SOS_CASE(4) D4W_SOS_CASE(5)
         D4W_SOS_CASE(6) D4W_SOS_CASE(7) D4W_SOS_CASE(8) D4W_SOS_CASE(9) D4W_SOS_CASE(10)
@@ -446,7 +529,7 @@ extern "C" {
 
 size_t d4w_sosfiltfilt_ws_bytes(int nx, int ns, int padlen) {
     if (nx < 1 || ns < 1 || padlen < 0) return 0;
-    return ((size_t)nx * ns + (size_t)nx * std::max(padlen, 1)) * sizeof(float);
+    return ((size_t)nx * ns + (size_t)nx * std::max(padlen, 1) + (size_t)nx) * sizeof(float);
 }
 
 int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi,
@@ -457,14 +540,31 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     if (ns <= padlen)
         return fail(D4W_EINVAL, "The length of the input vector x must be greater than padlen, which is %d.", padlen);
     SosArgs A;
+    SosArgsT<double> Ad;
     memset(&A, 0, sizeof(A));
+    memset(&Ad, 0, sizeof(Ad));
+    double dmin = 1e30;                                     // smallest |A_s(e^jw)| over the sections and w
+    double dcg = 1.0;                                       // DC gain H(1) of the cascade
     for (int s = 0; s < nsec; ++s) {
         const double* c = sos + 6 * s;
         if (c[3] == 0.0) return fail(D4W_EINVAL, "section %d has a0 = 0", s);
-        const double a0 = c[3];
-        A.s[s] = SosCoef{(float)(c[0] / a0), (float)(c[1] / a0), (float)(c[2] / a0), (float)(c[4] / a0),
-                         (float)(c[5] / a0), (float)zi[2 * s], (float)zi[2 * s + 1], 0.f};
+        const double a0 = c[3], a1 = c[4] / a0, a2 = c[5] / a0;
+        A.s[s] = SosCoef{(float)(c[0] / a0), (float)(c[1] / a0), (float)(c[2] / a0), (float)a1, (float)a2,
+                         (float)zi[2 * s], (float)zi[2 * s + 1], 0.f};
+        Ad.s[s] = SosCoefT<double>{c[0] / a0, c[1] / a0, c[2] / a0, a1, a2, zi[2 * s], zi[2 * s + 1], 0.0};
+        dcg *= ((c[0] + c[1] + c[2]) / a0) / (1.0 + a1 + a2);
+        for (int k = 0; k <= 1024; ++k) {                   // |1 + a1 z^-1 + a2 z^-2| on the unit circle
+            const double w = M_PI * k / 1024.0;
+            const double re = 1.0 + a1 * cos(w) + a2 * cos(2.0 * w), im = -a1 * sin(w) - a2 * sin(2.0 * w);
+            dmin = std::min(dmin, sqrt(re * re + im * im));
+        }
     }
+    // The float32 recursion's rounding noise grows like 1 / dmin^2 (dmin ~ (1 - r) 2 sin(theta) for a pole
+    // r e^(j theta): low-frequency poles are the ill-conditioned ones).  Order-8 14-30 Hz at 200 Hz:
+    // dmin = 0.027, error 1.5e-6 of the output; 5-38 Hz: dmin = 0.0078, 2e-5.  Below 0.015: float64 states.
+    static const int f64_env = [] { const char* v = getenv("D4W_SOS_F64"); return v ? atoi(v) : -1; }();
+    const bool precise = (f64_env >= 0) ? (f64_env > 0) : (dmin < 0.015);
+    const double dcg2 = dcg * dcg;                          // forward and backward pass
     int S = seg_len, W = warm;
     if (S <= 0 || W <= 0 || S >= ns) { S = ns; W = ns; }           // one exact segment per row
     S = ((S + kSosChunk - 1) / kSosChunk) * kSosChunk;
@@ -472,9 +572,18 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     float* t = (float*)ws;
     float* edge = t + (size_t)nx * ns;
     const dim3 grid(ceil_div(nx, kSosRows), nseg);
-    int rc = sos_launch<false>(nsec, grid, stream, A, x, nullptr, t, edge, nx, ns, padlen, S, W);
+    // x may alias y: the backward pass needs the rows' first samples after y[.][0] may have been written
+    // by another workgroup, so they are saved in the workspace's edge area tail first
+    float* first = edge + (size_t)nx * std::max(padlen, 1);
+    D4W_LAUNCH(sos_first_samples, dim3(ceil_div(nx, 256)), dim3(256), 0, stream, x, nx, ns, first);
+    if (precise) {
+        int rcd = sos_launch<false, double>(nsec, grid, stream, Ad, x, nullptr, t, edge, nx, ns, padlen, S, W, first, 0.f);
+        if (rcd) return rcd;
+        return sos_launch<true, double>(nsec, grid, stream, Ad, t, edge, y, nullptr, nx, ns, padlen, S, W, first, (float)dcg2);
+    }
+    int rc = sos_launch<false, float>(nsec, grid, stream, A, x, nullptr, t, edge, nx, ns, padlen, S, W, first, 0.f);
     if (rc) return rc;
-    return sos_launch<true>(nsec, grid, stream, A, t, edge, y, nullptr, nx, ns, padlen, S, W);
+    return sos_launch<true, float>(nsec, grid, stream, A, t, edge, y, nullptr, nx, ns, padlen, S, W, first, (float)dcg2);
 }
 
 int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep, int nx_out, double scale_factor,
@@ -487,6 +596,14 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
         case 3: D4W_LAUNCH(raw2strain_rows<double>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const double*)raw, ns, c0, cstep, scale_factor, y); break;
         default: return fail(D4W_EINVAL, "raw_dtype = %d (0 int32, 1 int16, 2 float32, 3 float64)", raw_dtype);
     }
+    return D4W_OK;
+}
+
+int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, double coef,
+                          int support, float* y, void* stream) {
+    if (!x || !y || nx < 1 || ns < 1 || support < 1) return fail(D4W_EINVAL, "bad argument");
+    if (coef == 0.0 || support >= ns) return D4W_OK;
+    D4W_LAUNCH(xcorr_dc_tail, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs, (float)coef, support, y);
     return D4W_OK;
 }
 

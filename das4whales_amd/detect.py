@@ -120,8 +120,8 @@ def shift_nxcorr(x, y):
 
 def _normalised_support(template):
     """detect.py:158: (template - mean) / max|template| over the zero-padded length; returns the
-    non-zero support of the ORIGINAL template (the constant -mean/max tail is dropped, see
-    include/d4w.h)."""
+    non-zero support of the ORIGINAL template (the constant -mean/max tail on the padded part is
+    handled by _tail_coef / d4w_xcorr_dc_tail_f32)."""
     t = _host_vec(template)
     a = np.max(np.abs(t))
     if a == 0:
@@ -129,23 +129,55 @@ def _normalised_support(template):
     return ((t - t.mean()) / a)[:_support(t)]
 
 
-def compute_cross_correlograms(data, templates):
-    """Several templates against one block in a single pass over `data` (two templates per kernel
-    launch) -- what scripts/main_mfdetect.py:79-80 does with two separate calls."""
+def _tail_coef(template):
+    """mean(template) / max|template| over the zero-padded length: minus the constant that detect.py:158
+    leaves on the padded part (0 when the template fills its whole length)."""
+    t = _host_vec(template)
+    if _support(t) >= len(t):
+        return 0.0
+    return float(t.mean() / np.max(np.abs(t)))
+
+
+# the DC tail is added when |coef| * sqrt(ns) exceeds this (its size relative to the correlogram of
+# white data is ~ coef * sqrt(ns) / 15); the fin-whale templates on 60-s files stay below it
+TAIL_THRESHOLD = 1e-4
+
+
+def compute_cross_correlograms(data, templates, exact_tail=None):
+    """Several templates against one block (detect.compute_cross_correlogram for each) -- what
+    scripts/main_mfdetect.py:79-80 does with two separate calls.  exact_tail: True / False forces /
+    skips the DC-tail term of the zero-padded template (detect.py:158); None applies it when it is not
+    negligible (TAIL_THRESHOLD)."""
     if getattr(data, "ndim", 0) != 2:
         raise ValueError("data must be a 2-D [channel x time] array")
     xd = dev.to_device_f32(data)
-    outs = _xcorr_device(xd, [_normalised_support(t) for t in templates], normalize=True)
+    nx, ns = xd.shape
+    taps = [_normalised_support(t) for t in templates]
+    coefs = [_tail_coef(t) for t in templates]
+    need_tail = [exact_tail if exact_tail is not None else abs(c) * np.sqrt(ns) > TAIL_THRESHOLD for c in coefs]
+    stats = None
+    if any(need_tail):
+        with torch.cuda.device(xd.device):
+            mean = torch.empty(nx, dtype=torch.float32, device=xd.device)
+            mx = torch.empty(nx, dtype=torch.float32, device=xd.device)
+            check(lib.d4w_row_stats_f32(dev.ptr(xd), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(xd)))
+        stats = (mean, mx)
+    outs = _xcorr_device(xd, taps, normalize=True, stats=stats)
+    for o, tp, c, need in zip(outs, taps, coefs, need_tail):
+        if need and c != 0.0:
+            with torch.cuda.device(xd.device):
+                check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(xd), nx, ns, dev.ptr(stats[0]), dev.ptr(stats[1]), c, len(tp),
+                                                dev.ptr(o), dev.stream_ptr(xd)))
     return [dev.like_input(o, data) for o in outs]
 
 
-def compute_cross_correlogram(data, template):
+def compute_cross_correlogram(data, template, exact_tail=None):
     """Peak-normalised matched filter, every row against `template` -- reference detect.py:140-166.
 
     Rows: (x - mean) / max|x| (max of the un-de-meaned row, detect.py:157).  Output is floating
     point (the reference's np.empty_like would truncate integer input); an all-zero row gives
     zeros where the reference divides by zero."""
-    return compute_cross_correlograms(data, [template])[0]
+    return compute_cross_correlograms(data, [template], exact_tail=exact_tail)[0]
 
 
 # ---------------------------------------------------------------------------------------------

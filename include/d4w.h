@@ -169,8 +169,8 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
  *       all-zero row, where the reference divides by zero).
  *   taps: DEVICE float32 [ntpl][ltaps] (ltaps multiple of 4, zero padded), the template's
  *   support already normalised by the host exactly as detect.py:158 does.
- * The de-meaned zero-padded template's DC tail (-mean/max on the padded part, detect.py:158)
- * is NOT applied: it changes the correlogram by < 3e-6 of its peak.
+ * The de-meaned zero-padded template's DC tail (-mean/max on the padded part, detect.py:158) is a
+ * separate entry point, d4w_xcorr_dc_tail_f32.
  * ------------------------------------------------------------------------------------------ */
 int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream);
 int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
@@ -180,6 +180,15 @@ int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float
 int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
                        const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                        float* y1, void* stream);
+
+/* The constant the reference leaves on the zero-padded part of the de-meaned template (detect.py:158):
+ *   y[c][k] += coef * g[c] * sum_{i < k + support} (x[c][i] - m[c]),  k + support < ns,
+ * coef = mean(template) / max|template| over the zero-padded length, support = length of the non-zero
+ * part.  Added in place to a correlogram produced by d4w_xcorr_*_f32 with the same mean / maxabs.
+ * |coef| ~ 5e-7 for the fin-whale templates (a < 3e-6 effect on a 60-s file), so hosts apply it only
+ * when coef * sqrt(ns) is not negligible. */
+int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+                          double coef, int support, float* y, void* stream);
 
 /* Overlap-save FFT form of the same correlation for short templates (support <=
  * d4w_xcorr_fft_max_support() = 161 samples; the fin-whale templates have 136 / 156): blocks of

@@ -236,3 +236,58 @@ def test_raw2strain_ingest(emu):
         assert rc == 0, emu.d4w_last_error()
         assert rel(y, rr) < 1e-6
     assert emu.d4w_raw2strain_f32(vp(raw), 7, ns, 0, 1, 2, ctypes.c_double(1.0), vp(y), None) == -1
+
+
+def test_xcorr_dc_tail_exact(emu):
+    """With the DC-tail term the correlogram equals detect.compute_cross_correlogram for templates of
+    non-zero mean (rows of non-zero mean, ragged length, support longer / shorter than a scan chunk)."""
+    rng = np.random.default_rng(12)
+    for nx, ns, L in ((3, 2600, 40), (2, 1031, 300), (1, 5000, 1)):
+        x = rng.standard_normal((nx, ns)) + 0.4
+        tpl = np.zeros(ns)
+        tpl[:L] = np.abs(rng.standard_normal(L)) + 0.2            # clearly non-zero mean
+        ref = orc.compute_cross_correlogram(x, tpl)
+        taps = norm_taps(tpl)
+        coef = tpl.mean() / np.max(np.abs(tpl))
+        (y,), mean, mx = xcorr_emu(emu, x, [taps])
+        assert rel(y, ref) > 1e-3                                  # without the tail: far off
+        xf = np.ascontiguousarray(x, dtype=np.float32)
+        rc = emu.d4w_xcorr_dc_tail_f32(vp(xf), nx, ns, vp(mean), vp(mx), ctypes.c_double(coef), L, vp(y), None)
+        assert rc == 0, emu.d4w_last_error()
+        assert rel(y, ref) < TOL, (nx, ns, L, rel(y, ref))
+
+
+def test_bandpass_low_edge_uses_float64_states(emu):
+    """A 5 Hz band edge at 200 Hz puts poles at radius > 0.98: the float32 recursion's rounding noise
+    (2e-5) exceeds the budget, the library switches to float64 states (float32 I/O)."""
+    rng = np.random.default_rng(40)
+    x = rng.standard_normal((8, 3250)) + rng.standard_normal((8, 1)) * 3
+    fs, lo, hi = 200.0, 5.074, 38.506
+    sos = sps.butter(8, [lo / (fs / 2), hi / (fs / 2)], "bp", output="sos")
+    ref = orc.bp_filt(x, fs, lo, hi)
+    y = sosfiltfilt_emu(emu, x, sos, padlen=51)
+    assert rel(y, ref) < TOL
+
+
+def test_sosfiltfilt_dc_offset_and_lowpass(emu):
+    """Rows with a large offset in front of a narrow low band (the offset is taken out before the float32
+    recursion and c |H(1)|^2 put back after), and a low-pass whose DC gain is 1 (the put-back term)."""
+    rng = np.random.default_rng(41)
+    fs = 200.0
+    x = rng.standard_normal((70, 3654)) + rng.standard_normal((70, 1)) * 30
+    sos = sps.butter(8, [8.258 / (fs / 2), 19.632 / (fs / 2)], "bp", output="sos")
+    # ground truth = the float64 second-order-section filter: for this narrow low band the reference's
+    # 17-coefficient `ba` form (dsp.py:878-879) is itself 5.5e-5 away from it in float64
+    ref = sps.sosfiltfilt(sos, x, axis=1, padlen=51)
+    assert rel(orc.bp_filt(x, fs, 8.258, 19.632), ref) > 3e-5
+    assert rel(sosfiltfilt_emu(emu, x, sos, padlen=51), ref) < TOL
+    assert rel(sosfiltfilt_emu(emu, x, sos, padlen=51, seg_len=1024, warm=2048), ref) < TOL
+    lp = sps.butter(4, 0.2, "lp", output="sos")
+    ref_lp = sps.sosfiltfilt(lp, x, axis=1)
+    assert rel(sosfiltfilt_emu(emu, x, lp, padlen=15), ref_lp) < TOL
+    buf = np.ascontiguousarray(x, dtype=np.float32)                     # in place (x aliases y)
+    zi = np.ascontiguousarray(sps.sosfilt_zi(lp), dtype=np.float64)
+    ws = np.empty(emu.d4w_sosfiltfilt_ws_bytes(70, 3654, 15), dtype=np.uint8)
+    assert emu.d4w_sosfiltfilt_f32(vp(buf), vp(buf), 70, 3654, vp(np.ascontiguousarray(lp)), vp(zi), lp.shape[0], 15, 0, 0,
+                                   vp(ws), None) == 0
+    assert rel(buf, ref_lp) < TOL

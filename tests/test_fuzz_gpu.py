@@ -1,0 +1,151 @@
+"""Seeded random-shape sweep of every row of SURVEY 8(a) on the GPU against SciPy / the oracle:
+ragged and odd shapes, prime factors, tiny inputs, rows of zeros / constants.  Complements the
+golden-vector and full-size tests with breadth."""
+import numpy as np
+import pytest
+import scipy.signal as sps
+import torch
+
+from oracle import d4w_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+FS = 200.0
+
+
+def rel(y, ref):
+    d = np.max(np.abs(np.asarray(y, dtype=np.float64) - ref))
+    s = np.max(np.abs(ref))
+    return float(d / s) if s > 0 else float(d)
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available()
+    import das4whales_amd as dw_
+    return dw_
+
+
+def smooth_lengths(rng, n, lo, hi, even=False):
+    """Random lengths whose prime factors are <= 31 (what the transforms support)."""
+    out = []
+    while len(out) < n:
+        v = int(rng.integers(lo, hi))
+        if even and v % 2:
+            v += 1
+        m = v
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            out.append(v)
+    return out
+
+
+def test_fk_filter_random_shapes(dw):
+    rng = np.random.default_rng(101)
+    for nx, ns in zip(smooth_lengths(rng, 6, 2, 400), smooth_lengths(rng, 6, 4, 3000, even=True)):
+        x = rng.standard_normal((nx, ns))
+        m = rng.random((nx, ns)) * (rng.random((nx, 1)) > 0.3)          # some all-zero wavenumber rows
+        ref = orc.fk_filter_filt(x, m)
+        assert rel(dw.dsp.fk_filter_filt(x, m), ref) < TOL, (nx, ns)
+        assert rel(dw.dsp.fk_filter_filt(x, m, tapering=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL, (nx, ns)
+
+
+def test_bandpass_random_shapes(dw):
+    rng = np.random.default_rng(102)
+    for _ in range(5):
+        nx, ns = int(rng.integers(1, 300)), int(rng.integers(60, 20000))
+        x = rng.standard_normal((nx, ns)) + rng.standard_normal((nx, 1)) * 3
+        lo = float(rng.uniform(5, 20))
+        hi = lo + float(rng.uniform(5, 40))
+        # ground truth = the float64 second-order-section filter with filtfilt's padlen; the reference's
+        # 17-coefficient `ba` form (dsp.py:878-879) agrees with it to ~1e-7 for well-conditioned bands
+        # (14-30 Hz) but is itself several 1e-5 off for narrow low bands, in float64
+        sos = sps.butter(8, [lo / (FS / 2), hi / (FS / 2)], "bp", output="sos")
+        truth = sps.sosfiltfilt(sos, x, axis=1, padlen=51)
+        assert rel(dw.dsp.bp_filt(x, FS, lo, hi), truth) < TOL, (nx, ns, lo, hi)
+        assert rel(orc.bp_filt(x, FS, lo, hi), truth) < 2e-4
+        sos = dw.dsp.butterworth_filter([int(rng.integers(1, 6)), float(rng.uniform(2, 40)), "hp"], FS)
+        assert rel(dw.dsp.sosfiltfilt(sos, x, axis=1), sps.sosfiltfilt(sos, x, axis=1)) < TOL
+
+
+def test_matched_filter_random_shapes(dw):
+    rng = np.random.default_rng(103)
+    for _ in range(6):
+        nx, ns = int(rng.integers(1, 200)), int(rng.integers(200, 30000))
+        x = rng.standard_normal((nx, ns)) + 0.2
+        if nx > 2:
+            x[1] = 0.0                                                   # all-zero row -> zeros (documented)
+        L = int(rng.integers(2, min(161, ns // 2)))
+        tpl = np.zeros(ns)
+        tpl[:L] = rng.standard_normal(L) * np.hanning(L)
+        c = dw.detect.compute_cross_correlogram(x, tpl)
+        keep = [r for r in range(nx) if np.any(x[r] != 0)]
+        ref = orc.compute_cross_correlogram(x[keep], tpl)
+        assert rel(c[keep], ref) < TOL, (nx, ns, L)                   # incl. the zero-padded template's DC tail
+        if nx > 2:
+            assert np.all(c[1] == 0)
+        # long second operand: direct form
+        y = rng.standard_normal(ns)
+        assert rel(dw.detect.shift_xcorr(x[0], y), orc.shift_xcorr(x[0], y)) < TOL
+        assert rel(dw.detect.shift_nxcorr(x[0], y), orc.shift_nxcorr(x[0], y)) < TOL
+
+
+def test_analytic_and_snr_random_shapes(dw):
+    rng = np.random.default_rng(104)
+    for ns in smooth_lengths(rng, 4, 16, 30000, even=True) + smooth_lengths(rng, 2, 15, 15000) + [120000 // 2, 2 * 3 * 5 * 7 * 11 * 13]:
+        nx = int(rng.integers(1, 40))
+        x = rng.standard_normal((nx, ns))
+        z = orc.hilbert(x)
+        assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL, ns
+        if ns % 2 == 0:
+            s = dw.dsp.snr_tr_array(x, env=True)
+            lin, ref = 10.0 ** (s / 10), np.abs(z) ** 2 / np.var(x, axis=1, keepdims=True)
+            assert np.max(np.abs(lin - ref)) / np.max(ref) < TOL, ns
+
+
+def test_spectrogram_random_parameters(dw):
+    rng = np.random.default_rng(105)
+    for _ in range(6):
+        ns = int(rng.integers(300, 20000))
+        nfft = int(rng.choice([32, 64, 100, 128, 160, 256, 500, 512, 1024]))
+        ov = float(rng.choice([0.5, 0.75, 0.8, 0.9, 0.95]))
+        x = rng.standard_normal(ns)
+        p, tt, ff = dw.dsp.get_spectrogram(x, FS, nfft=nfft, overlap_pct=ov)
+        pr, ttr, ffr = orc.get_spectrogram(x, FS, nfft=nfft, overlap_pct=ov)
+        assert p.shape == pr.shape and np.allclose(tt, ttr) and np.allclose(ff, ffr)
+        assert np.max(np.abs(10.0 ** (p / 20) - 10.0 ** (pr / 20))) < TOL, (ns, nfft, ov)
+        nfx = int(rng.choice([64, 300, 512, 1000, 4096]))
+        xm = rng.standard_normal((int(rng.integers(1, 50)), int(rng.integers(10, 900))))
+        assert rel(dw.dsp.get_fx(xm, nfx), orc.get_fx(xm, nfx)) < TOL
+
+
+def test_spectrocorr_random_parameters(dw):
+    rng = np.random.default_rng(106)
+    for _ in range(4):
+        nx, ns = int(rng.integers(1, 60)), int(rng.integers(3000, 16000))
+        x = rng.standard_normal((nx, ns))
+        win = float(rng.choice([0.4, 0.64, 0.8]))
+        ov = float(rng.choice([0.9, 0.95]))
+        ker = {"f0": 27., "f1": 17., "dur": float(rng.choice([0.6, 0.8, 1.0])), "bdwidth": float(rng.choice([3., 4.]))}
+        sc = dw.detect.compute_cross_correlogram_spectrocorr(x, FS, [14., 30.], ker, win, ov)
+        ref = orc.compute_cross_correlogram_spectrocorr(x, FS, [14., 30.], ker, win, ov)
+        assert sc.shape == ref.shape and rel(sc, ref) < TOL, (nx, ns, win, ov)
+
+
+def test_picks_random_rows(dw):
+    rng = np.random.default_rng(107)
+    for ns in (3, 4, 64, 65, 1000, 16384, 16385, 50001):
+        nx = int(rng.integers(1, 30))
+        x = rng.standard_normal((nx, ns)).astype(np.float32)
+        x[0] = np.round(x[0] * 2) / 2                                    # plateaus
+        if nx > 1:
+            x[1] = 1.0                                                   # constant row
+        if nx > 2:
+            x[2] = np.abs(sps.hilbert(x[2].astype(np.float64))).astype(np.float32) if ns > 8 else x[2]
+        for thr in (0.0, 0.5, 2.0, 1e9):
+            got = dw.detect.pick_times(x, thr)
+            for c in range(nx):
+                ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+                assert np.array_equal(got[c], ref), (ns, thr, c)
