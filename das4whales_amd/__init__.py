@@ -10,5 +10,6 @@ from . import dsp  # noqa: F401
 from . import detect  # noqa: F401
 from . import data_handle  # noqa: F401
 from . import stream  # noqa: F401
+from . import improcess  # noqa: F401
 
-__all__ = ["dsp", "detect", "data_handle", "stream"]
+__all__ = ["dsp", "detect", "data_handle", "stream", "improcess"]

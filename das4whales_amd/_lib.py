@@ -83,6 +83,14 @@ def _load():
         "d4w_spectrocorr_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_int, c_void_p, c_void_p]),
         "d4w_find_peaks_f32": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_int, c_void_p]),
+        "d4w_minmax_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
+        "d4w_scale_pixels_f32": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_double, c_void_p]),
+        "d4w_threshold_f32": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.c_double, c_void_p]),
+        "d4w_mask_mul_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+        "d4w_resize_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+        "d4w_resize_bilinear_aa_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+        "d4w_filter2d_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),
+        "d4w_filter2d_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly

@@ -1426,13 +1426,14 @@ __global__ __launch_bounds__(kThreads) void analytic_combine(const float* __rest
     const size_t base = (size_t)blockIdx.y * ns;
     const int nout = (mode == 3) ? ns - 1 : ns;
     float* yr = y + (size_t)blockIdx.y * nout;
-    const float inv_var = (mode == 2) ? 1.0f / var[blockIdx.y] : 0.f;
+    const float inv_var = (mode == 2 || mode == 4) ? 1.0f / var[blockIdx.y] : 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += gridDim.x * blockDim.x) {
         const float re = x[base + i], im = h[base + i];
         float v;
         if (mode == 0) v = sqrtf(fmaf(re, re, im * im));
         else if (mode == 1) v = im;
         else if (mode == 2) v = 10.0f * log10f(fmaf(re, re, im * im) * inv_var);
+        else if (mode == 4) v = sqrtf(fmaf(re, re, im * im) * inv_var);
         else {
             const float2 p = c_mulc(make_float2(x[base + i + 1], h[base + i + 1]), make_float2(re, im));
             v = atan2f(p.y, p.x) * fscale;
@@ -1453,8 +1454,8 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
                           void* ws, void* stream) {
     if (!x || !y || !ws || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");
     if (ns & 1) return fail(D4W_EINVAL, "ns = %d must be even on the long-row path", ns);
-    if (mode < 0 || mode > 3) return fail(D4W_EINVAL, "mode = %d not in 0..3", mode);
-    if (mode == 2 && !var) return fail(D4W_EINVAL, "mode 2 needs the row variances");
+    if (mode < 0 || mode > 4) return fail(D4W_EINVAL, "mode = %d not in 0..4", mode);
+    if ((mode == 2 || mode == 4) && !var) return fail(D4W_EINVAL, "modes 2 and 4 need the row variances");
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
     int devid = 0;
     D4W_HIP(hipGetDevice(&devid));

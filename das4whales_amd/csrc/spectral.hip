@@ -101,10 +101,11 @@ static int row_fft_get(int L, const RowFftHost** out) {
 //   mode 0: |z|                               (envelope, detect.py:192)
 //   mode 1: imag(z) = H[x]
 //   mode 2: 10 log10(|z|^2 / var[row])        (dsp.py:975)
+//   mode 4: |z| / std[row]                    (improcess.trace2image before scaling, improcess.py:60)
 //   mode 3: arg(z[i+1] conj(z[i])) * fscale   (diff(unwrap(angle z)) / 2 pi * fs, dsp.py:846-855),
 //           ns - 1 outputs per row
 // ---------------------------------------------------------------------------------------------
-enum { kAnEnvelope = 0, kAnHilbert = 1, kAnSnr = 2, kAnIfreq = 3 };
+enum { kAnEnvelope = 0, kAnHilbert = 1, kAnSnr = 2, kAnIfreq = 3, kAnEnvStd = 4 };
 
 __device__ __forceinline__ float an_ifreq(float2 z0, float2 z1, float fscale) {
     const float2 p = c_mulc(z1, z0);
@@ -176,12 +177,13 @@ __global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const f
         return;
     }
     float* yr = y + (size_t)blockIdx.x * ns;
-    const float inv_var = (mode == kAnSnr) ? 1.0f / var[blockIdx.x] : 0.f;
+    const float inv_var = (mode == kAnSnr || mode == kAnEnvStd) ? 1.0f / var[blockIdx.x] : 0.f;
     for (int i = tid; i < ns; i += nthr) {
         const float2 z = zat(i);
         float v;
         if (mode == kAnEnvelope) v = sqrtf(fmaf(z.x, z.x, z.y * z.y));
         else if (mode == kAnHilbert) v = z.y;
+        else if (mode == kAnEnvStd) v = sqrtf(fmaf(z.x, z.x, z.y * z.y) * inv_var);
         else v = 10.0f * log10f(fmaf(z.x, z.x, z.y * z.y) * inv_var);
         yr[i] = v;
     }
@@ -696,8 +698,8 @@ int d4w_analytic_row_fits_lds(int ns) {
 int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
                      void* stream) {
     if (!x || !y || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");
-    if (mode < 0 || mode > 3) return fail(D4W_EINVAL, "mode = %d not in 0..3", mode);
-    if (mode == kAnSnr && !var) return fail(D4W_EINVAL, "mode 2 needs the row variances");
+    if (mode < 0 || mode > 4) return fail(D4W_EINVAL, "mode = %d not in 0..4", mode);
+    if ((mode == kAnSnr || mode == kAnEnvStd) && !var) return fail(D4W_EINVAL, "modes 2 and 4 need the row variances");
     const bool packed = (ns % 2 == 0);
     const int L = packed ? ns / 2 : ns;
     const RowFftHost* h = nullptr;

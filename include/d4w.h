@@ -235,6 +235,7 @@ int d4w_minmax_normalise_f32(float* x, size_t n, void* stream);
  *   mode 1  y = imag(z) = H[x]
  *   mode 2  y = 10 log10(|z|^2 / var[c]) var = DEVICE [nx] row variances   (dsp.py:975)
  *   mode 3  y[c][i] = diff(unwrap(angle z))[i] / (2 pi) * fs, [nx][ns-1]   (dsp.instant_freq, dsp.py:830-856)
+ *   mode 4  y = |z| / sqrt(var[c])       improcess.trace2image before scaling   (improcess.py:60)
  *   Row length limit: ns <= ~37 000 (even) / ~18 000 (odd); ns/2 (even) or ns (odd) must factor
  *   into primes <= 31.  D4W_EINVAL otherwise.
  * d4w_row_var_f32: var[c] = np.std(x[c])**2 (population).
@@ -294,6 +295,35 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
  * ------------------------------------------------------------------------------------------ */
 int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx,
                        int32_t* counts, int cap, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Image operators of the Gabor detector: replaces improcess.scale_pixels /
+ * trace2image (improcess.py:23-62), improcess.binning (improcess.py:395-420, torchvision Resize =
+ * antialiased bilinear interpolation), cv2.filter2D and the thresholds of
+ * scripts/main_gabordetect.py:109-134, improcess.apply_smooth_mask (improcess.py:423-454).
+ * Images are row-major float32 [h][w] on the DEVICE.
+ *
+ * d4w_minmax_f32: minmax[0] = min(x), minmax[1] = max(x) over n values; minmax = DEVICE [2].
+ * d4w_scale_pixels_f32: y = (x - minmax[0]) / (minmax[1] - minmax[0]) * gain; y may alias x.
+ * d4w_threshold_f32: y = (x > thr) ? 1 : 0, compared in float64.
+ * d4w_mask_mul_f32: y = x where mask != 0, else 0 (array * bool mask).
+ * d4w_resize_bilinear_aa_f32: torch.nn.functional.interpolate(x, (oh, ow), mode="bilinear",
+ *   align_corners=False, antialias=True) -- what torchvision 0.17 Resize runs; horizontal pass, then
+ *   vertical pass; ws = DEVICE scratch of d4w_resize_ws_bytes(h, w, oh, ow) bytes.
+ * d4w_filter2d_f32: cv2.filter2D(img, CV_64F, kernel): out[y][x] = sum K[ky][kx] *
+ *   img[y + ky - kh/2][x + kx - kw/2] with BORDER_REFLECT_101; kernel = DEVICE [kh][kw];
+ *   accumulate != 0 adds to out; ws = DEVICE scratch of d4w_filter2d_ws_bytes(kh, kw) bytes.
+ *   (64 + kw - 1)(32 + kh - 1) floats must fit in 160 KiB of LDS (101 x 101: 85 KiB).
+ * ------------------------------------------------------------------------------------------ */
+int d4w_minmax_f32(const float* x, size_t n, float* minmax, void* stream);
+int d4w_scale_pixels_f32(const float* x, float* y, size_t n, const float* minmax, double gain, void* stream);
+int d4w_threshold_f32(const float* x, float* y, size_t n, double thr, void* stream);
+int d4w_mask_mul_f32(const float* x, const float* mask, float* y, size_t n, void* stream);
+size_t d4w_resize_ws_bytes(int h, int w, int oh, int ow);
+int d4w_resize_bilinear_aa_f32(const float* x, int h, int w, float* y, int oh, int ow, void* ws, void* stream);
+size_t d4w_filter2d_ws_bytes(int kh, int kw);
+int d4w_filter2d_f32(const float* img, int h, int w, const float* kernel, int kh, int kw, float* out,
+                     int accumulate, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

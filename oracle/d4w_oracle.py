@@ -650,6 +650,125 @@ def compute_cross_correlogram_spectrocorr(data, fs, flims, kernel, win_size, ove
 # --------------------------------------------------------------------------------------------
 # deterministic synthetic strain block (SURVEY.md 8d "S-small" recipe, scaled by arguments)
 # --------------------------------------------------------------------------------------------
+# =============================================================================================
+# Image pipeline of the Gabor detector: improcess.py + scripts/main_gabordetect.py
+#
+# Third-party arithmetic that is ABSENT here (authors' env: opencv-python 4.9.0.80, torchvision 0.17.2,
+# DAS4Whales_ExampleNotebook.md:67-69) and therefore restated from the published algorithms --
+# "parity unpinned" for these two:
+#   cv2.getGaborKernel (OpenCV 4.9 modules/imgproc/src/gabor.cpp), cv2.filter2D (correlation, anchor
+#   at the kernel centre, BORDER_REFLECT_101);
+#   torchvision.transforms.Resize on a tensor = torch.nn.functional.interpolate(mode="bilinear",
+#   align_corners=False, antialias=True) (torchvision 0.17 default antialias=True; non-float input is
+#   cast to float32, interpolated and cast back).  torch IS present here, so `resize_bilinear_aa`
+#   below (the NumPy restatement of aten's _upsample_bilinear2d_aa weights) is pinned against
+#   torch's own CPU kernel in tests/test_oracle_image.py.
+# =============================================================================================
+def scale_pixels(img):
+    """improcess.py:23-40."""
+    return (img - img.min()) / (img.max() - img.min())
+
+
+def trace2image(trace):
+    """improcess.py:43-62: |hilbert| / std per row, min-max scaled to [0, 255]."""
+    trace = np.asarray(trace, dtype=np.float64)
+    image = np.abs(hilbert(trace)) / np.std(trace, axis=1, keepdims=True)
+    return scale_pixels(image) * 255
+
+
+def angle_fromspeed(c0, fs, dx, selected_channels):
+    """improcess.py:65-96 (degrees)."""
+    return np.arctan(c0 / (fs * dx * selected_channels[2])) * 180 / np.pi
+
+
+def get_gabor_kernel(ksize, sigma, theta, lambd, gamma, psi=np.pi * 0.5):
+    """cv2.getGaborKernel(ksize=(w, h), ..., ktype=CV_64F), OpenCV 4.9 gabor.cpp: the kernel has
+    2*(w//2)+1 columns and 2*(h//2)+1 rows and is written mirrored (kernel[ymax-y][xmax-x])."""
+    sigma_x, sigma_y = sigma, sigma / gamma
+    xmax, ymax = ksize[0] // 2, ksize[1] // 2
+    c, s = np.cos(theta), np.sin(theta)
+    y, x = np.mgrid[-ymax:ymax + 1, -xmax:xmax + 1].astype(np.float64)
+    xr = x * c + y * s
+    yr = -x * s + y * c
+    v = np.exp(-0.5 / sigma_x ** 2 * xr * xr - 0.5 / sigma_y ** 2 * yr * yr) * np.cos(2 * np.pi / lambd * xr + psi)
+    return v[::-1, ::-1].copy()
+
+
+def gabor_filt_design(theta_c0):
+    """improcess.py:99-140: (up, down) 101 x 101 kernels."""
+    up = get_gabor_kernel((100, 100), 4, np.pi / 2 + np.deg2rad(theta_c0), 20, 0.15, 0)
+    return up, np.flipud(up)
+
+
+def filter2d(img, kernel):
+    """cv2.filter2D(img, cv2.CV_64F, kernel) (scripts/main_gabordetect.py:109,132): correlation,
+    anchor = kernel centre, border reflect-101 (= scipy 'mirror')."""
+    return ndimage.correlate(np.asarray(img, dtype=np.float64), np.asarray(kernel, dtype=np.float64), mode="mirror")
+
+
+def _aa_weights(in_size, out_size):
+    """Rows of (first input index, weights) of aten's antialiased bilinear resize along one axis
+    (ATen/native/cpu/UpSampleKernel.cpp, _compute_indices_weights_aa with the triangle filter)."""
+    scale = in_size / out_size
+    support = scale if scale >= 1.0 else 1.0
+    invscale = 1.0 / scale if scale >= 1.0 else 1.0
+    rows = []
+    for i in range(out_size):
+        center = scale * (i + 0.5)
+        xmin = max(int(center - support + 0.5), 0)
+        xsize = min(int(center + support + 0.5), in_size) - xmin
+        w = np.array([max(0.0, 1.0 - abs((j + xmin - center + 0.5) * invscale)) for j in range(xsize)])
+        rows.append((xmin, w / w.sum()))
+    return rows
+
+
+def resize_bilinear_aa(img, out_h, out_w):
+    """torch.nn.functional.interpolate(img[None, None], (out_h, out_w), mode='bilinear',
+    align_corners=False, antialias=True)[0, 0]: horizontal pass, then vertical pass."""
+    img = np.asarray(img, dtype=np.float64)
+    h, w = img.shape
+    tmp = np.empty((h, out_w))
+    for j, (x0, wt) in enumerate(_aa_weights(w, out_w)):
+        tmp[:, j] = img[:, x0:x0 + len(wt)] @ wt
+    out = np.empty((out_h, out_w))
+    for i, (y0, wt) in enumerate(_aa_weights(h, out_h)):
+        out[i] = wt @ tmp[y0:y0 + len(wt)]
+    return out
+
+
+def binning(image, ft, fx):
+    """improcess.py:395-420: transforms.Resize((int(H*fx), int(W*ft))) of ToTensor()(image).  A bool
+    image (the mask, scripts/main_gabordetect.py:163) is interpolated as float32 0/1 and cast back
+    to bool, i.e. True wherever any True pixel has non-zero weight."""
+    image = np.asarray(image)
+    oh, ow = int(image.shape[0] * fx), int(image.shape[1] * ft)
+    if image.dtype == bool:
+        return resize_bilinear_aa(image.astype(np.float64), oh, ow) != 0
+    return resize_bilinear_aa(image, oh, ow)
+
+
+def apply_smooth_mask(array, mask, sigma=1.5):
+    """improcess.py:423-454: the Gaussian-smoothed mask is computed but NOT used; the product is with
+    the raw mask (:452)."""
+    return array * mask
+
+
+def gabor_mask_pipeline(trf_fk, fs, dx, selected_channels, c0=1500., threshold=9100., threshold2=150.):
+    """scripts/main_gabordetect.py:78-166 without the plots."""
+    image = trace2image(trf_fk)
+    theta_c0 = angle_fromspeed(c0, fs, dx, selected_channels)
+    imagebin = binning(image, 1 / 10, 1 / 10)
+    up, down = gabor_filt_design(theta_c0)
+    fimage = filter2d(imagebin, up) + filter2d(imagebin, down)
+    binary = fimage > threshold
+    score = filter2d(binary.astype(float), up) + filter2d(binary.astype(float), down)
+    mask = score > threshold2
+    mask_sparse = binning(mask, 10, 10)
+    masked_tr = apply_smooth_mask(np.asarray(trf_fk, dtype=np.float64), mask_sparse)
+    return {"image": image, "imagebin": imagebin, "fimage": fimage, "binary": binary, "score": score,
+            "mask": mask, "mask_sparse": mask_sparse, "masked_tr": masked_tr}
+
+
 def synth_block(nx, ns, fs=200.0, dx=2.0419046878814697, step=4, seed=1234, n_calls=6,
                 n_waves=40):
     """White noise + slow 'ocean-wave' plane waves + fin-whale notes on hyperbolic moveouts."""

@@ -68,11 +68,11 @@ class COO:
 def _install_stubs():
     from oracle.d4w_oracle import librosa_stft
 
-    for name in ["h5py", "wget", "dask", "dask.array", "nptdms", "xarray", "cv2",
-                 "torchvision", "torchvision.transforms", "skimage", "skimage.transform",
+    for name in ["h5py", "wget", "dask", "dask.array", "nptdms", "xarray", "skimage", "skimage.transform",
                  "pyproj", "tqdm"]:
         if name not in sys.modules:
             sys.modules[name] = MagicMock(name=name)
+    _install_image_shims()
     # tqdm must be transparent: `for i in tqdm(range(n))`
     tq = types.ModuleType("tqdm")
     tq.tqdm = lambda it=None, *a, **k: it
@@ -88,6 +88,51 @@ def _install_stubs():
 
     import matplotlib
     matplotlib.use("Agg")
+
+
+def _install_image_shims():
+    """cv2 and torchvision.transforms as far as improcess.py's Gabor path touches them
+    (improcess.py:116-123 getGaborKernel, :416-420 ToTensor / Resize; scripts/main_gabordetect.py:
+    109,132 filter2D).  Both packages are absent here: cv2 is the oracle's restatement of OpenCV 4.9
+    (parity unpinned), torchvision's Resize is the call torchvision 0.17.2 itself makes into torch,
+    which IS installed (torch.nn.functional.interpolate, antialias=True)."""
+    from oracle import d4w_oracle as orc
+
+    cv2 = types.ModuleType("cv2")
+    cv2.CV_64F = 6
+    cv2.getGaborKernel = lambda ksize, sigma, theta, lambd, gamma, psi=np.pi * 0.5, ktype=6: \
+        orc.get_gabor_kernel(ksize, sigma, theta, lambd, gamma, psi)
+    cv2.filter2D = lambda src, ddepth, kernel: orc.filter2d(src, kernel)
+    sys.modules["cv2"] = cv2
+
+    import torch
+    import torch.nn.functional as F
+
+    class ToTensor:
+        def __call__(self, pic):                       # torchvision functional.to_tensor for a 2-D ndarray
+            t = torch.from_numpy(np.ascontiguousarray(pic[:, :, None].transpose(2, 0, 1)))
+            return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
+
+    class Resize:
+        def __init__(self, size):
+            self.size = tuple(size)
+
+        def __call__(self, img):                       # functional_tensor.resize, bilinear, antialias=True
+            cast = img.dtype not in (torch.float32, torch.float64)
+            x = img.to(torch.float32) if cast else img
+            y = F.interpolate(x[None], size=self.size, mode="bilinear", align_corners=False, antialias=True)[0]
+            if cast:
+                if img.dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
+                    y = torch.round(y)
+                y = y.to(img.dtype)
+            return y
+
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+    tr.ToTensor, tr.Resize = ToTensor, Resize
+    tv.transforms = tr
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tr
 
 
 def import_reference():

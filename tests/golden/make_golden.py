@@ -125,6 +125,43 @@ def main():
     det["ker_tpl"] = dw.detect.buildkernel_from_template(17., 27., 0.8, FS, 160, 8)
     np.savez_compressed(os.path.join(HERE, "detect_12x2000.npz"), **det)
 
+    # ------------------------------------------------------------------ Gabor image pipeline: 240 x 1600
+    # improcess functions are the reference's own code; cv2 / torchvision underneath are the shims of
+    # oracle/ref_harness.py (cv2 restated, Resize = torch's own interpolate)
+    import io
+    import contextlib
+    nx4, ns4 = 240, 1600
+    sel4 = [0, nx4 * 4, 4]
+    x4 = orc.synth_block(nx4, ns4, fs=FS, dx=DX, step=4, seed=23, n_calls=4, n_waves=6) * 1e9
+    x4 = dw.dsp.bp_filt(x4, FS, 14., 30.)
+    with contextlib.redirect_stdout(io.StringIO()):
+        coo4 = dw.dsp.hybrid_ninf_filter_design((nx4, ns4), sel4, DX, FS, **args_scripts)
+    trf = dw.dsp.fk_filter_sparsefilt(x4, coo4).astype(np.float32)          # stored as float32, fed as float64
+    trf64 = trf.astype(np.float64)
+    img = {"trf_fk": trf, "sel": np.array(sel4), "fs": FS, "dx": DX, "c0": 1500.}
+    img["image"] = dw.improcess.trace2image(trf64)
+    with contextlib.redirect_stdout(io.StringIO()):
+        img["theta_c0"] = dw.improcess.angle_fromspeed(1500., FS, DX, sel4)
+    img["imagebin"] = dw.improcess.binning(img["image"], 1 / 10, 1 / 10)
+    up, down = dw.improcess.gabor_filt_design(img["theta_c0"])
+    img["gab_up"], img["gab_down"] = up, down
+    import cv2                                                                # the shim
+    fimage = cv2.filter2D(img["imagebin"], cv2.CV_64F, up) + cv2.filter2D(img["imagebin"], cv2.CV_64F, down)
+    img["fimage"] = fimage
+    img["threshold"] = 0.5 * fimage.max()
+    binary = fimage > img["threshold"]
+    score = cv2.filter2D(binary.astype(float), cv2.CV_64F, up) + cv2.filter2D(binary.astype(float), cv2.CV_64F, down)
+    img["score"] = score
+    img["threshold2"] = 0.3 * score.max()
+    mask = score > img["threshold2"]
+    img["mask"] = mask
+    img["smoothed_image"] = dw.improcess.apply_smooth_mask(img["imagebin"], mask)
+    img["mask_sparse"] = dw.improcess.binning(mask, 10, 10)
+    assert np.array_equal(dw.improcess.apply_smooth_mask(trf64, img["mask_sparse"]), trf64 * img["mask_sparse"])
+    img["scale_pixels"] = dw.improcess.scale_pixels(trf64[:4])
+    img["image"] = img["image"].astype(np.float32)                            # fixture size; 6e-8 relative
+    np.savez_compressed(os.path.join(HERE, "image_240x1600.npz"), **img)
+
     # ------------------------------------------------------------------ reference's own pinned vectors
     # tests/test_dsp.py:85-88 (taper) and :136-141 (snr) -- literal values from the reference tests.
     lit = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=float)
