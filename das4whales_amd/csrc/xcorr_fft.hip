@@ -134,19 +134,35 @@ __device__ __forceinline__ void xf_st(float4* p, c2 v) {
     *p = make_float4(v2_x(v.re), v2_y(v.re), v2_x(v.im), v2_y(v.im));
 }
 
-template <int NT>
-__global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
+// FUSED (two templates off ONE read and ONE forward transform of the block): 256 threads; waves 0-1 run
+// the forward stages into `buf`, then all four waves read their middle-stage groups of the block spectrum,
+// and waves 0-1 / 2-3 carry template 0 / 1 through pair op and inverse stages -- template 0 in a second
+// row buffer, template 1 in place in `buf` (every item owns its two groups, and a barrier separates the
+// last read of the spectrum from the first write).  Same registers and code size as the one-template
+// kernel, same 8 waves per CU (two 76 KiB workgroups), 3 instead of 4 transforms per row block and
+// 12 instead of 16 bytes of HBM traffic per sample.
+template <int NT, bool FUSED>
+__global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
                                                                   int ns, const float* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1) {
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
     D4W_DYN_LDS(smem_raw);
     float4* buf = reinterpret_cast<float4*>(smem_raw);          // [ROWP] block spectra of both rows, then each template's correlation
-    float2* tw1 = reinterpret_cast<float2*>(buf + ROWP);        // [M1]
+    float2* tw1 = reinterpret_cast<float2*>(buf + (FUSED ? 2 : 1) * ROWP);        // [M1]
     float2* tw2 = tw1 + M1;                                     // [NB][NC]
-    const int tid = threadIdx.x;
-    tw1[tid] = T.tw1[tid];
-    tw2[tid] = T.tw2[tid];
+#ifdef D4W_EMU
+    const int tsel = FUSED ? (int)(threadIdx.x >> 7) : 0;        // template carried by this half of the workgroup
+#else
+    const int tsel = FUSED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
+#endif
+    const int tid = FUSED ? (int)(threadIdx.x & (kXfThreads - 1)) : (int)threadIdx.x;
+    const bool fwd = !FUSED || tsel == 0;                         // this wave runs the forward stages
+    float4* mine = FUSED ? (tsel ? buf : buf + ROWP) : buf;       // row buffer of this wave's template
+    if (fwd) {
+        tw1[tid] = T.tw1[tid];
+        tw2[tid] = T.tw2[tid];
+    }
     const int rowA = 2 * blockIdx.y;
     const bool hasB = rowA + 1 < nx;
     const int rowB = hasB ? rowA + 1 : rowA;
@@ -196,7 +212,8 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
                 }
                 return v;
             };
-            if (interior) {
+            if (!fwd) {
+            } else if (interior) {
                 const float2* pa = reinterpret_cast<const float2*>(xa + k0) + j1;
                 const float2* pb = reinterpret_cast<const float2*>(xb + k0) + j1;
                 const v2f mu2 = v2_make(mua, mub);
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
         float2 pw[NA];
         xf_pw_load<NA>(T.twa, tid, pw);                             // in flight together with the samples
         if (t == 0) __syncthreads();                                // twiddle tables visible
-        {
+        if (fwd) {
             const int j1 = tid;
             dftp<NA>(pf);
             static_for<NA>([&](auto aa) {
@@ -227,19 +244,19 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
         // the middle stage's table operands: issued here, in flight across S2
         float2 GA[NC], GB[NC];
         {
-            const float2* gpa = T.gp + (size_t)t * MB + Gi * NC;
-            const float2* gpb = T.gp + (size_t)t * MB + PG * NC;
+            const float2* gpa = T.gp + (size_t)(FUSED ? tsel : t) * MB + Gi * NC;
+            const float2* gpb = T.gp + (size_t)(FUSED ? tsel : t) * MB + PG * NC;
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
                 GA[d] = gpa[d];
                 GB[d] = gpb[d];
             });
         }
-        const float gny = T.gn[t];
+        const float gny = T.gn[FUSED ? tsel : t];
         const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];       // W_B^f, f = f0(G) + 256 d: W_B^(256 d) are literals
         lds_barrier();
         // ---------------- S2: radix NB in place, x W_M1^(j2 b')
-        {
+        if (fwd) {
             const int g = tid >> 3, j2 = tid & 7;
             c2 v[NB];
             static_for<NB>([&](auto bb) {
@@ -270,6 +287,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
             dftp<NC>(a);
             dftp<NC>(b);
         }
+        if (FUSED) lds_barrier();                                   // every read of the spectrum precedes the in-place writes
         {
             c2 ra[NC], rb[NC];
             if (!selfitem) {
@@ -298,8 +316,8 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
             }
             idftp<NC>(ra);
             idftp<NC>(rb);
-            float4* oa = buf + xf_ad(Gi * NC);
-            float4* ob = buf + xf_ad(PG * NC);
+            float4* oa = mine + xf_ad(Gi * NC);
+            float4* ob = mine + xf_ad(PG * NC);
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
                 xf_st(oa + d, ra[d]);
@@ -315,13 +333,13 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
             c2 v[NB];
             static_for<NB>([&](auto bb) {
                 constexpr int bq = decltype(bb)::value;
-                const c2 xv = xf_ld(buf + xf_ad(g * M1 + j2 + bq * NC));
+                const c2 xv = xf_ld(mine + xf_ad(g * M1 + j2 + bq * NC));
                 v[bq] = (bq == 0) ? xv : c2_mulwc(xv, tw2[bq * NC + j2]);
             });
             idftp<NB>(v);
             static_for<NB>([&](auto bb) {
                 constexpr int bq = decltype(bb)::value;
-                xf_st(buf + xf_ad(g * M1 + j2 + bq * NC), v[bq]);
+                xf_st(mine + xf_ad(g * M1 + j2 + bq * NC), v[bq]);
             });
         }
         lds_barrier();
@@ -331,12 +349,12 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_blocks(XfTables T, co
             c2 v[NA];
             static_for<NA>([&](auto aa) {
                 constexpr int aq = decltype(aa)::value;
-                const c2 xv = xf_ld(buf + xf_ad(j1 + aq * M1));
+                const c2 xv = xf_ld(mine + xf_ad(j1 + aq * M1));
                 v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pwi[aq]);
             });
             idftp<NA>(v);
-            float* ya = (t == 0 ? y0 : y1) + (size_t)rowA * ns;
-            float* yb = (t == 0 ? y0 : y1) + (size_t)rowB * ns;
+            float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * ns;
+            float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * ns;
             if (interior) {
                 float2* oa = reinterpret_cast<float2*>(ya + k0) + j1;
                 float2* ob = reinterpret_cast<float2*>(yb + k0) + j1;
@@ -636,7 +654,8 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
 #ifndef D4W_EMU
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
 #endif
@@ -657,11 +676,18 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
         D4W_LAUNCH(xcorr_fft_tpair, dim3(grid.x, nx), dim3(kXfThreads), lds, stream, T, x, ns, mean, maxabs, y0, y1);
         return D4W_OK;
     }
+    // both templates off one read and one forward transform of every block (D4W_XF_FUSED=0: one launch per template)
+    static const int fusedmode = [] { const char* v = getenv("D4W_XF_FUSED"); return v ? atoi(v) : 1; }();
+    if (ntpl == 2 && fusedmode) {
+        const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+        D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1);
+        return D4W_OK;
+    }
     for (int t = 0; t < ntpl; ++t) {
         XfTables Tt = T;
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
-        D4W_LAUNCH(xcorr_fft_blocks<1>, grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
+        D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
                    t == 0 ? y0 : y1, (float*)nullptr);
     }
     return D4W_OK;
