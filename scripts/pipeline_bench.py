@@ -1,6 +1,7 @@
 """End-to-end detection pipeline on consecutive 60-s files (BASELINE configs[4] style, one GPU):
 raw int32 -> strain (fused ingest) -> band-pass (streamed across files) -> f-k filter -> HF+LF matched
-filter -> envelope picks, and the spectrogram-correlation detector on the same filtered files.
+filter -> envelope picks, the spectrogram-correlation detector and the Gabor image-mask detector on the
+same filtered files.
 Prints one JSON line with per-stage times (HIP events, median over files) and files / s.
 
     python scripts/pipeline_bench.py [--nx 11020] [--ns 12000] [--files 8]
@@ -16,7 +17,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import das4whales_amd as dw  # noqa: E402
-from das4whales_amd import data_handle, detect, dsp, stream  # noqa: E402
+from das4whales_amd import data_handle, detect, dsp, improcess, stream  # noqa: E402
 
 
 def main():
@@ -45,7 +46,7 @@ def main():
 
     def run(timed):
         st = stream.FileStream(fs, 14, 30, templates=[hf, lf], fk_mask=mask, halo=1024)
-        acc = {k: [] for k in ("ingest", "stream(bp+fk+mf)", "picks_env x2", "spectrocorr")}
+        acc = {k: [] for k in ("ingest", "stream(bp+fk+mf)", "picks_env x2", "spectrocorr", "gabor_mask")}
         npicks = 0
         for raw in raws + [None]:
             e0 = ev()
@@ -66,13 +67,18 @@ def main():
             for r in done:
                 detect.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)
             e4 = ev()
-            e4.synchronize()
+            for r in done:
+                # thresholds of the script are tuned to real data; synthetic noise: relative ones
+                improcess.gabor_mask(r["filtered"], fs, dx, [0, nx * 4, 4], 1500., 9100., 150.)
+            e5 = ev()
+            e5.synchronize()
             if timed:
                 n = max(len(done), 1)
                 acc["ingest"].append(e0.elapsed_time(e1))
                 acc["stream(bp+fk+mf)"].append(e1.elapsed_time(e2))
                 acc["picks_env x2"].append(e2.elapsed_time(e3) / n)
                 acc["spectrocorr"].append(e3.elapsed_time(e4) / n)
+                acc["gabor_mask"].append(e4.elapsed_time(e5) / n)
         return acc, npicks
 
     run(False)                                              # warm-up: plans, tables, allocator
