@@ -520,7 +520,7 @@ static int make_axis(d4w_fk_plan* pl, int L, AxisDesc* ax, std::vector<int>* p2f
     std::vector<int> rad;
     if (forced) rad = *forced;
     else if (!factor_radices(L, rad))
-        return fail(D4W_EINVAL, "length %d has a prime factor > 31 (Bluestein fallback not implemented)", L);
+        return fail(D4W_EINVAL, "length %d has a prime factor > 31 (Bluestein fallback not implemented; dsp.supported_length(n) gives the nearest shorter supported length)", L);
     ax->L = L;
     ax->nstage = (L == 1) ? 0 : (int)rad.size();
     for (int i = 0; i < kMaxStages; ++i) ax->radix[i] = (i < (int)rad.size() && L > 1) ? rad[i] : 1;

@@ -618,6 +618,344 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two templates, FOUR radix stages (MB = 8 x 8 x 8 x 4), 512 threads: the kernel the two-template
+// matched filter runs.  Same algebra as xcorr_fft_blocks<1, true> (one read and ONE forward transform of
+// a block of two packed rows, waves 0-3 / 4-7 carry template 0 / 1 through pair op and inverse stages,
+// template 1 in place in the spectrum buffer, template 0 in a second row buffer), but every stage has
+// 256 items of radix <= 8: ~100 VGPRs instead of 212-233, so that two 76-KiB workgroups put 16 waves on
+// a CU instead of 8 -- the three-stage kernel is bound by what its 8 waves can overlap, not by VALU
+// issue or HBM bandwidth.  One more LDS round trip per direction.
+//   position e = d0 256 + d1 32 + d2 4 + d3 holds frequency d0 + 8 d1 + 64 d2 + 512 d3 after the forward
+//   stages (DIF, digit-reversed in place); groups of 4 consecutive positions; Hermitian partner of group
+//   (d0, d1, d2): (8-d0, 7-d1, 7-d2) | d0 = 0: (0, 8-d1, 7-d2) | d0 = d1 = 0: (0, 0, 8-d2); groups 0 and 4
+//   are their own partners (item 255).
+// ---------------------------------------------------------------------------------------------
+constexpr int kX4Items = 256;                      // items per stage = threads per template half
+constexpr int kX4NG = kXfMB / 4;                   // 512 groups of 4 positions
+constexpr int kX4RowP = kXfMB + kXfMB / 8;         // one pad element per 8 positions
+
+__host__ __device__ constexpr int x4_ad(int e) { return e + (e >> 3); }
+__host__ __device__ constexpr int x4_freq(int e) { return (e >> 8) + 8 * ((e >> 5) & 7) + 64 * ((e >> 2) & 7) + 512 * (e & 3); }
+__host__ __device__ constexpr int x4_partner(int G) {
+    const int d0 = G >> 6, d1 = (G >> 3) & 7, d2 = G & 7;
+    if (d0) return ((8 - d0) << 6) | ((7 - d1) << 3) | (7 - d2);
+    if (d1) return ((8 - d1) << 3) | (7 - d2);
+    if (d2) return 8 - d2;
+    return 0;
+}
+
+struct X4Tables {
+    const float2* gp;     // [2][MB]   conj(T_t(f)) / 4 at position e (f = x4_freq(e))
+    const float* gn;      // [2]       conj(T_t(MB)) / 4 (real)
+    const float2* tw1;    // [8][256]  W_MB^(j q)
+    const float2* tw2;    // [8][32]   W_256^(j q)
+    const float2* tw3;    // [8][4]    W_32^(j q)
+    const float2* wg;     // [512]     W_B^(frequency of the group's first position)
+    const int2* pairs;    // [256]     (Gi, PG) of every middle-stage item; item 255 = the self-paired groups (0, 4)
+};
+
+__global__ __launch_bounds__(256) void xcf_tables4(const float* __restrict__ taps, int ltaps, int len0, int len1,
+                                                   float2* __restrict__ gp, float* __restrict__ gn,
+                                                   float2* __restrict__ tw1, float2* __restrict__ tw2,
+                                                   float2* __restrict__ tw3, float2* __restrict__ wg,
+                                                   int2* __restrict__ pairs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * kXfMB) {
+        const int t = i / kXfMB, e = i - t * kXfMB;
+        const int f = x4_freq(e), L = t ? len1 : len0;
+        const float* tp = taps + (size_t)t * ltaps;
+        double re = 0.0, im = 0.0;
+        for (int n = 0; n < L; ++n) {
+            float sn, cs;
+            sincospif(2.0f * (float)((f * n) & (kXfB - 1)) / (float)kXfB, &sn, &cs);
+            re += (double)tp[n] * cs;
+            im += (double)tp[n] * sn;
+        }
+        gp[i] = make_float2((float)(0.25 * re), (float)(0.25 * im));
+        const int q = e >> 8, j = e & 255;                       // stage-1 twiddles W_MB^(j q)
+        float sn, cs;
+        if (t == 0) {
+            sincospif(-2.0f * (float)((q * j) % kXfMB) / (float)kXfMB, &sn, &cs);
+            tw1[e] = make_float2(cs, sn);
+        }
+    }
+    if (i < 2) {
+        const int L = i ? len1 : len0;
+        double sacc = 0.0;
+        for (int n = 0; n < L; ++n) sacc += (n & 1) ? -(double)taps[(size_t)i * ltaps + n] : (double)taps[(size_t)i * ltaps + n];
+        gn[i] = (float)(0.25 * sacc);
+    }
+    if (i < 256) {
+        const int q = i >> 5, j = i & 31;
+        float sn, cs;
+        sincospif(-2.0f * (float)((q * j) % 256) / 256.0f, &sn, &cs);
+        tw2[i] = make_float2(cs, sn);
+    }
+    if (i < 32) {
+        const int q = i >> 2, j = i & 3;
+        float sn, cs;
+        sincospif(-2.0f * (float)((q * j) % 32) / 32.0f, &sn, &cs);
+        tw3[i] = make_float2(cs, sn);
+    }
+    if (i < kX4NG) {
+        float sn, cs;
+        sincospif(-2.0f * (float)x4_freq(4 * i) / (float)kXfB, &sn, &cs);
+        wg[i] = make_float2(cs, sn);
+    }
+    if (i == 0) {
+        int n = 0;
+        for (int G = 0; G < kX4NG; ++G) {
+            const int PG = x4_partner(G);
+            if (G < PG) pairs[n++] = make_int2(G, PG);
+        }
+        pairs[kX4Items - 1] = make_int2(0, 4);
+    }
+}
+
+__global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, const float* __restrict__ x, int nx, int ns,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ maxabs,
+                                                                    float* __restrict__ y0, float* __restrict__ y1) {
+    constexpr int MB = kXfMB, ROWP = kX4RowP;
+    D4W_DYN_LDS(smem_raw);
+    float4* buf = reinterpret_cast<float4*>(smem_raw);            // [ROWP] block spectrum, then template 1's correlation
+    float2* tw2 = reinterpret_cast<float2*>(buf + 2 * ROWP);      // [8][32]
+    float2* tw3 = tw2 + 256;                                      // [8][4]
+#ifdef D4W_EMU
+    const int tsel = (int)(threadIdx.x >> 8);
+#else
+    const int tsel = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+#endif
+    const int tid = (int)(threadIdx.x & (kX4Items - 1));
+    const bool fwd = tsel == 0;
+    float4* mine = tsel ? buf : buf + ROWP;
+    if (fwd) {
+        tw2[tid] = T.tw2[tid];
+        if (tid < 32) tw3[tid] = T.tw3[tid];
+    }
+    const int rowA = 2 * blockIdx.y;
+    const bool hasB = rowA + 1 < nx;
+    const int rowB = hasB ? rowA + 1 : rowA;
+    const int k0 = blockIdx.x * kXfStep;
+    const float* xa = x + (size_t)rowA * ns;
+    const float* xb = x + (size_t)rowB * ns;
+    const float mua = mean ? mean[rowA] : 0.f, mub = mean ? mean[rowB] : 0.f;
+    float ga_ = 1.f, gb_ = 1.f;
+    if (maxabs) {
+        const float a = maxabs[rowA], b = maxabs[rowB];
+        ga_ = (a > 0.f) ? 1.0f / a : 0.f;
+        gb_ = (b > 0.f) ? 1.0f / b : 0.f;
+    }
+    const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
+    const bool veca = ((((size_t)rowA * ns + k0) & 1) == 0), vecb = ((((size_t)rowB * ns + k0) & 1) == 0);
+    const bool interior = (k0 + kXfB <= ns) && veca && vecb;
+    // ---------------- S1: radix 8 on the packed samples z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = tid + 256 q
+    c2 pf[8];
+    float2 pw[8];
+    if (fwd) {
+        auto fetch = [&](const float* xr, float mu, bool vec, int i) -> float2 {
+            float2 v = make_float2(0.f, 0.f);
+            if (vec && i + 1 < ns) {
+                v = *reinterpret_cast<const float2*>(xr + i);
+                v.x -= mu;
+                v.y -= mu;
+            } else {
+                if (i < ns) v.x = xr[i] - mu;
+                if (i + 1 < ns) v.y = xr[i + 1] - mu;
+            }
+            return v;
+        };
+        if (interior) {
+            const float2* pa = reinterpret_cast<const float2*>(xa + k0) + tid;
+            const float2* pb = reinterpret_cast<const float2*>(xb + k0) + tid;
+            const v2f mu2 = v2_make(mua, mub);
+            static_for<8>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                const float2 va = pa[q * 256], vb = pb[q * 256];
+                pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+            });
+        } else {
+            static_for<8>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                const int i = k0 + 2 * (tid + q * 256);
+                pf[q] = c2_make(fetch(xa, mua, veca, i), fetch(xb, mub, vecb, i));
+            });
+        }
+        static_for<7>([&](auto qq) {
+            constexpr int q = decltype(qq)::value + 1;
+            pw[q] = T.tw1[q * 256 + tid];
+        });
+    }
+    __syncthreads();                                              // LDS twiddle tables visible
+    if (fwd) {
+        dftp<8>(pf);
+        static_for<8>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            xf_st(buf + x4_ad(tid + q * 256), (q == 0) ? pf[0] : c2_mulw(pf[q], pw[q]));
+        });
+    }
+    // the middle stage's table operands: issued here, in flight across S2 / S3
+    const int2 grp = T.pairs[tid];
+    const int Gi = grp.x, PG = grp.y;
+    const bool selfitem = (tid == kX4Items - 1);
+    float2 GA[4], GB[4];
+    {
+        const float2* gpa = T.gp + (size_t)tsel * MB + Gi * 4;
+        const float2* gpb = T.gp + (size_t)tsel * MB + PG * 4;
+        static_for<4>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;
+            GA[d] = gpa[d];
+            GB[d] = gpb[d];
+        });
+    }
+    const float gny = T.gn[tsel];
+    const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];
+    lds_barrier();
+    // ---------------- S2: radix 8 inside every block of 256, x W_256^(j q)
+    if (fwd) {
+        const int e0 = (tid >> 5) * 256 + (tid & 31), j = tid & 31;
+        c2 v[8];
+        static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; v[q] = xf_ld(buf + x4_ad(e0 + q * 32)); });
+        dftp<8>(v);
+        static_for<8>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            xf_st(buf + x4_ad(e0 + q * 32), (q == 0) ? v[0] : c2_mulw(v[q], tw2[q * 32 + j]));
+        });
+    }
+    lds_barrier();
+    // ---------------- S3: radix 8 inside every block of 32, x W_32^(j q)
+    if (fwd) {
+        const int e0 = (tid >> 2) * 32 + (tid & 3), j = tid & 3;
+        c2 v[8];
+        static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; v[q] = xf_ld(buf + x4_ad(e0 + q * 4)); });
+        dftp<8>(v);
+        static_for<8>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            xf_st(buf + x4_ad(e0 + q * 4), (q == 0) ? v[0] : c2_mulw(v[q], tw3[q * 4 + j]));
+        });
+    }
+    lds_barrier();
+    // ---------------- MID: radix 4 on a group and its Hermitian partner group, pair op, inverse radix 4
+    c2 a[4], b[4];
+    static_for<4>([&](auto dd) {
+        constexpr int d = decltype(dd)::value;
+        a[d] = xf_ld(buf + x4_ad(Gi * 4 + d));
+        b[d] = xf_ld(buf + x4_ad(PG * 4 + d));
+    });
+    dftp<4>(a);
+    dftp<4>(b);
+    lds_barrier();                                                // every read of the spectrum precedes the in-place writes
+    {
+        c2 ra[4], rb[4];
+        if (!selfitem) {
+            static_for<4>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pn = 3 - d;
+                xf_pair(a[d], b[pn], rot_const<d, 8>(wa0), GA[d], GB[pn], ra[d], rb[pn]);
+            });
+        } else {
+            // group 0 (array a): partner digit (4 - d) % 4, f = 0 pairs with the Nyquist bin; group 4 (array b): 3 - d
+            static_for<3>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pz = (4 - d) % 4;
+                const float2 gm = (d == 0) ? make_float2(gny, 0.f) : GA[pz];
+                c2 na;
+                xf_pair(a[d], a[pz], rot_const<d, 8>(wa0), GA[d], gm, na, ra[pz]);
+                if constexpr (pz != d) ra[d] = na;
+            });
+            static_for<2>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pn = 3 - d;
+                xf_pair(b[d], b[pn], rot_const<d, 8>(wb0), GB[d], GB[pn], rb[d], rb[pn]);
+            });
+        }
+        idftp<4>(ra);
+        idftp<4>(rb);
+        static_for<4>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;
+            xf_st(mine + x4_ad(Gi * 4 + d), ra[d]);
+            xf_st(mine + x4_ad(PG * 4 + d), rb[d]);
+        });
+    }
+    lds_barrier();
+    float2 pwi[8];
+    static_for<7>([&](auto qq) {
+        constexpr int q = decltype(qq)::value + 1;
+        pwi[q] = T.tw1[q * 256 + tid];                           // for S1', in flight across S3' / S2'
+    });
+    // ---------------- S3', S2': inverse radix 8
+    {
+        const int e0 = (tid >> 2) * 32 + (tid & 3), j = tid & 3;
+        c2 v[8];
+        static_for<8>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const c2 xv = xf_ld(mine + x4_ad(e0 + q * 4));
+            v[q] = (q == 0) ? xv : c2_mulwc(xv, tw3[q * 4 + j]);
+        });
+        idftp<8>(v);
+        static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; xf_st(mine + x4_ad(e0 + q * 4), v[q]); });
+    }
+    lds_barrier();
+    {
+        const int e0 = (tid >> 5) * 256 + (tid & 31), j = tid & 31;
+        c2 v[8];
+        static_for<8>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const c2 xv = xf_ld(mine + x4_ad(e0 + q * 32));
+            v[q] = (q == 0) ? xv : c2_mulwc(xv, tw2[q * 32 + j]);
+        });
+        idftp<8>(v);
+        static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; xf_st(mine + x4_ad(e0 + q * 32), v[q]); });
+    }
+    lds_barrier();
+    // ---------------- S1': inverse radix 8 -> lags k0 + 2m, k0 + 2m + 1 (m = tid + 256 q), the first kXfStep of them
+    {
+        c2 v[8];
+        static_for<8>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const c2 xv = xf_ld(mine + x4_ad(tid + q * 256));
+            v[q] = (q == 0) ? xv : c2_mulwc(xv, pwi[q]);
+        });
+        idftp<8>(v);
+        float* ya = (tsel == 0 ? y0 : y1) + (size_t)rowA * ns;
+        float* yb = (tsel == 0 ? y0 : y1) + (size_t)rowB * ns;
+        if (interior) {
+            float2* oa = reinterpret_cast<float2*>(ya + k0) + tid;
+            float2* ob = reinterpret_cast<float2*>(yb + k0) + tid;
+            static_for<8>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                if (2 * (tid + q * 256) < kXfStep) {
+                    const c2 o = c2_scale2(v[q], sc);
+                    oa[q * 256] = c2_a(o);
+                    if (hasB) ob[q * 256] = c2_b(o);
+                }
+            });
+        } else {
+            auto put = [&](float* yr, bool vec, int k, float2 o) {
+                if (k >= ns) return;
+                if (vec && k + 1 < ns) *reinterpret_cast<float2*>(yr + k) = o;
+                else {
+                    yr[k] = o.x;
+                    if (k + 1 < ns) yr[k + 1] = o.y;
+                }
+            };
+            static_for<8>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                const int m = tid + q * 256;
+                if (2 * m < kXfStep) {
+                    const c2 o = c2_scale2(v[q], sc);
+                    put(ya, veca, k0 + 2 * m, c2_a(o));
+                    if (hasB) put(yb, vecb, k0 + 2 * m, c2_b(o));
+                }
+            });
+        }
+    }
+}
+
+// extra tables of the four-stage kernel: gp [2][MB] + tw1 [8][256] + tw2 [8][32] + tw3 [8][4] + wg [512] (float2), pairs [256] (int2)
+constexpr size_t kX4WsFloats = 2 * (2 * kXfMB + 8 * 256 + 8 * 32 + 8 * 4 + kX4NG + kX4Items);
+
 constexpr size_t kXfWsFloats = 2 * 2 * kXfMB + 8 + 2 * kXfM1 * 2 + 2 * kXfNG + 2 * kXfNA * kXfM1;
 
 }  // namespace d4w
@@ -628,7 +966,7 @@ extern "C" {
 
 int d4w_xcorr_fft_max_support(void) { return kXfPad + 1; }
 
-size_t d4w_xcorr_fft_ws_bytes(void) { return kXfWsFloats * sizeof(float); }
+size_t d4w_xcorr_fft_ws_bytes(void) { return (kXfWsFloats + kX4WsFloats) * sizeof(float); }
 
 int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
                       int ntpl, int ltaps, int len0, int len1, float* y0, float* y1, void* ws, void* stream) {
@@ -676,8 +1014,32 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
         D4W_LAUNCH(xcorr_fft_tpair, dim3(grid.x, nx), dim3(kXfThreads), lds, stream, T, x, ns, mean, maxabs, y0, y1);
         return D4W_OK;
     }
-    // both templates off one read and one forward transform of every block (D4W_XF_FUSED=0: one launch per template)
+    // both templates off one read and one forward transform of every block
+    // (D4W_XF_FUSED: 1 = four-stage 512-thread kernel [default], 2 = three-stage 256-thread kernel, 0 = one launch per template)
     static const int fusedmode = [] { const char* v = getenv("D4W_XF_FUSED"); return v ? atoi(v) : 1; }();
+    if (ntpl == 2 && fusedmode == 1) {                            // four-stage, 512-thread kernel (default)
+        float2* f4 = reinterpret_cast<float2*>(w + kXfWsFloats);
+        X4Tables Q;
+        float2* gp4 = f4;
+        float2* q1 = gp4 + 2 * kXfMB;
+        float2* q2 = q1 + 8 * 256;
+        float2* q3 = q2 + 8 * 32;
+        float2* qg = q3 + 8 * 4;
+        int2* qp = reinterpret_cast<int2*>(qg + kX4NG);
+        Q.gp = gp4; Q.gn = gn; Q.tw1 = q1; Q.tw2 = q2; Q.tw3 = q3; Q.wg = qg; Q.pairs = qp;
+        D4W_LAUNCH(xcf_tables4, dim3(ceil_div(2 * kXfMB, 256)), dim3(256), 0, stream, taps, ltaps, len0, len1, gp4, gn, q1, q2,
+                   q3, qg, qp);
+        const size_t lds4 = 2 * (size_t)kX4RowP * sizeof(float4) + (256 + 32) * sizeof(float2);
+#ifndef D4W_EMU
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            attr4 = true;
+        }
+#endif
+        D4W_LAUNCH(xcorr_fft_fused4, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1);
+        return D4W_OK;
+    }
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1);

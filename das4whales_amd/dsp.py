@@ -116,6 +116,22 @@ class FkPlan:
             pass
 
 
+def supported_length(n, even=False):
+    """Largest length <= n the transforms accept: every prime factor <= 31 (the mixed-radix kernels
+    carry radices up to 31; there is no Bluestein fallback), optionally even.  Use it to trim a channel
+    selection or a record, e.g. nx = 4001 (prime) -> 4000."""
+    n = int(n)
+    while n > 1:
+        m = n
+        for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
+            while m % p == 0:
+                m //= p
+        if m == 1 and (not even or n % 2 == 0):
+            return n
+        n -= 1
+    return max(n, 1)
+
+
 _plans = {}
 _plans_lock = threading.Lock()
 

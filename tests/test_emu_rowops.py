@@ -170,9 +170,12 @@ def xcorr_fft_emu(lib, x, taps_list, normalize=True):
     return ys
 
 
-def test_xcorr_fft_template_pair_kernel(golden):
-    """The one-read two-template kernel (D4W_XF_TPAIR=1; the library reads the switch once per
-    process, hence the subprocess) gives the same correlograms."""
+@pytest.mark.parametrize("switch", [{"D4W_XF_TPAIR": "1"}, {"D4W_XF_FUSED": "2"}, {"D4W_XF_FUSED": "0"}])
+def test_xcorr_fft_template_pair_kernel(golden, switch):
+    """The alternative two-template kernels give the same correlograms as the default four-stage fused
+    one: templates packed through one inverse transform (D4W_XF_TPAIR=1), the three-stage fused kernel
+    (D4W_XF_FUSED=2), one launch per template (D4W_XF_FUSED=0).  The library reads the switches once
+    per process, hence the subprocess."""
     import os
     import subprocess
     import sys
@@ -186,7 +189,7 @@ def test_xcorr_fft_template_pair_kernel(golden):
             "assert t.rel(y1[1], t.orc.shift_xcorr(x[1], np.pad(b, (0, 9001 - 7)))) < 1e-5; print('ok')"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detect_12x2000.npz")))
-    env = dict(os.environ, D4W_XF_TPAIR="1")
+    env = dict(os.environ, **switch)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 

@@ -149,3 +149,13 @@ def test_picks_random_rows(dw):
             for c in range(nx):
                 ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
                 assert np.array_equal(got[c], ref), (ns, thr, c)
+
+
+def test_unsupported_length_is_a_clear_error(dw):
+    """A prime factor > 31 has no kernel (no Bluestein fallback): ValueError naming the remedy."""
+    assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
+    x = np.zeros((37 * 2, 64))
+    with pytest.raises(ValueError, match="supported_length"):
+        dw.dsp.fk_filter_filt(x, np.ones_like(x))
+    nx = dw.dsp.supported_length(74)
+    assert rel(dw.dsp.fk_filter_filt(np.ones((nx, 64)), np.ones((nx, 64))), np.ones((nx, 64))) < TOL
