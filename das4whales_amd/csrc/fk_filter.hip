@@ -48,6 +48,12 @@ struct FkDev {  // kernel argument block (by value)
     const float* nyq;         // [nx pos r] M_h(k, M)
     const int2* pairs;        // pass-B work list (keyA, keyB)
     float scale;              // 1 / (nx * M)
+    // Bluestein form of the c2 sub-transform (C2 has a prime factor > 31): a length-C2 DFT as a circular
+    // convolution of length bs_L = 2^k >= 2 C2 - 1 with the chirp exp(-i pi n^2 / C2); bs_L = 0: off
+    int bs_L;
+    AxisDesc ax_bs;           // the length-bs_L transform
+    const float2* bs_chirp;   // [C2]    exp(-i pi n^2 / C2)
+    const float2* bs_filt;    // [bs_L]  FFT of the conjugate chirp (wrapped) / bs_L, at the DIF positions of ax_bs
 };
 
 }  // namespace d4w
@@ -257,6 +263,53 @@ __global__ __launch_bounds__(kMaxThreads) void fk_passC(FkDev P, float2* __restr
         }
         lds_barrier();
         t = next;
+    }
+}
+
+// pass C when C2 has a prime factor > 31 (Bluestein): the tile holds bs_L >= 2 C2 - 1 rows per column,
+//   a[n] = x[n] w[n] (n < C2, zero above), A = FFT_L(a), A *= FFT_L(conj w wrapped) / L, c = IFFT_L(A),
+//   X[k] = w[k] c[k] (k < C2), w[n] = exp(-i pi n^2 / C2); the inverse transform conjugates w and the filter.
+// Output in NATURAL order (the plan's c2 position -> wavenumber map is the identity).  Exact in the same
+// sense as the other passes (float32 rounding), slower: twice the LDS tile and three transforms per column.
+template <bool INV>
+__global__ __launch_bounds__(kMaxThreads) void fk_passC_bluestein(FkDev P, float2* __restrict__ data, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TC = d.TC, L = P.bs_L;
+    const int nelem = d.C2 * TC, ntile = L * TC;
+    const int ntx = (d.M + TC - 1) / TC;
+    const TwLds tw = tw_stage(P.ax_bs, tile + ntile, tid, nthr);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int q = t / ntx, p0 = (t - q * ntx) * TC;
+        const int ncol = min(TC, d.M - p0);
+        float2* base = data + ((size_t)q * d.C2) * d.M + p0;
+        for (int w = tid; w < ntile; w += nthr) {
+            const int c2 = w / TC, tt = w - c2 * TC;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem && tt < ncol) {
+                const float2 ch = P.bs_chirp[c2];
+                v = INV ? c_mulc(base[(size_t)c2 * d.M + tt], ch) : c_mul(base[(size_t)c2 * d.M + tt], ch);
+            }
+            tile[w] = v;
+        }
+        lds_barrier();
+        lds_fft<false, true, false>(tile, P.ax_bs, tw, TC, TC, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < ntile; w += nthr) {
+            const float2 f = P.bs_filt[w / TC];
+            tile[w] = INV ? c_mulc(tile[w], f) : c_mul(tile[w], f);
+        }
+        lds_barrier();
+        lds_fft<true, true, false>(tile, P.ax_bs, tw, TC, TC, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int c2 = w / TC, tt = w - c2 * TC;
+            if (tt < ncol) {
+                const float2 ch = P.bs_chirp[c2];
+                base[(size_t)c2 * d.M + tt] = INV ? c_mulc(tile[w], ch) : c_mul(tile[w], ch);
+            }
+        }
+        lds_barrier();
     }
 }
 
@@ -520,7 +573,7 @@ static int make_axis(d4w_fk_plan* pl, int L, AxisDesc* ax, std::vector<int>* p2f
     std::vector<int> rad;
     if (forced) rad = *forced;
     else if (!factor_radices(L, rad))
-        return fail(D4W_EINVAL, "length %d has a prime factor > 31 (Bluestein fallback not implemented; dsp.supported_length(n) gives the nearest shorter supported length)", L);
+        return fail(D4W_EINVAL, "length %d has a prime factor > 31 and this axis has no Bluestein form (only the channel axis of the f-k filter has); dsp.supported_length(n) gives the nearest shorter supported length", L);
     ax->L = L;
     ax->nstage = (L == 1) ? 0 : (int)rad.size();
     for (int i = 0; i < kMaxStages; ++i) ax->radix[i] = (i < (int)rad.size() && L > 1) ? rad[i] : 1;
@@ -534,6 +587,35 @@ static int launch_k(K kern, dim3 grid, dim3 blk, size_t lds, void* stream, Args.
     hipLaunchKernelGGL(kern, grid, blk, lds, (hipStream_t)stream, args...);
     D4W_HIP(hipGetLastError());
     return D4W_OK;
+}
+
+// in-place radix-2 FFT (forward sign) of a power-of-two length, double precision: plan-time tables only
+static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
+    const int n = (int)re.size();
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * k), wi = sin(ang * k);
+                const int a = i + k, b = i + k + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+}
+
+// n with every prime factor <= 31 divided out
+static int rough_part(int n) {
+    for (int p = 2; p <= 31; ++p)
+        while (n % p == 0) n /= p;
+    return n;
 }
 
 static int largest_divisor_le(int n, int lim) {
@@ -603,8 +685,22 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         C2 = largest_divisor_le(nx, kMaxTile / 8);
         C1 = nx / C2;
     }
+    // a prime factor > 31 of nx goes into C2, whose sub-transform then runs as a Bluestein convolution of
+    // length bs_L (pass C); C1 keeps the smooth part
+    int bs_L = 0;
+    if (!fast && rough_part(nx) > 1) {
+        C2 = rough_part(nx);
+        C1 = nx / C2;
+        for (int f = 2; f <= 31 && (long)C1 * N1 > kMaxTile; ++f)      // pass A's tile must hold C1 x N1 columns
+            while (C1 % f == 0 && (long)C1 * N1 > kMaxTile && 2L * C2 * f - 1 <= kMaxTile) { C2 *= f; C1 /= f; }
+        bs_L = 1;
+        while (bs_L < 2 * C2 - 1) bs_L *= 2;
+        if (bs_L > kMaxTile)
+            return fail(D4W_EINVAL, "nx = %d: the part with prime factors > 31 (%d) is too long for the Bluestein tile (limit %d); "
+                        "dsp.supported_length(n) gives the nearest shorter length with a direct kernel", nx, C2, kMaxTile / 2);
+    }
     int TC = o[5] > 0 ? o[5] : 16;
-    while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
+    while (TC > 1 && (long)(bs_L ? bs_L : C2) * TC > kMaxTile) TC /= 2;
     int TA = o[4] > 0 ? o[4] : 16;
     while (TA > 1 && (long)C1 * N1 * TA > kMaxTile) TA /= 2;
     std::vector<int> r_c1, r_c2, r_n1, r_n2;
@@ -613,7 +709,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         TA = fast->TA; TC = fast->TC;
         r_c1 = {C1}; r_c2 = {fast->C2A, fast->C2B}; r_n1 = {N1}; r_n2 = {fast->NA, fast->NB, fast->NC};
     }
-    if (!fast && ((long)C2 * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * N2 > kMaxTile))
+    if (!fast && ((long)(bs_L ? bs_L : C2) * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * N2 > kMaxTile))
         return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling (C1=%d C2=%d N1=%d N2=%d)",
                     nx, ns, C1, C2, N1, N2);
 
@@ -627,7 +723,28 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
 #define D4W_TRY(x) do { rc = (x); if (rc != D4W_OK) { d4w_fk_plan_destroy(pl); return rc; } } while (0)
     pl->fast = fast;
     D4W_TRY(make_axis(pl, C1, &pl->dev.ax_c1, &f_c1, fast ? &r_c1 : nullptr));
-    D4W_TRY(make_axis(pl, C2, &pl->dev.ax_c2, &f_c2, fast ? &r_c2 : nullptr));
+    if (bs_L) {
+        std::vector<int> one, f_L;
+        D4W_TRY(make_axis(pl, 1, &pl->dev.ax_c2, &one));                      // unused: pass C runs fk_passC_bluestein
+        D4W_TRY(make_axis(pl, bs_L, &pl->dev.ax_bs, &f_L));
+        f_c2.resize(C2);
+        for (int i = 0; i < C2; ++i) f_c2[i] = i;                             // natural output order
+        std::vector<float2> chirp(C2), filt(bs_L);
+        std::vector<double> bre(bs_L, 0.0), bim(bs_L, 0.0);
+        for (int n = 0; n < C2; ++n) {
+            const double ph = M_PI * (double)(((long long)n * n) % (2LL * C2)) / (double)C2;
+            chirp[n] = make_float2((float)cos(ph), (float)-sin(ph));
+            bre[n] = cos(ph); bim[n] = sin(ph);                               // conj(chirp)
+            if (n) { bre[bs_L - n] = cos(ph); bim[bs_L - n] = sin(ph); }
+        }
+        host_fft_pow2(bre, bim);
+        for (int p = 0; p < bs_L; ++p)
+            filt[p] = make_float2((float)(bre[f_L[p]] / bs_L), (float)(bim[f_L[p]] / bs_L));
+        D4W_TRY(upload(pl, chirp, &pl->dev.bs_chirp));
+        D4W_TRY(upload(pl, filt, &pl->dev.bs_filt));
+        pl->dev.bs_L = bs_L;
+    } else
+        D4W_TRY(make_axis(pl, C2, &pl->dev.ax_c2, &f_c2, fast ? &r_c2 : nullptr));
     D4W_TRY(make_axis(pl, N1, &pl->dev.ax_n1, &f_n1, fast ? &r_n1 : nullptr));
     D4W_TRY(make_axis(pl, N2, &pl->dev.ax_n2, &f_n2, fast ? &r_n2 : nullptr));
     if (fast) {     // exchange-stage twiddles of the specialised kernels
@@ -747,6 +864,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     pl->genericC = needs_generic(pl->dev.ax_c2);
     pl->ldsA = ((size_t)C1 * N1 * TA + 2 * kTwLo + pl->dev.ax_c1.nhi + pl->dev.ax_n1.nhi) * sizeof(float2);
     pl->ldsC = ((size_t)C2 * TC + kTwLo + pl->dev.ax_c2.nhi) * sizeof(float2);
+    if (bs_L) pl->ldsC = ((size_t)bs_L * TC + kTwLo + pl->dev.ax_bs.nhi) * sizeof(float2);
     pl->ldsB = ((size_t)2 * N2 + kTwLo + pl->dev.ax_n2.nhi) * sizeof(float2);
     auto env_int = [](const char* name, int dflt) {
         const char* v = getenv(name);
@@ -783,6 +901,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
                 (const void*)fk_passA_inv<true>, (const void*)fk_passA_inv<false>,
                 (const void*)fk_passC<false, true>, (const void*)fk_passC<false, false>,
                 (const void*)fk_passC<true, true>, (const void*)fk_passC<true, false>,
+                (const void*)fk_passC_bluestein<false>, (const void*)fk_passC_bluestein<true>,
                 (const void*)fk_passB<true>, (const void*)fk_passB<false>};
             for (const void* f : fns)
                 (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -922,11 +1041,15 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         rc = launch_k(gA ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, gridA, blk, pl->ldsA, stream, P, src, dst, ntA);
     if (rc) return rc;
     D4W_MARK(1);
-    if ((rc = launch_k(gC ? fk_passC<false, true> : fk_passC<false, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC))) return rc;
+    if (P.bs_L) rc = launch_k(fk_passC_bluestein<false>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
+    else rc = launch_k(gC ? fk_passC<false, true> : fk_passC<false, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
+    if (rc) return rc;
     D4W_MARK(2);
     if ((rc = launch_k(gB ? fk_passB<true> : fk_passB<false>, gridB, blk, pl->ldsB, stream, P, dst, ntB))) return rc;
     D4W_MARK(3);
-    if ((rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC))) return rc;
+    if (P.bs_L) rc = launch_k(fk_passC_bluestein<true>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
+    else rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
+    if (rc) return rc;
     D4W_MARK(4);
     if ((rc = launch_k(gA ? fk_passA_inv<true> : fk_passA_inv<false>, gridA, blk, pl->ldsA, stream, P, dst, ntA))) return rc;
     if (row_mean && (rc = d4w_row_stats_f32(y, d.nx, d.ns, row_mean, row_maxabs, stream))) return rc;   // generic kernels: separate pass

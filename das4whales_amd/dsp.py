@@ -117,9 +117,11 @@ class FkPlan:
 
 
 def supported_length(n, even=False):
-    """Largest length <= n the transforms accept: every prime factor <= 31 (the mixed-radix kernels
-    carry radices up to 31; there is no Bluestein fallback), optionally even.  Use it to trim a channel
-    selection or a record, e.g. nx = 4001 (prime) -> 4000."""
+    """Largest length <= n whose prime factors are all <= 31 (what the mixed-radix kernels carry), optionally
+    even.  The f-k filter accepts ANY channel count whose part with prime factors > 31 is <= 4096 (that
+    sub-transform runs as a Bluestein convolution, slower); the time axis (ns / 2) and the row transforms
+    (hilbert, spectrogram window, get_fx) need smooth lengths.  Use this to trim a record or a selection,
+    e.g. 12002 samples -> 12000."""
     n = int(n)
     while n > 1:
         m = n

@@ -143,3 +143,21 @@ def test_apply_with_row_statistics(emu, nx, ns, opts):
     y64 = y1.astype(np.float64)
     assert np.allclose(mx, np.abs(y64).max(axis=1), rtol=1e-6)
     assert np.max(np.abs(mean - y64.mean(axis=1))) < 1e-6 * np.abs(y64).max()
+
+
+@pytest.mark.parametrize("nx,ns", [(37, 48), (74, 40), (41 * 6, 24), (127, 16), (2 * 3 * 43, 64), (211, 6)])
+def test_channel_count_with_large_prime_factor(emu, nx, ns):
+    """nx with a prime factor > 31: the c2 sub-transform of pass C runs as a Bluestein convolution
+    (fk_passC_bluestein); everything else is the ordinary five-pass scheme."""
+    rng = np.random.default_rng(nx)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    assert rel(fk_emu(emu, x, m), orc.fk_filter_filt(x, m)) < TOL
+    assert rel(fk_emu(emu, x, np.ones((nx, ns))), x) < TOL
+    assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+
+
+def test_channel_count_too_long_for_bluestein_tile(emu):
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(4099, 16, ctypes.byref(plan)) != 0           # prime > 4096
+    assert b"supported_length" in emu.d4w_last_error()

@@ -151,11 +151,27 @@ def test_picks_random_rows(dw):
                 assert np.array_equal(got[c], ref), (ns, thr, c)
 
 
+def test_channel_counts_with_large_prime_factors(dw):
+    """nx with a prime factor > 31 (any channel selection): pass C runs its Bluestein form."""
+    rng = np.random.default_rng(108)
+    for nx, ns in ((4001, 600), (37 * 2, 64), (2 * 3 * 211, 1200), (1009, 256)):
+        x = rng.standard_normal((nx, ns))
+        m = rng.random((nx, ns))
+        assert rel(dw.dsp.fk_filter_filt(x, m), orc.fk_filter_filt(x, m)) < TOL, (nx, ns)
+    sel = [0, 4001, 1]
+    x = rng.standard_normal((4001, 1200))
+    mask = dw.dsp.hybrid_ninf_filter_design((4001, 1200), sel, 2.04, FS, cs_min=1350., cp_min=1450., cp_max=3300, cs_max=3450,
+                                            fmin=14., fmax=30.)
+    ref = orc.fk_filter_filt(x, orc.hybrid_ninf_filter_design((4001, 1200), sel, 2.04, FS, cs_min=1350., cp_min=1450.,
+                                                              cp_max=3300, cs_max=3450, fmin=14., fmax=30.))
+    assert rel(dw.dsp.fk_filter_sparsefilt(x, mask), ref) < TOL
+
+
 def test_unsupported_length_is_a_clear_error(dw):
-    """A prime factor > 31 has no kernel (no Bluestein fallback): ValueError naming the remedy."""
+    """What has no kernel: a time axis (ns / 2) with a prime factor > 31, a channel count whose part with
+    prime factors > 31 exceeds 4096.  ValueError naming the remedy."""
     assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
-    x = np.zeros((37 * 2, 64))
-    with pytest.raises(ValueError, match="supported_length"):
-        dw.dsp.fk_filter_filt(x, np.ones_like(x))
-    nx = dw.dsp.supported_length(74)
-    assert rel(dw.dsp.fk_filter_filt(np.ones((nx, 64)), np.ones((nx, 64))), np.ones((nx, 64))) < TOL
+    for shape in ((8, 2 * 37), (4099, 16)):
+        x = np.zeros(shape)
+        with pytest.raises(ValueError, match="supported_length"):
+            dw.dsp.fk_filter_filt(x, np.ones_like(x))
