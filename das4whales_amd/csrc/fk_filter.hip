@@ -667,22 +667,22 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
             for (const FkFastEntry& e : fast_shapes())
                 if (e.nx == nx && e.ns == ns && (e.variant == want || (!fast && e.variant == 0))) fast = &e;
     }
-    // --- split the time axis: smallest N1 whose N2 = M/N1 fits one LDS row pair
-    int N1 = o[2], N2 = o[3];
-    if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
-        N1 = 0;
-        for (int cand = 1; cand <= M; ++cand) {
-            if (M % cand) continue;
-            if (M / cand <= kMaxTile / 2) { N1 = cand; break; }
-        }
-        N2 = M / N1;
-    }
+    // admissible time splits: N1 | M with N2 = M / N1 fitting one LDS row pair
+    int n1_min = 0;
+    for (int cand = 1; cand <= M && !n1_min; ++cand)
+        if (M % cand == 0 && M / cand <= kMaxTile / 2) n1_min = cand;
+    if (!n1_min) return fail(D4W_EINVAL, "ns/2 = %d has no factorisation with N2 <= %d", M, kMaxTile / 2);
     // --- split the channel axis
     int C1 = o[0], C2 = o[1];
     if (C1 <= 0 || C2 <= 0 || C1 * C2 != nx) {
         // measured on MI355X (20000 x 120000): a long c2 axis with 64-byte column segments in
         // pass C leaves room for 128-byte segments in the 2-D pass A and wins overall
         C2 = largest_divisor_le(nx, kMaxTile / 8);
+        // ... but not at the price of fewer than 8 c1 rows: pass A's tile is C1 x N1 x TA, and a tile of a few
+        // dozen elements costs more than a shorter c2 axis saves (1000 x 12000: C1 = 1 1.9 ms, C1 = 10 0.47 ms)
+        if (nx / C2 < 8)
+            for (int cand = C2; cand >= 1; --cand)
+                if (nx % cand == 0 && nx / cand >= 8) { C2 = cand; break; }
         C1 = nx / C2;
     }
     // a prime factor > 31 of nx goes into C2, whose sub-transform then runs as a Bluestein convolution of
@@ -691,13 +691,29 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     if (!fast && rough_part(nx) > 1) {
         C2 = rough_part(nx);
         C1 = nx / C2;
-        for (int f = 2; f <= 31 && (long)C1 * N1 > kMaxTile; ++f)      // pass A's tile must hold C1 x N1 columns
-            while (C1 % f == 0 && (long)C1 * N1 > kMaxTile && 2L * C2 * f - 1 <= kMaxTile) { C2 *= f; C1 /= f; }
+        for (int f = 2; f <= 31 && (long)C1 * n1_min > kMaxTile; ++f)      // pass A's tile must hold C1 x N1 columns
+            while (C1 % f == 0 && (long)C1 * n1_min > kMaxTile && 2L * C2 * f - 1 <= kMaxTile) { C2 *= f; C1 /= f; }
         bs_L = 1;
         while (bs_L < 2 * C2 - 1) bs_L *= 2;
         if (bs_L > kMaxTile)
             return fail(D4W_EINVAL, "nx = %d: the part with prime factors > 31 (%d) is too long for the Bluestein tile (limit %d); "
                         "dsp.supported_length(n) gives the nearest shorter length with a direct kernel", nx, C2, kMaxTile / 2);
+    }
+    // --- split the time axis.  Pass A's cost falls like 1 / (C1 N1) until its tile holds ~100 columns, pass B's
+    //     grows with N1 (shorter rows): N1 ~ sqrt(1000 / C1), at least the smallest admissible one
+    //     (measured at 1000 x 12000 and 500 x 120000 over C1 = 1..10, N1 = 2..75)
+    int N1 = o[2], N2 = o[3];
+    if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
+        N1 = n1_min;
+        const double target = sqrt(1000.0 / (double)C1);
+        double best = fabs(log((double)N1 / target));
+        if (target > n1_min)
+            for (int cand = n1_min + 1; cand <= M && cand <= 4 * target; ++cand) {
+                if (M % cand || M / cand < 64 || (long)C1 * cand * 16 > kMaxTile) continue;
+                const double sc = fabs(log((double)cand / target));
+                if (sc < best) { best = sc; N1 = cand; }
+            }
+        N2 = M / N1;
     }
     int TC = o[5] > 0 ? o[5] : 16;
     while (TC > 1 && (long)(bs_L ? bs_L : C2) * TC > kMaxTile) TC /= 2;
