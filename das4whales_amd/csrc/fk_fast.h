@@ -115,10 +115,14 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
         if (act2) R.tc = P.twc[hi * G::C2 + c2];
     };
     int par = 0;
-    auto body = [&](Pre& R, Pre& Rn, int t) {
+    // Two register sets, each prefetching TWO tiles ahead: tile t + 2 gstep is loaded into the set of tile t as
+    // soon as S1 has consumed it, i.e. BEFORE tile t's stores are issued.  A wave's vector-memory operations
+    // retire in order, so a prefetch issued after a tile's stores (one tile ahead, at the top of the next
+    // iteration) could not be consumed before those stores were acknowledged -- the store latency of a
+    // write-heavy pass then sat on the loop's critical path.
+    auto body = [&](Pre& R, int t) {
         const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
         float2* tw_cur = twl + par * (G::N1 * G::TA);
-        if (t + gstep < ntiles) issue(Rn, t + gstep);
         if (act1) {
             if (TAPER) {
                 static_for<G::C1>([&](auto cc) {
@@ -134,7 +138,9 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
             });
             tw_cur[hi * G::TA + tt] = R.tw;
         }
+        const float2 tc_cur = R.tc;
         lds_barrier();
+        if (t + 2 * gstep < ntiles) issue(R, t + 2 * gstep);       // R is free: S1 consumed it
         float2 v[G::N1];
         if (act2) {
             static_for<G::N1>([&](auto kk) {
@@ -148,16 +154,17 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
             float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
             static_for<G::N1>([&](auto kk) {
                 constexpr int q1 = decltype(kk)::value;
-                o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
+                o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur));
             });
         }
         par ^= 1;
     };
     int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
     if (t < ntiles) issue(A, t);
+    if (t + gstep < ntiles) issue(B, t + gstep);
     for (; t < ntiles; t += 2 * gstep) {
-        body(A, B, t);
-        if (t + gstep < ntiles) body(B, A, t + gstep);
+        body(A, t);
+        if (t + gstep < ntiles) body(B, t + gstep);
     }
 }
 
@@ -389,9 +396,9 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     for (int i = tid; i < G::C1 * RA; i += G::THRC) livel[i] = F.live ? F.live[i] : 0xFFFFFFFFu;
     __syncthreads();
     constexpr int NPF = INV ? RB : RA;
-    // Two register sets: the loads of tile i+1 are issued at the TOP of iteration i (before the
-    // butterflies of tile i), so the memory pipe never idles while a tile is in its compute
-    // phases; the loop is unrolled by two so that the sets swap roles without copies.
+    // Two register sets, each prefetching TWO tiles ahead (see fkf_passA_fwd): tile t + 2 gstep is loaded into
+    // the set of tile t right after S1 has consumed it, before tile t's stores are issued; the loop is unrolled
+    // by two so that the sets swap roles without copies.
     float2 pfA[NPF], pfB[NPF];
     auto issue = [&](float2 (&pf)[NPF], int t) {
         const int q = t / NBX, p0 = (t % NBX) * TC;
@@ -412,10 +419,9 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     const bool act_first = INV ? actB : actA;
     const bool act_second = INV ? actA : actB;
     const int gstep = gridDim.x;
-    auto body = [&](float2 (&pf)[NPF], float2 (&pn)[NPF], int t) {
+    auto body = [&](float2 (&pf)[NPF], int t) {
         const int q = t / NBX, p0 = (t % NBX) * TC;
         float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
-        if (t + gstep < ntiles && act_first) issue(pn, t + gstep);
         if (D4W_ABL == 4) {          // timing ablation: stream the tile through registers only
             if (act_first) {
                 static_for<NPF>([&](auto aa) {
@@ -424,6 +430,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                     else base[(size_t)(hi * RB + a) * G::M] = pf[a];
                 });
             }
+            if (t + 2 * gstep < ntiles && act_first) issue(pf, t + 2 * gstep);
             return;
         }
         if (act_first) {
@@ -446,6 +453,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
             }
         }
         lds_barrier();
+        if (t + 2 * gstep < ntiles && act_first) issue(pf, t + 2 * gstep);     // pf is free: S1 consumed it
         constexpr int NV = INV ? RA : RB;
         float2 v[NV];
         if (act_second) {
@@ -487,9 +495,10 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     };
     int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
     if (t < ntiles && act_first) issue(pfA, t);
+    if (t + gstep < ntiles && act_first) issue(pfB, t + gstep);
     for (; t < ntiles; t += 2 * gstep) {
-        body(pfA, pfB, t);
-        if (t + gstep < ntiles) body(pfB, pfA, t + gstep);
+        body(pfA, t);
+        if (t + gstep < ntiles) body(pfB, t + gstep);
     }
 }
 
