@@ -542,6 +542,39 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
             });
         }
     };
+    // MID operands of a pair (mask values of the item's two groups, Nyquist-column mask value, row twiddle):
+    // loaded ONE PAIR AHEAD and before the current pair's stores -- a wave's memory operations retire in order,
+    // so operands requested after the previous pair's stores could not be used before those stores were
+    // acknowledged.  The per-thread constants (column twiddles, mirror group) are loaded once.
+    const int Gi = tid;
+    const bool midrange = Gi < NG;
+    int PGz = 0;
+    float2 wc[NC];
+    if (midrange) {
+        PGz = P.mirror0[Gi * NC] / NC;
+        const float2* wcp = P.wcol + Gi * NC;
+        static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; wc[d] = wcp[d]; });
+    }
+    struct MidOps {
+        float ma[NC], mbr[NC];
+        float nyq;
+        float2 wr;
+    };
+    MidOps cur, nxt;
+    auto issue_mid = [&](MidOps& O, int2 pr) {
+        if (!midrange) return;
+        const int rpos = pr.x / G::N1, q1 = pr.x - rpos * G::N1;
+        const int PG = (q1 == 0) ? PGz : (NG - 1 - Gi);
+        const float* mA = P.mask + (size_t)pr.x * N2 + Gi * NC;
+        const float* mB = P.mask + (size_t)pr.y * N2 + PG * NC;
+        static_for<NC>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;
+            O.ma[d] = mA[d];
+            O.mbr[d] = mB[d];
+        });
+        O.nyq = P.nyq[rpos];
+        O.wr = P.wrow[q1];
+    };
     // the work list is read two tiles ahead (wave-uniform scalar loads whose latency would
     // otherwise sit in front of every prefetch)
     int t = tbase + blockIdx.x;     // tiles [tbase, ntiles): a sub-range when passes are chunked
@@ -549,7 +582,10 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
     int2 pr_cur = make_int2(0, 0), pr_nxt = make_int2(0, 0);
     if (t < npairs) pr_cur = F.pairs[t];
     if (t + gstep < npairs) pr_nxt = F.pairs[t + gstep];
-    if (t < npairs) issue(pr_cur);
+    if (t < npairs) {
+        issue_mid(cur, pr_cur);
+        issue(pr_cur);
+    }
     for (; t < npairs; t += gstep) {
         const int2 pr = pr_cur;
         int2 pr_nn = pr_cur;
@@ -570,29 +606,11 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
             });
         }
         lds_barrier();
-        // ---------------- MID operands that come from global memory: issued BEFORE the prefetch of
-        // the next tile so that waiting for them does not wait for the prefetch (vmcnt is in order)
-        const int Gi = tid;
-        const bool midrange = Gi < NG;
-        int PG = 0;
-        float ma[NC], mbr[NC];
-        float2 wc[NC];
-        float nyq = 0.f;
-        float2 wr = make_float2(1.f, 0.f);
-        if (midrange) {
-            PG = k1zero ? (P.mirror0[Gi * NC] / NC) : (NG - 1 - Gi);
-            const float* mA = P.mask + (size_t)pr.x * N2 + Gi * NC;
-            const float* mB = P.mask + (size_t)pr.y * N2 + PG * NC;
-            const float2* wcp = P.wcol + Gi * NC;
-            static_for<NC>([&](auto dd) {
-                constexpr int d = decltype(dd)::value;
-                ma[d] = mA[d];
-                mbr[d] = mB[d];
-                wc[d] = wcp[d];
-            });
-            nyq = P.nyq[rpos];
-            wr = P.wrow[q1];
-        }
+        const int PG = k1zero ? PGz : (NG - 1 - Gi);
+        const float (&ma)[NC] = cur.ma;
+        const float (&mbr)[NC] = cur.mbr;
+        const float nyq = cur.nyq;
+        const float2 wr = cur.wr;
         if (t + gstep < npairs) issue(pr_nxt);
         // ---------------- S2 (in place)
         for (int it = tid; it < nrows * NA * NC; it += THR) {
@@ -694,6 +712,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
             });
         }
         lds_barrier();
+        if (t + gstep < npairs) issue_mid(nxt, pr_nxt);       // next pair's MID operands, ahead of this pair's stores
         // ---------------- S1' -> global
         if (it1 && r1 < nrows) {
             float2 v[NA], pw[NA];
@@ -714,6 +733,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         lds_barrier();
         pr_cur = pr_nxt;
         pr_nxt = pr_nn;
+        cur = nxt;
     }
 }
 
