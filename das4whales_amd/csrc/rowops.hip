@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
                 tile[rl * kSosPitch + ml] = v;
             }
         }
-        __syncthreads();
+        lds_barrier();          // LDS only: __syncthreads() would also drain the prefetch loads and the stores
         const int nextm = m0 + kSosChunk;
         if (nextm < count && interior(nextm)) { issue(nextm); pre_for = nextm; }
         // ---- recursion: lane = row, 4 samples per LDS access
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
             }
             mine[g] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        __syncthreads();
+        lds_barrier();
         // ---- stage out (only this segment's own samples; the last forward segment also feeds
         //      the right-extension outputs to the edge buffer for the backward pass)
         const int lo = REV ? i_start - m0 - (kSosChunk - 1) : i_start + m0;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();          // the chunk's stores stay in flight under the next chunk
     }
 }
 
