@@ -510,6 +510,9 @@ using FkShapeBench = FkFastCfg<25, 25, 32, 25, 20, 12, 10, 16, 16, 448, 512, 256
 // primes are register butterflies of the c2 axis)
 using FkShapeC1 = FkFastCfg<20, 10, 20, 5, 10, 12, 10, 16, 16, 320, 320, 256>;      // 4000 x 12000
 using FkShapeOOI = FkFastCfg<20, 19, 29, 5, 10, 12, 10, 16, 16, 320, 464, 256>;     // 11020 x 12000
+// the reference notebook's channel selection on the OOI RAPID cable ([20000, 65000, 10] m -> 5510 channels;
+// scripts/main_mfdetect.py's [12000, 66000, 5] m gives 13223 = 7 x 1889 channels: Bluestein pass C)
+using FkShapeNB = FkFastCfg<10, 19, 29, 5, 10, 12, 10, 16, 16, 192, 464, 256>;      // 5510 x 12000
 using FkShapeT1 = FkFastCfg<3, 2, 3, 2, 2, 3, 2, 2, 2, 64, 64, 64>;                 // 18 x 48    (tests)
 using FkShapeT2 = FkFastCfg<2, 2, 2, 2, 8, 3, 5, 2, 2, 64, 64, 64>;                 // 8 x 480    (tests)
 using FkShapeT3 = FkFastCfg<5, 4, 5, 5, 4, 3, 5, 4, 4, 64, 64, 64>;                 // 100 x 600  (tests)
@@ -519,6 +522,7 @@ static const std::vector<FkFastEntry>& fast_shapes() {
         fast_entry<FkShapeBench>(1, 1, 2),
         fast_entry<FkShapeC1>(2, 2, 2),
         fast_entry<FkShapeOOI>(2, 2, 2),
+        fast_entry<FkShapeNB>(2, 2, 2),
         fast_entry<FkShapeT1>(2, 2, 2),
         fast_entry<FkShapeT2>(2, 2, 2),
         fast_entry<FkShapeT3>(2, 2, 2),

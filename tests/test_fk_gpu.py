@@ -217,7 +217,7 @@ def test_apply_stats_bench_shape(dw):
     assert float((c_own - c_fed).abs().max()) < 2e-6 * float(c_own.abs().max())
 
 
-@pytest.mark.parametrize("nx,ns", [(4000, 12000), (11020, 12000)])
+@pytest.mark.parametrize("nx,ns", [(4000, 12000), (11020, 12000), (5510, 12000)])
 def test_config_shapes_specialised_vs_generic(dw, nx, ns):
     """The 60-s file shapes (BASELINE configs[0..1]; the real OOI channel count 11020 = 20 x 19 x 29)
     run shape-specialised kernels: same result as the generic five passes, pruned and unpruned, and a
