@@ -96,6 +96,20 @@ __device__ __forceinline__ float2 c_mulc(float2 a, float2 b) {
 }
 #endif
 
+// Streaming (non-temporal) store for write-once outputs far larger than L2 + MALL (the correlograms):
+// fused matched filter 8.05 -> 7.78 ms at 20000 x 120000.  (No effect on the f-k passes, which keep plain stores.)
+__device__ __forceinline__ void st_stream(float2* p, float2 v) {
+#ifdef D4W_EMU
+    *p = v;
+#else
+    typedef float d4w_f2v __attribute__((ext_vector_type(2)));
+    d4w_f2v t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<d4w_f2v*>(p));
+#endif
+}
+
 // 24-bit integer multiply (full-rate v_mul_i32_i24; v_mul_lo_u32 is quarter rate) and fast reciprocal
 #ifdef D4W_EMU
 __device__ __forceinline__ int d4w_mul24(int a, int b) { return a * b; }

@@ -362,8 +362,8 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                     constexpr int aq = decltype(aa)::value;
                     if (2 * (j1 + aq * M1) < kXfStep) {
                         const c2 o = c2_scale2(v[aq], sc);
-                        oa[aq * M1] = c2_a(o);
-                        if (hasB) ob[aq * M1] = c2_b(o);
+                        st_stream(oa + aq * M1, c2_a(o));
+                        if (hasB) st_stream(ob + aq * M1, c2_b(o));
                     }
                 });
             } else {
@@ -927,8 +927,8 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
                 constexpr int q = decltype(qq)::value;
                 if (2 * (tid + q * 256) < kXfStep) {
                     const c2 o = c2_scale2(v[q], sc);
-                    oa[q * 256] = c2_a(o);
-                    if (hasB) ob[q * 256] = c2_b(o);
+                    st_stream(oa + q * 256, c2_a(o));
+                    if (hasB) st_stream(ob + q * 256, c2_b(o));
                 }
             });
         } else {
