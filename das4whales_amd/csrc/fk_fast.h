@@ -567,11 +567,20 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         const int PG = (q1 == 0) ? PGz : (NG - 1 - Gi);
         const float* mA = P.mask + (size_t)pr.x * N2 + Gi * NC;
         const float* mB = P.mask + (size_t)pr.y * N2 + PG * NC;
-        static_for<NC>([&](auto dd) {
-            constexpr int d = decltype(dd)::value;
-            O.ma[d] = mA[d];
-            O.mbr[d] = mB[d];
-        });
+        if constexpr (NC % 2 == 0 && N2 % 2 == 0) {              // 8-byte lanes: half the load instructions
+            static_for<NC / 2>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                const float2 a2 = reinterpret_cast<const float2*>(mA)[d], b2 = reinterpret_cast<const float2*>(mB)[d];
+                O.ma[2 * d] = a2.x; O.ma[2 * d + 1] = a2.y;
+                O.mbr[2 * d] = b2.x; O.mbr[2 * d + 1] = b2.y;
+            });
+        } else {
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                O.ma[d] = mA[d];
+                O.mbr[d] = mB[d];
+            });
+        }
         O.nyq = P.nyq[rpos];
         O.wr = P.wrow[q1];
     };
