@@ -109,15 +109,20 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
         const int lo = REV ? i_start - m0 - (kSosChunk - 1) : i_start + m0;
         return lo >= 0 && lo + kSosChunk <= ns;
     };
+    // Interior chunks address memory as (wave-uniform 64-bit base of the row group) + (32-bit lane offset): element
+    // e = lane + 64 k sits in row (lane >> 5) + 2 k at sample lane & 31, so nothing but the row term changes with k
+    // and no table of 64-bit addresses has to live in registers.
+    static_assert(kSosChunk == 32 && kSosRows == 64, "lane -> (row, sample) map of the interior chunks");
+    const float* src_grp = src + (size_t)row0 * ns;
+    float* dst_grp = dst + (size_t)row0 * ns;
+    const unsigned rl0 = (unsigned)(lane >> 5), ml0 = (unsigned)(lane & 31), rmax = (unsigned)(nx - 1 - row0);
     float pre[kSosChunk];
     auto issue = [&](int m0) {
+        const unsigned i = (unsigned)(REV ? i_start - (m0 + (int)ml0) : i_start + m0 + (int)ml0);
 #pragma unroll
         for (int k = 0; k < kSosChunk; ++k) {
-            const int e = lane + k * kSosRows;
-            const int rl = e / kSosChunk, ml = e % kSosChunk;
-            const int row = min(row0 + rl, nx - 1);
-            const int i = REV ? i_start - (m0 + ml) : i_start + m0 + ml;
-            pre[k] = src[(size_t)row * ns + i];
+            const unsigned rl = min(rl0 + 2u * k, rmax);
+            pre[k] = src_grp[rl * (unsigned)ns + i];
         }
     };
     int pre_for = -1;
@@ -174,12 +179,11 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
         //      the right-extension outputs to the edge buffer for the backward pass)
         const int lo = REV ? i_start - m0 - (kSosChunk - 1) : i_start + m0;
         if (full_rows && m0 + kSosChunk <= count && lo >= a && lo + kSosChunk <= b) {
+            const unsigned i = (unsigned)(REV ? i_start - (m0 + (int)ml0) : i_start + m0 + (int)ml0);
 #pragma unroll
             for (int k = 0; k < kSosChunk; ++k) {
-                const int e = lane + k * kSosRows;
-                const int rl = e / kSosChunk, ml = e % kSosChunk;
-                const int i = REV ? i_start - (m0 + ml) : i_start + m0 + ml;
-                dst[(size_t)(row0 + rl) * ns + i] = tile[rl * kSosPitch + ml];
+                const unsigned rl = rl0 + 2u * k;
+                dst_grp[rl * (unsigned)ns + i] = tile[rl * kSosPitch + ml0];
             }
         } else {
 #pragma unroll 4
