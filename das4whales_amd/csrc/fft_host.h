@@ -2,6 +2,7 @@
 // digit-order position <-> frequency maps and the two-level twiddle tables of fft_lds.h.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "fft_lds.h"
@@ -98,5 +99,28 @@ static inline bool axis_needs_generic(const AxisDesc& ax) {
     }
     return false;
 }
+
+// in-place radix-2 FFT (forward sign) of a power-of-two length, double precision: plan-time tables only
+static inline void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
+    const int n = (int)re.size();
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * k), wi = sin(ang * k);
+                const int a = i + k, b = i + k + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+}
+
 
 }  // namespace d4w

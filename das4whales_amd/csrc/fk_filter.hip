@@ -593,28 +593,6 @@ static int launch_k(K kern, dim3 grid, dim3 blk, size_t lds, void* stream, Args.
     return D4W_OK;
 }
 
-// in-place radix-2 FFT (forward sign) of a power-of-two length, double precision: plan-time tables only
-static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
-    const int n = (int)re.size();
-    for (int i = 1, j = 0; i < n; ++i) {
-        int bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
-    }
-    for (int len = 2; len <= n; len <<= 1) {
-        const double ang = -2.0 * M_PI / len;
-        for (int i = 0; i < n; i += len)
-            for (int k = 0; k < len / 2; ++k) {
-                const double wr = cos(ang * k), wi = sin(ang * k);
-                const int a = i + k, b = i + k + len / 2;
-                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
-                re[b] = re[a] - tr; im[b] = im[a] - ti;
-                re[a] += tr; im[a] += ti;
-            }
-    }
-}
-
 // n with every prime factor <= 31 divided out
 static int rough_part(int n) {
     for (int p = 2; p <= 31; ++p)

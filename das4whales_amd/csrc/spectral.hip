@@ -30,6 +30,13 @@ struct RowFftDev {
     const int* p2f;       // [L] position -> frequency
     const float2* wpack;  // [L] exp(-2 pi i f / (2L)): real-packing twiddle of a 2L-point real row
     const float* hann;    // [L] periodic Hann window (scipy get_window('hann', L, fftbins=True))
+    // Bluestein form for a length with a prime factor > 31 (single-row transforms only): the L-point DFT as a
+    // circular convolution of length bs_L = 2^k >= 2 L - 1 with the chirp exp(-i pi n^2 / L); pos / p2f are the
+    // identity then.  bs_L = 0: the mixed-radix transform of `ax`.
+    int bs_L;
+    AxisDesc ax_bs;
+    const float2* bs_chirp;   // [L]
+    const float2* bs_filt;    // [bs_L]  FFT of the wrapped conjugate chirp / bs_L, at the DIF positions of ax_bs
 };
 
 struct RowFftHost {
@@ -58,8 +65,16 @@ static int row_fft_get(int L, const RowFftHost** out) {
     auto it = g_rowfft.find({devid, L});
     if (it != g_rowfft.end()) { *out = it->second; return D4W_OK; }
     std::vector<int> rad;
-    if (!factor_radices(L, rad))
-        return fail(D4W_EINVAL, "transform length %d has a prime factor > 31 (not supported)", L);
+    const bool bluestein = !factor_radices(L, rad);
+    int bs_L = 0;
+    if (bluestein) {
+        bs_L = 1;
+        while (bs_L < 2 * L - 1) bs_L *= 2;
+        if (((size_t)bs_L + kTwLo + (size_t)(bs_L + kTwLo - 1) / kTwLo) * sizeof(float2) > kSpLdsMax)
+            return fail(D4W_EINVAL, "transform length %d has a prime factor > 31 and is too long for the Bluestein form "
+                        "(dsp.supported_length(n) gives the nearest shorter length with a direct kernel)", L);
+        rad.clear();
+    }
     RowFftHost* h = new RowFftHost();
     memset(&h->dev, 0, sizeof(h->dev));
     AxisDesc& ax = h->dev.ax;
@@ -67,7 +82,9 @@ static int row_fft_get(int L, const RowFftHost** out) {
     ax.nstage = (L == 1) ? 0 : (int)rad.size();
     for (int i = 0; i < kMaxStages; ++i) ax.radix[i] = (i < (int)rad.size() && L > 1) ? rad[i] : 1;
     if (L == 1) rad.clear();
-    const std::vector<int> p2f = pos_to_freq(L, rad);
+    std::vector<int> p2f = pos_to_freq(L, rad);
+    if (bluestein)
+        for (int i = 0; i < L; ++i) p2f[i] = i;                   // natural order
     std::vector<int> pos(L);
     for (int p = 0; p < L; ++p) pos[p2f[p]] = p;
     std::vector<float2> wp(L);
@@ -75,6 +92,29 @@ static int row_fft_get(int L, const RowFftHost** out) {
     std::vector<float> hann(L);
     for (int n = 0; n < L; ++n) hann[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)L));
     int rc = sp_upload(h, twiddle_table2(L, &ax.nhi), &ax.tw2);
+    if (!rc && bluestein) {
+        std::vector<int> radL;
+        factor_radices(bs_L, radL);
+        AxisDesc& ab = h->dev.ax_bs;
+        ab.L = bs_L;
+        ab.nstage = (int)radL.size();
+        for (int i = 0; i < kMaxStages; ++i) ab.radix[i] = (i < (int)radL.size()) ? radL[i] : 1;
+        const std::vector<int> fL = pos_to_freq(bs_L, radL);
+        std::vector<float2> chirp(L), filt(bs_L);
+        std::vector<double> bre(bs_L, 0.0), bim(bs_L, 0.0);
+        for (int n = 0; n < L; ++n) {
+            const double ph = M_PI * (double)(((long long)n * n) % (2LL * L)) / (double)L;
+            chirp[n] = make_float2((float)cos(ph), (float)-sin(ph));
+            bre[n] = cos(ph); bim[n] = sin(ph);
+            if (n) { bre[bs_L - n] = cos(ph); bim[bs_L - n] = sin(ph); }
+        }
+        host_fft_pow2(bre, bim);
+        for (int q = 0; q < bs_L; ++q) filt[q] = make_float2((float)(bre[fL[q]] / bs_L), (float)(bim[fL[q]] / bs_L));
+        rc = sp_upload(h, twiddle_table2(bs_L, &ab.nhi), &ab.tw2);
+        if (!rc) rc = sp_upload(h, chirp, &h->dev.bs_chirp);
+        if (!rc) rc = sp_upload(h, filt, &h->dev.bs_filt);
+        h->dev.bs_L = bs_L;
+    }
     if (!rc) rc = sp_upload(h, pos, &h->dev.pos);
     if (!rc) rc = sp_upload(h, p2f, &h->dev.p2f);
     if (!rc) rc = sp_upload(h, wp, &h->dev.wpack);
@@ -84,7 +124,7 @@ static int row_fft_get(int L, const RowFftHost** out) {
         delete h;
         return rc;
     }
-    h->generic = axis_needs_generic(ax);
+    h->generic = !bluestein && axis_needs_generic(ax);
     g_rowfft[{devid, L}] = h;
     *out = h;
     return D4W_OK;
@@ -107,6 +147,34 @@ static int row_fft_get(int L, const RowFftHost** out) {
 // ---------------------------------------------------------------------------------------------
 enum { kAnEnvelope = 0, kAnHilbert = 1, kAnSnr = 2, kAnIfreq = 3, kAnEnvStd = 4 };
 
+// elements / twiddle axis of a single-row transform tile
+__device__ __forceinline__ int row_tile_elems(const RowFftDev& F) { return F.bs_L ? F.bs_L : F.ax.L; }
+__device__ __forceinline__ const AxisDesc& row_tw_axis(const RowFftDev& F) { return F.bs_L ? F.ax_bs : F.ax; }
+
+// DFT (INV = false) or unnormalised inverse DFT of the F.ax.L values at the start of `tile`, in place; result at
+// positions F.pos[f].  The tile is synchronised on entry and on return.  Bluestein form when F.bs_L != 0 (the tile
+// then holds F.bs_L elements): x w -> FFT -> x filter -> IFFT -> x w, w = exp(-i pi n^2 / L), conjugated for INV.
+template <bool INV, bool GENERIC>
+__device__ __forceinline__ void row_dft(float2* tile, const RowFftDev& F, const TwLds tw, int tid, int nthr) {
+    if (F.bs_L == 0) {
+        lds_fft<INV, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+        return;
+    }
+    const int L = F.ax.L, BL = F.bs_L;
+    for (int i = tid; i < BL; i += nthr) {
+        float2 v = make_float2(0.f, 0.f);
+        if (i < L) v = INV ? c_mulc(tile[i], F.bs_chirp[i]) : c_mul(tile[i], F.bs_chirp[i]);
+        tile[i] = v;
+    }
+    lds_barrier();
+    lds_fft<false, false, false>(tile, F.ax_bs, tw, 1, 1, 0, 1, 0, tid, nthr);
+    for (int i = tid; i < BL; i += nthr) tile[i] = INV ? c_mulc(tile[i], F.bs_filt[i]) : c_mul(tile[i], F.bs_filt[i]);
+    lds_barrier();
+    lds_fft<true, false, false>(tile, F.ax_bs, tw, 1, 1, 0, 1, 0, tid, nthr);
+    for (int i = tid; i < L; i += nthr) tile[i] = INV ? c_mulc(tile[i], F.bs_chirp[i]) : c_mul(tile[i], F.bs_chirp[i]);
+    lds_barrier();
+}
+
 __device__ __forceinline__ float an_ifreq(float2 z0, float2 z1, float fscale) {
     const float2 p = c_mulc(z1, z0);
     return atan2f(p.y, p.x) * fscale;
@@ -120,7 +188,7 @@ __global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const f
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int L = F.ax.L;
-    const TwLds tw = tw_stage(F.ax, tile + L, tid, nthr);
+    const TwLds tw = tw_stage(row_tw_axis(F), tile + row_tile_elems(F), tid, nthr);
     const float* xr = x + (size_t)blockIdx.x * ns;
     if (PACKED) {
         const float2* x2 = reinterpret_cast<const float2*>(xr);       // ns even: 8-byte aligned rows
@@ -129,7 +197,7 @@ __global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const f
         for (int n = tid; n < L; n += nthr) tile[n] = make_float2(xr[n], 0.f);
     }
     lds_barrier();
-    lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+    row_dft<false, GENERIC>(tile, F, tw, tid, nthr);
     if (PACKED) {
         const int M = L;
         for (int f = tid; f <= M / 2; f += nthr) {
@@ -162,7 +230,7 @@ __global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const f
         }
     }
     lds_barrier();
-    lds_fft<true, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+    row_dft<true, GENERIC>(tile, F, tw, tid, nthr);
     const float scale = 1.0f / (float)L;
     auto zat = [&](int i) -> float2 {
         if (PACKED) {
@@ -246,11 +314,11 @@ __global__ __launch_bounds__(kSpThreads) void fx_rows(RowFftDev F, const float* 
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int L = F.ax.L;
-    const TwLds tw = tw_stage(F.ax, tile + L, tid, nthr);
+    const TwLds tw = tw_stage(row_tw_axis(F), tile + row_tile_elems(F), tid, nthr);
     const float* xr = x + (size_t)blockIdx.x * ns;
     for (int n = tid; n < L; n += nthr) tile[n] = make_float2(n < ns ? xr[n] : 0.f, 0.f);
     lds_barrier();
-    lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, 1, 0, 1, 0, tid, nthr);
+    row_dft<false, GENERIC>(tile, F, tw, tid, nthr);
     const float scale = (float)(2.0e9 / (double)L);
     float* yr = y + (size_t)blockIdx.x * L;
     const int sh = L / 2;                                             // fftshift: out[j] = F[(j - L//2) mod L]
@@ -689,9 +757,20 @@ int d4w_row_var_f32(const float* x, int nx, int ns, float* var, void* stream) {
     return D4W_OK;
 }
 
+static size_t row_tile_lds(const RowFftDev& F) {
+    const int n = F.bs_L ? F.bs_L : F.ax.L;
+    return ((size_t)n + kTwLo + (F.bs_L ? F.ax_bs.nhi : F.ax.nhi)) * sizeof(float2);
+}
+
 int d4w_analytic_row_fits_lds(int ns) {
     if (ns < 2) return 0;
-    const int L = (ns % 2 == 0) ? ns / 2 : ns;
+    int L = (ns % 2 == 0) ? ns / 2 : ns;
+    std::vector<int> rad;
+    if (!factor_radices(L, rad)) {                      // Bluestein tile
+        int b = 1;
+        while (b < 2 * L - 1) b *= 2;
+        L = b;
+    }
     return ((size_t)L + kTwLo + (size_t)(L + kTwLo - 1) / kTwLo) * sizeof(float2) <= kSpLdsMax ? 1 : 0;
 }
 
@@ -705,7 +784,7 @@ int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const f
     const RowFftHost* h = nullptr;
     int rc = row_fft_get(L, &h);
     if (rc) return rc;
-    const size_t lds = ((size_t)L + kTwLo + h->dev.ax.nhi) * sizeof(float2);
+    const size_t lds = row_tile_lds(h->dev);
     if (lds > kSpLdsMax)
         return fail(D4W_EINVAL, "rows of %d samples exceed the single-workgroup transform (max %d even / %d odd)",
                     ns, (int)(2 * (kSpLdsMax / 8 - 512)), (int)(kSpLdsMax / 8 - 512));
@@ -738,7 +817,7 @@ int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream)
     const RowFftHost* h = nullptr;
     int rc = row_fft_get(nfft, &h);
     if (rc) return rc;
-    const size_t lds = ((size_t)nfft + kTwLo + h->dev.ax.nhi) * sizeof(float2);
+    const size_t lds = row_tile_lds(h->dev);
     if (lds > kSpLdsMax) return fail(D4W_EINVAL, "nfft = %d exceeds the single-workgroup transform", nfft);
     if (h->generic) {
         sp_allow_lds(fx_rows<true>, lds);
@@ -761,6 +840,9 @@ int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, in
     const RowFftHost* h = nullptr;
     int rc = row_fft_get(n_fft, &h);
     if (rc) return rc;
+    if (h->dev.bs_L)
+        return fail(D4W_EINVAL, "n_fft = %d has a prime factor > 31 (the frame transform has no Bluestein form; "
+                    "dsp.supported_length(n) gives the nearest shorter supported length)", n_fft);
     StftDims d;
     d.ns = ns; d.n_fft = n_fft; d.hop = hop; d.nframes = 1 + ns / hop; d.b_lo = bin_lo; d.b_hi = bin_hi;
     int nb = std::max(1, 6144 / n_fft);                      // complex transforms (frame pairs) per workgroup

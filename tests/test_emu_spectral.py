@@ -242,8 +242,12 @@ def test_argument_errors(emu):
     x = np.zeros((2, 64), dtype=np.float32)
     y = np.zeros((2, 64), dtype=np.float32)
     assert emu.d4w_analytic_f32(vp(x), vp(y), 2, 64, 7, None, ctypes.c_double(0), None) == -1
-    assert emu.d4w_analytic_f32(vp(x), vp(y), 2, 2 * 37, 0, None, ctypes.c_double(0), None) == -1   # prime 37
-    assert b"prime" in emu.d4w_last_error()
+    big = np.zeros((1, 2 * 20011), dtype=np.float32)                                                # prime 20011: no room
+    assert emu.d4w_analytic_f32(vp(big), vp(np.empty_like(big)), 1, 2 * 20011, 0, None, ctypes.c_double(0), None) == -1
+    assert b"prime" in emu.d4w_last_error() and emu.d4w_analytic_row_fits_lds(2 * 20011) == 0
+    x74 = np.zeros((2, 740), dtype=np.float32)
+    assert emu.d4w_stft_mag_f32(vp(x74), vp(np.zeros((2, 38, 21), dtype=np.float32)), vp(y), 2, 740, 74, 37, 0, 37, None) == -1
+    assert b"prime" in emu.d4w_last_error()                                                         # frame transform: no Bluestein
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 15, 4, 0, 7, None) == -1                # odd n_fft
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 16, 4, 0, 9, None) == -1                # bin range
 
@@ -295,3 +299,22 @@ def test_find_peaks_long_rows_block_walks(emu, ns):
             ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
             assert cnt[c] == len(ref), (thr, c, cnt[c], len(ref))
             assert np.array_equal(idx[c, :cnt[c]], ref)
+
+
+@pytest.mark.parametrize("ns", [2 * 37, 2 * 1009, 2 * 3 * 43, 1091, 41])
+def test_analytic_and_fx_lengths_with_large_prime_factors(emu, ns):
+    """Row lengths whose transform (ns / 2 for even ns, ns for odd) has a prime factor > 31 run the Bluestein
+    form of the single-row transform."""
+    rng = np.random.default_rng(ns)
+    x = np.ascontiguousarray(rng.standard_normal((3, ns)), dtype=np.float32)
+    assert emu.d4w_analytic_row_fits_lds(ns) == 1
+    z = orc.hilbert(x.astype(np.float64))
+    y = np.empty_like(x)
+    assert emu.d4w_analytic_f32(vp(x), vp(y), 3, ns, 0, None, ctypes.c_double(0.0), None) == 0, emu.d4w_last_error()
+    assert rel(y, np.abs(z)) < TOL
+    assert emu.d4w_analytic_f32(vp(x), vp(y), 3, ns, 1, None, ctypes.c_double(0.0), None) == 0
+    assert rel(y, z.imag) < TOL
+    nfft = ns if ns % 2 else ns // 2 + 1 if (ns // 2 + 1) % 2 else ns // 2        # an awkward nfft as well
+    fx = np.empty((3, nfft), dtype=np.float32)
+    assert emu.d4w_fx_f32(vp(x), vp(fx), 3, ns, nfft, None) == 0, emu.d4w_last_error()
+    assert rel(fx, orc.get_fx(x.astype(np.float64), nfft)) < TOL

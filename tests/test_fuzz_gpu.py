@@ -167,6 +167,24 @@ def test_channel_counts_with_large_prime_factors(dw):
     assert rel(dw.dsp.fk_filter_sparsefilt(x, mask), ref) < TOL
 
 
+def test_row_lengths_with_large_prime_factors(dw):
+    """Analytic-signal rows whose transform has a prime factor > 31 (12002 = 2 x 6001): Bluestein row transform."""
+    rng = np.random.default_rng(109)
+    for nx, ns in ((5, 12002), (3, 2 * 1009), (4, 1091)):
+        x = rng.standard_normal((nx, ns))
+        z = orc.hilbert(x)
+        assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL, ns
+        assert rel(dw.dsp.hilbert_imag(x), z.imag) < TOL, ns
+    c = rng.standard_normal((6, 12002)).astype(np.float32)
+    got = dw.detect.pick_times_env(c, 2.5)
+    env = np.abs(orc.hilbert(c.astype(np.float64)))
+    for r in range(6):
+        ref = sps.find_peaks(env[r], prominence=2.5)[0]
+        pr = sps.peak_prominences(env[r], np.union1d(ref, got[r]).astype(int))[0] if len(ref) or len(got[r]) else []
+        sym = np.setxor1d(ref, got[r])
+        assert all(abs(p - 2.5) < 1e-3 for p in sps.peak_prominences(env[r], sym.astype(int))[0]), (r, sym)
+
+
 def test_unsupported_length_is_a_clear_error(dw):
     """What has no kernel: a time axis (ns / 2) with a prime factor > 31, a channel count whose part with
     prime factors > 31 exceeds 4096.  ValueError naming the remedy."""
