@@ -6,6 +6,7 @@
 // exactly as NumPy forms them (integer index x 1/(n d)); masks are stored as float32 on the
 // fftshift-ed (k, f) grid, row-major [nx][ns] -- the layout d4w_fk_set_mask_dense_f32 takes.
 #include <algorithm>
+#include <limits>
 
 #include "d4w_internal.h"
 
@@ -260,8 +261,9 @@ int d4w_minmax_normalise_f32(float* x, size_t n, void* stream) {
     if (e != hipSuccess) return fail(D4W_EHIP, "min/max reduction failed: %s", hipGetErrorString(e));
     float lo = h[0], hi = h[1];
     for (int b = 1; b < blocks; ++b) { lo = std::min(lo, h[2 * b]); hi = std::max(hi, h[2 * b + 1]); }
-    if (!(hi > lo)) return fail(D4W_EINVAL, "mask is constant: cannot normalise");
-    const float a = 1.0f / (hi - lo);
+    // a constant g: NumPy's (g - min) / (max - min) is 0 / 0 = NaN everywhere (the reference's own test_fk_filt
+    // runs into this on its 2 x 5 block and only checks the shape) -- same here, no error
+    const float a = (hi > lo) ? 1.0f / (hi - lo) : std::numeric_limits<float>::quiet_NaN();
     D4W_LAUNCH(affine_kernel, dim3(blocks), dim3(256), 0, stream, x, n, a, -lo * a);
     return D4W_OK;
 }

@@ -150,10 +150,37 @@ def get_fk_plan(nx, ns, device=None):
         return p
 
 
+def _fk_apply_odd(trace, fk_filter_matrix, tapering):
+    """Odd record length, exactly, through the even-length (packed real) machinery: z[2n] = x[n], z[2n+1] = 0 has
+    the spectrum of x repeated twice along f, so filtering z with the mask repeated twice along f returns y
+    interleaved with zeros.  Twice the work of an even length; only data movement happens here."""
+    nx, ns = trace.shape
+    device = trace.device if dev.is_tensor(trace) and trace.is_cuda else None
+    m = fk_filter_matrix.tensor if isinstance(fk_filter_matrix, DeviceMask) else fk_filter_matrix
+    if hasattr(m, "todense") and not dev.is_tensor(m):
+        m = m.todense()
+    if tuple(m.shape) != (nx, ns):
+        raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s" % (nx, ns, tuple(m.shape)))
+    plan = get_fk_plan(nx, 2 * ns, device)
+    md = dev.to_device_f32(m, plan.device)
+    mu = torch.roll(md, shifts=-(ns // 2), dims=1)              # time axis back to the unshifted grid
+    plan.set_mask(torch.cat((mu, mu), dim=1))                    # periodic in f: fftshift by ns leaves it unchanged
+    x = dev.to_device_f32(trace, plan.device)
+    if tapering:
+        x = x.clone()
+        check(lib.d4w_taper_f32(dev.ptr(x), nx, ns, dev.stream_ptr(x)))
+    x2 = torch.zeros((nx, 2 * ns), dtype=torch.float32, device=x.device)
+    x2[:, 0::2] = x
+    y = plan.apply(x2)[:, 0::2].contiguous()
+    return dev.like_input(y, trace)
+
+
 def _fk_apply(trace, fk_filter_matrix, tapering):
     if getattr(trace, "ndim", 0) != 2:
         raise ValueError("trace must be a 2-D [channel x time] array")
     nx, ns = trace.shape
+    if ns % 2:
+        return _fk_apply_odd(trace, fk_filter_matrix, tapering)
     device = trace.device if dev.is_tensor(trace) and trace.is_cuda else None
     plan = get_fk_plan(nx, ns, device)
     plan.set_mask(fk_filter_matrix)

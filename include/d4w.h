@@ -217,7 +217,8 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
  * column range the reference's loop runs over (np.argmax(f >= ...), host).
  * d4w_gaussian_filter_f32 = scipy.ndimage.gaussian_filter(., sigma) (truncate 4, reflect), used at
  * dsp.py:540,659,940; d4w_flip_sum_f32 = M + fliplr(M), then + flipud (dsp.py:660-661);
- * d4w_minmax_normalise_f32 = (g - min)/(max - min) in place (dsp.py:945), synchronises `stream`.
+ * d4w_minmax_normalise_f32 = (g - min)/(max - min) in place (dsp.py:945), synchronises `stream`; a constant g
+ * gives NaN everywhere like NumPy's 0 / 0.
  * ------------------------------------------------------------------------------------------ */
 int d4w_design_mask_f32(int mode, int nx, int ns, double k_spacing, double t_spacing,
                         const double* params8_host, int i0, int i1, const double* hrow_dev,

@@ -1,0 +1,121 @@
+"""The scenarios of the reference's own unit tests (tests/test_dsp.py, tests/test_detect.py of
+leabouffaut/DAS4Whales) run against this package on the GPU: same tiny inputs (including odd lengths and
+integer arrays), same expectations -- lengths / shapes everywhere, values where the reference pins them
+(test_dsp.py:85-88 taper, :136-141 SNR) -- plus the oracle's values for the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available()
+    import das4whales_amd as dw_
+    return dw_
+
+
+def close(a, b, tol=1e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b)) <= tol * max(np.max(np.abs(b)), 1e-30)
+
+
+# ---------------------------------------------------------------- tests/test_detect.py
+def test_chirps_and_template_lengths(dw):                       # test_detect.py:5-41
+    assert len(dw.detect.gen_linear_chirp(100, 1000, 1, 44100)) == 44100
+    assert len(dw.detect.gen_hyperbolic_chirp(100, 1000, 1, 44100)) == 44100
+    time = np.linspace(0, 1, 44100)
+    assert len(dw.detect.gen_template_fincall(time, 44100, 15, 25, 1, True)) == len(time)
+
+
+def test_shift_xcorr_and_nxcorr_five_samples(dw):              # test_detect.py:44-61
+    x, y = np.array([1, 2, 3, 4, 5]), np.array([5, 4, 3, 2, 1])
+    r = dw.detect.shift_xcorr(x, y)
+    assert len(r) == len(x) and close(r, orc.shift_xcorr(x.astype(float), y.astype(float)))
+    r = dw.detect.shift_nxcorr(x, y)
+    assert len(r) == len(x) and close(r, orc.shift_nxcorr(x.astype(float), y.astype(float)))
+
+
+def test_compute_cross_correlogram_two_rows_of_five(dw):       # test_detect.py:64-71
+    x = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]])
+    y = np.array([5, 4, 3, 2, 1])
+    r = dw.detect.compute_cross_correlogram(x, y)
+    assert len(r) == len(x) and r.shape == x.shape
+    assert close(r, orc.compute_cross_correlogram(x.astype(float), y.astype(float)))
+
+
+def test_pick_times_and_convert(dw):                            # test_detect.py:74-94
+    x = np.array([[1, 2, 3, 2, 1], [1, 2, 3, 2, 1]])
+    r = dw.detect.pick_times(x, 3)
+    assert len(r) == 2
+    import scipy.signal as sp
+    for c in range(2):
+        assert np.array_equal(r[c], sp.find_peaks(x[c].astype(float), prominence=3)[0])
+    conv = dw.detect.convert_pick_times(x)                      # the reference feeds the 2-D array itself
+    assert len(conv) == 2 and np.array_equal(np.asarray(conv), np.asarray(orc.convert_pick_times(x)))
+
+
+# ---------------------------------------------------------------- tests/test_dsp.py
+@pytest.mark.parametrize("design,kw", [
+    ("fk_filter_design", dict(cs_min=1400, cp_min=1450, cp_max=3400, cs_max=3500)),
+    ("hybrid_filter_design", dict(cs_min=1400, cp_min=1450, fmin=15, fmax=25)),
+    ("hybrid_ninf_filter_design", dict(cs_min=1400, cp_min=1450, cp_max=3400, cs_max=3500, fmin=15, fmax=25)),
+    ("hybrid_gs_filter_design", dict(cs_min=1400, cp_min=1450, fmin=15, fmax=25)),
+    ("hybrid_ninf_gs_filter_design", dict(cs_min=1400, cp_min=1450, cp_max=3400, cs_max=3500, fmin=15, fmax=25)),
+])
+def test_designs_ten_by_ten(dw, design, kw):                    # test_dsp.py:21-83
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = getattr(dw.dsp, design)((10, 10), [0, 1, 2], 1, 100, *kw.values())
+        ref = getattr(orc, design)((10, 10), [0, 1, 2], 1, 100, *kw.values())
+    assert m.shape == (10, 10)
+    dense = np.asarray(m.todense() if hasattr(m, "todense") else m, dtype=np.float64)
+    ref = np.asarray(ref.todense() if hasattr(ref, "todense") else ref, dtype=np.float64)
+    assert np.max(np.abs(dense - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_taper_data_values(dw):                                 # test_dsp.py:85-88
+    trace = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=float)
+    out = dw.dsp.taper_data(trace)
+    assert np.allclose(out, np.array([[0, 2, 3, 4, 0], [0, 2, 3, 4, 0]]))
+    assert np.allclose(trace, out)                              # in place, like the reference
+
+
+def test_butterworth_filter_sections(dw):                       # test_dsp.py:104-109
+    b, a = dw.dsp.butterworth_filter([4, 1000, 'lp'], 10000)
+    assert len(b) == 6 and len(a) == 6
+
+
+def test_instant_freq_five_samples(dw):                         # test_dsp.py:111-115
+    channel = np.array([1, 2, 3, 4, 5])
+    f = dw.dsp.instant_freq(channel, 10)
+    assert len(f) == len(channel) - 1 and close(f, orc.instant_freq(channel.astype(float), 10), 1e-5)
+
+
+def test_fk_filt_two_by_five(dw):                               # test_dsp.py:125-134 (odd record length)
+    data = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=float)
+    out = dw.dsp.fk_filt(data, 0.1, 1, 0.1, 1, 1400, 3500)
+    assert np.shape(out) == np.shape(data)
+    ref = orc.fk_filt(data, 0.1, 1, 0.1, 1, 1400, 3500)
+    assert np.all(np.isfinite(out)) == np.all(np.isfinite(ref))
+    if np.all(np.isfinite(ref)):
+        assert close(out, ref)
+
+
+def test_fk_filter_odd_record_lengths(dw):
+    """Odd ns (the reference's test_fk_filt uses 5 samples): exact via zero interleaving."""
+    rng = np.random.default_rng(5)
+    for nx, ns in ((2, 5), (12, 75), (40, 405)):
+        x, m = rng.standard_normal((nx, ns)), rng.random((nx, ns))
+        assert close(dw.dsp.fk_filter_filt(x, m), orc.fk_filter_filt(x, m))
+        assert close(dw.dsp.fk_filter_filt(x, m, tapering=True), orc.fk_filter_filt(x, m, tapering=True))
+
+
+def test_snr_tr_array_values(dw):                               # test_dsp.py:136-141
+    trace = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=float)
+    snr = dw.dsp.snr_tr_array(trace)
+    assert np.allclose(snr, np.array([[-3.01029996, 3.01029996, 6.53212514, 9.03089987, 10.96910013]] * 2), atol=2e-5)
