@@ -119,3 +119,10 @@ def test_snr_tr_array_values(dw):                               # test_dsp.py:13
     trace = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=float)
     snr = dw.dsp.snr_tr_array(trace)
     assert np.allclose(snr, np.array([[-3.01029996, 3.01029996, 6.53212514, 9.03089987, 10.96910013]] * 2), atol=2e-5)
+
+
+def test_raw2strain_two_by_five(dw):                            # tests/test_data_handle.py:29-34
+    trace = np.array([[1, 2, 3, 4, 5], [1, 2, 3, 4, 5]], dtype=float)
+    result = dw.data_handle.raw2strain(trace, {"scale_factor": 1000})
+    assert result.shape == trace.shape
+    assert close(result, (trace - trace.mean(axis=1, keepdims=True)) * 1000)
