@@ -161,3 +161,18 @@ def test_channel_count_too_long_for_bluestein_tile(emu):
     plan = ctypes.c_void_p()
     assert emu.d4w_fk_plan_create(4099, 16, ctypes.byref(plan)) != 0           # prime > 4096
     assert b"supported_length" in emu.d4w_last_error()
+
+
+@pytest.mark.parametrize("nx,ns", [(2, 5), (6, 15), (9, 27)])
+def test_odd_record_length_by_zero_interleaving(emu, nx, ns):
+    """What dsp._fk_apply_odd does for odd ns: z[2n] = x[n], z[2n+1] = 0 filtered with the mask repeated twice
+    along f (time axis back on the unshifted grid) returns y interleaved with zeros."""
+    rng = np.random.default_rng(ns)
+    x, m = rng.standard_normal((nx, ns)), rng.random((nx, ns))
+    mu = np.roll(m, -(ns // 2), axis=1)
+    x2 = np.zeros((nx, 2 * ns))
+    x2[:, ::2] = x
+    y2 = fk_emu(emu, x2, np.concatenate((mu, mu), axis=1))
+    ref = orc.fk_filter_filt(x, m)
+    assert rel(y2[:, ::2], ref) < TOL
+    assert np.max(np.abs(y2[:, 1::2])) < TOL * np.max(np.abs(ref))
