@@ -173,7 +173,9 @@ def main():
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="8000x24000")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask f-k timing")
+    ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask / hybrid_ninf f-k timings")
+    ap.add_argument("--prune-eps", type=float, default=4e-6,
+                    help="opt-in tail pruning threshold of the fk_hybrid_ninf_pruned block (relative to the mask maximum)")
     ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
     ap.add_argument("--no-fused-stats", action="store_true",
                     help="matched-filter row statistics by a separate pass over the filtered block instead of the f-k epilogue")
@@ -353,20 +355,31 @@ def main():
         roofline.update({"fk_algorithmic_GBps": fk_gbs, "fk_algorithmic_frac": fk_gbs / HBM_PEAK_GBS,
                          "fk_only_samples_per_s": samples / (float(acc.sum()) * 1e-3),
                          "fk_live_wavenumber_rows": live_rows})
-        if live_rows < nx and not args.no_dense:
-            # the same filter with a fully dense mask (nothing skipped), for reference
-            dm = torch.rand((nx, ns), dtype=torch.float32, device=device, generator=gen)
-            plan.set_mask(dm)
-            del dm
-            accd = np.zeros(5)
+        def time_mask(m, **set_kw):
+            """The same filter with another mask: five pass times (HIP events) and the 24 B/sample fraction."""
+            plan.set_mask(m, **set_kw)
+            accm = np.zeros(5)
             plan.apply(x, out=y)
-            for _ in range(max(2, args.steps // 2)):
+            nrep = max(2, args.steps // 2)
+            for _ in range(nrep):
                 _, ms = plan.apply_timed(x, out=y)
-                accd += np.array(ms)
-            accd /= max(2, args.steps // 2)
-            roofline["fk_dense_mask"] = {"fk_filter_ms": float(accd.sum()),
-                                         "kernel_ms": {PASS_NAMES[i]: float(accd[i]) for i in range(5)},
-                                         "fk_algorithmic_frac": 24.0 * samples / (float(accd.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                accm += np.array(ms)
+            accm /= nrep
+            return {"fk_filter_ms": float(accm.sum()), "live_wavenumber_rows": plan.live_rows(),
+                    "kernel_ms": {PASS_NAMES[i]: float(accm[i]) for i in range(5)},
+                    "fk_algorithmic_frac": 24.0 * samples / (float(accm.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        if not args.no_dense:
+            # a fully dense mask (nothing skipped) and the design every reference script uses,
+            # hybrid_ninf_filter_design(1350, 1450, 3300, 3450, 14, 30) (scripts/main_mfdetect.py:46-47), exact and
+            # with the opt-in tail pruning (rows whose folded gain stays below prune_eps * max are treated as dead)
+            dm = torch.rand((nx, ns), dtype=torch.float32, device=device, generator=gen)
+            roofline["fk_dense_mask"] = time_mask(dm)
+            del dm
+            hm = dw.dsp.hybrid_ninf_filter_design((nx, ns), [0, nx, 1], dx, fs, 1350., 1450., 3300, 3450, 14., 30.)
+            roofline["fk_hybrid_ninf"] = time_mask(hm)
+            roofline["fk_hybrid_ninf_pruned"] = dict(time_mask(hm, prune_eps=args.prune_eps), prune_eps=args.prune_eps)
+            del hm
 
     if rank == 0:
         out = {"metric": "channel-samples/sec through " + " + ".join(

@@ -24,6 +24,8 @@ def to_device_f32(x, device=None):
     if is_tensor(x):
         if not x.is_cuda:
             x = x.to(device or "cuda")
+        elif device is not None and x.device != torch.device(device):
+            x = x.to(device)              # a tensor on another GPU: the kernels run on `device`
         return x.to(torch.float32).contiguous()
     a = np.asarray(x)
     if a.dtype != np.float32:

@@ -34,6 +34,7 @@ def _load():
         "d4w_fk_plan_destroy": (c_int, [c_void_p]),
         "d4w_fk_plan_info": (c_int, [c_void_p, P(c_int)]),
         "d4w_fk_set_mask_dense_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
+        "d4w_fk_set_mask_dense_pruned_f32": (c_int, [c_void_p, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_fk_plan_live_rows": (c_int, [c_void_p]),
         "d4w_fk_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fk_apply_timed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(ctypes.c_float)]),

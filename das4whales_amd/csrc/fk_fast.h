@@ -89,11 +89,12 @@ struct FkPrefetchA {          // what one thread prefetches for one pass-A tile
 
 template <class G, bool TAPER>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* __restrict__ src,
-                                                         float2* __restrict__ dst, int tbase, int ntiles) {
+                                                         float2* __restrict__ dst, int tbase, int ntiles, int sw, int sbase) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
-    constexpr int NBX = G::N2 / G::TA;
+    // tile u -> (c2 = u / sw, column block sbase + u % sw): sw = N2 / TA, sbase = 0 is the plain order; a slab
+    // (sbase, sw) restricts the pass to sw column blocks of every n1 sub-row (see fkf_passC)
     const int tid = threadIdx.x;
     const int hi = tid / G::TA, tt = tid % G::TA;      // hi = n1 (S1) or q (S2)
     const bool act1 = hi < G::N1, act2 = hi < G::C1;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
     typedef FkPrefetchA<G::C1> Pre;
     Pre A, B;       // two register sets, see fkf_passC
     auto issue = [&](Pre& R, int t) {
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         if (act1) {
             const int col = hi * G::N2 + b0 + tt;
             const float2* p = src + (size_t)c2 * G::M + col;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
     // iteration) could not be consumed before those stores were acknowledged -- the store latency of a
     // write-heavy pass then sat on the loop's critical path.
     auto body = [&](Pre& R, int t) {
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         float2* tw_cur = twl + par * (G::N1 * G::TA);
         if (act1) {
             if (TAPER) {
@@ -175,11 +176,10 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
 // of iteration i) and is written to the other half of the strip double buffer before the first
 // barrier of iteration i+... see the body: it is in LDS one full iteration before it is read.
 template <class G>
-__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int tbase, int ntiles) {
+__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int tbase, int ntiles, int sw, int sbase) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
-    constexpr int NBX = G::N2 / G::TA;
     constexpr int STRIP = G::N1 * G::TA;
     const int tid = threadIdx.x;
     const int hi = tid / G::TA, tt = tid % G::TA;      // hi = q (S1') or n1 (S2'); also q1 for the strip
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
     typedef FkPrefetchA<G::N1> Pre;
     Pre A, B;
     auto issue = [&](Pre& R, int t) {                   // data + W_nx value + strip element of tile t
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         // strip element FIRST: it is consumed one iteration before the data, and vmcnt retires
         // loads in order -- waiting for the oldest load of a set does not wait for the rest
         if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
     int par = 0;
     // strip of tile i lives in twl[par(i)]: written during iteration i-1 (before its first barrier)
     auto body = [&](Pre& R, Pre& Rn, int t, bool first) {
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         const float2* tw_cur = twl + par * STRIP;
         const bool more = (t + gstep < ntiles);
         if (first) {                                    // very first tile of this workgroup
@@ -266,11 +266,10 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
 template <class G>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* __restrict__ data, int run, int nruns,
                                                                float* __restrict__ rowmean,
-                                                               unsigned* __restrict__ rowmaxbits) {
+                                                               unsigned* __restrict__ rowmaxbits, int sw, int sbase) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
-    constexpr int NBX = G::N2 / G::TA;
     constexpr int STRIP = G::N1 * G::TA;
     const int tid = threadIdx.x;
     const int hi = tid / G::TA, tt = tid % G::TA;
@@ -284,7 +283,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
     typedef FkPrefetchA<G::N1> Pre;
     Pre A, B;
     auto issue = [&](Pre& R, int t) {
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
         if (act1) {
             const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
     int par = 0;
     auto body = [&](Pre& R, Pre& Rn, int sq, bool first) {
         const int t = tile_of(sq);
-        const int c2 = t / NBX, b0 = (t % NBX) * G::TA;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         const float2* tw_cur = twl + par * STRIP;
         const bool more = (sq + 1 < nseq);
         if (first) {
@@ -379,11 +378,15 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
 // LDS row index c2 + c2 / C2B (one pad row per C2B rows) keeps the S2 reads conflict-free.
 // ---------------------------------------------------------------------------------------------
 template <class G, bool INV>
-__global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int ntiles) {
+__global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int ntiles,
+                                                     int sw, int sbase) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C2A * (G::C2B + 1) * G::TC;
-    constexpr int NBX = G::M / G::TC;
+    // tile u -> (q, n1, column block): u = (q N1 + n1) sw + j covers the column blocks sbase + j, j < sw, of every
+    // n1 sub-row; sw = N2 / TC, sbase = 0 is the plain order q (M / TC) + block.  A slab (sbase, sw) holds the
+    // same columns as the pass-A tiles with the same (sbase, sw): the two passes can then run slab by slab.
+    constexpr int NBS = G::N2 / G::TC;
     constexpr int RA = G::C2A, RB = G::C2B, TC = G::TC;
     const int tid = threadIdx.x;
     const int hi = tid / TC, tt = tid % TC;            // hi = j (radix-RA items) or g (radix-RB items)
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     // by two so that the sets swap roles without copies.
     float2 pfA[NPF], pfB[NPF];
     auto issue = [&](float2 (&pf)[NPF], int t) {
-        const int q = t / NBX, p0 = (t % NBX) * TC;
+        const int hq = t / sw, q = hq / G::N1, p0 = ((hq - q * G::N1) * NBS + sbase + t % sw) * TC;
         const float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
         if constexpr (!INV) {
             static_for<RA>([&](auto aa) {
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     const bool act_second = INV ? actA : actB;
     const int gstep = gridDim.x;
     auto body = [&](float2 (&pf)[NPF], int t) {
-        const int q = t / NBX, p0 = (t % NBX) * TC;
+        const int hq = t / sw, q = hq / G::N1, p0 = ((hq - q * G::N1) * NBS + sbase + t % sw) * TC;
         float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
         if (D4W_ABL == 4) {          // timing ablation: stream the tile through registers only
             if (act_first) {

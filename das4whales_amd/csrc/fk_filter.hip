@@ -411,34 +411,77 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* 
                                                           const int* __restrict__ k1_of_q1,
                                                           const int* __restrict__ k2_of_i,
                                                           float* __restrict__ mask,
-                                                          float* __restrict__ nyq) {
+                                                          float* __restrict__ nyq, unsigned* __restrict__ rowmaxbits) {
     const int r = blockIdx.y;
     const int k = rowk[r];
     const int km = (d.nx - k) % d.nx;
     const int sx = d.nx / 2, st = d.ns / 2;
     const size_t rowp = (size_t)((k + sx) % d.nx) * d.ns;    // shifted-grid row of +k
     const size_t rowm = (size_t)((km + sx) % d.nx) * d.ns;   // shifted-grid row of -k
+    unsigned vbits = 0u;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.M; p += gridDim.x * blockDim.x) {
         const int q1 = p / d.N2, i = p - q1 * d.N2;
         const int f = k1_of_q1[q1] + d.N1 * k2_of_i[i];
         const int fm = (d.ns - f) % d.ns;
         const float v = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
         mask[(size_t)r * d.M + p] = v;
+        vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int f = d.M, fm = d.ns - d.M;
-        nyq[r] = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+        const float v = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+        nyq[r] = v;
+        vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
+    if (vbits) atomicMax(rowmaxbits + r, vbits);
 }
 
-// live[r] = 1 when the folded mask of row position r has any non-zero entry (incl. the Nyquist column)
-__global__ __launch_bounds__(kThreads) void fk_row_live(FkDims d, const float* __restrict__ mask,
-                                                         const float* __restrict__ nyq, int* __restrict__ live) {
-    const int r = blockIdx.x;
-    const float* row = mask + (size_t)r * d.M;
-    bool any = (threadIdx.x == 0) && (nyq[r] != 0.f);
-    for (int p = threadIdx.x; p < d.M; p += blockDim.x) any |= (row[p] != 0.f);
-    if (any) live[r] = 1;       // same value from every writer
+// The same fold with both sides of the permutation coalesced (the gather above reads 4 useful bytes per 64-byte
+// sector: 178 GB of traffic and 23 ms at 20000 x 120000).  The first radix R0 of the n2 transform carries the LOWEST
+// digit d0 of k2 and the HIGHEST of the position: k2 = d0 + R0 k2'(i'), i = d0 (N2 / R0) + i'.  So for one i' the
+// frequencies f = k1 + N1 k2 over all (k1, d0) form ONE contiguous run of RL = N1 R0 samples of the mask row
+// (and a reversed run of the partner row), and for one (k1, d0) the positions of IB consecutive i' are contiguous.
+// Tile = (row r, all k1, all d0, IB consecutive i'): runs in, LDS transpose [RL][IB + 1], runs out.
+// Also leaves max |M_h| of every row (Nyquist column included) in rowmaxbits -- liveness and the opt-in tail pruning.
+__global__ __launch_bounds__(kThreads) void fk_fold_mask_tiled(FkDims d, int R0, int IB, const float* __restrict__ ms,
+                                                                const int* __restrict__ rowk,
+                                                                const int* __restrict__ q1_of_k1,
+                                                                const int* __restrict__ k2_of_i,
+                                                                float* __restrict__ mask, float* __restrict__ nyq,
+                                                                unsigned* __restrict__ rowmaxbits) {
+    D4W_DYN_LDS(smem_raw);
+    float* buf = reinterpret_cast<float*>(smem_raw);
+    const int r = blockIdx.y;
+    const int k = rowk[r];
+    const int km = (d.nx - k) % d.nx;
+    const int sx = d.nx / 2, st = d.ns / 2;
+    const float* rowp = ms + (size_t)((k + sx) % d.nx) * d.ns + st;    // + f : M(+k, f),  0 <= f < M
+    const float* rowm = ms + (size_t)((km + sx) % d.nx) * d.ns + st;   // - f : M(-k, -f)
+    const int RL = d.N1 * R0, N2r = d.N2 / R0, pitch = IB + 1;
+    const int ib0 = blockIdx.x * IB, nb = min(IB, N2r - ib0);
+    // max |M_h| as the bit pattern of |v|: unsigned order = value order, and a NaN gain (above +inf) keeps its
+    // row alive like NumPy would
+    unsigned vbits = 0u;
+    for (int w = threadIdx.x; w < RL * nb; w += blockDim.x) {
+        const int j = w / RL, u = w - j * RL;
+        const int f = u + RL * (k2_of_i[ib0 + j] / R0);
+        const float v = 0.5f * (rowp[f] + rowm[-f]);
+        vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
+        buf[u * pitch + j] = v;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < RL * nb; w += blockDim.x) {
+        const int u = w / nb, j = w - u * nb;
+        const int d0 = u / d.N1, k1 = u - d0 * d.N1;
+        mask[(size_t)r * d.M + (size_t)q1_of_k1[k1] * d.N2 + d0 * N2r + ib0 + j] = buf[u * pitch + j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float v = 0.5f * (rowp[d.M - d.ns] + rowm[d.M - d.ns]);   // f = M (Nyquist): shifted column 0 of both rows
+        nyq[r] = v;
+        vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
+    }
+    for (int off = 32; off >= 1; off >>= 1) vbits = max(vbits, __shfl_xor(vbits, off));
+    if ((threadIdx.x & 63) == 0 && vbits) atomicMax(rowmaxbits + r, vbits);
 }
 
 __global__ __launch_bounds__(kThreads) void taper_rows(float* __restrict__ x, const float* __restrict__ win,
@@ -475,12 +518,12 @@ struct FkFastEntry {
     int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
     size_t ldsA, ldsC, ldsB;
     int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
-    void (*A_fwd)(FkDev, const float2*, float2*, int, int);
-    void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int);
-    void (*A_inv)(FkDev, float2*, int, int);
-    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*);
-    void (*C_fwd)(FkDev, FkFastDev, float2*, int, int);
-    void (*C_inv)(FkDev, FkFastDev, float2*, int, int);
+    void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int);
+    void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int);
+    void (*A_inv)(FkDev, float2*, int, int, int, int);
+    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int);
+    void (*C_fwd)(FkDev, FkFastDev, float2*, int, int, int, int);
+    void (*C_inv)(FkDev, FkFastDev, float2*, int, int, int, int);
     void (*B_mid)(FkDev, FkFastDev, float2*, int, int);
 };
 
@@ -554,12 +597,16 @@ struct d4w_fk_plan {
     FkFastDev fdev;
     // dead-row pruning of the specialised path (set per mask)
     std::vector<int2> h_pairs;             // full pass-B work list (host copy)
-    int* d_live = nullptr;                 // [nx] scratch of fk_row_live
+    unsigned* d_rowmax = nullptr;          // [nx] bit pattern of max |M_h| per row (fk_fold_mask_tiled)
+    int* d_q1_of_k1 = nullptr;             // [N1] position of time-axis digit k1
+    int fold_R0 = 0, fold_IB = 0;          // tiling of fk_fold_mask_tiled (0: the gather kernel)
+    double prune_eps = 0.0;                // tail pruning of the current mask (0 = exact)
     unsigned* d_livebits = nullptr;        // [C1][C2A]
     int2* d_pairs_live = nullptr;          // [npairs] compacted list
     int npairs_run = 0;                    // pairs the specialised pass B runs
     int live_rows = 0;
     int wgA = 1, wgC = 1, wgB = 1;
+    int slab_sw = 0;                       // > 0: passes A/C and C'/A' run slab by slab, sw column blocks per slab
 };
 
 template <typename T>
@@ -799,10 +846,13 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         pl->live_rows = nx;
         pl->fdev.pairs = pl->dev.pairs;
         pl->fdev.live = nullptr;
+        {
+            void* q = nullptr;
+            if (hipMalloc(&q, (size_t)nx * sizeof(unsigned)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+            pl->allocs.push_back(q); pl->d_rowmax = (unsigned*)q;
+        }
         if (fast) {
             void* q = nullptr;
-            if (hipMalloc(&q, (size_t)nx * sizeof(int)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
-            pl->allocs.push_back(q); pl->d_live = (int*)q;
             if (hipMalloc(&q, (size_t)C1 * fast->C2A * sizeof(unsigned)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
             pl->allocs.push_back(q); pl->d_livebits = (unsigned*)q;
             if (hipMalloc(&q, pairs.size() * sizeof(int2)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
@@ -816,6 +866,17 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     D4W_TRY(upload(pl, rowk, &c_rowk));
     D4W_TRY(upload(pl, f_n1, &c_k1));
     D4W_TRY(upload(pl, f_n2, &c_k2));
+    {
+        const int* c_q1k;
+        D4W_TRY(upload(pl, p_n1, &c_q1k));
+        pl->d_q1_of_k1 = const_cast<int*>(c_q1k);
+        // tiling of the mask fold: runs of N1 * R0 samples in, IB positions out, transposed in <= 144 KiB of LDS
+        const int R0 = pl->dev.ax_n2.nstage > 0 ? pl->dev.ax_n2.radix[0] : 1;
+        const long RL = (long)N1 * R0;
+        int IB = (int)std::min<long>(64, 36864 / RL - 1);
+        IB = std::min(IB, N2 / R0);
+        if (IB >= 1) { pl->fold_R0 = R0; pl->fold_IB = IB; }
+    }
     pl->d_rowk = const_cast<int*>(c_rowk);
     pl->d_k1 = const_cast<int*>(c_k1);
     pl->d_k2 = const_cast<int*>(c_k2);
@@ -873,6 +934,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         pl->wgA = env_int("D4W_FK_WG_A", fast->wgA);
         pl->wgC = env_int("D4W_FK_WG_C", fast->wgC);
         pl->wgB = env_int("D4W_FK_WG_B", fast->wgB);
+        pl->slab_sw = env_int("D4W_FK_SLAB", 0);
     }
 #ifndef D4W_EMU
     {
@@ -922,27 +984,53 @@ int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
     return D4W_OK;
 }
 
-int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* stream) {
+static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
     if (!pl || !mask_shifted) return fail(D4W_EINVAL, "NULL argument");
+    if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
     const FkDims& d = pl->dev.d;
-    dim3 grid(std::min(ceil_div(d.M, kThreads), 64), d.nx);
-    D4W_LAUNCH(fk_fold_mask, grid, dim3(kThreads), 0, stream, d, mask_shifted, (const int*)pl->d_rowk,
-               (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq);
+    hipStream_t st = (hipStream_t)stream;
+    D4W_HIP(hipMemsetAsync(pl->d_rowmax, 0, (size_t)d.nx * sizeof(unsigned), st));
+    const char* gather = getenv("D4W_FK_FOLD_GATHER");
+    if (pl->fold_IB > 0 && !(gather && atoi(gather) > 0)) {
+        const int N2r = d.N2 / pl->fold_R0;
+        const size_t lds = (size_t)d.N1 * pl->fold_R0 * (pl->fold_IB + 1) * sizeof(float);
+#ifndef D4W_EMU
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)fk_fold_mask_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); });
+#endif
+        if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
+        D4W_LAUNCH(fk_fold_mask_tiled, dim3(ceil_div(N2r, pl->fold_IB), d.nx), dim3(kThreads), lds, stream, d, pl->fold_R0,
+                   pl->fold_IB, mask_shifted, (const int*)pl->d_rowk, (const int*)pl->d_q1_of_k1, (const int*)pl->d_k2,
+                   pl->d_mask, pl->d_nyq, pl->d_rowmax);
+    } else {
+        dim3 grid(std::min(ceil_div(d.M, kThreads), 64), d.nx);
+        D4W_LAUNCH(fk_fold_mask, grid, dim3(kThreads), 0, stream, d, mask_shifted, (const int*)pl->d_rowk,
+                   (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, pl->d_rowmax);
+    }
     pl->has_mask = true;
+    pl->prune_eps = prune_eps;
     pl->npairs_run = pl->npairs;
     pl->live_rows = d.nx;
     pl->fdev.pairs = pl->dev.pairs;
     pl->fdev.live = nullptr;
     const char* np = getenv("D4W_FK_NOPRUNE");
     if (pl->fast && !(np && atoi(np) > 0)) {
-        // rows whose folded mask (and whose Hermitian partner's) is identically zero
-        hipStream_t st = (hipStream_t)stream;
-        D4W_HIP(hipMemsetAsync(pl->d_live, 0, (size_t)d.nx * sizeof(int), st));
-        D4W_LAUNCH(fk_row_live, dim3(d.nx), dim3(kThreads), 0, stream, d, (const float*)pl->d_mask,
-                   (const float*)pl->d_nyq, pl->d_live);
-        std::vector<int> live(d.nx);
-        D4W_HIP(hipMemcpyAsync(live.data(), pl->d_live, (size_t)d.nx * sizeof(int), hipMemcpyDeviceToHost, st));
+        // Dead rows: a wavenumber row whose folded gains (and whose Hermitian partner's) are all zero -- exact -- or,
+        // opt-in, all below prune_eps * max |M_h| (the Butterworth tails of hybrid_ninf_filter_design, dsp.py:348-349,
+        // never reach zero: 7.7e-7 at fmax + 14 Hz; treating them as zero changes the output by at most that gain
+        // times the energy the input holds there)
+        std::vector<unsigned> rmax(d.nx);
+        D4W_HIP(hipMemcpyAsync(rmax.data(), pl->d_rowmax, (size_t)d.nx * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         D4W_HIP(hipStreamSynchronize(st));
+        float gmax = 0.f;
+        std::vector<float> rm(d.nx);
+        for (int r = 0; r < d.nx; ++r) {
+            memcpy(&rm[r], &rmax[r], sizeof(float));
+            if (rm[r] == rm[r] && rm[r] > gmax) gmax = rm[r];
+        }
+        const float thr = (float)(prune_eps * (double)gmax);
+        std::vector<int> live(d.nx);
+        for (int r = 0; r < d.nx; ++r) live[r] = !(rm[r] <= thr);             // NaN rows stay alive
         const int N1 = d.N1;
         std::vector<char> lv(d.nx, 0);
         std::vector<int2> run;
@@ -977,6 +1065,14 @@ int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* 
     return D4W_OK;
 }
 
+int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* stream) {
+    return fk_set_mask_impl(pl, mask_shifted, 0.0, stream);
+}
+
+int d4w_fk_set_mask_dense_pruned_f32(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
+    return fk_set_mask_impl(pl, mask_shifted, prune_eps, stream);
+}
+
 int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
 
 static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev,
@@ -997,33 +1093,67 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     hipStream_t st = (hipStream_t)stream;
     if (pl->fast) {
         const FkFastEntry& F = *pl->fast;
-        const int fA = (d.N2 / d.TA) * d.C2, fC = (d.M / d.TC) * d.C1;
+        const int NBX = d.N2 / d.TA, NBC = d.N2 / d.TC;
+        const int fA = NBX * d.C2, fC = (d.M / d.TC) * d.C1;
         const dim3 gA(std::min(fA, pl->num_cu * pl->wgA)), gC(std::min(fC, pl->num_cu * pl->wgC)),
             gB(std::max(1, std::min(pl->npairs_run, pl->num_cu * pl->wgB)));
         int rc;
 #define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
+        // row statistics in the epilogue of the last pass: tiles walked in runs of `run` (a divisor of the tiles
+        // per c2 of the pass / slab, so that a run stays on the same C1 rows)
+        auto stats_run = [](int per_c2) {
+            static const int run_env = [] { const char* v = getenv("D4W_FK_RUN_A"); return v ? atoi(v) : 30; }();
+            int run = 1;
+            for (int r = 1; r <= per_c2 && r <= std::max(run_env, 1); ++r) if (per_c2 % r == 0) run = r;
+            return run;
+        };
+        if (row_mean) {
+            D4W_HIP(hipMemsetAsync(row_mean, 0, (size_t)d.nx * sizeof(float), st));
+            D4W_HIP(hipMemsetAsync(row_maxabs, 0, (size_t)d.nx * sizeof(float), st));
+        }
+        const int sw = pl->slab_sw;
+        if (sw > 0 && d.TA == d.TC && NBX % sw == 0 && sw < NBX) {
+            // Slab order: passes A and C run back to back on one slab of sw column blocks of every n1
+            // sub-row (all channels x N1 sw TA columns), slab after slab, so that what pass A wrote is still in the
+            // 256 MiB Infinity Cache when pass C reads it -- and the same for C' -> A'.  Same kernels, same tiles,
+            // same arithmetic as the plain order; only the order of the tiles differs.
+            const int nslab = NBX / sw, nA = d.C2 * sw, nC = d.C1 * d.N1 * sw;
+            const dim3 gsA(std::min(nA, pl->num_cu * pl->wgA)), gsC(std::min(nC, pl->num_cu * pl->wgC));
+            D4W_MARK(0);
+            for (int sl = 0; sl < nslab; ++sl) {
+                if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gsA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, nA, sw, sl * sw))) return rc;
+                if ((rc = launch_k(F.C_fwd, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw))) return rc;
+            }
+            D4W_MARK(1);
+            D4W_MARK(2);
+            if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run))) return rc;
+            D4W_MARK(3);
+            const int run = stats_run(sw), nruns = nA / run;
+            for (int sl = 0; sl < nslab; ++sl) {
+                if ((rc = launch_k(F.C_inv, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw))) return rc;
+                if (row_mean) {
+                    if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
+                                       dst, run, nruns, row_mean, (unsigned*)row_maxabs, sw, sl * sw))) return rc;
+                } else if ((rc = launch_k(F.A_inv, gsA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, nA, sw, sl * sw))) return rc;
+            }
+            D4W_MARK(4);
+            D4W_MARK(5);
+            return D4W_OK;
+        }
         D4W_MARK(0);
-        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA))) return rc;
+        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0))) return rc;
         D4W_MARK(1);
-        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
+        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0))) return rc;
         D4W_MARK(2);
         if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run))) return rc;
         D4W_MARK(3);
-        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC))) return rc;
+        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0))) return rc;
         D4W_MARK(4);
         if (row_mean) {
-            // row statistics in the epilogue of the last pass: tiles walked in runs of `run` (a divisor of
-            // the tiles per c2, so that a run stays on the same C1 rows)
-            const int nbx = d.N2 / d.TA;
-            static const int run_env = [] { const char* v = getenv("D4W_FK_RUN_A"); return v ? atoi(v) : 30; }();
-            int run = 1;
-            for (int r = 1; r <= nbx && r <= std::max(run_env, 1); ++r) if (nbx % r == 0) run = r;
-            const int nruns = fA / run;
-            D4W_HIP(hipMemsetAsync(row_mean, 0, (size_t)d.nx * sizeof(float), st));
-            D4W_HIP(hipMemsetAsync(row_maxabs, 0, (size_t)d.nx * sizeof(float), st));
+            const int run = stats_run(NBX), nruns = fA / run;
             if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
-                               dst, run, nruns, row_mean, (unsigned*)row_maxabs))) return rc;
-        } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA))) return rc;
+                               dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0))) return rc;
+        } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0))) return rc;
         D4W_MARK(5);
 #undef D4W_MARK
         return D4W_OK;
@@ -1102,11 +1232,11 @@ int d4w_fk_debug_run_pass(d4w_fk_plan* pl, float* data, int pass, int t_begin, i
     const int n = t_end - t_begin;
     if (n <= 0) return D4W_OK;
     switch (pass) {
-        case 0: return launch_k(F.A_fwd, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, (const float2*)d2, d2, t_begin, t_end);
-        case 1: return launch_k(F.C_fwd, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end);
+        case 0: return launch_k(F.A_fwd, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, (const float2*)d2, d2, t_begin, t_end, P.d.N2 / P.d.TA, 0);
+        case 1: return launch_k(F.C_fwd, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end, P.d.N2 / P.d.TC, 0);
         case 2: return launch_k(F.B_mid, dim3(std::min(n, pl->num_cu * pl->wgB)), dim3(F.thrB), F.ldsB, stream, P, pl->fdev, d2, t_begin, t_end);
-        case 3: return launch_k(F.C_inv, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end);
-        case 4: return launch_k(F.A_inv, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, d2, t_begin, t_end);
+        case 3: return launch_k(F.C_inv, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end, P.d.N2 / P.d.TC, 0);
+        case 4: return launch_k(F.A_inv, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, d2, t_begin, t_end, P.d.N2 / P.d.TA, 0);
     }
     return fail(D4W_EINVAL, "pass %d", pass);
 }

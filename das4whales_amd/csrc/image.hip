@@ -74,11 +74,11 @@ __global__ __launch_bounds__(kImThreads) void threshold_gt(const float* __restri
         y[i] = ((double)x[i] > thr) ? 1.0f : 0.0f;
 }
 
-// y = x * (m != 0)    (array * bool mask, improcess.py:452)
+// y = x * m    (array * mask, improcess.py:452; bool masks arrive as 0 / 1 floats)
 __global__ __launch_bounds__(kImThreads) void mask_mul(const float* __restrict__ x, const float* __restrict__ m,
                                                        float* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * kImThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kImThreads)
-        y[i] = (m[i] != 0.0f) ? x[i] : 0.0f;
+        y[i] = x[i] * m[i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,15 +41,21 @@ class FkPlan:
         """Wavenumber rows the current mask keeps alive (nx = nothing is skipped), include/d4w.h."""
         return int(lib.d4w_fk_plan_live_rows(self._h))
 
-    def set_mask(self, fk_filter_matrix):
+    def set_mask(self, fk_filter_matrix, prune_eps=0.0):
         """Dense ndarray (any order / float dtype), sparse.COO-like (.todense()) or CUDA tensor,
-        on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return."""
+        on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return.
+        prune_eps > 0 (opt-in, not exact): wavenumber rows whose folded gains stay below
+        prune_eps * max are skipped like all-zero rows (include/d4w.h d4w_fk_set_mask_dense_pruned_f32)."""
         m = fk_filter_matrix
         if isinstance(m, DeviceMask):
             m = m.tensor
-        key = (id(m), getattr(m, "_version", None))
-        if self._mask_key == key and self._mask_ref is not None and self._mask_ref() is m:
+        # Only objects that carry a modification counter are cached (torch tensors, hence DeviceMask): a NumPy
+        # array or a sparse.COO edited in place (`mask *= w`) keeps its id(), so those are re-folded every call.
+        version = getattr(m, "_version", None) if dev.is_tensor(m) else None
+        key = (id(m), version, float(prune_eps)) if version is not None else None
+        if key is not None and self._mask_key == key and self._mask_ref is not None and self._mask_ref() is m:
             return
+        self._mask_ref, self._mask_key = None, None
         if hasattr(m, "todense") and not dev.is_tensor(m):
             md = m.todense()
         else:
@@ -60,13 +66,11 @@ class FkPlan:
                              % (self.nx, self.ns, shape))
         t = dev.to_device_f32(md, self.device)
         with torch.cuda.device(self.device):
-            check(lib.d4w_fk_set_mask_dense_f32(self._h, dev.ptr(t), dev.stream_ptr(t)))
+            check(lib.d4w_fk_set_mask_dense_pruned_f32(self._h, dev.ptr(t), float(prune_eps), dev.stream_ptr(t)))
             torch.cuda.current_stream().synchronize()   # t may be a temporary
-        try:
+        if key is not None:
             self._mask_ref = weakref.ref(m)
             self._mask_key = key
-        except TypeError:
-            self._mask_ref, self._mask_key = None, None
 
     def apply(self, x, out=None, taper=False):
         """x: float32 CUDA tensor [nx, ns]; returns the filtered tensor (out may alias x)."""
@@ -142,11 +146,12 @@ def get_fk_plan(nx, ns, device=None):
     device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
     key = (str(device), int(nx), int(ns))
     with _plans_lock:
-        p = _plans.get(key)
+        p = _plans.pop(key, None)
         if p is None:
-            if len(_plans) >= 4:          # plans hold an nx*ns/2 float mask each: keep few
+            if len(_plans) >= 4:          # plans hold an nx*ns/2 float mask each: keep few, drop the least recently used
                 _plans.pop(next(iter(_plans)))
-            p = _plans[key] = FkPlan(nx, ns, device=device)
+            p = FkPlan(nx, ns, device=device)
+        _plans[key] = p                   # (re-)insert at the most-recent end
         return p
 
 

@@ -58,6 +58,13 @@ int d4w_fk_plan_info(const d4w_fk_plan* plan, int* info8_host);
  * what `.real` at dsp.py:756,786 keeps -- and stores it in the plan's internal order.
  * Synchronises `stream` (the row-liveness scan of the folded mask is read back by the host). */
 int d4w_fk_set_mask_dense_f32(d4w_fk_plan* plan, const float* mask_shifted, void* stream);
+/* Same, with the OPT-IN tail pruning: wavenumber rows whose folded gains all stay at or below
+ * prune_eps * max|M_h| (together with their Hermitian partner row's) are treated as zero, i.e. dead
+ * (see d4w_fk_plan_live_rows).  hybrid_ninf_filter_design (dsp.py:348-406) multiplies every
+ * wavenumber row by Butterworth tails that never reach zero (7.7e-7 at fmax + 14 Hz), so its rows are
+ * all formally alive; prune_eps = 4e-6 keeps only the rows the speed band touches.  Not exact: the
+ * output changes by at most the pruned gain times the input's energy in those bins.  0 = exact. */
+int d4w_fk_set_mask_dense_pruned_f32(d4w_fk_plan* plan, const float* mask_shifted, double prune_eps, void* stream);
 
 /* Number of wavenumber rows (0..nx) the current mask keeps alive.  A row whose folded mask -- and
  * whose Hermitian partner's -- is identically zero is multiplied by zero whatever it holds; the

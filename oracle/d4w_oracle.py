@@ -136,6 +136,67 @@ def hybrid_ninf_filter_design(trace_shape, selected_channels, dx, fs, cs_min=140
     return M
 
 
+# --------------------------------------------------------------------------------------------
+# Pointwise evaluation of two designs at selected (row, column) indices of the SHIFTED grid -- for the
+# known-answer tests at shapes where the dense float64 mask (19 GB at 20 000 x 120 000) is not
+# affordable.  tests/test_oracle_pointwise.py pins them bit-exactly against the full designs above.
+# --------------------------------------------------------------------------------------------
+def fk_filter_design_at(trace_shape, selected_channels, dx, fs, ii, jj, cs_min=1400, cp_min=1450,
+                        cp_max=3400, cs_max=3500):
+    """fk_filter_design(...)[ii, jj] (dsp.py:140-161), ii / jj integer arrays of equal length."""
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    K, F = k[np.asarray(ii)], f[np.asarray(jj)]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.abs(F / K)
+        m = np.ones(s.shape)
+        up = (s >= cs_min) & (s <= cp_min)
+        m = np.where(up, np.sin(0.5 * np.pi * (s - cs_min) / (cp_min - cs_min)), m)
+        dn = (s >= cp_max) & (s <= cs_max)
+        m = np.where(dn, 1.0 - np.sin(0.5 * np.pi * (s - cp_max) / (cs_max - cp_max)), m)
+        m = np.where(s >= cs_max, 0.0, m)
+        m = np.where(s < cs_min, 0.0, m)
+    return np.where(np.abs(K) < 0.005, 0.0, m)
+
+
+def hybrid_ninf_filter_design_at(trace_shape, selected_channels, dx, fs, ii, jj, cs_min=1400.,
+                                 cp_min=1450., cp_max=3400, cs_max=3500, fmin=15., fmax=25.):
+    """hybrid_ninf_filter_design(...)[ii, jj] (dsp.py:348-406): with C the matrix before the flips,
+    M[i, j] = C[i, j] + C[i, ns-1-j] + C[nx-1-i, j] + C[nx-1-i, ns-1-j] (dsp.py:405-406)."""
+    k, f = _shifted_axes(trace_shape, selected_channels, dx, fs)
+    nx, ns = len(k), len(f)
+    b, a = sps.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp")              # dsp.py:348
+    H = np.concatenate((np.zeros(ns // 2),
+                        np.abs(sps.freqz(b, a, worN=ns // 2)[1]) ** 2))         # dsp.py:349
+    i0, i1 = _first_index_ge(f, fmin - 14.0), _first_index_ge(f, fmax + 14.0)   # dsp.py:354-360
+
+    def core(i, j):
+        K, fc = k[i], f[j]
+        ks_min, kp_min = fc / cs_max, fc / cp_max                               # dsp.py:381-382
+        ks_max, kp_max = fc / cs_min, fc / cp_min                               # dsp.py:384-385
+        col = np.zeros(K.shape)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            a_ = (ks_min != kp_min) & (K >= ks_min) & (K <= kp_min)             # dsp.py:388-391
+            col = np.where(a_, np.sin(0.5 * np.pi * (K - ks_min) / (kp_min - ks_min)), col)
+            b_ = (ks_max != kp_max) & (K >= kp_max) & (K <= ks_max)             # dsp.py:392-395
+            col = np.where(b_, -np.sin(0.5 * np.pi * (K - ks_max) / (ks_max - kp_max)), col)
+        col = np.where((K > kp_min) & (K < kp_max), 1.0, col)                   # dsp.py:399
+        inside = (j >= i0) & (j < i1)
+        return np.where(inside, H[j] * col, H[j])                               # dsp.py:372,402
+
+    i, j = np.asarray(ii), np.asarray(jj)
+    return (core(i, j) + core(i, ns - 1 - j)) + (core(nx - 1 - i, j) + core(nx - 1 - i, ns - 1 - j))
+
+
+def folded_gain_at(design_at, trace_shape, kx, kt):
+    """M_h(kx, kt) = (M'(kx, kt) + M'(-kx, -kt)) / 2 at UNSHIFTED integer bins: the gain
+    the reference's real(ifft2(fft2(x) M')) applies to cos(2 pi (kx c / nx + kt n / ns) + phi).
+    design_at(ii, jj) evaluates the mask at shifted-grid indices."""
+    nx, ns = trace_shape
+    kx, kt = np.asarray(kx), np.asarray(kt)
+    sh = lambda a, n: (a + n // 2) % n                                          # unshifted bin -> fftshift-ed index
+    return 0.5 * (design_at(sh(kx % nx, nx), sh(kt % ns, ns)) + design_at(sh((-kx) % nx, nx), sh((-kt) % ns, ns)))
+
+
 def hybrid_gs_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450.,
                             fmin=15., fmax=25.):
     """Box band x box |k| < f/cp_min, Gaussian-blurred (sigma 20) -- dsp.py:457-579."""

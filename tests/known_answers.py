@@ -1,0 +1,61 @@
+"""Closed-form answers of the f-k filter that are cheap at any size (test infrastructure).
+
+On-grid plane waves: for integer bins (kx, kt), 0 <= kt <= ns/2,
+    x[c, n] = sum_i a_i cos(2 pi (kx_i c / nx + kt_i n / ns) + phi_i)
+the reference's real(ifft2(fft2(x) * M')) (dsp.py:748-756) returns
+    y[c, n] = sum_i a_i M_h(kx_i, kt_i) cos(...),   M_h = (M'(k, f) + M'(-k, -f)) / 2   
+Unit impulse at (c0, n0): y[c, n] = Re ifft2(M')[c - c0, n - n0]."""
+import numpy as np
+
+
+def pick_plane_waves(nx, ns, sel, dx, fs, rng, n_waves=36):
+    """Bins spread over the pass band, the tapers, the stop band and the special rows / columns of the
+    speed-fan designs: returns integer arrays (kx, kt), amplitudes and phases."""
+    dk = 1.0 / (nx * sel[2] * dx)
+    df = fs / ns
+    kx, kt = [], []
+
+    def add_speed(speed, f_hz, sign):
+        j = int(round(f_hz / df))
+        i = int(round(f_hz / speed / dk))
+        if 0 < i < nx // 2 and 0 < j < ns // 2:
+            kx.append(i if sign > 0 else nx - i)
+            kt.append(j)
+    for speed in (1500.0, 2000.0, 2600.0, 3200.0):                 # inside the fan, inside 14-30 Hz
+        for f_hz in (16.0, 21.5, 27.0):
+            add_speed(speed, f_hz, +1 if len(kx) % 2 else -1)
+    for speed, f_hz in ((1425.0, 20.0), (3450.0, 24.0), (1380.0, 18.0), (3350.0, 22.0), (1440.0, 40.0),
+                        (2500.0, 8.0), (2500.0, 60.0), (900.0, 20.0), (6000.0, 20.0), (300.0, 3.0)):
+        add_speed(speed, f_hz, +1 if len(kx) % 2 else -1)         # tapers, stop band, out-of-band columns
+    kx += [0, nx // 2, 0, 1, nx - 1, nx // 3]                      # DC / Nyquist rows and columns
+    kt += [0, ns // 2, int(round(20.0 / df)), 0, ns // 2, 1]
+    while len(kx) < n_waves:                                       # anywhere
+        kx.append(int(rng.integers(0, nx)))
+        kt.append(int(rng.integers(0, ns // 2 + 1)))
+    kx, kt = np.array(kx), np.array(kt)
+    return kx, kt, rng.uniform(0.5, 2.0, len(kx)), rng.uniform(0, 2 * np.pi, len(kx))
+
+
+def wave_factors(nx, ns, kx, kt, ph):
+    """[nx, 2K] and [2K, ns] float64 factors with x = A @ diag(a, a) @ B, from
+    cos(alpha_c + beta_n) = cos alpha cos beta - sin alpha sin beta (phases reduced in integers)."""
+    c, n = np.arange(nx)[:, None], np.arange(ns)[None, :]
+    alpha = 2 * np.pi * ((kx[None, :] * c) % nx) / nx + ph[None, :]
+    beta = 2 * np.pi * ((kt[:, None] * n) % ns) / ns
+    A = np.concatenate((np.cos(alpha), -np.sin(alpha)), axis=1)
+    B = np.concatenate((np.cos(beta), np.sin(beta)), axis=0)
+    return A, B
+
+
+def impulse_response_rows(mask_rows_fn, nx, ns, rows):
+    """Rows `rows` of Re ifft2(M') for a real mask M' on the UNSHIFTED grid, in float64:
+    h[c, :] = Re ifft_n( (1/nx) sum_k M'[k, :] exp(2 pi i k c / nx) ).  mask_rows_fn(k0, k1) returns the
+    float64 rows k0:k1 of M' (so that the caller can stream a mask that does not fit in float64)."""
+    rows = np.asarray(rows)
+    acc = np.zeros((len(rows), ns), dtype=np.complex128)
+    step = 512
+    for k0 in range(0, nx, step):
+        k1 = min(nx, k0 + step)
+        ph = 2 * np.pi * ((np.arange(k0, k1)[None, :] * rows[:, None]) % nx) / nx
+        acc += np.exp(1j * ph) @ mask_rows_fn(k0, k1)
+    return np.fft.ifft(acc / nx, axis=1).real

@@ -176,3 +176,80 @@ def test_odd_record_length_by_zero_interleaving(emu, nx, ns):
     ref = orc.fk_filter_filt(x, m)
     assert rel(y2[:, ::2], ref) < TOL
     assert np.max(np.abs(y2[:, 1::2])) < TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("nx,ns,sw", [(18, 48, 1), (18, 48, 3), (100, 600, 1), (100, 600, 5), (8, 480, 2)])
+def test_slab_ordered_passes(emu, nx, ns, sw, monkeypatch):
+    """D4W_FK_SLAB: passes A/C and C'/A' run slab by slab (sw column blocks of every n1 sub-row per slab) so that
+    the intermediate stays in the Infinity Cache; same tiles, same arithmetic -> bit-identical output, incl. the row
+    statistics epilogue and dead-row skipping."""
+    rng = np.random.default_rng(nx + ns + sw)
+    x = np.ascontiguousarray(rng.standard_normal((nx, ns)) + 0.3, dtype=np.float32)
+    m = rng.random((nx, ns))
+    ks = np.fft.fftshift(np.arange(nx))
+    m[np.minimum(ks, nx - ks) > nx // 4, :] = 0.0
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    outs = []
+    for env in (None, str(sw)):
+        if env is None:
+            monkeypatch.delenv("D4W_FK_SLAB", raising=False)
+        else:
+            monkeypatch.setenv("D4W_FK_SLAB", env)
+        plan = ctypes.c_void_p()
+        assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+        assert emu.d4w_fk_set_mask_dense_f32(plan, vp(m), None) == 0
+        y, ys = np.empty_like(x), np.empty_like(x)
+        mean, mx = np.empty(nx, np.float32), np.empty(nx, np.float32)
+        assert emu.d4w_fk_apply_f32(plan, vp(x), vp(y), 1, None) == 0, emu.d4w_last_error()
+        assert emu.d4w_fk_apply_stats_f32(plan, vp(x), vp(ys), 1, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
+        emu.d4w_fk_plan_destroy(plan)
+        assert np.array_equal(y, ys)
+        outs.append((y, mean, mx))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert np.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-6 * np.abs(outs[0][0]).max())
+    assert rel(outs[1][0], orc.fk_filter_filt(x.astype(np.float64), m.astype(np.float64), tapering=True)) < TOL
+
+
+@pytest.mark.parametrize("nx,ns,opts", [(18, 48, None), (100, 600, None), (40, 480, None), (38, 406, [19, 2, 7, 29, 4, 4]),
+                                        (7, 14, None), (1, 64, None), (64, 2, None), (37, 48, None)])
+def test_tiled_mask_fold_equals_gather(emu, nx, ns, opts, monkeypatch):
+    """fk_fold_mask_tiled (coalesced runs + LDS transpose) against the plain gather kernel: the folded masks, hence
+    the filter outputs, are bit-identical."""
+    rng = np.random.default_rng(nx * 3 + ns)
+    x, m = rng.standard_normal((nx, ns)), rng.random((nx, ns))
+    monkeypatch.setenv("D4W_FK_FOLD_GATHER", "1")
+    y0 = fk_emu(emu, x, m, opts)
+    monkeypatch.delenv("D4W_FK_FOLD_GATHER")
+    y1 = fk_emu(emu, x, m, opts)
+    assert np.array_equal(y0, y1)
+    assert rel(y1, orc.fk_filter_filt(x, m)) < TOL
+
+
+def test_opt_in_tail_pruning(emu):
+    """d4w_fk_set_mask_dense_pruned_f32: rows whose folded gains stay below eps * max count as dead; eps = 0 is the
+    exact filter; the pruned output equals the filter with those rows zeroed."""
+    nx, ns = 100, 600
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    ks = np.fft.fftshift(np.arange(nx))
+    tail = np.minimum(ks, nx - ks) > nx // 5
+    m[tail, :] *= 1e-6                                  # "Butterworth tails": tiny but non-zero everywhere
+    emu.d4w_fk_set_mask_dense_pruned_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+    mf, xf = np.ascontiguousarray(m, np.float32), np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(xf)
+    assert emu.d4w_fk_set_mask_dense_pruned_f32(plan, vp(mf), 0.0, None) == 0
+    assert emu.d4w_fk_plan_live_rows(plan) == nx
+    assert emu.d4w_fk_set_mask_dense_pruned_f32(plan, vp(mf), 4e-6, None) == 0
+    live = emu.d4w_fk_plan_live_rows(plan)
+    assert live == nx - int(tail.sum())
+    assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) == 0
+    mz = m.copy()
+    mz[tail, :] = 0.0
+    assert rel(y, orc.fk_filter_filt(x, mz)) < TOL
+    assert rel(y, orc.fk_filter_filt(x, m)) < TOL      # and within tolerance of the exact filter on this input
+    assert emu.d4w_fk_set_mask_dense_pruned_f32(plan, vp(mf), -1.0, None) != 0
+    emu.d4w_fk_plan_destroy(plan)

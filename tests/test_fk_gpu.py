@@ -220,8 +220,8 @@ def test_apply_stats_bench_shape(dw):
 @pytest.mark.parametrize("nx,ns", [(4000, 12000), (11020, 12000), (5510, 12000)])
 def test_config_shapes_specialised_vs_generic(dw, nx, ns):
     """The 60-s file shapes (BASELINE configs[0..1]; the real OOI channel count 11020 = 20 x 19 x 29)
-    run shape-specialised kernels: same result as the generic five passes, pruned and unpruned, and a
-    row subset against the float64 oracle's channel-axis / time-axis separable identity check."""
+    run shape-specialised kernels: same result as the generic five passes, pruned and unpruned (the
+    independent known answers at these shapes are in tests/test_fk_known_gpu.py)."""
     gen = torch.Generator(device="cuda").manual_seed(nx)
     x = torch.randn((nx, ns), device="cuda", generator=gen)
     dense = torch.rand((nx, ns), device="cuda", generator=gen)

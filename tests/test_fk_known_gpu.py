@@ -1,0 +1,150 @@
+"""Known-answer parity tests of the f-k filter at the benchmarked configuration (20 000 x 120 000, the
+shape-specialised kernels BENCH times) and at the 60-s file shapes: answers that are independent of any
+other implementation of the filter (tests/known_answers.py), with the mask gains taken from the CPU
+oracle's pointwise evaluators (oracle/d4w_oracle.py, pinned in tests/test_oracle_pointwise.py).
+
+Reference: dsp.fk_filter_filt / fk_filter_sparsefilt dsp.py:725-786, designs dsp.py:85-171, 308-454,
+the scripts' call scripts/main_mfdetect.py:46-55.  Tolerance: max|y - y_ref| <= 1e-5 max|y_ref|."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+from tests import known_answers as ka
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DX, FS = 2.0419046878814697, 200.0
+NINF = dict(cs_min=1350., cp_min=1450., cp_max=3300, cs_max=3450, fmin=14., fmax=30.)   # scripts/main_mfdetect.py:46-47
+
+
+@pytest.fixture(scope="module")
+def dw():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import das4whales_amd as dw_
+    from das4whales_amd import _lib
+    assert "gfx950" in _lib.version()
+    torch.set_float32_matmul_precision("highest")
+    return dw_
+
+
+def _design(dw, kind, shape, sel):
+    if kind == "classic":
+        m = dw.dsp.fk_filter_design(shape, sel, DX, FS)
+        at = lambda i, j: orc.fk_filter_design_at(shape, sel, DX, FS, i, j)
+    else:
+        m = dw.dsp.hybrid_ninf_filter_design(shape, sel, DX, FS, NINF["cs_min"], NINF["cp_min"], NINF["cp_max"],
+                                             NINF["cs_max"], NINF["fmin"], NINF["fmax"])
+        at = lambda i, j: orc.hybrid_ninf_filter_design_at(shape, sel, DX, FS, i, j, **NINF)
+    return m, at
+
+
+def _plane_wave_check(plan, shape, sel, at, seed, host_rows=16):
+    """Filter a superposition of on-grid plane waves with `plan` (mask already set): the output must be the
+    same waves scaled by the oracle's folded gains -- on the whole block (float32 factors on the device)
+    and on `host_rows` rows in float64 on the host."""
+    nx, ns = shape
+    rng = np.random.default_rng(seed)
+    kx, kt, amp, ph = ka.pick_plane_waves(nx, ns, sel, DX, FS, rng)
+    g = orc.folded_gain_at(at, shape, kx, kt)
+    assert np.count_nonzero(g) >= 6 and np.count_nonzero(g == 0) >= 6
+    A, B = ka.wave_factors(nx, ns, kx, kt, ph)
+    A32, B32 = A.astype(np.float32), B.astype(np.float32)
+    Ad, Bd = torch.from_numpy(A32).cuda(), torch.from_numpy(B32).cuda()
+    x = (Ad * torch.from_numpy(np.tile(amp, 2).astype(np.float32)).cuda()) @ Bd
+    y = plan.apply(x)
+    del x
+    ref = (Ad * torch.from_numpy(np.tile(amp * g, 2).astype(np.float32)).cuda()) @ Bd
+    scale = float(ref.abs().max())
+    err_dev = float((y - ref).abs().max()) / scale
+    del ref
+    rows = np.unique(np.concatenate(([0, 1, nx // 2, nx - 1], rng.integers(0, nx, host_rows))))
+    ref64 = (A32[rows].astype(np.float64) * np.tile(amp * g, 2)) @ B32.astype(np.float64)
+    err_host = float(np.max(np.abs(y[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64) - ref64))) / scale
+    return err_dev, err_host, int(np.count_nonzero(g))
+
+
+def _impulse_check(plan, mask_tensor, shape, c0, n0, deltas):
+    """Unit impulse at (c0, n0): rows c0 + deltas of the output against Re ifft2(M') evaluated in float64
+    (channel-axis sum on the device in float64, time-axis inverse transform on the host)."""
+    nx, ns = shape
+    x = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    x[c0, n0] = 1.0
+    y = plan.apply(x)
+    del x
+    deltas = np.asarray(deltas)
+    rows = (c0 + deltas) % nx
+    accR = torch.zeros((len(deltas), ns), dtype=torch.float64, device="cuda")
+    accI = torch.zeros_like(accR)
+    dl = torch.from_numpy(deltas % nx).cuda()
+    for s0 in range(0, nx, 1024):                   # shifted-grid rows s0:s1 hold wavenumbers k = s - nx//2 (mod nx)
+        s1 = min(nx, s0 + 1024)
+        k = (torch.arange(s0, s1, device="cuda") - nx // 2) % nx
+        phase = 2 * np.pi * ((k[None, :] * dl[:, None]) % nx).double() / nx
+        m = mask_tensor[s0:s1].double()
+        accR += torch.cos(phase) @ m
+        accI += torch.sin(phase) @ m
+    G = (accR.cpu().numpy() + 1j * accI.cpu().numpy()) / nx
+    G = np.fft.ifftshift(G, axes=1)                  # time axis of the mask back to the unshifted grid
+    h = np.fft.ifft(G, axis=1).real
+    got = np.roll(y[torch.from_numpy(rows).cuda()].cpu().numpy().astype(np.float64), -n0, axis=1)
+    scale = float(y.abs().max())
+    assert abs(scale - np.max(np.abs(h))) < 1e-4 * scale          # the peak of the response sits in the checked rows
+    return float(np.max(np.abs(got - h))) / scale
+
+
+@pytest.mark.parametrize("kind", ["classic", "hybrid_ninf"])
+def test_bench_shape_plane_waves_and_impulse(dw, kind):
+    """20 000 x 120 000 with the masks of SURVEY 8(d): the specialised kernels (the only instantiation the
+    benchmark times) against closed-form answers."""
+    shape, sel = (20000, 120000), [0, 20000, 1]
+    mask, at = _design(dw, kind, shape, sel)
+    plan = dw.dsp.get_fk_plan(*shape)
+    plan.set_mask(mask)
+    live = plan.live_rows()
+    err_dev, err_host, npass = _plane_wave_check(plan, shape, sel, at, seed=20 + len(kind))
+    print("20000x120000 %s (%d live rows): plane waves, %d with non-zero gain: device %.3e host-f64 %.3e"
+          % (kind, live, npass, err_dev, err_host))
+    assert err_dev < TOL and err_host < TOL
+    err_imp = _impulse_check(plan, mask.tensor, shape, 12345, 67891, [0, 1, 2, 5, 40, 999, shape[0] // 2, shape[0] - 1, -7, 7654])
+    print("20000x120000 %s: unit impulse, 10 rows vs float64 Re ifft2(M): %.3e" % (kind, err_imp))
+    assert err_imp < TOL
+
+
+@pytest.mark.parametrize("nx,ns,step", [(4000, 12000, 4), (11020, 12000, 4), (5510, 12000, 8), (13223, 12000, 4)])
+@pytest.mark.parametrize("kind", ["classic", "hybrid_ninf"])
+def test_file_shapes_plane_waves(dw, nx, ns, step, kind):
+    """60-s file shapes (BASELINE configs[0..1], the real OOI selections incl. 13223 = 7 x 1889 channels):
+    plane waves against the oracle's gains, impulse rows against float64 Re ifft2(M)."""
+    shape, sel = (nx, ns), [0, nx * step, step]
+    mask, at = _design(dw, kind, shape, sel)
+    plan = dw.dsp.get_fk_plan(nx, ns)
+    plan.set_mask(mask)
+    err_dev, err_host, npass = _plane_wave_check(plan, shape, sel, at, seed=nx)
+    print("%dx%d %s: plane waves device %.3e host %.3e (%d passing)" % (nx, ns, kind, err_dev, err_host, npass))
+    assert err_dev < TOL and err_host < TOL
+    err_imp = _impulse_check(plan, mask.tensor, shape, nx // 3, 4321, [0, 1, 3, nx // 2, nx - 1, -2])
+    assert err_imp < TOL
+
+
+def test_mask_edited_in_place_is_refolded(dw):
+    """A NumPy mask modified in place between two calls must not reuse the folded copy of the first call
+    (round-1 bug: the plan cache keyed on id(mask))."""
+    rng = np.random.default_rng(5)
+    nx, ns = 40, 480
+    x = rng.standard_normal((nx, ns))
+    m = rng.uniform(size=(nx, ns))
+    y1 = dw.dsp.fk_filter_filt(x, m)
+    assert np.max(np.abs(y1 - orc.fk_filter_filt(x, m))) < TOL * np.max(np.abs(y1))
+    m *= 0.25
+    m[:, ::3] = 0.0
+    y2 = dw.dsp.fk_filter_filt(x, m)
+    ref2 = orc.fk_filter_filt(x, m)
+    assert np.max(np.abs(y2 - ref2)) < TOL * np.max(np.abs(ref2))
+    # a torch mask edited in place bumps its version counter: also re-folded
+    mt = torch.from_numpy(m.astype(np.float32)).cuda()
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    y3 = dw.dsp.fk_filter_filt(xt, mt)
+    mt.mul_(2.0)
+    y4 = dw.dsp.fk_filter_filt(xt, mt)
+    assert float((y4 - 2.0 * y3).abs().max()) < TOL * float(y4.abs().max())
