@@ -436,6 +436,7 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* 
     if (vbits) atomicMax(rowmaxbits + r, vbits);
 }
 
+constexpr int kFoldThreads = 1024;   // 16 waves per workgroup: the tile's loads are latency-bound with fewer in flight
 // The same fold with both sides of the permutation coalesced (the gather above reads 4 useful bytes per 64-byte
 // sector: 178 GB of traffic and 23 ms at 20000 x 120000).  The first radix R0 of the n2 transform carries the LOWEST
 // digit d0 of k2 and the HIGHEST of the position: k2 = d0 + R0 k2'(i'), i = d0 (N2 / R0) + i'.  So for one i' the
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* 
 // (and a reversed run of the partner row), and for one (k1, d0) the positions of IB consecutive i' are contiguous.
 // Tile = (row r, all k1, all d0, IB consecutive i'): runs in, LDS transpose [RL][IB + 1], runs out.
 // Also leaves max |M_h| of every row (Nyquist column included) in rowmaxbits -- liveness and the opt-in tail pruning.
-__global__ __launch_bounds__(kThreads) void fk_fold_mask_tiled(FkDims d, int R0, int IB, const float* __restrict__ ms,
+__global__ __launch_bounds__(kFoldThreads) void fk_fold_mask_tiled(FkDims d, int R0, int IB, const float* __restrict__ ms,
                                                                 const int* __restrict__ rowk,
                                                                 const int* __restrict__ q1_of_k1,
                                                                 const int* __restrict__ k2_of_i,
@@ -462,17 +463,21 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask_tiled(FkDims d, int R0,
     // max |M_h| as the bit pattern of |v|: unsigned order = value order, and a NaN gain (above +inf) keeps its
     // row alive like NumPy would
     unsigned vbits = 0u;
+    const FDiv dRL(RL);
+#pragma unroll 4
     for (int w = threadIdx.x; w < RL * nb; w += blockDim.x) {
-        const int j = w / RL, u = w - j * RL;
+        const int j = dRL.div(w), u = w - j * RL;
         const int f = u + RL * (k2_of_i[ib0 + j] / R0);
         const float v = 0.5f * (rowp[f] + rowm[-f]);
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
         buf[u * pitch + j] = v;
     }
     __syncthreads();
+    const FDiv dnb(nb), dN1(d.N1);
+#pragma unroll 4
     for (int w = threadIdx.x; w < RL * nb; w += blockDim.x) {
-        const int u = w / nb, j = w - u * nb;
-        const int d0 = u / d.N1, k1 = u - d0 * d.N1;
+        const int u = dnb.div(w), j = w - u * nb;
+        const int d0 = dN1.div(u), k1 = u - d0 * d.N1;
         mask[(size_t)r * d.M + (size_t)q1_of_k1[k1] * d.N2 + d0 * N2r + ib0 + j] = buf[u * pitch + j];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -873,7 +878,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
         // tiling of the mask fold: runs of N1 * R0 samples in, IB positions out, transposed in <= 144 KiB of LDS
         const int R0 = pl->dev.ax_n2.nstage > 0 ? pl->dev.ax_n2.radix[0] : 1;
         const long RL = (long)N1 * R0;
-        int IB = (int)std::min<long>(64, 36864 / RL - 1);
+        int IB = (int)std::min<long>(32, 16384 / RL - 1);          // <= 64 KiB of LDS: two 1024-thread workgroups per CU
         IB = std::min(IB, N2 / R0);
         if (IB >= 1) { pl->fold_R0 = R0; pl->fold_IB = IB; }
     }
@@ -999,7 +1004,7 @@ static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double p
         std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)fk_fold_mask_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); });
 #endif
         if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
-        D4W_LAUNCH(fk_fold_mask_tiled, dim3(ceil_div(N2r, pl->fold_IB), d.nx), dim3(kThreads), lds, stream, d, pl->fold_R0,
+        D4W_LAUNCH(fk_fold_mask_tiled, dim3(ceil_div(N2r, pl->fold_IB), d.nx), dim3(kFoldThreads), lds, stream, d, pl->fold_R0,
                    pl->fold_IB, mask_shifted, (const int*)pl->d_rowk, (const int*)pl->d_q1_of_k1, (const int*)pl->d_k2,
                    pl->d_mask, pl->d_nyq, pl->d_rowmax);
     } else {

@@ -34,6 +34,9 @@ class FileStream:
         self.fs, self.fmin, self.fmax = float(fs), float(fmin), float(fmax)
         self.halo = int(halo)
         self.taps = [detect._normalised_support(t) for t in templates]
+        # DC tail of a zero-padded full-length template (detect.py:158), applied per file exactly as
+        # detect.compute_cross_correlograms does (0 for support-only vectors)
+        self.tail = [detect._tail_coef(t) for t in templates]
         self.lmax = max((len(t) for t in self.taps), default=1)
         self.fk_mask = fk_mask
         self._raw = []          # raw files waiting for their right halo: [(index, tensor)]
@@ -69,10 +72,10 @@ class FileStream:
         if not self.taps:
             return out
         nx, ns = y.shape
+        from ._lib import lib, check
         with torch.cuda.device(y.device):
             mean = torch.empty(nx, dtype=torch.float32, device=y.device)
             mx = torch.empty(nx, dtype=torch.float32, device=y.device)
-            from ._lib import lib, check
             check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
         if next_head is not None and self.lmax > 1:
             # rows continue into the next file; the padding must enter de-meaned like the file's own
@@ -81,7 +84,13 @@ class FileStream:
         else:
             ext = y
         cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
-        out["correlograms"] = [c[:, :ns].contiguous() for c in cs]
+        cs = [c[:, :ns].contiguous() for c in cs]
+        for c, tp, coef in zip(cs, self.taps, self.tail):
+            if coef != 0.0 and abs(coef) * np.sqrt(ns) > detect.TAIL_THRESHOLD:
+                with torch.cuda.device(y.device):
+                    check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), float(coef), len(tp),
+                                                    dev.ptr(c), dev.stream_ptr(y)))
+        out["correlograms"] = cs
         return out
 
     # ------------------------------------------------------------------------------------------

@@ -59,3 +59,19 @@ def impulse_response_rows(mask_rows_fn, nx, ns, rows):
         ph = 2 * np.pi * ((np.arange(k0, k1)[None, :] * rows[:, None]) % nx) / nx
         acc += np.exp(1j * ph) @ mask_rows_fn(k0, k1)
     return np.fft.ifft(acc / nx, axis=1).real
+
+
+def assert_picks_match(got, ref_signal, thr, what=""):
+    """the pick index set must equal scipy.signal.find_peaks(ref_signal, prominence=thr)[0]
+    except for peaks whose float64 prominence lies within 1e-4 * thr of the threshold.  Every differing index is
+    inspected: it must be a local maximum of the reference signal and marginal in that sense."""
+    import scipy.signal as sps
+    ref_signal = np.asarray(ref_signal, dtype=np.float64)
+    ref = sps.find_peaks(ref_signal, prominence=thr)[0]
+    diff = sorted(set(int(i) for i in got) ^ set(int(i) for i in ref))
+    for i in diff:
+        assert 0 < i < len(ref_signal) - 1, (what, i, "differing pick at the row edge")
+        assert ref_signal[i] >= ref_signal[i - 1] and ref_signal[i] >= ref_signal[i + 1], (what, i, "differing pick is not a local maximum of the reference")
+        prom = float(sps.peak_prominences(ref_signal, [i])[0][0])
+        assert abs(prom - thr) <= 1e-4 * thr, (what, i, "differing pick is not marginal: prominence %.9g vs threshold %.9g" % (prom, thr))
+    return len(diff), len(ref)

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import d4w_oracle as orc
+from tests.known_answers import assert_picks_match
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -45,8 +46,12 @@ def test_snr_fx_ifreq_golden(dw, golden):
     assert fi.shape == g["ifreq"].shape
     d = np.abs(fi - g["ifreq"])
     d = np.minimum(d, np.abs(d - FS))                               # a +-pi phase step may take either sign
-    assert np.max(d) < 2e-3 * FS / 2
     z = orc.hilbert(x)
+    # the angle of z[i+1] conj(z[i]) is conditioned like 1 / |z|: the error is weighed by the smaller envelope
+    # sample of the pair relative to the row maximum (float32 analytic signal: absolute error ~1e-7 max|z|)
+    w = np.minimum(np.abs(z[3][1:]), np.abs(z[3][:-1])) / np.max(np.abs(z[3]))
+    assert np.max(d * w) < TOL * FS / 2
+    assert np.max(d[w > 0.05]) < 20 * TOL * FS / 2
     assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL
     assert rel(dw.dsp.hilbert_imag(x[7]), z[7].imag) < TOL
     xo = x[:, :475]                                                 # odd length: full complex transform
@@ -83,8 +88,8 @@ def test_envelope_long_rows(dw):
     thr = 3.0
     got = dw.detect.pick_times_env(x[:3], thr)
     for c in range(3):
-        refp = sps.find_peaks(orc.envelope(x[c]), prominence=thr)[0]
-        assert len(set(got[c]) ^ set(refp)) <= max(1, len(refp) // 200)
+        ndiff, nref = assert_picks_match(got[c], orc.envelope(x[c]), thr, "envelope picks, 120000-sample row %d" % c)
+        print("row %d: %d picks, %d marginal differences" % (c, nref, ndiff))
 
 
 def test_spectrograms_golden(dw, golden):
@@ -179,7 +184,9 @@ def test_pick_pipeline_config1(dw):
     a, b = _sets(got), _sets(ref_p)
     print("picks: %d vs %d reference, symmetric difference %d" % (len(a), len(b), len(a ^ b)))
     assert len(b) > 50
-    assert len(a ^ b) <= max(2, len(b) // 200)
+    env = orc.envelope(ref_c)
+    for ch in range(nx):                        # every differing pick must be marginal (prominence within 1e-4 thr of thr)
+        assert_picks_match(got[ch], env[ch], thr, "pipeline picks, channel %d" % ch)
 
 
 def test_detectors_on_long_rows(dw):
@@ -203,8 +210,8 @@ def test_detectors_on_long_rows(dw):
     picks = dw.detect.pick_times_env(c, thr)
     assert len(picks) == nx
     for i, r in enumerate(rows):
-        refp = sps.find_peaks(orc.envelope(ref_c[i]), prominence=thr)[0]
-        assert len(refp) >= 3 and len(set(picks[r]) ^ set(refp)) <= 1
+        ndiff, nref = assert_picks_match(picks[r], orc.envelope(ref_c[i]), thr, "long-row picks, row %d" % r)
+        assert nref >= 3
     sc = dw.detect.compute_cross_correlogram_spectrocorr(xt, FS, [14., 30.], KERNEL, 0.8, 0.95)
     assert tuple(sc.shape) == (nx, 1 + ns // 8)
     ref_sc = orc.compute_cross_correlogram_spectrocorr(x[rows], FS, [14., 30.], KERNEL, 0.8, 0.95)
