@@ -154,9 +154,10 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
                "config": {"workload": "ONE %d channels x %d samples float32 block sharded by channel block over %d GPU(s), "
                                       "classic f-k fan mask, stages %s%s" % (nx, ns, world, "+".join(stages),
                                                                              ", all-gather of the t-x output" if args.gather else ""),
-                          "plan": {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq},
+                          "plan": {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "packed": bool(plan.packed),
+                                   "exchange_row_chunks": plan.CHUNKS},
                           "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
-               "roofline": {"bound": "hbm", "kernel": "distributed step (generic pass kernels + exchange)",
+               "roofline": {"bound": "hbm", "kernel": "distributed step (%s pass kernels + exchange)" % ("shape-specialised" if plan.packed else "generic"),
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                             "traffic": None}}
         print(json.dumps(out), flush=True)
@@ -179,10 +180,14 @@ def main():
     ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
     ap.add_argument("--no-fused-stats", action="store_true",
                     help="matched-filter row statistics by a separate pass over the filtered block instead of the f-k epilogue")
-    ap.add_argument("--shard", type=str, default="replicas", choices=["replicas", "channel"],
-                    help="N > 1: 'replicas' = one independent block per GPU (default, weak scaling); 'channel' = ONE "
-                         "block sharded by channel block, exact distributed f-k filter (two all-to-alls), strong scaling")
-    ap.add_argument("--gather", action="store_true", help="--shard channel: all-gather the filtered t-x matrix each step")
+    ap.add_argument("--shard", type=str, default="auto", choices=["auto", "replicas", "channel"],
+                    help="'channel' = ONE block sharded by channel block over the GPUs: exact distributed f-k filter (two "
+                         "exchanges) + matched filter on the local rows + RCCL all-gather of the filtered t-x matrix -- "
+                         "BASELINE configs[3], strong scaling, the default for N > 1; 'replicas' = one independent block "
+                         "per GPU (no collective, weak scaling); auto = single-device step at N = 1, 'channel' otherwise")
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="--shard channel: all-gather the filtered t-x matrix each step (default when N > 1)")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
     args = ap.parse_args()
     stages = [t for t in args.stages.split(",") if t]
     assert set(stages) <= {"bp", "fk", "mf"} and stages, "--stages: comma list of bp, fk, mf"
@@ -192,6 +197,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.shard == "auto":
+        args.shard = "channel" if world > 1 else "replicas"
+    if args.gather is None:
+        args.gather = world > 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

@@ -46,6 +46,11 @@ def _load():
         "d4w_fkd_time_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fkd_chan_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
         "d4w_fkd_time_inv_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
+        "d4w_fkd_plan_is_packed": (c_int, [c_void_p]),
+        "d4w_fkd_time_fwd_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+        "d4w_fkd_time_inv_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+        "d4w_fkd_time_fwd_packed_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+        "d4w_fkd_time_inv_packed_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
         "d4w_fk_apply_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_fk_apply_timed_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                  P(ctypes.c_float)]),
@@ -84,6 +89,7 @@ def _load():
         "d4w_spectrocorr_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_int, c_void_p, c_void_p]),
         "d4w_find_peaks_f32": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_int, c_void_p]),
+        "d4w_pack_picks_i64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
         "d4w_minmax_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
         "d4w_scale_pixels_f32": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_threshold_f32": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, ctypes.c_double, c_void_p]),

@@ -35,7 +35,7 @@ struct FkFastCfg {
     static constexpr int N1 = N1_, NA = NA_, NB = NB_, NC = NC_, N2 = NA_ * NB_ * NC_, M = N1_ * NA_ * NB_ * NC_;
     static constexpr int TA = TA_, TC = TC_, THRA = THRA_, THRC = THRC_, THRB = THRB_;
     // pass A: tile [C1][N1][TA] + double-buffered four-step twiddle strip [2][N1][TA]
-    static constexpr size_t ldsA = (size_t)(C1 * N1 * TA + 2 * N1 * TA) * sizeof(float2);
+    static constexpr size_t ldsA = (size_t)(C1 * N1 * TA + 2 * N1 * TA) * sizeof(float2) + 2 * N1 * sizeof(int);
     // pass C: tile [(C2A)(C2B + 1)][TC] (one pad row per C2B rows) + twiddles [C2A][C2B]
     static constexpr size_t ldsC = (size_t)(C2A * (C2B + 1) * TC + (CTREE_ ? C2B : C2A * C2B)) * sizeof(float2) +
                                    (size_t)C1 * C2A * sizeof(unsigned);
@@ -59,6 +59,23 @@ struct FkFastDev {
     // not write it, pass B skips its pairs and pass C' reads zeros instead of memory.
     const unsigned* live; // [C1][C2A] bit b = row position q*C2 + g*C2B + b is live; NULL = all live
     const int2* pairs;    // pass-B work list actually run (all pairs, or the live ones)
+};
+
+// Runtime geometry of the distributed (channel-sharded) layouts, DESIGN.md 6.  The single-device passes (MODE 0)
+// ignore it: their pitches and strides are compile-time constants.
+//   MODE 1 of pass A  = TIME phase on the local rows [nrows][M]: the (c1, n1) tile keeps its shape but the c1
+//                       index walks C1 CONSECUTIVE rows and no channel transform is applied; sub-row q1 of every row
+//                       is written to / read from the PACKED exchange buffer, destination rank major:
+//                       element q1_off[q1] + row * q1_pitch[q1] (what the all-to-all sends without any repacking);
+//   MODE 2 of pass A  = c1 transform on the slab [nx][ncols] (all channels x the columns of the owned sub-rows): the
+//                       n1 index walks N1 ADJACENT column strips and no time transform is applied;
+//   MODE 1 of pass C / pass B = the same kernels on the slab (row pitch ncols, sub-rows keyed r * nq + jq).
+struct FkGeo {
+    int nrows, ncols;            // valid rows of the local block / columns of the slab
+    int nq;                      // owned sub-rows per channel (pass B), blocks per row (pass C)
+    const int* q1_off;           // [N1] MODE 1 of pass A
+    const int* q1_pitch;         // [N1]
+    const int* q1_of;            // [nq] pass B: n1 position of local sub-row jq
 };
 
 template <int R>
@@ -87,9 +104,10 @@ struct FkPrefetchA {          // what one thread prefetches for one pass-A tile
     float2 tc;                // W_nx^(c2 kc1(q)) of the thread's q
 };
 
-template <class G, bool TAPER>
+template <class G, bool TAPER, int MODE = 0>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* __restrict__ src,
-                                                         float2* __restrict__ dst, int tbase, int ntiles, int sw, int sbase) {
+                                                         float2* __restrict__ dst, int tbase, int ntiles, int sw, int sbase,
+                                                         FkGeo geo = FkGeo()) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
@@ -101,19 +119,47 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
     const int gstep = gridDim.x;
     typedef FkPrefetchA<G::C1> Pre;
     Pre A, B;       // two register sets, see fkf_passC
+    int* qtab = reinterpret_cast<int*>(twl + 2 * G::N1 * G::TA);     // MODE 1: [N1] offsets, [N1] pitches of the packed buffer
+    if constexpr (MODE == 1) {
+        for (int i = tid; i < G::N1; i += G::THRA) {
+            qtab[i] = geo.q1_off[i];
+            qtab[G::N1 + i] = geo.q1_pitch[i];
+        }
+        __syncthreads();
+    }
+    // element offset of (c1 index, tile) for the loads; MODE 0: row c1 C2 + c2 of [nx][M], column n1 N2 + b0 + tt
     auto issue = [&](Pre& R, int t) {
         const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         if (act1) {
-            const int col = hi * G::N2 + b0 + tt;
-            const float2* p = src + (size_t)c2 * G::M + col;
-            static_for<G::C1>([&](auto cc) {
-                constexpr int c1 = decltype(cc)::value;
-                R.pf[c1] = p[(size_t)c1 * G::C2 * G::M];
-            });
-            R.tw = P.twt[col];
-            if (TAPER) R.win = P.win[col];
+            if constexpr (MODE == 0) {
+                const int col = hi * G::N2 + b0 + tt;
+                const float2* p = src + (size_t)c2 * G::M + col;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    R.pf[c1] = p[(size_t)c1 * G::C2 * G::M];
+                });
+                R.tw = P.twt[col];
+                if (TAPER) R.win = P.win[col];
+            } else if constexpr (MODE == 1) {            // C1 consecutive local rows, group c2
+                const int col = hi * G::N2 + b0 + tt;
+                const float2* p = src + (size_t)c2 * G::C1 * G::M + col;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    R.pf[c1] = (c2 * G::C1 + c1 < geo.nrows) ? p[(size_t)c1 * G::M] : make_float2(0.f, 0.f);
+                });
+                R.tw = P.twt[col];
+                if (TAPER) R.win = P.win[col];
+            } else {                                     // slab: N1 adjacent strips of column block b0 / TA
+                const int col = (b0 / G::TA) * (G::N1 * G::TA) + hi * G::TA + tt;
+                const float2* p = src + (size_t)c2 * geo.ncols + col;
+                const bool ok = col < geo.ncols;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    R.pf[c1] = ok ? p[(size_t)c1 * G::C2 * geo.ncols] : make_float2(0.f, 0.f);
+                });
+            }
         }
-        if (act2) R.tc = P.twc[hi * G::C2 + c2];
+        if (MODE != 1 && act2) R.tc = P.twc[hi * G::C2 + c2];
     };
     int par = 0;
     // Two register sets, each prefetching TWO tiles ahead: tile t + 2 gstep is loaded into the set of tile t as
@@ -125,19 +171,19 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
         const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         float2* tw_cur = twl + par * (G::N1 * G::TA);
         if (act1) {
-            if (TAPER) {
+            if (TAPER && MODE != 2) {
                 static_for<G::C1>([&](auto cc) {
                     constexpr int c1 = decltype(cc)::value;
                     R.pf[c1].x *= R.win.x;
                     R.pf[c1].y *= R.win.y;
                 });
             }
-            dft<G::C1>(R.pf);
+            if constexpr (MODE != 1) dft<G::C1>(R.pf);
             static_for<G::C1>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 tile[(q * G::N1 + hi) * G::TA + tt] = R.pf[q];
             });
-            tw_cur[hi * G::TA + tt] = R.tw;
+            if constexpr (MODE != 2) tw_cur[hi * G::TA + tt] = R.tw;
         }
         const float2 tc_cur = R.tc;
         lds_barrier();
@@ -151,12 +197,30 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
         }
         lds_barrier();
         if (act2) {
-            dft<G::N1>(v);
-            float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
-            static_for<G::N1>([&](auto kk) {
-                constexpr int q1 = decltype(kk)::value;
-                o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur));
-            });
+            if constexpr (MODE == 0) {
+                dft<G::N1>(v);
+                float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    o[q1 * G::N2] = c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur));
+                });
+            } else if constexpr (MODE == 1) {
+                dft<G::N1>(v);
+                const int row = c2 * G::C1 + hi;
+                if (row < geo.nrows) {
+                    static_for<G::N1>([&](auto kk) {
+                        constexpr int q1 = decltype(kk)::value;
+                        dst[(size_t)qtab[q1] + (size_t)row * qtab[G::N1 + q1] + b0 + tt] = c_mul(v[q1], tw_cur[q1 * G::TA + tt]);
+                    });
+                }
+            } else {
+                const int colb = (b0 / G::TA) * (G::N1 * G::TA) + tt;
+                float2* o = dst + ((size_t)hi * G::C2 + c2) * geo.ncols + colb;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    if (colb + k * G::TA < geo.ncols) o[k * G::TA] = c_mul(v[k], tc_cur);
+                });
+            }
         }
         par ^= 1;
     };
@@ -175,8 +239,9 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
 // The W_M strip element of tile i+1 travels with the data prefetch of tile i+1 (issued at the top
 // of iteration i) and is written to the other half of the strip double buffer before the first
 // barrier of iteration i+... see the body: it is in LDS one full iteration before it is read.
-template <class G>
-__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int tbase, int ntiles, int sw, int sbase) {
+template <class G, int MODE = 0>
+__global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __restrict__ data, int tbase, int ntiles, int sw, int sbase,
+                                                         FkGeo geo = FkGeo(), const float2* __restrict__ packed = nullptr) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
@@ -187,18 +252,43 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
     const int gstep = gridDim.x;
     typedef FkPrefetchA<G::N1> Pre;
     Pre A, B;
+    int* qtab = reinterpret_cast<int*>(twl + 2 * STRIP);
+    if constexpr (MODE == 1) {
+        for (int i = tid; i < G::N1; i += G::THRA) {
+            qtab[i] = geo.q1_off[i];
+            qtab[G::N1 + i] = geo.q1_pitch[i];
+        }
+        __syncthreads();
+    }
     auto issue = [&](Pre& R, int t) {                   // data + W_nx value + strip element of tile t
         const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         // strip element FIRST: it is consumed one iteration before the data, and vmcnt retires
         // loads in order -- waiting for the oldest load of a set does not wait for the rest
-        if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
+        if (MODE != 2 && act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
         if (act1) {
-            const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
-            static_for<G::N1>([&](auto kk) {
-                constexpr int q1 = decltype(kk)::value;
-                R.pf[q1] = p[q1 * G::N2];
-            });
-            R.tc = P.twc[hi * G::C2 + c2];
+            if constexpr (MODE == 0) {
+                const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    R.pf[q1] = p[q1 * G::N2];
+                });
+                R.tc = P.twc[hi * G::C2 + c2];
+            } else if constexpr (MODE == 1) {            // sub-rows of local row c2 C1 + hi from the packed buffer
+                const int row = c2 * G::C1 + hi;
+                const bool ok = row < geo.nrows;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    R.pf[q1] = ok ? packed[(size_t)qtab[q1] + (size_t)row * qtab[G::N1 + q1] + b0 + tt] : make_float2(0.f, 0.f);
+                });
+            } else {                                     // slab row q C2 + c2, N1 adjacent strips
+                const int colb = (b0 / G::TA) * STRIP + tt;
+                const float2* p = data + ((size_t)hi * G::C2 + c2) * geo.ncols + colb;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    R.pf[k] = (colb + k * G::TA < geo.ncols) ? p[k * G::TA] : make_float2(0.f, 0.f);
+                });
+                R.tc = P.twc[hi * G::C2 + c2];
+            }
         }
     };
     int par = 0;
@@ -207,19 +297,34 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
         const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         const float2* tw_cur = twl + par * STRIP;
         const bool more = (t + gstep < ntiles);
-        if (first) {                                    // very first tile of this workgroup
-            if (act2) twl[par * STRIP + hi * G::TA + tt] = R.tw;
-            __syncthreads();
+        if constexpr (MODE != 2) {
+            if (first) {                                    // very first tile of this workgroup
+                if (act2) twl[par * STRIP + hi * G::TA + tt] = R.tw;
+                __syncthreads();
+            }
+            // the NEXT tile's registers were issued one iteration ago (or in the prologue): its strip
+            // element is already here, publish it; then start the loads of the tile after that
+            if (more && act2) twl[(par ^ 1) * STRIP + hi * G::TA + tt] = Rn.tw;
         }
-        // the NEXT tile's registers were issued one iteration ago (or in the prologue): its strip
-        // element is already here, publish it; then start the loads of the tile after that
-        if (more && act2) twl[(par ^ 1) * STRIP + hi * G::TA + tt] = Rn.tw;
         if (act1) {
-            static_for<G::N1>([&](auto kk) {
-                constexpr int q1 = decltype(kk)::value;
-                R.pf[q1] = c_mulc(R.pf[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
-            });
-            idft<G::N1>(R.pf);
+            if constexpr (MODE == 0) {
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    R.pf[q1] = c_mulc(R.pf[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
+                });
+                idft<G::N1>(R.pf);
+            } else if constexpr (MODE == 1) {
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    R.pf[q1] = c_mulc(R.pf[q1], tw_cur[q1 * G::TA + tt]);
+                });
+                idft<G::N1>(R.pf);
+            } else {
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    R.pf[k] = c_mulc(R.pf[k], R.tc);
+                });
+            }
             static_for<G::N1>([&](auto kk) {
                 constexpr int n1 = decltype(kk)::value;
                 tile[(hi * G::N1 + n1) * G::TA + tt] = R.pf[n1];
@@ -237,12 +342,30 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
         }
         lds_barrier();
         if (act2) {
-            idft<G::C1>(v);
-            float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
-            static_for<G::C1>([&](auto cc) {
-                constexpr int c1 = decltype(cc)::value;
-                o[(size_t)c1 * G::C2 * G::M] = c_scale(v[c1], P.scale);
-            });
+            if constexpr (MODE == 0) {
+                idft<G::C1>(v);
+                float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    o[(size_t)c1 * G::C2 * G::M] = c_scale(v[c1], P.scale);
+                });
+            } else if constexpr (MODE == 1) {            // C1 consecutive local rows, no channel transform
+                float2* o = data + (size_t)c2 * G::C1 * G::M + hi * G::N2 + b0 + tt;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    if (c2 * G::C1 + c1 < geo.nrows) o[(size_t)c1 * G::M] = c_scale(v[c1], P.scale);
+                });
+            } else {
+                idft<G::C1>(v);
+                const int col = (b0 / G::TA) * STRIP + hi * G::TA + tt;
+                if (col < geo.ncols) {
+                    float2* o = data + (size_t)c2 * geo.ncols + col;
+                    static_for<G::C1>([&](auto cc) {
+                        constexpr int c1 = decltype(cc)::value;
+                        o[(size_t)c1 * G::C2 * geo.ncols] = c_scale(v[c1], P.scale);
+                    });
+                }
+            }
         }
         par ^= 1;
     };
@@ -377,9 +500,9 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
 //   inverse : the same two steps backwards.
 // LDS row index c2 + c2 / C2B (one pad row per C2B rows) keeps the S2 reads conflict-free.
 // ---------------------------------------------------------------------------------------------
-template <class G, bool INV>
+template <class G, bool INV, int MODE = 0>
 __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int ntiles,
-                                                     int sw, int sbase) {
+                                                     int sw, int sbase, FkGeo geo = FkGeo()) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C2A * (G::C2B + 1) * G::TC;
@@ -398,24 +521,37 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     unsigned* livel = reinterpret_cast<unsigned*>(twl + (G::CTREE ? RB : RA * RB));
     for (int i = tid; i < G::C1 * RA; i += G::THRC) livel[i] = F.live ? F.live[i] : 0xFFFFFFFFu;
     __syncthreads();
+    // MODE 1 (slab [nx][geo.ncols]): tile u -> (q = u / geo.nq, column block u % geo.nq), row pitch geo.ncols
+    auto PITCH = [&]() -> size_t { return MODE == 0 ? (size_t)G::M : (size_t)geo.ncols; };
+    auto tile_qp = [&](int t, int& q, int& p0) {
+        if constexpr (MODE == 0) {
+            const int hq = t / sw;
+            q = hq / G::N1;
+            p0 = ((hq - q * G::N1) * NBS + sbase + t % sw) * TC;
+        } else {
+            q = t / geo.nq;
+            p0 = (t - q * geo.nq) * TC;
+        }
+    };
     constexpr int NPF = INV ? RB : RA;
     // Two register sets, each prefetching TWO tiles ahead (see fkf_passA_fwd): tile t + 2 gstep is loaded into
     // the set of tile t right after S1 has consumed it, before tile t's stores are issued; the loop is unrolled
     // by two so that the sets swap roles without copies.
     float2 pfA[NPF], pfB[NPF];
     auto issue = [&](float2 (&pf)[NPF], int t) {
-        const int hq = t / sw, q = hq / G::N1, p0 = ((hq - q * G::N1) * NBS + sbase + t % sw) * TC;
-        const float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
+        int q, p0;
+        tile_qp(t, q, p0);
+        const float2* base = data + ((size_t)q * G::C2) * PITCH() + p0 + tt;
         if constexpr (!INV) {
             static_for<RA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
-                pf[a] = base[(size_t)(hi + a * RB) * G::M];
+                pf[a] = base[(size_t)(hi + a * RB) * PITCH()];
             });
         } else {
             const unsigned bits = livel[q * RA + hi];       // dead rows are zeros by construction
             static_for<RB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                pf[b] = ((bits >> b) & 1u) ? base[(size_t)(hi * RB + b) * G::M] : make_float2(0.f, 0.f);
+                pf[b] = ((bits >> b) & 1u) ? base[(size_t)(hi * RB + b) * PITCH()] : make_float2(0.f, 0.f);
             });
         }
     };
@@ -423,14 +559,15 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     const bool act_second = INV ? actA : actB;
     const int gstep = gridDim.x;
     auto body = [&](float2 (&pf)[NPF], int t) {
-        const int hq = t / sw, q = hq / G::N1, p0 = ((hq - q * G::N1) * NBS + sbase + t % sw) * TC;
-        float2* base = data + ((size_t)q * G::C2) * G::M + p0 + tt;
+        int q, p0;
+        tile_qp(t, q, p0);
+        float2* base = data + ((size_t)q * G::C2) * PITCH() + p0 + tt;
         if (D4W_ABL == 4) {          // timing ablation: stream the tile through registers only
             if (act_first) {
                 static_for<NPF>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    if constexpr (!INV) base[(size_t)(hi + a * RB) * G::M] = pf[a];
-                    else base[(size_t)(hi * RB + a) * G::M] = pf[a];
+                    if constexpr (!INV) base[(size_t)(hi + a * RB) * PITCH()] = pf[a];
+                    else base[(size_t)(hi * RB + a) * PITCH()] = pf[a];
                 });
             }
             if (t + 2 * gstep < ntiles && act_first) issue(pf, t + 2 * gstep);
@@ -479,7 +616,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 const unsigned bits = livel[q * RA + hi];   // dead rows are never read again
                 static_for<RB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    if ((bits >> b) & 1u) base[(size_t)(hi * RB + b) * G::M] = v[b];
+                    if ((bits >> b) & 1u) base[(size_t)(hi * RB + b) * PITCH()] = v[b];
                 });
             } else {
                 float2 pw[RA];
@@ -491,7 +628,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 idft<RA>(v);
                 static_for<RA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    base[(size_t)(hi + a * RB) * G::M] = v[a];
+                    base[(size_t)(hi + a * RB) * PITCH()] = v[a];
                 });
             }
         }
@@ -516,8 +653,11 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
 //   S2', S1' : inverse of S2, S1; S1' feeds the global stores.
 // LDS position e lives at e + e / NC (one pad per group: the MID reads are conflict-free).
 // ---------------------------------------------------------------------------------------------
-template <class G>
-__global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int npairs) {
+// MODE 1 (slab): a pair key is r * geo.nq + jq (row position, local sub-row) instead of r * N1 + q1, and the n1 position
+// of local sub-row jq is geo.q1_of[jq]; data and mask are both laid out [nx][nq][N2].
+template <class G, int MODE = 0>
+__global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int npairs,
+                                                                 FkGeo geo = FkGeo()) {
     D4W_DYN_LDS(smem_raw);
     constexpr int N2 = G::N2, NA = G::NA, NB = G::NB, NC = G::NC, M1 = NB * NC, NG = NA * NB, ROWP = G::ROWP;
     constexpr int THR = G::THRB;
@@ -564,9 +704,19 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         float2 wr;
     };
     MidOps cur, nxt;
+    auto split = [&](int key, int& rpos, int& q1) {      // pair key -> (row position, n1 position)
+        if constexpr (MODE == 0) {
+            rpos = key / G::N1;
+            q1 = key - rpos * G::N1;
+        } else {
+            rpos = key / geo.nq;
+            q1 = geo.q1_of[key - rpos * geo.nq];
+        }
+    };
     auto issue_mid = [&](MidOps& O, int2 pr) {
         if (!midrange) return;
-        const int rpos = pr.x / G::N1, q1 = pr.x - rpos * G::N1;
+        int rpos, q1;
+        split(pr.x, rpos, q1);
         const int PG = (q1 == 0) ? PGz : (NG - 1 - Gi);
         const float* mA = P.mask + (size_t)pr.x * N2 + Gi * NC;
         const float* mB = P.mask + (size_t)pr.y * N2 + PG * NC;
@@ -604,7 +754,8 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         if (t + 2 * gstep < npairs) pr_nn = F.pairs[t + 2 * gstep];
         const bool same = (pr.x == pr.y);
         const int nrows = same ? 1 : 2;
-        const int rpos = pr.x / G::N1, q1 = pr.x - rpos * G::N1;
+        int rpos, q1;
+        split(pr.x, rpos, q1);
         const bool k1zero = (q1 == 0);
         // ---------------- S1
         if (it1 && r1 < nrows) {

@@ -523,13 +523,22 @@ struct FkFastEntry {
     int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
     size_t ldsA, ldsC, ldsB;
     int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
-    void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int);
-    void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int);
-    void (*A_inv)(FkDev, float2*, int, int, int, int);
+    void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
+    void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
+    void (*A_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
     void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int);
-    void (*C_fwd)(FkDev, FkFastDev, float2*, int, int, int, int);
-    void (*C_inv)(FkDev, FkFastDev, float2*, int, int, int, int);
-    void (*B_mid)(FkDev, FkFastDev, float2*, int, int);
+    void (*C_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
+    void (*C_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
+    void (*B_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);
+    // distributed (channel-sharded) layouts, fk_fast.h FkGeo
+    void (*T_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);          // pass A MODE 1 (time phase)
+    void (*T_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
+    void (*T_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
+    void (*Ac_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);         // pass A MODE 2 (c1 transform on the slab)
+    void (*Ac_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
+    void (*Cs_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);             // pass C on the slab
+    void (*Cs_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
+    void (*Bs_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);                       // pass B on the slab
 };
 
 template <class G>
@@ -541,13 +550,21 @@ static FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0) {
     e.TA = G::TA; e.TC = G::TC; e.thrA = G::THRA; e.thrC = G::THRC; e.thrB = G::THRB;
     e.ldsA = G::ldsA; e.ldsC = G::ldsC; e.ldsB = G::ldsB;
     e.wgA = wgA; e.wgC = wgC; e.wgB = wgB;
-    e.A_fwd = fkf_passA_fwd<G, false>;
-    e.A_fwd_taper = fkf_passA_fwd<G, true>;
-    e.A_inv = fkf_passA_inv<G>;
+    e.A_fwd = fkf_passA_fwd<G, false, 0>;
+    e.A_fwd_taper = fkf_passA_fwd<G, true, 0>;
+    e.A_inv = fkf_passA_inv<G, 0>;
     e.A_inv_stats = fkf_passA_inv_stats<G>;
-    e.C_fwd = fkf_passC<G, false>;
-    e.C_inv = fkf_passC<G, true>;
-    e.B_mid = fkf_passB<G>;
+    e.C_fwd = fkf_passC<G, false, 0>;
+    e.C_inv = fkf_passC<G, true, 0>;
+    e.B_mid = fkf_passB<G, 0>;
+    e.T_fwd = fkf_passA_fwd<G, false, 1>;
+    e.T_fwd_taper = fkf_passA_fwd<G, true, 1>;
+    e.T_inv = fkf_passA_inv<G, 1>;
+    e.Ac_fwd = fkf_passA_fwd<G, false, 2>;
+    e.Ac_inv = fkf_passA_inv<G, 2>;
+    e.Cs_fwd = fkf_passC<G, false, 1>;
+    e.Cs_inv = fkf_passC<G, true, 1>;
+    e.Bs_mid = fkf_passB<G, 1>;
     return e;
 }
 
@@ -678,7 +695,15 @@ int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
     return D4W_OK;
 }
 
+static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool fast_only, d4w_fk_plan** out);
+
 int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
+    return fk_plan_build(nx, ns, opts, true, false, out);
+}
+
+// alloc_mask = false: tables only (the distributed plan keeps its own slab mask); fast_only: D4W_EINVAL unless the
+// shape has specialised kernels
+static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool fast_only, d4w_fk_plan** out) {
     if (!out) return fail(D4W_EINVAL, "plan pointer is NULL");
     *out = nullptr;
     if (nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad shape %d x %d", nx, ns);
@@ -701,6 +726,7 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
             for (const FkFastEntry& e : fast_shapes())
                 if (e.nx == nx && e.ns == ns && (e.variant == want || (!fast && e.variant == 0))) fast = &e;
     }
+    if (fast_only && !fast) return fail(D4W_EINVAL, "no shape-specialised kernels for %d x %d", nx, ns);
     // admissible time splits: N1 | M with N2 = M / N1 fitting one LDS row pair
     int n1_min = 0;
     for (int cand = 1; cand <= M && !n1_min; ++cand)
@@ -899,13 +925,15 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
     D4W_TRY(upload(pl, winp, &pl->dev.win));
 
     void* p = nullptr;
-    if (hipMalloc(&p, (size_t)nx * M * sizeof(float)) != hipSuccess) {
-        d4w_fk_plan_destroy(pl);
-        return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte mask failed", (size_t)nx * M * sizeof(float));
+    if (alloc_mask) {
+        if (hipMalloc(&p, (size_t)nx * M * sizeof(float)) != hipSuccess) {
+            d4w_fk_plan_destroy(pl);
+            return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte mask failed", (size_t)nx * M * sizeof(float));
+        }
+        pl->allocs.push_back(p);
+        pl->d_mask = (float*)p;
+        pl->dev.mask = pl->d_mask;
     }
-    pl->allocs.push_back(p);
-    pl->d_mask = (float*)p;
-    pl->dev.mask = pl->d_mask;
     if (hipMalloc(&p, (size_t)nx * sizeof(float)) != hipSuccess) {
         d4w_fk_plan_destroy(pl);
         return fail(D4W_ENOMEM, "hipMalloc failed");
@@ -955,6 +983,12 @@ int d4w_fk_plan_create_ex(int nx, int ns, const int* opts, d4w_fk_plan** out) {
             (void)hipFuncSetAttribute((const void*)fast->C_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->C_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->B_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
+            const void* fa[] = {(const void*)fast->T_fwd, (const void*)fast->T_fwd_taper, (const void*)fast->T_inv,
+                                (const void*)fast->Ac_fwd, (const void*)fast->Ac_inv};
+            for (const void* f : fa) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
+            (void)hipFuncSetAttribute((const void*)fast->Cs_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+            (void)hipFuncSetAttribute((const void*)fast->Cs_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+            (void)hipFuncSetAttribute((const void*)fast->Bs_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
         }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
         if (!fast && lds_max > 64 * 1024) {
@@ -990,7 +1024,7 @@ int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
 }
 
 static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
-    if (!pl || !mask_shifted) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
     const FkDims& d = pl->dev.d;
     hipStream_t st = (hipStream_t)stream;
@@ -1126,39 +1160,39 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
             const dim3 gsA(std::min(nA, pl->num_cu * pl->wgA)), gsC(std::min(nC, pl->num_cu * pl->wgC));
             D4W_MARK(0);
             for (int sl = 0; sl < nslab; ++sl) {
-                if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gsA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, nA, sw, sl * sw))) return rc;
-                if ((rc = launch_k(F.C_fwd, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw))) return rc;
+                if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gsA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, nA, sw, sl * sw, FkGeo()))) return rc;
+                if ((rc = launch_k(F.C_fwd, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw, FkGeo()))) return rc;
             }
             D4W_MARK(1);
             D4W_MARK(2);
-            if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run))) return rc;
+            if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run, FkGeo()))) return rc;
             D4W_MARK(3);
             const int run = stats_run(sw), nruns = nA / run;
             for (int sl = 0; sl < nslab; ++sl) {
-                if ((rc = launch_k(F.C_inv, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw))) return rc;
+                if ((rc = launch_k(F.C_inv, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw, FkGeo()))) return rc;
                 if (row_mean) {
                     if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
                                        dst, run, nruns, row_mean, (unsigned*)row_maxabs, sw, sl * sw))) return rc;
-                } else if ((rc = launch_k(F.A_inv, gsA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, nA, sw, sl * sw))) return rc;
+                } else if ((rc = launch_k(F.A_inv, gsA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, nA, sw, sl * sw, FkGeo(), (const float2*)nullptr))) return rc;
             }
             D4W_MARK(4);
             D4W_MARK(5);
             return D4W_OK;
         }
         D4W_MARK(0);
-        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0))) return rc;
+        if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0, FkGeo()))) return rc;
         D4W_MARK(1);
-        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0))) return rc;
+        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0, FkGeo()))) return rc;
         D4W_MARK(2);
-        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run))) return rc;
+        if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run, FkGeo()))) return rc;
         D4W_MARK(3);
-        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0))) return rc;
+        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0, FkGeo()))) return rc;
         D4W_MARK(4);
         if (row_mean) {
             const int run = stats_run(NBX), nruns = fA / run;
             if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
                                dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0))) return rc;
-        } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0))) return rc;
+        } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0, FkGeo(), (const float2*)nullptr))) return rc;
         D4W_MARK(5);
 #undef D4W_MARK
         return D4W_OK;
@@ -1237,11 +1271,11 @@ int d4w_fk_debug_run_pass(d4w_fk_plan* pl, float* data, int pass, int t_begin, i
     const int n = t_end - t_begin;
     if (n <= 0) return D4W_OK;
     switch (pass) {
-        case 0: return launch_k(F.A_fwd, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, (const float2*)d2, d2, t_begin, t_end, P.d.N2 / P.d.TA, 0);
-        case 1: return launch_k(F.C_fwd, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end, P.d.N2 / P.d.TC, 0);
-        case 2: return launch_k(F.B_mid, dim3(std::min(n, pl->num_cu * pl->wgB)), dim3(F.thrB), F.ldsB, stream, P, pl->fdev, d2, t_begin, t_end);
-        case 3: return launch_k(F.C_inv, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end, P.d.N2 / P.d.TC, 0);
-        case 4: return launch_k(F.A_inv, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, d2, t_begin, t_end, P.d.N2 / P.d.TA, 0);
+        case 0: return launch_k(F.A_fwd, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, (const float2*)d2, d2, t_begin, t_end, P.d.N2 / P.d.TA, 0, FkGeo());
+        case 1: return launch_k(F.C_fwd, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end, P.d.N2 / P.d.TC, 0, FkGeo());
+        case 2: return launch_k(F.B_mid, dim3(std::min(n, pl->num_cu * pl->wgB)), dim3(F.thrB), F.ldsB, stream, P, pl->fdev, d2, t_begin, t_end, FkGeo());
+        case 3: return launch_k(F.C_inv, dim3(std::min(n, pl->num_cu * pl->wgC)), dim3(F.thrC), F.ldsC, stream, P, pl->fdev, d2, t_begin, t_end, P.d.N2 / P.d.TC, 0, FkGeo());
+        case 4: return launch_k(F.A_inv, dim3(std::min(n, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P, d2, t_begin, t_end, P.d.N2 / P.d.TA, 0, FkGeo(), (const float2*)nullptr);
     }
     return fail(D4W_EINVAL, "pass %d", pass);
 }
@@ -1396,6 +1430,17 @@ struct d4w_fkd_plan {
     float* d_mask = nullptr; float* d_nyq = nullptr;
     bool has_mask = false;
     int num_cu = 256;
+    // ---- packed path: the shape has specialised kernels (fk_fast.h, FkGeo).  The exchange buffers need no repacking:
+    //      the time phase writes sub-row q1 of local row l at  blk_off[owner[q1]] + l * nq[owner] * N2 + jq(q1) * N2
+    //      (destination rank major), so that the all-to-all delivers the slab [nx][nq][N2] as it stands.
+    d4w_fk_plan* sp = nullptr;              // tables of the single-device plan of the whole shape (no mask of its own)
+    FkDev dev_t, dev_c;                     // time-phase / channel-phase argument blocks
+    FkFastDev fdev_c;
+    FkGeo geo_t, geo_c;
+    std::vector<int2> h_pairs_slab;         // pass-B work list in slab keys r * nq + jq
+    int2* d_pairs_slab = nullptr; int2* d_pairs_live = nullptr;
+    unsigned* d_livebits = nullptr; unsigned* d_rowmax = nullptr;
+    int npairs_run = 0, live_rows = 0;
 };
 
 static void fkd_block(int nx, int world, int r, int* a, int* b) {
@@ -1410,7 +1455,127 @@ int d4w_fkd_plan_destroy(d4w_fkd_plan* pl) {
     if (!pl) return D4W_OK;
     for (void* p : pl->tp.allocs) (void)hipFree(p);
     for (void* p : pl->cp.allocs) (void)hipFree(p);
+    if (pl->sp) d4w_fk_plan_destroy(pl->sp);
     delete pl;
+    return D4W_OK;
+}
+
+namespace d4w {
+// bit pattern of max |mask| over the owned sub-rows of every row position (slab mask [nx][W]) and its Nyquist gain
+__global__ __launch_bounds__(kThreads) void fkd_row_max(const float* __restrict__ mask, const float* __restrict__ nyq, int W,
+                                                         unsigned* __restrict__ rowmaxbits) {
+    const int r = blockIdx.x;
+    unsigned vb = (threadIdx.x == 0) ? (__float_as_uint(nyq[r]) & 0x7fffffffu) : 0u;
+    for (int p = threadIdx.x; p < W; p += blockDim.x) vb = max(vb, __float_as_uint(mask[(size_t)r * W + p]) & 0x7fffffffu);
+    for (int off = 32; off >= 1; off >>= 1) vb = max(vb, __shfl_xor(vb, off));
+    if ((threadIdx.x & 63) == 0 && vb) atomicMax(rowmaxbits + r, vb);
+}
+}  // namespace d4w
+
+// Packed path of the distributed plan: shapes with specialised kernels (fk_fast.h).  Returns D4W_EINVAL (and leaves
+// *out NULL) when the shape has none -- the caller then builds the generic plan.
+static int fkd_plan_build_packed(int nx, int ns, int world, int rank, bool want_mask, d4w_fkd_plan** out) {
+    *out = nullptr;
+    const char* g = getenv("D4W_FKD_GENERIC");
+    if (g && atoi(g) > 0) return fail(D4W_EINVAL, "generic distributed plan requested");
+    d4w_fk_plan* sp = nullptr;
+    int rc = fk_plan_build(nx, ns, nullptr, false, true, &sp);
+    if (rc) return rc;
+    const FkFastEntry& F = *sp->fast;
+    if (F.TA != F.TC || (F.NA * F.NB * F.NC) % (F.N1 * F.TA) != 0) {     // pass A MODE 2 walks N1 adjacent strips inside a sub-row
+        d4w_fk_plan_destroy(sp);
+        return fail(D4W_EINVAL, "shape config not usable for the packed distributed plan");
+    }
+    d4w_fkd_plan* pl = new d4w_fkd_plan();
+    pl->sp = sp;
+    const FkDims& d = sp->dev.d;
+    pl->nx = nx; pl->ns = ns; pl->M = d.M; pl->world = world; pl->rank = rank;
+    fkd_block(nx, world, rank, &pl->row_begin, &pl->row_end);
+    pl->N1 = d.N1; pl->N2 = d.N2; pl->C1 = d.C1; pl->C2 = d.C2; pl->TA_t = d.TA; pl->TA_c = d.TA; pl->TC = d.TC;
+    pl->num_cu = sp->num_cu;
+    const int N1 = d.N1, N2 = d.N2, nxl = pl->row_end - pl->row_begin;
+    // ownership of the n1-positions (single radix: position = frequency digit): Hermitian classes {q1, N1 - q1} dealt
+    // to the least loaded rank
+    pl->owner.assign(N1, -1);
+    {
+        std::vector<int> load(world, 0);
+        for (int q1 = 0; q1 < N1; ++q1) {
+            if (pl->owner[q1] >= 0) continue;
+            int best = 0;
+            for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+            const int qp = (N1 - q1) % N1;
+            pl->owner[q1] = best; ++load[best];
+            if (qp != q1) { pl->owner[qp] = best; ++load[best]; }
+        }
+    }
+    std::vector<int> nq_of(world, 0), jq_of(N1, 0);
+    for (int q1 = 0; q1 < N1; ++q1) jq_of[q1] = nq_of[pl->owner[q1]]++;
+    for (int q1 = 0; q1 < N1; ++q1) if (pl->owner[q1] == rank) pl->myq.push_back(q1);
+    const int nq = (int)pl->myq.size();
+    const long W = (long)std::max(nq, 1) * N2;
+    if ((long)nx * W >= (1L << 31) || (long)nxl * d.M >= (1L << 31)) {
+        d4w_fkd_plan_destroy(pl);
+        return fail(D4W_EINVAL, "block too large for 32-bit element offsets");
+    }
+    // packed buffer layout of THIS rank's local rows
+    std::vector<int> qoff(N1), qpitch(N1);
+    {
+        std::vector<long> blk(world + 1, 0);
+        for (int sr = 0; sr < world; ++sr) blk[sr + 1] = blk[sr] + (long)nxl * nq_of[sr] * N2;
+        for (int q1 = 0; q1 < N1; ++q1) {
+            const int o = pl->owner[q1];
+            qoff[q1] = (int)(blk[o] + (long)jq_of[q1] * N2);
+            qpitch[q1] = nq_of[o] * N2;
+        }
+    }
+    std::vector<int> myq = pl->myq;
+    if (myq.empty()) myq.push_back(0);
+    const int *c_qoff, *c_qpitch, *c_q1of;
+#define D4W_TRY(x) do { rc = (x); if (rc != D4W_OK) { d4w_fkd_plan_destroy(pl); return rc; } } while (0)
+    D4W_TRY(upload(sp, qoff, &c_qoff));
+    D4W_TRY(upload(sp, qpitch, &c_qpitch));
+    D4W_TRY(upload(sp, myq, &c_q1of));
+    pl->d_q1of = const_cast<int*>(c_q1of);
+    pl->geo_t = FkGeo{nxl, d.M, nq, c_qoff, c_qpitch, c_q1of};
+    pl->geo_c = FkGeo{nx, (int)W, (int)(W / d.TC), c_qoff, c_qpitch, c_q1of};     // pass C: nq = column blocks per row
+    pl->dev_t = sp->dev;
+    pl->dev_t.scale = 1.0f;
+    pl->dev_c = sp->dev;
+    // pass-B work list in slab keys
+    std::vector<int> jq_mine(N1, -1);
+    for (int j = 0; j < nq; ++j) jq_mine[pl->myq[j]] = j;
+    for (const int2& pr : sp->h_pairs) {
+        const int ra = pr.x / N1, qa = pr.x % N1, rb = pr.y / N1, qb = pr.y % N1;
+        if (jq_mine[qa] < 0) continue;
+        pl->h_pairs_slab.push_back(make_int2(ra * nq + jq_mine[qa], rb * nq + jq_mine[qb]));
+    }
+    {
+        const int2* c_pairs;
+        D4W_TRY(upload(sp, pl->h_pairs_slab, &c_pairs));
+        pl->d_pairs_slab = const_cast<int2*>(c_pairs);
+        void* q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(pl->h_pairs_slab.size(), 1) * sizeof(int2)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        sp->allocs.push_back(q); pl->d_pairs_live = (int2*)q;
+        if (hipMalloc(&q, (size_t)d.C1 * F.C2A * sizeof(unsigned)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        sp->allocs.push_back(q); pl->d_livebits = (unsigned*)q;
+        if (hipMalloc(&q, (size_t)nx * sizeof(unsigned)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        sp->allocs.push_back(q); pl->d_rowmax = (unsigned*)q;
+    }
+    pl->fdev_c = sp->fdev;
+    pl->fdev_c.pairs = pl->d_pairs_slab;
+    pl->fdev_c.live = nullptr;
+    pl->npairs_run = (int)pl->h_pairs_slab.size();
+    pl->live_rows = nx;
+    if (want_mask) {
+        void* q = nullptr;
+        if (hipMalloc(&q, (size_t)nx * W * sizeof(float)) != hipSuccess) { d4w_fkd_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc of the slab mask failed"); }
+        sp->allocs.push_back(q); pl->d_mask = (float*)q;
+        pl->d_nyq = sp->d_nyq;
+    }
+    pl->dev_c.mask = pl->d_mask;
+    pl->dev_c.nyq = pl->d_nyq;
+#undef D4W_TRY
+    *out = pl;
     return D4W_OK;
 }
 
@@ -1419,6 +1584,7 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     *out = nullptr;
     if (nx < 1 || ns < 2 || (ns & 1)) return fail(D4W_EINVAL, "bad shape %d x %d (ns must be even)", nx, ns);
     if (world < 1 || rank < 0 || rank >= world || world > nx) return fail(D4W_EINVAL, "bad world %d / rank %d", world, rank);
+    if (want_mask && fkd_plan_build_packed(nx, ns, world, rank, want_mask, out) == D4W_OK) return D4W_OK;
     const int M = ns / 2;
     // time axis M = N1 * N2: N2 in one LDS row, and enough n1-positions (Hermitian classes) to balance the ranks
     int N1 = 0;
@@ -1589,11 +1755,11 @@ int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** out)
     return fkd_plan_build(nx, ns, world, rank, true, out);
 }
 
-/* info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq_local, C1, C2, 0} */
+/* info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq_local, C1, C2, packed (0 / 1)} */
 int d4w_fkd_plan_info(const d4w_fkd_plan* pl, int* info) {
     if (!pl || !info) return fail(D4W_EINVAL, "NULL argument");
     const int v[12] = {pl->nx, pl->ns, pl->world, pl->rank, pl->row_begin, pl->row_end, pl->N1, pl->N2,
-                       (int)pl->myq.size(), pl->C1, pl->C2, 0};
+                       (int)pl->myq.size(), pl->C1, pl->C2, pl->sp ? 1 : 0};
     memcpy(info, v, sizeof(v));
     return D4W_OK;
 }
@@ -1604,8 +1770,69 @@ int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* pl, int* owner) {
     return D4W_OK;
 }
 
+static int fkd_set_mask_packed(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
+    d4w_fk_plan* sp = pl->sp;
+    const FkDims& d = sp->dev.d;
+    const int nq = (int)pl->myq.size();
+    hipStream_t st = (hipStream_t)stream;
+    pl->has_mask = true;
+    pl->fdev_c.pairs = pl->d_pairs_slab;
+    pl->fdev_c.live = nullptr;
+    pl->npairs_run = (int)pl->h_pairs_slab.size();
+    pl->live_rows = d.nx;
+    if (nq == 0) return D4W_OK;
+    const int W = nq * d.N2;
+    dim3 grid(std::min(ceil_div(W, kThreads), 64), d.nx);
+    D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, d.nx, d.ns, d.N1, d.N2, nq, mask_shifted,
+               (const int*)sp->d_rowk, (const int*)pl->d_q1of, (const int*)sp->d_k1, (const int*)sp->d_k2,
+               pl->d_mask, pl->d_nyq);
+    const char* np = getenv("D4W_FK_NOPRUNE");
+    if (np && atoi(np) > 0) return D4W_OK;
+    // rows whose gains are all zero in the owned sub-rows (and whose Hermitian partner's are): skipped by passes
+    // C, B, C' of this rank's slab, exactly as in the single-device plan
+    D4W_HIP(hipMemsetAsync(pl->d_rowmax, 0, (size_t)d.nx * sizeof(unsigned), st));
+    D4W_LAUNCH(fkd_row_max, dim3(d.nx), dim3(kThreads), 0, stream, (const float*)pl->d_mask, (const float*)pl->d_nyq, W,
+               pl->d_rowmax);
+    std::vector<unsigned> rmax(d.nx);
+    D4W_HIP(hipMemcpyAsync(rmax.data(), pl->d_rowmax, (size_t)d.nx * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    D4W_HIP(hipStreamSynchronize(st));
+    std::vector<char> lv(d.nx, 0);
+    std::vector<int2> run;
+    run.reserve(pl->h_pairs_slab.size());
+    for (const int2& pr : pl->h_pairs_slab) {
+        const int ra = pr.x / nq, rb = pr.y / nq;
+        if (rmax[ra] || rmax[rb]) {
+            lv[ra] = lv[rb] = 1;
+            run.push_back(pr);
+        }
+    }
+    int nlive = 0;
+    for (int r = 0; r < d.nx; ++r) nlive += lv[r];
+    if (nlive < d.nx) {
+        const int RA = sp->fast->C2A, RB = sp->fast->C2B;
+        std::vector<unsigned> bits((size_t)d.C1 * RA, 0u);
+        for (int r = 0; r < d.nx; ++r)
+            if (lv[r]) {
+                const int q = r / d.C2, p2 = r % d.C2;
+                bits[(size_t)q * RA + p2 / RB] |= 1u << (p2 % RB);
+            }
+        D4W_HIP(hipMemcpyAsync(pl->d_livebits, bits.data(), bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        if (!run.empty())
+            D4W_HIP(hipMemcpyAsync(pl->d_pairs_live, run.data(), run.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        D4W_HIP(hipStreamSynchronize(st));
+        pl->fdev_c.live = pl->d_livebits;
+        pl->fdev_c.pairs = pl->d_pairs_live;
+        pl->npairs_run = (int)run.size();
+        pl->live_rows = nlive;
+    }
+    return D4W_OK;
+}
+
+int d4w_fkd_plan_is_packed(const d4w_fkd_plan* pl) { return (pl && pl->sp) ? 1 : 0; }
+
 int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
     if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
+    if (pl->sp) return fkd_set_mask_packed(pl, mask_shifted, stream);
     const int nq = (int)pl->myq.size();
     if (nq > 0) {
         dim3 grid(std::min(ceil_div(nq * pl->N2, kThreads), 64), pl->nx);
@@ -1617,8 +1844,76 @@ int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void
     return D4W_OK;
 }
 
+/* packed path: x_loc [nxl][ns] -> packed [dest rank][nxl][nq(dest)][N2] complex (what the all-to-all sends) */
+int d4w_fkd_time_fwd_packed_rows_f32(d4w_fkd_plan* pl, const float* x_loc, float* packed, int taper, int l0, int l1,
+                                     void* stream) {
+    if (!pl || !x_loc || !packed) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl->sp) return fail(D4W_EINVAL, "this shape runs the generic distributed plan: d4w_fkd_time_fwd_f32");
+    const FkFastEntry& F = *pl->sp->fast;
+    const FkDims& d = pl->sp->dev.d;
+    const int nxl = pl->row_end - pl->row_begin;
+    if (l0 < 0 || l1 > nxl || l0 > l1 || l0 % d.C1) return fail(D4W_EINVAL, "row range [%d, %d) must start at a multiple of %d inside the local block", l0, l1, d.C1);
+    const int NBX = d.N2 / d.TA, t0 = (l0 / d.C1) * NBX, t1 = ceil_div(l1, d.C1) * NBX;
+    if (t1 <= t0) return D4W_OK;
+    FkGeo geo = pl->geo_t;
+    geo.nrows = l1;                                   // rows >= l1 of the last group belong to the next chunk
+    return launch_k(taper ? F.T_fwd_taper : F.T_fwd, dim3(std::min(t1 - t0, pl->num_cu * pl->sp->wgA)), dim3(F.thrA), F.ldsA, stream,
+                    pl->dev_t, reinterpret_cast<const float2*>(x_loc), reinterpret_cast<float2*>(packed), t0, t1, NBX, 0, geo);
+}
+
+int d4w_fkd_time_fwd_packed_f32(d4w_fkd_plan* pl, const float* x_loc, float* packed, int taper, void* stream) {
+    if (!pl) return fail(D4W_EINVAL, "NULL argument");
+    return d4w_fkd_time_fwd_packed_rows_f32(pl, x_loc, packed, taper, 0, pl->row_end - pl->row_begin, stream);
+}
+
+/* packed path: packed [src rank][nxl][nq(src)][N2] (what the second all-to-all delivers) -> y_loc [nxl][ns] */
+int d4w_fkd_time_inv_packed_rows_f32(d4w_fkd_plan* pl, const float* packed, float* y_loc, int l0, int l1, void* stream) {
+    if (!pl || !packed || !y_loc) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl->sp) return fail(D4W_EINVAL, "this shape runs the generic distributed plan: d4w_fkd_time_inv_f32");
+    const FkFastEntry& F = *pl->sp->fast;
+    const FkDims& d = pl->sp->dev.d;
+    const int nxl = pl->row_end - pl->row_begin;
+    if (l0 < 0 || l1 > nxl || l0 > l1 || l0 % d.C1) return fail(D4W_EINVAL, "row range [%d, %d) must start at a multiple of %d inside the local block", l0, l1, d.C1);
+    const int NBX = d.N2 / d.TA, t0 = (l0 / d.C1) * NBX, t1 = ceil_div(l1, d.C1) * NBX;
+    if (t1 <= t0) return D4W_OK;
+    FkGeo geo = pl->geo_t;
+    geo.nrows = l1;
+    return launch_k(F.T_inv, dim3(std::min(t1 - t0, pl->num_cu * pl->sp->wgA)), dim3(F.thrA), F.ldsA, stream, pl->dev_t,
+                    reinterpret_cast<float2*>(y_loc), t0, t1, NBX, 0, geo, reinterpret_cast<const float2*>(packed));
+}
+
+int d4w_fkd_time_inv_packed_f32(d4w_fkd_plan* pl, const float* packed, float* y_loc, void* stream) {
+    if (!pl) return fail(D4W_EINVAL, "NULL argument");
+    return d4w_fkd_time_inv_packed_rows_f32(pl, packed, y_loc, 0, pl->row_end - pl->row_begin, stream);
+}
+
+static int fkd_chan_apply_packed(d4w_fkd_plan* pl, float* slab, void* stream) {
+    const FkFastEntry& F = *pl->sp->fast;
+    const FkDims& d = pl->sp->dev.d;
+    const int nq = (int)pl->myq.size();
+    if (nq == 0) return D4W_OK;
+    const int W = nq * d.N2;
+    const int nblkA = ceil_div(W, d.N1 * d.TA), nblkC = W / d.TC;
+    const int ntA = d.C2 * nblkA, ntC = d.C1 * nblkC;
+    float2* d2 = reinterpret_cast<float2*>(slab);
+    const int cu = pl->num_cu;
+    const dim3 gA(std::min(ntA, cu * pl->sp->wgA)), gC(std::min(ntC, cu * pl->sp->wgC)),
+        gB(std::max(1, std::min(pl->npairs_run, cu * pl->sp->wgB)));
+    int rc;
+    // pass A MODE 2: tile u -> (c2 = u / nblkA, column block u % nblkA)
+    if ((rc = launch_k(F.Ac_fwd, gA, dim3(F.thrA), F.ldsA, stream, pl->dev_c, (const float2*)d2, d2, 0, ntA, nblkA, 0, pl->geo_c))) return rc;
+    if ((rc = launch_k(F.Cs_fwd, gC, dim3(F.thrC), F.ldsC, stream, pl->dev_c, pl->fdev_c, d2, 0, ntC, nblkC, 0, pl->geo_c))) return rc;
+    FkGeo gb = pl->geo_c;
+    gb.nq = nq;
+    if (pl->npairs_run > 0 &&
+        (rc = launch_k(F.Bs_mid, gB, dim3(F.thrB), F.ldsB, stream, pl->dev_c, pl->fdev_c, d2, 0, pl->npairs_run, gb))) return rc;
+    if ((rc = launch_k(F.Cs_inv, gC, dim3(F.thrC), F.ldsC, stream, pl->dev_c, pl->fdev_c, d2, 0, ntC, nblkC, 0, pl->geo_c))) return rc;
+    return launch_k(F.Ac_inv, gA, dim3(F.thrA), F.ldsA, stream, pl->dev_c, d2, 0, ntA, nblkA, 0, pl->geo_c, (const float2*)nullptr);
+}
+
 int d4w_fkd_time_fwd_f32(d4w_fkd_plan* pl, const float* x_loc, float* z_loc, int taper, void* stream) {
     if (!pl || !x_loc || !z_loc) return fail(D4W_EINVAL, "NULL argument");
+    if (pl->sp) return fail(D4W_EINVAL, "this shape runs the packed distributed plan: d4w_fkd_time_fwd_packed_f32");
     const FkDev& P = pl->tp.dev;
     const int nxl = P.d.nx;
     const int ntA = ceil_div(P.d.N2, P.d.TA) * nxl, nsub = nxl * pl->N1;
@@ -1635,6 +1930,7 @@ int d4w_fkd_time_fwd_f32(d4w_fkd_plan* pl, const float* x_loc, float* z_loc, int
 
 int d4w_fkd_time_inv_f32(d4w_fkd_plan* pl, float* z_loc, void* stream) {
     if (!pl || !z_loc) return fail(D4W_EINVAL, "NULL argument");
+    if (pl->sp) return fail(D4W_EINVAL, "this shape runs the packed distributed plan: d4w_fkd_time_inv_packed_f32");
     const FkDev& P = pl->tp.dev;
     const int nxl = P.d.nx;
     const int ntA = ceil_div(P.d.N2, P.d.TA) * nxl, nsub = nxl * pl->N1;
@@ -1649,6 +1945,7 @@ int d4w_fkd_time_inv_f32(d4w_fkd_plan* pl, float* z_loc, void* stream) {
 int d4w_fkd_chan_apply_f32(d4w_fkd_plan* pl, float* slab, void* stream) {
     if (!pl || (!slab && !pl->myq.empty())) return fail(D4W_EINVAL, "NULL argument");
     if (!pl->has_mask) return fail(D4W_EINVAL, "no mask set on this plan");
+    if (pl->sp) return fkd_chan_apply_packed(pl, slab, stream);
     const int nq = (int)pl->myq.size();
     if (nq == 0) return D4W_OK;
     const FkDev& P = pl->cp.dev;

@@ -686,9 +686,14 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
     __syncthreads();
     {
         const float* r = STAGED ? rowl : rg;
+        // no base can lie below the row minimum: a maximum with v - thr below it cannot reach the threshold and is
+        // rejected without a walk (with thr = a fraction of the strongest peak that is almost every maximum)
+        float gmin = INFINITY;
+        for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, s2[k].y);
         for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
             const float v = r[i];
             if (!(r[i - 1] < v)) continue;
+            if ((double)v - thr < (double)gmin) continue;
             int ia = i + 1;
             while (ia < ns - 1 && r[ia] == v) ++ia;
             if (!(r[ia] < v)) continue;
@@ -734,6 +739,21 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
         __syncthreads();
     }
     if (tid == 0) counts[blockIdx.x] = base;
+}
+
+// picks of all rows as ONE packed 2 x K table (detect.convert_pick_times, detect.py:277-303: row 0 = channel,
+// row 1 = time index): row c's cnt[c] indices go to columns [off[c] - cnt[c], off[c]) (off = inclusive prefix sum)
+__global__ __launch_bounds__(kSpThreads) void pack_picks(const int* __restrict__ idx, const int* __restrict__ cnt,
+                                                          const long long* __restrict__ off, int nx, int cap, long long total,
+                                                          long long* __restrict__ out) {
+    for (int c = blockIdx.x; c < nx; c += gridDim.x) {
+        const int n = min(cnt[c], cap);
+        const long long base = off[c] - cnt[c];
+        for (int j = threadIdx.x; j < n; j += kSpThreads) {
+            out[base + j] = c;
+            out[total + base + j] = idx[(size_t)c * cap + j];
+        }
+    }
 }
 
 }  // namespace d4w
@@ -907,6 +927,16 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
         D4W_LAUNCH(find_peaks_prom<false>, dim3(nx), dim3(kSpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
                    (int*)counts, cap);
     }
+    return D4W_OK;
+}
+
+int d4w_pack_picks_i64(const int32_t* idx, const int32_t* counts, const int64_t* offsets, int nx, int cap, int64_t total,
+                       int64_t* out, void* stream) {
+    if (!idx || !counts || !offsets || nx < 1 || cap < 1 || total < 0) return fail(D4W_EINVAL, "bad argument");
+    if (total == 0) return D4W_OK;
+    if (!out) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(pack_picks, dim3(std::min(nx, 4096)), dim3(kSpThreads), 0, stream, (const int*)idx, (const int*)counts,
+               (const long long*)offsets, nx, cap, (long long)total, (long long*)out);
     return D4W_OK;
 }
 

@@ -183,8 +183,52 @@ def compute_cross_correlogram(data, template, exact_tail=None):
 # ---------------------------------------------------------------------------------------------
 # peak picking (d4w_find_peaks_f32; the envelope of the *_env variants is d4w_analytic_f32)
 # ---------------------------------------------------------------------------------------------
+class PickRows:
+    """The picks of every channel: behaves like the list of per-channel int64 index arrays the reference returns
+    (detect.py:169-274: len(), indexing, iteration, in channel order), backed by ONE packed 2 x K table on the
+    device (`packed`: row 0 = channel, row 1 = time index = detect.convert_pick_times' output) and `counts`.
+    Nothing is copied to the host until a row (or the table) is asked for."""
+
+    def __init__(self, packed, counts):
+        self.packed, self.counts = packed, counts
+        self._host = None
+
+    def _rows(self):
+        if self._host is None:
+            cnt = self.counts.cpu().numpy().astype(np.int64)
+            self._host = (self.packed[1].cpu().numpy(), np.concatenate(([0], np.cumsum(cnt))))
+        return self._host
+
+    def __len__(self):
+        return int(self.counts.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        flat, off = self._rows()
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError("channel index out of range")
+        return flat[off[i]:off[i + 1]]
+
+    def __iter__(self):
+        flat, off = self._rows()
+        return (flat[off[i]:off[i + 1]] for i in range(len(self)))
+
+    @property
+    def total(self):
+        return int(self.packed.shape[1])
+
+    def table(self):
+        """2 x K int64 ndarray (channel, time): detect.convert_pick_times of these picks."""
+        return self.packed.cpu().numpy()
+
+
 def _find_peaks_device(c, threshold, cap0=1024):
-    """c: float32 CUDA [nx, ns] -> list of int64 index arrays, one per row, in row order."""
+    """c: float32 CUDA [nx, ns] -> PickRows.  One host synchronisation per call (total and largest per-row count);
+    the ragged result is compacted on the device."""
     nx, ns = c.shape
     cap = max(1, min(ns // 2 + 1, int(cap0)))
     with torch.cuda.device(c.device):
@@ -193,15 +237,15 @@ def _find_peaks_device(c, threshold, cap0=1024):
             cnt = torch.empty(nx, dtype=torch.int32, device=c.device)
             check(lib.d4w_find_peaks_f32(dev.ptr(c), nx, ns, float(threshold), dev.ptr(idx), dev.ptr(cnt), cap,
                                          dev.stream_ptr(c)))
-            counts = cnt.cpu().numpy().astype(np.int64)
-            need = int(counts.max()) if nx else 0
+            off = torch.cumsum(cnt, 0, dtype=torch.int64)
+            need, total = (int(v) for v in torch.stack((cnt.max().to(torch.int64), off[-1])).cpu())
             if need <= cap:
                 break
             cap = min(ns // 2 + 1, max(need, 2 * cap))          # rare: a row with more peaks than the first guess
-        keep = torch.arange(cap, device=c.device)[None, :] < cnt[:, None]
-        flat = idx[keep].cpu().numpy().astype(np.int64)
-    off = np.concatenate(([0], np.cumsum(counts)))                # plain slices: 3x cheaper than np.split for 10^4 rows
-    return [flat[off[i]:off[i + 1]] for i in range(nx)]
+        packed = torch.empty((2, total), dtype=torch.int64, device=c.device)
+        check(lib.d4w_pack_picks_i64(dev.ptr(idx), dev.ptr(cnt), dev.ptr(off), nx, cap, total,
+                                     dev.ptr(packed) if total else None, dev.stream_ptr(c)))
+    return PickRows(packed, cnt)
 
 
 def pick_times_env(corr_m, threshold):
@@ -387,6 +431,8 @@ def compute_cross_correlogram_spectrocorr(data, fs, flims, kernel, win_size, ove
 def convert_pick_times(peaks_indexes_m):
     """Ragged per-channel index lists -> 2 x K array, row 0 = channel index, row 1 = time index
     -- reference detect.py:277-303."""
+    if isinstance(peaks_indexes_m, PickRows):
+        return peaks_indexes_m.table()
     ch = [np.full(len(p), i, dtype=np.int64) for i, p in enumerate(peaks_indexes_m)]
     if not ch:
         return np.zeros((2, 0), dtype=np.int64)

@@ -78,7 +78,8 @@ class ShardedFkPlan:
         self.check(self.lib.d4w_fkd_plan_create(int(nx), int(ns), self.world, self.rank, ctypes.byref(self._h)))
         info = (ctypes.c_int * 12)()
         self.check(self.lib.d4w_fkd_plan_info(self._h, info))
-        (self.nx, self.ns, _, _, self.row_begin, self.row_end, self.N1, self.N2, self.nq, _, _, _) = list(info)
+        (self.nx, self.ns, _, _, self.row_begin, self.row_end, self.N1, self.N2, self.nq, self.C1, _, packed) = list(info)
+        self.packed = bool(packed)          # shape-specialised kernels + exchange buffers that need no repacking
         own = (ctypes.c_int * self.N1)()
         self.check(self.lib.d4w_fkd_plan_q1_owner(self._h, own))
         owner = torch.tensor(list(own), dtype=torch.int64)
@@ -121,12 +122,91 @@ class ShardedFkPlan:
         else:
             dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
 
+    # row chunks of the packed exchanges (transfer of chunk i overlaps the time-axis transform of chunk i + 1)
+    CHUNKS = 4
+
+    def _chunks(self, r, nch):
+        """Local row ranges [l0, l1) of rank r's nch chunks: boundaries at multiples of C1 (the time-phase tile)."""
+        n = self.blocks[r][1] - self.blocks[r][0]
+        grp = -(-n // self.C1)
+        cut = [min(n, self.C1 * ((grp * j) // nch)) for j in range(nch)] + [n]
+        return [(cut[j], cut[j + 1]) for j in range(nch)]
+
+    def _exchange(self, send_views, recv_views):
+        """One grouped exchange: send_views[s] goes to rank s, recv_views[r] arrives from rank r (contiguous float32
+        views; the own piece is a device copy).  Returns the outstanding work handles."""
+        recv_views[self.rank].copy_(send_views[self.rank])
+        ops = []
+        for k in range(1, self.world):                      # pairwise schedule: every link busy, no hot receiver
+            to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
+            if send_views[to].numel():
+                ops.append(dist.P2POp(dist.isend, send_views[to], to, group=self.group))
+            if recv_views[frm].numel():
+                ops.append(dist.P2POp(dist.irecv, recv_views[frm], frm, group=self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _apply_packed(self, x_loc, taper):
+        """Packed plan (include/d4w.h): 7 block passes of the shape-specialised kernels per rank, the exchange
+        buffers are written / read in place by the time-phase kernels (no index packing), and the transfers run in
+        row chunks behind the kernels of the neighbouring chunks."""
+        nxl = self.row_end - self.row_begin
+        per = self.N2 * 2
+        dev_ = x_loc.device
+        nqs = [len(q) for q in self.qidx]
+        send = self._scratch("send", nxl * self.N1 * per, dev_)
+        boff = [0]
+        for s in range(self.world):
+            boff.append(boff[-1] + nxl * nqs[s] * per)
+        if self.world == 1:                                   # one destination: the send buffer IS the slab
+            self.check(self.lib.d4w_fkd_time_fwd_packed_f32(self._h, x_loc.data_ptr(), send.data_ptr(), int(bool(taper)), _sptr(send)))
+            self.check(self.lib.d4w_fkd_chan_apply_f32(self._h, send.data_ptr(), _sptr(send)))
+            y = torch.empty((nxl, self.ns), dtype=torch.float32, device=dev_)
+            self.check(self.lib.d4w_fkd_time_inv_packed_f32(self._h, send.data_ptr(), y.data_ptr(), _sptr(y)))
+            return y
+        slab = self._scratch("slab", self.nx * self.nq * per, dev_)
+        nch = max(1, min(self.CHUNKS, -(-nxl // self.C1)))
+        chunks = [self._chunks(r, nch) for r in range(self.world)]
+        works = []
+        for j in range(nch):
+            l0, l1 = chunks[self.rank][j]
+            self.check(self.lib.d4w_fkd_time_fwd_packed_rows_f32(self._h, x_loc.data_ptr(), send.data_ptr(), int(bool(taper)),
+                                                                   l0, l1, _sptr(send)))
+            sv = [send[boff[s] + l0 * nqs[s] * per: boff[s] + l1 * nqs[s] * per] for s in range(self.world)]
+            rv = []
+            for r in range(self.world):
+                a = self.blocks[r][0]
+                r0, r1 = chunks[r][j]
+                rv.append(slab[(a + r0) * self.nq * per:(a + r1) * self.nq * per])
+            works += self._exchange(sv, rv)
+        for w in works:
+            w.wait()
+        self.check(self.lib.d4w_fkd_chan_apply_f32(self._h, slab.data_ptr() if self.nq else None, _sptr(slab)))
+        y = torch.empty((nxl, self.ns), dtype=torch.float32, device=dev_)
+        pending = []
+        for j in range(nch):                                  # all transfers are queued; chunk j is transformed as it lands
+            l0, l1 = chunks[self.rank][j]
+            rv = [send[boff[s] + l0 * nqs[s] * per: boff[s] + l1 * nqs[s] * per] for s in range(self.world)]
+            sv = []
+            for r in range(self.world):
+                a = self.blocks[r][0]
+                r0, r1 = chunks[r][j]
+                sv.append(slab[(a + r0) * self.nq * per:(a + r1) * self.nq * per])
+            pending.append(self._exchange(sv, rv))
+        for j in range(nch):
+            for w in pending[j]:
+                w.wait()
+            l0, l1 = chunks[self.rank][j]
+            self.check(self.lib.d4w_fkd_time_inv_packed_rows_f32(self._h, send.data_ptr(), y.data_ptr(), l0, l1, _sptr(y)))
+        return y
+
     def apply(self, x_loc, taper=False):
         """x_loc: float32 [rows of this rank, ns] -> filtered rows of this rank (same shape)."""
         nxl = self.row_end - self.row_begin
         if tuple(x_loc.shape) != (nxl, self.ns):
             raise ValueError("local block has shape %s, expected (%d, %d)" % (tuple(x_loc.shape), nxl, self.ns))
         x_loc = x_loc.to(torch.float32).contiguous()
+        if self.packed:
+            return self._apply_packed(x_loc, taper)
         per = self.N2 * 2                                        # floats per sub-row
         z = torch.empty((nxl, self.N1, per), dtype=torch.float32, device=x_loc.device)     # returned to the caller
         self.check(self.lib.d4w_fkd_time_fwd_f32(self._h, x_loc.data_ptr(), z.data_ptr(), int(bool(taper)), _sptr(z)))

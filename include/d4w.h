@@ -111,7 +111,20 @@ int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* plan, const float* x, float* y, in
  *
  * The exchange itself (RCCL all_to_all_single over xGMI, gloo in the CPU tests) is host plumbing:
  * das4whales_amd/shard.py fk_filter_sharded.  All buffers are DEVICE float32 (complex = 2 floats).
- * info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq, C1, C2, 0}.
+ * info12 = {nx, ns, world, rank, row_begin, row_end, N1, N2, nq, C1, C2, packed}.
+ *
+ * PACKED plans (d4w_fkd_plan_is_packed; every shape with shape-specialised kernels, e.g. 20000 x 120000 and the
+ * 60-s file shapes) need no repacking around the exchanges: the time phase writes straight into the send buffer,
+ * destination rank major --
+ *   packed = [dest rank s][local row l][jq < nq(s)][N2] complex, block s holding nxl * nq(s) * N2 elements,
+ * so that all_to_all_single delivers the slab [nx][nq][N2] as it stands (senders in rank order = channel order), and
+ * the second exchange delivers the same layout back:
+ *   d4w_fkd_time_fwd_packed_f32   x_loc [nxl][ns] -> packed            (n1 sub-transform + four-step twiddle)
+ *   d4w_fkd_chan_apply_f32        slab, in place: c1 transform, c2 transform, n2 transform + pair op x mask +
+ *                                 inverse n2, inverse c2, inverse c1    (five launches of the fk_fast.h kernels)
+ *   d4w_fkd_time_inv_packed_f32   packed -> y_loc [nxl][ns]
+ * Seven block passes per rank over its share instead of the single-device five; the generic plan (any other
+ * shape) keeps the z_loc / index-packing protocol above.
  * ------------------------------------------------------------------------------------------ */
 typedef struct d4w_fkd_plan d4w_fkd_plan;
 int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** plan);
@@ -124,6 +137,14 @@ int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* plan, const float* mask_shifted, vo
 int d4w_fkd_time_fwd_f32(d4w_fkd_plan* plan, const float* x_loc, float* z_loc, int taper, void* stream);
 int d4w_fkd_chan_apply_f32(d4w_fkd_plan* plan, float* slab, void* stream);
 int d4w_fkd_time_inv_f32(d4w_fkd_plan* plan, float* z_loc, void* stream);
+int d4w_fkd_plan_is_packed(const d4w_fkd_plan* plan);
+int d4w_fkd_time_fwd_packed_f32(d4w_fkd_plan* plan, const float* x_loc, float* packed, int taper, void* stream);
+int d4w_fkd_time_inv_packed_f32(d4w_fkd_plan* plan, const float* packed, float* y_loc, void* stream);
+/* the same on local rows [l0, l1) only (l0 a multiple of C1): row chunks whose transfer overlaps the next chunk's
+ * transform (das4whales_amd/shard.py) */
+int d4w_fkd_time_fwd_packed_rows_f32(d4w_fkd_plan* plan, const float* x_loc, float* packed, int taper, int l0, int l1,
+                                     void* stream);
+int d4w_fkd_time_inv_packed_rows_f32(d4w_fkd_plan* plan, const float* packed, float* y_loc, int l0, int l1, void* stream);
 
 /* dsp.taper_data (dsp.py:705-722): x *= tukey(ns, 0.03) in place, every row */
 int d4w_taper_f32(float* x, int nx, int ns, void* stream);
@@ -303,6 +324,12 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
  * ------------------------------------------------------------------------------------------ */
 int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx,
                        int32_t* counts, int cap, void* stream);
+/* The picks of all rows as one packed table out[2][total] int64, row 0 = channel index, row 1 = time index
+ * -- what detect.convert_pick_times builds from the ragged lists (detect.py:277-303; the reference's docstring
+ * has the two rows swapped, :289 vs :297-299).  offsets[c] = counts[0] + ... + counts[c] (inclusive prefix sum,
+ * device), total = offsets[nx - 1]; every counts[c] must be <= cap. */
+int d4w_pack_picks_i64(const int32_t* idx, const int32_t* counts, const int64_t* offsets, int nx, int cap,
+                       int64_t total, int64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Image operators of the Gabor detector: replaces improcess.scale_pixels /

@@ -62,7 +62,7 @@ def main():
             for r in done:
                 thr = 0.45 * float(r["correlograms"][0].max())
                 for c in r["correlograms"]:
-                    npicks += sum(len(p) for p in detect.pick_times_env(c, thr))
+                    npicks += detect.pick_times_env(c, thr).total      # packed 2 x K table on the device
             e3 = ev()
             for r in done:
                 detect.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)

@@ -119,3 +119,65 @@ def test_dist_plan_errors(emu):
     assert emu.d4w_fkd_plan_create(40, 481, 2, 0, ctypes.byref(h)) == -1
     assert emu.d4w_fkd_plan_create(40, 480, 2, 2, ctypes.byref(h)) == -1
     assert emu.d4w_fkd_plan_create(4, 480, 8, 0, ctypes.byref(h)) == -1       # more ranks than channels
+
+
+def fk_sharded_packed_emu(lib, x, mask, world, taper=False):
+    """The PACKED protocol of include/d4w.h (shapes with specialised kernels): the time phase writes the send buffer,
+    destination rank major; the exchanges are plain concatenations -- no index packing anywhere."""
+    nx, ns = x.shape
+    ranks = [Rank(lib, nx, ns, world, r) for r in range(world)]
+    assert all(lib.d4w_fkd_plan_is_packed(rk.h) == 1 for rk in ranks)
+    N1, N2 = ranks[0].N1, ranks[0].N2
+    owner = ranks[0].owner
+    assert all(np.array_equal(rk.owner, owner) for rk in ranks)
+    nq = [int(np.sum(owner == s)) for s in range(world)]
+    assert [rk.nq for rk in ranks] == nq
+    mf = np.ascontiguousarray(mask, dtype=np.float32)
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    send = []
+    for rk in ranks:
+        assert lib.d4w_fkd_set_mask_dense_f32(rk.h, vp(mf), None) == 0, lib.d4w_last_error()
+        nxl = rk.b - rk.a
+        buf = np.full(nxl * N1 * N2 * 2, np.nan, dtype=np.float32)
+        xl = np.ascontiguousarray(xf[rk.a:rk.b])
+        assert lib.d4w_fkd_time_fwd_packed_f32(rk.h, vp(xl), vp(buf), int(taper), None) == 0, lib.d4w_last_error()
+        assert not np.isnan(buf).any()
+        send.append(buf)
+    # all_to_all_single: rank r's block for s = elements [off_r[s], off_r[s+1])
+    def splits(r):
+        nxl = ranks[r].b - ranks[r].a
+        return np.concatenate(([0], np.cumsum([nxl * nq[s] * N2 * 2 for s in range(world)])))
+    slabs = []
+    for s, rk in enumerate(ranks):
+        parts = [send[r][splits(r)[s]:splits(r)[s + 1]] for r in range(world)]
+        slab = np.ascontiguousarray(np.concatenate(parts))
+        assert slab.size == nx * nq[s] * N2 * 2
+        assert lib.d4w_fkd_chan_apply_f32(rk.h, vp(slab) if nq[s] else None, None) == 0, lib.d4w_last_error()
+        slabs.append(slab)
+    y = np.empty((nx, ns), dtype=np.float32)
+    for r, rk in enumerate(ranks):
+        nxl = rk.b - rk.a
+        parts = [slabs[s][rk.a * nq[s] * N2 * 2:rk.b * nq[s] * N2 * 2] for s in range(world)]
+        back = np.ascontiguousarray(np.concatenate(parts))
+        yl = np.full((nxl, ns), np.nan, dtype=np.float32)
+        assert lib.d4w_fkd_time_inv_packed_f32(rk.h, vp(back), vp(yl), None) == 0, lib.d4w_last_error()
+        y[rk.a:rk.b] = yl
+    for rk in ranks:
+        rk.close()
+    return y
+
+
+@pytest.mark.parametrize("nx,ns", [(18, 48), (100, 600), (8, 480)])
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_dist_packed_specialised_shapes(emu, nx, ns, world):
+    """Shapes with specialised kernels run the packed distributed plan (pass kernels of fk_fast.h in their slab modes):
+    same filter as the oracle for dense masks, masks with dead wavenumber rows, with the taper, uneven blocks."""
+    if world > nx:
+        pytest.skip("more ranks than channels")
+    rng = np.random.default_rng(nx * 7 + ns + world)
+    x = rng.standard_normal((nx, ns))
+    m = rng.uniform(0, 1, (nx, ns))
+    assert rel(fk_sharded_packed_emu(emu, x, m, world), orc.fk_filter_filt(x, m)) < TOL
+    ks = np.fft.fftshift(np.arange(nx))
+    m[np.minimum(ks, nx - ks) > nx // 4, :] = 0.0            # dead rows: pruned per rank
+    assert rel(fk_sharded_packed_emu(emu, x, m, world, taper=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL

@@ -318,3 +318,23 @@ def test_analytic_and_fx_lengths_with_large_prime_factors(emu, ns):
     fx = np.empty((3, nfft), dtype=np.float32)
     assert emu.d4w_fx_f32(vp(x), vp(fx), 3, ns, nfft, None) == 0, emu.d4w_last_error()
     assert rel(fx, orc.get_fx(x.astype(np.float64), nfft)) < TOL
+
+
+def test_pack_picks_table(emu):
+    """d4w_pack_picks_i64: the ragged per-row index lists of d4w_find_peaks_f32 as the packed 2 x K (channel, time)
+    table of detect.convert_pick_times (reference detect.py:277-303)."""
+    rng = np.random.default_rng(12)
+    nx, ns, cap, thr = 9, 700, 256, 1.5
+    x = rng.standard_normal((nx, ns)).astype(np.float32)
+    x[4] = 0.0                                          # a row without picks
+    idx = np.zeros((nx, cap), dtype=np.int32)
+    cnt = np.zeros(nx, dtype=np.int32)
+    ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
+    off = np.cumsum(cnt).astype(np.int64)
+    total = int(off[-1])
+    out = np.full((2, total), -1, dtype=np.int64)
+    emu.d4w_pack_picks_i64.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    ok(emu, emu.d4w_pack_picks_i64(vp(idx), vp(cnt), vp(off), nx, cap, total, vp(out), None))
+    ref = [sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0] for c in range(nx)]
+    want = np.asarray((np.concatenate([np.full(len(p), i) for i, p in enumerate(ref)]), np.concatenate(ref)))
+    assert total == want.shape[1] and np.array_equal(out, want)

@@ -78,5 +78,16 @@ def test_sharded_bench_shape_identity(pg):
     del ident
     y = plan.apply(x)
     err = float((y - x).abs().max()) / float(x.abs().max())
-    print("sharded 20000x120000 identity-mask error %.3e (N1=%d N2=%d)" % (err, plan.N1, plan.N2))
+    print("sharded 20000x120000 identity-mask error %.3e (N1=%d N2=%d, packed plan: %s)" % (err, plan.N1, plan.N2, plan.packed))
     assert err < TOL
+    assert plan.packed                      # this shape has specialised kernels: packed exchange layout, 7 passes
+    del y
+    # the classic fan (dead wavenumber rows pruned per rank) against the single-device five-pass plan
+    import das4whales_amd as dw
+    fan = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419046878814697, 200.0)
+    plan.set_mask(fan.tensor)
+    y = plan.apply(x, taper=True)
+    y1 = dw.dsp.fk_filter_filt(x, fan, tapering=True)
+    err = float((y - y1).abs().max()) / float(y1.abs().max())
+    print("sharded (packed) vs single-device 20000x120000, classic fan + taper: %.3e" % err)
+    assert err < 3e-6

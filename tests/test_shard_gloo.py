@@ -144,3 +144,76 @@ def test_fk_filter_sharded_gloo(world):
     for rank, r in res:
         for k, v in r.items():
             assert v < 1e-5, (rank, k, v)
+
+
+# ------------------------------------------------------------------------------------------
+# PACKED distributed plan (shapes with specialised kernels): grouped send / recv in row chunks,
+# no index packing -- the real exchange code of shard.ShardedFkPlan._apply_packed over gloo
+# ------------------------------------------------------------------------------------------
+def _fk_packed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+        import numpy as np
+        from oracle import d4w_oracle as orc
+        from tests.emu_util import load_emu
+        emu = load_emu()
+        vp_, ci = ctypes.c_void_p, ctypes.c_int
+        emu.d4w_fkd_plan_create.argtypes = [ci] * 4 + [ctypes.POINTER(vp_)]
+        emu.d4w_fkd_plan_destroy.argtypes = [vp_]
+        emu.d4w_fkd_plan_info.argtypes = [vp_, ctypes.POINTER(ci)]
+        emu.d4w_fkd_plan_q1_owner.argtypes = [vp_, ctypes.POINTER(ci)]
+        emu.d4w_fkd_set_mask_dense_f32.argtypes = [vp_] * 3
+        emu.d4w_fkd_chan_apply_f32.argtypes = [vp_] * 3
+        emu.d4w_fkd_time_fwd_packed_f32.argtypes = [vp_] * 3 + [ci, vp_]
+        emu.d4w_fkd_time_inv_packed_f32.argtypes = [vp_] * 4
+        emu.d4w_fkd_time_fwd_packed_rows_f32.argtypes = [vp_] * 3 + [ci, ci, ci, vp_]
+        emu.d4w_fkd_time_inv_packed_rows_f32.argtypes = [vp_] * 3 + [ci, ci, vp_]
+
+        def check(rc):
+            assert rc == 0, emu.d4w_last_error()
+        shard = _load_shard()
+        rng = np.random.default_rng(21)
+        nx, ns = 100, 600                                  # FkShapeT3: C1 = 5 rows per time-phase tile
+        x = rng.standard_normal((nx, ns))
+        m = rng.uniform(0, 1, (nx, ns))
+        ks = np.fft.fftshift(np.arange(nx))
+        m[np.minimum(ks, nx - ks) > 30, :] = 0.0           # dead wavenumber rows
+        ref = orc.fk_filter_filt(x, m, tapering=True)
+        a, b = shard.channel_block(nx, world, rank)
+        plan = shard.ShardedFkPlan(nx, ns, native=(emu, check))
+        assert plan.packed
+        plan.set_mask(torch.from_numpy(m).float())
+        xl = torch.from_numpy(x[a:b]).float()
+        res = {}
+        for chunks in (1, 3):
+            plan.CHUNKS = chunks
+            y = plan.apply(xl, taper=True)
+            res["chunks%d" % chunks] = float(np.max(np.abs(y.numpy() - ref[a:b])) / np.max(np.abs(ref)))
+        y_all = shard.fk_filter_sharded(xl, None, nx, tapering=True, gather=True, plan=plan)
+        res["gathered"] = float(np.max(np.abs(y_all.numpy() - ref)) / np.max(np.abs(ref)))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fk_filter_sharded_packed_gloo(world):
+    from tests.emu_util import build_emu
+    build_emu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fk_packed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        for k, v in r.items():
+            assert v < 1e-5, (rank, k, v)
