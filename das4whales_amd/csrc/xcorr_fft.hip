@@ -145,7 +145,11 @@ template <int NT, bool FUSED>
 __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
                                                                   int ns, const float* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
-                                                                  float* __restrict__ y0, float* __restrict__ y1) {
+                                                                  float* __restrict__ y0, float* __restrict__ y1,
+                                                                  int step, int yshift, int ns_out, float dcg) {
+    // step = lags kept per block (B - (support - 1)); lags k < ns_out are stored, lag k at column k + yshift of its row
+    // (the zero-phase FIR use, d4w_fir_fft_f32: taps centred at yshift); dcg: mean[row] * dcg is added to every output
+    // (the gain the subtracted constant would have had)
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
     D4W_DYN_LDS(smem_raw);
     float4* buf = reinterpret_cast<float4*>(smem_raw);          // [ROWP] block spectra of both rows, then each template's correlation
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     const int rowA = 2 * blockIdx.y;
     const bool hasB = rowA + 1 < nx;
     const int rowB = hasB ? rowA + 1 : rowA;
-    const int k0 = blockIdx.x * kXfStep;                        // first lag / first sample of the block
+    const int k0 = blockIdx.x * step;                           // first lag / first sample of the block
     const float* xa = x + (size_t)rowA * ns;
     const float* xb = x + (size_t)rowB * ns;
     const float mua = mean ? mean[rowA] : 0.f, mub = mean ? mean[rowB] : 0.f;
@@ -353,33 +357,36 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                 v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pwi[aq]);
             });
             idftp<NA>(v);
-            float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * ns;
-            float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * ns;
+            float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * ns + yshift;
+            float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * ns + yshift;
+            const v2f dc = v2_make(mua * dcg, mub * dcg);
             if (interior) {
                 float2* oa = reinterpret_cast<float2*>(ya + k0) + j1;
                 float2* ob = reinterpret_cast<float2*>(yb + k0) + j1;
                 static_for<NA>([&](auto aa) {
                     constexpr int aq = decltype(aa)::value;
-                    if (2 * (j1 + aq * M1) < kXfStep) {
-                        const c2 o = c2_scale2(v[aq], sc);
+                    if (2 * (j1 + aq * M1) < step) {
+                        c2 o = c2_scale2(v[aq], sc);
+                        o = c2{v2_add(o.re, dc), v2_add(o.im, dc)};
                         st_stream(oa + aq * M1, c2_a(o));
                         if (hasB) st_stream(ob + aq * M1, c2_b(o));
                     }
                 });
             } else {
                 auto put = [&](float* yr, bool vec, int k, float2 o) {
-                    if (k >= ns) return;
-                    if (vec && k + 1 < ns) *reinterpret_cast<float2*>(yr + k) = o;
+                    if (k >= ns_out) return;
+                    if (vec && k + 1 < ns_out) *reinterpret_cast<float2*>(yr + k) = o;
                     else {
                         yr[k] = o.x;
-                        if (k + 1 < ns) yr[k + 1] = o.y;
+                        if (k + 1 < ns_out) yr[k + 1] = o.y;
                     }
                 };
                 static_for<NA>([&](auto aa) {
                     constexpr int aq = decltype(aa)::value;
                     const int m = j1 + aq * M1;
-                    if (2 * m < kXfStep) {
-                        const c2 o = c2_scale2(v[aq], sc);
+                    if (2 * m < step) {
+                        c2 o = c2_scale2(v[aq], sc);
+                        o = c2{v2_add(o.re, dc), v2_add(o.im, dc)};
                         put(ya, veca, k0 + 2 * m, c2_a(o));
                         if (hasB) put(yb, vecb, k0 + 2 * m, c2_b(o));
                     }
@@ -1042,7 +1049,8 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
     }
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
-        D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1);
+        D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,
+                   kXfStep, 0, ns, 0.f);
         return D4W_OK;
     }
     for (int t = 0; t < ntpl; ++t) {
@@ -1050,8 +1058,44 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
         D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
-                   t == 0 ? y0 : y1, (float*)nullptr);
+                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f);
     }
+    return D4W_OK;
+}
+
+/* Zero-phase FIR along time by overlap-save FFT blocks (the interior of a zero-phase IIR filter: its two-sided
+ * response truncated where it has decayed): y[r][n] = sum_j taps[j] x[r][n - K + j], j < 2K + 1, for K <= n < ns - K.
+ * The columns within K of either row end are NOT written.  first[r] (a constant per row, e.g. the row's first sample)
+ * is subtracted from the samples before the transform and first[r] * dc_gain added back (dc_gain = sum of the taps
+ * as the exact filter has it), which keeps a large offset out of the float32 transform. */
+int d4w_fir_fft_max_halfwidth(void) { return (kXfB - 2048) / 2; }
+
+int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
+                    float* y, void* ws, void* stream) {
+    if (!x || !taps || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (K < 0 || (K & 1) || K > d4w_fir_fft_max_halfwidth()) return fail(D4W_EINVAL, "half width %d must be even and <= %d", K, d4w_fir_fft_max_halfwidth());
+    if (ns <= 2 * K) return fail(D4W_EINVAL, "rows of %d samples have no interior for a half width of %d", ns, K);
+    if (nx > 2 * 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
+    float* w = (float*)ws;
+    XfTables T;
+    float2* gp = (float2*)w;
+    float* gn = w + 2 * 2 * kXfMB;
+    float2* tw1 = (float2*)(gn + 8);
+    float2* tw2 = tw1 + kXfM1;
+    float2* wg = tw2 + kXfM1;
+    float2* twa = wg + kXfNG;
+    T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg; T.twa = twa;
+    const int L = 2 * K + 1;
+    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
+               tw1, tw2, wg, twa);
+    const int step = kXfB - 2 * K;
+    const dim3 grid(ceil_div(ns - 2 * K, step), ceil_div(nx, 2));
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+#ifndef D4W_EMU
+    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+#endif
+    D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
+               (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain);
     return D4W_OK;
 }
 

@@ -271,15 +271,75 @@ def _sos_segment_length(nx, ns, warm, half_waves=None):
     return best
 
 
-def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
-    """x: float32 CUDA tensor [nx, ns] -> filtered tensor (new)."""
+def _zero_phase_response(sos, tol_taps=1e-8, tol_edge=1e-9, nmax=1 << 18):
+    """Two-sided response g = h * h(-t) of the zero-phase cascade (host, float64): returns (taps [2K + 1], K, E) with
+    K the even half width beyond which sum|g| is below tol_taps of the total, E >= K the distance from a row end
+    beyond which the edge rule of filtfilt (odd extension, steady-state initial conditions) has decayed below
+    tol_edge.  None when the response does not decay within nmax samples."""
     import scipy.signal as sp
-    sos = np.ascontiguousarray(np.atleast_2d(np.asarray(sos, dtype=np.float64)))
-    if sos.ndim != 2 or sos.shape[1] != 6:
-        raise ValueError("sos array must be shape (n_sections, 6)")
+    n = 4096
+    while True:
+        imp = np.zeros(n)
+        imp[0] = 1.0
+        h = sp.sosfilt(sos, imp)
+        H = np.fft.rfft(h, 2 * n)
+        g = np.fft.irfft(H * np.conj(H), 2 * n)[:n]             # g[m], m >= 0 (symmetric)
+        a = np.abs(g)
+        tail = np.cumsum(a[::-1])[::-1]
+        tail = tail / max(tail[0], 1e-300)
+        ok_t, ok_e = np.nonzero(tail < tol_taps)[0], np.nonzero(tail < tol_edge)[0]
+        if len(ok_e) and ok_e[0] < n // 4:
+            K = int(ok_t[0]) + (int(ok_t[0]) & 1)
+            E = int(ok_e[0]) + (int(ok_e[0]) & 1)
+            taps = np.concatenate((g[K:0:-1], g[:K + 1]))
+            return taps, K, max(E, K)
+        if n >= nmax:
+            return None
+        n *= 2
+
+
+_zp_cache = {}
+
+
+def _sosfiltfilt_fft(x, sos, padlen):
+    """Interior by ONE overlap-save FFT pass with the truncated zero-phase response (d4w_fir_fft_f32, 8 B per sample),
+    the E columns at either row end by the exact recursion on short row pieces.  Returns None when the form does not
+    apply (response too long for the FFT block, rows too short for it to pay)."""
+    import os
+    import scipy.signal as sp
+    if os.environ.get("D4W_BP_FFT", "1") == "0":
+        return None
     nx, ns = x.shape
-    if ns <= padlen:
-        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % padlen)
+    key = (sos.tobytes(), sos.shape)
+    zp = _zp_cache.get(key)
+    if zp is None:
+        if len(_zp_cache) > 16:
+            _zp_cache.clear()
+        zp = _zp_cache[key] = _zero_phase_response(sos) or ()
+    if not zp:
+        return None
+    taps, K, E = zp
+    P = 2 * E                                        # piece length: E kept + E for the artificial cut to decay
+    if K > int(lib.d4w_fir_fft_max_halfwidth()) or ns < 8 * P or P <= padlen:
+        return None
+    dcg = float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        t = torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(x.device)
+        first = x[:, 0].contiguous()
+        ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
+        check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y), dev.ptr(ws),
+                                  dev.stream_ptr(x)))
+        y[:, :E] = _sosfiltfilt_recursive(x[:, :P].contiguous(), sos, padlen, 0, 0)[:, :E]
+        y[:, ns - E:] = _sosfiltfilt_recursive(x[:, ns - P:].contiguous(), sos, padlen, 0, 0)[:, P - E:]
+        torch.cuda.current_stream().synchronize()    # t, first, ws are temporaries
+    return y
+
+
+def _sosfiltfilt_recursive(x, sos, padlen, seg_len=None, warm=None):
+    """The exact second-order-section recursion (forward + backward launch, 16 B per sample)."""
+    import scipy.signal as sp
+    nx, ns = x.shape
     zi = np.ascontiguousarray(sp.sosfilt_zi(sos), dtype=np.float64)
     if warm is None:
         warm = -(-int(1.5 * _sos_decay_samples(sos)) // 32) * 32
@@ -296,6 +356,23 @@ def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
                                       sos.shape[0], int(padlen), int(seg_len), int(warm), dev.ptr(ws),
                                       dev.stream_ptr(x)))
     return y
+
+
+def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
+    """x: float32 CUDA tensor [nx, ns] -> filtered tensor (new).  Long rows with a response short enough for one FFT
+    block run the overlap-save form (interior) + the recursion at the row ends; everything else the recursion.
+    seg_len / warm pin the recursion's segmentation (and select it)."""
+    sos = np.ascontiguousarray(np.atleast_2d(np.asarray(sos, dtype=np.float64)))
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError("sos array must be shape (n_sections, 6)")
+    nx, ns = x.shape
+    if ns <= padlen:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % padlen)
+    if seg_len is None and warm is None:
+        y = _sosfiltfilt_fft(x, sos, padlen)
+        if y is not None:
+            return y
+    return _sosfiltfilt_recursive(x, sos, padlen, seg_len, warm)
 
 
 def _rows_2d(data):

@@ -195,10 +195,12 @@ def gabor_mask(trf_fk, fs, dx, selected_channels, c0=1500., threshold=9100., thr
     uh, uw = int(bh * bin_factor), int(bw * bin_factor)
     if (uh, uw) != (nx, ns):
         raise ValueError(f"operands could not be broadcast together with shapes ({nx},{ns}) ({uh},{uw})")
-    mask_sparse = _resize_device(mask, uh, uw)
-    masked = _mask_mul_device(x, mask_sparse)
+    # binning() of a bool mask is bool (True wherever a True pixel has non-zero weight, improcess.py:416-420): the
+    # interpolated weights are binarised before the multiplication (array * bool mask, improcess.py:452)
+    mask_sparse = (_resize_device(mask, uh, uw) != 0)
+    masked = _mask_mul_device(x, mask_sparse.to(torch.float32))
     res = {"image": image, "imagebin": imagebin, "fimage": fimage, "score": score, "mask": mask != 0,
-           "mask_sparse": mask_sparse != 0, "masked_tr": masked}
+           "mask_sparse": mask_sparse, "masked_tr": masked}
     if dev.is_tensor(trf_fk):
         return res
     out = {}

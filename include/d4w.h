@@ -230,6 +230,18 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
                       const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                       float* y1, void* ws, void* stream);
 
+/* Zero-phase FIR along time by overlap-save FFT blocks -- the INTERIOR of dsp.bp_filt / scipy.signal.sosfiltfilt
+ * (dsp.py:859-880): away from the row ends a zero-phase IIR filter is the convolution with its two-sided response
+ * g = h * h(-t), truncated at half width K where it has decayed below the tolerance (north star: "overlap-save FIR").
+ *   y[r][n] = sum_{j <= 2K} taps[j] x[r][n - K + j]   for K <= n < ns - K;  the K columns at either row end are not
+ *   written (the caller fills them with the exact recursion, d4w_sosfiltfilt_f32 on short pieces).
+ * first[r] (device, e.g. the row's first sample) is subtracted before the transform and first[r] * dc_gain added
+ * back, which keeps a large offset out of the float32 transform (dc_gain = |H(1)|^2 of the exact filter).
+ * One read and one write of the block (8 B per sample).  K even, <= d4w_fir_fft_max_halfwidth(); ws as d4w_xcorr_fft_f32. */
+int d4w_fir_fft_max_halfwidth(void);
+int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
+                    float* y, void* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * f-k mask design on the device (one-off per shape), float32 masks on the fftshift-ed (k, f)
  * grid, row-major [nx][ns] -- what d4w_fk_set_mask_dense_f32 takes.  Closed forms of the

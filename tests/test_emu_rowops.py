@@ -294,3 +294,29 @@ def test_sosfiltfilt_dc_offset_and_lowpass(emu):
     assert emu.d4w_sosfiltfilt_f32(vp(buf), vp(buf), 70, 3654, vp(np.ascontiguousarray(lp)), vp(zi), lp.shape[0], 15, 0, 0,
                                    vp(ws), None) == 0
     assert rel(buf, ref_lp) < TOL
+
+
+@pytest.mark.parametrize("ns,K", [(9000, 460), (5000, 0), (12000, 1024), (4500, 30)])
+def test_fir_fft_interior(emu, ns, K):
+    """d4w_fir_fft_f32 (overlap-save FFT blocks, the interior of the zero-phase band-pass): y[n] = sum_j taps[j] x[n - K + j]
+    on K <= n < ns - K, nothing written outside, the subtracted row constant restored through dc_gain."""
+    rng = np.random.default_rng(ns + K)
+    nx = 5
+    x = (rng.standard_normal((nx, ns)) + np.arange(nx)[:, None] * 30.0).astype(np.float32)      # large per-row offsets
+    taps = rng.standard_normal(2 * K + 1) * np.hanning(2 * K + 3)[1:-1]
+    taps = ((taps + taps[::-1]) / 2).astype(np.float32)
+    first = np.ascontiguousarray(x[:, 0])
+    y = np.full((nx, ns), np.nan, dtype=np.float32)
+    emu.d4w_xcorr_fft_ws_bytes.restype = ctypes.c_size_t
+    ws = np.empty(emu.d4w_xcorr_fft_ws_bytes(), dtype=np.uint8)
+    emu.d4w_fir_fft_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    dcg = float(taps.astype(np.float64).sum())
+    rc = emu.d4w_fir_fft_f32(vp(x), nx, ns, vp(taps), K, vp(first), dcg, vp(y), vp(ws), None)
+    assert rc == 0, emu.d4w_last_error()
+    assert np.isnan(y[:, :K]).all() and np.isnan(y[:, ns - K:]).all()
+    ref = np.stack([np.convolve(r.astype(np.float64), taps.astype(np.float64)[::-1], "valid") for r in x])
+    got = y[:, K:ns - K]
+    assert not np.isnan(got).any()
+    assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(ref))
+    assert emu.d4w_fir_fft_f32(vp(x), nx, ns, vp(taps), 1026, vp(first), dcg, vp(y), vp(ws), None) != 0
