@@ -303,36 +303,42 @@ _zp_cache = {}
 
 def _sosfiltfilt_fft(x, sos, padlen):
     """Interior by ONE overlap-save FFT pass with the truncated zero-phase response (d4w_fir_fft_f32, 8 B per sample),
-    the E columns at either row end by the exact recursion on short row pieces.  Returns None when the form does not
-    apply (response too long for the FFT block, rows too short for it to pay)."""
+    the E columns at either row end by the exact recursion on short row pieces (both ends of all rows in one call).
+    Returns None when the form does not apply (response too long for the FFT block) or does not pay (the recursion is
+    faster on rows shorter than ~24 pieces: measured 0.95 vs 1.8 ms at 4000 x 12000, 10.3 vs 6.7 ms at 20000 x 120000)."""
     import os
-    import scipy.signal as sp
     if os.environ.get("D4W_BP_FFT", "1") == "0":
         return None
     nx, ns = x.shape
-    key = (sos.tobytes(), sos.shape)
+    key = (sos.tobytes(), sos.shape, str(x.device))
     zp = _zp_cache.get(key)
     if zp is None:
         if len(_zp_cache) > 16:
             _zp_cache.clear()
-        zp = _zp_cache[key] = _zero_phase_response(sos) or ()
+        r = _zero_phase_response(sos, tol_taps=1e-7)
+        if r is not None:
+            taps, K, E = r
+            r = (torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(x.device), K, E,
+                 float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2)
+        zp = _zp_cache[key] = r or ()
     if not zp:
         return None
-    taps, K, E = zp
+    t, K, E, dcg = zp
     P = 2 * E                                        # piece length: E kept + E for the artificial cut to decay
-    if K > int(lib.d4w_fir_fft_max_halfwidth()) or ns < 8 * P or P <= padlen:
+    if K > int(lib.d4w_fir_fft_max_halfwidth()) or ns < 24 * P or P <= padlen:
         return None
-    dcg = float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        t = torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(x.device)
         first = x[:, 0].contiguous()
         ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
         check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y), dev.ptr(ws),
                                   dev.stream_ptr(x)))
-        y[:, :E] = _sosfiltfilt_recursive(x[:, :P].contiguous(), sos, padlen, 0, 0)[:, :E]
-        y[:, ns - E:] = _sosfiltfilt_recursive(x[:, ns - P:].contiguous(), sos, padlen, 0, 0)[:, P - E:]
-        torch.cuda.current_stream().synchronize()    # t, first, ws are temporaries
+        # the row ends: the left and the right piece of every row as one [2 nx, P] block (filtfilt's edge rule is not
+        # symmetric under time reversal, so the right pieces stay in natural order and keep their LAST E outputs)
+        ends = torch.cat((x[:, :P], x[:, ns - P:]), dim=0)
+        ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
+        y[:, :E] = ye[:nx, :E]
+        y[:, ns - E:] = ye[nx:, P - E:]
     return y
 
 
