@@ -164,13 +164,132 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     dist.destroy_process_group()
 
 
+def bench_stream(args, world, rank, device, dist):
+    """BASELINE configs[4]: consecutive 60-s files streamed through the whole detection chain -- fused ingest, band-pass
+    carried across file boundaries (halo), per-file f-k filter, HF + LF matched filter whose last lags continue into the
+    next file, envelope picks, spectrogram-correlation detector.  N GPUs: the record is dealt in runs of consecutive
+    files (rank r owns files [r F, (r + 1) F), SURVEY 8e "consecutive files to the same GPU"), so only the run boundaries
+    cross ranks: one raw halo each way (exchanged up front, the raw data being resident) and one filtered head that rank
+    r + 1 sends as soon as its first file is filtered and rank r needs only for its last file.  Weak scaling."""
+    import das4whales_amd as dw
+    from das4whales_amd import data_handle, detect as ddet, dsp as ddsp, stream
+    nx = args.nx if args.nx else 11020
+    ns = args.ns if args.ns else 12000
+    fs, dx, halo = 200.0, 2.0419046878814697, 1024
+    F = max(2, args.files)
+    sel = [0, nx, 1]
+    meta = {"scale_factor": 1.7e-11, "fs": fs, "dx": dx}
+    mask = ddsp.hybrid_ninf_filter_design((nx, ns), [0, nx * 4, 4], dx, fs, 1350., 1450., 3300, 3450, 14., 30.)
+    t = np.arange(ns) / fs
+    hf = ddet.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)
+    lf = ddet.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)
+    lmax = max(len(ddet._normalised_support(hf)), len(ddet._normalised_support(lf)))
+    kernel = {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}
+
+    def raw_file(i):                                   # synthetic raw int32 file i of the record (same on whichever rank makes it)
+        g = torch.Generator(device=device).manual_seed(1000 + i)
+        return (torch.randn((nx, ns), device=device, generator=g) * 3e4).to(torch.int32)
+
+    def strain(raw):
+        x, _, _ = data_handle.load_das_data_array(raw, sel, meta)
+        return x * 1e9
+
+    first_file = rank * F
+    raws = [raw_file(first_file + j) for j in range(F)]
+    # raw halos across the run boundaries (set-up, not timed: the raw record is resident)
+    prev_tail = next_head = None
+    if world > 1:
+        my_head = strain(raws[0])[:, :halo].contiguous()
+        my_tail = strain(raws[-1])[:, -halo:].contiguous()
+        prev_tail = torch.empty_like(my_tail) if rank > 0 else None
+        next_head = torch.empty_like(my_head) if rank < world - 1 else None
+        ops = []
+        if rank < world - 1:
+            ops += [dist.P2POp(dist.isend, my_tail, rank + 1), dist.P2POp(dist.irecv, next_head, rank + 1)]
+        if rank > 0:
+            ops += [dist.P2POp(dist.isend, my_head, rank - 1), dist.P2POp(dist.irecv, prev_tail, rank - 1)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def run():
+        pend = {}
+        nxt_filt = torch.empty((nx, lmax - 1), dtype=torch.float32, device=device) if (world > 1 and rank < world - 1) else None
+        if nxt_filt is not None:
+            pend["recv"] = dist.irecv(nxt_filt, rank + 1)
+
+        def on_filtered(idx, y):
+            if idx == 0 and world > 1 and rank > 0:          # the previous rank's last file waits for this head
+                pend["head"] = y[:, :lmax - 1].contiguous()
+                pend["send"] = dist.isend(pend["head"], rank - 1)
+
+        def filtered_head():
+            pend["recv"].wait()
+            return nxt_filt
+
+        st = stream.FileStream(fs, 14, 30, templates=[hf, lf], fk_mask=mask, halo=halo, prev_tail=prev_tail, on_filtered=on_filtered)
+        npicks = 0
+
+        def detect_on(done):
+            n = 0
+            for r in done:
+                thr = 0.45 * float(r["correlograms"][0].max())
+                for c in r["correlograms"]:
+                    n += ddet.pick_times_env(c, thr).total
+                ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)
+            return n
+        for raw in raws:
+            npicks += detect_on(st.push(strain(raw)))
+        npicks += detect_on(st.flush(next_head=next_head, next_filtered_head=filtered_head if nxt_filt is not None else None))
+        if "send" in pend:
+            pend["send"].wait()
+        return npicks
+
+    for _ in range(max(1, args.warmup // 2)):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    npicks = 0
+    reps = max(1, args.steps // 5)
+    for _ in range(reps):
+        npicks += run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt, float(npicks)], dtype=torch.float64, device=device)
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+        dt, npicks = float(tt[0]), float(tt[1])
+    if rank == 0:
+        nfiles = reps * F * world
+        out = {"metric": "channel-samples/sec through the streaming detection chain (ingest + band-pass + f-k + matched filter + picks + spectrogram correlation)",
+               "value": nfiles * float(nx) * ns / dt, "unit": "channel-samples/s", "n_gpus": world, "steps": reps * F, "warmup": args.warmup,
+               "ms_per_step": dt / (reps * F) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "files_per_s": nfiles / dt, "detections_per_s": npicks / dt, "detections": npicks,
+               "config": {"workload": "%d consecutive 60-s files of %d channels x %d samples per GPU (int32 raw), halo %d samples, "
+                                      "hybrid_ninf f-k mask, HF+LF templates, envelope picks at 0.45 max, spectrogram correlation"
+                                      % (F, nx, ns, halo), "parallelism": "runs of consecutive files x%d, halo hand-off between neighbours" % world}}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nx", type=int, default=20000)
-    ap.add_argument("--ns", type=int, default=120000)
+    ap.add_argument("--nx", type=int, default=0, help="channels (default 20000; --config stream: 11020)")
+    ap.add_argument("--ns", type=int, default=0, help="samples (default 120000; --config stream: 12000)")
+    ap.add_argument("--config", type=str, default="block", choices=["block", "stream"],
+                    help="block = the f-k + matched-filter step on one resident block (BASELINE configs[2] / [3]); stream = "
+                         "BASELINE configs[4]: consecutive 60-s files through the whole detection chain, files/s and detections/s")
+    ap.add_argument("--files", type=int, default=8, help="--config stream: consecutive files per GPU")
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="8000x24000")
     ap.add_argument("--no-cpu", action="store_true")
@@ -210,6 +329,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    if args.config == "stream":
+        return bench_stream(args, world, rank, device, dist)
+    args.nx = args.nx or 20000
+    args.ns = args.ns or 120000
     if args.shard == "channel":
         return bench_channel_sharded(args, stages, world, rank, device, dist)
 

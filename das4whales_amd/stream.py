@@ -27,10 +27,13 @@ from . import detect, dsp
 
 
 class FileStream:
-    def __init__(self, fs, fmin, fmax, templates=(), fk_mask=None, halo=1024):
+    def __init__(self, fs, fmin, fmax, templates=(), fk_mask=None, halo=1024, prev_tail=None, on_filtered=None):
         """fs, fmin, fmax: band-pass (dsp.bp_filt arguments); templates: full-length or support-only
         template vectors (detect.gen_template_fincall output) for the matched filter; fk_mask: f-k mask
-        for one file's shape (any form dsp.fk_filter_filt accepts) or None to skip the f-k filter."""
+        for one file's shape (any form dsp.fk_filter_filt accepts) or None to skip the f-k filter.
+        prev_tail: the last `halo` raw samples of the file BEFORE the first one pushed (a stream that continues a
+        record another process holds, e.g. the previous rank's last file); on_filtered(index, y): called as soon as a
+        file's band-passed (+ f-k filtered) version exists (the neighbour that needs its head can be served early)."""
         self.fs, self.fmin, self.fmax = float(fs), float(fmin), float(fmax)
         self.halo = int(halo)
         self.taps = [detect._normalised_support(t) for t in templates]
@@ -40,7 +43,8 @@ class FileStream:
         self.lmax = max((len(t) for t in self.taps), default=1)
         self.fk_mask = fk_mask
         self._raw = []          # raw files waiting for their right halo: [(index, tensor)]
-        self._prev_tail = None  # last `halo` raw samples of the file before self._raw[0]
+        self._prev_tail = dev.to_device_f32(prev_tail) if prev_tail is not None else None   # last `halo` raw samples of the file before self._raw[0]
+        self._on_filtered = on_filtered
         self._filt = []         # filtered (band-pass [+ f-k]) files waiting for the next file's head
         self._n = 0
         self._sos = None
@@ -64,6 +68,8 @@ class FileStream:
         self._prev_tail = cur[:, -self.halo:].contiguous() if self.halo > 0 else None
         if self.fk_mask is not None:
             y = dsp.fk_filter_filt(y, self.fk_mask)
+        if self._on_filtered is not None:
+            self._on_filtered(idx, y)
         return idx, y
 
     def _correlate(self, idx, y, next_head):
@@ -109,15 +115,22 @@ class FileStream:
             done.append(self._correlate(idx, y, self._filt[0][1]))
         return done
 
-    def flush(self):
-        """End of the stream: finish the files still waiting (their right edge is a true record end)."""
+    def flush(self, next_head=None, next_filtered_head=None):
+        """End of the stream: finish the files still waiting.  By default their right edge is a true record end;
+        when the record continues elsewhere, next_head = the first `halo` raw samples of the following file and
+        next_filtered_head = the first lmax - 1 filtered samples of it (a tensor, or a callable returning one -- e.g.
+        the wait on a receive posted earlier)."""
         done = []
+        head = dev.to_device_f32(next_head)[:, :self.halo].contiguous() if next_head is not None and self.halo > 0 else None
         while self._raw:
-            self._filt.append(self._finish_bandpass(None))
+            self._filt.append(self._finish_bandpass(head if len(self._raw) == 1 else self._raw[1][1][:, :self.halo].contiguous()))
             while len(self._filt) >= 2:
                 idx, y = self._filt.pop(0)
                 done.append(self._correlate(idx, y, self._filt[0][1]))
         while self._filt:
             idx, y = self._filt.pop(0)
-            done.append(self._correlate(idx, y, self._filt[0][1] if self._filt else None))
+            nxt = self._filt[0][1] if self._filt else None
+            if nxt is None and next_filtered_head is not None:
+                nxt = next_filtered_head() if callable(next_filtered_head) else next_filtered_head
+            done.append(self._correlate(idx, y, nxt))
         return done

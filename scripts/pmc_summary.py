@@ -32,16 +32,20 @@ if "--traffic" in sys.argv:
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024.0
         write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024.0
         name = k.split("<")[0]
-        if name == "fk_passC":
-            name = "fk_passC_inv" if "<true" in k else "fk_passC_fwd"
+        if name in ("fk_passC", "fkf_passC"):
+            # generic kernel: fk_passC<INV, GENERIC>; specialised: fkf_passC<FkFastCfg<...>, INV, MODE>
+            targ = k[k.rindex(">, ") + 3:] if name == "fkf_passC" and ">, " in k else k[k.index("<") + 1:]
+            name = "fk_passC_inv" if targ.strip().startswith("true") else "fk_passC_fwd"
+        name = {"fkf_passA_fwd": "fk_passA_fwd", "fkf_passA_inv": "fk_passA_inv", "fkf_passA_inv_stats": "fk_passA_inv",
+                "fkf_passB": "fk_passB"}.get(name, name)
         if (name == "xcorr_fft_blocks" and ", true>" in k) or name == "xcorr_fft_fused4":
             name = "xcorr_fft_fused"                    # the two-template launch (one read, two correlograms)
         name = alias.get(name, name)
-        # gfx950: FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM), so
-        # kernels whose reads are >= 128-byte contiguous per row piece are doubled; pass C reads
-        # 64-byte column strips (TC = 8 complex) whose requests are counted in full -- calibrated
-        # on the known byte count of the block (raw FETCH_SIZE == 9.6 GB == the block).
-        factor = 1.0 if name.startswith("fk_passC") else 2.0
+        # gfx950: FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM), so kernels whose reads
+        # are >= 128-byte contiguous per row piece are doubled: every pass of the shape-specialised f-k kernels reads
+        # 128-byte strips (TA = TC = 16 complex).  Only the GENERIC pass C at TC = 8 (64-byte strips) is counted in
+        # full -- calibrated on the known byte count of the block (raw FETCH_SIZE == 9.6 GB == the block).
+        factor = 1.0 if (name.startswith("fk_passC") and k.startswith("fk_passC")) else 2.0
         out[name] = {"kernel": k, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
                      "fetch_factor": factor, "hbm_bytes_per_launch": factor * fetch + write,
                      "note": "FETCH_SIZE in KiB; x2 for wide (>=128 B) requests, x1 for 64-byte strips"}
