@@ -54,6 +54,11 @@ struct FkDev {  // kernel argument block (by value)
     AxisDesc ax_bs;           // the length-bs_L transform
     const float2* bs_chirp;   // [C2]    exp(-i pi n^2 / C2)
     const float2* bs_filt;    // [bs_L]  FFT of the conjugate chirp (wrapped) / bs_L, at the DIF positions of ax_bs
+    // the same for the n2 sub-transform of pass B (ns / 2 has a prime factor > 31): bn_L = 0: off
+    int bn_L;
+    AxisDesc ax_bn;
+    const float2* bn_chirp;   // [N2]
+    const float2* bn_filt;    // [bn_L]
 };
 
 }  // namespace d4w
@@ -403,6 +408,82 @@ __global__ __launch_bounds__(kMaxThreads) void fk_passB(FkDev P, float2* __restr
     }
 }
 
+// pass B when N2 has a prime factor > 31: the n2 sub-transforms of the row pair run as Bluestein convolutions of
+// length bn_L inside the tile (see fk_passC_bluestein), spectra in NATURAL order (the plan's position -> frequency
+// tables of the n2 axis are the identity, so the pair op below is fk_passB's, table for table).
+__global__ __launch_bounds__(kMaxThreads) void fk_passB_bluestein(FkDev P, float2* __restrict__ data, int npairs) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N2 = d.N2, L = P.bn_L;
+    const TwLds tw = tw_stage(P.ax_bn, tile + 2 * L, tid, nthr);
+    for (int t = blockIdx.x; t < npairs; t += gridDim.x) {
+        const int2 pr = P.pairs[t];
+        const bool same = (pr.x == pr.y);
+        const int nrows = same ? 1 : 2;
+        float2* rowA = data + (size_t)pr.x * N2;
+        float2* rowB = data + (size_t)pr.y * N2;
+        for (int w = tid; w < nrows * L; w += nthr) {
+            const int r = w / L, n = w - r * L;
+            tile[w] = (n < N2) ? c_mul((r ? rowB : rowA)[n], P.bn_chirp[n]) : make_float2(0.f, 0.f);
+        }
+        lds_barrier();
+        lds_fft<false, false, false>(tile, P.ax_bn, tw, 1, nrows, L, 1, 0, tid, nthr);
+        for (int w = tid; w < nrows * L; w += nthr) tile[w] = c_mul(tile[w], P.bn_filt[w % L]);
+        lds_barrier();
+        lds_fft<true, false, false>(tile, P.ax_bn, tw, 1, nrows, L, 1, 0, tid, nthr);
+        for (int w = tid; w < nrows * N2; w += nthr) {
+            const int r = w / N2, k = w - r * N2;
+            tile[r * L + k] = c_mul(tile[r * L + k], P.bn_chirp[k]);
+        }
+        lds_barrier();
+        // ---- pair op x mask (fk_passB)
+        float2* A = tile;
+        float2* B = same ? tile : tile + L;
+        const int r = pr.x / d.N1, q1 = pr.x - r * d.N1;
+        const bool k1zero = (q1 == 0);
+        const float* mA = P.mask + (size_t)pr.x * N2;
+        const float* mB = P.mask + (size_t)pr.y * N2;
+        const float2 wr = P.wrow[q1];
+        const float nyq = P.nyq[r];
+        for (int i = tid; i < N2; i += nthr) {
+            const int j = k1zero ? P.mirror0[i] : (N2 - 1 - i);
+            if (same && j < i) continue;
+            const float2 a = A[i];
+            const float2 Bc = c_conj(B[j]);
+            const float ma = mA[i];
+            const float mb = (k1zero && i == 0) ? nyq : mB[j];
+            const float2 w = c_mul(wr, P.wcol[i]);
+            const float2 E = c_scale(c_add(a, Bc), 0.5f);
+            const float2 O = c_mul_mi(c_scale(c_sub(a, Bc), 0.5f));
+            const float2 tO = c_mul(w, O);
+            const float2 Yp = c_scale(c_add(E, tO), ma);
+            const float2 Ym = c_scale(c_sub(E, tO), mb);
+            const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
+            const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+            A[i] = c_add(S, D);
+            B[j] = c_conj(c_sub(S, D));
+        }
+        lds_barrier();
+        // ---- inverse n2 transforms (conjugate chirp and filter), zero padding restored first
+        for (int w = tid; w < nrows * L; w += nthr) {
+            const int rr = w / L, n = w - rr * L;
+            tile[w] = (n < N2) ? c_mulc(tile[w], P.bn_chirp[n]) : make_float2(0.f, 0.f);
+        }
+        lds_barrier();
+        lds_fft<false, false, false>(tile, P.ax_bn, tw, 1, nrows, L, 1, 0, tid, nthr);
+        for (int w = tid; w < nrows * L; w += nthr) tile[w] = c_mulc(tile[w], P.bn_filt[w % L]);
+        lds_barrier();
+        lds_fft<true, false, false>(tile, P.ax_bn, tw, 1, nrows, L, 1, 0, tid, nthr);
+        for (int w = tid; w < nrows * N2; w += nthr) {
+            const int rr = w / N2, k = w - rr * N2;
+            (rr ? rowB : rowA)[k] = c_mulc(tile[rr * L + k], P.bn_chirp[k]);
+        }
+        lds_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // mask fold + permutation into pass-B order (one-off per mask)
 // ---------------------------------------------------------------------------------------------
@@ -727,10 +808,22 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
                 if (e.nx == nx && e.ns == ns && (e.variant == want || (!fast && e.variant == 0))) fast = &e;
     }
     if (fast_only && !fast) return fail(D4W_EINVAL, "no shape-specialised kernels for %d x %d", nx, ns);
+    // A prime factor > 31 of ns / 2 goes into N2, whose sub-transforms (pass B) then run as Bluestein convolutions of
+    // length bn_L = 2^k >= 2 N2 - 1 inside the tile (two rows of bn_L); N1 keeps the smooth part.
+    int bn_L = 0, bn_N2 = 0;
+    if (!fast && rough_part(M) > 1) {
+        bn_N2 = rough_part(M);
+        bn_L = 1;
+        while (bn_L < 2 * bn_N2 - 1) bn_L *= 2;
+        if (2L * bn_L > kMaxTile)
+            return fail(D4W_EINVAL, "ns / 2 = %d: the part with prime factors > 31 (%d) is too long for the Bluestein tile (limit %d); "
+                        "dsp.supported_length(n) gives the nearest shorter length with a direct kernel", M, bn_N2, kMaxTile / 4);
+    }
     // admissible time splits: N1 | M with N2 = M / N1 fitting one LDS row pair
     int n1_min = 0;
     for (int cand = 1; cand <= M && !n1_min; ++cand)
         if (M % cand == 0 && M / cand <= kMaxTile / 2) n1_min = cand;
+    if (bn_L) n1_min = M / bn_N2;
     if (!n1_min) return fail(D4W_EINVAL, "ns/2 = %d has no factorisation with N2 <= %d", M, kMaxTile / 2);
     // --- split the channel axis
     int C1 = o[0], C2 = o[1];
@@ -763,7 +856,16 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
     //     grows with N1 (shorter rows): N1 ~ sqrt(1000 / C1), at least the smallest admissible one
     //     (measured at 1000 x 12000 and 500 x 120000 over C1 = 1..10, N1 = 2..75)
     int N1 = o[2], N2 = o[3];
-    if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
+    if (bn_L) {
+        // smooth factors move from N1 into N2 while the Bluestein tile allows it and pass A's tile needs it
+        N1 = M / bn_N2; N2 = bn_N2;
+        for (int f = 2; f <= 31 && (long)C1 * N1 > kMaxTile; ++f)
+            while (N1 % f == 0 && (long)C1 * N1 > kMaxTile && 2L * (2L * N2 * f - 1) <= kMaxTile) { N2 *= f; N1 /= f; }
+        bn_L = 1;
+        while (bn_L < 2 * N2 - 1) bn_L *= 2;
+        if (2L * bn_L > kMaxTile || (long)C1 * N1 > kMaxTile)
+            return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling with a Bluestein time axis (C1=%d N1=%d N2=%d)", nx, ns, C1, N1, N2);
+    } else if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
         N1 = n1_min;
         const double target = sqrt(1000.0 / (double)C1);
         double best = fabs(log((double)N1 / target));
@@ -785,7 +887,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         TA = fast->TA; TC = fast->TC;
         r_c1 = {C1}; r_c2 = {fast->C2A, fast->C2B}; r_n1 = {N1}; r_n2 = {fast->NA, fast->NB, fast->NC};
     }
-    if (!fast && ((long)(bs_L ? bs_L : C2) * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * N2 > kMaxTile))
+    if (!fast && ((long)(bs_L ? bs_L : C2) * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * (bn_L ? bn_L : N2) > kMaxTile))
         return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling (C1=%d C2=%d N1=%d N2=%d)",
                     nx, ns, C1, C2, N1, N2);
 
@@ -822,7 +924,28 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
     } else
         D4W_TRY(make_axis(pl, C2, &pl->dev.ax_c2, &f_c2, fast ? &r_c2 : nullptr));
     D4W_TRY(make_axis(pl, N1, &pl->dev.ax_n1, &f_n1, fast ? &r_n1 : nullptr));
-    D4W_TRY(make_axis(pl, N2, &pl->dev.ax_n2, &f_n2, fast ? &r_n2 : nullptr));
+    if (bn_L) {
+        std::vector<int> one, f_L;
+        D4W_TRY(make_axis(pl, 1, &pl->dev.ax_n2, &one));                      // unused: pass B runs fk_passB_bluestein
+        D4W_TRY(make_axis(pl, bn_L, &pl->dev.ax_bn, &f_L));
+        f_n2.resize(N2);
+        for (int i = 0; i < N2; ++i) f_n2[i] = i;                             // natural output order
+        std::vector<float2> chirp(N2), filt(bn_L);
+        std::vector<double> bre(bn_L, 0.0), bim(bn_L, 0.0);
+        for (int n = 0; n < N2; ++n) {
+            const double ph = M_PI * (double)(((long long)n * n) % (2LL * N2)) / (double)N2;
+            chirp[n] = make_float2((float)cos(ph), (float)-sin(ph));
+            bre[n] = cos(ph); bim[n] = sin(ph);                               // conj(chirp)
+            if (n) { bre[bn_L - n] = cos(ph); bim[bn_L - n] = sin(ph); }
+        }
+        host_fft_pow2(bre, bim);
+        for (int p = 0; p < bn_L; ++p)
+            filt[p] = make_float2((float)(bre[f_L[p]] / bn_L), (float)(bim[f_L[p]] / bn_L));
+        D4W_TRY(upload(pl, chirp, &pl->dev.bn_chirp));
+        D4W_TRY(upload(pl, filt, &pl->dev.bn_filt));
+        pl->dev.bn_L = bn_L;
+    } else
+        D4W_TRY(make_axis(pl, N2, &pl->dev.ax_n2, &f_n2, fast ? &r_n2 : nullptr));
     if (fast) {     // exchange-stage twiddles of the specialised kernels
         const int RA = fast->C2A, RB = fast->C2B, M1 = fast->NB * fast->NC;
         std::vector<float2> twC((size_t)RA * RB), twB1(M1), twB2(M1);
@@ -958,6 +1081,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
     pl->ldsC = ((size_t)C2 * TC + kTwLo + pl->dev.ax_c2.nhi) * sizeof(float2);
     if (bs_L) pl->ldsC = ((size_t)bs_L * TC + kTwLo + pl->dev.ax_bs.nhi) * sizeof(float2);
     pl->ldsB = ((size_t)2 * N2 + kTwLo + pl->dev.ax_n2.nhi) * sizeof(float2);
+    if (bn_L) pl->ldsB = ((size_t)2 * bn_L + kTwLo + pl->dev.ax_bn.nhi) * sizeof(float2);
     auto env_int = [](const char* name, int dflt) {
         const char* v = getenv(name);
         return (v && atoi(v) > 0) ? atoi(v) : dflt;
@@ -1001,7 +1125,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
                 (const void*)fk_passC<false, true>, (const void*)fk_passC<false, false>,
                 (const void*)fk_passC<true, true>, (const void*)fk_passC<true, false>,
                 (const void*)fk_passC_bluestein<false>, (const void*)fk_passC_bluestein<true>,
-                (const void*)fk_passB<true>, (const void*)fk_passB<false>};
+                (const void*)fk_passB<true>, (const void*)fk_passB<false>, (const void*)fk_passB_bluestein};
             for (const void* f : fns)
                 (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         }
@@ -1212,7 +1336,9 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     else rc = launch_k(gC ? fk_passC<false, true> : fk_passC<false, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
     if (rc) return rc;
     D4W_MARK(2);
-    if ((rc = launch_k(gB ? fk_passB<true> : fk_passB<false>, gridB, blk, pl->ldsB, stream, P, dst, ntB))) return rc;
+    if (P.bn_L) rc = launch_k(fk_passB_bluestein, gridB, blk, pl->ldsB, stream, P, dst, ntB);
+    else rc = launch_k(gB ? fk_passB<true> : fk_passB<false>, gridB, blk, pl->ldsB, stream, P, dst, ntB);
+    if (rc) return rc;
     D4W_MARK(3);
     if (P.bs_L) rc = launch_k(fk_passC_bluestein<true>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
     else rc = launch_k(gC ? fk_passC<true, true> : fk_passC<true, false>, gridC, blk, pl->ldsC, stream, P, dst, ntC);

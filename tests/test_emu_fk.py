@@ -253,3 +253,21 @@ def test_opt_in_tail_pruning(emu):
     assert rel(y, orc.fk_filter_filt(x, m)) < TOL      # and within tolerance of the exact filter on this input
     assert emu.d4w_fk_set_mask_dense_pruned_f32(plan, vp(mf), -1.0, None) != 0
     emu.d4w_fk_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("nx,ns", [(12, 74), (20, 246), (74, 86), (6, 12002), (9, 2 * 5 * 67)])
+def test_record_length_with_large_prime_factor(emu, nx, ns):
+    """ns / 2 with a prime factor > 31 (numpy.fft.fft2 at dsp.py:748 takes any length): the n2 sub-transforms of pass B
+    run as Bluestein convolutions (fk_passB_bluestein); 12002 = 2 x 17 x 353 is a 60-s file cut two samples long."""
+    rng = np.random.default_rng(nx + ns)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    assert rel(fk_emu(emu, x, m), orc.fk_filter_filt(x, m)) < TOL
+    assert rel(fk_emu(emu, x, np.ones((nx, ns))), x) < TOL
+    assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+
+
+def test_record_length_too_long_for_bluestein_tile(emu):
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(8, 2 * 4099, ctypes.byref(plan)) != 0        # prime > 2048 in ns / 2
+    assert b"supported_length" in emu.d4w_last_error()

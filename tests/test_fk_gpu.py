@@ -240,3 +240,14 @@ def test_config_shapes_specialised_vs_generic(dw, nx, ns):
     ident = torch.ones((nx, ns), device="cuda")
     fast.set_mask(ident)
     assert float((fast.apply(x) - x).abs().max()) / float(x.abs().max()) < TOL
+
+
+@pytest.mark.parametrize("nx,ns", [(300, 12002), (40, 2 * 3 * 1009), (74, 2 * 37 * 5)])
+def test_record_length_with_large_prime_factor(dw, nx, ns):
+    """ns / 2 with a prime factor > 31 -- numpy.fft.fft2 (dsp.py:748) takes any length: pass B runs Bluestein
+    convolutions for the n2 sub-transforms.  12002 = 2 x 17 x 353 is a 60-s file cut two samples long."""
+    rng = np.random.default_rng(ns)
+    x = rng.standard_normal((nx, ns))
+    m = orc.hybrid_ninf_filter_design((nx, ns), [0, nx * 4, 4], 2.0419046878814697, 200.0, 1350., 1450., 3300, 3450, 14., 30.)
+    assert rel(dw.dsp.fk_filter_filt(x, m), orc.fk_filter_filt(x, m)) < TOL
+    assert rel(dw.dsp.fk_filter_filt(x, m, tapering=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
