@@ -143,6 +143,26 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    # per-stage times of rank 0 (HIP events on the launch stream; transfers are waited on there), a few extra steps
+    stage_ms = {}
+    for _ in range(3):
+        plan.marks = []
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        y = plan.apply(x_loc) if "fk" in stages else x_loc
+        ev[1].record()
+        if "mf" in stages:
+            ddet._xcorr_device(y, tpl, normalize=True)
+        ev[2].record()
+        if args.gather:
+            shard.all_gather_rows(y, nx)
+        ev[3].record()
+        ev[3].synchronize()
+        for k, (a_, b_) in {"fk_filter": (0, 1), "matched_filter": (1, 2), "all_gather": (2, 3)}.items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + ev[a_].elapsed_time(ev[b_]) / 3
+        for (l0, e0), (l1, e1) in zip(plan.marks[:-1], plan.marks[1:]):
+            stage_ms["fk:" + l1] = stage_ms.get("fk:" + l1, 0.0) + e0.elapsed_time(e1) / 3
+    plan.marks = None
     if rank == 0:
         samples = float(nx) * ns
         ms = dt / args.steps * 1e3
@@ -159,7 +179,7 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
                           "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
                "roofline": {"bound": "hbm", "kernel": "distributed step (%s pass kernels + exchange)" % ("shape-specialised" if plan.packed else "generic"),
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": None}}
+                            "traffic": None, "stage_ms_rank0": stage_ms}}
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 

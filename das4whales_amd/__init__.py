@@ -11,5 +11,8 @@ from . import detect  # noqa: F401
 from . import data_handle  # noqa: F401
 from . import stream  # noqa: F401
 from . import improcess  # noqa: F401
+from . import fkjit  # noqa: F401
+
+fkjit.load_cached()     # shape-specialised f-k kernels compiled on demand earlier (lib/jit/*.so)
 
 __all__ = ["dsp", "detect", "data_handle", "stream", "improcess"]

@@ -32,6 +32,8 @@ def _load():
         "d4w_fk_plan_create": (c_int, [c_int, c_int, P(c_void_p)]),
         "d4w_fk_plan_create_ex": (c_int, [c_int, c_int, P(c_int), P(c_void_p)]),
         "d4w_fk_plan_destroy": (c_int, [c_void_p]),
+        "d4w_fk_shape_is_specialised": (c_int, [c_int, c_int]),
+        "d4w_fk_register_shape": (c_int, [c_void_p, ctypes.c_size_t]),
         "d4w_fk_plan_info": (c_int, [c_void_p, P(c_int)]),
         "d4w_fk_set_mask_dense_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
         "d4w_fk_set_mask_dense_pruned_f32": (c_int, [c_void_p, c_void_p, ctypes.c_double, c_void_p]),

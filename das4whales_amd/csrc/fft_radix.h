@@ -151,17 +151,36 @@ template <int R>
 __device__ __forceinline__ void dft(float2 (&x)[R]) {
     constexpr int R1 = split_r1(R);
     if constexpr (R1 == R) {
-        float2 y[R];
-        static_for<R>([&](auto kk) {
-            constexpr int k = decltype(kk)::value;
-            float2 acc = x[0];
-            static_for<R - 1>([&](auto qq) {
-                constexpr int q = decltype(qq)::value + 1;
-                acc = c_add(acc, rot_const<(q * k) % R, R>(x[q]));
-            });
-            y[k] = acc;
+        // odd prime: the conjugate symmetry of the twiddles halves the work of the naive O(R^2) sum --
+        //   s_q = x_q + x_(R-q), d_q = x_q - x_(R-q)  (q = 1 .. H = (R-1)/2)
+        //   A_k = x_0 + sum_q cos(2 pi q k / R) s_q,   B_k = sum_q sin(2 pi q k / R) d_q
+        //   X_k = A_k - i B_k,   X_(R-k) = A_k + i B_k
+        // real coefficients only (2 FMAs per term instead of a complex multiply), outputs in pairs
+        static_assert(R % 2 == 1, "prime radix 2 has its own butterfly");
+        constexpr int H = (R - 1) / 2;
+        float2 sq[H], dq[H];
+        static_for<H>([&](auto qq) {
+            constexpr int q = decltype(qq)::value + 1;
+            sq[q - 1] = c_add(x[q], x[R - q]);
+            dq[q - 1] = c_sub(x[q], x[R - q]);
         });
-        static_for<R>([&](auto kk) { x[decltype(kk)::value] = y[decltype(kk)::value]; });
+        const float2 x0 = x[0];
+        float2 sum = x0;
+        static_for<H>([&](auto qq) { sum = c_add(sum, sq[decltype(qq)::value]); });
+        x[0] = sum;
+        static_for<H>([&](auto kk) {
+            constexpr int k = decltype(kk)::value + 1;
+            float2 A = x0, B = make_float2(0.f, 0.f);
+            static_for<H>([&](auto qq) {
+                constexpr int q = decltype(qq)::value + 1;
+                constexpr float c = (float)ct_cos2pi((q * k) % R, R);
+                constexpr float sn = (float)ct_sin2pi((q * k) % R, R);
+                A = make_float2(fmaf(c, sq[q - 1].x, A.x), fmaf(c, sq[q - 1].y, A.y));
+                B = make_float2(fmaf(sn, dq[q - 1].x, B.x), fmaf(sn, dq[q - 1].y, B.y));
+            });
+            x[k] = c_add(A, c_mul_mi(B));
+            x[R - k] = c_add(A, c_mul_pi(B));
+        });
     } else {
         // n = R2*n1 + n2 ; k = k1 + R1*k2
         constexpr int R2 = R / R1;

@@ -541,17 +541,21 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
     auto issue = [&](float2 (&pf)[NPF], int t) {
         int q, p0;
         tile_qp(t, q, p0);
+        // row offsets = a per-thread part (hi) + a wave-uniform multiple of the pitch: with a runtime pitch (MODE 1) the
+        // uniform part stays in scalar registers instead of one 64-bit vector address per load
         const float2* base = data + ((size_t)q * G::C2) * PITCH() + p0 + tt;
         if constexpr (!INV) {
+            const float2* bh = base + (size_t)hi * PITCH();
             static_for<RA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
-                pf[a] = base[(size_t)(hi + a * RB) * PITCH()];
+                pf[a] = bh[(size_t)(a * RB) * PITCH()];
             });
         } else {
             const unsigned bits = livel[q * RA + hi];       // dead rows are zeros by construction
+            const float2* bh = base + (size_t)(hi * RB) * PITCH();
             static_for<RB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                pf[b] = ((bits >> b) & 1u) ? base[(size_t)(hi * RB + b) * PITCH()] : make_float2(0.f, 0.f);
+                pf[b] = ((bits >> b) & 1u) ? bh[(size_t)b * PITCH()] : make_float2(0.f, 0.f);
             });
         }
     };
@@ -566,8 +570,8 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
             if (act_first) {
                 static_for<NPF>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    if constexpr (!INV) base[(size_t)(hi + a * RB) * PITCH()] = pf[a];
-                    else base[(size_t)(hi * RB + a) * PITCH()] = pf[a];
+                    if constexpr (!INV) (base + (size_t)hi * PITCH())[(size_t)(a * RB) * PITCH()] = pf[a];
+                    else (base + (size_t)(hi * RB) * PITCH())[(size_t)a * PITCH()] = pf[a];
                 });
             }
             if (t + 2 * gstep < ntiles && act_first) issue(pf, t + 2 * gstep);
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 const unsigned bits = livel[q * RA + hi];   // dead rows are never read again
                 static_for<RB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    if ((bits >> b) & 1u) base[(size_t)(hi * RB + b) * PITCH()] = v[b];
+                    if ((bits >> b) & 1u) (base + (size_t)(hi * RB) * PITCH())[(size_t)b * PITCH()] = v[b];
                 });
             } else {
                 float2 pw[RA];
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 idft<RA>(v);
                 static_for<RA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    base[(size_t)(hi + a * RB) * PITCH()] = v[a];
+                    (base + (size_t)hi * PITCH())[(size_t)(a * RB) * PITCH()] = v[a];
                 });
             }
         }

@@ -27,43 +27,7 @@
 #include "fft_lds.h"
 #include "fft_host.h"
 
-namespace d4w {
-
-struct FkDims {
-    int nx, ns, M, C1, C2, N1, N2, TA, TC;
-};
-
-struct FkDev {  // kernel argument block (by value)
-    FkDims d;
-    AxisDesc ax_c1, ax_c2, ax_n1, ax_n2;
-    const float2* twc;        // [C1 pos q][C2]   W_nx^{c2 * kc1(q)}
-    const float2* twt;        // [N1 pos q1][N2]  W_M^{n2 * k1(q1)}
-    const float2* win;        // [M] packed tukey(ns, 0.03): (w[2m], w[2m+1])
-    const int* row_partner;   // [nx] row position of wavenumber -k
-    const int* q1_partner;    // [N1] position of (N1 - k1) mod N1
-    const int* mirror0;       // [N2] position of (N2 - k2) mod N2
-    const float2* wrow;       // [N1] W_ns^{k1(q1)}
-    const float2* wcol;       // [N2] W_ns^{N1 * k2(i)}
-    const float* mask;        // [nx pos r][N1 pos q1][N2 pos i] folded mask M_h(k, f), f < M
-    const float* nyq;         // [nx pos r] M_h(k, M)
-    const int2* pairs;        // pass-B work list (keyA, keyB)
-    float scale;              // 1 / (nx * M)
-    // Bluestein form of the c2 sub-transform (C2 has a prime factor > 31): a length-C2 DFT as a circular
-    // convolution of length bs_L = 2^k >= 2 C2 - 1 with the chirp exp(-i pi n^2 / C2); bs_L = 0: off
-    int bs_L;
-    AxisDesc ax_bs;           // the length-bs_L transform
-    const float2* bs_chirp;   // [C2]    exp(-i pi n^2 / C2)
-    const float2* bs_filt;    // [bs_L]  FFT of the conjugate chirp (wrapped) / bs_L, at the DIF positions of ax_bs
-    // the same for the n2 sub-transform of pass B (ns / 2 has a prime factor > 31): bn_L = 0: off
-    int bn_L;
-    AxisDesc ax_bn;
-    const float2* bn_chirp;   // [N2]
-    const float2* bn_filt;    // [bn_L]
-};
-
-}  // namespace d4w
-
-#include "fk_fast.h"
+#include "fk_entry.h"
 
 namespace d4w {
 
@@ -596,59 +560,7 @@ static std::vector<float> tukey_window(int n, double alpha) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// shape-specialised kernels (fk_fast.h): one table entry per instantiated shape
-// ---------------------------------------------------------------------------------------------
-struct FkFastEntry {
-    int variant;           // D4W_FK_VARIANT picks among entries of one shape (0 = default)
-    int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
-    size_t ldsA, ldsC, ldsB;
-    int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
-    void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
-    void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
-    void (*A_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
-    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int);
-    void (*C_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
-    void (*C_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
-    void (*B_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);
-    // distributed (channel-sharded) layouts, fk_fast.h FkGeo
-    void (*T_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);          // pass A MODE 1 (time phase)
-    void (*T_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
-    void (*T_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
-    void (*Ac_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);         // pass A MODE 2 (c1 transform on the slab)
-    void (*Ac_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
-    void (*Cs_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);             // pass C on the slab
-    void (*Cs_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
-    void (*Bs_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);                       // pass B on the slab
-};
-
-template <class G>
-static FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0) {
-    FkFastEntry e;
-    e.variant = variant;
-    e.nx = G::NX; e.ns = 2 * G::M;
-    e.C1 = G::C1; e.C2A = G::C2A; e.C2B = G::C2B; e.N1 = G::N1; e.NA = G::NA; e.NB = G::NB; e.NC = G::NC;
-    e.TA = G::TA; e.TC = G::TC; e.thrA = G::THRA; e.thrC = G::THRC; e.thrB = G::THRB;
-    e.ldsA = G::ldsA; e.ldsC = G::ldsC; e.ldsB = G::ldsB;
-    e.wgA = wgA; e.wgC = wgC; e.wgB = wgB;
-    e.A_fwd = fkf_passA_fwd<G, false, 0>;
-    e.A_fwd_taper = fkf_passA_fwd<G, true, 0>;
-    e.A_inv = fkf_passA_inv<G, 0>;
-    e.A_inv_stats = fkf_passA_inv_stats<G>;
-    e.C_fwd = fkf_passC<G, false, 0>;
-    e.C_inv = fkf_passC<G, true, 0>;
-    e.B_mid = fkf_passB<G, 0>;
-    e.T_fwd = fkf_passA_fwd<G, false, 1>;
-    e.T_fwd_taper = fkf_passA_fwd<G, true, 1>;
-    e.T_inv = fkf_passA_inv<G, 1>;
-    e.Ac_fwd = fkf_passA_fwd<G, false, 2>;
-    e.Ac_inv = fkf_passA_inv<G, 2>;
-    e.Cs_fwd = fkf_passC<G, false, 1>;
-    e.Cs_inv = fkf_passC<G, true, 1>;
-    e.Bs_mid = fkf_passB<G, 1>;
-    return e;
-}
-
+// shape-specialised kernels: fk_entry.h (FkFastEntry, fast_entry<G>) -- one table entry per instantiated shape
 //                 C1  C2A C2B  N1  NA  NB  NC  TA  TC  thrA thrC thrB
 // 20000 x 120000: 128-byte column strips in pass C (TC = 16) are worth 3.8 vs 6.9 ms per pass over 64-byte ones
 using FkShapeBench = FkFastCfg<25, 25, 32, 25, 20, 12, 10, 16, 16, 448, 512, 256>;
@@ -662,6 +574,15 @@ using FkShapeNB = FkFastCfg<10, 19, 29, 5, 10, 12, 10, 16, 16, 192, 464, 256>;  
 using FkShapeT1 = FkFastCfg<3, 2, 3, 2, 2, 3, 2, 2, 2, 64, 64, 64>;                 // 18 x 48    (tests)
 using FkShapeT2 = FkFastCfg<2, 2, 2, 2, 8, 3, 5, 2, 2, 64, 64, 64>;                 // 8 x 480    (tests)
 using FkShapeT3 = FkFastCfg<5, 4, 5, 5, 4, 3, 5, 4, 4, 64, 64, 64>;                 // 100 x 600  (tests)
+using FkShapeT4 = FkFastCfg<2, 7, 11, 2, 2, 3, 2, 2, 2, 64, 64, 64>;                // 154 x 48   (tests: prime butterflies 7, 11)
+using FkShapeT5 = FkFastCfg<2, 19, 29, 2, 2, 3, 2, 2, 2, 64, 64, 64>;               // 1102 x 48  (tests: the OOI shapes' radices 19, 29)
+
+// shape configurations registered at run time (compiled on demand, das4whales_amd/fkjit.py); entries are never removed
+static std::mutex g_dyn_mu;
+static std::vector<FkFastEntry*>& dyn_shapes() {
+    static std::vector<FkFastEntry*> v;
+    return v;
+}
 
 static const std::vector<FkFastEntry>& fast_shapes() {
     static const std::vector<FkFastEntry> v = {
@@ -672,6 +593,8 @@ static const std::vector<FkFastEntry>& fast_shapes() {
         fast_entry<FkShapeT1>(2, 2, 2),
         fast_entry<FkShapeT2>(2, 2, 2),
         fast_entry<FkShapeT3>(2, 2, 2),
+        fast_entry<FkShapeT4>(2, 2, 2),
+        fast_entry<FkShapeT5>(2, 2, 2),
     };
     return v;
 }
@@ -769,6 +692,30 @@ const char* d4w_version(void) {
 #endif
 }
 
+/* 1 when the shape runs shape-specialised kernels (built in or registered), 0 when it runs the generic passes */
+int d4w_fk_shape_is_specialised(int nx, int ns) {
+    for (const FkFastEntry& e : fast_shapes())
+        if (e.nx == nx && e.ns == ns) return 1;
+    std::lock_guard<std::mutex> lk(g_dyn_mu);
+    for (const FkFastEntry* e : dyn_shapes())
+        if (e->nx == nx && e->ns == ns) return 1;
+    return 0;
+}
+
+/* Registers a shape configuration compiled on demand (the caller passes the FkFastEntry its own translation unit
+ * built from csrc/fk_entry.h; entry_size guards against a header mismatch). */
+int d4w_fk_register_shape(const void* entry, size_t entry_size) {
+    if (!entry || entry_size != sizeof(FkFastEntry)) return fail(D4W_EINVAL, "shape entry of %zu bytes, expected %zu (stale build?)", entry_size, sizeof(FkFastEntry));
+    FkFastEntry* e = new FkFastEntry(*static_cast<const FkFastEntry*>(entry));
+    if (e->nx < 1 || e->ns < 2 || e->C1 * e->C2A * e->C2B != e->nx || 2 * e->N1 * e->NA * e->NB * e->NC != e->ns || e->TA != e->TC) {
+        delete e;
+        return fail(D4W_EINVAL, "inconsistent shape entry");
+    }
+    std::lock_guard<std::mutex> lk(g_dyn_mu);
+    dyn_shapes().push_back(e);
+    return D4W_OK;
+}
+
 int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
     if (!pl) return D4W_OK;
     for (void* p : pl->allocs) (void)hipFree(p);
@@ -803,9 +750,15 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         const char* g = getenv("D4W_FK_GENERIC");
         const char* vs = getenv("D4W_FK_VARIANT");
         const int want = vs ? atoi(vs) : 0;
-        if (!pinned && !(g && atoi(g) > 0))
+        if (!pinned && !(g && atoi(g) > 0)) {
             for (const FkFastEntry& e : fast_shapes())
                 if (e.nx == nx && e.ns == ns && (e.variant == want || (!fast && e.variant == 0))) fast = &e;
+            if (!fast) {
+                std::lock_guard<std::mutex> lk(g_dyn_mu);
+                for (const FkFastEntry* e : dyn_shapes())
+                    if (e->nx == nx && e->ns == ns) fast = e;
+            }
+        }
     }
     if (fast_only && !fast) return fail(D4W_EINVAL, "no shape-specialised kernels for %d x %d", nx, ns);
     // A prime factor > 31 of ns / 2 goes into N2, whose sub-transforms (pass B) then run as Bluestein convolutions of

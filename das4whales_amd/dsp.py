@@ -142,12 +142,28 @@ _plans = {}
 _plans_lock = threading.Lock()
 
 
+def compile_fk_shape(nx, ns, verbose=False):
+    """Compile (once, cached on disk) shape-specialised f-k kernels for [nx, ns] -- any shape whose axes factor into
+    parts <= 32; see das4whales_amd/fkjit.py.  Returns True when the shape runs specialised kernels afterwards.
+    Plans created before the call keep the kernels they were planned with (drop them with dsp.clear_fk_plans())."""
+    from . import fkjit
+    return fkjit.compile_fk_shape(nx, ns, verbose=verbose)
+
+
+def clear_fk_plans():
+    with _plans_lock:
+        _plans.clear()
+
+
 def get_fk_plan(nx, ns, device=None):
     device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
     key = (str(device), int(nx), int(ns))
     with _plans_lock:
         p = _plans.pop(key, None)
         if p is None:
+            import os
+            if os.environ.get("D4W_FK_JIT", "0") == "1" and int(nx) * int(ns) >= (1 << 24):
+                compile_fk_shape(nx, ns)      # opt-in: every new large shape gets its own kernels (~40 s, cached)
             if len(_plans) >= 4:          # plans hold an nx*ns/2 float mask each: keep few, drop the least recently used
                 _plans.pop(next(iter(_plans)))
             p = FkPlan(nx, ns, device=device)

@@ -145,6 +145,14 @@ class ShardedFkPlan:
                 ops.append(dist.P2POp(dist.irecv, recv_views[frm], frm, group=self.group))
         return dist.batch_isend_irecv(ops) if ops else []
 
+    def _mark(self, label):
+        """Stage boundary for bench.py's per-stage times (no-op unless `self.marks` is a list and the data is on a GPU)."""
+        marks = getattr(self, "marks", None)
+        if marks is not None and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((label, e))
+
     def _apply_packed(self, x_loc, taper):
         """Packed plan (include/d4w.h): 7 block passes of the shape-specialised kernels per rank, the exchange
         buffers are written / read in place by the time-phase kernels (no index packing), and the transfers run in
@@ -167,6 +175,7 @@ class ShardedFkPlan:
         nch = max(1, min(self.CHUNKS, -(-nxl // self.C1)))
         chunks = [self._chunks(r, nch) for r in range(self.world)]
         works = []
+        self._mark("start")
         for j in range(nch):
             l0, l1 = chunks[self.rank][j]
             self.check(self.lib.d4w_fkd_time_fwd_packed_rows_f32(self._h, x_loc.data_ptr(), send.data_ptr(), int(bool(taper)),
@@ -180,7 +189,9 @@ class ShardedFkPlan:
             works += self._exchange(sv, rv)
         for w in works:
             w.wait()
+        self._mark("time_fwd+exchange")
         self.check(self.lib.d4w_fkd_chan_apply_f32(self._h, slab.data_ptr() if self.nq else None, _sptr(slab)))
+        self._mark("channel_phase")
         y = torch.empty((nxl, self.ns), dtype=torch.float32, device=dev_)
         pending = []
         for j in range(nch):                                  # all transfers are queued; chunk j is transformed as it lands
@@ -197,6 +208,7 @@ class ShardedFkPlan:
                 w.wait()
             l0, l1 = chunks[self.rank][j]
             self.check(self.lib.d4w_fkd_time_inv_packed_rows_f32(self._h, send.data_ptr(), y.data_ptr(), l0, l1, _sptr(y)))
+        self._mark("exchange+time_inv")
         return y
 
     def apply(self, x_loc, taper=False):

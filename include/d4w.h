@@ -50,6 +50,12 @@ int d4w_fk_plan_create(int nx, int ns, d4w_fk_plan** plan);
 /* opts: NULL or 6 ints {C1, C2, N1, N2, TA, TC}; any entry <= 0 keeps the planner's choice */
 int d4w_fk_plan_create_ex(int nx, int ns, const int* opts_host, d4w_fk_plan** plan);
 int d4w_fk_plan_destroy(d4w_fk_plan* plan);
+/* 1 when [nx][ns] runs shape-specialised kernels (every sub-transform a compile-time register butterfly), 0 when it
+ * runs the generic runtime-radix passes.  Specialised configurations for further shapes are compiled on demand by the
+ * host side (das4whales_amd/fkjit.py: same templates, one translation unit per shape) and handed over with
+ * d4w_fk_register_shape (entry = the d4w::FkFastEntry of csrc/fk_entry.h, entry_size = its sizeof as a build guard). */
+int d4w_fk_shape_is_specialised(int nx, int ns);
+int d4w_fk_register_shape(const void* entry, size_t entry_size);
 /* fills {nx, ns, C1, C2, N1, N2, TA, TC} */
 int d4w_fk_plan_info(const d4w_fk_plan* plan, int* info8_host);
 

@@ -64,7 +64,7 @@ def test_in_place(emu, golden):
     assert rel(buf, g["y_ninf"]) < TOL
 
 
-@pytest.mark.parametrize("nx,ns", [(18, 48), (8, 480), (100, 600)])
+@pytest.mark.parametrize("nx,ns", [(18, 48), (8, 480), (100, 600), (154, 48), (1102, 48)])
 def test_shape_specialised_kernels(emu, nx, ns):
     """Shapes in fk_filter.hip's kFastShapes run the fat-stage register-FFT kernels (fk_fast.h);
     opts[0] = -1 forces the generic passes on the same shape: both must match the oracle."""
