@@ -121,9 +121,16 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     tpl = [ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 17.8, 28.8, 0.68)),
            ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 14.7, 21.8, 0.78))]
 
+    fused_stats = plan.packed and "fk" in stages and "mf" in stages     # row mean / max|.| from the last f-k pass's epilogue
+
     def step():
-        y = plan.apply(x_loc) if "fk" in stages else x_loc
-        out = ddet._xcorr_device(y, tpl, normalize=True) if "mf" in stages else None
+        st = None
+        if fused_stats:
+            y, mean, mx = plan.apply(x_loc, stats=True)
+            st = (mean, mx)
+        else:
+            y = plan.apply(x_loc) if "fk" in stages else x_loc
+        out = ddet._xcorr_device(y, tpl, normalize=True, stats=st) if "mf" in stages else None
         if args.gather:
             shard.all_gather_rows(y, nx)
         return out
@@ -149,10 +156,15 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         plan.marks = []
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        y = plan.apply(x_loc) if "fk" in stages else x_loc
+        st = None
+        if fused_stats:
+            y, mean, mx = plan.apply(x_loc, stats=True)
+            st = (mean, mx)
+        else:
+            y = plan.apply(x_loc) if "fk" in stages else x_loc
         ev[1].record()
         if "mf" in stages:
-            ddet._xcorr_device(y, tpl, normalize=True)
+            ddet._xcorr_device(y, tpl, normalize=True, stats=st)
         ev[2].record()
         if args.gather:
             shard.all_gather_rows(y, nx)

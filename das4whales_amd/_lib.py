@@ -53,6 +53,7 @@ def _load():
         "d4w_fkd_time_inv_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
         "d4w_fkd_time_fwd_packed_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
         "d4w_fkd_time_inv_packed_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+        "d4w_fkd_time_inv_packed_rows_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_fk_apply_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_fk_apply_timed_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                  P(ctypes.c_float)]),

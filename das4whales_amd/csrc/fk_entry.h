@@ -55,7 +55,8 @@ struct FkFastEntry {
     void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
     void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
     void (*A_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
-    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int);
+    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int, FkGeo, const float2*, int);
+    void (*T_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int, FkGeo, const float2*, int);   // MODE 1
     void (*C_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
     void (*C_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
     void (*B_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);
@@ -82,7 +83,8 @@ static inline FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0)
     e.A_fwd = fkf_passA_fwd<G, false, 0>;
     e.A_fwd_taper = fkf_passA_fwd<G, true, 0>;
     e.A_inv = fkf_passA_inv<G, 0>;
-    e.A_inv_stats = fkf_passA_inv_stats<G>;
+    e.A_inv_stats = fkf_passA_inv_stats<G, 0>;
+    e.T_inv_stats = fkf_passA_inv_stats<G, 1>;
     e.C_fwd = fkf_passC<G, false, 0>;
     e.C_inv = fkf_passC<G, true, 0>;
     e.B_mid = fkf_passB<G, 0>;

@@ -386,10 +386,14 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
 // cut into RUNS of `run` consecutive tiles (same c2, i.e. the same C1 rows) that one workgroup walks in
 // order, accumulating per-thread partial sums / maxima in registers and reducing them once per run
 // (wave shuffle + one float atomicAdd / integer atomicMax per row and wave).
-template <class G>
+// MODE 1: the distributed plan's inverse time phase (fkf_passA_inv MODE 1: C1 consecutive local rows per tile, input from
+// the packed exchange buffer, no channel transform) with the same epilogue; tile0 = first tile of the row chunk.
+template <class G, int MODE = 0>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* __restrict__ data, int run, int nruns,
                                                                float* __restrict__ rowmean,
-                                                               unsigned* __restrict__ rowmaxbits, int sw, int sbase) {
+                                                               unsigned* __restrict__ rowmaxbits, int sw, int sbase,
+                                                               FkGeo geo = FkGeo(), const float2* __restrict__ packed = nullptr,
+                                                               int tile0 = 0) {
     D4W_DYN_LDS(smem_raw);
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     float2* twl = tile + G::C1 * G::N1 * G::TA;
@@ -401,20 +405,37 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
     const int nseq = max(myruns, 0) * run;              // tiles this workgroup walks, in order
     auto tile_of = [&](int sq) {
         const int k = sq / run, j = sq - k * run;
-        return ((int)blockIdx.x + k * (int)gridDim.x) * run + j;
+        return tile0 + ((int)blockIdx.x + k * (int)gridDim.x) * run + j;
     };
+    int* qtab = reinterpret_cast<int*>(twl + 2 * STRIP);
+    if constexpr (MODE == 1) {
+        for (int i = tid; i < G::N1; i += G::THRA) {
+            qtab[i] = geo.q1_off[i];
+            qtab[G::N1 + i] = geo.q1_pitch[i];
+        }
+        __syncthreads();
+    }
     typedef FkPrefetchA<G::N1> Pre;
     Pre A, B;
     auto issue = [&](Pre& R, int t) {
         const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
         if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
         if (act1) {
-            const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
-            static_for<G::N1>([&](auto kk) {
-                constexpr int q1 = decltype(kk)::value;
-                R.pf[q1] = p[q1 * G::N2];
-            });
-            R.tc = P.twc[hi * G::C2 + c2];
+            if constexpr (MODE == 0) {
+                const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    R.pf[q1] = p[q1 * G::N2];
+                });
+                R.tc = P.twc[hi * G::C2 + c2];
+            } else {
+                const int row = c2 * G::C1 + hi;
+                const bool ok = row < geo.nrows;
+                static_for<G::N1>([&](auto kk) {
+                    constexpr int q1 = decltype(kk)::value;
+                    R.pf[q1] = ok ? packed[(size_t)qtab[q1] + (size_t)row * qtab[G::N1 + q1] + b0 + tt] : make_float2(0.f, 0.f);
+                });
+            }
         }
     };
     float asum[G::C1], amax[G::C1];
@@ -434,7 +455,8 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
         if (act1) {
             static_for<G::N1>([&](auto kk) {
                 constexpr int q1 = decltype(kk)::value;
-                R.pf[q1] = c_mulc(R.pf[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
+                if constexpr (MODE == 0) R.pf[q1] = c_mulc(R.pf[q1], c_mul(tw_cur[q1 * G::TA + tt], R.tc));
+                else R.pf[q1] = c_mulc(R.pf[q1], tw_cur[q1 * G::TA + tt]);
             });
             idft<G::N1>(R.pf);
             static_for<G::N1>([&](auto kk) {
@@ -453,15 +475,26 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
         }
         lds_barrier();
         if (act2) {
-            idft<G::C1>(v);
-            float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
-            static_for<G::C1>([&](auto cc) {
-                constexpr int c1 = decltype(cc)::value;
-                const float2 y2 = c_scale(v[c1], P.scale);
-                o[(size_t)c1 * G::C2 * G::M] = y2;
-                asum[c1] += y2.x + y2.y;
-                amax[c1] = fmaxf(amax[c1], fmaxf(fabsf(y2.x), fabsf(y2.y)));
-            });
+            if constexpr (MODE == 0) {
+                idft<G::C1>(v);
+                float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    const float2 y2 = c_scale(v[c1], P.scale);
+                    o[(size_t)c1 * G::C2 * G::M] = y2;
+                    asum[c1] += y2.x + y2.y;
+                    amax[c1] = fmaxf(amax[c1], fmaxf(fabsf(y2.x), fabsf(y2.y)));
+                });
+            } else {
+                float2* o = data + (size_t)c2 * G::C1 * G::M + hi * G::N2 + b0 + tt;
+                static_for<G::C1>([&](auto cc) {
+                    constexpr int c1 = decltype(cc)::value;
+                    const float2 y2 = c_scale(v[c1], P.scale);
+                    if (c2 * G::C1 + c1 < geo.nrows) o[(size_t)c1 * G::M] = y2;
+                    asum[c1] += y2.x + y2.y;
+                    amax[c1] = fmaxf(amax[c1], fmaxf(fabsf(y2.x), fabsf(y2.y)));
+                });
+            }
         }
         if ((sq % run) == run - 1) {                     // end of a run: its C1 rows are complete for these columns
             static_for<G::C1>([&](auto cc) {
@@ -473,9 +506,11 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
                     mv = fmaxf(mv, __shfl_xor(mv, off));
                 }
                 if ((tid & 63) == 0) {
-                    const size_t row = (size_t)c1 * G::C2 + c2;
-                    atomicAdd(rowmean + row, sv * inv_ns);
-                    atomicMax(rowmaxbits + row, __float_as_uint(mv));      // mv >= 0: bit order = value order
+                    const size_t row = (MODE == 0) ? (size_t)c1 * G::C2 + c2 : (size_t)c2 * G::C1 + c1;
+                    if (MODE == 0 || (int)row < geo.nrows) {
+                        atomicAdd(rowmean + row, sv * inv_ns);
+                        atomicMax(rowmaxbits + row, __float_as_uint(mv));      // mv >= 0: bit order = value order
+                    }
                 }
                 asum[c1] = 0.f;
                 amax[c1] = 0.f;

@@ -1060,7 +1060,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             (void)hipFuncSetAttribute((const void*)fast->C_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->C_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->B_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
-            const void* fa[] = {(const void*)fast->T_fwd, (const void*)fast->T_fwd_taper, (const void*)fast->T_inv,
+            const void* fa[] = {(const void*)fast->T_fwd, (const void*)fast->T_fwd_taper, (const void*)fast->T_inv, (const void*)fast->T_inv_stats,
                                 (const void*)fast->Ac_fwd, (const void*)fast->Ac_inv};
             for (const void* f : fa) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
             (void)hipFuncSetAttribute((const void*)fast->Cs_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
@@ -1249,7 +1249,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
                 if ((rc = launch_k(F.C_inv, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw, FkGeo()))) return rc;
                 if (row_mean) {
                     if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
-                                       dst, run, nruns, row_mean, (unsigned*)row_maxabs, sw, sl * sw))) return rc;
+                                       dst, run, nruns, row_mean, (unsigned*)row_maxabs, sw, sl * sw, FkGeo(), (const float2*)nullptr, 0))) return rc;
                 } else if ((rc = launch_k(F.A_inv, gsA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, nA, sw, sl * sw, FkGeo(), (const float2*)nullptr))) return rc;
             }
             D4W_MARK(4);
@@ -1268,7 +1268,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         if (row_mean) {
             const int run = stats_run(NBX), nruns = fA / run;
             if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
-                               dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0))) return rc;
+                               dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0, FkGeo(), (const float2*)nullptr, 0))) return rc;
         } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0, FkGeo(), (const float2*)nullptr))) return rc;
         D4W_MARK(5);
 #undef D4W_MARK
@@ -1959,6 +1959,28 @@ int d4w_fkd_time_inv_packed_rows_f32(d4w_fkd_plan* pl, const float* packed, floa
     geo.nrows = l1;
     return launch_k(F.T_inv, dim3(std::min(t1 - t0, pl->num_cu * pl->sp->wgA)), dim3(F.thrA), F.ldsA, stream, pl->dev_t,
                     reinterpret_cast<float2*>(y_loc), t0, t1, NBX, 0, geo, reinterpret_cast<const float2*>(packed));
+}
+
+/* ... with the row statistics of the filtered rows (mean, max|.|: what the matched filter normalises by, detect.py:157)
+ * from the pass's epilogue; row_mean / row_maxabs [nxl] must be zeroed before the first chunk */
+int d4w_fkd_time_inv_packed_rows_stats_f32(d4w_fkd_plan* pl, const float* packed, float* y_loc, int l0, int l1,
+                                           float* row_mean, float* row_maxabs, void* stream) {
+    if (!pl || !packed || !y_loc || !row_mean || !row_maxabs) return fail(D4W_EINVAL, "NULL argument");
+    if (!pl->sp) return fail(D4W_EINVAL, "this shape runs the generic distributed plan");
+    const FkFastEntry& F = *pl->sp->fast;
+    const FkDims& d = pl->sp->dev.d;
+    const int nxl = pl->row_end - pl->row_begin;
+    if (l0 < 0 || l1 > nxl || l0 > l1 || l0 % d.C1) return fail(D4W_EINVAL, "row range [%d, %d) must start at a multiple of %d inside the local block", l0, l1, d.C1);
+    const int NBX = d.N2 / d.TA, t0 = (l0 / d.C1) * NBX, t1 = ceil_div(l1, d.C1) * NBX;
+    if (t1 <= t0) return D4W_OK;
+    int run = 1;
+    for (int r = 1; r <= NBX && r <= 30; ++r) if (NBX % r == 0) run = r;
+    const int nruns = (t1 - t0) / run;
+    FkGeo geo = pl->geo_t;
+    geo.nrows = l1;
+    return launch_k(F.T_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->sp->wgA)), dim3(F.thrA), F.ldsA, stream, pl->dev_t,
+                    reinterpret_cast<float2*>(y_loc), run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0, geo,
+                    reinterpret_cast<const float2*>(packed), t0);
 }
 
 int d4w_fkd_time_inv_packed_f32(d4w_fkd_plan* pl, const float* packed, float* y_loc, void* stream) {

@@ -153,7 +153,7 @@ class ShardedFkPlan:
             e.record()
             marks.append((label, e))
 
-    def _apply_packed(self, x_loc, taper):
+    def _apply_packed(self, x_loc, taper, stats=False):
         """Packed plan (include/d4w.h): 7 block passes of the shape-specialised kernels per rank, the exchange
         buffers are written / read in place by the time-phase kernels (no index packing), and the transfers run in
         row chunks behind the kernels of the neighbouring chunks."""
@@ -165,12 +165,23 @@ class ShardedFkPlan:
         boff = [0]
         for s in range(self.world):
             boff.append(boff[-1] + nxl * nqs[s] * per)
+        mean = mx = None
+        if stats:
+            mean = torch.zeros(nxl, dtype=torch.float32, device=dev_)
+            mx = torch.zeros(nxl, dtype=torch.float32, device=dev_)
+
+        def time_inv(buf, y, l0, l1):
+            if stats:
+                self.check(self.lib.d4w_fkd_time_inv_packed_rows_stats_f32(self._h, buf.data_ptr(), y.data_ptr(), l0, l1,
+                                                                             mean.data_ptr(), mx.data_ptr(), _sptr(y)))
+            else:
+                self.check(self.lib.d4w_fkd_time_inv_packed_rows_f32(self._h, buf.data_ptr(), y.data_ptr(), l0, l1, _sptr(y)))
         if self.world == 1:                                   # one destination: the send buffer IS the slab
             self.check(self.lib.d4w_fkd_time_fwd_packed_f32(self._h, x_loc.data_ptr(), send.data_ptr(), int(bool(taper)), _sptr(send)))
             self.check(self.lib.d4w_fkd_chan_apply_f32(self._h, send.data_ptr(), _sptr(send)))
             y = torch.empty((nxl, self.ns), dtype=torch.float32, device=dev_)
-            self.check(self.lib.d4w_fkd_time_inv_packed_f32(self._h, send.data_ptr(), y.data_ptr(), _sptr(y)))
-            return y
+            time_inv(send, y, 0, nxl)
+            return (y, mean, mx) if stats else y
         slab = self._scratch("slab", self.nx * self.nq * per, dev_)
         nch = max(1, min(self.CHUNKS, -(-nxl // self.C1)))
         chunks = [self._chunks(r, nch) for r in range(self.world)]
@@ -207,18 +218,21 @@ class ShardedFkPlan:
             for w in pending[j]:
                 w.wait()
             l0, l1 = chunks[self.rank][j]
-            self.check(self.lib.d4w_fkd_time_inv_packed_rows_f32(self._h, send.data_ptr(), y.data_ptr(), l0, l1, _sptr(y)))
+            time_inv(send, y, l0, l1)
         self._mark("exchange+time_inv")
-        return y
+        return (y, mean, mx) if stats else y
 
-    def apply(self, x_loc, taper=False):
-        """x_loc: float32 [rows of this rank, ns] -> filtered rows of this rank (same shape)."""
+    def apply(self, x_loc, taper=False, stats=False):
+        """x_loc: float32 [rows of this rank, ns] -> filtered rows of this rank (same shape).  stats=True (packed plans)
+        also returns (mean, max|.|) of every filtered local row, formed in the last pass's epilogue."""
         nxl = self.row_end - self.row_begin
         if tuple(x_loc.shape) != (nxl, self.ns):
             raise ValueError("local block has shape %s, expected (%d, %d)" % (tuple(x_loc.shape), nxl, self.ns))
         x_loc = x_loc.to(torch.float32).contiguous()
         if self.packed:
-            return self._apply_packed(x_loc, taper)
+            return self._apply_packed(x_loc, taper, stats)
+        if stats:
+            raise ValueError("row statistics come with the packed plan only")
         per = self.N2 * 2                                        # floats per sub-row
         z = torch.empty((nxl, self.N1, per), dtype=torch.float32, device=x_loc.device)     # returned to the caller
         self.check(self.lib.d4w_fkd_time_fwd_f32(self._h, x_loc.data_ptr(), z.data_ptr(), int(bool(taper)), _sptr(z)))

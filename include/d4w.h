@@ -151,6 +151,10 @@ int d4w_fkd_time_inv_packed_f32(d4w_fkd_plan* plan, const float* packed, float* 
 int d4w_fkd_time_fwd_packed_rows_f32(d4w_fkd_plan* plan, const float* x_loc, float* packed, int taper, int l0, int l1,
                                      void* stream);
 int d4w_fkd_time_inv_packed_rows_f32(d4w_fkd_plan* plan, const float* packed, float* y_loc, int l0, int l1, void* stream);
+/* ... also leaving mean and max|.| of the filtered local rows (what detect.compute_cross_correlogram normalises by,
+ * detect.py:157) in row_mean / row_maxabs [nxl], which the caller zeroes before the first chunk */
+int d4w_fkd_time_inv_packed_rows_stats_f32(d4w_fkd_plan* plan, const float* packed, float* y_loc, int l0, int l1,
+                                           float* row_mean, float* row_maxabs, void* stream);
 
 /* dsp.taper_data (dsp.py:705-722): x *= tukey(ns, 0.03) in place, every row */
 int d4w_taper_f32(float* x, int nx, int ns, void* stream);

@@ -162,6 +162,16 @@ def fk_sharded_packed_emu(lib, x, mask, world, taper=False):
         yl = np.full((nxl, ns), np.nan, dtype=np.float32)
         assert lib.d4w_fkd_time_inv_packed_f32(rk.h, vp(back), vp(yl), None) == 0, lib.d4w_last_error()
         y[rk.a:rk.b] = yl
+        # the same pass with the row statistics in its epilogue, in two row chunks
+        ys = np.full((nxl, ns), np.nan, dtype=np.float32)
+        mean, mx = np.zeros(nxl, np.float32), np.zeros(nxl, np.float32)
+        cut = min(nxl, rk.C1 * max(1, (nxl // rk.C1) // 2))
+        for l0, l1 in ((0, cut), (cut, nxl)):
+            if l1 > l0:
+                assert lib.d4w_fkd_time_inv_packed_rows_stats_f32(rk.h, vp(back), vp(ys), l0, l1, vp(mean), vp(mx), None) == 0, lib.d4w_last_error()
+        assert np.array_equal(ys, yl)
+        assert np.allclose(mx, np.abs(yl).max(axis=1), rtol=1e-6)
+        assert np.max(np.abs(mean - yl.astype(np.float64).mean(axis=1))) < 1e-6 * max(np.abs(yl).max(), 1e-30)
     for rk in ranks:
         rk.close()
     return y
