@@ -162,8 +162,11 @@ def get_fk_plan(nx, ns, device=None):
         p = _plans.pop(key, None)
         if p is None:
             import os
-            if os.environ.get("D4W_FK_JIT", "0") == "1" and int(nx) * int(ns) >= (1 << 24):
-                compile_fk_shape(nx, ns)      # opt-in: every new large shape gets its own kernels (~40 s, cached)
+            if os.environ.get("D4W_FK_JIT", "1") != "0" and int(nx) * int(ns) >= (1 << 24):
+                try:
+                    compile_fk_shape(nx, ns)  # a new large shape gets its own kernels (~15 s once, cached on disk);
+                except Exception:             # without a configuration or a compiler it runs the generic passes
+                    pass
             if len(_plans) >= 4:          # plans hold an nx*ns/2 float mask each: keep few, drop the least recently used
                 _plans.pop(next(iter(_plans)))
             p = FkPlan(nx, ns, device=device)

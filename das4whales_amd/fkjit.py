@@ -9,8 +9,8 @@ parts <= 32, instantiates the same templates in a one-file translation unit, com
 registers the resulting table entry with the library (d4w_fk_register_shape).  Host-side planning only -- the
 arithmetic is the HIP kernels'.
 
-    dw.dsp.compile_fk_shape(8000, 12000)      # once per shape; later plans for it use the specialised kernels
-    D4W_FK_JIT=1                               # or: compile automatically for every new large shape
+    dw.dsp.compile_fk_shape(8000, 12000)      # explicitly, once per shape; later plans for it use the specialised kernels
+    D4W_FK_JIT=0                               # switches off the automatic compilation for new large shapes (>= 2^24 samples)
 """
 import ctypes
 import glob
@@ -129,15 +129,16 @@ def compile_fk_shape(nx, ns, verbose=False):
             if not os.path.exists(hipcc):
                 return False
             os.makedirs(_JITDIR, exist_ok=True)
-            src = path[:-3] + ".hip"
+            src = "%s.%d.hip" % (path[:-3], os.getpid())
             with open(src, "w") as f:
                 f.write('// generated by das4whales_amd/fkjit.py for %d x %d\n#include "fk_entry.h"\n'
                         "using G = d4w::FkFastCfg<%s>;\n"
                         'extern "C" int d4w_jit_register(int (*reg)(const void*, size_t)) {\n'
                         "    d4w::FkFastEntry e = d4w::fast_entry<G>(%d, %d, %d);\n"
                         "    return reg(&e, sizeof(e));\n}\n" % (nx, ns, ", ".join(str(v) for v in cfg[:12]), cfg[12], cfg[13], cfg[14]))
+            tmp = "%s.%d.tmp" % (path, os.getpid())          # several ranks may compile the same shape at once
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
-                   "-I", _CSRC, "-I", _INC, src, "-o", path + ".tmp"]
+                   "-I", _CSRC, "-I", _INC, src, "-o", tmp]
             if verbose:
                 print("[fkjit]", " ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -145,7 +146,11 @@ def compile_fk_shape(nx, ns, verbose=False):
                 if verbose:
                     print(r.stderr[-2000:], flush=True)
                 return False
-            os.replace(path + ".tmp", path)
+            os.replace(tmp, path)
+            try:
+                os.remove(src)
+            except OSError:
+                pass
         _register(path)
         return is_specialised(nx, ns)
 
