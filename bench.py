@@ -130,8 +130,12 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
             st = (mean, mx)
         else:
             y = plan.apply(x_loc) if "fk" in stages else x_loc
+        # the all-gather of the filtered t-x matrix travels behind the matched filter of the local rows
+        pend = shard.all_gather_rows(y, nx, async_op=True) if (args.gather and nx % world == 0) else None
         out = ddet._xcorr_device(y, tpl, normalize=True, stats=st) if "mf" in stages else None
-        if args.gather:
+        if pend is not None:
+            pend[1].wait()
+        elif args.gather:
             shard.all_gather_rows(y, nx)
         return out
 

@@ -18,10 +18,12 @@ def channel_block(nx, world_size, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local, nx_total, group=None):
+def all_gather_rows(local, nx_total, group=None, async_op=False):
     """Reassemble a row-sharded [rows_local, ...] tensor into [nx_total, ...] on every rank with a
     single all-gather (dist.all_gather_into_tensor).  Uneven shards are padded to the largest block
-    for the collective and stripped afterwards."""
+    for the collective and stripped afterwards.  async_op=True (even shards only) returns (out, work): the
+    collective runs behind whatever the caller launches next -- e.g. the matched filter of the local rows --
+    until work.wait()."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     blocks = [channel_block(nx_total, world, r) for r in range(world)]
@@ -32,8 +34,10 @@ def all_gather_rows(local, nx_total, group=None):
     local = local.contiguous()
     if nx_total % world == 0:
         out = torch.empty((nx_total,) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    if async_op:
+        raise ValueError("async_op needs even channel blocks")
     padded = torch.zeros((rmax,) + tail, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     buf = torch.empty((world * rmax,) + tail, dtype=local.dtype, device=local.device)
