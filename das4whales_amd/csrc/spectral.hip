@@ -625,77 +625,132 @@ __device__ __forceinline__ float fp_walk(const float* __restrict__ r, const floa
     return lmin;
 }
 
-template <bool STAGED>
-__global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
-                                                              int bshift, int* __restrict__ idx,
-                                                              int* __restrict__ counts, int cap) {
-    D4W_DYN_LDS(smem_raw);
-    __shared__ int wave_tot[kSpThreads / 64];
-    const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
-    const int nwords = (ns + 31) >> 5;
-    float2* s1 = reinterpret_cast<float2*>(smem_raw);          // [nb]  (max, min) of every block
-    float2* s2 = s1 + nb;                                      // [nb2] (max, min) of every super-block
-    unsigned* bits = reinterpret_cast<unsigned*>(s2 + nb2);    // [nwords] accepted peaks
-    float* rowl = reinterpret_cast<float*>(bits + nwords);     // [ns] when STAGED
-    const float* rg = x + (size_t)blockIdx.x * ns;
-    int* orow = idx + (size_t)blockIdx.x * cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int w = tid; w < nwords; w += kSpThreads) bits[w] = 0u;
-    if (STAGED) {
-        for (int i = tid; i < ns; i += kSpThreads) rowl[i] = rg[i];
-        __syncthreads();
-    }
-    // ---- block summaries: eight blocks per wave iteration (their loads are independent and in flight
-    //      together), lanes stride a block, wave shuffle reduction
-    {
-        const float* r = STAGED ? rowl : rg;
-        constexpr int kBatch = 8;
-        for (int bk0 = wave * kBatch; bk0 < nb; bk0 += (kSpThreads / 64) * kBatch) {
-            float mx[kBatch], mn[kBatch];
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                mx[j] = -INFINITY;
-                mn[j] = INFINITY;
-                const int lo = (bk0 + j) << bshift, hi = min(lo + BS, ns);
-                for (int i = lo + lane; i < hi; i += 64) {
-                    const float u = r[i];
-                    mx[j] = fmaxf(mx[j], u);
-                    mn[j] = fminf(mn[j], u);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], off));
-                    mn[j] = fminf(mn[j], __shfl_xor(mn[j], off));
-                }
-                if (lane == 0 && bk0 + j < nb) s1[bk0 + j] = make_float2(mx[j], mn[j]);
-            }
-        }
-    }
-    __syncthreads();
+// LDS tables of the picker for one row (after `lead` bytes the caller uses itself)
+struct FpLds {
+    float2* s1;        // [nb]  (max, min) of every block
+    float2* s2;        // [nb2] (max, min) of every super-block
+    unsigned* bits;    // [nwords] accepted peaks
+    unsigned* cand;    // [nwords] rising edges of the maxima worth a walk
+    int* clist;        // [kFpList] their positions, one round of bitmap words at a time
+    float* rowl;       // [ns] the row (STAGED)
+};
+
+__device__ __forceinline__ void fp_summaries2(const FpLds& T, int nb, int nb2, int tid) {
     for (int b2 = tid; b2 < nb2; b2 += kSpThreads) {
         float mx = -INFINITY, mn = INFINITY;
         for (int k = b2 * kFpFan; k < min((b2 + 1) * kFpFan, nb); ++k) {
-            mx = fmaxf(mx, s1[k].x);
-            mn = fminf(mn, s1[k].y);
+            mx = fmaxf(mx, T.s1[k].x);
+            mn = fminf(mn, T.s1[k].y);
         }
-        s2[b2] = make_float2(mx, mn);
+        T.s2[b2] = make_float2(mx, mn);
+    }
+}
+
+// block summaries of a row held in `r` (LDS or global): eight blocks per wave iteration (their loads are independent
+// and in flight together), lanes stride a block, wave shuffle reduction
+__device__ __forceinline__ void fp_summaries1(const float* __restrict__ r, const FpLds& T, int ns, int nb, int bshift, int tid) {
+    const int BS = 1 << bshift, lane = tid & 63, wave = tid >> 6;
+    constexpr int kBatch = 8;
+    for (int bk0 = wave * kBatch; bk0 < nb; bk0 += (kSpThreads / 64) * kBatch) {
+        float mx[kBatch], mn[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            mx[j] = -INFINITY;
+            mn[j] = INFINITY;
+            const int lo = (bk0 + j) << bshift, hi = min(lo + BS, ns);
+            for (int i = lo + lane; i < hi; i += 64) {
+                const float u = r[i];
+                mx[j] = fmaxf(mx[j], u);
+                mn[j] = fminf(mn[j], u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], off));
+                mn[j] = fminf(mn[j], __shfl_xor(mn[j], off));
+            }
+            if (lane == 0 && bk0 + j < nb) T.s1[bk0 + j] = make_float2(mx[j], mn[j]);
+        }
+    }
+}
+
+// stage the row into LDS and form the 32-sample block summaries in the same sweep: a lane loads four consecutive
+// samples (16 bytes), eight neighbouring lanes cover one block and reduce with three shuffle steps
+__device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, const FpLds& T, int ns, int nb, int tid) {
+    const int ns4 = ns >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(rg);
+    float4* l4 = reinterpret_cast<float4*>(T.rowl);
+    for (int base = 0; base < 8 * nb; base += kSpThreads) {             // wave-uniform trip count: every lane shuffles
+        const int v4 = base + tid;
+        float mx = -INFINITY, mn = INFINITY;
+        if (v4 < ns4) {
+            const float4 q = g4[v4];
+            l4[v4] = q;
+            mx = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
+            mn = fminf(fminf(q.x, q.y), fminf(q.z, q.w));
+        }
+#pragma unroll
+        for (int off = 1; off <= 4; off <<= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+            mn = fminf(mn, __shfl_xor(mn, off));
+        }
+        if ((v4 & 7) == 0 && (v4 >> 3) < nb) T.s1[v4 >> 3] = make_float2(mx, mn);
+    }
+}
+
+// candidates -> accepted-peak bitmap, in two phases so that the prominence walks run with every lane busy:
+//   (1) every thread marks the rising edges of maxima that can reach the threshold at all in the `cand` bitmap -- no
+//       base can lie below the row minimum, so a maximum with v - thr below it is rejected here, without a walk (with
+//       thr = a fraction of the strongest peak that is almost every maximum);
+//   (2) per round of kSpThreads bitmap words the marked positions are listed (popcount prefix sum) and lane c walks
+//       candidate c.  Walking inside the marking loop instead made a wave pay the SUM of its lanes' walks (one lane
+//       walking, 63 masked): 0.72 of 0.97 ms at 11020 x 12000 with ~15 picks per row.
+// r: the row (LDS or global).  Ends with the accepted peaks in T.bits; the last barrier is the caller's.
+constexpr int kFpList = kSpThreads * 16;          // candidates per round: at most every second sample of 32 x kSpThreads
+
+__device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds& T, int ns, int nb, int nb2, int bshift,
+                                        double thr, int nwords, int* wave_tot, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    float gmin = INFINITY;
+    for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
+    for (int w = tid; w < nwords; w += kSpThreads) T.cand[w] = 0u;
+    __syncthreads();
+    for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
+        const float v = r[i];
+        if (r[i - 1] < v && !(r[i + 1] > v) && !((double)v - thr < (double)gmin)) atomicOr(&T.cand[i >> 5], 1u << (i & 31));
     }
     __syncthreads();
-    {
-        const float* r = STAGED ? rowl : rg;
-        // no base can lie below the row minimum: a maximum with v - thr below it cannot reach the threshold and is
-        // rejected without a walk (with thr = a fraction of the strongest peak that is almost every maximum)
-        float gmin = INFINITY;
-        for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, s2[k].y);
-        for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
+    for (int w0 = 0; w0 < nwords; w0 += kSpThreads) {
+        const int w = w0 + tid;
+        unsigned word = (w < nwords) ? T.cand[w] : 0u;
+        const int cnt = __popc(word);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(incl, off);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < kSpThreads / 64; ++k) {
+            if (k < wave) before += wave_tot[k];
+            total += wave_tot[k];
+        }
+        int p = before + incl - cnt;
+        while (word) {
+            const int bit = __builtin_ctz(word);
+            word &= word - 1u;
+            T.clist[p++] = (w << 5) + bit;
+        }
+        __syncthreads();
+        for (int c = tid; c < total; c += kSpThreads) {
+            const int i = T.clist[c];
             const float v = r[i];
-            if (!(r[i - 1] < v)) continue;
-            if ((double)v - thr < (double)gmin) continue;
             int ia = i + 1;
-            while (ia < ns - 1 && r[ia] == v) ++ia;
+            while (ia < ns - 1 && r[ia] == v) ++ia;                  // plateau: reported at its middle sample
             if (!(r[ia] < v)) continue;
             const int mid = (i + ia - 1) / 2;
             // float64 like scipy (float32 samples are exact in float64, a float32 subtraction is not):
@@ -703,17 +758,22 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
             const double dl = (double)v - thr;
             float lim = (float)dl;
             if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
-            if (fp_walk<-1>(r, s1, s2, ns, nb, nb2, bshift, i - 1, v, lim) > lim) continue;   // left base too high
-            if (fp_walk<+1>(r, s1, s2, ns, nb, nb2, bshift, ia, v, lim) > lim) continue;
-            atomicOr(&bits[mid >> 5], 1u << (mid & 31));
+            if (fp_walk<-1>(r, T.s1, T.s2, ns, nb, nb2, bshift, i - 1, v, lim) > lim) continue;   // left base too high
+            if (fp_walk<+1>(r, T.s1, T.s2, ns, nb, nb2, bshift, ia, v, lim) > lim) continue;
+            atomicOr(&T.bits[mid >> 5], 1u << (mid & 31));
         }
+        __syncthreads();
     }
-    __syncthreads();
-    // ---- time-ordered index list: popcount prefix sum over the bitmap, kSpThreads words per round
+}
+
+// time-ordered index list: popcount prefix sum over the bitmap, kSpThreads words per round
+__device__ __forceinline__ void fp_emit(const FpLds& T, int nwords, int* __restrict__ orow, int* __restrict__ count, int cap,
+                                        int* wave_tot, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     int base = 0;
     for (int w0 = 0; w0 < nwords; w0 += kSpThreads) {
         const int w = w0 + tid;
-        unsigned word = (w < nwords) ? bits[w] : 0u;
+        unsigned word = (w < nwords) ? T.bits[w] : 0u;
         const int cnt = __popc(word);
         int incl = cnt;
 #pragma unroll
@@ -738,7 +798,49 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
         base += total;
         __syncthreads();
     }
-    if (tid == 0) counts[blockIdx.x] = base;
+    if (tid == 0) *count = base;
+}
+
+__device__ __forceinline__ FpLds fp_lds(unsigned char* p, int nb, int nb2, int nwords) {
+    FpLds T;
+    T.s1 = reinterpret_cast<float2*>(p);
+    T.s2 = T.s1 + nb;
+    const int nw4 = (nwords + 3) & ~3;
+    T.bits = reinterpret_cast<unsigned*>(T.s1 + ((nb + nb2 + 1) & ~1));   // every table starts on 16 bytes:
+    T.cand = T.bits + nw4;                                                // the row is staged with 16-byte accesses
+    T.clist = reinterpret_cast<int*>(T.cand + nw4);
+    T.rowl = reinterpret_cast<float*>(T.clist + kFpList);
+    return T;
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
+                                                              int bshift, int* __restrict__ idx,
+                                                              int* __restrict__ counts, int cap) {
+    D4W_DYN_LDS(smem_raw);
+    __shared__ int wave_tot[kSpThreads / 64];
+    const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
+    const int nwords = (ns + 31) >> 5;
+    const FpLds T = fp_lds(smem_raw, nb, nb2, nwords);
+    const float* rg = x + (size_t)blockIdx.x * ns;
+    const int tid = threadIdx.x;
+    for (int w = tid; w < nwords; w += kSpThreads) T.bits[w] = 0u;
+    const bool vec4 = STAGED && bshift == 5 && (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
+    if (vec4) {
+        fp_stage_rows4(rg, T, ns, nb, tid);
+    } else {
+        if (STAGED) {
+            for (int i = tid; i < ns; i += kSpThreads) T.rowl[i] = rg[i];
+            __syncthreads();
+        }
+        fp_summaries1(STAGED ? T.rowl : rg, T, ns, nb, bshift, tid);
+    }
+    __syncthreads();
+    fp_summaries2(T, nb, nb2, tid);
+    __syncthreads();
+    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, tid);
+    __syncthreads();
+    fp_emit(T, nwords, idx + (size_t)blockIdx.x * cap, counts + blockIdx.x, cap, wave_tot, tid);
 }
 
 // picks of all rows as ONE packed 2 x K table (detect.convert_pick_times, detect.py:277-303: row 0 = channel,
@@ -916,7 +1018,8 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
     const int nb = (ns + (1 << bshift) - 1) >> bshift;
     const bool staged = (ns <= kFpRowLds);
     const int nb2 = (nb + kFpFan - 1) / kFpFan;
-    const size_t lds = ((size_t)2 * (nb + nb2) + (size_t)((ns + 31) >> 5) + (staged ? (size_t)ns : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * ((nb + nb2 + 1) & ~1) + 2 * (size_t)((((ns + 31) >> 5) + 3) & ~3) + (size_t)kFpList +
+                        (staged ? (size_t)ns : 0)) * sizeof(float);
     if (lds > kSpLdsMax) return fail(D4W_EINVAL, "rows of %d samples exceed the peak-picking LDS tables", ns);
     if (staged) {
         sp_allow_lds(find_peaks_prom<true>, lds);

@@ -186,10 +186,13 @@ def test_row_lengths_with_large_prime_factors(dw):
 
 
 def test_unsupported_length_is_a_clear_error(dw):
-    """What has no kernel: a time axis (ns / 2) with a prime factor > 31, a channel count whose part with
-    prime factors > 31 exceeds 4096.  ValueError naming the remedy."""
+    """What has no kernel: a time axis whose part with prime factors > 31 exceeds 2048 (ns / 2 = 4099), a channel count
+    whose part with prime factors > 31 exceeds 4096.  ValueError naming the remedy.  (Smaller primes run Bluestein passes.)"""
     assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
-    for shape in ((8, 2 * 37), (4099, 16)):
+    x = np.random.default_rng(0).standard_normal((8, 2 * 37))
+    m = np.random.default_rng(1).uniform(size=x.shape)
+    assert np.max(np.abs(dw.dsp.fk_filter_filt(x, m) - orc.fk_filter_filt(x, m))) < 1e-5 * np.max(np.abs(x))
+    for shape in ((8, 2 * 4099), (4099, 16)):
         x = np.zeros(shape)
         with pytest.raises(ValueError, match="supported_length"):
             dw.dsp.fk_filter_filt(x, np.ones_like(x))
