@@ -99,6 +99,43 @@ def cpu_baseline(sample_nx, sample_ns, stages):
     return out
 
 
+def replicas_step_ms(args, stages, world, rank, device, dist):
+    """One independent [nx x ns] block per GPU (no collective in the data path, weak scaling): ms per step, max over ranks --
+    the second line of the N > 1 bench (SURVEY 8e "replicas")."""
+    import das4whales_amd as dw
+    from das4whales_amd import detect as ddet
+    nx, ns, fs, dx = args.nx, args.ns, 200.0, 2.0419046878814697
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4321 + rank)
+    x = torch.randn((nx, ns), dtype=torch.float32, device=device, generator=gen)
+    y = torch.empty_like(x)
+    plan = dw.dsp.FkPlan(nx, ns, device=device)
+    mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)
+    plan.set_mask(mask)
+    del mask
+    time_ax = np.arange(ns) / fs
+    tpl = [ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 17.8, 28.8, 0.68)),
+           ddet._normalised_support(ddet.gen_template_fincall(time_ax, fs, 14.7, 21.8, 0.78))]
+
+    def step():
+        _, mean, mx = plan.apply_stats(x, out=y)
+        return ddet._xcorr_device(y, tpl, normalize=True, stats=(mean, mx))
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item()) / args.steps * 1e3
+
+
 def bench_channel_sharded(args, stages, world, rank, device, dist):
     """BASELINE configs[3]: ONE nx x ns block sharded by contiguous channel block over the ranks; a step
     is the exact distributed f-k filter (time phase, all-to-all, channel phase, all-to-all, inverse
@@ -179,6 +216,13 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         for (l0, e0), (l1, e1) in zip(plan.marks[:-1], plan.marks[1:]):
             stage_ms["fk:" + l1] = stage_ms.get("fk:" + l1, 0.0) + e0.elapsed_time(e1) / 3
     plan.marks = None
+    rep_ms = None
+    plan_info = {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "packed": bool(plan.packed), "exchange_row_chunks": plan.CHUNKS}
+    kernels = "shape-specialised" if plan.packed else "generic"
+    if (world > 1 or args.force_replicas) and stages == ["fk", "mf"] and not args.no_replicas:
+        del x_loc, plan
+        torch.cuda.empty_cache()
+        rep_ms = replicas_step_ms(args, stages, world, rank, device, dist)
     if rank == 0:
         samples = float(nx) * ns
         ms = dt / args.steps * 1e3
@@ -190,12 +234,15 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
                "config": {"workload": "ONE %d channels x %d samples float32 block sharded by channel block over %d GPU(s), "
                                       "classic f-k fan mask, stages %s%s" % (nx, ns, world, "+".join(stages),
                                                                              ", all-gather of the t-x output" if args.gather else ""),
-                          "plan": {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "packed": bool(plan.packed),
-                                   "exchange_row_chunks": plan.CHUNKS},
+                          "plan": plan_info,
                           "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
-               "roofline": {"bound": "hbm", "kernel": "distributed step (%s pass kernels + exchange)" % ("shape-specialised" if plan.packed else "generic"),
+               "roofline": {"bound": "hbm", "kernel": "distributed step (%s pass kernels + exchange)" % kernels,
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                             "traffic": None, "stage_ms_rank0": stage_ms}}
+        if rep_ms is not None:
+            out["replicas"] = {"note": "second line: one independent block per GPU, no collective in the data path (weak scaling)",
+                               "ms_per_step": rep_ms, "value": samples * world / (rep_ms * 1e-3), "unit": "channel-samples/s",
+                               "scaling": "weak"}
         print(json.dumps(out), flush=True)
     dist.destroy_process_group()
 
@@ -343,6 +390,8 @@ def main():
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="--shard channel: all-gather the filtered t-x matrix each step (default when N > 1)")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the second (replicas, weak-scaling) measurement")
+    ap.add_argument("--force-replicas", action="store_true", help="run the second measurement at N = 1 as well (exercises the N > 1 code path)")
     args = ap.parse_args()
     stages = [t for t in args.stages.split(",") if t]
     assert set(stages) <= {"bp", "fk", "mf"} and stages, "--stages: comma list of bp, fk, mf"
