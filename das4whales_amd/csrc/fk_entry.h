@@ -50,6 +50,7 @@ namespace d4w {
 struct FkFastEntry {
     int variant;           // D4W_FK_VARIANT picks among entries of one shape (0 = default)
     int nx, ns, C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB;
+    int C2X;               // > 1: the c2 axis (= C2X, with C2A = C2B = 1) runs the generic Bluestein pass C
     size_t ldsA, ldsC, ldsB;
     int wgA, wgC, wgB;     // resident workgroups per CU the persistent grids are sized for
     void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
@@ -78,6 +79,7 @@ static inline FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0)
     e.nx = G::NX; e.ns = 2 * G::M;
     e.C1 = G::C1; e.C2A = G::C2A; e.C2B = G::C2B; e.N1 = G::N1; e.NA = G::NA; e.NB = G::NB; e.NC = G::NC;
     e.TA = G::TA; e.TC = G::TC; e.thrA = G::THRA; e.thrC = G::THRC; e.thrB = G::THRB;
+    e.C2X = G::C2X;
     e.ldsA = G::ldsA; e.ldsC = G::ldsC; e.ldsB = G::ldsB;
     e.wgA = wgA; e.wgC = wgC; e.wgB = wgB;
     e.A_fwd = fkf_passA_fwd<G, false, 0>;

@@ -25,13 +25,16 @@
 namespace d4w {
 
 template <int C1_, int C2A_, int C2B_, int N1_, int NA_, int NB_, int NC_, int TA_, int TC_, int THRA_,
-          int THRC_, int THRB_, bool CTREE_ = false, int WAVES_B_ = 1>
+          int THRC_, int THRB_, bool CTREE_ = false, int WAVES_B_ = 1, int C2X_ = 1>
 struct FkFastCfg {
+    // C2X > 1: the c2 axis has a factor C2X with prime factors > 31 and its whole sub-transform runs as the generic Bluestein
+    // pass C (fk_filter.hip); the configuration then sets C2A = C2B = 1 and only passes A and B are the kernels below
+    static constexpr int C2X = C2X_;
     static constexpr int WAVES_B = WAVES_B_;   // min waves per SIMD pass B is compiled for (register cap)
     // CTREE: pass C forms W_C2^(j a) as powers of W_C2^j in registers instead of reading a
     // [C2A][C2B] table from LDS (frees C2A*C2B*8 bytes of LDS per workgroup)
     static constexpr bool CTREE = CTREE_;
-    static constexpr int C1 = C1_, C2A = C2A_, C2B = C2B_, C2 = C2A_ * C2B_, NX = C1_ * C2A_ * C2B_;
+    static constexpr int C1 = C1_, C2A = C2A_, C2B = C2B_, C2 = C2A_ * C2B_ * C2X_, NX = C1_ * C2A_ * C2B_ * C2X_;
     static constexpr int N1 = N1_, NA = NA_, NB = NB_, NC = NC_, N2 = NA_ * NB_ * NC_, M = N1_ * NA_ * NB_ * NC_;
     static constexpr int TA = TA_, TC = TC_, THRA = THRA_, THRC = THRC_, THRB = THRB_;
     // pass A: tile [C1][N1][TA] + double-buffered four-step twiddle strip [2][N1][TA]

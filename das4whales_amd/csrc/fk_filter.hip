@@ -37,6 +37,7 @@ constexpr int kThreads = 256;      // threads of the small helper kernels
 #endif
 constexpr int kMaxThreads = D4W_FK_THREADS;   // block size of the pass kernels
 constexpr int kMaxTile = 8192;     // complex elements per LDS tile (64 KiB)
+constexpr int kMaxTileBs = 8192;   // ... of the Bluestein pass C (16384 = 128 KiB, one workgroup per CU, measured slower: 2.36 vs 2.06 ms at 13223 x 12000)
 constexpr int kPF = kMaxTile / kMaxThreads;   // prefetch registers (float2) per thread
 
 // Every pass kernel is persistent (grid = 2 workgroups per CU) and software-pipelined:
@@ -250,7 +251,13 @@ __global__ __launch_bounds__(kMaxThreads) void fk_passC_bluestein(FkDev P, float
     const int nelem = d.C2 * TC, ntile = L * TC;
     const int ntx = (d.M + TC - 1) / TC;
     const TwLds tw = tw_stage(P.ax_bs, tile + ntile, tid, nthr);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (8 of them, each with its own L2), and a
+    // tile reads only TC * 8 bytes of every row -- a quarter of a 64-byte sector at TC = 2.  XCD x therefore walks its own
+    // contiguous eighth of the tiles, so that the neighbours sharing a tile's sectors run on the same L2.
+    const int nxcd = (gridDim.x % 8 == 0 && ntiles >= 64) ? 8 : 1;
+    const int xcd = blockIdx.x % nxcd, jx = blockIdx.x / nxcd, gx = gridDim.x / nxcd;
+    const int t8 = (ntiles + nxcd - 1) / nxcd, tend = min(ntiles, (xcd + 1) * t8);
+    for (int t = xcd * t8 + jx; t < tend; t += gx) {
         const int q = t / ntx, p0 = (t - q * ntx) * TC;
         const int ncol = min(TC, d.M - p0);
         float2* base = data + ((size_t)q * d.C2) * d.M + p0;
@@ -707,7 +714,8 @@ int d4w_fk_shape_is_specialised(int nx, int ns) {
 int d4w_fk_register_shape(const void* entry, size_t entry_size) {
     if (!entry || entry_size != sizeof(FkFastEntry)) return fail(D4W_EINVAL, "shape entry of %zu bytes, expected %zu (stale build?)", entry_size, sizeof(FkFastEntry));
     FkFastEntry* e = new FkFastEntry(*static_cast<const FkFastEntry*>(entry));
-    if (e->nx < 1 || e->ns < 2 || e->C1 * e->C2A * e->C2B != e->nx || 2 * e->N1 * e->NA * e->NB * e->NC != e->ns || e->TA != e->TC) {
+    if (e->nx < 1 || e->ns < 2 || e->C2X < 1 || e->C1 * e->C2A * e->C2B * e->C2X != e->nx || (e->C2X > 1 && e->C2A * e->C2B != 1) ||
+        2 * e->N1 * e->NA * e->NB * e->NC != e->ns || e->TA != e->TC) {
         delete e;
         return fail(D4W_EINVAL, "inconsistent shape entry");
     }
@@ -794,6 +802,13 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
     // a prime factor > 31 of nx goes into C2, whose sub-transform then runs as a Bluestein convolution of
     // length bs_L (pass C); C1 keeps the smooth part
     int bs_L = 0;
+    if (fast && fast->C2X > 1) {                       // specialised passes A and B around the generic Bluestein pass C
+        C2 = fast->C2X;
+        C1 = nx / C2;
+        bs_L = 1;
+        while (bs_L < 2 * C2 - 1) bs_L *= 2;
+        if (bs_L > kMaxTile) return fail(D4W_EINVAL, "registered configuration: Bluestein factor %d too long", C2);
+    }
     if (!fast && rough_part(nx) > 1) {
         C2 = rough_part(nx);
         C1 = nx / C2;
@@ -831,16 +846,17 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         N2 = M / N1;
     }
     int TC = o[5] > 0 ? o[5] : 16;
-    while (TC > 1 && (long)(bs_L ? bs_L : C2) * TC > kMaxTile) TC /= 2;
+    while (TC > 1 && (long)(bs_L ? bs_L : C2) * TC > (bs_L ? kMaxTileBs : kMaxTile)) TC /= 2;
     int TA = o[4] > 0 ? o[4] : 16;
     while (TA > 1 && (long)C1 * N1 * TA > kMaxTile) TA /= 2;
     std::vector<int> r_c1, r_c2, r_n1, r_n2;
     if (fast) {
-        C1 = fast->C1; C2 = fast->C2A * fast->C2B; N1 = fast->N1; N2 = fast->NA * fast->NB * fast->NC;
-        TA = fast->TA; TC = fast->TC;
+        C1 = fast->C1; C2 = fast->C2A * fast->C2B * fast->C2X; N1 = fast->N1; N2 = fast->NA * fast->NB * fast->NC;
+        TA = fast->TA;
+        if (!bs_L) TC = fast->TC;                       // Bluestein pass C keeps its own strip width
         r_c1 = {C1}; r_c2 = {fast->C2A, fast->C2B}; r_n1 = {N1}; r_n2 = {fast->NA, fast->NB, fast->NC};
     }
-    if (!fast && ((long)(bs_L ? bs_L : C2) * TC > kMaxTile || (long)C1 * N1 * TA > kMaxTile || 2L * (bn_L ? bn_L : N2) > kMaxTile))
+    if (!fast && ((long)(bs_L ? bs_L : C2) * TC > (bs_L ? kMaxTileBs : kMaxTile) || (long)C1 * N1 * TA > kMaxTile || 2L * (bn_L ? bn_L : N2) > kMaxTile))
         return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling (C1=%d C2=%d N1=%d N2=%d)",
                     nx, ns, C1, C2, N1, N2);
 
@@ -1082,6 +1098,10 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             for (const void* f : fns)
                 (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         }
+        if (bs_L) {
+            (void)hipFuncSetAttribute((const void*)fk_passC_bluestein<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute((const void*)fk_passC_bluestein<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        }
     }
 #else
     pl->num_cu = 3;
@@ -1130,7 +1150,7 @@ static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double p
     pl->fdev.pairs = pl->dev.pairs;
     pl->fdev.live = nullptr;
     const char* np = getenv("D4W_FK_NOPRUNE");
-    if (pl->fast && !(np && atoi(np) > 0)) {
+    if (pl->fast && !pl->dev.bs_L && !(np && atoi(np) > 0)) {
         // Dead rows: a wavenumber row whose folded gains (and whose Hermitian partner's) are all zero -- exact -- or,
         // opt-in, all below prune_eps * max |M_h| (the Butterworth tails of hybrid_ninf_filter_design, dsp.py:348-349,
         // never reach zero: 7.7e-7 at fmax + 14 Hz; treating them as zero changes the output by at most that gain
@@ -1259,11 +1279,15 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         D4W_MARK(0);
         if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0, FkGeo()))) return rc;
         D4W_MARK(1);
-        if ((rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0, FkGeo()))) return rc;
+        if (P.bs_L) rc = launch_k(fk_passC_bluestein<false>, gridC, blk, pl->ldsC, stream, P, dst, ntC);      // C2X > 1
+        else rc = launch_k(F.C_fwd, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0, FkGeo());
+        if (rc) return rc;
         D4W_MARK(2);
         if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run, FkGeo()))) return rc;
         D4W_MARK(3);
-        if ((rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0, FkGeo()))) return rc;
+        if (P.bs_L) rc = launch_k(fk_passC_bluestein<true>, gridC, blk, pl->ldsC, stream, P, dst, ntC);
+        else rc = launch_k(F.C_inv, gC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, fC, NBC, 0, FkGeo());
+        if (rc) return rc;
         D4W_MARK(4);
         if (row_mean) {
             const int run = stats_run(NBX), nruns = fA / run;
@@ -1561,7 +1585,7 @@ static int fkd_plan_build_packed(int nx, int ns, int world, int rank, bool want_
     int rc = fk_plan_build(nx, ns, nullptr, false, true, &sp);
     if (rc) return rc;
     const FkFastEntry& F = *sp->fast;
-    if (F.TA != F.TC || (F.NA * F.NB * F.NC) % (F.N1 * F.TA) != 0) {     // pass A MODE 2 walks N1 adjacent strips inside a sub-row
+    if (F.C2X > 1 || F.TA != F.TC || (F.NA * F.NB * F.NC) % (F.N1 * F.TA) != 0) {     // pass A MODE 2 walks N1 adjacent strips inside a sub-row
         d4w_fk_plan_destroy(sp);
         return fail(D4W_EINVAL, "shape config not usable for the packed distributed plan");
     }

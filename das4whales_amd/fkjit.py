@@ -53,6 +53,16 @@ def choose_config(nx, ns):
     if nx < 1 or ns < 2 or ns % 2:
         return None
     M = ns // 2
+    # a channel count with prime factors > 31 (e.g. 13223 = 7 x 1889, scripts/main_mfdetect.py's selection): that part of
+    # the c2 axis runs the generic Bluestein pass C (C2X), passes A and B are specialised around it
+    c2x, rest = 1, nx
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
+        while rest % p == 0:
+            rest //= p
+    if rest > 1:
+        if rest > 4096 or nx // rest > 32:
+            return None
+        c2x = rest
     best = None
     for N1, NA, NB, NC in _splits(M, 4):
         N2 = NA * NB * NC
@@ -61,7 +71,7 @@ def choose_config(nx, ns):
         TA = next((t for t in (16, 8, 4, 2) if N2 % t == 0 and M % t == 0), 0)
         if not TA:
             continue
-        for C1, C2A, C2B in _splits(nx, 3):
+        for C1, C2A, C2B in ([(nx // c2x, 1, 1)] if c2x > 1 else _splits(nx, 3)):
             if C2A > C2B or C1 * N1 * TA > 16000 or C2A * (C2B + 1) * TA > 16000:
                 continue
             tileA = C1 * N1 * TA
@@ -80,8 +90,10 @@ def choose_config(nx, ns):
     ldsA = (C1 * N1 * TA + 2 * N1 * TA) * 8
     ldsC = (C2A * (C2B + 1) * TA + C2A * C2B) * 8
     ldsB = (2 * (NA * NB * NC + NA * NB) + 2 * NB * NC) * 8
-    wg = lambda l: max(1, min(2, (150 * 1024) // max(l, 1)))
-    return (C1, C2A, C2B, N1, NA, NB, NC, TA, TA, thrA, thrC, thrB, wg(ldsA), wg(ldsC), wg(ldsB))
+    # resident workgroups per CU the persistent grids are sized for: what LDS and the 2048 threads of a CU admit, at most 8;
+    # the large tiles of the measured shapes run 1-2 (their register pipelines hide the latency), small tiles need more
+    wg = lambda l, thr: max(1, min(2 if l > 40 * 1024 else 8, (150 * 1024) // max(l, 1), 2048 // thr))
+    return (C1, C2A, C2B, N1, NA, NB, NC, TA, TA, thrA, thrC, thrB, wg(ldsA, thrA), wg(ldsC, thrC), wg(ldsB, thrB), c2x)
 
 
 def _header_hash():
@@ -92,7 +104,7 @@ def _header_hash():
 
 
 def _lib_path(nx, ns, cfg):
-    tag = "_".join(str(v) for v in cfg[:12])
+    tag = "_".join(str(v) for v in cfg[:12]) + ("_x%d" % cfg[15] if cfg[15] > 1 else "")
     return os.path.join(_JITDIR, "fk_%dx%d_%s_%s.so" % (nx, ns, tag, _header_hash()))
 
 
@@ -132,10 +144,10 @@ def compile_fk_shape(nx, ns, verbose=False):
             src = "%s.%d.hip" % (path[:-3], os.getpid())
             with open(src, "w") as f:
                 f.write('// generated by das4whales_amd/fkjit.py for %d x %d\n#include "fk_entry.h"\n'
-                        "using G = d4w::FkFastCfg<%s>;\n"
+                        "using G = d4w::FkFastCfg<%s, false, 1, %d>;\n"
                         'extern "C" int d4w_jit_register(int (*reg)(const void*, size_t)) {\n'
                         "    d4w::FkFastEntry e = d4w::fast_entry<G>(%d, %d, %d);\n"
-                        "    return reg(&e, sizeof(e));\n}\n" % (nx, ns, ", ".join(str(v) for v in cfg[:12]), cfg[12], cfg[13], cfg[14]))
+                        "    return reg(&e, sizeof(e));\n}\n" % (nx, ns, ", ".join(str(v) for v in cfg[:12]), cfg[15], cfg[12], cfg[13], cfg[14]))
             tmp = "%s.%d.tmp" % (path, os.getpid())          # several ranks may compile the same shape at once
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
                    "-I", _CSRC, "-I", _INC, src, "-o", tmp]

@@ -20,12 +20,12 @@ def fkjit():
 
 
 @pytest.mark.parametrize("nx,ns", [(20000, 120000), (4000, 12000), (11020, 12000), (8000, 12000), (1000, 12000), (2000, 24000),
-                                   (12000, 60000), (16384, 16384), (50, 12000), (3, 48), (29 * 31 * 16, 2 * 25 * 16 * 10 * 10)])
+                                   (12000, 60000), (16384, 16384), (50, 12000), (3, 48), (13223, 12000), (4001, 1200), (29 * 31 * 16, 2 * 25 * 16 * 10 * 10)])
 def test_chooser_respects_template_constraints(fkjit, nx, ns):
     cfg = fkjit.choose_config(nx, ns)
     assert cfg is not None
-    C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB, wgA, wgC, wgB = cfg
-    assert C1 * C2A * C2B == nx and 2 * N1 * NA * NB * NC == ns
+    C1, C2A, C2B, N1, NA, NB, NC, TA, TC, thrA, thrC, thrB, wgA, wgC, wgB, C2X = cfg
+    assert C1 * C2A * C2B * C2X == nx and 2 * N1 * NA * NB * NC == ns and (C2X == 1 or C2A * C2B == 1)
     assert max(C1, C2A, C2B, N1, NA, NB, NC) <= 32 and C2B <= 32
     N2, M = NA * NB * NC, ns // 2
     assert TA == TC and N2 % TA == 0 and M % TC == 0
@@ -39,7 +39,8 @@ def test_chooser_respects_template_constraints(fkjit, nx, ns):
 
 
 def test_chooser_declines_shapes_without_a_configuration(fkjit):
-    assert fkjit.choose_config(13223, 12000) is None          # 13223 = 7 x 1889: Bluestein pass C, generic kernels
+    assert fkjit.choose_config(2 * 4099, 12000) is None       # rough part beyond the Bluestein tile
+    assert fkjit.choose_config(37 * 64, 12000) is None        # smooth part 64 > 32 rows per pass-A tile
     assert fkjit.choose_config(300, 12002) is None            # 6001 = 17 x 353
     assert fkjit.choose_config(40, 481) is None
     assert fkjit.is_specialised(20000, 120000) and not fkjit.is_specialised(20001, 120000)

@@ -81,3 +81,45 @@ def test_file_shape_8000_channels(dw):
     t_jit, t_gen = timed(plan), timed(gen)
     print("8000 x 12000: compiled configuration %.3f ms, generic passes %.3f ms" % (t_jit, t_gen))
     assert t_jit < t_gen
+
+
+def test_channel_count_with_large_prime_factor(dw):
+    """74 = 2 x 37 channels and the 13223 = 7 x 1889 channels of scripts/main_mfdetect.py's selection: compiled passes A and
+    B around the generic Bluestein pass C (configuration with C2X > 1), against the oracle / the generic plan."""
+    nx, ns = 74, 480
+    assert dw.dsp.compile_fk_shape(nx, ns)
+    rng = np.random.default_rng(74)
+    x, m = rng.standard_normal((nx, ns)), rng.uniform(size=(nx, ns))
+    dw.dsp.clear_fk_plans()
+    y = dw.dsp.fk_filter_filt(x, m, tapering=True)
+    ref = orc.fk_filter_filt(x, m, tapering=True)
+    assert np.max(np.abs(y - ref)) < TOL * np.max(np.abs(ref))
+    m[::3] = 0.0                                          # all-zero rows: this path prunes nothing, still exact
+    y = dw.dsp.fk_filter_filt(x, m)
+    ref = orc.fk_filter_filt(x, m)
+    assert np.max(np.abs(y - ref)) < TOL * np.max(np.abs(ref))
+    nx, ns = 13223, 12000
+    assert dw.dsp.compile_fk_shape(nx, ns)
+    dw.dsp.clear_fk_plans()
+    gen_ = torch.Generator(device="cuda").manual_seed(5)
+    xt = torch.randn((nx, ns), device="cuda", generator=gen_)
+    mt = torch.rand((nx, ns), device="cuda", generator=gen_)
+    plan = dw.dsp.get_fk_plan(nx, ns)
+    plan.set_mask(mt)
+    gen = dw.dsp.FkPlan(nx, ns, opts=(-1, 0, 0, 0, 0, 0))
+    gen.set_mask(mt)
+    y1, y2 = plan.apply(xt), gen.apply(xt)
+    assert float((y1 - y2).abs().max()) < 3e-6 * float(y2.abs().max())
+
+    def timed(p):
+        p.apply(xt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            p.apply(xt)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 5
+    t_jit, t_gen = timed(plan), timed(gen)
+    print("13223 x 12000: compiled A / B + Bluestein C %.3f ms, generic passes %.3f ms" % (t_jit, t_gen))
+    assert t_jit < t_gen
