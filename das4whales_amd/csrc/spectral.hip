@@ -30,6 +30,7 @@ struct RowFftDev {
     const int* p2f;       // [L] position -> frequency
     const float2* wpack;  // [L] exp(-2 pi i f / (2L)): real-packing twiddle of a 2L-point real row
     const float* hann;    // [L] periodic Hann window (scipy get_window('hann', L, fftbins=True))
+    const float2* wfull;  // [L] exp(-2 pi i m / L)
     // Bluestein form for a length with a prime factor > 31 (single-row transforms only): the L-point DFT as a
     // circular convolution of length bs_L = 2^k >= 2 L - 1 with the chirp exp(-i pi n^2 / L); pos / p2f are the
     // identity then.  bs_L = 0: the mixed-radix transform of `ax`.
@@ -119,6 +120,11 @@ static int row_fft_get(int L, const RowFftHost** out) {
     if (!rc) rc = sp_upload(h, p2f, &h->dev.p2f);
     if (!rc) rc = sp_upload(h, wp, &h->dev.wpack);
     if (!rc) rc = sp_upload(h, hann, &h->dev.hann);
+    {
+        std::vector<float2> wf(L);
+        for (int m = 0; m < L; ++m) wf[m] = wexp(m, L);
+        if (!rc) rc = sp_upload(h, wf, &h->dev.wfull);
+    }
     if (rc) {
         for (void* p : h->allocs) (void)hipFree(p);
         delete h;
@@ -392,6 +398,93 @@ __global__ __launch_bounds__(kSpThreads) void stft_mag(RowFftDev F, StftDims d, 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if ((tid & 63) == 0) atomicMax(rowmax + blockIdx.y, __float_as_uint(mx));   // mx >= 0: bit order = value order
+}
+
+// The same for frame lengths n_fft = RA * RB with both factors register butterflies (160 = 10 x 16, the detector's
+// 0.8-s window; 128, 256, 512): one DIF split n = j + RB a, k = k1 + RA k2 --
+//   S1 item (pair b, j)  : the RA windowed samples of two real frames (one complex value each), radix RA, x W_N^(j k1) -> LDS
+//   S2 item (pair b, k1) : radix RB over j -> Z[k1 + RA k2], back in place
+//   then the magnitudes of the kept bins (all bins when the row maximum is wanted) from Z[k] and conj Z[N - k].
+// Two LDS round trips per transform instead of the generic kernel's staging pass + three runtime-radix stages:
+// 5.5 -> see DESIGN.md 3.4 at 11020 x 12000, n_fft 160, hop 8.
+template <int RA, int RB>
+__global__ __launch_bounds__(kSpThreads) void stft_fat(RowFftDev F, StftDims d, const float* __restrict__ x,
+                                                       float* __restrict__ S, unsigned* __restrict__ rowmax) {
+    D4W_DYN_LDS(smem_raw);
+    constexpr int N = RA * RB, PB = RB + 1, TP = RA * PB;           // LDS pitch of a k1 row / of a transform
+    float2* buf = reinterpret_cast<float2*>(smem_raw);                // [nb][RA][RB + 1]
+    const int tid = threadIdx.x, nb = d.FT / 2;
+    float2* twl = buf + nb * TP;                                      // [RA][RB] W_N^(j k1)
+    float* win = reinterpret_cast<float*>(twl + N);                   // [N]
+    float* seg = win + N;
+    const int seg_len = (d.FT - 1) * d.hop + N;
+    const int t0 = blockIdx.x * d.FT;
+    const int s0 = t0 * d.hop - N / 2;
+    const float* xr = x + (size_t)blockIdx.y * d.ns;
+    for (int j = tid; j < seg_len; j += kSpThreads) {
+        const int s = s0 + j;
+        seg[j] = (s >= 0 && s < d.ns) ? xr[s] : 0.f;
+    }
+    for (int i = tid; i < N; i += kSpThreads) {
+        const int k1 = i / RB, j = i - k1 * RB;
+        twl[i] = F.wfull[(j * k1) % N];
+        win[i] = F.hann[i];
+    }
+    __syncthreads();
+    for (int it = tid; it < nb * RB; it += kSpThreads) {              // S1
+        const int b = it / RB, j = it - b * RB;
+        const float* sa = seg + 2 * b * d.hop + j;
+        const float* sb = sa + d.hop;
+        float2 z[RA];
+        static_for<RA>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            const float wn = win[j + RB * a];
+            z[a] = make_float2(sa[RB * a] * wn, sb[RB * a] * wn);
+        });
+        dft<RA>(z);
+        float2* o = buf + b * TP + j;
+        static_for<RA>([&](auto kk) {
+            constexpr int k1 = decltype(kk)::value;
+            o[k1 * PB] = (k1 == 0) ? z[0] : c_mul(z[k1], twl[k1 * RB + j]);
+        });
+    }
+    __syncthreads();
+    for (int it = tid; it < nb * RA; it += kSpThreads) {              // S2
+        const int b = it / RA, k1 = it - b * RA;
+        float2* r = buf + b * TP + k1 * PB;
+        float2 v[RB];
+        static_for<RB>([&](auto jj) { v[decltype(jj)::value] = r[decltype(jj)::value]; });
+        dft<RB>(v);
+        static_for<RB>([&](auto kk) { r[decltype(kk)::value] = v[decltype(kk)::value]; });
+    }
+    __syncthreads();
+    // Z[k] of transform b sits at buf[b][(k % RA)][k / RA]
+    const int klo = rowmax ? 0 : d.b_lo, khi = rowmax ? N / 2 : d.b_hi, nk = khi - klo + 1, nkeep = d.b_hi - d.b_lo + 1;
+    float mx = 0.f;
+    for (int w = tid; w < nk * nb; w += kSpThreads) {
+        const int kk = w / nb, b = w - kk * nb, k = klo + kk;
+        const int tA = t0 + 2 * b;
+        if (tA >= d.nframes) continue;
+        const float2* tb = buf + b * TP;
+        const int km = (k == 0) ? 0 : N - k;
+        const float2 zk = tb[(k % RA) * PB + k / RA], zm = c_conj(tb[(km % RA) * PB + km / RA]);
+        const float2 A = c_scale(c_add(zk, zm), 0.5f);
+        const float2 B = c_mul_mi(c_scale(c_sub(zk, zm), 0.5f));
+        const float ma = sqrtf(fmaf(A.x, A.x, A.y * A.y)), mb = sqrtf(fmaf(B.x, B.x, B.y * B.y));
+        const bool hasB = (tA + 1 < d.nframes);
+        mx = fmaxf(mx, ma);
+        if (hasB) mx = fmaxf(mx, mb);
+        if (k >= d.b_lo && k <= d.b_hi) {
+            float* o = S + ((size_t)blockIdx.y * nkeep + (k - d.b_lo)) * d.nframes + tA;
+            o[0] = ma;
+            if (hasB) o[1] = mb;
+        }
+    }
+    if (rowmax) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((tid & 63) == 0) atomicMax(rowmax + blockIdx.y, __float_as_uint(mx));   // mx >= 0: bit order = value order
+    }
 }
 
 // S[c][i] /= denom[c]  (mode 0, detect.py:387)   or   20 log10(S[c][i] / denom[c])  (mode 1, dsp.py:76)
@@ -955,7 +1048,7 @@ int d4w_stft_frames(int ns, int hop) { return (hop > 0 && ns >= 0) ? 1 + ns / ho
 
 int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, int n_fft, int hop, int bin_lo,
                      int bin_hi, void* stream) {
-    if (!x || !S || !rowmax || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (!x || !S || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (n_fft < 2 || (n_fft & 1) || hop < 1) return fail(D4W_EINVAL, "n_fft = %d must be even and >= 2, hop = %d >= 1", n_fft, hop);
     if (bin_lo < 0 || bin_hi > n_fft / 2 || bin_lo > bin_hi) return fail(D4W_EINVAL, "bin range [%d, %d] outside 0..%d", bin_lo, bin_hi, n_fft / 2);
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
@@ -970,6 +1063,35 @@ int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, in
     int nb = std::max(1, 6144 / n_fft);                      // complex transforms (frame pairs) per workgroup
     nb = std::min(nb, std::max(1, (d.nframes + 1) / 2));
     d.FT = 2 * nb;
+    // two-factor register transforms for the common frame lengths (rowmax may be NULL there: only the kept bins are formed)
+    {
+        static const int fat_env = [] { const char* v = getenv("D4W_STFT_FAT"); return v ? atoi(v) : 1; }();
+        int RA = 0, RB = 0;
+        if (n_fft == 160) { RA = 10; RB = 16; }
+        else if (n_fft == 128) { RA = 8; RB = 16; }
+        else if (n_fft == 256) { RA = 16; RB = 16; }
+        else if (n_fft == 512) { RA = 32; RB = 16; }
+        if (RA && fat_env) {
+            const size_t ldsf = ((size_t)nb * RA * (RB + 1) + n_fft) * sizeof(float2) +
+                                ((size_t)n_fft + (size_t)(d.FT - 1) * hop + n_fft) * sizeof(float);
+            if (ldsf <= kSpLdsMax) {
+                if (rowmax) D4W_HIP(hipMemsetAsync(rowmax, 0, (size_t)nx * sizeof(float), (hipStream_t)stream));
+                const dim3 gridf(ceil_div(d.nframes, d.FT), nx);
+#define D4W_FAT(A_, B_)                                                                                             \
+    do {                                                                                                            \
+        sp_allow_lds(stft_fat<A_, B_>, ldsf);                                                                       \
+        D4W_LAUNCH((stft_fat<A_, B_>), gridf, dim3(kSpThreads), ldsf, stream, h->dev, d, x, S, (unsigned*)rowmax);  \
+    } while (0)
+                if (n_fft == 160) D4W_FAT(10, 16);
+                else if (n_fft == 128) D4W_FAT(8, 16);
+                else if (n_fft == 256) D4W_FAT(16, 16);
+                else D4W_FAT(32, 16);
+#undef D4W_FAT
+                return D4W_OK;
+            }
+        }
+    }
+    if (!rowmax) return fail(D4W_EINVAL, "rowmax is NULL (only the two-factor frame lengths 128, 160, 256, 512 form the kept bins alone)");
     const size_t lds = ((size_t)nb * n_fft + kTwLo + h->dev.ax.nhi) * sizeof(float2) +
                        ((size_t)(d.FT - 1) * hop + n_fft) * sizeof(float);
     if (lds > kSpLdsMax) return fail(D4W_EINVAL, "n_fft = %d / hop = %d exceed the LDS frame tile", n_fft, hop);

@@ -420,7 +420,7 @@ def compute_cross_correlogram_spectrocorr(data, fs, flims, kernel, win_size, ove
     per_ch = (hi - lo + 1) * nt * 4
     step = int(max(1, min(65535, (2 << 30) // per_ch)))          # <= 2 GiB of spectrogram in flight
     for a in range(0, nx, step):
-        S, _ = dsp._stft_mag(x[a:a + step], nperseg, nhop, lo, hi)
+        S, _ = dsp._stft_mag(x[a:a + step], nperseg, nhop, lo, hi, want_max=False)     # the max-normalisation cancels (docstring)
         out[a:a + step] = _spectrocorr_device(S, ker, ker.shape[1] // 2, nt)
     return dev.like_input(out, data)
 

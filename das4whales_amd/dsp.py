@@ -652,14 +652,16 @@ def get_fx(trace, nfft):
     return dev.like_input(y, trace)
 
 
-def _stft_mag(x2d, n_fft, hop, bin_lo, bin_hi):
-    """|librosa.stft| of every row: returns (S [nx, bins, frames] raw magnitudes, rowmax [nx])."""
+def _stft_mag(x2d, n_fft, hop, bin_lo, bin_hi, want_max=True):
+    """|librosa.stft| of every row: returns (S [nx, bins, frames] raw magnitudes, rowmax [nx]).  want_max=False (frame
+    lengths with a two-factor register transform only): the kept bins alone are formed and rowmax is None."""
     nx, ns = x2d.shape
     nt = int(lib.d4w_stft_frames(ns, int(hop)))
     S = torch.empty((nx, bin_hi - bin_lo + 1, nt), dtype=torch.float32, device=x2d.device)
-    mx = torch.empty(nx, dtype=torch.float32, device=x2d.device)
+    want_max = want_max or int(n_fft) not in (128, 160, 256, 512)
+    mx = torch.empty(nx, dtype=torch.float32, device=x2d.device) if want_max else None
     with torch.cuda.device(x2d.device):
-        check(lib.d4w_stft_mag_f32(dev.ptr(x2d), dev.ptr(S), dev.ptr(mx), nx, ns, int(n_fft), int(hop),
+        check(lib.d4w_stft_mag_f32(dev.ptr(x2d), dev.ptr(S), dev.ptr(mx) if want_max else None, nx, ns, int(n_fft), int(hop),
                                    int(bin_lo), int(bin_hi), dev.stream_ptr(x2d)))
     return S, mx
 

@@ -99,7 +99,7 @@ def stft(lib, x, n_fft, hop, lo, hi):
     return S, mx
 
 
-@pytest.mark.parametrize("n_fft,hop,ns", [(160, 8, 2000), (256, 12, 2000), (128, 25, 999), (64, 3, 130)])
+@pytest.mark.parametrize("n_fft,hop,ns", [(160, 8, 2000), (256, 12, 2000), (128, 25, 999), (64, 3, 130), (512, 100, 3000), (100, 7, 700)])
 def test_stft_magnitude(emu, n_fft, hop, ns):
     rng = np.random.default_rng(n_fft + hop)
     x = rng.standard_normal((3, ns))
@@ -111,6 +111,14 @@ def test_stft_magnitude(emu, n_fft, hop, ns):
         assert abs(mx[c] - ref.max()) < TOL * ref.max()
     S2, mx2 = stft(emu, x, n_fft, hop, 5, 17)                       # sliced bins, max still over all bins
     assert np.array_equal(S2, S[:, 5:18]) and np.array_equal(mx2, mx)
+    # kept bins only (rowmax = NULL): the two-factor frame lengths; the others need the row maximum
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    S3 = np.full_like(S2, np.nan)
+    rc = emu.d4w_stft_mag_f32(vp(xf), vp(S3), None, 3, ns, n_fft, hop, 5, 17, None)
+    if n_fft in (128, 160, 256, 512):
+        assert rc == 0 and np.array_equal(S3, S2)
+    else:
+        assert rc != 0
 
 
 def test_spectrogram_and_nspectrogram_golden(emu, golden):
