@@ -1,0 +1,31 @@
+#!/bin/bash
+# One GPU-box session that produces everything the round's measured claims rest on (copied into profiles/rNN/ afterwards):
+# parity tests, smoke, the bench lines (default, bp+fk+mf, stream, channel-sharded on one rank), rocprofv3 kernel statistics,
+# PMC FETCH_SIZE / WRITE_SIZE passes, band-pass and pipeline timings, the CPU column at the config-1 shape.
+#   gpurun --timeout 2400 -- 'bash scripts/evidence_run.sh gpurun_out/r02c'
+set -u
+O=${1:-gpurun_out/evidence}
+mkdir -p $O
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; grep "smoke" $O/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | grep "^{" > $O/bench_line.json; cut -c1-300 $O/bench_line.json
+timeout 900 python bench.py --stages bp,fk,mf --steps 10 --warmup 3 --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_bp_fk_mf.json; cut -c1-200 $O/bench_bp_fk_mf.json
+timeout 900 python bench.py --config stream --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_1gpu.json; cut -c1-600 $O/bench_stream_1gpu.json
+timeout 900 python bench.py --shard channel --steps 5 --warmup 2 --force-replicas 2>/dev/null | grep "^{" > $O/bench_shard_channel_1rank.json; cut -c1-200 $O/bench_shard_channel_1rank.json
+timeout 600 python scripts/time_bp.py 2>/dev/null | grep "^{" > $O/time_bp.txt; cat $O/time_bp.txt
+timeout 600 python scripts/pipeline_bench.py 2>/dev/null | grep "^{" > $O/pipeline_11020x12000.json; cat $O/pipeline_11020x12000.json
+timeout 600 python scripts/time_shapes.py 13223x12000 8000x12000 11020x12000 5510x12000 4000x12000 2>/dev/null | grep "^{" > $O/time_shapes.txt; cat $O/time_shapes.txt
+NX=11020 timeout 600 python scripts/time_spectral.py 2>/dev/null | grep "^{" > $O/time_spectral_11020x12000.json
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o fk -- python $R/bench.py --steps 5 --warmup 2 --no-cpu > $R/$O/rocprof_bench.log 2>&1
+cd $R
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && grep -E "d4w|Name" "$f" | cut -c1-160 | head -16
+rm -rf $O/prof
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o fk -- python $R/bench.py --stages bp,fk,mf --steps 5 --warmup 2 --no-cpu --no-dense > $R/$O/rocprof_bench_bp.log 2>&1
+cd $R
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_bp_fk_mf.csv
+rm -rf $O/prof
+BENCH_ARGS="--stages bp,fk,mf --no-dense" PMC_GROUPS="fetch write" bash scripts/pmc.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
+cp $O/pmc/summary.txt $O/pmc_fetch_write_summary.txt; cp $O/pmc/pmc_traffic.json $O/pmc_traffic.json; rm -rf $O/pmc
+timeout 900 python scripts/cpu_baseline_c1.py > $O/cpu_baseline_c1.json 2>/dev/null; cut -c1-300 $O/cpu_baseline_c1.json

@@ -1,4 +1,4 @@
-"""Per-pass f-k times (HIP events) for shapes without specialised kernels."""
+"""Per-pass f-k times (HIP events), dense random mask, for any shapes (built-in, compiled on demand or generic kernels)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,6 +6,7 @@ import das4whales_amd as dw
 shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(13223, 12000), (8000, 12000), (6000, 12000), (11020, 12000), (300, 12002)]
 for nx, ns in shapes:
     x = torch.randn((nx, ns), device="cuda")
+    dw.dsp.compile_fk_shape(nx, ns)
     plan = dw.dsp.FkPlan(nx, ns)
     plan.set_mask(torch.rand((nx, ns), device="cuda"))
     y = torch.empty_like(x)
@@ -14,5 +15,5 @@ for nx, ns in shapes:
     for _ in range(5):
         _, ms = plan.apply_timed(x, out=y)
         acc = [a + b / 5 for a, b in zip(acc, ms)]
-    print(json.dumps({"shape": [nx, ns], "plan": plan.info(), "passes_ms": [round(a, 3) for a in acc], "total_ms": round(sum(acc), 3),
+    print(json.dumps({"shape": [nx, ns], "specialised": bool(dw.fkjit.is_specialised(nx, ns)), "plan": plan.info(), "passes_ms": [round(a, 3) for a in acc], "total_ms": round(sum(acc), 3),
                       "GBps_24B": round(24.0 * nx * ns / (sum(acc) * 1e-3) / 1e9, 1)}), flush=True)
