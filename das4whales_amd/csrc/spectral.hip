@@ -511,13 +511,12 @@ __device__ __forceinline__ float med_unkey(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-// the radix select on a row held anywhere (global memory or LDS); every thread of the workgroup returns the median.
-// hist: 256 words of LDS, ctl: 4 words of LDS
-__device__ __forceinline__ float median_select(const float* __restrict__ row, size_t n, unsigned* hist, unsigned* ctl, int tid) {
-    unsigned& s_prefix = ctl[0];
-    unsigned& s_k = ctl[1];
-    unsigned& s_cnt = ctl[2];
-    unsigned& s_min = ctl[3];
+__global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict__ v, size_t n,
+                                                         float* __restrict__ med) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_k, s_cnt, s_min;
+    const float* row = v + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
     if (tid == 0) { s_prefix = 0u; s_k = (unsigned)((n - 1) / 2); }
     unsigned mask = 0u;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -542,7 +541,10 @@ __device__ __forceinline__ float median_select(const float* __restrict__ row, si
         __syncthreads();
     }
     const unsigned a = s_prefix;
-    if (n & 1) return med_unkey(a);
+    if (n & 1) {
+        if (tid == 0) med[blockIdx.x] = med_unkey(a);
+        return;
+    }
     if (tid == 0) { s_cnt = 0u; s_min = 0xFFFFFFFFu; }
     __syncthreads();
     unsigned cnt = 0u, mn = 0xFFFFFFFFu;
@@ -554,17 +556,10 @@ __device__ __forceinline__ float median_select(const float* __restrict__ row, si
     atomicAdd(&s_cnt, cnt);
     atomicMin(&s_min, mn);
     __syncthreads();
-    const unsigned b = (s_cnt > (unsigned)(n / 2)) ? a : s_min;
-    return 0.5f * (med_unkey(a) + med_unkey(b));
-}
-
-__global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict__ v, size_t n,
-                                                         float* __restrict__ med) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned ctl[4];
-    static_assert(kSpThreads == 256, "one histogram bin per thread");
-    const float m = median_select(v + (size_t)blockIdx.x * n, n, hist, ctl, threadIdx.x);
-    if (threadIdx.x == 0) med[blockIdx.x] = m;
+    if (tid == 0) {
+        const unsigned b = (s_cnt > (unsigned)(n / 2)) ? a : s_min;
+        med[blockIdx.x] = 0.5f * (med_unkey(a) + med_unkey(b));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -609,51 +604,6 @@ __global__ __launch_bounds__(kScTile) void spectro_corr(const float* __restrict_
         if (zero_ends && (t == 0 || t == nout - 1)) v = 0.f;
         if (v < 0.f) v = 0.f;                                        // NaN (0/0 on an all-zero row) passes through
         out[(size_t)blockIdx.y * nout + t] = v;
-    }
-}
-
-// The two launches above as ONE per channel when its sliced spectrogram fits a workgroup's LDS (13 bins x 1501 frames =
-// 78 KB for the detector's setting): S[c] is read from memory once, its median (np.median over the whole sliced
-// spectrogram, detect.py:600) and the correlation both run on the LDS copy.
-__global__ __launch_bounds__(kSpThreads) void spectro_corr_row(const float* __restrict__ S, int nf, int nt,
-                                                               const float* __restrict__ K, int nk, int off, int nout,
-                                                               int zero_ends, float* __restrict__ out) {
-    D4W_DYN_LDS(smem_raw);
-    __shared__ unsigned hist[256];
-    __shared__ unsigned ctl[4];
-    float* Sl = reinterpret_cast<float*>(smem_raw);                    // [nf][nt]
-    const int tid = threadIdx.x;
-    const size_t n = (size_t)nf * nt;
-    const float* Sc = S + (size_t)blockIdx.x * n;
-    if ((n & 3) == 0 && (reinterpret_cast<size_t>(Sc) & 15) == 0) {
-        const float4* g4 = reinterpret_cast<const float4*>(Sc);
-        float4* l4 = reinterpret_cast<float4*>(Sl);
-        for (size_t i = tid; i < n / 4; i += kSpThreads) l4[i] = g4[i];
-    } else {
-        for (size_t i = tid; i < n; i += kSpThreads) Sl[i] = Sc[i];
-    }
-    __syncthreads();
-    const float med = median_select(Sl, n, hist, ctl, tid);
-    const float denom = med * (float)nk;
-    for (int t = tid; t < nout; t += kSpThreads) {
-        float acc = 0.f;
-        const int s0 = t - off;
-        for (int f = 0; f < nf; ++f) {
-            const float* kr = K + (size_t)f * nk;
-            const float* sr = Sl + (size_t)f * nt;
-            if (s0 >= 0 && s0 + nk <= nt) {
-                for (int j = 0; j < nk; ++j) acc = fmaf(sr[s0 + j], kr[j], acc);
-            } else {
-                for (int j = 0; j < nk; ++j) {
-                    const int q = s0 + j;
-                    if (q >= 0 && q < nt) acc = fmaf(sr[q], kr[j], acc);
-                }
-            }
-        }
-        float v = acc / denom;
-        if (zero_ends && (t == 0 || t == nout - 1)) v = 0.f;
-        if (v < 0.f) v = 0.f;                                          // NaN (0/0 on an all-zero row) passes through
-        out[(size_t)blockIdx.x * nout + t] = v;
     }
 }
 
@@ -1173,15 +1123,8 @@ int d4w_row_median_f32(const float* v, int nx, size_t per_row, float* med, void*
 
 int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, int nk, int off, int nout,
                         const float* med, int zero_ends, float* out, void* stream) {
-    if (!S || !K || !out || nx < 1 || nf < 1 || nt < 1 || nk < 1 || nout < 1)
+    if (!S || !K || !med || !out || nx < 1 || nf < 1 || nt < 1 || nk < 1 || nout < 1)
         return fail(D4W_EINVAL, "bad argument");
-    if (!med) {                                                   // median formed in the same launch (row spectrogram in LDS)
-        const size_t lds = (size_t)nf * nt * sizeof(float);
-        if (lds > kSpLdsMax) return fail(D4W_EINVAL, "med is NULL and the row spectrogram (%zu bytes) exceeds the LDS tile: pass the medians", lds);
-        sp_allow_lds(spectro_corr_row, lds);
-        D4W_LAUNCH(spectro_corr_row, dim3(nx), dim3(kSpThreads), lds, stream, S, nf, nt, K, nk, off, nout, zero_ends, out);
-        return D4W_OK;
-    }
     if (nk > kScLdsFloats - kScTile) return fail(D4W_EINVAL, "kernel of %d frames is too long", nk);
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
     D4W_LAUNCH(spectro_corr, dim3(ceil_div(nout, kScTile), nx), dim3(kScTile), 0, stream, S, nf, nt, K, nk, off,

@@ -329,12 +329,11 @@ def _spectrocorr_device(S, K, off, nout, med=None, zero_ends=False):
     Kd = torch.from_numpy(K).to(S.device)
     out = torch.empty((nx, nout), dtype=torch.float32, device=S.device)
     with torch.cuda.device(S.device):
-        if med is None and nf * nt * 4 > 150 * 1024:          # row spectrogram too large for the one-launch form
+        if med is None:
             med = torch.empty(nx, dtype=torch.float32, device=S.device)
             check(lib.d4w_row_median_f32(dev.ptr(S), nx, nf * nt, dev.ptr(med), dev.stream_ptr(S)))   # detect.py:600
         check(lib.d4w_spectrocorr_f32(dev.ptr(S), nx, nf, nt, dev.ptr(Kd), K.shape[1], int(off), int(nout),
-                                      dev.ptr(med) if med is not None else None, int(bool(zero_ends)), dev.ptr(out),
-                                      dev.stream_ptr(S)))
+                                      dev.ptr(med), int(bool(zero_ends)), dev.ptr(out), dev.stream_ptr(S)))
         torch.cuda.current_stream().synchronize()               # Kd is a temporary
     return out
 

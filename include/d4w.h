@@ -327,8 +327,7 @@ int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream)
  *   raw[c][t] = sum_f sum_j S[c][f][t + j - off] K[f][j]  (zero outside the spectrogram), t < nout
  *   out[c][t] = max(raw, 0) / (med[c] * nk);  zero_ends != 0 also forces out[c][0] = out[c][nout-1] = 0.
  *   off = nk/2, nout = nt: detect.xcorr2d;  off = 0, nout = nt-nk+1, zero_ends: detect.xcorr.
- *   S [nx][nf][nt], K [nf][nk], med [nx], out [nx][nout], all DEVICE float32.  med = NULL: the median of S[c] (np.median
- *   over the whole sliced spectrogram, detect.py:600) is formed in the same launch -- S[c] must fit 150 KB of LDS.
+ *   S [nx][nf][nt], K [nf][nk], med [nx], out [nx][nout], all DEVICE float32.
  * ------------------------------------------------------------------------------------------ */
 int d4w_stft_frames(int ns, int hop);
 int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, int n_fft, int hop,
