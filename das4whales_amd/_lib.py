@@ -37,6 +37,8 @@ def _load():
         "d4w_fk_plan_info": (c_int, [c_void_p, P(c_int)]),
         "d4w_fk_set_mask_dense_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
         "d4w_fk_set_mask_dense_pruned_f32": (c_int, [c_void_p, c_void_p, ctypes.c_double, c_void_p]),
+        "d4w_fk_set_mask_design_f32": (c_int, [c_void_p, c_int, ctypes.c_double, ctypes.c_double, P(ctypes.c_double),
+                                               c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_fk_plan_live_rows": (c_int, [c_void_p]),
         "d4w_fk_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fk_apply_timed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(ctypes.c_float)]),
@@ -45,6 +47,8 @@ def _load():
         "d4w_fkd_plan_info": (c_int, [c_void_p, P(c_int)]),
         "d4w_fkd_plan_q1_owner": (c_int, [c_void_p, P(c_int)]),
         "d4w_fkd_set_mask_dense_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
+        "d4w_fkd_set_mask_design_f32": (c_int, [c_void_p, c_int, ctypes.c_double, ctypes.c_double, P(ctypes.c_double),
+                                                c_int, c_int, c_void_p, c_void_p]),
         "d4w_fkd_time_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fkd_chan_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
         "d4w_fkd_time_inv_f32": (c_int, [c_void_p, c_void_p, c_void_p]),

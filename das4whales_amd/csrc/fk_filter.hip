@@ -28,6 +28,7 @@
 #include "fft_host.h"
 
 #include "fk_entry.h"
+#include "design_eval.h"
 
 namespace d4w {
 
@@ -482,6 +483,39 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int f = d.M, fm = d.ns - d.M;
         const float v = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+        nyq[r] = v;
+        vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
+    }
+    if (vbits) atomicMax(rowmaxbits + r, vbits);
+}
+
+// The same fold with the mask evaluated in closed form (design_eval.h) instead of read: a reference design goes
+// straight into pass-B order and no dense [nx][ns] mask exists (9.6 GB at 20 000 x 120 000).  Each of the two
+// values is rounded to float32 before the average exactly as the dense design kernel stores it, so the folded
+// mask is bit-identical to design + fold.
+__global__ __launch_bounds__(kThreads) void fk_fold_design(FkDims d, DesignArgs A, int mode,
+                                                            const int* __restrict__ rowk,
+                                                            const int* __restrict__ k1_of_q1,
+                                                            const int* __restrict__ k2_of_i,
+                                                            float* __restrict__ mask,
+                                                            float* __restrict__ nyq, unsigned* __restrict__ rowmaxbits) {
+    const int r = blockIdx.y;
+    const int k = rowk[r];
+    const int km = (d.nx - k) % d.nx;
+    const int sx = d.nx / 2, st = d.ns / 2;
+    const int ip = (k + sx) % d.nx, im = (km + sx) % d.nx;
+    unsigned vbits = 0u;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < d.M; p += gridDim.x * blockDim.x) {
+        const int q1 = p / d.N2, i = p - q1 * d.N2;
+        const int f = k1_of_q1[q1] + d.N1 * k2_of_i[i];
+        const int fm = (d.ns - f) % d.ns;
+        const float v = 0.5f * ((float)design_value(A, mode, ip, (f + st) % d.ns) + (float)design_value(A, mode, im, (fm + st) % d.ns));
+        mask[(size_t)r * d.M + p] = v;
+        vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int f = d.M, fm = d.ns - d.M;
+        const float v = 0.5f * ((float)design_value(A, mode, ip, (f + st) % d.ns) + (float)design_value(A, mode, im, (fm + st) % d.ns));
         nyq[r] = v;
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
@@ -1120,6 +1154,8 @@ int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
     return D4W_OK;
 }
 
+static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream);
+
 static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
     if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
@@ -1143,6 +1179,13 @@ static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double p
         D4W_LAUNCH(fk_fold_mask, grid, dim3(kThreads), 0, stream, d, mask_shifted, (const int*)pl->d_rowk,
                    (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, pl->d_rowmax);
     }
+    return fk_mask_finish(pl, prune_eps, stream);
+}
+
+// after a fold (d_mask, d_nyq, d_rowmax written on `stream`): liveness of the wavenumber rows
+static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
+    const FkDims& d = pl->dev.d;
+    hipStream_t st = (hipStream_t)stream;
     pl->has_mask = true;
     pl->prune_eps = prune_eps;
     pl->npairs_run = pl->npairs;
@@ -1207,6 +1250,23 @@ int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* 
 
 int d4w_fk_set_mask_dense_pruned_f32(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
     return fk_set_mask_impl(pl, mask_shifted, prune_eps, stream);
+}
+
+int d4w_fk_set_mask_design_f32(d4w_fk_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
+                               int i0, int i1, const double* hrow_dev, double prune_eps, void* stream) {
+    if (!pl || !params8_host || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
+    if (mode < 0 || mode > 2)
+        return fail(D4W_EINVAL, "mode %d has no closed form (the Gaussian-blurred designs go through d4w_design_mask_f32)", mode);
+    if (mode == 2 && !hrow_dev) return fail(D4W_EINVAL, "hybrid_ninf needs the |H|^2 row");
+    if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
+    const FkDims& d = pl->dev.d;
+    if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
+    D4W_HIP(hipMemsetAsync(pl->d_rowmax, 0, (size_t)d.nx * sizeof(unsigned), (hipStream_t)stream));
+    const DesignArgs A = make_design_args(d.nx, d.ns, k_spacing, t_spacing, params8_host, i0, i1, hrow_dev);
+    dim3 grid(std::min(ceil_div(d.M, kThreads), 64), d.nx);
+    D4W_LAUNCH(fk_fold_design, grid, dim3(kThreads), 0, stream, d, A, mode, (const int*)pl->d_rowk, (const int*)pl->d_k1,
+               (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, pl->d_rowmax);
+    return fk_mask_finish(pl, prune_eps, stream);
 }
 
 int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
@@ -1516,6 +1576,37 @@ __global__ __launch_bounds__(kThreads) void fkd_fold_mask(int nx, int ns, int N1
     if (blockIdx.x == 0 && threadIdx.x == 0)
         nyq[r] = 0.5f * (ms[rowp + (M + st) % ns] + ms[rowm + ((ns - M) + st) % ns]);
 }
+
+// ... evaluated in closed form instead of read (fk_fold_design restricted to a q1 subset): a rank never holds the
+// dense mask, only the gains of the sub-rows it owns
+__global__ __launch_bounds__(kThreads) void fkd_fold_design(int nx, int ns, int N1, int N2, int nq, DesignArgs A, int mode,
+                                                             const int* __restrict__ rowk,
+                                                             const int* __restrict__ q1_of,
+                                                             const int* __restrict__ k1_of_q1,
+                                                             const int* __restrict__ k2_of_i,
+                                                             float* __restrict__ mask, float* __restrict__ nyq) {
+    const int r = blockIdx.y;
+    const int k = rowk[r];
+    const int km = (nx - k) % nx;
+    const int sx = nx / 2, st = ns / 2, M = ns / 2;
+    const int ip = (k + sx) % nx, im = (km + sx) % nx;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nq * N2; p += gridDim.x * blockDim.x) {
+        const int jq = p / N2, i = p - jq * N2;
+        const int f = k1_of_q1[q1_of[jq]] + N1 * k2_of_i[i];
+        const int fm = (ns - f) % ns;
+        mask[(size_t)r * nq * N2 + p] =
+            0.5f * ((float)design_value(A, mode, ip, (f + st) % ns) + (float)design_value(A, mode, im, (fm + st) % ns));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        nyq[r] = 0.5f * ((float)design_value(A, mode, ip, (M + st) % ns) + (float)design_value(A, mode, im, ((ns - M) + st) % ns));
+}
+
+// where a distributed plan's mask comes from: a dense shifted-grid mask, or a closed-form design
+struct FkdMaskSrc {
+    const float* dense = nullptr;
+    DesignArgs A{};
+    int mode = -1;
+};
 
 }  // namespace d4w
 
@@ -1873,7 +1964,18 @@ int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* pl, int* owner) {
     return D4W_OK;
 }
 
-static int fkd_set_mask_packed(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
+static int fkd_launch_fold(const FkdMaskSrc& src, int nx, int ns, int N1, int N2, int nq, const int* rowk, const int* q1of,
+                           const int* k1, const int* k2, float* mask, float* nyq, void* stream) {
+    dim3 grid(std::min(ceil_div(nq * N2, kThreads), 64), nx);
+    if (src.dense)
+        D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, nx, ns, N1, N2, nq, src.dense, rowk, q1of, k1, k2, mask, nyq);
+    else
+        D4W_LAUNCH(fkd_fold_design, grid, dim3(kThreads), 0, stream, nx, ns, N1, N2, nq, src.A, src.mode, rowk, q1of, k1, k2,
+                   mask, nyq);
+    return D4W_OK;
+}
+
+static int fkd_set_mask_packed(d4w_fkd_plan* pl, const FkdMaskSrc& src, void* stream) {
     d4w_fk_plan* sp = pl->sp;
     const FkDims& d = sp->dev.d;
     const int nq = (int)pl->myq.size();
@@ -1885,10 +1987,9 @@ static int fkd_set_mask_packed(d4w_fkd_plan* pl, const float* mask_shifted, void
     pl->live_rows = d.nx;
     if (nq == 0) return D4W_OK;
     const int W = nq * d.N2;
-    dim3 grid(std::min(ceil_div(W, kThreads), 64), d.nx);
-    D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, d.nx, d.ns, d.N1, d.N2, nq, mask_shifted,
-               (const int*)sp->d_rowk, (const int*)pl->d_q1of, (const int*)sp->d_k1, (const int*)sp->d_k2,
-               pl->d_mask, pl->d_nyq);
+    if (int rc = fkd_launch_fold(src, d.nx, d.ns, d.N1, d.N2, nq, (const int*)sp->d_rowk, (const int*)pl->d_q1of,
+                                 (const int*)sp->d_k1, (const int*)sp->d_k2, pl->d_mask, pl->d_nyq, stream))
+        return rc;
     const char* np = getenv("D4W_FK_NOPRUNE");
     if (np && atoi(np) > 0) return D4W_OK;
     // rows whose gains are all zero in the owned sub-rows (and whose Hermitian partner's are): skipped by passes
@@ -1933,18 +2034,35 @@ static int fkd_set_mask_packed(d4w_fkd_plan* pl, const float* mask_shifted, void
 
 int d4w_fkd_plan_is_packed(const d4w_fkd_plan* pl) { return (pl && pl->sp) ? 1 : 0; }
 
-int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
-    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
-    if (pl->sp) return fkd_set_mask_packed(pl, mask_shifted, stream);
+static int fkd_set_mask_src(d4w_fkd_plan* pl, const FkdMaskSrc& src, void* stream) {
+    if (pl->nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", pl->nx);
+    if (pl->sp) return fkd_set_mask_packed(pl, src, stream);
     const int nq = (int)pl->myq.size();
-    if (nq > 0) {
-        dim3 grid(std::min(ceil_div(nq * pl->N2, kThreads), 64), pl->nx);
-        D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, pl->nx, pl->ns, pl->N1, pl->N2, nq, mask_shifted,
-                   (const int*)pl->d_rowk, (const int*)pl->d_q1of, (const int*)pl->d_k1, (const int*)pl->d_k2,
-                   pl->d_mask, pl->d_nyq);
-    }
+    if (nq > 0)
+        if (int rc = fkd_launch_fold(src, pl->nx, pl->ns, pl->N1, pl->N2, nq, (const int*)pl->d_rowk, (const int*)pl->d_q1of,
+                                     (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, stream))
+            return rc;
     pl->has_mask = true;
     return D4W_OK;
+}
+
+int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void* stream) {
+    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
+    FkdMaskSrc src;
+    src.dense = mask_shifted;
+    return fkd_set_mask_src(pl, src, stream);
+}
+
+int d4w_fkd_set_mask_design_f32(d4w_fkd_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
+                                int i0, int i1, const double* hrow_dev, void* stream) {
+    if (!pl || !params8_host || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
+    if (mode < 0 || mode > 2)
+        return fail(D4W_EINVAL, "mode %d has no closed form (the Gaussian-blurred designs go through d4w_design_mask_f32)", mode);
+    if (mode == 2 && !hrow_dev) return fail(D4W_EINVAL, "hybrid_ninf needs the |H|^2 row");
+    FkdMaskSrc src;
+    src.A = make_design_args(pl->nx, pl->ns, k_spacing, t_spacing, params8_host, i0, i1, hrow_dev);
+    src.mode = mode;
+    return fkd_set_mask_src(pl, src, stream);
 }
 
 /* packed path: x_loc [nxl][ns] -> packed [dest rank][nxl][nq(dest)][N2] complex (what the all-to-all sends) */

@@ -47,6 +47,8 @@ class FkPlan:
         prune_eps > 0 (opt-in, not exact): wavenumber rows whose folded gains stay below
         prune_eps * max are skipped like all-zero rows (include/d4w.h d4w_fk_set_mask_dense_pruned_f32)."""
         m = fk_filter_matrix
+        if isinstance(m, DesignedMask):
+            return self._set_mask_design(m, prune_eps)
         if isinstance(m, DeviceMask):
             m = m.tensor
         # Only objects that carry a modification counter are cached (torch tensors, hence DeviceMask): a NumPy
@@ -71,6 +73,22 @@ class FkPlan:
         if key is not None:
             self._mask_ref = weakref.ref(m)
             self._mask_key = key
+
+    def _set_mask_design(self, m, prune_eps):
+        """A closed-form design (immutable) straight into the plan -- no dense mask."""
+        key = (id(m), "design", float(prune_eps))
+        if self._mask_key == key and self._mask_ref is not None and self._mask_ref() is m:
+            return
+        self._mask_ref, self._mask_key = None, None
+        if m.shape != (self.nx, self.ns):
+            raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s" % (self.nx, self.ns, m.shape))
+        h = m.hrow_on(self.device)
+        p8 = (ctypes.c_double * 8)(*m.params)
+        with torch.cuda.device(self.device):
+            check(lib.d4w_fk_set_mask_design_f32(self._h, m.mode, m.k_spacing, m.t_spacing, p8, m.i0, m.i1,
+                                                 dev.ptr(h) if h is not None else None, float(prune_eps),
+                                                 torch.cuda.current_stream(self.device).cuda_stream))
+        self._mask_ref, self._mask_key = weakref.ref(m), key
 
     def apply(self, x, out=None, taper=False):
         """x: float32 CUDA tensor [nx, ns]; returns the filtered tensor (out may alias x)."""
@@ -458,10 +476,14 @@ class DeviceMask:
     tools.py:248), and `np.asarray(mask)` (the dense ndarray fk_filter_design returns)."""
 
     def __init__(self, tensor):
-        self.tensor = tensor
+        self._tensor = tensor
         self.shape = tuple(tensor.shape)
         self.ndim = 2
         self.dtype = np.dtype(np.float64)
+
+    @property
+    def tensor(self):
+        return self._tensor
 
     def todense(self):
         return self.tensor.cpu().numpy().astype(np.float64)
@@ -478,6 +500,51 @@ class DeviceMask:
     @property
     def nnz(self):
         return int(torch.count_nonzero(self.tensor))
+
+
+class DesignedMask(DeviceMask):
+    """What fk_filter_design / hybrid_filter_design / hybrid_ninf_filter_design return: the closed-form design itself.
+
+    fk_filter_filt / fk_filter_sparsefilt write it straight into the plan's folded pass-B order
+    (d4w_fk_set_mask_design_f32) -- bit-identical to folding the dense mask, which is never formed
+    (9.6 GB at 20 000 x 120 000).  The dense [nx, ns] tensor is built on first use of `.tensor`,
+    `np.asarray(mask)`, `.todense()`, `.data` or `.nnz`, on the device current at that moment."""
+
+    def __init__(self, mode, trace_shape, k_spacing, t_spacing, params, i0=0, i1=0, hrow=None):
+        self.mode = int(mode)
+        self.shape = (int(trace_shape[0]), int(trace_shape[1]))
+        self.ndim = 2
+        self.dtype = np.dtype(np.float64)
+        self.k_spacing, self.t_spacing = float(k_spacing), float(t_spacing)
+        self.params = [float(v) for v in params] + [0.0] * (8 - len(params))
+        self.i0, self.i1 = int(i0), int(i1)
+        self.hrow = None if hrow is None else np.ascontiguousarray(hrow, dtype=np.float64)
+        self._tensor = None
+        self._hrow_dev = {}
+
+    def hrow_on(self, device):
+        """The |H|^2 row of hybrid_ninf as a float64 tensor on `device` (None for the other designs)."""
+        if self.hrow is None:
+            return None
+        key = str(device)
+        if key not in self._hrow_dev:
+            self._hrow_dev[key] = torch.from_numpy(self.hrow).to(device)
+        return self._hrow_dev[key]
+
+    @property
+    def tensor(self):
+        if self._tensor is None:
+            dev.require_gpu()
+            device = torch.device("cuda:%d" % torch.cuda.current_device())
+            out = torch.empty(self.shape, dtype=torch.float32, device=device)
+            p8 = (ctypes.c_double * 8)(*self.params)
+            h = self.hrow_on(device)
+            with torch.cuda.device(device):
+                check(lib.d4w_design_mask_f32(self.mode, self.shape[0], self.shape[1], self.k_spacing, self.t_spacing, p8,
+                                              self.i0, self.i1, dev.ptr(h) if h is not None else None, dev.ptr(out),
+                                              dev.stream_ptr(out)))
+            self._tensor = out
+        return self._tensor
 
 
 def _shifted_axis(n, d):
@@ -516,8 +583,9 @@ def _first_index_ge(f, val):
 
 def fk_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400, cp_min=1450, cp_max=3400, cs_max=3500):
     """Classic speed fan with sine tapers -- reference dsp.py:85-171.  Returns a DeviceMask
-    (np.asarray(mask) gives the dense array; the reference returns a Fortran-ordered ndarray)."""
-    return DeviceMask(_design(0, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, cp_max, cs_max]))
+    (np.asarray(mask) gives the dense array; the reference returns a Fortran-ordered ndarray); the dense grid is only
+    built if asked for -- the filter functions take the closed form (DesignedMask)."""
+    return DesignedMask(0, trace_shape, selected_channels[2] * dx, 1.0 / float(fs), [cs_min, cp_min, cp_max, cs_max])
 
 
 def hybrid_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., fmin=15., fmax=25.,
@@ -526,7 +594,7 @@ def hybrid_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., c
     a plotting path of the reference and is ignored)."""
     f = _shifted_axis(trace_shape[1], 1.0 / fs)
     i0, i1 = _first_index_ge(f, fmin - 4.0), _first_index_ge(f, fmax + 4.0)     # dsp.py:216-222
-    return DeviceMask(_design(1, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, fmin, fmax], i0, i1))
+    return DesignedMask(1, trace_shape, selected_channels[2] * dx, 1.0 / float(fs), [cs_min, cp_min, fmin, fmax], i0, i1)
 
 
 def hybrid_ninf_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., cp_max=3400,
@@ -541,7 +609,7 @@ def hybrid_ninf_filter_design(trace_shape, selected_channels, dx, fs, cs_min=140
     b, a = sp.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp")               # dsp.py:348
     H = np.concatenate((np.zeros(ns // 2), np.abs(sp.freqz(b, a, worN=ns // 2)[1]) ** 2))   # dsp.py:349
     i0, i1 = _first_index_ge(f, fmin - 14.0), _first_index_ge(f, fmax + 14.0)   # dsp.py:354-360
-    return DeviceMask(_design(2, trace_shape, selected_channels, dx, fs, [cs_min, cp_min, cp_max, cs_max], i0, i1, H))
+    return DesignedMask(2, trace_shape, selected_channels[2] * dx, 1.0 / float(fs), [cs_min, cp_min, cp_max, cs_max], i0, i1, H)
 
 
 def hybrid_gs_filter_design(trace_shape, selected_channels, dx, fs, cs_min=1400., cp_min=1450., fmin=15., fmax=25.,

@@ -76,6 +76,7 @@ class ShardedFkPlan:
         import ctypes
         self._ct = ctypes
         self.lib, self.check = native if native is not None else _native()
+        self._emulated = native is not None
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self._h = ctypes.c_void_p()
@@ -93,10 +94,24 @@ class ShardedFkPlan:
 
     def set_mask(self, mask):
         """mask: dense float32 [nx, ns] tensor on this rank's device, fftshift-ed grid (what the
-        reference designers return; every rank designs or loads the same mask)."""
+        reference designers return; every rank designs or loads the same mask), or the closed-form
+        dsp.DesignedMask that fk_filter_design / hybrid_filter_design / hybrid_ninf_filter_design return --
+        then every rank evaluates only the gains of the sub-rows it owns and no dense mask exists anywhere."""
         if tuple(mask.shape) != (self.nx, self.ns):
             raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s"
                              % (self.nx, self.ns, tuple(mask.shape)))
+        if hasattr(mask, "hrow_on"):
+            ct = self._ct
+            device = torch.device("cpu") if self._emulated else torch.device("cuda", torch.cuda.current_device())
+            h = mask.hrow_on(device)
+            p8 = (ct.c_double * 8)(*mask.params)
+            self.check(self.lib.d4w_fkd_set_mask_design_f32(
+                self._h, ct.c_int(mask.mode), ct.c_double(mask.k_spacing), ct.c_double(mask.t_spacing), p8, ct.c_int(mask.i0),
+                ct.c_int(mask.i1), ct.c_void_p(h.data_ptr()) if h is not None else None,
+                ct.c_void_p(None if self._emulated else torch.cuda.current_stream(device).cuda_stream)))
+            if not self._emulated:
+                torch.cuda.current_stream(device).synchronize()
+            return
         m = mask.to(torch.float32).contiguous()
         self.check(self.lib.d4w_fkd_set_mask_dense_f32(self._h, m.data_ptr(), _sptr(m)))
         if m.is_cuda:
@@ -308,11 +323,14 @@ def fk_filter_sharded(x_loc, fk_filter_matrix, nx_total, tapering=False, gather=
     when gather=True (north star: RCCL all-gather of the t-x output)."""
     if plan is None:
         plan = ShardedFkPlan(nx_total, x_loc.shape[1], group=group)
-        m = fk_filter_matrix.tensor if hasattr(fk_filter_matrix, "tensor") else fk_filter_matrix
-        if not isinstance(m, torch.Tensor):
-            import numpy as np
-            m = torch.from_numpy(np.ascontiguousarray(np.asarray(m.todense() if hasattr(m, "todense") else m),
-                                                      dtype=np.float32))
-        plan.set_mask(m.to(x_loc.device))
+        if hasattr(fk_filter_matrix, "hrow_on"):          # closed-form design: straight into the plan
+            plan.set_mask(fk_filter_matrix)
+        else:
+            m = fk_filter_matrix.tensor if hasattr(fk_filter_matrix, "tensor") else fk_filter_matrix
+            if not isinstance(m, torch.Tensor):
+                import numpy as np
+                m = torch.from_numpy(np.ascontiguousarray(np.asarray(m.todense() if hasattr(m, "todense") else m),
+                                                          dtype=np.float32))
+            plan.set_mask(m.to(x_loc.device))
     y = plan.apply(x_loc, taper=tapering)
     return all_gather_rows(y, nx_total, group=group) if gather else y

@@ -71,6 +71,16 @@ int d4w_fk_set_mask_dense_f32(d4w_fk_plan* plan, const float* mask_shifted, void
  * all formally alive; prune_eps = 4e-6 keeps only the rows the speed band touches.  Not exact: the
  * output changes by at most the pruned gain times the input's energy in those bins.  0 = exact. */
 int d4w_fk_set_mask_dense_pruned_f32(d4w_fk_plan* plan, const float* mask_shifted, double prune_eps, void* stream);
+/* A reference design written straight into the plan, with no dense mask in between: what
+ * d4w_design_mask_f32(mode, ...) followed by d4w_fk_set_mask_dense_pruned_f32 leaves in the plan, bit for bit
+ * (same closed forms, same float32 rounding before the fold), for the three designs that have a closed
+ * form -- mode 0 dsp.fk_filter_design (dsp.py:85-171), 1 dsp.hybrid_filter_design (dsp.py:174-305),
+ * 2 dsp.hybrid_ninf_filter_design (dsp.py:308-454); arguments as d4w_design_mask_f32 below.  The Gaussian-blurred
+ * designs (modes 3-5) need the dense grid and are refused.  Saves the nx*ns*4-byte mask (9.6 GB at
+ * 20 000 x 120 000) and its write + read.  Synchronises `stream`. */
+int d4w_fk_set_mask_design_f32(d4w_fk_plan* plan, int mode, double k_spacing, double t_spacing,
+                               const double* params8_host, int i0, int i1, const double* hrow_dev,
+                               double prune_eps, void* stream);
 
 /* Number of wavenumber rows (0..nx) the current mask keeps alive.  A row whose folded mask -- and
  * whose Hermitian partner's -- is identically zero is multiplied by zero whatever it holds; the
@@ -140,6 +150,10 @@ int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* plan, int* owner_host /* [N1] */);
 /* mask: the full dense [nx][ns] float32 mask on the fftshift-ed grid (as d4w_fk_set_mask_dense_f32);
  * only the owned sub-rows are folded and kept */
 int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* plan, const float* mask_shifted, void* stream);
+/* the closed-form designs straight into the plan (see d4w_fk_set_mask_design_f32): a rank evaluates only the
+ * gains of the sub-rows it owns, so no rank ever holds the dense mask.  Bit-identical to the dense route. */
+int d4w_fkd_set_mask_design_f32(d4w_fkd_plan* plan, int mode, double k_spacing, double t_spacing,
+                                const double* params8_host, int i0, int i1, const double* hrow_dev, void* stream);
 int d4w_fkd_time_fwd_f32(d4w_fkd_plan* plan, const float* x_loc, float* z_loc, int taper, void* stream);
 int d4w_fkd_chan_apply_f32(d4w_fkd_plan* plan, float* slab, void* stream);
 int d4w_fkd_time_inv_f32(d4w_fkd_plan* plan, float* z_loc, void* stream);

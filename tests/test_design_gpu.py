@@ -59,3 +59,40 @@ def test_designs_config1_shape_vs_oracle(dw):
     del m, ref
     mc = dw.dsp.fk_filter_design(shape, sel, dx, fs).todense()
     assert np.max(np.abs(mc - orc.fk_filter_design(shape, sel, dx, fs))) < 1e-6
+
+
+def test_design_goes_into_the_plan_without_a_dense_mask(dw):
+    """BASELINE configs[3] block: fk_filter_design / hybrid_ninf_filter_design return the closed form (DesignedMask);
+    the filter folds it straight into the plan.  No 9.6 GB mask is allocated, and the result is bit-identical to
+    designing the dense mask and folding that."""
+    import time
+    nx, ns, dx, fs = 20000, 120000, 2.0419046878814697, 200.0
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((nx, ns), device="cuda", generator=gen)
+    plan = dw.dsp.get_fk_plan(nx, ns)
+    for name, mk, eps in (("classic", lambda: dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs), 0.0),
+                          ("hybrid_ninf", lambda: dw.dsp.hybrid_ninf_filter_design((nx, ns), [0, nx, 1], dx, fs, **ARGS), 0.0),
+                          ("hybrid_ninf pruned", lambda: dw.dsp.hybrid_ninf_filter_design((nx, ns), [0, nx, 1], dx, fs, **ARGS), 4e-6)):
+        m = mk()
+        assert isinstance(m, dw.dsp.DesignedMask) and m._tensor is None
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        t0 = time.perf_counter()
+        plan.set_mask(m, prune_eps=eps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        assert m._tensor is None                                           # still no dense mask
+        assert torch.cuda.max_memory_allocated() - base < 64 << 20
+        live = plan.live_rows()
+        y = plan.apply(x)
+        dense = m.tensor                                                   # now materialise it (9.6 GB) and fold that
+        t0 = time.perf_counter()
+        plan.set_mask(dense, prune_eps=eps)
+        torch.cuda.synchronize()
+        ms_dense = (time.perf_counter() - t0) * 1e3
+        assert plan.live_rows() == live
+        y2 = plan.apply(x)
+        assert torch.equal(y, y2), name
+        print("%s: design -> plan %.1f ms (dense mask -> plan %.1f ms), %d live rows" % (name, ms, ms_dense, live))
+        del y, y2, dense, m

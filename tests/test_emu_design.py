@@ -77,3 +77,52 @@ def test_gaussian_and_normalise(emu):
     ref = (x - x.min()) / (x.max() - x.min())
     assert emu.d4w_minmax_normalise_f32(vp(x), x.size, None) == 0
     assert np.max(np.abs(x - ref)) < 1e-6
+
+
+@pytest.mark.parametrize("nx,ns,opts", [(40, 480, None), (18, 48, None), (38, 406, [19, 2, 7, 29, 4, 4]), (100, 600, None),
+                                        (7, 14, None)])
+def test_design_folded_straight_into_the_plan(emu, nx, ns, opts):
+    """d4w_fk_set_mask_design_f32 (closed form evaluated in pass-B order, no dense mask) leaves exactly what
+    d4w_design_mask_f32 + d4w_fk_set_mask_dense_f32 leave: the filtered blocks agree bit for bit, the liveness too."""
+    emu.d4w_fk_set_mask_design_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+    emu.d4w_fk_set_mask_dense_pruned_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+    fs, step = 200.0, 2.0419046878814697
+    f = np.fft.fftshift(np.fft.fftfreq(ns, d=1 / fs))
+    A = ARGS
+    b, a = sps.butter(8, [A["fmin"] / (fs / 2), A["fmax"] / (fs / 2)], "bp")
+    H = np.concatenate((np.zeros(ns // 2), np.abs(sps.freqz(b, a, worN=ns // 2)[1]) ** 2))
+    cases = [(0, [1400, 1450, 3400, 3500], 0, 0, None, 0.0),
+             (1, [A["cs_min"], A["cp_min"], A["fmin"], A["fmax"]], first_ge(f, A["fmin"] - 4), first_ge(f, A["fmax"] + 4), None, 0.0),
+             (2, [A["cs_min"], A["cp_min"], A["cp_max"], A["cs_max"]], first_ge(f, A["fmin"] - 14), first_ge(f, A["fmax"] + 14), H, 0.0),
+             (2, [A["cs_min"], A["cp_min"], A["cp_max"], A["cs_max"]], first_ge(f, A["fmin"] - 14), first_ge(f, A["fmax"] + 14), H, 4e-6)]
+    x = np.random.default_rng(nx * ns).standard_normal((nx, ns)).astype(np.float32)
+    o = (ctypes.c_int * 6)(*opts) if opts else None
+    for mode, params, i0, i1, hrow, eps in cases:
+        dense = design(emu, mode, (nx, ns), step, fs, params, i0, i1, hrow)
+        p8 = np.zeros(8)
+        p8[:len(params)] = params
+        h = np.ascontiguousarray(hrow, dtype=np.float64) if hrow is not None else None
+        ys, live = [], []
+        for analytic in (False, True):
+            plan = ctypes.c_void_p()
+            assert emu.d4w_fk_plan_create_ex(nx, ns, o, ctypes.byref(plan)) == 0, emu.d4w_last_error()
+            if analytic:
+                rc = emu.d4w_fk_set_mask_design_f32(plan, mode, step, 1.0 / fs, vp(p8), i0, i1, vp(h) if h is not None else None,
+                                                    eps, None)
+            else:
+                rc = emu.d4w_fk_set_mask_dense_pruned_f32(plan, vp(dense), eps, None)
+            assert rc == 0, emu.d4w_last_error()
+            y = np.empty_like(x)
+            assert emu.d4w_fk_apply_f32(plan, vp(x), vp(y), 0, None) == 0, emu.d4w_last_error()
+            live.append(emu.d4w_fk_plan_live_rows(plan))
+            emu.d4w_fk_plan_destroy(plan)
+            ys.append(y)
+        assert np.array_equal(ys[0], ys[1]), (mode, eps)
+        assert live[0] == live[1]
+    plan = ctypes.c_void_p()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+    p8 = np.zeros(8)
+    assert emu.d4w_fk_set_mask_design_f32(plan, 3, step, 1.0 / fs, vp(p8), 0, 0, None, 0.0, None) != 0    # blurred designs: refused
+    assert b"closed form" in emu.d4w_last_error()
+    emu.d4w_fk_plan_destroy(plan)

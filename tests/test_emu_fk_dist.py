@@ -38,7 +38,7 @@ class Rank:
         self.lib.d4w_fkd_plan_destroy(self.h)
 
 
-def fk_sharded_emu(lib, x, mask, world, taper=False):
+def fk_sharded_emu(lib, x, mask, world, taper=False, setter=None):
     nx, ns = x.shape
     M = ns // 2
     ranks = [Rank(lib, nx, ns, world, r) for r in range(world)]
@@ -51,7 +51,10 @@ def fk_sharded_emu(lib, x, mask, world, taper=False):
     xf = np.ascontiguousarray(x, dtype=np.float32)
     z = []
     for rk in ranks:
-        assert lib.d4w_fkd_set_mask_dense_f32(rk.h, vp(mf), None) == 0
+        if setter is not None:
+            setter(rk)
+        else:
+            assert lib.d4w_fkd_set_mask_dense_f32(rk.h, vp(mf), None) == 0
         xl = np.ascontiguousarray(xf[rk.a:rk.b])
         zl = np.empty((rk.b - rk.a, N1, N2, 2), dtype=np.float32)
         assert lib.d4w_fkd_time_fwd_f32(rk.h, vp(xl), vp(zl), int(taper), None) == 0, lib.d4w_last_error()
@@ -191,3 +194,23 @@ def test_dist_packed_specialised_shapes(emu, nx, ns, world):
     ks = np.fft.fftshift(np.arange(nx))
     m[np.minimum(ks, nx - ks) > nx // 4, :] = 0.0            # dead rows: pruned per rank
     assert rel(fk_sharded_packed_emu(emu, x, m, world, taper=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_dist_design_straight_into_the_plans(emu, world):
+    """Generic (unpacked) distributed plan: d4w_fkd_set_mask_design_f32 == design the dense mask + fold it, bit for bit."""
+    cd, ci, cv = ctypes.c_double, ctypes.c_int, ctypes.c_void_p
+    emu.d4w_design_mask_f32.argtypes = [ci, ci, ci, cd, cd, cv, ci, ci, cv, cv, cv]
+    emu.d4w_fkd_set_mask_design_f32.argtypes = [cv, ci, cd, cd, cv, ci, ci, cv, cv]
+    nx, ns, fs, step = 40, 480, 200.0, 2.0419046878814697
+    x = np.random.default_rng(3).standard_normal((nx, ns))
+    p8 = np.array([1400., 1450., 3400., 3500., 0., 0., 0., 0.])
+    dense = np.empty((nx, ns), dtype=np.float32)
+    assert emu.d4w_design_mask_f32(0, nx, ns, step, 1.0 / fs, vp(p8), 0, 0, None, vp(dense), None) == 0
+
+    def setter(rk):
+        assert emu.d4w_fkd_set_mask_design_f32(rk.h, 0, step, 1.0 / fs, vp(p8), 0, 0, None, None) == 0, emu.d4w_last_error()
+    y_design = fk_sharded_emu(emu, x, None, world, setter=setter)
+    y_dense = fk_sharded_emu(emu, x, dense, world)
+    assert np.array_equal(y_design, y_dense)
+    assert rel(y_design, orc.fk_filter_filt(x, dense.astype(np.float64))) < TOL

@@ -85,8 +85,11 @@ def test_sharded_bench_shape_identity(pg):
     # the classic fan (dead wavenumber rows pruned per rank) against the single-device five-pass plan
     import das4whales_amd as dw
     fan = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419046878814697, 200.0)
-    plan.set_mask(fan.tensor)
+    plan.set_mask(fan)                        # the closed form straight into the plan (no dense mask)
+    assert fan._tensor is None
     y = plan.apply(x, taper=True)
+    plan.set_mask(fan.tensor)                 # ... and folded from the dense mask: bit-identical
+    assert torch.equal(plan.apply(x, taper=True), y)
     y1 = dw.dsp.fk_filter_filt(x, fan, tapering=True)
     err = float((y - y1).abs().max()) / float(y1.abs().max())
     print("sharded (packed) vs single-device 20000x120000, classic fan + taper: %.3e" % err)

@@ -195,6 +195,36 @@ def _fk_packed_worker(rank, world, port, q):
             res["chunks%d" % chunks] = float(np.max(np.abs(y.numpy() - ref[a:b])) / np.max(np.abs(ref)))
         y_all = shard.fk_filter_sharded(xl, None, nx, tapering=True, gather=True, plan=plan)
         res["gathered"] = float(np.max(np.abs(y_all.numpy() - ref)) / np.max(np.abs(ref)))
+        # a closed-form design evaluated per rank for the sub-rows it owns (no dense mask on any rank) is bit-identical
+        # to designing the dense mask and folding it
+        import scipy.signal as sps
+        cd = ctypes.c_double
+        emu.d4w_design_mask_f32.argtypes = [ci, ci, ci, cd, cd, vp_, ci, ci, vp_, vp_, vp_]
+        emu.d4w_fkd_set_mask_design_f32.argtypes = [vp_, ci, cd, cd, vp_, ci, ci, vp_, vp_]
+        fs, step = 200.0, 2.0419046878814697
+        f = np.fft.fftshift(np.fft.fftfreq(ns, d=1 / fs))
+        bb, aa = sps.butter(8, [14. / (fs / 2), 30. / (fs / 2)], "bp")
+
+        class Design:                                      # duck type of das4whales_amd.dsp.DesignedMask
+            shape, mode, k_spacing, t_spacing = (nx, ns), 2, step, 1.0 / fs
+            params = [1350., 1450., 3300., 3450., 0., 0., 0., 0.]
+            i0, i1 = int(np.argmax(f >= 0.)), int(np.argmax(f >= 44.))
+            hrow = torch.from_numpy(np.concatenate((np.zeros(ns // 2), np.abs(sps.freqz(bb, aa, worN=ns // 2)[1]) ** 2)))
+
+            def hrow_on(self, device):
+                return self.hrow
+        dmask = Design()
+        dense = np.empty((nx, ns), dtype=np.float32)
+        p8 = np.array(dmask.params)
+        check(emu.d4w_design_mask_f32(2, nx, ns, step, 1.0 / fs, p8.ctypes.data, dmask.i0, dmask.i1, dmask.hrow.data_ptr(),
+                                      dense.ctypes.data, None))
+        plan.set_mask(torch.from_numpy(dense))
+        y_dense = plan.apply(xl)
+        plan.set_mask(dmask)
+        y_design = plan.apply(xl)
+        res["design_vs_dense"] = 0.0 if torch.equal(y_dense, y_design) else 1.0
+        refd = orc.fk_filter_filt(x, dense.astype(np.float64))
+        res["design"] = float(np.max(np.abs(y_design.numpy() - refd[a:b])) / np.max(np.abs(refd)))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
