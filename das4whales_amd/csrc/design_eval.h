@@ -53,7 +53,7 @@ __device__ __forceinline__ double d_hybrid_core(const DesignArgs& A, int i, int 
 // ---- hybrid_ninf: Butterworth |H|^2 row x speed band-pass, before the flips (dsp.py:348-402) ----
 __device__ __forceinline__ double d_ninf_core(const DesignArgs& A, int i, int j) {
     const double H = A.hrow[j];
-    if (j < A.i0 || j >= A.i1) return H;
+    if (j < A.i0 || j >= A.i1 || H == 0.0) return H;     // (the negative-frequency half of the row is zero: H * col = 0)
     const double k = axis_val(i, A.nx, A.kval), f = axis_val(j, A.ns, A.fval);
     const double cs_min = A.p[0], cp_min = A.p[1], cp_max = A.p[2], cs_max = A.p[3];
     const double ks_min = f / cs_max, kp_min = f / cp_max, ks_max = f / cs_min, kp_max = f / cp_min;
@@ -98,6 +98,15 @@ __device__ __forceinline__ double design_value(const DesignArgs& A, int mode, in
         default:
             return (d_wedge(A, i, j, A.p[0]) + d_wedge(A, i, rj, A.p[0])) - (d_wedge(A, i, j, A.p[1]) + d_wedge(A, i, rj, A.p[1]));
     }
+}
+
+// Hermitian part M_h = (M(k, f) + M(-k, -f)) / 2 at shifted-grid points (ip, jp) and its mirror (im, jm), each value
+// rounded to float32 first (as the dense design kernel stores it).  The classic fan is even in (k, f) -- |f / k| and
+// |k| are formed from exactly negated axis values -- so its mirror value is the same number: one evaluation.
+__device__ __forceinline__ float design_folded(const DesignArgs& A, int mode, int ip, int jp, int im, int jm) {
+    const float a = (float)design_value(A, mode, ip, jp);
+    if (mode == 0) return a;
+    return 0.5f * (a + (float)design_value(A, mode, im, jm));
 }
 
 inline DesignArgs make_design_args(int nx, int ns, double k_spacing, double t_spacing, const double* params8, int i0, int i1,

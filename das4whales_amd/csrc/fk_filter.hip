@@ -509,13 +509,13 @@ __global__ __launch_bounds__(kThreads) void fk_fold_design(FkDims d, DesignArgs 
         const int q1 = p / d.N2, i = p - q1 * d.N2;
         const int f = k1_of_q1[q1] + d.N1 * k2_of_i[i];
         const int fm = (d.ns - f) % d.ns;
-        const float v = 0.5f * ((float)design_value(A, mode, ip, (f + st) % d.ns) + (float)design_value(A, mode, im, (fm + st) % d.ns));
+        const float v = design_folded(A, mode, ip, (f + st) % d.ns, im, (fm + st) % d.ns);
         mask[(size_t)r * d.M + p] = v;
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int f = d.M, fm = d.ns - d.M;
-        const float v = 0.5f * ((float)design_value(A, mode, ip, (f + st) % d.ns) + (float)design_value(A, mode, im, (fm + st) % d.ns));
+        const float v = design_folded(A, mode, ip, (f + st) % d.ns, im, (fm + st) % d.ns);
         nyq[r] = v;
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
@@ -1594,11 +1594,10 @@ __global__ __launch_bounds__(kThreads) void fkd_fold_design(int nx, int ns, int 
         const int jq = p / N2, i = p - jq * N2;
         const int f = k1_of_q1[q1_of[jq]] + N1 * k2_of_i[i];
         const int fm = (ns - f) % ns;
-        mask[(size_t)r * nq * N2 + p] =
-            0.5f * ((float)design_value(A, mode, ip, (f + st) % ns) + (float)design_value(A, mode, im, (fm + st) % ns));
+        mask[(size_t)r * nq * N2 + p] = design_folded(A, mode, ip, (f + st) % ns, im, (fm + st) % ns);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        nyq[r] = 0.5f * ((float)design_value(A, mode, ip, (M + st) % ns) + (float)design_value(A, mode, im, ((ns - M) + st) % ns));
+        nyq[r] = design_folded(A, mode, ip, (M + st) % ns, im, ((ns - M) + st) % ns);
 }
 
 // where a distributed plan's mask comes from: a dense shifted-grid mask, or a closed-form design
