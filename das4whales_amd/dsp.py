@@ -4,6 +4,7 @@ Same function names, positional signatures and array conventions as the referenc
 arithmetic runs in the HIP library (include/d4w.h).  Filter *design* of 1-D IIR coefficients stays
 on the host in float64 (SciPy), exactly like the reference does.
 """
+import atexit
 import ctypes
 import threading
 import weakref
@@ -171,6 +172,10 @@ def compile_fk_shape(nx, ns, verbose=False):
 def clear_fk_plans():
     with _plans_lock:
         _plans.clear()
+
+
+# cached plans own device memory: free it while the HIP runtime is still up, not during interpreter teardown
+atexit.register(clear_fk_plans)
 
 
 def get_fk_plan(nx, ns, device=None):

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC counter passes over the bench (separate runs per counter group; kernel-trace only).
 # usage: PMC_GROUPS="sq1 sq2 fetch write cache" BENCH_ARGS="--stages mf" bash scripts/pmc.sh [outdir]
+#        PMC_CMD="python scripts/one_shape.py 13223 12000" profiles that command instead of the bench
 set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
@@ -15,7 +16,7 @@ G[write]="WRITE_SIZE"
 G[cache]="GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"
 G[tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"
 for g in ${PMC_GROUPS:-fetch write}; do
-  timeout 600 rocprofv3 --kernel-trace --pmc ${G[$g]} --output-format csv -d $R/$OUT/$g -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu ${BENCH_ARGS:-} > $R/$OUT/$g.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc ${G[$g]} --output-format csv -d $R/$OUT/$g -o pmc -- ${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no-cpu ${BENCH_ARGS:-}} > $R/$OUT/$g.log 2>&1
   echo "group $g rc=$?"
 done
 cd $R
