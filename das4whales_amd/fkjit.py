@@ -167,6 +167,20 @@ def compile_fk_shape(nx, ns, verbose=False):
         return is_specialised(nx, ns)
 
 
+def prune_stale():
+    """Delete cached objects built from other versions of the kernel headers (they are never loaded again)."""
+    tag = "_" + _header_hash() + ".so"
+    n = 0
+    for path in glob.glob(os.path.join(_JITDIR, "fk_*")):
+        if not path.endswith(tag) and ".so." not in os.path.basename(path) and not path.endswith(".hip"):
+            try:
+                os.remove(path)
+                n += 1
+            except OSError:
+                pass
+    return n
+
+
 def load_cached():
     """Register every cached configuration built from the current kernel headers (called at import: a dlopen each)."""
     tag = "_" + _header_hash() + ".so"
