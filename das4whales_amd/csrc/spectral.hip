@@ -634,7 +634,8 @@ static_assert(kFpFan == 32, "fp_walk shifts by 5");
 // min over the walk from q in direction DIR until the first sample > v (exclusive) or the row end.
 // Every phase reads a BATCH of operands with independent loads before it looks at them: a walk is a
 // chain of dependent decisions, and one LDS round trip per step is what it would otherwise cost.
-constexpr int kFpBatch = 8;
+constexpr int kFpBatch = 8;        // samples / summary entries read per dependent LDS round trip of a walk
+constexpr int kFpBlkBatch = 4;
 
 // Only the decision prominence >= thr is needed, not the prominence itself: a side is SATISFIED as soon
 // as the running minimum reaches lim = the largest float <= v - thr, and the walk may stop there
@@ -667,13 +668,13 @@ __device__ __forceinline__ int fp_scan_samples(const float* __restrict__ r, int 
 template <int DIR>
 __device__ __forceinline__ int fp_scan_blocks(const float2* __restrict__ sm, int nent, int shift, int& q, int n,
                                               int step, float v, float lim, float& lmin) {
-    for (int done = 0; done < n; done += 4) {
-        float2 e[4];
+    for (int done = 0; done < n; done += kFpBlkBatch) {
+        float2 e[kFpBlkBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = sm[min(max((q + DIR * k * step) >> shift, 0), nent - 1)];
-        const int m = min(4, n - done);
+        for (int k = 0; k < kFpBlkBatch; ++k) e[k] = sm[min(max((q + DIR * k * step) >> shift, 0), nent - 1)];
+        const int m = min(kFpBlkBatch, n - done);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kFpBlkBatch; ++k) {
             if (k < m) {
                 if (e[k].x > v) { q += DIR * k * step; return 1; }
                 lmin = fminf(lmin, e[k].y);
@@ -729,14 +730,23 @@ struct FpLds {
 };
 
 __device__ __forceinline__ void fp_summaries2(const FpLds& T, int nb, int nb2, int tid) {
-    for (int b2 = tid; b2 < nb2; b2 += kSpThreads) {
+    // one block summary per lane, 32-lane shuffle reduction (kFpFan = 32 = half a wave)
+    for (int base = 0; base < nb; base += kSpThreads) {                  // wave-uniform trip count: every lane shuffles
+        const int k = base + tid;
         float mx = -INFINITY, mn = INFINITY;
-        for (int k = b2 * kFpFan; k < min((b2 + 1) * kFpFan, nb); ++k) {
-            mx = fmaxf(mx, T.s1[k].x);
-            mn = fminf(mn, T.s1[k].y);
+        if (k < nb) {
+            const float2 e = T.s1[k];
+            mx = e.x;
+            mn = e.y;
         }
-        T.s2[b2] = make_float2(mx, mn);
+#pragma unroll
+        for (int off = 1; off < kFpFan; off <<= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+            mn = fminf(mn, __shfl_xor(mn, off));
+        }
+        if ((k & (kFpFan - 1)) == 0 && k < nb) T.s2[k / kFpFan] = make_float2(mx, mn);
     }
+    (void)nb2;
 }
 
 // block summaries of a row held in `r` (LDS or global): eight blocks per wave iteration (their loads are independent
@@ -775,21 +785,30 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
     const int ns4 = ns >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(rg);
     float4* l4 = reinterpret_cast<float4*>(T.rowl);
-    for (int base = 0; base < 8 * nb; base += kSpThreads) {             // wave-uniform trip count: every lane shuffles
-        const int v4 = base + tid;
-        float mx = -INFINITY, mn = INFINITY;
-        if (v4 < ns4) {
-            const float4 q = g4[v4];
-            l4[v4] = q;
-            mx = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
-            mn = fminf(fminf(q.x, q.y), fminf(q.z, q.w));
+    constexpr int kAhead = 12;                                          // loads in flight per lane: the sweep is latency-bound
+    for (int base = 0; base < 8 * nb; base += kAhead * kSpThreads) {    // wave-uniform trip count: every lane shuffles
+        float4 q[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const int v4 = base + k * kSpThreads + tid;
+            q[k] = (v4 < ns4) ? g4[v4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int off = 1; off <= 4; off <<= 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, off));
-            mn = fminf(mn, __shfl_xor(mn, off));
+        for (int k = 0; k < kAhead; ++k) {
+            const int v4 = base + k * kSpThreads + tid;
+            float mx = -INFINITY, mn = INFINITY;
+            if (v4 < ns4) {
+                l4[v4] = q[k];
+                mx = fmaxf(fmaxf(q[k].x, q[k].y), fmaxf(q[k].z, q[k].w));
+                mn = fminf(fminf(q[k].x, q[k].y), fminf(q[k].z, q[k].w));
+            }
+#pragma unroll
+            for (int off = 1; off <= 4; off <<= 1) {
+                mx = fmaxf(mx, __shfl_xor(mx, off));
+                mn = fminf(mn, __shfl_xor(mn, off));
+            }
+            if ((v4 & 7) == 0 && (v4 >> 3) < nb) T.s1[v4 >> 3] = make_float2(mx, mn);
         }
-        if ((v4 & 7) == 0 && (v4 >> 3) < nb) T.s1[v4 >> 3] = make_float2(mx, mn);
     }
 }
 
@@ -804,17 +823,99 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
 constexpr int kFpList = kSpThreads * 16;          // candidates per round: at most every second sample of 32 x kSpThreads
 
 __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds& T, int ns, int nb, int nb2, int bshift,
-                                        double thr, int nwords, int* wave_tot, int tid) {
+                                        double thr, int nwords, int* wave_tot, unsigned* cfail, bool vec4, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     float gmin = INFINITY;
     for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
     for (int w = tid; w < nwords; w += kSpThreads) T.cand[w] = 0u;
     __syncthreads();
-    for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
-        const float v = r[i];
-        if (r[i - 1] < v && !(r[i + 1] > v) && !((double)v - thr < (double)gmin)) atomicOr(&T.cand[i >> 5], 1u << (i & 31));
+    if (vec4) {
+        // four samples per lane: one 16-byte read and the two neighbours instead of three reads per sample
+        const float4* r4 = reinterpret_cast<const float4*>(r);
+        for (int v4 = tid; v4 < (ns >> 2); v4 += kSpThreads) {
+            const float4 q = r4[v4];
+            const int i0 = 4 * v4;
+            const float u[6] = {i0 ? r[i0 - 1] : INFINITY, q.x, q.y, q.z, q.w, (i0 + 4 < ns) ? r[i0 + 4] : INFINITY};
+            unsigned m = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = u[k + 1];
+                const int i = i0 + k;
+                if (i >= 1 && i < ns - 1 && u[k] < v && !(u[k + 2] > v) && !((double)v - thr < (double)gmin)) m |= 1u << k;
+            }
+            if (m) atomicOr(&T.cand[i0 >> 5], m << (i0 & 31));
+        }
+    } else {
+        for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
+            const float v = r[i];
+            if (r[i - 1] < v && !(r[i + 1] > v) && !((double)v - thr < (double)gmin)) atomicOr(&T.cand[i >> 5], 1u << (i & 31));
+        }
     }
     __syncthreads();
+    // walks + acceptance of the `total` candidates listed in T.clist (any order: accepted peaks go to a bitmap)
+    auto walk_listed = [&](int total) {
+        for (int w2 = tid; w2 < kFpList / 32; w2 += kSpThreads) cfail[w2] = 0u;
+        __syncthreads();
+        // the left and the right walk of a candidate run on two lanes (a walk is a chain of dependent LDS reads: with
+        // ~20 candidates per row most lanes idle anyway); a direction whose base is too high marks the candidate failed
+        // ... dealt round-robin to the waves: a wave pays the longest of its lanes' walks in every phase of fp_walk
+        for (int c2 = (tid & 63) * (kSpThreads / 64) + (tid >> 6); c2 < 2 * total; c2 += kSpThreads) {
+            const int c = c2 >> 1;
+            const int i = T.clist[c];
+            const float v = r[i];
+            int ia = i + 1;
+            while (ia < ns - 1 && r[ia] == v) ++ia;                  // plateau: reported at its middle sample
+            bool ok = r[ia] < v;
+            if (ok) {
+                // float64 like scipy (float32 samples are exact in float64, a float32 subtraction is not):
+                // lim = the largest float u with (double)v - (double)u >= thr
+                const double dl = (double)v - thr;
+                float lim = (float)dl;
+                if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
+                if (c2 & 1) ok = !(fp_walk<+1>(r, T.s1, T.s2, ns, nb, nb2, bshift, ia, v, lim) > lim);
+                else ok = !(fp_walk<-1>(r, T.s1, T.s2, ns, nb, nb2, bshift, i - 1, v, lim) > lim);    // left base too high
+            }
+            if (!ok) atomicOr(&cfail[c >> 5], 1u << (c & 31));
+        }
+        __syncthreads();
+        for (int c = tid; c < total; c += kSpThreads) {
+            if ((cfail[c >> 5] >> (c & 31)) & 1u) continue;
+            const int i = T.clist[c];
+            const float v = r[i];
+            int ia = i + 1;
+            while (ia < ns - 1 && r[ia] == v) ++ia;
+            const int mid = (i + ia - 1) / 2;
+            atomicOr(&T.bits[mid >> 5], 1u << (mid & 31));
+        }
+        __syncthreads();
+    };
+    // all candidates of the row in ONE list when they fit (the usual case: a walk phase costs its longest walk, however
+    // few lanes walk), else one round of kSpThreads bitmap words at a time (at most 16 candidates per word)
+    int* ccount = wave_tot + kSpThreads / 64;
+    int mine = 0;
+    for (int w = tid; w < nwords; w += kSpThreads) mine += __popc(T.cand[w]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) wave_tot[wave] = mine;
+    if (tid == 0) *ccount = 0;
+    __syncthreads();
+    int total_all = 0;
+    for (int k = 0; k < kSpThreads / 64; ++k) total_all += wave_tot[k];
+    if (total_all <= kFpList) {
+        for (int w = tid; w < nwords; w += kSpThreads) {
+            unsigned word = T.cand[w];
+            if (!word) continue;
+            int p = atomicAdd(ccount, __popc(word));
+            while (word) {
+                const int bit = __builtin_ctz(word);
+                word &= word - 1u;
+                T.clist[p++] = (w << 5) + bit;
+            }
+        }
+        walk_listed(total_all);
+        return;
+    }
+    __syncthreads();                                          // wave_tot is reused below
     for (int w0 = 0; w0 < nwords; w0 += kSpThreads) {
         const int w = w0 + tid;
         unsigned word = (w < nwords) ? T.cand[w] : 0u;
@@ -838,24 +939,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             word &= word - 1u;
             T.clist[p++] = (w << 5) + bit;
         }
-        __syncthreads();
-        for (int c = tid; c < total; c += kSpThreads) {
-            const int i = T.clist[c];
-            const float v = r[i];
-            int ia = i + 1;
-            while (ia < ns - 1 && r[ia] == v) ++ia;                  // plateau: reported at its middle sample
-            if (!(r[ia] < v)) continue;
-            const int mid = (i + ia - 1) / 2;
-            // float64 like scipy (float32 samples are exact in float64, a float32 subtraction is not):
-            // lim = the largest float u with (double)v - (double)u >= thr
-            const double dl = (double)v - thr;
-            float lim = (float)dl;
-            if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
-            if (fp_walk<-1>(r, T.s1, T.s2, ns, nb, nb2, bshift, i - 1, v, lim) > lim) continue;   // left base too high
-            if (fp_walk<+1>(r, T.s1, T.s2, ns, nb, nb2, bshift, ia, v, lim) > lim) continue;
-            atomicOr(&T.bits[mid >> 5], 1u << (mid & 31));
-        }
-        __syncthreads();
+        walk_listed(total);
     }
 }
 
@@ -911,7 +995,8 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
                                                               int bshift, int* __restrict__ idx,
                                                               int* __restrict__ counts, int cap) {
     D4W_DYN_LDS(smem_raw);
-    __shared__ int wave_tot[kSpThreads / 64];
+    __shared__ int wave_tot[kSpThreads / 64 + 1];              // + the candidate counter of fp_scan
+    __shared__ unsigned cfail[kFpList / 32];
     const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
     const int nwords = (ns + 31) >> 5;
     const FpLds T = fp_lds(smem_raw, nb, nb2, nwords);
@@ -931,7 +1016,7 @@ __global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __res
     __syncthreads();
     fp_summaries2(T, nb, nb2, tid);
     __syncthreads();
-    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, tid);
+    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, cfail, STAGED && (ns & 3) == 0, tid);
     __syncthreads();
     fp_emit(T, nwords, idx + (size_t)blockIdx.x * cap, counts + blockIdx.x, cap, wave_tot, tid);
 }

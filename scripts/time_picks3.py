@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from das4whales_amd import dsp, detect
 from das4whales_amd._lib import lib, check
 nx, ns = int(os.environ.get("NX", 11020)), int(os.environ.get("NS", 12000))
+torch.manual_seed(0)
 x = torch.randn((nx, ns), device="cuda")
 x = dsp.bp_filt(x, 200.0, 14, 30)
 t = np.arange(ns) / 200.0
