@@ -196,9 +196,22 @@ __global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const f
     const int L = F.ax.L;
     const TwLds tw = tw_stage(row_tw_axis(F), tile + row_tile_elems(F), tid, nthr);
     const float* xr = x + (size_t)blockIdx.x * ns;
+    constexpr int kAhead = 8;                                         // global loads in flight per lane (the sweeps are latency-bound)
     if (PACKED) {
         const float2* x2 = reinterpret_cast<const float2*>(xr);       // ns even: 8-byte aligned rows
-        for (int m = tid; m < L; m += nthr) tile[m] = x2[m];
+        for (int m0 = tid; m0 < L; m0 += kAhead * nthr) {
+            float2 q[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int m = m0 + k * nthr;
+                q[k] = (m < L) ? x2[m] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int m = m0 + k * nthr;
+                if (m < L) tile[m] = q[k];
+            }
+        }
     } else {
         for (int n = tid; n < L; n += nthr) tile[n] = make_float2(xr[n], 0.f);
     }
@@ -252,6 +265,36 @@ __global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const f
     }
     float* yr = y + (size_t)blockIdx.x * ns;
     const float inv_var = (mode == kAnSnr || mode == kAnEnvStd) ? 1.0f / var[blockIdx.x] : 0.f;
+    if (PACKED) {
+        // two samples per lane: the pair of inputs again (8 bytes, kAhead loads in flight), the pair of Hilbert values from
+        // the tile, one 8-byte store
+        const float2* x2 = reinterpret_cast<const float2*>(xr);
+        float2* y2 = reinterpret_cast<float2*>(yr);
+        auto val = [&](float re, float im) -> float {
+            const float p = fmaf(re, re, im * im);
+            if (mode == kAnEnvelope) return sqrtf(p);
+            if (mode == kAnHilbert) return im;
+            if (mode == kAnEnvStd) return sqrtf(p * inv_var);
+            return 10.0f * log10f(p * inv_var);
+        };
+        for (int m0 = tid; m0 < L; m0 += kAhead * nthr) {
+            float2 q[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int m = m0 + k * nthr;
+                q[k] = (m < L) ? x2[m] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int m = m0 + k * nthr;
+                if (m < L) {
+                    const float2 h = tile[m];
+                    y2[m] = make_float2(val(q[k].x, h.x * scale), val(q[k].y, h.y * scale));
+                }
+            }
+        }
+        return;
+    }
     for (int i = tid; i < ns; i += nthr) {
         const float2 z = zat(i);
         float v;
@@ -514,7 +557,9 @@ __device__ __forceinline__ float med_unkey(unsigned k) {
 __global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict__ v, size_t n,
                                                          float* __restrict__ med) {
     __shared__ unsigned hist[256];
+    __shared__ unsigned wtot[kSpThreads / 64];
     __shared__ unsigned s_prefix, s_k, s_cnt, s_min;
+    static_assert(kSpThreads == 256, "one histogram bin per thread");
     const float* row = v + (size_t)blockIdx.x * n;
     const int tid = threadIdx.x;
     if (tid == 0) { s_prefix = 0u; s_k = (unsigned)((n - 1) / 2); }
@@ -523,19 +568,77 @@ __global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict
         hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
-        for (size_t i = tid; i < n; i += kSpThreads) {
-            const unsigned k = med_key(row[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        if (shift == 24) {
+            // first sweep: every value takes part and the top byte (sign + upper exponent bits) of a row of magnitudes
+            // falls into two or three bins -- as LDS atomics that is a 64-way same-address conflict per wave.  Four
+            // bins around the first value's are counted in registers and added once per wave.
+            const unsigned hot = (med_key(row[0]) >> 24) - 1u;
+            unsigned priv[4] = {0u, 0u, 0u, 0u};
+            constexpr int kAhead = 4;
+            for (size_t i0 = tid; i0 < n; i0 += (size_t)kAhead * kSpThreads) {
+                float q[kAhead];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const size_t i = i0 + (size_t)j * kSpThreads;
+                    q[j] = (i < n) ? row[i] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    if (i0 + (size_t)j * kSpThreads < n) {
+                        const unsigned b = med_key(q[j]) >> 24, d = b - hot;
+                        if (d < 4u) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) priv[t] += (d == (unsigned)t) ? 1u : 0u;
+                        } else {
+                            atomicAdd(&hist[b], 1u);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned c = priv[t];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+                if ((tid & 63) == 0 && c && hot + (unsigned)t < 256u) atomicAdd(&hist[hot + (unsigned)t], c);
+            }
+        } else {
+            constexpr int kAhead = 4;
+            for (size_t i0 = tid; i0 < n; i0 += (size_t)kAhead * kSpThreads) {
+                float q[kAhead];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const size_t i = i0 + (size_t)j * kSpThreads;
+                    q[j] = (i < n) ? row[i] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const unsigned k = med_key(q[j]);
+                    if (i0 + (size_t)j * kSpThreads < n && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned k = s_k, b = 0;
-            for (; b < 255u; ++b) {
-                if (hist[b] > k) break;
-                k -= hist[b];
+        // the bin holding rank s_k: one bin per thread, inclusive scan (wave shuffles + the four wave totals) -- a serial
+        // walk of the 256 bins by one thread was a fifth of the kernel
+        {
+            const unsigned kk = s_k, h = hist[tid];
+            unsigned incl = h;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = __shfl_up(incl, off);
+                if ((tid & 63) >= off) incl += up;
             }
-            s_k = k;
-            s_prefix = prefix | (b << shift);
+            if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+            __syncthreads();
+            unsigned before = 0u;
+            for (int w = 0; w < (tid >> 6); ++w) before += wtot[w];
+            incl += before;
+            const unsigned excl = incl - h;
+            if (kk >= excl && kk < incl) {             // exactly one thread: the counts sum to more than s_k
+                s_k = kk - excl;
+                s_prefix = prefix | ((unsigned)tid << shift);
+            }
         }
         mask |= 255u << shift;
         __syncthreads();
