@@ -672,41 +672,76 @@ __global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict
 // off = nk/2 reproduces fftconvolve(S, flip(K, 1), 'same', axes=1); off = 0 with nout = nt-nk+1
 // and zero_ends reproduces detect.xcorr (detect.py:632-644: first and last value forced to 0).
 // ---------------------------------------------------------------------------------------------
-constexpr int kScTile = 256;
-constexpr int kScLdsFloats = 8192;
+constexpr int kScThreads = 128, kScPer = 4, kScTile = kScThreads * kScPer;      // 512 correlation lags per workgroup
+constexpr int kScLdsFloats = 2560;          // a few strip rows at a time: a small footprint keeps ~30 waves on a CU
+__host__ __device__ constexpr int sc_width(int nk) { return (kScTile + nk + 2 + 3) & ~3; }
 
-__global__ __launch_bounds__(kScTile) void spectro_corr(const float* __restrict__ S, int nf, int nt,
-                                                        const float* __restrict__ K, int nk, int off, int nout,
-                                                        const float* __restrict__ med, int zero_ends,
-                                                        float* __restrict__ out) {
-    __shared__ float strip[kScLdsFloats];
+// Four consecutive lags per lane: a lane reads its window of a strip row in 16-byte pieces (conflict-free) and every piece
+// feeds 16 FMAs -- a quarter of the LDS reads of one lag per lane -- with the 7 kernel taps a piece meets as wave-uniform
+// scalars; the strip itself is filled with eight global loads in flight per lane.
+__global__ __launch_bounds__(kScThreads) void spectro_corr(const float* __restrict__ S, int nf, int nt,
+                                                           const float* __restrict__ K, int nk, int off, int nout,
+                                                           const float* __restrict__ med, int zero_ends,
+                                                           float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float strip[kScLdsFloats];
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * kScTile;
-    const int width = kScTile + nk - 1;
+    const int width = sc_width(nk);
     const int fchunk = max(1, kScLdsFloats / width);
     const float* Sc = S + (size_t)blockIdx.y * nf * nt;
-    float acc = 0.f;
+    float acc[kScPer] = {0.f, 0.f, 0.f, 0.f};
     for (int f0 = 0; f0 < nf; f0 += fchunk) {
         const int fn = min(fchunk, nf - f0);
-        for (int w = tid; w < fn * width; w += kScTile) {
-            const int fl = w / width, j = w - fl * width;
-            const int s = t0 + j - off;
-            strip[w] = (s >= 0 && s < nt) ? Sc[(size_t)(f0 + fl) * nt + s] : 0.f;
+        constexpr int kAhead = 8;
+        for (int w0 = tid; w0 < fn * width; w0 += kAhead * kScThreads) {
+            float q[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int w = w0 + k * kScThreads;
+                const int fl = w / width, j = w - fl * width;
+                const int s = t0 + j - off;
+                q[k] = (w < fn * width && s >= 0 && s < nt) ? Sc[(size_t)(f0 + fl) * nt + s] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int w = w0 + k * kScThreads;
+                if (w < fn * width) strip[w] = q[k];
+            }
         }
         __syncthreads();
         for (int fl = 0; fl < fn; ++fl) {
             const float* kr = K + (size_t)(f0 + fl) * nk;
-            const float* sr = strip + fl * width + tid;
-            for (int j = 0; j < nk; ++j) acc = fmaf(sr[j], kr[j], acc);
+            const float4* sr4 = reinterpret_cast<const float4*>(strip + fl * width) + tid;
+            for (int c = 0; 4 * c < nk + 3; ++c) {
+                const float4 v4 = sr4[c];
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                // sample e of the piece sits at lag offset 4 c + e: tap j = 4 c + e - q for lag q of this lane.  Taps outside
+                // [0, nk) are skipped (wave-uniform branch), not multiplied by zero: a NaN next to the window stays out
+#pragma unroll
+                for (int d = 0; d < 7; ++d) {
+                    const int j = 4 * c - 3 + d;
+                    if (j >= 0 && j < nk) {
+                        const float tap = kr[j];
+#pragma unroll
+                        for (int q = 0; q < kScPer; ++q) {
+                            const int e = d - 3 + q;
+                            if (e >= 0 && e < 4) acc[q] = fmaf(v[e], tap, acc[q]);
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
     }
-    const int t = t0 + tid;
-    if (t < nout) {
-        float v = acc / (med[blockIdx.y] * (float)nk);
-        if (zero_ends && (t == 0 || t == nout - 1)) v = 0.f;
-        if (v < 0.f) v = 0.f;                                        // NaN (0/0 on an all-zero row) passes through
-        out[(size_t)blockIdx.y * nout + t] = v;
+#pragma unroll
+    for (int q = 0; q < kScPer; ++q) {
+        const int t = t0 + kScPer * tid + q;
+        if (t < nout) {
+            float v = acc[q] / (med[blockIdx.y] * (float)nk);
+            if (zero_ends && (t == 0 || t == nout - 1)) v = 0.f;
+            if (v < 0.f) v = 0.f;                                    // NaN (0/0 on an all-zero row) passes through
+            out[(size_t)blockIdx.y * nout + t] = v;
+        }
     }
 }
 
@@ -1313,9 +1348,9 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
                         const float* med, int zero_ends, float* out, void* stream) {
     if (!S || !K || !med || !out || nx < 1 || nf < 1 || nt < 1 || nk < 1 || nout < 1)
         return fail(D4W_EINVAL, "bad argument");
-    if (nk > kScLdsFloats - kScTile) return fail(D4W_EINVAL, "kernel of %d frames is too long", nk);
+    if (sc_width(nk) > kScLdsFloats) return fail(D4W_EINVAL, "kernel of %d frames is too long", nk);
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
-    D4W_LAUNCH(spectro_corr, dim3(ceil_div(nout, kScTile), nx), dim3(kScTile), 0, stream, S, nf, nt, K, nk, off,
+    D4W_LAUNCH(spectro_corr, dim3(ceil_div(nout, kScTile), nx), dim3(kScThreads), 0, stream, S, nf, nt, K, nk, off,
                nout, med, zero_ends, out);
     return D4W_OK;
 }
