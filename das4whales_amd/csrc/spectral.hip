@@ -186,8 +186,9 @@ __device__ __forceinline__ float an_ifreq(float2 z0, float2 z1, float fscale) {
     return atan2f(p.y, p.x) * fscale;
 }
 
+constexpr int kAnMaxThreads = 512;
 template <bool PACKED, bool GENERIC>
-__global__ __launch_bounds__(kSpThreads) void analytic_rows(RowFftDev F, const float* __restrict__ x, int ns,
+__global__ __launch_bounds__(kAnMaxThreads) void analytic_rows(RowFftDev F, const float* __restrict__ x, int ns,
                                                             float* __restrict__ y, int mode,
                                                             const float* __restrict__ var, float fscale) {
     D4W_DYN_LDS(smem_raw);
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(kScThreads) void spectro_corr(const float* __restri
 // the end by a popcount prefix sum over the bitmap.
 constexpr int kFpMaxBlocks = 4096;
 constexpr int kFpRowLds = 16384;
+constexpr int kFpThreads = 512;                // two 70-KB rows fit a CU: 16 waves instead of 8
 constexpr int kFpFan = 32;                      // blocks per super-block (the walk code shifts by 5)
 static_assert(kFpFan == 32, "fp_walk shifts by 5");
 
@@ -869,7 +871,7 @@ struct FpLds {
 
 __device__ __forceinline__ void fp_summaries2(const FpLds& T, int nb, int nb2, int tid) {
     // one block summary per lane, 32-lane shuffle reduction (kFpFan = 32 = half a wave)
-    for (int base = 0; base < nb; base += kSpThreads) {                  // wave-uniform trip count: every lane shuffles
+    for (int base = 0; base < nb; base += kFpThreads) {                  // wave-uniform trip count: every lane shuffles
         const int k = base + tid;
         float mx = -INFINITY, mn = INFINITY;
         if (k < nb) {
@@ -892,7 +894,7 @@ __device__ __forceinline__ void fp_summaries2(const FpLds& T, int nb, int nb2, i
 __device__ __forceinline__ void fp_summaries1(const float* __restrict__ r, const FpLds& T, int ns, int nb, int bshift, int tid) {
     const int BS = 1 << bshift, lane = tid & 63, wave = tid >> 6;
     constexpr int kBatch = 8;
-    for (int bk0 = wave * kBatch; bk0 < nb; bk0 += (kSpThreads / 64) * kBatch) {
+    for (int bk0 = wave * kBatch; bk0 < nb; bk0 += (kFpThreads / 64) * kBatch) {
         float mx[kBatch], mn[kBatch];
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
@@ -924,16 +926,16 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
     const float4* g4 = reinterpret_cast<const float4*>(rg);
     float4* l4 = reinterpret_cast<float4*>(T.rowl);
     constexpr int kAhead = 12;                                          // loads in flight per lane: the sweep is latency-bound
-    for (int base = 0; base < 8 * nb; base += kAhead * kSpThreads) {    // wave-uniform trip count: every lane shuffles
+    for (int base = 0; base < 8 * nb; base += kAhead * kFpThreads) {    // wave-uniform trip count: every lane shuffles
         float4 q[kAhead];
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) {
-            const int v4 = base + k * kSpThreads + tid;
+            const int v4 = base + k * kFpThreads + tid;
             q[k] = (v4 < ns4) ? g4[v4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) {
-            const int v4 = base + k * kSpThreads + tid;
+            const int v4 = base + k * kFpThreads + tid;
             float mx = -INFINITY, mn = INFINITY;
             if (v4 < ns4) {
                 l4[v4] = q[k];
@@ -954,23 +956,23 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
 //   (1) every thread marks the rising edges of maxima that can reach the threshold at all in the `cand` bitmap -- no
 //       base can lie below the row minimum, so a maximum with v - thr below it is rejected here, without a walk (with
 //       thr = a fraction of the strongest peak that is almost every maximum);
-//   (2) per round of kSpThreads bitmap words the marked positions are listed (popcount prefix sum) and lane c walks
+//   (2) per round of kFpThreads bitmap words the marked positions are listed (popcount prefix sum) and lane c walks
 //       candidate c.  Walking inside the marking loop instead made a wave pay the SUM of its lanes' walks (one lane
 //       walking, 63 masked): 0.72 of 0.97 ms at 11020 x 12000 with ~15 picks per row.
 // r: the row (LDS or global).  Ends with the accepted peaks in T.bits; the last barrier is the caller's.
-constexpr int kFpList = kSpThreads * 16;          // candidates per round: at most every second sample of 32 x kSpThreads
+constexpr int kFpList = 4096;          // candidates per walk round
 
 __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds& T, int ns, int nb, int nb2, int bshift,
                                         double thr, int nwords, int* wave_tot, unsigned* cfail, bool vec4, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     float gmin = INFINITY;
     for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
-    for (int w = tid; w < nwords; w += kSpThreads) T.cand[w] = 0u;
+    for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
     __syncthreads();
     if (vec4) {
         // four samples per lane: one 16-byte read and the two neighbours instead of three reads per sample
         const float4* r4 = reinterpret_cast<const float4*>(r);
-        for (int v4 = tid; v4 < (ns >> 2); v4 += kSpThreads) {
+        for (int v4 = tid; v4 < (ns >> 2); v4 += kFpThreads) {
             const float4 q = r4[v4];
             const int i0 = 4 * v4;
             const float u[6] = {i0 ? r[i0 - 1] : INFINITY, q.x, q.y, q.z, q.w, (i0 + 4 < ns) ? r[i0 + 4] : INFINITY};
@@ -984,7 +986,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             if (m) atomicOr(&T.cand[i0 >> 5], m << (i0 & 31));
         }
     } else {
-        for (int i = 1 + tid; i < ns - 1; i += kSpThreads) {
+        for (int i = 1 + tid; i < ns - 1; i += kFpThreads) {
             const float v = r[i];
             if (r[i - 1] < v && !(r[i + 1] > v) && !((double)v - thr < (double)gmin)) atomicOr(&T.cand[i >> 5], 1u << (i & 31));
         }
@@ -992,12 +994,12 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
     __syncthreads();
     // walks + acceptance of the `total` candidates listed in T.clist (any order: accepted peaks go to a bitmap)
     auto walk_listed = [&](int total) {
-        for (int w2 = tid; w2 < kFpList / 32; w2 += kSpThreads) cfail[w2] = 0u;
+        for (int w2 = tid; w2 < kFpList / 32; w2 += kFpThreads) cfail[w2] = 0u;
         __syncthreads();
         // the left and the right walk of a candidate run on two lanes (a walk is a chain of dependent LDS reads: with
         // ~20 candidates per row most lanes idle anyway); a direction whose base is too high marks the candidate failed
         // ... dealt round-robin to the waves: a wave pays the longest of its lanes' walks in every phase of fp_walk
-        for (int c2 = (tid & 63) * (kSpThreads / 64) + (tid >> 6); c2 < 2 * total; c2 += kSpThreads) {
+        for (int c2 = (tid & 63) * (kFpThreads / 64) + (tid >> 6); c2 < 2 * total; c2 += kFpThreads) {
             const int c = c2 >> 1;
             const int i = T.clist[c];
             const float v = r[i];
@@ -1016,7 +1018,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             if (!ok) atomicOr(&cfail[c >> 5], 1u << (c & 31));
         }
         __syncthreads();
-        for (int c = tid; c < total; c += kSpThreads) {
+        for (int c = tid; c < total; c += kFpThreads) {
             if ((cfail[c >> 5] >> (c & 31)) & 1u) continue;
             const int i = T.clist[c];
             const float v = r[i];
@@ -1028,19 +1030,19 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
         __syncthreads();
     };
     // all candidates of the row in ONE list when they fit (the usual case: a walk phase costs its longest walk, however
-    // few lanes walk), else one round of kSpThreads bitmap words at a time (at most 16 candidates per word)
-    int* ccount = wave_tot + kSpThreads / 64;
+    // few lanes walk), else one round of kFpList / 16 bitmap words at a time
+    int* ccount = wave_tot + kFpThreads / 64;
     int mine = 0;
-    for (int w = tid; w < nwords; w += kSpThreads) mine += __popc(T.cand[w]);
+    for (int w = tid; w < nwords; w += kFpThreads) mine += __popc(T.cand[w]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
     if (lane == 0) wave_tot[wave] = mine;
     if (tid == 0) *ccount = 0;
     __syncthreads();
     int total_all = 0;
-    for (int k = 0; k < kSpThreads / 64; ++k) total_all += wave_tot[k];
+    for (int k = 0; k < kFpThreads / 64; ++k) total_all += wave_tot[k];
     if (total_all <= kFpList) {
-        for (int w = tid; w < nwords; w += kSpThreads) {
+        for (int w = tid; w < nwords; w += kFpThreads) {
             unsigned word = T.cand[w];
             if (!word) continue;
             int p = atomicAdd(ccount, __popc(word));
@@ -1054,9 +1056,10 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
         return;
     }
     __syncthreads();                                          // wave_tot is reused below
-    for (int w0 = 0; w0 < nwords; w0 += kSpThreads) {
+    constexpr int kWordsPerRound = kFpList / 16;              // a word marks at most 16 maxima
+    for (int w0 = 0; w0 < nwords; w0 += kWordsPerRound) {
         const int w = w0 + tid;
-        unsigned word = (w < nwords) ? T.cand[w] : 0u;
+        unsigned word = (tid < kWordsPerRound && w < nwords) ? T.cand[w] : 0u;
         const int cnt = __popc(word);
         int incl = cnt;
 #pragma unroll
@@ -1067,7 +1070,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         int before = 0, total = 0;
-        for (int k = 0; k < kSpThreads / 64; ++k) {
+        for (int k = 0; k < kFpThreads / 64; ++k) {
             if (k < wave) before += wave_tot[k];
             total += wave_tot[k];
         }
@@ -1081,12 +1084,12 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
     }
 }
 
-// time-ordered index list: popcount prefix sum over the bitmap, kSpThreads words per round
+// time-ordered index list: popcount prefix sum over the bitmap, kFpThreads words per round
 __device__ __forceinline__ void fp_emit(const FpLds& T, int nwords, int* __restrict__ orow, int* __restrict__ count, int cap,
                                         int* wave_tot, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     int base = 0;
-    for (int w0 = 0; w0 < nwords; w0 += kSpThreads) {
+    for (int w0 = 0; w0 < nwords; w0 += kFpThreads) {
         const int w = w0 + tid;
         unsigned word = (w < nwords) ? T.bits[w] : 0u;
         const int cnt = __popc(word);
@@ -1099,7 +1102,7 @@ __device__ __forceinline__ void fp_emit(const FpLds& T, int nwords, int* __restr
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         int before = 0, total = 0;
-        for (int k = 0; k < kSpThreads / 64; ++k) {
+        for (int k = 0; k < kFpThreads / 64; ++k) {
             if (k < wave) before += wave_tot[k];
             total += wave_tot[k];
         }
@@ -1129,24 +1132,24 @@ __device__ __forceinline__ FpLds fp_lds(unsigned char* p, int nb, int nb2, int n
 }
 
 template <bool STAGED>
-__global__ __launch_bounds__(kSpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
+__global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
                                                               int bshift, int* __restrict__ idx,
                                                               int* __restrict__ counts, int cap) {
     D4W_DYN_LDS(smem_raw);
-    __shared__ int wave_tot[kSpThreads / 64 + 1];              // + the candidate counter of fp_scan
+    __shared__ int wave_tot[kFpThreads / 64 + 1];              // + the candidate counter of fp_scan
     __shared__ unsigned cfail[kFpList / 32];
     const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
     const int nwords = (ns + 31) >> 5;
     const FpLds T = fp_lds(smem_raw, nb, nb2, nwords);
     const float* rg = x + (size_t)blockIdx.x * ns;
     const int tid = threadIdx.x;
-    for (int w = tid; w < nwords; w += kSpThreads) T.bits[w] = 0u;
+    for (int w = tid; w < nwords; w += kFpThreads) T.bits[w] = 0u;
     const bool vec4 = STAGED && bshift == 5 && (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
     if (vec4) {
         fp_stage_rows4(rg, T, ns, nb, tid);
     } else {
         if (STAGED) {
-            for (int i = tid; i < ns; i += kSpThreads) T.rowl[i] = rg[i];
+            for (int i = tid; i < ns; i += kFpThreads) T.rowl[i] = rg[i];
             __syncthreads();
         }
         fp_summaries1(STAGED ? T.rowl : rg, T, ns, nb, bshift, tid);
@@ -1227,10 +1230,15 @@ int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const f
         return fail(D4W_EINVAL, "rows of %d samples exceed the single-workgroup transform (max %d even / %d odd)",
                     ns, (int)(2 * (kSpLdsMax / 8 - 512)), (int)(kSpLdsMax / 8 - 512));
     const float fscale = (float)(fs / (2.0 * M_PI));
+    static const int an_env = [] { const char* v = getenv("D4W_AN_THREADS"); return v ? atoi(v) : 0; }();
+    // long rows: 512 threads per row (three 48-KB tiles fit a CU either way: 24 waves instead of 12; 0.69 -> 0.56 ms at
+    // 11020 x 12000)
+    const int an_threads = (an_env >= 64 && an_env <= kAnMaxThreads && an_env % 64 == 0) ? an_env
+                           : (L >= 2048 ? kAnMaxThreads : kSpThreads);
 #define D4W_AN(P, G)                                                                              \
     do {                                                                                          \
         sp_allow_lds(analytic_rows<P, G>, lds);                                                   \
-        D4W_LAUNCH((analytic_rows<P, G>), dim3(nx), dim3(kSpThreads), lds, stream, h->dev, x, ns, \
+        D4W_LAUNCH((analytic_rows<P, G>), dim3(nx), dim3(an_threads), lds, stream, h->dev, x, ns, \
                    y, mode, var, fscale);                                                         \
     } while (0)
     if (packed) { if (h->generic) D4W_AN(true, true); else D4W_AN(true, false); }
@@ -1284,6 +1292,15 @@ int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, in
     StftDims d;
     d.ns = ns; d.n_fft = n_fft; d.hop = hop; d.nframes = 1 + ns / hop; d.b_lo = bin_lo; d.b_hi = bin_hi;
     int nb = std::max(1, 6144 / n_fft);                      // complex transforms (frame pairs) per workgroup
+    // two-factor frame lengths: 16 pairs make the first stage exactly one item per thread (RB = 16) and keep the tile at
+    // 22-35 KB, i.e. 16-24 waves on a CU instead of 8 (measured at 11020 x 12000: n_fft 160 kept bins 2.61 -> 1.80 ms, all bins
+    // 3.98 -> 2.77 ms, n_fft 256 5.05 -> 3.70 ms)
+    if (n_fft == 128 || n_fft == 160 || n_fft == 256) nb = 16;
+    else if (n_fft == 512) nb = 8;
+    {
+        static const int nb_env = [] { const char* v = getenv("D4W_STFT_NB"); return v ? atoi(v) : 0; }();
+        if (nb_env > 0) nb = nb_env;
+    }
     nb = std::min(nb, std::max(1, (d.nframes + 1) / 2));
     d.FT = 2 * nb;
     // two-factor register transforms for the common frame lengths (rowmax may be NULL there: only the kept bins are formed)
@@ -1368,11 +1385,11 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
     if (lds > kSpLdsMax) return fail(D4W_EINVAL, "rows of %d samples exceed the peak-picking LDS tables", ns);
     if (staged) {
         sp_allow_lds(find_peaks_prom<true>, lds);
-        D4W_LAUNCH(find_peaks_prom<true>, dim3(nx), dim3(kSpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
+        D4W_LAUNCH(find_peaks_prom<true>, dim3(nx), dim3(kFpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
                    (int*)counts, cap);
     } else {
         sp_allow_lds(find_peaks_prom<false>, lds);
-        D4W_LAUNCH(find_peaks_prom<false>, dim3(nx), dim3(kSpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
+        D4W_LAUNCH(find_peaks_prom<false>, dim3(nx), dim3(kFpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
                    (int*)counts, cap);
     }
     return D4W_OK;

@@ -346,3 +346,22 @@ def test_pack_picks_table(emu):
     ref = [sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0] for c in range(nx)]
     want = np.asarray((np.concatenate([np.full(len(p), i) for i, p in enumerate(ref)]), np.concatenate(ref)))
     assert total == want.shape[1] and np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("ns", [12000, 16384, 10001])
+def test_find_peaks_more_candidates_than_one_list(emu, ns):
+    """Rows with more maxima than the 4096-entry candidate list (white noise has ~ns/3): thr = 0 sends the scan through
+    the word-round fallback, a threshold through the single merged list; staged rows with 16-byte and scalar loads."""
+    rng = np.random.default_rng(ns)
+    x = rng.standard_normal((2, ns)).astype(np.float32)
+    x[1, ::2] = np.abs(x[1, ::2]) + 4.0                                 # every second sample a maximum: ns / 2 candidates
+    x[1, 1::2] = -np.abs(x[1, 1::2])
+    for thr in (0.0, 1.0, 5.0):
+        cap = ns // 2 + 1
+        idx = np.empty((2, cap), dtype=np.int32)
+        cnt = np.empty(2, dtype=np.int32)
+        ok(emu, emu.d4w_find_peaks_f32(vp(x), 2, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
+        for c in range(2):
+            ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+            assert cnt[c] == len(ref), (thr, c, cnt[c], len(ref))
+            assert np.array_equal(idx[c, :cnt[c]], ref)
