@@ -82,6 +82,8 @@ def _load():
         "d4w_xcorr_fft_ws_bytes": (ctypes.c_size_t, []),
         "d4w_xcorr_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+        "d4w_xcorr_fft_cont_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
         "d4w_fir_fft_max_halfwidth": (c_int, []),
         "d4w_fir_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_double, c_void_p, c_void_p,
                                     c_void_p]),

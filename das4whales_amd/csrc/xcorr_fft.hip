@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void xcf_tables4(const float* __restrict__ tap
 __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, const float* __restrict__ x, int nx, int ns,
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ maxabs,
-                                                                    float* __restrict__ y0, float* __restrict__ y1) {
+                                                                    float* __restrict__ y0, float* __restrict__ y1,
+                                                                    const float* __restrict__ xnext, int ld_next, int n_next) {
     constexpr int MB = kXfMB, ROWP = kX4RowP;
     D4W_DYN_LDS(smem_raw);
     float4* buf = reinterpret_cast<float4*>(smem_raw);            // [ROWP] block spectrum, then template 1's correlation
@@ -761,18 +762,24 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
     c2 pf[8];
     float2 pw[8];
     if (fwd) {
-        auto fetch = [&](const float* xr, float mu, bool vec, int i) -> float2 {
-            float2 v = make_float2(0.f, 0.f);
+        // beyond the row: the first n_next samples of the record's continuation (the next file's rows, pitch ld_next),
+        // de-meaned like the row's own samples, then zeros
+        auto sample = [&](const float* xr, const float* xn, float mu, int i) -> float {
+            if (i < ns) return xr[i] - mu;
+            if (xn && i - ns < n_next) return xn[i - ns] - mu;
+            return 0.f;
+        };
+        auto fetch = [&](const float* xr, const float* xn, float mu, bool vec, int i) -> float2 {
             if (vec && i + 1 < ns) {
-                v = *reinterpret_cast<const float2*>(xr + i);
+                float2 v = *reinterpret_cast<const float2*>(xr + i);
                 v.x -= mu;
                 v.y -= mu;
-            } else {
-                if (i < ns) v.x = xr[i] - mu;
-                if (i + 1 < ns) v.y = xr[i + 1] - mu;
+                return v;
             }
-            return v;
+            return make_float2(sample(xr, xn, mu, i), sample(xr, xn, mu, i + 1));
         };
+        const float* xna = xnext ? xnext + (size_t)rowA * ld_next : nullptr;
+        const float* xnb = xnext ? xnext + (size_t)rowB * ld_next : nullptr;
         if (interior) {
             const float2* pa = reinterpret_cast<const float2*>(xa + k0) + tid;
             const float2* pb = reinterpret_cast<const float2*>(xb + k0) + tid;
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
             static_for<8>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 const int i = k0 + 2 * (tid + q * 256);
-                pf[q] = c2_make(fetch(xa, mua, veca, i), fetch(xb, mub, vecb, i));
+                pf[q] = c2_make(fetch(xa, xna, mua, veca, i), fetch(xb, xnb, mub, vecb, i));
             });
         }
         static_for<7>([&](auto qq) {
@@ -977,7 +984,15 @@ size_t d4w_xcorr_fft_ws_bytes(void) { return (kXfWsFloats + kX4WsFloats) * sizeo
 
 int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
                       int ntpl, int ltaps, int len0, int len1, float* y0, float* y1, void* ws, void* stream) {
+    return d4w_xcorr_fft_cont_f32(x, nx, ns, nullptr, 0, 0, mean, maxabs, taps, ntpl, ltaps, len0, len1, y0, y1, ws, stream);
+}
+
+int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const float* mean,
+                           const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
+                           float* y1, void* ws, void* stream) {
     if (!x || !taps || !y0 || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (xnext && (ntpl != 2 || n_next < 0 || ld_next < n_next))
+        return fail(D4W_EINVAL, "a continuation needs two templates (the fused kernel) and 0 <= n_next <= ld_next");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
     if (ntpl == 1) len1 = len0;
     if (len0 < 1 || len1 < 1 || len0 > ltaps || len1 > ltaps || std::max(len0, len1) > kXfPad + 1)
@@ -1044,9 +1059,11 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
             attr4 = true;
         }
 #endif
-        D4W_LAUNCH(xcorr_fft_fused4, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1);
+        D4W_LAUNCH(xcorr_fft_fused4, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1, xnext, ld_next,
+                   n_next);
         return D4W_OK;
     }
+    if (xnext) return fail(D4W_EINVAL, "a continuation runs the four-stage fused kernel only (D4W_XF_FUSED / D4W_XF_TPAIR are set)");
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,

@@ -56,14 +56,21 @@ def _taps_tensor(taps_list, device):
     return torch.from_numpy(taps).to(device), lt
 
 
-def _xcorr_device(x, taps_list, normalize, method="auto", stats=None):
+def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None):
     """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
     method: "fft" (overlap-save, supports <= 161 samples), "direct", or "auto" (fft when it applies).
-    stats: optional (mean, maxabs) CUDA tensors of the rows, e.g. from FkPlan.apply_stats."""
+    stats: optional (mean, maxabs) CUDA tensors of the rows, e.g. from FkPlan.apply_stats.
+    cont: optional (tensor [nx, >= n], n): the record continues -- the last lags read the first n samples of these rows
+    instead of zeros (stream.FileStream); exactly two templates and the FFT form (xcorr_continuation_ok)."""
     nx, ns = x.shape
     outs = []
     use_fft = method == "fft" or (method == "auto" and ns >= 1024
                                   and max(len(t) for t in taps_list) <= int(lib.d4w_xcorr_fft_max_support()))
+    if cont is not None:
+        nxt, n_next = cont
+        if not (use_fft and len(taps_list) == 2 and nxt.is_cuda and nxt.dtype == torch.float32 and nxt.stride(1) == 1
+                and nxt.shape[0] == nx and nxt.shape[1] >= n_next):
+            raise ValueError("a continuation needs two templates, the FFT form and float32 CUDA rows")
     with torch.cuda.device(x.device):
         mean = mx = None
         if normalize and stats is not None:
@@ -78,11 +85,15 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None):
             ys = [torch.empty_like(x) for _ in grp]
             if use_fft:
                 ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
-                check(lib.d4w_xcorr_fft_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
-                                            dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
-                                            len(grp[0]), len(grp[-1]),
-                                            dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
-                                            dev.ptr(ws), dev.stream_ptr(x)))
+                check(lib.d4w_xcorr_fft_cont_f32(dev.ptr(x), nx, ns,
+                                                 dev.ptr(cont[0]) if cont is not None else None,
+                                                 int(cont[0].stride(0)) if cont is not None else 0,
+                                                 int(cont[1]) if cont is not None else 0,
+                                                 dev.ptr(mean) if normalize else None,
+                                                 dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
+                                                 len(grp[0]), len(grp[-1]),
+                                                 dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
+                                                 dev.ptr(ws), dev.stream_ptr(x)))
                 outs.extend(ys)
                 continue
             check(lib.d4w_xcorr_lens_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
@@ -92,6 +103,13 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None):
                                          dev.stream_ptr(x)))
             outs.extend(ys)
     return outs
+
+
+def xcorr_continuation_ok(taps_list, ns):
+    """Whether _xcorr_device(..., cont=...) applies: two templates that run the fused overlap-save kernel."""
+    import os
+    return (len(taps_list) == 2 and ns >= 1024 and max(len(t) for t in taps_list) <= int(lib.d4w_xcorr_fft_max_support())
+            and os.environ.get("D4W_XF_FUSED", "1") == "1" and os.environ.get("D4W_XF_TPAIR", "0") == "0")
 
 
 def _host_vec(v):

@@ -83,14 +83,20 @@ class FileStream:
             mean = torch.empty(nx, dtype=torch.float32, device=y.device)
             mx = torch.empty(nx, dtype=torch.float32, device=y.device)
             check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
-        if next_head is not None and self.lmax > 1:
-            # rows continue into the next file; the padding must enter de-meaned like the file's own
-            # samples (the kernel subtracts the mean from every sample it reads)
-            ext = torch.cat((y, next_head[:, :self.lmax - 1]), dim=1).contiguous()
+        if next_head is not None and self.lmax > 1 and next_head.is_cuda and next_head.dtype == torch.float32 \
+                and next_head.stride(1) == 1 and detect.xcorr_continuation_ok(self.taps, ns):
+            # rows continue into the next file: the kernel reads the head of the next file's rows in place (de-meaned
+            # like the file's own samples) -- no concatenated copy, no cropped copies of the correlograms
+            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, self.lmax - 1))
         else:
-            ext = y
-        cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
-        cs = [c[:, :ns].contiguous() for c in cs]
+            if next_head is not None and self.lmax > 1:
+                # the padding must enter de-meaned like the file's own samples (the kernel subtracts the mean from
+                # every sample it reads)
+                ext = torch.cat((y, next_head[:, :self.lmax - 1]), dim=1).contiguous()
+            else:
+                ext = y
+            cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
+            cs = [c[:, :ns].contiguous() for c in cs]
         for c, tp, coef in zip(cs, self.taps, self.tail):
             if coef != 0.0 and abs(coef) * np.sqrt(ns) > detect.TAIL_THRESHOLD:
                 with torch.cuda.device(y.device):

@@ -253,6 +253,14 @@ size_t d4w_xcorr_fft_ws_bytes(void);
 int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
                       const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                       float* y1, void* ws, void* stream);
+/* The same for a record that continues: lags whose window runs past sample ns - 1 read the first n_next samples of
+ * xnext [nx][ld_next] (the head of the next file of the same cable, filtered the same way; de-meaned with THIS file's
+ * row means like the row's own samples) instead of zeros -- what das4whales_amd/stream.py used to do by concatenating
+ * the two files first (no reference counterpart, parity target = the reference run on the concatenated
+ * record).  Two templates per call (the fused kernel).  xnext = NULL: identical to d4w_xcorr_fft_f32. */
+int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
+                           const float* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
+                           int len0, int len1, float* y0, float* y1, void* ws, void* stream);
 
 /* Zero-phase FIR along time by overlap-save FFT blocks -- the INTERIOR of dsp.bp_filt / scipy.signal.sosfiltfilt
  * (dsp.py:859-880): away from the row ends a zero-phase IIR filter is the convolution with its two-sided response

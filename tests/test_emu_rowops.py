@@ -320,3 +320,44 @@ def test_fir_fft_interior(emu, ns, K):
     assert not np.isnan(got).any()
     assert np.max(np.abs(got - ref)) < 1e-5 * np.max(np.abs(ref))
     assert emu.d4w_fir_fft_f32(vp(x), nx, ns, vp(taps), 1026, vp(first), dcg, vp(y), vp(ws), None) != 0
+
+
+@pytest.mark.parametrize("nx,ns", [(3, 4100), (4, 9000), (2, 3936 * 2)])
+def test_xcorr_fft_continuation(emu, nx, ns):
+    """d4w_xcorr_fft_cont_f32: the last lags read the head of the next file's rows in place -- the same numbers as
+    correlating the concatenation [x | head] with x's own row statistics and keeping the first ns lags; without a
+    continuation it is d4w_xcorr_fft_f32."""
+    rng = np.random.default_rng(nx * ns)
+    x = (rng.standard_normal((nx, ns)) + 0.3).astype(np.float32)
+    nxt = (rng.standard_normal((nx, 500)) - 0.2).astype(np.float32)             # pitch 500, only the first L - 1 are read
+    t0, t1 = rng.standard_normal(136) * np.hanning(136), rng.standard_normal(156) * np.hanning(156)
+    L = 156
+    lt = 156
+    taps = np.zeros((2, lt), dtype=np.float32)
+    taps[0, :136], taps[1, :156] = t0, t1
+    mean, mx = np.empty(nx, dtype=np.float32), np.empty(nx, dtype=np.float32)
+    assert emu.d4w_row_stats_f32(vp(x), nx, ns, vp(mean), vp(mx), None) == 0
+    emu.d4w_xcorr_fft_ws_bytes.restype = ctypes.c_size_t
+    ws = np.empty(emu.d4w_xcorr_fft_ws_bytes(), dtype=np.uint8)
+
+    def run(xin, n, xn=None, ld=0, nn=0):
+        ys = [np.full((nx, n), np.nan, dtype=np.float32) for _ in range(2)]
+        rc = emu.d4w_xcorr_fft_cont_f32(vp(xin), nx, n, vp(xn) if xn is not None else None, ld, nn, vp(mean), vp(mx), vp(taps), 2,
+                                        lt, 136, 156, vp(ys[0]), vp(ys[1]), vp(ws), None)
+        assert rc == 0, emu.d4w_last_error()
+        return ys
+    cont = run(x, ns, nxt, 500, L - 1)
+    ext = np.ascontiguousarray(np.concatenate((x, nxt[:, :L - 1]), axis=1))
+    ref = run(ext, ns + L - 1)
+    for c, r in zip(cont, ref):
+        assert np.max(np.abs(c - r[:, :ns])) <= 2e-6 * np.max(np.abs(r))
+    plain = run(x, ns)
+    assert not np.array_equal(plain[0][:, -L:], cont[0][:, -L:])                 # the continuation did change the last lags
+    assert np.max(np.abs(plain[0][:, :ns - L] - cont[0][:, :ns - L])) <= 2e-6 * np.max(np.abs(plain[0]))   # same block transform, other tail
+    # float64 ground truth of the last lags of row 0, template 1
+    xa = (np.concatenate((x[0], nxt[0, :L - 1])).astype(np.float64) - float(mean[0])) / float(mx[0])
+    for k in (ns - 1, ns - 77, ns - L + 1):
+        want = float(np.dot(xa[k:k + 156], t1))
+        assert abs(cont[1][0, k] - want) < 1e-5 * np.max(np.abs(ref[1]))
+    assert emu.d4w_xcorr_fft_cont_f32(vp(x), nx, ns, vp(nxt), 500, L - 1, vp(mean), vp(mx), vp(taps), 1, lt, 136, 136,
+                                      vp(cont[0]), None, vp(ws), None) != 0      # one template: no continuation form
