@@ -87,6 +87,8 @@ def _load():
         "d4w_fir_fft_max_halfwidth": (c_int, []),
         "d4w_fir_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_double, c_void_p, c_void_p,
                                     c_void_p]),
+        "d4w_fir_fft_halo_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                         c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
         "d4w_analytic_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_analytic_row_fits_lds": (c_int, [c_int]),
         "d4w_analytic_long_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),

@@ -141,12 +141,20 @@ __device__ __forceinline__ void xf_st(float4* p, c2 v) {
 // last read of the spectrum from the first write).  Same registers and code size as the one-template
 // kernel, same 8 waves per CU (two 76 KiB workgroups), 3 instead of 4 transforms per row block and
 // 12 instead of 16 bytes of HBM traffic per sample.
+// A row seen through its neighbours (d4w_fir_fft_halo_f32): virtual samples [left (n_left) | the row (ns) | right (n_right)];
+// lag / sample index i of the kernel is virtual sample v0 + i.  All zero = the plain row.
+struct XfHalo {
+    const float* left;      // [nx][ld_left], the n_left samples before the row (NULL: zeros)
+    const float* right;     // [nx][ld_right], the n_right samples after it (NULL: zeros)
+    int ld_left, n_left, ld_right, n_right, v0;
+};
+
 template <int NT, bool FUSED>
 __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
                                                                   int ns, const float* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1,
-                                                                  int step, int yshift, int ns_out, float dcg) {
+                                                                  int step, int yshift, int ns_out, float dcg, XfHalo H) {
     // step = lags kept per block (B - (support - 1)); lags k < ns_out are stored, lag k at column k + yshift of its row
     // (the zero-phase FIR use, d4w_fir_fft_f32: taps centred at yshift); dcg: mean[row] * dcg is added to every output
     // (the gain the subtracted constant would have had)
@@ -181,8 +189,9 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
         gb_ = (b > 0.f) ? 1.0f / b : 0.f;
     }
     const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
-    const bool veca = ((((size_t)rowA * ns + k0) & 1) == 0), vecb = ((((size_t)rowB * ns + k0) & 1) == 0);
-    const bool interior = (k0 + kXfB <= ns) && veca && vecb;   // whole block inside both rows, 8-byte aligned pairs
+    const int c0 = H.v0 + k0 - H.n_left;                         // the block's first sample in the row's own coordinates
+    const bool veca = ((((long long)rowA * ns + c0) & 1) == 0), vecb = ((((long long)rowB * ns + c0) & 1) == 0);
+    const bool interior = (c0 >= 0) && (c0 + kXfB <= ns) && veca && vecb;   // whole block inside both rows, 8-byte aligned pairs
     // NT templates per launch: the host launches NT = 1 once per template.  Measured at 20000 x 120000
     // (HF + LF): two NT = 1 launches 9.1 ms; one NT = 2 launch 11.2 ms (57 KiB of straight-line code
     // against a 64 KiB instruction cache shared by two CUs), 11.6 ms when the block spectrum is kept
@@ -204,22 +213,30 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
         c2 pf[NA];
         {
             const int j1 = tid;
-            auto fetch = [&](const float* xr, float mu, bool vec, int i) -> float2 {
-                float2 v = make_float2(0.f, 0.f);
-                if (vec && i + 1 < ns) {
-                    v = *reinterpret_cast<const float2*>(xr + i);
+            // sample c of the row in its own coordinates; outside [0, ns) the neighbours' halos (de-meaned alike), then zeros
+            auto sample = [&](const float* xr, int row, float mu, int c) -> float {
+                if (c < 0) {
+                    const int l = c + H.n_left;
+                    return (H.left && l >= 0) ? H.left[(size_t)row * H.ld_left + l] - mu : 0.f;
+                }
+                if (c < ns) return xr[c] - mu;
+                const int rr = c - ns;
+                return (H.right && rr < H.n_right) ? H.right[(size_t)row * H.ld_right + rr] - mu : 0.f;
+            };
+            auto fetch = [&](const float* xr, int row, float mu, bool vec, int i) -> float2 {
+                const int c = i + H.v0 - H.n_left;
+                if (vec && c >= 0 && c + 1 < ns) {
+                    float2 v = *reinterpret_cast<const float2*>(xr + c);
                     v.x -= mu;
                     v.y -= mu;
-                } else {
-                    if (i < ns) v.x = xr[i] - mu;
-                    if (i + 1 < ns) v.y = xr[i + 1] - mu;
+                    return v;
                 }
-                return v;
+                return make_float2(sample(xr, row, mu, c), sample(xr, row, mu, c + 1));
             };
             if (!fwd) {
             } else if (interior) {
-                const float2* pa = reinterpret_cast<const float2*>(xa + k0) + j1;
-                const float2* pb = reinterpret_cast<const float2*>(xb + k0) + j1;
+                const float2* pa = reinterpret_cast<const float2*>(xa + c0) + j1;
+                const float2* pb = reinterpret_cast<const float2*>(xb + c0) + j1;
                 const v2f mu2 = v2_make(mua, mub);
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
                     const int i = k0 + 2 * (j1 + a * M1);
-                    pf[a] = c2_make(fetch(xa, mua, veca, i), fetch(xb, mub, vecb, i));
+                    pf[a] = c2_make(fetch(xa, rowA, mua, veca, i), fetch(xb, rowB, mub, vecb, i));
                 });
             }
         }
@@ -1067,7 +1084,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,
-                   kXfStep, 0, ns, 0.f);
+                   kXfStep, 0, ns, 0.f, XfHalo{});
         return D4W_OK;
     }
     for (int t = 0; t < ntpl; ++t) {
@@ -1075,7 +1092,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
         D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
-                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f);
+                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{});
     }
     return D4W_OK;
 }
@@ -1112,7 +1129,41 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 #endif
     D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
-               (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain);
+               (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain, XfHalo{});
+    return D4W_OK;
+}
+
+int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int ld_left, int n_left, const float* right,
+                         int ld_right, int n_right, const float* taps, int K, const float* first, double dc_gain, float* y,
+                         void* ws, void* stream) {
+    if (!x || !taps || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (K < 0 || (K & 1) || K > d4w_fir_fft_max_halfwidth()) return fail(D4W_EINVAL, "half width %d must be even and <= %d", K, d4w_fir_fft_max_halfwidth());
+    if ((left && (n_left < K || ld_left < n_left)) || (right && (n_right < K || ld_right < n_right)) || (!left && n_left) || (!right && n_right))
+        return fail(D4W_EINVAL, "a halo holds at least the half width (%d) samples per row (n_left = %d, n_right = %d)", K, n_left, n_right);
+    if (!left || !right) return fail(D4W_EINVAL, "both halos are needed: a row end without a neighbour is d4w_sosfiltfilt_f32's edge rule");
+    if (nx > 2 * 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
+    float* w = (float*)ws;
+    XfTables T;
+    float2* gp = (float2*)w;
+    float* gn = w + 2 * 2 * kXfMB;
+    float2* tw1 = (float2*)(gn + 8);
+    float2* tw2 = tw1 + kXfM1;
+    float2* wg = tw2 + kXfM1;
+    float2* twa = wg + kXfNG;
+    T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg; T.twa = twa;
+    const int L = 2 * K + 1;
+    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
+               tw1, tw2, wg, twa);
+    const int step = kXfB - 2 * K;
+    const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+#ifndef D4W_EMU
+    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+#endif
+    // lag k of the virtual row starting K samples before the row = output sample k of the row
+    XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
+    D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
+               (float*)nullptr, step, 0, ns, (float)dc_gain, H);
     return D4W_OK;
 }
 

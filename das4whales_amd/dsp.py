@@ -352,22 +352,12 @@ def _sosfiltfilt_fft(x, sos, padlen):
     if os.environ.get("D4W_BP_FFT", "1") == "0":
         return None
     nx, ns = x.shape
-    key = (sos.tobytes(), sos.shape, str(x.device))
-    zp = _zp_cache.get(key)
+    zp = _zero_phase_taps(sos, x.device)
     if zp is None:
-        if len(_zp_cache) > 16:
-            _zp_cache.clear()
-        r = _zero_phase_response(sos, tol_taps=1e-7)
-        if r is not None:
-            taps, K, E = r
-            r = (torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(x.device), K, E,
-                 float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2)
-        zp = _zp_cache[key] = r or ()
-    if not zp:
         return None
     t, K, E, dcg = zp
     P = 2 * E                                        # piece length: E kept + E for the artificial cut to decay
-    if K > int(lib.d4w_fir_fft_max_halfwidth()) or ns < 24 * P or P <= padlen:
+    if ns < 24 * P or P <= padlen:
         return None
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
@@ -381,6 +371,51 @@ def _sosfiltfilt_fft(x, sos, padlen):
         ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
         y[:, :E] = ye[:nx, :E]
         y[:, ns - E:] = ye[nx:, P - E:]
+    return y
+
+
+def _zero_phase_taps(sos, device):
+    """(taps tensor, K, E, dc gain) of the truncated zero-phase response of `sos` on `device`, cached; None when the
+    response is too long for one FFT block."""
+    key = (sos.tobytes(), sos.shape, str(device))
+    zp = _zp_cache.get(key)
+    if zp is None:
+        if len(_zp_cache) > 16:
+            _zp_cache.clear()
+        r = _zero_phase_response(sos, tol_taps=1e-7)
+        if r is not None:
+            taps, K, E = r
+            r = (torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(device), K, E,
+                 float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2)
+        zp = _zp_cache[key] = r or ()
+    if not zp or zp[1] > int(lib.d4w_fir_fft_max_halfwidth()):
+        return None
+    return zp
+
+
+def _sosfiltfilt_between(x, left, right, sos):
+    """Zero-phase filter of rows that continue on both sides: x [nx, ns] with the samples before (left [nx, >= K], its LAST
+    columns adjacent to x) and after (right [nx, >= K]) read in place by ONE overlap-save pass (d4w_fir_fft_halo_f32,
+    8 B per sample, no concatenation).  Equal to filtering the concatenated record, to the 1e-7 truncation of the
+    response.  Returns None when the form does not apply (response too long, halos shorter than its half width)."""
+    sos = np.ascontiguousarray(np.atleast_2d(np.asarray(sos, dtype=np.float64)))
+    zp = _zero_phase_taps(sos, x.device)
+    if zp is None:
+        return None
+    t, K, E, dcg = zp
+    ok = lambda h: dev.is_tensor(h) and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.stride(1) == 1 \
+        and h.shape[0] == x.shape[0] and h.shape[1] >= K
+    if not (ok(left) and ok(right) and x.is_contiguous()):
+        return None
+    nx, ns = x.shape
+    lv = left[:, left.shape[1] - K:]                     # views: the kernel takes a base pointer and a row pitch
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        first = x[:, 0].contiguous()
+        ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
+        check(lib.d4w_fir_fft_halo_f32(dev.ptr(x), nx, ns, lv.data_ptr(), int(left.stride(0)), int(K), right.data_ptr(),
+                                       int(right.stride(0)), int(K), dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
+                                       dev.ptr(ws), dev.stream_ptr(x)))
     return y
 
 

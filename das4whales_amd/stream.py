@@ -55,6 +55,12 @@ class FileStream:
         import scipy.signal as sp
         if self._sos is None:
             self._sos = sp.butter(8, [self.fmin / (self.fs / 2), self.fmax / (self.fs / 2)], "bp", output="sos")
+        if left is not None and right is not None:
+            # a file between two others: one overlap-save pass that reads the halos in place (no concatenated copy, no
+            # cropped copy; the halo is longer than the filter's truncated response)
+            y = dsp._sosfiltfilt_between(cur if cur.is_contiguous() else cur.contiguous(), left, right, self._sos)
+            if y is not None:
+                return y
         parts = [p for p in (left, cur, right) if p is not None]
         ext = torch.cat(parts, dim=1) if len(parts) > 1 else cur
         y = dsp._sosfiltfilt_device(ext.contiguous(), self._sos, 51)

@@ -273,6 +273,14 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
 int d4w_fir_fft_max_halfwidth(void);
 int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
                     float* y, void* ws, void* stream);
+/* The same for a row that has neighbours on both sides (consecutive files of one record, das4whales_amd/stream.py):
+ * left [nx][ld_left] holds the n_left samples before every row, right [nx][ld_right] the n_right samples after it
+ * (n_left, n_right >= K), read in place -- no concatenated copy -- and ALL ns columns of y are written:
+ *   y[r][n] = sum_j taps[j] xv[r][n - K + j],   xv = [left | x | right].
+ * The row ends of a record (no neighbour) keep filtfilt's edge rule: d4w_sosfiltfilt_f32. */
+int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int ld_left, int n_left,
+                         const float* right, int ld_right, int n_right, const float* taps, int K,
+                         const float* first, double dc_gain, float* y, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * f-k mask design on the device (one-off per shape), float32 masks on the fftshift-ed (k, f)

@@ -361,3 +361,38 @@ def test_xcorr_fft_continuation(emu, nx, ns):
         assert abs(cont[1][0, k] - want) < 1e-5 * np.max(np.abs(ref[1]))
     assert emu.d4w_xcorr_fft_cont_f32(vp(x), nx, ns, vp(nxt), 500, L - 1, vp(mean), vp(mx), vp(taps), 1, lt, 136, 136,
                                       vp(cont[0]), None, vp(ws), None) != 0      # one template: no continuation form
+
+
+@pytest.mark.parametrize("nx,ns,K,nl,nr", [(3, 5000, 100, 100, 130), (4, 4096 - 200, 100, 256, 100), (5, 9001, 462, 1024, 1024),
+                                            (2, 300, 60, 64, 61)])
+def test_fir_fft_between_neighbours(emu, nx, ns, K, nl, nr):
+    """d4w_fir_fft_halo_f32: a row with neighbours on both sides -- every column of y, the halos read in place from
+    pitched buffers (the left halo's LAST K columns, the right halo's first), equal to the FIR over the concatenation."""
+    rng = np.random.default_rng(ns + K)
+    x = (rng.standard_normal((nx, ns)) + np.arange(nx)[:, None] * 20.0).astype(np.float32)
+    left = (rng.standard_normal((nx, nl + 7)) + np.arange(nx)[:, None] * 20.0).astype(np.float32)     # pitch nl + 7
+    right = (rng.standard_normal((nx, nr + 3)) + np.arange(nx)[:, None] * 20.0).astype(np.float32)
+    taps = rng.standard_normal(2 * K + 1) * np.hanning(2 * K + 3)[1:-1]
+    taps = ((taps + taps[::-1]) / 2).astype(np.float32)
+    first = np.ascontiguousarray(x[:, 0])
+    y = np.full((nx, ns), np.nan, dtype=np.float32)
+    emu.d4w_xcorr_fft_ws_bytes.restype = ctypes.c_size_t
+    ws = np.empty(emu.d4w_xcorr_fft_ws_bytes(), dtype=np.uint8)
+    cv, ci = ctypes.c_void_p, ctypes.c_int
+    emu.d4w_fir_fft_halo_f32.argtypes = [cv, ci, ci, cv, ci, ci, cv, ci, ci, cv, ci, cv, ctypes.c_double, cv, cv, cv]
+    dcg = float(taps.astype(np.float64).sum())
+    lview = left[:, 7:]                                     # the nl samples adjacent to the row
+    rc = emu.d4w_fir_fft_halo_f32(vp(x), nx, ns, lview.ctypes.data, left.shape[1], nl, vp(right), right.shape[1], nr, vp(taps), K,
+                                  vp(first), dcg, vp(y), vp(ws), None)
+    assert rc == 0, emu.d4w_last_error()
+    assert not np.isnan(y).any()
+    xv = np.concatenate((lview, x, right[:, :nr]), axis=1).astype(np.float64)
+    full = np.stack([np.convolve(r, taps.astype(np.float64)[::-1], "valid") for r in xv])       # index m <-> centre m + K of xv
+    ref = full[:, nl - K: nl - K + ns]
+    assert ref.shape == y.shape
+    assert np.max(np.abs(y - ref)) < 1e-5 * np.max(np.abs(ref))
+    # halos shorter than the half width, or a missing side: refused
+    assert emu.d4w_fir_fft_halo_f32(vp(x), nx, ns, lview.ctypes.data, left.shape[1], K - 1, vp(right), right.shape[1], nr, vp(taps),
+                                    K, vp(first), dcg, vp(y), vp(ws), None) != 0
+    assert emu.d4w_fir_fft_halo_f32(vp(x), nx, ns, None, 0, 0, vp(right), right.shape[1], nr, vp(taps), K, vp(first), dcg, vp(y),
+                                    vp(ws), None) != 0
