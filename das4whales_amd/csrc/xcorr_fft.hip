@@ -1007,7 +1007,7 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
 int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const float* mean,
                            const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                            float* y1, void* ws, void* stream) {
-    if (!x || !taps || !y0 || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (!x || !y0 || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (xnext && (ntpl != 2 || n_next < 0 || ld_next < n_next))
         return fail(D4W_EINVAL, "a continuation needs two templates (the fused kernel) and 0 <= n_next <= ld_next");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
@@ -1024,8 +1024,11 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     float2* wg = tw2 + kXfM1;
     float2* twa = wg + kXfNG;
     T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg; T.twa = twa;
-    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(ntpl * kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, ntpl,
-               ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
+    // taps == NULL: ws still holds the tables a previous call built for the same templates (same ntpl, supports and kernel
+    // selection) -- a stream of files pays the template spectra once
+    if (taps)
+        D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(ntpl * kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, ntpl,
+                   ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
 #ifndef D4W_EMU
@@ -1066,8 +1069,9 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
         float2* qg = q3 + 8 * 4;
         int2* qp = reinterpret_cast<int2*>(qg + kX4NG);
         Q.gp = gp4; Q.gn = gn; Q.tw1 = q1; Q.tw2 = q2; Q.tw3 = q3; Q.wg = qg; Q.pairs = qp;
-        D4W_LAUNCH(xcf_tables4, dim3(ceil_div(2 * kXfMB, 256)), dim3(256), 0, stream, taps, ltaps, len0, len1, gp4, gn, q1, q2,
-                   q3, qg, qp);
+        if (taps)
+            D4W_LAUNCH(xcf_tables4, dim3(ceil_div(2 * kXfMB, 256)), dim3(256), 0, stream, taps, ltaps, len0, len1, gp4, gn, q1, q2,
+                       q3, qg, qp);
         const size_t lds4 = 2 * (size_t)kX4RowP * sizeof(float4) + (256 + 32) * sizeof(float2);
 #ifndef D4W_EMU
         static bool attr4 = false;
@@ -1106,7 +1110,7 @@ int d4w_fir_fft_max_halfwidth(void) { return (kXfB - 2048) / 2; }
 
 int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
                     float* y, void* ws, void* stream) {
-    if (!x || !taps || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (!x || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (K < 0 || (K & 1) || K > d4w_fir_fft_max_halfwidth()) return fail(D4W_EINVAL, "half width %d must be even and <= %d", K, d4w_fir_fft_max_halfwidth());
     if (ns <= 2 * K) return fail(D4W_EINVAL, "rows of %d samples have no interior for a half width of %d", ns, K);
     if (nx > 2 * 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
@@ -1120,8 +1124,9 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
     float2* twa = wg + kXfNG;
     T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg; T.twa = twa;
     const int L = 2 * K + 1;
-    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
-               tw1, tw2, wg, twa);
+    if (taps)                                                    // NULL: ws holds the tables of a previous call with these taps
+        D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
+                   tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns - 2 * K, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
@@ -1136,7 +1141,7 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
 int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int ld_left, int n_left, const float* right,
                          int ld_right, int n_right, const float* taps, int K, const float* first, double dc_gain, float* y,
                          void* ws, void* stream) {
-    if (!x || !taps || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (!x || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (K < 0 || (K & 1) || K > d4w_fir_fft_max_halfwidth()) return fail(D4W_EINVAL, "half width %d must be even and <= %d", K, d4w_fir_fft_max_halfwidth());
     if ((left && (n_left < K || ld_left < n_left)) || (right && (n_right < K || ld_right < n_right)) || (!left && n_left) || (!right && n_right))
         return fail(D4W_EINVAL, "a halo holds at least the half width (%d) samples per row (n_left = %d, n_right = %d)", K, n_left, n_right);
@@ -1152,8 +1157,9 @@ int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int 
     float2* twa = wg + kXfNG;
     T.gp = gp; T.gn = gn; T.tw1 = tw1; T.tw2 = tw2; T.wg = wg; T.twa = twa;
     const int L = 2 * K + 1;
-    D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
-               tw1, tw2, wg, twa);
+    if (taps)                                                    // NULL: ws holds the tables of a previous call with these taps
+        D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
+                   tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);

@@ -56,6 +56,25 @@ def _taps_tensor(taps_list, device):
     return torch.from_numpy(taps).to(device), lt
 
 
+_xf_tables = {}     # (templates, device, stream) -> [taps tensor, lt, workspace, tables built]
+
+
+def _xf_prepared(grp, device):
+    """Device taps + the overlap-save workspace of a template group, kept per (templates, device, stream): the second
+    call with the same templates on the same stream finds the template spectra already in the workspace (taps = NULL
+    in d4w_xcorr_fft_cont_f32) and uploads nothing."""
+    key = (tuple(np.asarray(t, dtype=np.float64).tobytes() for t in grp), str(device),
+           int(torch.cuda.current_stream(device).cuda_stream))
+    ent = _xf_tables.get(key)
+    if ent is None:
+        if len(_xf_tables) > 32:
+            _xf_tables.clear()
+        taps, lt = _taps_tensor(grp, device)
+        ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device)
+        ent = _xf_tables[key] = [taps, lt, ws, False]
+    return ent
+
+
 def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None):
     """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
     method: "fft" (overlap-save, supports <= 161 samples), "direct", or "auto" (fft when it applies).
@@ -81,21 +100,23 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
             check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))
         for i in range(0, len(taps_list), 2):                      # two templates per read of x
             grp = taps_list[i:i + 2]
-            taps, lt = _taps_tensor(grp, x.device)
             ys = [torch.empty_like(x) for _ in grp]
             if use_fft:
-                ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
+                ent = _xf_prepared(grp, x.device)
+                taps, lt, ws, built = ent
                 check(lib.d4w_xcorr_fft_cont_f32(dev.ptr(x), nx, ns,
                                                  dev.ptr(cont[0]) if cont is not None else None,
                                                  int(cont[0].stride(0)) if cont is not None else 0,
                                                  int(cont[1]) if cont is not None else 0,
                                                  dev.ptr(mean) if normalize else None,
-                                                 dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
+                                                 dev.ptr(mx) if normalize else None, None if built else dev.ptr(taps), len(grp), lt,
                                                  len(grp[0]), len(grp[-1]),
                                                  dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
                                                  dev.ptr(ws), dev.stream_ptr(x)))
+                ent[3] = True
                 outs.extend(ys)
                 continue
+            taps, lt = _taps_tensor(grp, x.device)
             check(lib.d4w_xcorr_lens_f32(dev.ptr(x), nx, ns, dev.ptr(mean) if normalize else None,
                                          dev.ptr(mx) if normalize else None, dev.ptr(taps), len(grp), lt,
                                          len(grp[0]), len(grp[-1]),

@@ -362,9 +362,10 @@ def _sosfiltfilt_fft(x, sos, padlen):
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
         first = x[:, 0].contiguous()
-        ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
-        check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y), dev.ptr(ws),
-                                  dev.stream_ptr(x)))
+        ent = _fir_workspace(t, x.device)
+        check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, None if ent[1] else dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
+                                  dev.ptr(ent[0]), dev.stream_ptr(x)))
+        ent[1] = True
         # the row ends: the left and the right piece of every row as one [2 nx, P] block (filtfilt's edge rule is not
         # symmetric under time reversal, so the right pieces stay in natural order and keep their LAST E outputs)
         ends = torch.cat((x[:, :P], x[:, ns - P:]), dim=0)
@@ -393,6 +394,21 @@ def _zero_phase_taps(sos, device):
     return zp
 
 
+_fir_ws = {}        # (taps tensor id, stream) -> [workspace, tables built]
+
+
+def _fir_workspace(t, device):
+    """Overlap-save workspace of a cached taps tensor per stream: after the first call it holds the taps' block spectrum
+    and the next calls pass taps = NULL (include/d4w.h)."""
+    key = (id(t), int(torch.cuda.current_stream(device).cuda_stream))
+    ent = _fir_ws.get(key)
+    if ent is None or ent[2] is not t:
+        if len(_fir_ws) > 32:
+            _fir_ws.clear()
+        ent = _fir_ws[key] = [torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device), False, t]
+    return ent
+
+
 def _sosfiltfilt_between(x, left, right, sos):
     """Zero-phase filter of rows that continue on both sides: x [nx, ns] with the samples before (left [nx, >= K], its LAST
     columns adjacent to x) and after (right [nx, >= K]) read in place by ONE overlap-save pass (d4w_fir_fft_halo_f32,
@@ -412,10 +428,11 @@ def _sosfiltfilt_between(x, left, right, sos):
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
         first = x[:, 0].contiguous()
-        ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=x.device)
+        ent = _fir_workspace(t, x.device)
         check(lib.d4w_fir_fft_halo_f32(dev.ptr(x), nx, ns, lv.data_ptr(), int(left.stride(0)), int(K), right.data_ptr(),
-                                       int(right.stride(0)), int(K), dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
-                                       dev.ptr(ws), dev.stream_ptr(x)))
+                                       int(right.stride(0)), int(K), None if ent[1] else dev.ptr(t), int(K), dev.ptr(first),
+                                       dcg, dev.ptr(y), dev.ptr(ent[0]), dev.stream_ptr(x)))
+        ent[1] = True
     return y
 
 

@@ -248,6 +248,9 @@ int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, con
  * the direct form, bound by HBM instead of the vector ALUs.  Same arguments and result as
  * d4w_xcorr_lens_f32 (agreement to float32 rounding); ws = DEVICE scratch of
  * d4w_xcorr_fft_ws_bytes() bytes (template spectra, rebuilt per call on `stream`). */
+/* taps may be NULL in d4w_xcorr_fft_cont_f32 / d4w_fir_fft_f32 / d4w_fir_fft_halo_f32 when `ws` still holds the tables a
+ * previous call on the same stream built from the same taps (same supports / half width): consecutive files of a record
+ * then pay the template spectra once. */
 int d4w_xcorr_fft_max_support(void);
 size_t d4w_xcorr_fft_ws_bytes(void);
 int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
