@@ -462,19 +462,43 @@ __global__ __launch_bounds__(kSpThreads) void stft_fat(RowFftDev F, StftDims d, 
     float* win = reinterpret_cast<float*>(twl + N);                   // [N]
     float* seg = win + N;
     const int seg_len = (d.FT - 1) * d.hop + N;
-    const int t0 = blockIdx.x * d.FT;
-    const int s0 = t0 * d.hop - N / 2;
     const float* xr = x + (size_t)blockIdx.y * d.ns;
-    for (int j = tid; j < seg_len; j += kSpThreads) {
-        const int s = s0 + j;
-        seg[j] = (s >= 0 && s < d.ns) ? xr[s] : 0.f;
-    }
     for (int i = tid; i < N; i += kSpThreads) {
         const int k1 = i / RB, j = i - k1 * RB;
         twl[i] = F.wfull[(j * k1) % N];
         win[i] = F.hann[i];
     }
+    float mx = 0.f;
+    // a workgroup walks several frame tiles of its row: the twiddle / window tables are staged once, and a long record
+    // is a few thousand workgroups instead of half a million
+    const int ntiles = (d.nframes + d.FT - 1) / d.FT;
+    // the samples of the NEXT tile travel in registers while this one is transformed (kSegPer per lane; longer segments --
+    // large hops -- load the remainder directly)
+    constexpr int kSegPer = 4;
+    float nxt[kSegPer];
+    auto seg_fetch = [&](int tile) {
+        const int s0 = tile * d.FT * d.hop - N / 2;
+#pragma unroll
+        for (int k = 0; k < kSegPer; ++k) {
+            const int j = tid + k * kSpThreads, sidx = s0 + j;
+            nxt[k] = (j < seg_len && sidx >= 0 && sidx < d.ns) ? xr[sidx] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) seg_fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int t0 = tile * d.FT;
+    const int s0 = t0 * d.hop - N / 2;
+#pragma unroll
+    for (int k = 0; k < kSegPer; ++k) {
+        const int j = tid + k * kSpThreads;
+        if (j < seg_len) seg[j] = nxt[k];
+    }
+    for (int j = tid + kSegPer * kSpThreads; j < seg_len; j += kSpThreads) {
+        const int sidx = s0 + j;
+        seg[j] = (sidx >= 0 && sidx < d.ns) ? xr[sidx] : 0.f;
+    }
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) seg_fetch(tile + gridDim.x);
     for (int it = tid; it < nb * RB; it += kSpThreads) {              // S1
         const int b = it / RB, j = it - b * RB;
         const float* sa = seg + 2 * b * d.hop + j;
@@ -504,7 +528,6 @@ __global__ __launch_bounds__(kSpThreads) void stft_fat(RowFftDev F, StftDims d, 
     __syncthreads();
     // Z[k] of transform b sits at buf[b][(k % RA)][k / RA]
     const int klo = rowmax ? 0 : d.b_lo, khi = rowmax ? N / 2 : d.b_hi, nk = khi - klo + 1, nkeep = d.b_hi - d.b_lo + 1;
-    float mx = 0.f;
     for (int w = tid; w < nk * nb; w += kSpThreads) {
         const int kk = w / nb, b = w - kk * nb, k = klo + kk;
         const int tA = t0 + 2 * b;
@@ -523,6 +546,8 @@ __global__ __launch_bounds__(kSpThreads) void stft_fat(RowFftDev F, StftDims d, 
             o[0] = ma;
             if (hasB) o[1] = mb;
         }
+    }
+    __syncthreads();                                              // seg / buf are refilled by the next tile
     }
     if (rowmax) {
 #pragma unroll
@@ -1316,7 +1341,10 @@ int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, in
                                 ((size_t)n_fft + (size_t)(d.FT - 1) * hop + n_fft) * sizeof(float);
             if (ldsf <= kSpLdsMax) {
                 if (rowmax) D4W_HIP(hipMemsetAsync(rowmax, 0, (size_t)nx * sizeof(float), (hipStream_t)stream));
-                const dim3 gridf(ceil_div(d.nframes, d.FT), nx);
+                // tiles per row walked by min(tiles, ~8192 / nx) workgroups (one per row for a whole file, all tiles in parallel
+                // for a single channel)
+                const int ntile = ceil_div(d.nframes, d.FT);
+                const dim3 gridf(std::max(1, std::min(ntile, 8192 / std::max(nx, 1))), nx);
 #define D4W_FAT(A_, B_)                                                                                             \
     do {                                                                                                            \
         sp_allow_lds(stft_fat<A_, B_>, ldsf);                                                                       \
