@@ -149,7 +149,7 @@ struct XfHalo {
     int ld_left, n_left, ld_right, n_right, v0;
 };
 
-template <int NT, bool FUSED>
+template <int NT, bool FUSED, bool HALO = false>      // HALO: a separate instantiation, the plain kernels keep their code
 __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
                                                                   int ns, const float* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
         gb_ = (b > 0.f) ? 1.0f / b : 0.f;
     }
     const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
-    const int c0 = H.v0 + k0 - H.n_left;                         // the block's first sample in the row's own coordinates
+    const int c0 = HALO ? H.v0 + k0 - H.n_left : k0;             // the block's first sample in the row's own coordinates
     const bool veca = ((((long long)rowA * ns + c0) & 1) == 0), vecb = ((((long long)rowB * ns + c0) & 1) == 0);
-    const bool interior = (c0 >= 0) && (c0 + kXfB <= ns) && veca && vecb;   // whole block inside both rows, 8-byte aligned pairs
+    const bool interior = (!HALO || c0 >= 0) && (c0 + kXfB <= ns) && veca && vecb;   // whole block inside both rows, 8-byte aligned pairs
     // NT templates per launch: the host launches NT = 1 once per template.  Measured at 20000 x 120000
     // (HF + LF): two NT = 1 launches 9.1 ms; one NT = 2 launch 11.2 ms (57 KiB of straight-line code
     // against a 64 KiB instruction cache shared by two CUs), 11.6 ms when the block spectrum is kept
@@ -215,17 +215,17 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
             const int j1 = tid;
             // sample c of the row in its own coordinates; outside [0, ns) the neighbours' halos (de-meaned alike), then zeros
             auto sample = [&](const float* xr, int row, float mu, int c) -> float {
-                if (c < 0) {
+                if (HALO && c < 0) {
                     const int l = c + H.n_left;
                     return (H.left && l >= 0) ? H.left[(size_t)row * H.ld_left + l] - mu : 0.f;
                 }
                 if (c < ns) return xr[c] - mu;
                 const int rr = c - ns;
-                return (H.right && rr < H.n_right) ? H.right[(size_t)row * H.ld_right + rr] - mu : 0.f;
+                return (HALO && H.right && rr < H.n_right) ? H.right[(size_t)row * H.ld_right + rr] - mu : 0.f;
             };
             auto fetch = [&](const float* xr, int row, float mu, bool vec, int i) -> float2 {
-                const int c = i + H.v0 - H.n_left;
-                if (vec && c >= 0 && c + 1 < ns) {
+                const int c = HALO ? i + H.v0 - H.n_left : i;
+                if (vec && (!HALO || c >= 0) && c + 1 < ns) {
                     float2 v = *reinterpret_cast<const float2*>(xr + c);
                     v.x -= mu;
                     v.y -= mu;
@@ -737,6 +737,7 @@ __global__ __launch_bounds__(256) void xcf_tables4(const float* __restrict__ tap
     }
 }
 
+template <bool CONT>      // CONT: the rows continue in xnext (a separate instantiation: the plain kernel keeps its registers)
 __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, const float* __restrict__ x, int nx, int ns,
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ maxabs,
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
         // de-meaned like the row's own samples, then zeros
         auto sample = [&](const float* xr, const float* xn, float mu, int i) -> float {
             if (i < ns) return xr[i] - mu;
-            if (xn && i - ns < n_next) return xn[i - ns] - mu;
+            if (CONT && i - ns < n_next) return xn[i - ns] - mu;
             return 0.f;
         };
         auto fetch = [&](const float* xr, const float* xn, float mu, bool vec, int i) -> float2 {
@@ -795,8 +796,8 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
             }
             return make_float2(sample(xr, xn, mu, i), sample(xr, xn, mu, i + 1));
         };
-        const float* xna = xnext ? xnext + (size_t)rowA * ld_next : nullptr;
-        const float* xnb = xnext ? xnext + (size_t)rowB * ld_next : nullptr;
+        const float* xna = CONT ? xnext + (size_t)rowA * ld_next : nullptr;
+        const float* xnb = CONT ? xnext + (size_t)rowB * ld_next : nullptr;
         if (interior) {
             const float2* pa = reinterpret_cast<const float2*>(xa + k0) + tid;
             const float2* pb = reinterpret_cast<const float2*>(xb + k0) + tid;
@@ -1076,12 +1077,17 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
 #ifndef D4W_EMU
         static bool attr4 = false;
         if (!attr4) {
-            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             attr4 = true;
         }
 #endif
-        D4W_LAUNCH(xcorr_fft_fused4, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1, xnext, ld_next,
-                   n_next);
+        if (xnext)
+            D4W_LAUNCH(xcorr_fft_fused4<true>, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1, xnext,
+                       ld_next, n_next);
+        else
+            D4W_LAUNCH(xcorr_fft_fused4<false>, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1,
+                       (const float*)nullptr, 0, 0);
         return D4W_OK;
     }
     if (xnext) return fail(D4W_EINVAL, "a continuation runs the four-stage fused kernel only (D4W_XF_FUSED / D4W_XF_TPAIR are set)");
@@ -1164,11 +1170,11 @@ int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int 
     const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
 #ifndef D4W_EMU
-    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 #endif
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
-    D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
+    D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
                (float*)nullptr, step, 0, ns, (float)dc_gain, H);
     return D4W_OK;
 }

@@ -29,3 +29,10 @@ rm -rf $O/prof
 BENCH_ARGS="--stages bp,fk,mf --no-dense" PMC_GROUPS="fetch write" bash scripts/pmc.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
 cp $O/pmc/summary.txt $O/pmc_fetch_write_summary.txt; cp $O/pmc/pmc_traffic.json $O/pmc_traffic.json; rm -rf $O/pmc
 timeout 900 python scripts/cpu_baseline_c1.py > $O/cpu_baseline_c1.json 2>/dev/null; cut -c1-300 $O/cpu_baseline_c1.json
+timeout 300 python scripts/time_picks3.py 2>/dev/null | grep -E "^\{|find_peaks" > $O/time_picks.txt; head -2 $O/time_picks.txt | cut -c1-300
+timeout 300 python scripts/time_stft.py 2>/dev/null | grep "^{" > $O/time_stft.txt; cat $O/time_stft.txt
+timeout 300 python scripts/time_bp_parts.py 2>/dev/null | grep "^{" > $O/time_bp_parts.txt
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o st -- python $R/bench.py --config stream --files 8 --steps 16 --warmup 2 > $R/$O/rocprof_stream.log 2>&1
+cd $R
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_stream.csv
+rm -rf $O/prof

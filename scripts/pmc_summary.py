@@ -38,7 +38,7 @@ if "--traffic" in sys.argv:
             name = "fk_passC_inv" if targ.strip().startswith("true") else "fk_passC_fwd"
         name = {"fkf_passA_fwd": "fk_passA_fwd", "fkf_passA_inv": "fk_passA_inv", "fkf_passA_inv_stats": "fk_passA_inv",
                 "fkf_passB": "fk_passB"}.get(name, name)
-        if (name == "xcorr_fft_blocks" and ", true>" in k) or name == "xcorr_fft_fused4":
+        if (name == "xcorr_fft_blocks" and "<1, true" in k) or name == "xcorr_fft_fused4":
             name = "xcorr_fft_fused"                    # the two-template launch (one read, two correlograms)
         name = alias.get(name, name)
         # gfx950: FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM), so kernels whose reads
