@@ -413,7 +413,9 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        import datetime
+        # a rank that dies must not leave the others waiting for the default half hour
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
     if args.config == "stream":
         return bench_stream(args, world, rank, device, dist)
     args.nx = args.nx or 20000
