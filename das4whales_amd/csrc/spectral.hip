@@ -946,6 +946,7 @@ __device__ __forceinline__ void fp_summaries1(const float* __restrict__ r, const
 
 // stage the row into LDS and form the 32-sample block summaries in the same sweep: a lane loads four consecutive
 // samples (16 bytes), eight neighbouring lanes cover one block and reduce with three shuffle steps
+template <bool STORE>     // STORE: keep the row in T.rowl (rows that fit); otherwise only the summaries are formed
 __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, const FpLds& T, int ns, int nb, int tid) {
     const int ns4 = ns >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(rg);
@@ -963,7 +964,7 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
             const int v4 = base + k * kFpThreads + tid;
             float mx = -INFINITY, mn = INFINITY;
             if (v4 < ns4) {
-                l4[v4] = q[k];
+                if (STORE) l4[v4] = q[k];
                 mx = fmaxf(fmaxf(q[k].x, q[k].y), fmaxf(q[k].z, q[k].w));
                 mn = fminf(fminf(q[k].x, q[k].y), fminf(q[k].z, q[k].w));
             }
@@ -995,20 +996,36 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
     for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
     __syncthreads();
     if (vec4) {
-        // four samples per lane: one 16-byte read and the two neighbours instead of three reads per sample
+        // four samples per lane: one 16-byte read and the two neighbours instead of three reads per sample; four such
+        // groups in flight per lane (rows too long for LDS are read from global memory here)
         const float4* r4 = reinterpret_cast<const float4*>(r);
-        for (int v4 = tid; v4 < (ns >> 2); v4 += kFpThreads) {
-            const float4 q = r4[v4];
-            const int i0 = 4 * v4;
-            const float u[6] = {i0 ? r[i0 - 1] : INFINITY, q.x, q.y, q.z, q.w, (i0 + 4 < ns) ? r[i0 + 4] : INFINITY};
-            unsigned m = 0u;
+        constexpr int kAhead = 4;
+        const int ns4 = ns >> 2;
+        for (int g0 = tid; g0 < ns4; g0 += kAhead * kFpThreads) {
+            float4 q[kAhead];
+            float lo[kAhead], hi[kAhead];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = u[k + 1];
-                const int i = i0 + k;
-                if (i >= 1 && i < ns - 1 && u[k] < v && !(u[k + 2] > v) && !((double)v - thr < (double)gmin)) m |= 1u << k;
+            for (int j = 0; j < kAhead; ++j) {
+                const int v4 = g0 + j * kFpThreads, i0 = 4 * v4;
+                const bool in = v4 < ns4;
+                q[j] = in ? r4[v4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                lo[j] = (in && i0) ? r[i0 - 1] : INFINITY;
+                hi[j] = (in && i0 + 4 < ns) ? r[i0 + 4] : INFINITY;
             }
-            if (m) atomicOr(&T.cand[i0 >> 5], m << (i0 & 31));
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const int v4 = g0 + j * kFpThreads, i0 = 4 * v4;
+                if (v4 >= ns4) continue;
+                const float u[6] = {lo[j], q[j].x, q[j].y, q[j].z, q[j].w, hi[j]};
+                unsigned m = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = u[k + 1];
+                    const int i = i0 + k;
+                    if (i >= 1 && i < ns - 1 && u[k] < v && !(u[k + 2] > v) && !((double)v - thr < (double)gmin)) m |= 1u << k;
+                }
+                if (m) atomicOr(&T.cand[i0 >> 5], m << (i0 & 31));
+            }
         }
     } else {
         for (int i = 1 + tid; i < ns - 1; i += kFpThreads) {
@@ -1169,9 +1186,10 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     const float* rg = x + (size_t)blockIdx.x * ns;
     const int tid = threadIdx.x;
     for (int w = tid; w < nwords; w += kFpThreads) T.bits[w] = 0u;
-    const bool vec4 = STAGED && bshift == 5 && (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
+    const bool al16 = (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
+    const bool vec4 = bshift == 5 && al16;
     if (vec4) {
-        fp_stage_rows4(rg, T, ns, nb, tid);
+        fp_stage_rows4<STAGED>(rg, T, ns, nb, tid);
     } else {
         if (STAGED) {
             for (int i = tid; i < ns; i += kFpThreads) T.rowl[i] = rg[i];
@@ -1182,7 +1200,7 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     __syncthreads();
     fp_summaries2(T, nb, nb2, tid);
     __syncthreads();
-    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, cfail, STAGED && (ns & 3) == 0, tid);
+    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, cfail, STAGED ? (ns & 3) == 0 : al16, tid);
     __syncthreads();
     fp_emit(T, nwords, idx + (size_t)blockIdx.x * cap, counts + blockIdx.x, cap, wave_tot, tid);
 }
