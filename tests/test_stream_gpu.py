@@ -60,3 +60,41 @@ def test_stream_equals_concatenated_record(with_fk):
     # a stand-alone file (the reference's per-file run) differs from the stream at the file edges
     alone = dw.dsp.bp_filt(rec[:, ns:2 * ns], FS, 14, 30)
     assert rel(alone, F[:, ns:2 * ns]) > 1e-3
+
+
+def test_stream_at_the_ooi_file_shape():
+    """Three consecutive 11 020 x 12 000 files (BASELINE configs[4] geometry): the middle file's band-pass is the halo form
+    (d4w_fir_fft_halo_f32, neighbours read in place), its correlograms continue into the third file
+    (d4w_xcorr_fft_cont_f32).  Rows are independent: eight of them against the oracle on the concatenated record."""
+    import das4whales_amd as dw
+    from das4whales_amd import stream
+    nx, ns = 11020, 12000
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    files = [torch.randn((nx, ns), device="cuda", generator=gen) + 0.2 for _ in range(3)]
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    lf = orc.gen_template_fincall(t, FS, 14.7, 21.8, 0.78)
+    st = stream.FileStream(FS, 14, 30, templates=[hf, lf], fk_mask=None, halo=1024)
+    results = []
+    for f in files:
+        results += st.push(f)
+    results += st.flush()
+    rows = [0, 1, 2, 777, 5509, 5510, nx - 2, nx - 1]
+    rec = np.concatenate([f[rows].cpu().numpy().astype(np.float64) for f in files], axis=1)
+    F = orc.bp_filt(rec, FS, 14, 30)
+    taps = [dw.detect._normalised_support(hf), dw.detect._normalised_support(lf)]
+    mid = results[1]
+    assert mid["index"] == 1
+    got = mid["filtered"][rows].cpu().numpy().astype(np.float64)
+    e = rel(got, F[:, ns:2 * ns])
+    print("stream 11020x12000, middle file: band-pass vs the concatenated record %.3e" % e)
+    assert e < TOL
+    nxt = results[2]["filtered"][rows].cpu().numpy().astype(np.float64)
+    m, A = got.mean(axis=1, keepdims=True), np.max(np.abs(got), axis=1, keepdims=True)
+    for tp, c in zip(taps, mid["correlograms"]):
+        L = len(tp)
+        xn = (np.concatenate((got, nxt[:, :L - 1]), axis=1) - m) / A
+        ref = np.stack([orc.shift_xcorr(xn[k], np.pad(tp, (0, xn.shape[1] - L)))[:ns] for k in range(len(rows))])
+        e = rel(c[rows].cpu().numpy(), ref)
+        print("stream 11020x12000, middle file: correlogram (continued) %.3e" % e)
+        assert e < TOL
