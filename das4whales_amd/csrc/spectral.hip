@@ -400,8 +400,12 @@ __global__ __launch_bounds__(kSpThreads) void stft_mag(RowFftDev F, StftDims d, 
     float2* tile = reinterpret_cast<float2*>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int n_fft = d.n_fft, nb = d.FT / 2;
-    const TwLds tw = tw_stage(F.ax, tile + nb * n_fft, tid, nthr);
-    float* seg = reinterpret_cast<float*>(tile + nb * n_fft + tw_lds_elems(F.ax));
+    // TL: LDS elements per transform -- the frame itself, or the Bluestein convolution length when n_fft has a prime factor
+    // > 31 (x chirp -> FFT -> x filter -> inverse FFT -> x chirp, as row_dft; spectra in natural order then)
+    const int TL = F.bs_L ? F.bs_L : n_fft;
+    const AxisDesc& axt = row_tw_axis(F);
+    const TwLds tw = tw_stage(axt, tile + nb * TL, tid, nthr);
+    float* seg = reinterpret_cast<float*>(tile + nb * TL + tw_lds_elems(axt));
     const int seg_len = (d.FT - 1) * d.hop + n_fft;
     const int t0 = blockIdx.x * d.FT;
     const int s0 = t0 * d.hop - n_fft / 2;
@@ -411,21 +415,38 @@ __global__ __launch_bounds__(kSpThreads) void stft_mag(RowFftDev F, StftDims d, 
         seg[j] = (s >= 0 && s < d.ns) ? xr[s] : 0.f;
     }
     lds_barrier();
-    const FDiv dn(n_fft), dnb(nb);
-    for (int w = tid; w < nb * n_fft; w += nthr) {
-        const int b = dn.div(w), n = w - b * n_fft;
-        const float wn = F.hann[n];
-        tile[w] = make_float2(seg[2 * b * d.hop + n] * wn, seg[(2 * b + 1) * d.hop + n] * wn);
+    const FDiv dn(TL), dnb(nb);
+    for (int w = tid; w < nb * TL; w += nthr) {
+        const int b = dn.div(w), n = w - b * TL;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < n_fft) {
+            const float wn = F.hann[n];
+            v = make_float2(seg[2 * b * d.hop + n] * wn, seg[(2 * b + 1) * d.hop + n] * wn);
+            if (F.bs_L) v = c_mul(v, F.bs_chirp[n]);
+        }
+        tile[w] = v;
     }
     lds_barrier();
-    lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, nb, n_fft, 1, 0, tid, nthr);
+    if (F.bs_L) {
+        lds_fft<false, false, false>(tile, F.ax_bs, tw, 1, nb, TL, 1, 0, tid, nthr);
+        for (int w = tid; w < nb * TL; w += nthr) tile[w] = c_mul(tile[w], F.bs_filt[w - dn.div(w) * TL]);
+        lds_barrier();
+        lds_fft<true, false, false>(tile, F.ax_bs, tw, 1, nb, TL, 1, 0, tid, nthr);
+        for (int w = tid; w < nb * n_fft; w += nthr) {
+            const int b = w / n_fft, k = w - b * n_fft;
+            tile[b * TL + k] = c_mul(tile[b * TL + k], F.bs_chirp[k]);
+        }
+        lds_barrier();
+    } else {
+        lds_fft<false, false, GENERIC>(tile, F.ax, tw, 1, nb, n_fft, 1, 0, tid, nthr);
+    }
     const int nbins = n_fft / 2 + 1, nkeep = d.b_hi - d.b_lo + 1;
     float mx = 0.f;
     for (int w = tid; w < nbins * nb; w += nthr) {
         const int k = dnb.div(w), b = w - k * nb;
         const int tA = t0 + 2 * b;
         if (tA >= d.nframes) continue;
-        const float2* tb = tile + b * n_fft;
+        const float2* tb = tile + b * TL;
         const float2 zk = tb[F.pos[k]], zm = c_conj(tb[F.pos[(k == 0) ? 0 : n_fft - k]]);
         const float2 A = c_scale(c_add(zk, zm), 0.5f);
         const float2 B = c_mul_mi(c_scale(c_sub(zk, zm), 0.5f));
@@ -1329,12 +1350,10 @@ int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, in
     const RowFftHost* h = nullptr;
     int rc = row_fft_get(n_fft, &h);
     if (rc) return rc;
-    if (h->dev.bs_L)
-        return fail(D4W_EINVAL, "n_fft = %d has a prime factor > 31 (the frame transform has no Bluestein form; "
-                    "dsp.supported_length(n) gives the nearest shorter supported length)", n_fft);
     StftDims d;
     d.ns = ns; d.n_fft = n_fft; d.hop = hop; d.nframes = 1 + ns / hop; d.b_lo = bin_lo; d.b_hi = bin_hi;
-    int nb = std::max(1, 6144 / n_fft);                      // complex transforms (frame pairs) per workgroup
+    const int tl = h->dev.bs_L ? h->dev.bs_L : n_fft;        // LDS elements per transform (Bluestein: the convolution length)
+    int nb = std::max(1, 6144 / tl);                         // complex transforms (frame pairs) per workgroup
     // two-factor frame lengths: 16 pairs make the first stage exactly one item per thread (RB = 16) and keep the tile at
     // 22-35 KB, i.e. 16-24 waves on a CU instead of 8 (measured at 11020 x 12000: n_fft 160 kept bins 2.61 -> 1.80 ms, all bins
     // 3.98 -> 2.77 ms, n_fft 256 5.05 -> 3.70 ms)
@@ -1378,7 +1397,7 @@ int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, in
         }
     }
     if (!rowmax) return fail(D4W_EINVAL, "rowmax is NULL (only the two-factor frame lengths 128, 160, 256, 512 form the kept bins alone)");
-    const size_t lds = ((size_t)nb * n_fft + kTwLo + h->dev.ax.nhi) * sizeof(float2) +
+    const size_t lds = ((size_t)nb * tl + kTwLo + (h->dev.bs_L ? h->dev.ax_bs.nhi : h->dev.ax.nhi)) * sizeof(float2) +
                        ((size_t)(d.FT - 1) * hop + n_fft) * sizeof(float);
     if (lds > kSpLdsMax) return fail(D4W_EINVAL, "n_fft = %d / hop = %d exceed the LDS frame tile", n_fft, hop);
     D4W_HIP(hipMemsetAsync(rowmax, 0, (size_t)nx * sizeof(float), (hipStream_t)stream));

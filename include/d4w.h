@@ -351,7 +351,8 @@ int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream)
  * d4w_stft_mag_f32: S[c][b - bin_lo][t] = |librosa.stft(x[c], n_fft, hop_length=hop)|[b][t] for
  *   bin_lo <= b <= bin_hi, t < d4w_stft_frames(ns, hop) = 1 + ns/hop (periodic Hann, center=True
  *   with zero padding: librosa >= 0.10 defaults).  rowmax[c] = max over ALL bins and frames (what
- *   detect.py:387 / dsp.py:76 normalise by).  n_fft even, <= 6144.  rowmax may be NULL for n_fft = 128, 160, 256, 512
+ *   detect.py:387 / dsp.py:76 normalise by).  n_fft even, <= 6144; a window with a prime factor > 31 runs its frame
+ *   transform as a Bluestein convolution.  rowmax may be NULL for n_fft = 128, 160, 256, 512
  *   (two-factor register transforms): then only the kept bins are formed (detect.compute_cross_correlogram_spectrocorr,
  *   where the normalisation cancels against the median).
  * d4w_scale_rows_f32: S[c][:] /= denom[c] (mode 0) or 20 log10(S[c][:] / denom[c]) (mode 1).

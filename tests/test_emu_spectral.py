@@ -99,7 +99,8 @@ def stft(lib, x, n_fft, hop, lo, hi):
     return S, mx
 
 
-@pytest.mark.parametrize("n_fft,hop,ns", [(160, 8, 2000), (256, 12, 2000), (128, 25, 999), (64, 3, 130), (512, 100, 3000), (100, 7, 700)])
+@pytest.mark.parametrize("n_fft,hop,ns", [(160, 8, 2000), (256, 12, 2000), (128, 25, 999), (64, 3, 130), (512, 100, 3000), (100, 7, 700),
+                                          (148, 7, 1500), (2 * 101, 10, 1200), (74, 40, 900)])   # 37, 101: Bluestein frame transform
 def test_stft_magnitude(emu, n_fft, hop, ns):
     rng = np.random.default_rng(n_fft + hop)
     x = rng.standard_normal((3, ns))
@@ -253,9 +254,9 @@ def test_argument_errors(emu):
     big = np.zeros((1, 2 * 20011), dtype=np.float32)                                                # prime 20011: no room
     assert emu.d4w_analytic_f32(vp(big), vp(np.empty_like(big)), 1, 2 * 20011, 0, None, ctypes.c_double(0), None) == -1
     assert b"prime" in emu.d4w_last_error() and emu.d4w_analytic_row_fits_lds(2 * 20011) == 0
-    x74 = np.zeros((2, 740), dtype=np.float32)
-    assert emu.d4w_stft_mag_f32(vp(x74), vp(np.zeros((2, 38, 21), dtype=np.float32)), vp(y), 2, 740, 74, 37, 0, 37, None) == -1
-    assert b"prime" in emu.d4w_last_error()                                                         # frame transform: no Bluestein
+    xl = np.zeros((1, 90000), dtype=np.float32)                                                     # a window with a prime too long for
+    assert emu.d4w_stft_mag_f32(vp(xl), vp(np.zeros((1, 8, 10), dtype=np.float32)), vp(y), 1, 90000, 2 * 20011, 10000, 0, 7, None) == -1
+    assert b"prime" in emu.d4w_last_error()                                                         # the Bluestein tile as well
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 15, 4, 0, 7, None) == -1                # odd n_fft
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 16, 4, 0, 9, None) == -1                # bin range
 

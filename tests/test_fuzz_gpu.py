@@ -109,7 +109,7 @@ def test_spectrogram_random_parameters(dw):
     rng = np.random.default_rng(105)
     for _ in range(6):
         ns = int(rng.integers(300, 20000))
-        nfft = int(rng.choice([32, 64, 100, 128, 160, 256, 500, 512, 1024]))
+        nfft = int(rng.choice([32, 64, 100, 128, 160, 256, 500, 512, 1024, 148, 202]))     # 148 = 4 x 37, 202 = 2 x 101: Bluestein frames
         ov = float(rng.choice([0.5, 0.75, 0.8, 0.9, 0.95]))
         x = rng.standard_normal(ns)
         p, tt, ff = dw.dsp.get_spectrogram(x, FS, nfft=nfft, overlap_pct=ov)
@@ -183,6 +183,22 @@ def test_row_lengths_with_large_prime_factors(dw):
         pr = sps.peak_prominences(env[r], np.union1d(ref, got[r]).astype(int))[0] if len(ref) or len(got[r]) else []
         sym = np.setxor1d(ref, got[r])
         assert all(abs(p - 2.5) < 1e-3 for p in sps.peak_prominences(env[r], sym.astype(int))[0]), (r, sym)
+
+
+def test_spectrogram_windows_with_large_prime_factors(dw):
+    """STFT windows with a prime factor > 31 (e.g. a 0.74-s window at 200 Hz = 148 samples): Bluestein frame transform."""
+    rng = np.random.default_rng(110)
+    x = rng.standard_normal(9000)
+    for nfft, ov in ((148, 0.9), (202, 0.8), (2 * 67, 0.95)):
+        p, tt, ff = dw.dsp.get_spectrogram(x, FS, nfft=nfft, overlap_pct=ov)
+        pr, ttr, ffr = orc.get_spectrogram(x, FS, nfft=nfft, overlap_pct=ov)
+        assert p.shape == pr.shape
+        assert np.max(np.abs(10.0 ** (p / 20) - 10.0 ** (pr / 20))) < TOL, nfft
+    xm = rng.standard_normal((7, 6000))
+    ker = {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}
+    sc = dw.detect.compute_cross_correlogram_spectrocorr(xm, FS, [14., 30.], ker, 0.74, 0.95)      # nperseg = 148
+    ref = orc.compute_cross_correlogram_spectrocorr(xm, FS, [14., 30.], ker, 0.74, 0.95)
+    assert sc.shape == ref.shape and rel(sc, ref) < TOL
 
 
 def test_unsupported_length_is_a_clear_error(dw):
