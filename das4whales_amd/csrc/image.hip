@@ -153,15 +153,45 @@ static int resize_axis_get(int in_size, int out_size, ResizeAxisDev* out) {
 }
 
 // horizontal pass: t[r][ox] = sum_j w[ox][j] x[r][first[ox] + j]
+// When the axis shrinks, neighbouring outputs read windows `scale` samples apart: a lane-per-output gather touches scale x 4
+// bytes per lane and every line ~kmax times (1.0 ms for an 11 020 x 12 000 -> 1200 binning).  The span of a workgroup's
+// outputs is therefore staged in LDS with coalesced loads first (four in flight per lane) whenever it fits.
+constexpr int kRsSpan = 4096;
 __global__ __launch_bounds__(kImThreads) void resize_rows(const float* __restrict__ x, int w, float* __restrict__ t, int ow,
                                                           ResizeAxisDev A) {
-    const int ox = blockIdx.x * kImThreads + threadIdx.x;
+    __shared__ float seg[kRsSpan];
+    const int ox0 = blockIdx.x * kImThreads, ox = ox0 + threadIdx.x;
+    const int oxl = min(ox0 + kImThreads, ow) - 1;
+    const int s0 = A.first[ox0], span = A.first[oxl] + A.count[oxl] - s0;
+    const float* row = x + (size_t)blockIdx.y * w;
+    const bool staged = span <= kRsSpan;                             // block-uniform
+    if (staged) {
+        constexpr int kAhead = 4;
+        for (int i0 = threadIdx.x; i0 < span; i0 += kAhead * kImThreads) {
+            float q[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int i = i0 + k * kImThreads;
+                q[k] = (i < span) ? row[s0 + i] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const int i = i0 + k * kImThreads;
+                if (i < span) seg[i] = q[k];
+            }
+        }
+        __syncthreads();
+    }
     if (ox >= ow) return;
-    const float* row = x + (size_t)blockIdx.y * w + A.first[ox];
     const float* wt = A.w + (size_t)ox * A.kmax;
-    const int n = A.count[ox];
+    const int n = A.count[ox], f = A.first[ox];
     float acc = 0.f;
-    for (int j = 0; j < n; ++j) acc = fmaf(wt[j], row[j], acc);
+    if (staged) {
+        const float* sp = seg + (f - s0);
+        for (int j = 0; j < n; ++j) acc = fmaf(wt[j], sp[j], acc);
+    } else {
+        for (int j = 0; j < n; ++j) acc = fmaf(wt[j], row[f + j], acc);
+    }
     t[(size_t)blockIdx.y * ow + ox] = acc;
 }
 
