@@ -243,6 +243,23 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                     const float2 va = pa[a * M1], vb = pb[a * M1];
                     pf[a] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
                 });
+            } else if (HALO && veca && vecb && ns >= 4) {
+                // a block that straddles a file boundary: most of its samples are still in the row -- their 8-byte loads
+                // go out together (clamped addresses), the few samples beyond the row are fetched one by one afterwards
+                const v2f mu2 = v2_make(mua, mub);
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    // clamped to the row without changing the parity of the index (the pairs stay 8-byte aligned)
+                    const int par = c0 & 1, c = c0 + 2 * (j1 + a * M1), cc = par + (min(max(c - par, 0), ns - 2 - par) & ~1);
+                    const float2 va = *reinterpret_cast<const float2*>(xa + cc);
+                    const float2 vb = *reinterpret_cast<const float2*>(xb + cc);
+                    pf[a] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+                });
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const int i = k0 + 2 * (j1 + a * M1), c = c0 + 2 * (j1 + a * M1);
+                    if (c < 0 || c + 1 >= ns) pf[a] = c2_make(fetch(xa, rowA, mua, veca, i), fetch(xb, rowB, mub, vecb, i));
+                });
             } else {
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
@@ -377,7 +394,12 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
             float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * ns + yshift;
             float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * ns + yshift;
             const v2f dc = v2_make(mua * dcg, mub * dcg);
-            if (interior) {
+            // stores: with neighbours (HALO) the block's lags can all lie inside the output although its samples straddle a
+            // file boundary -- the wide store path is chosen from the output's own geometry then
+            const bool oveca = HALO ? ((((long long)rowA * ns + yshift + k0) & 1) == 0) : veca;
+            const bool ovecb = HALO ? ((((long long)rowB * ns + yshift + k0) & 1) == 0) : vecb;
+            const bool ointerior = HALO ? (k0 + step <= ns_out && oveca && ovecb) : interior;
+            if (ointerior) {
                 float2* oa = reinterpret_cast<float2*>(ya + k0) + j1;
                 float2* ob = reinterpret_cast<float2*>(yb + k0) + j1;
                 static_for<NA>([&](auto aa) {
@@ -404,8 +426,8 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                     if (2 * m < step) {
                         c2 o = c2_scale2(v[aq], sc);
                         o = c2{v2_add(o.re, dc), v2_add(o.im, dc)};
-                        put(ya, veca, k0 + 2 * m, c2_a(o));
-                        if (hasB) put(yb, vecb, k0 + 2 * m, c2_b(o));
+                        put(ya, oveca, k0 + 2 * m, c2_a(o));
+                        if (hasB) put(yb, ovecb, k0 + 2 * m, c2_b(o));
                     }
                 });
             }
@@ -806,6 +828,23 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
                 constexpr int q = decltype(qq)::value;
                 const float2 va = pa[q * 256], vb = pb[q * 256];
                 pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+            });
+        } else if (veca && vecb && ns >= 4) {
+            // the last block of a row (a quarter of all blocks for 12 000-sample rows): the samples still inside the row go out
+            // as 8-byte loads together (clamped addresses), the ones beyond it are fetched one by one afterwards
+            const v2f mu2 = v2_make(mua, mub);
+            const int par = k0 & 1;
+            static_for<8>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                const int i = k0 + 2 * (tid + q * 256), ic = par + (min(max(i - par, 0), ns - 2 - par) & ~1);
+                const float2 va = *reinterpret_cast<const float2*>(xa + ic);
+                const float2 vb = *reinterpret_cast<const float2*>(xb + ic);
+                pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+            });
+            static_for<8>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                const int i = k0 + 2 * (tid + q * 256);
+                if (i + 1 >= ns) pf[q] = c2_make(fetch(xa, xna, mua, veca, i), fetch(xb, xnb, mub, vecb, i));
             });
         } else {
             static_for<8>([&](auto qq) {
