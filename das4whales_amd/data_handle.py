@@ -39,7 +39,8 @@ def load_das_data_array(raw_data, selected_channels, metadata):
     with torch.cuda.device(t.device):
         check(lib.d4w_raw2strain_f32(dev.ptr(t), _DTYPES[t.dtype], ns, c0, step, nx, float(metadata["scale_factor"]),
                                      dev.ptr(y), dev.stream_ptr(t)))
-        torch.cuda.current_stream().synchronize()               # t may be a temporary
+        # the kernel runs on torch's current stream, the stream a temporary `t` was allocated on: the caching allocator
+        # re-uses its memory in stream order, no host synchronisation needed (a resident raw file keeps the pipeline asynchronous)
     tx = np.arange(ns) / metadata["fs"]                                          # data_handle.py:227
     dist = (np.arange(nx) * step + c0) * metadata["dx"]                          # data_handle.py:228
     return y, tx, dist
