@@ -373,7 +373,8 @@ def _spectrocorr_device(S, K, off, nout, med=None, zero_ends=False):
             check(lib.d4w_row_median_f32(dev.ptr(S), nx, nf * nt, dev.ptr(med), dev.stream_ptr(S)))   # detect.py:600
         check(lib.d4w_spectrocorr_f32(dev.ptr(S), nx, nf, nt, dev.ptr(Kd), K.shape[1], int(off), int(nout),
                                       dev.ptr(med), int(bool(zero_ends)), dev.ptr(out), dev.stream_ptr(S)))
-        torch.cuda.current_stream().synchronize()               # Kd is a temporary
+        # Kd is a temporary on the stream the kernel runs on: the caching allocator re-uses it in stream order, no
+        # host synchronisation (a stream of files stays asynchronous)
     return out
 
 
