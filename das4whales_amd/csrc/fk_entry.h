@@ -70,6 +70,7 @@ struct FkFastEntry {
     void (*Cs_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);             // pass C on the slab
     void (*Cs_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
     void (*Bs_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);                       // pass B on the slab
+    void (*Bs_hilb)(FkDev, FkFastDev, float2*, int, int, FkGeo);                      // ... with the Hilbert pair operation (real rows)
 };
 
 template <class G>
@@ -98,6 +99,7 @@ static inline FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0)
     e.Cs_fwd = fkf_passC<G, false, 1>;
     e.Cs_inv = fkf_passC<G, true, 1>;
     e.Bs_mid = fkf_passB<G, 1>;
+    e.Bs_hilb = fkf_passB<G, 1, true>;
     return e;
 }
 

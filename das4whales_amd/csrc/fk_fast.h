@@ -697,7 +697,10 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
 // ---------------------------------------------------------------------------------------------
 // MODE 1 (slab): a pair key is r * geo.nq + jq (row position, local sub-row) instead of r * N1 + q1, and the n1 position
 // of local sub-row jq is geo.q1_of[jq]; data and mask are both laid out [nx][nq][N2].
-template <class G, int MODE = 0>
+// HILB: the pair operation of the Hilbert transform along time instead of the folded mask -- multiplier -i for 0 < f < M,
+// +i for the mirrored half, 0 at f = 0 and at the Nyquist frequency (scipy.signal.hilbert: the analytic signal's imaginary
+// part); no mask is read.  Used on real rows (each row its own Hermitian partner: d4w_analytic_long_f32).
+template <class G, int MODE = 0, bool HILB = false>
 __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFastDev F, float2* __restrict__ data, int tbase, int npairs,
                                                                  FkGeo geo = FkGeo()) {
     D4W_DYN_LDS(smem_raw);
@@ -759,6 +762,11 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         if (!midrange) return;
         int rpos, q1;
         split(pr.x, rpos, q1);
+        if constexpr (HILB) {
+            O.nyq = 0.f;
+            O.wr = P.wrow[q1];
+            return;
+        }
         const int PG = (q1 == 0) ? PGz : (NG - 1 - Gi);
         const float* mA = P.mask + (size_t)pr.x * N2 + Gi * NC;
         const float* mB = P.mask + (size_t)pr.y * N2 + PG * NC;
@@ -860,8 +868,16 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
                 const float2 E = c_scale(c_add(a[d], Bc), 0.5f);
                 const float2 O = c_mul_mi(c_scale(c_sub(a[d], Bc), 0.5f));
                 const float2 tO = c_mul(w, O);
-                const float2 Yp = c_scale(c_add(E, tO), ma[d]);
-                const float2 Ym = c_scale(c_sub(E, tO), mb);
+                float2 Yp, Ym;
+                if constexpr (HILB) {
+                    const bool dcn = (d == 0 && rev0);          // the (f = 0, Nyquist) pair: no Hilbert transform
+                    Yp = dcn ? make_float2(0.f, 0.f) : c_mul_mi(c_add(E, tO));
+                    Ym = dcn ? make_float2(0.f, 0.f) : c_mul_pi(c_sub(E, tO));
+                    (void)mb;
+                } else {
+                    Yp = c_scale(c_add(E, tO), ma[d]);
+                    Ym = c_scale(c_sub(E, tO), mb);
+                }
                 const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
                 const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
                 na[d] = c_add(S, D);

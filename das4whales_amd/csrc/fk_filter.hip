@@ -1116,6 +1116,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             (void)hipFuncSetAttribute((const void*)fast->Cs_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->Cs_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->Bs_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
+            (void)hipFuncSetAttribute((const void*)fast->Bs_hilb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
         }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
         if (!fast && lds_max > 64 * 1024) {
@@ -1632,6 +1633,7 @@ struct d4w_fkd_plan {
     FkGeo geo_t, geo_c;
     std::vector<int2> h_pairs_slab;         // pass-B work list in slab keys r * nq + jq
     int2* d_pairs_slab = nullptr; int2* d_pairs_live = nullptr;
+    int2* d_pairs_self = nullptr; int npairs_self = 0;   // pass-B work list "every row is its own Hermitian partner" (analytic signal)
     unsigned* d_livebits = nullptr; unsigned* d_rowmax = nullptr;
     int npairs_run = 0, live_rows = 0;
 };
@@ -1667,7 +1669,7 @@ __global__ __launch_bounds__(kThreads) void fkd_row_max(const float* __restrict_
 
 // Packed path of the distributed plan: shapes with specialised kernels (fk_fast.h).  Returns D4W_EINVAL (and leaves
 // *out NULL) when the shape has none -- the caller then builds the generic plan.
-static int fkd_plan_build_packed(int nx, int ns, int world, int rank, bool want_mask, d4w_fkd_plan** out) {
+static int fkd_plan_build_packed(int nx, int ns, int world, int rank, bool want_mask, d4w_fkd_plan** out, bool time_only = false) {
     *out = nullptr;
     const char* g = getenv("D4W_FKD_GENERIC");
     if (g && atoi(g) > 0) return fail(D4W_EINVAL, "generic distributed plan requested");
@@ -1675,7 +1677,9 @@ static int fkd_plan_build_packed(int nx, int ns, int world, int rank, bool want_
     int rc = fk_plan_build(nx, ns, nullptr, false, true, &sp);
     if (rc) return rc;
     const FkFastEntry& F = *sp->fast;
-    if (F.C2X > 1 || F.TA != F.TC || (F.NA * F.NB * F.NC) % (F.N1 * F.TA) != 0) {     // pass A MODE 2 walks N1 adjacent strips inside a sub-row
+    // (time_only: only the time phase and pass B are used -- the analytic signal of long rows -- and the channel-phase
+    // constraints do not apply)
+    if (!time_only && (F.C2X > 1 || F.TA != F.TC || (F.NA * F.NB * F.NC) % (F.N1 * F.TA) != 0)) {     // pass A MODE 2 walks N1 adjacent strips inside a sub-row
         d4w_fk_plan_destroy(sp);
         return fail(D4W_EINVAL, "shape config not usable for the packed distributed plan");
     }
@@ -2240,6 +2244,7 @@ __global__ __launch_bounds__(kThreads) void analytic_combine(const float* __rest
 
 static std::mutex g_long_mu;
 static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_plans;
+static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_fast;     // packed plans of specialised shapes (NULL: none)
 
 extern "C" {
 
@@ -2254,6 +2259,73 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
     int devid = 0;
     D4W_HIP(hipGetDevice(&devid));
+    float* h = (float*)ws;
+    // Shapes with specialised f-k kernels: the time phase of the packed plan (pass A MODE 1: n1 transform of the real rows),
+    // pass B with the Hilbert pair operation on the work list "sub-row q1 of a row pairs with sub-row N1 - q1 of the SAME
+    // row", the inverse time phase in place, the combine pass -- 36 B per sample on the fast kernels instead of 52 through
+    // the generic ones.  D4W_LONG_FAST=0 keeps the generic path.
+    {
+        static const int fast_env = [] { const char* v = getenv("D4W_LONG_FAST"); return v ? atoi(v) : 1; }();
+        d4w_fkd_plan* fp = nullptr;
+        if (fast_env) {
+            std::lock_guard<std::mutex> lk(g_long_mu);
+            auto key = std::make_tuple(devid, nx, ns);
+            auto it = g_long_fast.find(key);
+            if (it != g_long_fast.end()) {
+                fp = it->second;
+            } else {
+                if (fkd_plan_build_packed(nx, ns, 1, 0, false, &fp, true) == D4W_OK) {
+                    const int N1 = fp->N1;
+                    std::vector<int2> ps;
+                    ps.reserve((size_t)nx * (N1 / 2 + 1));
+                    for (int r = 0; r < nx; ++r)
+                        for (int q1 = 0; q1 <= N1 / 2; ++q1)       // single-radix n1: position = frequency digit
+                            ps.push_back(make_int2(r * N1 + q1, r * N1 + (N1 - q1) % N1));
+                    void* q = nullptr;
+                    if (hipMalloc(&q, ps.size() * sizeof(int2)) != hipSuccess ||
+                        hipMemcpy(q, ps.data(), ps.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
+                        if (q) (void)hipFree(q);
+                        d4w_fkd_plan_destroy(fp);
+                        fp = nullptr;
+                    } else {
+                        fp->sp->allocs.push_back(q);
+                        fp->d_pairs_self = (int2*)q;
+                        fp->npairs_self = (int)ps.size();
+                    }
+                } else {
+                    fp = nullptr;
+                }
+                g_long_fast[key] = fp;                            // NULL: no specialised kernels for this shape
+            }
+        }
+        if (fp) {
+            const FkFastEntry& F = *fp->sp->fast;
+            const FkDims& d = fp->sp->dev.d;
+            const int NBX = d.N2 / d.TA, nt = ceil_div(nx, d.C1) * NBX;
+            FkGeo geo = fp->geo_t;
+            geo.nrows = nx;
+            FkDev dv = fp->dev_t;
+            dv.scale = (float)(1.0 / (double)d.M);               // forward / inverse pair of the packed rows
+            dv.mask = nullptr;
+            dv.nyq = nullptr;
+            float2* h2 = reinterpret_cast<float2*>(h);
+            const dim3 gA(std::min(nt, fp->num_cu * fp->sp->wgA));
+            int rc = launch_k(F.T_fwd, gA, dim3(F.thrA), F.ldsA, stream, fp->dev_t, reinterpret_cast<const float2*>(x), h2, 0, nt, NBX, 0, geo);
+            if (rc) return rc;
+            FkFastDev fd = fp->fdev_c;
+            fd.pairs = fp->d_pairs_self;
+            fd.live = nullptr;
+            FkGeo gb = fp->geo_c;
+            gb.nq = d.N1;
+            const dim3 gB(std::max(1, std::min(fp->npairs_self, fp->num_cu * fp->sp->wgB)));
+            if ((rc = launch_k(F.Bs_hilb, gB, dim3(F.thrB), F.ldsB, stream, dv, fd, h2, 0, fp->npairs_self, gb))) return rc;
+            if ((rc = launch_k(F.T_inv, gA, dim3(F.thrA), F.ldsA, stream, dv, h2, 0, nt, NBX, 0, geo, (const float2*)h2))) return rc;
+            const float fscale = (float)(fs / (2.0 * M_PI));
+            D4W_LAUNCH(analytic_combine, dim3(std::min(ceil_div(ns, kThreads), 128), nx), dim3(kThreads), 0, stream, x,
+                       (const float*)h, y, ns, mode, var, fscale);
+            return D4W_OK;
+        }
+    }
     d4w_fkd_plan* pl = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_long_mu);
@@ -2269,7 +2341,6 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
             pl = it->second;
         }
     }
-    float* h = (float*)ws;
     int rc = d4w_fkd_time_fwd_f32(pl, x, h, 0, stream);
     if (rc) return rc;
     if ((rc = launch_k(fkd_pair_slab, dim3(std::min(ceil_div(pl->N2, kThreads), 8), nx, pl->N1), dim3(kThreads), 0, stream,

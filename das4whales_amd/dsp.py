@@ -717,6 +717,12 @@ def _analytic(x2d, mode, fs=0.0, var=None):
             check(lib.d4w_analytic_f32(dev.ptr(x2d), dev.ptr(y), nx, ns, int(mode),
                                        dev.ptr(var) if var is not None else None, float(fs), dev.stream_ptr(x2d)))
         else:                                        # long rows: four-step time-axis transform through HBM
+            import os
+            if nx <= 65535 and os.environ.get("D4W_FK_JIT", "1") != "0" and nx * ns >= (1 << 24):
+                try:                                 # shapes with specialised f-k kernels run their time phase + a Hilbert pass B
+                    compile_fk_shape(nx, ns)         # (once per shape, cached on disk; the f-k filter of the block uses the same)
+                except Exception:
+                    pass
             for a in range(0, nx, 65535):
                 xb, yb = x2d[a:a + 65535], y[a:a + 65535]
                 ws = torch.empty(int(lib.d4w_analytic_long_ws_bytes(xb.shape[0], ns)), dtype=torch.uint8, device=x2d.device)

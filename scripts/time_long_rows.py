@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from das4whales_amd import dsp, detect
 from das4whales_amd._lib import lib, check
-nx, ns = 4000, 120000
+nx, ns = int(os.environ.get("NX", 4000)), int(os.environ.get("NS", 120000))
 torch.manual_seed(0)
 x = torch.randn((nx, ns), device="cuda")
 x = dsp.bp_filt(x, 200.0, 14, 30)

@@ -219,3 +219,20 @@ def test_detectors_on_long_rows(dw):
     s = dw.dsp.snr_tr_array(xt[:8])
     ref_s = orc.snr_tr_array(x[:8])
     assert np.max(np.abs(10.0 ** (s.cpu().numpy() / 10) - 10.0 ** (ref_s / 10))) / np.max(10.0 ** (ref_s / 10)) < TOL
+
+
+def test_envelope_of_the_bench_block(dw):
+    """20 000 x 120 000: the long-row analytic signal on the shape-specialised f-k kernels (time phase + pass B with the Hilbert
+    pair operation, every row its own Hermitian partner); rows are independent -- a few against scipy.signal.hilbert."""
+    import scipy.signal as sps
+    nx, ns = 20000, 120000
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((nx, ns), device="cuda", generator=gen)
+    rows = [0, 1, 24, 25, 9999, 19999]
+    env = dw.dsp.envelope(x)
+    hil = dw.dsp.hilbert_imag(x[:, :])
+    z = sps.hilbert(x[rows].cpu().numpy().astype(np.float64), axis=1)
+    e1 = rel(env[rows].cpu().numpy(), np.abs(z))
+    e2 = rel(hil[rows].cpu().numpy(), z.imag)
+    print("envelope / Hilbert transform 20000x120000 (6 rows): rel err %.3e / %.3e" % (e1, e2))
+    assert e1 < TOL and e2 < TOL
