@@ -333,7 +333,9 @@ int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const f
 /* Rows too long for one workgroup's LDS (d4w_analytic_row_fits_lds(ns) == 0, e.g. 120 000 samples):
  * same modes through the four-step time-axis transform of the distributed f-k plan (two passes
  * each way over HBM) + the Hilbert pair op + one combine pass; ns even; ws = DEVICE scratch of
- * d4w_analytic_long_ws_bytes(nx, ns) bytes. */
+ * d4w_analytic_long_ws_bytes(nx, ns) bytes.  Shapes [nx][ns] with shape-specialised f-k kernels (built in or registered
+ * through d4w_fk_register_shape) run that plan's time phase, its pass B with the Hilbert pair operation on real rows and
+ * the inverse time phase instead (three fast passes + the combine pass; the ns / 2 prime-factor limit applies). */
 int d4w_analytic_row_fits_lds(int ns);
 size_t d4w_analytic_long_ws_bytes(int nx, int ns);
 int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
