@@ -69,7 +69,8 @@ def test_designs_vs_reference_golden(emu, golden):
 def test_gaussian_and_normalise(emu):
     rng = np.random.default_rng(1)
     from scipy import ndimage
-    for shape in [(37, 201), (100, 64), (9, 1100)]:          # smaller than the radius: multiple reflections
+    # smaller than the radius: multiple reflections; >= 2048 along an axis: the overlap-save FFT form with reflected halos
+    for shape in [(37, 201), (100, 64), (9, 1100), (30, 4200), (2100, 24)]:
         m = rng.random(shape).astype(np.float32)
         assert np.max(np.abs(gauss(emu, m, 20.0) - ndimage.gaussian_filter(m.astype(np.float64), 20))) < 2e-6
         assert np.max(np.abs(gauss(emu, m, 3.0) - ndimage.gaussian_filter(m.astype(np.float64), 3))) < 2e-6
