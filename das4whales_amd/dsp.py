@@ -276,8 +276,29 @@ def butterworth_filter(filterspec, fs):
     return sp.butter(filter_order, wn, btype=filter_type_str, output="sos")
 
 
+_sos_host_cache = {}        # sos bytes -> {"decay": samples, "zi": steady-state initial conditions}: host work once per design
+
+
+def _sos_host(sos):
+    key = (sos.tobytes(), sos.shape)
+    ent = _sos_host_cache.get(key)
+    if ent is None:
+        import scipy.signal as sp
+        if len(_sos_host_cache) > 64:
+            _sos_host_cache.clear()
+        ent = _sos_host_cache[key] = {"zi": np.ascontiguousarray(sp.sosfilt_zi(sos), dtype=np.float64),
+                                      "decay": _sos_decay_samples_uncached(sos)}
+    return ent
+
+
 def _sos_decay_samples(sos, tol=1e-9, nmax=1 << 17):
-    """Samples after which the cascade's impulse response stays below tol * peak (host, float64)."""
+    """Samples after which the cascade's impulse response stays below tol * peak (host, float64; cached per design)."""
+    if tol == 1e-9 and nmax == 1 << 17:
+        return _sos_host(sos)["decay"]
+    return _sos_decay_samples_uncached(sos, tol, nmax)
+
+
+def _sos_decay_samples_uncached(sos, tol=1e-9, nmax=1 << 17):
     import scipy.signal as sp
     n = 4096
     while True:
@@ -440,7 +461,7 @@ def _sosfiltfilt_recursive(x, sos, padlen, seg_len=None, warm=None):
     """The exact second-order-section recursion (forward + backward launch, 16 B per sample)."""
     import scipy.signal as sp
     nx, ns = x.shape
-    zi = np.ascontiguousarray(sp.sosfilt_zi(sos), dtype=np.float64)
+    zi = _sos_host(sos)["zi"]
     if warm is None:
         warm = -(-int(1.5 * _sos_decay_samples(sos)) // 32) * 32
     if seg_len is None:
@@ -509,13 +530,28 @@ def bp_filt(data, fs, fmin, fmax):
     The reference runs scipy.signal.filtfilt on the 17-coefficient `ba` form in float64 (that
     recursion overflows in float32); here the same filter runs as float32
     second-order sections with filtfilt's edge rule (odd extension, padlen = 3*17 = 51)."""
-    import scipy.signal as sp
-    sos = sp.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp", output="sos")
+    sos = _bp_sos(float(fs), float(fmin), float(fmax))
     x2, was1d = _rows_2d(data)
     xd = dev.to_device_f32(x2)
     y = _sosfiltfilt_device(xd, sos, 51)
     y = y[0] if was1d else y
     return dev.like_input(y, data)
+
+
+_bp_sos_cache = {}
+
+
+def _bp_sos(fs, fmin, fmax):
+    """butter(8, [fmin, fmax] / (fs / 2), 'bp') as second-order sections (host, float64), designed once per band."""
+    key = (fs, fmin, fmax)
+    sos = _bp_sos_cache.get(key)
+    if sos is None:
+        import scipy.signal as sp
+        if len(_bp_sos_cache) > 64:
+            _bp_sos_cache.clear()
+        sos = np.ascontiguousarray(sp.butter(8, [fmin / (fs / 2), fmax / (fs / 2)], "bp", output="sos"), dtype=np.float64)
+        _bp_sos_cache[key] = sos
+    return sos
 
 
 bp_filter = bp_filt             # north-star spelling
