@@ -61,6 +61,25 @@ def test_designs_config1_shape_vs_oracle(dw):
     assert np.max(np.abs(mc - orc.fk_filter_design(shape, sel, dx, fs))) < 1e-6
 
 
+def test_gaussian_designs_fft_blur_vs_oracle(dw):
+    """Shapes whose axes are longer than an FFT block: the sigma-20 blur runs as overlap-save passes with reflected halos
+    (+ transposes for the channel axis); *_gs designs and fk_filt against the oracle (scipy.ndimage.gaussian_filter)."""
+    shape, sel, dx, fs = (2500, 6000), [0, 10000, 4], 2.0419046878814697, 200.0
+    mg = dw.dsp.hybrid_gs_filter_design(shape, sel, dx, fs, cs_min=1350., cp_min=1450., fmin=14., fmax=30.).todense()
+    ref = orc.hybrid_gs_filter_design(shape, sel, dx, fs, cs_min=1350., cp_min=1450., fmin=14., fmax=30.)
+    e = float(np.max(np.abs(mg - ref)))
+    print("hybrid_gs_filter_design 2500 x 6000 (FFT blur): max abs err %.3e" % e)
+    assert e < 3e-6
+    del mg, ref
+    mng = dw.dsp.hybrid_ninf_gs_filter_design(shape, sel, dx, fs, **ARGS).todense()
+    assert np.max(np.abs(mng - orc.hybrid_ninf_gs_filter_design(shape, sel, dx, fs, **ARGS))) < 3e-6
+    del mng
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2100, 4200))                     # odd sizes: partial transpose tiles, partial FFT blocks
+    y = dw.dsp.fk_filt(x, 1, fs, 4, dx, 1400., 3400.)
+    assert rel(y, orc.fk_filt(x, 1, fs, 4, dx, 1400., 3400.)) < 1e-5
+
+
 def test_design_goes_into_the_plan_without_a_dense_mask(dw):
     """BASELINE configs[3] block: fk_filter_design / hybrid_ninf_filter_design return the closed form (DesignedMask);
     the filter folds it straight into the plan.  No 9.6 GB mask is allocated, and the result is bit-identical to
