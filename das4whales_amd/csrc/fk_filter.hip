@@ -459,12 +459,20 @@ __global__ __launch_bounds__(kMaxThreads) void fk_passB_bluestein(FkDev P, float
 // ---------------------------------------------------------------------------------------------
 // mask fold + permutation into pass-B order (one-off per mask)
 // ---------------------------------------------------------------------------------------------
+// mask values as they are read by the fold: m, or m * a + b (dsp.fk_filt's min-max normalisation, dsp.py:945, applied to
+// every value exactly as the separate pass did -- one fewer read and write of the dense mask)
+struct FkAffine {
+    float a, b;
+    int on;
+    __device__ __forceinline__ float operator()(float m) const { return on ? fmaf(m, a, b) : m; }
+};
+
 __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* __restrict__ ms,
                                                           const int* __restrict__ rowk,
                                                           const int* __restrict__ k1_of_q1,
                                                           const int* __restrict__ k2_of_i,
                                                           float* __restrict__ mask,
-                                                          float* __restrict__ nyq, unsigned* __restrict__ rowmaxbits) {
+                                                          float* __restrict__ nyq, unsigned* __restrict__ rowmaxbits, FkAffine aff) {
     const int r = blockIdx.y;
     const int k = rowk[r];
     const int km = (d.nx - k) % d.nx;
@@ -476,13 +484,13 @@ __global__ __launch_bounds__(kThreads) void fk_fold_mask(FkDims d, const float* 
         const int q1 = p / d.N2, i = p - q1 * d.N2;
         const int f = k1_of_q1[q1] + d.N1 * k2_of_i[i];
         const int fm = (d.ns - f) % d.ns;
-        const float v = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+        const float v = 0.5f * (aff(ms[rowp + (f + st) % d.ns]) + aff(ms[rowm + (fm + st) % d.ns]));
         mask[(size_t)r * d.M + p] = v;
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int f = d.M, fm = d.ns - d.M;
-        const float v = 0.5f * (ms[rowp + (f + st) % d.ns] + ms[rowm + (fm + st) % d.ns]);
+        const float v = 0.5f * (aff(ms[rowp + (f + st) % d.ns]) + aff(ms[rowm + (fm + st) % d.ns]));
         nyq[r] = v;
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(kFoldThreads) void fk_fold_mask_tiled(FkDims d, int
                                                                 const int* __restrict__ q1_of_k1,
                                                                 const int* __restrict__ k2_of_i,
                                                                 float* __restrict__ mask, float* __restrict__ nyq,
-                                                                unsigned* __restrict__ rowmaxbits) {
+                                                                unsigned* __restrict__ rowmaxbits, FkAffine aff) {
     D4W_DYN_LDS(smem_raw);
     float* buf = reinterpret_cast<float*>(smem_raw);
     const int r = blockIdx.y;
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(kFoldThreads) void fk_fold_mask_tiled(FkDims d, int
     for (int w = threadIdx.x; w < RL * nb; w += blockDim.x) {
         const int j = dRL.div(w), u = w - j * RL;
         const int f = u + RL * (k2_of_i[ib0 + j] / R0);
-        const float v = 0.5f * (rowp[f] + rowm[-f]);
+        const float v = 0.5f * (aff(rowp[f]) + aff(rowm[-f]));
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
         buf[u * pitch + j] = v;
     }
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(kFoldThreads) void fk_fold_mask_tiled(FkDims d, int
         mask[(size_t)r * d.M + (size_t)q1_of_k1[k1] * d.N2 + d0 * N2r + ib0 + j] = buf[u * pitch + j];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const float v = 0.5f * (rowp[d.M - d.ns] + rowm[d.M - d.ns]);   // f = M (Nyquist): shifted column 0 of both rows
+        const float v = 0.5f * (aff(rowp[d.M - d.ns]) + aff(rowm[d.M - d.ns]));   // f = M (Nyquist): shifted column 0 of both rows
         nyq[r] = v;
         vbits = max(vbits, __float_as_uint(v) & 0x7fffffffu);
     }
@@ -1157,7 +1165,7 @@ int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
 
 static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream);
 
-static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
+static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream, FkAffine aff = FkAffine{1.f, 0.f, 0}) {
     if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
     const FkDims& d = pl->dev.d;
@@ -1174,11 +1182,11 @@ static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double p
         if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
         D4W_LAUNCH(fk_fold_mask_tiled, dim3(ceil_div(N2r, pl->fold_IB), d.nx), dim3(kFoldThreads), lds, stream, d, pl->fold_R0,
                    pl->fold_IB, mask_shifted, (const int*)pl->d_rowk, (const int*)pl->d_q1_of_k1, (const int*)pl->d_k2,
-                   pl->d_mask, pl->d_nyq, pl->d_rowmax);
+                   pl->d_mask, pl->d_nyq, pl->d_rowmax, aff);
     } else {
         dim3 grid(std::min(ceil_div(d.M, kThreads), 64), d.nx);
         D4W_LAUNCH(fk_fold_mask, grid, dim3(kThreads), 0, stream, d, mask_shifted, (const int*)pl->d_rowk,
-                   (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, pl->d_rowmax);
+                   (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, pl->d_rowmax, aff);
     }
     return fk_mask_finish(pl, prune_eps, stream);
 }
@@ -1251,6 +1259,10 @@ int d4w_fk_set_mask_dense_f32(d4w_fk_plan* pl, const float* mask_shifted, void* 
 
 int d4w_fk_set_mask_dense_pruned_f32(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream) {
     return fk_set_mask_impl(pl, mask_shifted, prune_eps, stream);
+}
+
+int d4w_fk_set_mask_dense_affine_f32(d4w_fk_plan* pl, const float* mask_shifted, float scale, float offset, void* stream) {
+    return fk_set_mask_impl(pl, mask_shifted, 0.0, stream, FkAffine{scale, offset, 1});
 }
 
 int d4w_fk_set_mask_design_f32(d4w_fk_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,

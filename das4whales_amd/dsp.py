@@ -75,6 +75,23 @@ class FkPlan:
             self._mask_ref = weakref.ref(m)
             self._mask_key = key
 
+    def set_mask_normalised(self, g):
+        """g: float32 CUDA tensor [nx, ns] on the plan's device; the mask is (g - min) / (max - min) (dsp.fk_filt, reference
+        dsp.py:945), applied while the mask is folded -- no separate normalisation pass over g."""
+        if tuple(g.shape) != (self.nx, self.ns):
+            raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s" % (self.nx, self.ns, tuple(g.shape)))
+        self._mask_ref, self._mask_key = None, None
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            mm = torch.empty(2, dtype=torch.float32, device=self.device)
+            check(lib.d4w_minmax_f32(dev.ptr(g), g.numel(), dev.ptr(mm), st))
+            lohi = mm.cpu().numpy()
+            lo, hi = np.float32(lohi[0]), np.float32(lohi[1])
+            # a constant g: NumPy's 0 / 0 = NaN everywhere (as d4w_minmax_normalise_f32)
+            a = np.float32(1.0) / (hi - lo) if hi > lo else np.float32(np.nan)
+            b = -lo * a
+            check(lib.d4w_fk_set_mask_dense_affine_f32(self._h, dev.ptr(g), float(a), float(b), st))
+
     def _set_mask_design(self, m, prune_eps):
         """A closed-form design (immutable) straight into the plan -- no dense mask."""
         key = (id(m), "design", float(prune_eps))
@@ -736,6 +753,11 @@ def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
     # axes: fftfreq(ns, tint/fs), fftfreq(nx, xint*dx) (dsp.py:923-924) -> spacing arguments
     g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=device)    # dsp.py:930-936
     g = _gaussian_filter(g, 20)                                                 # dsp.py:940
+    if ns % 2 == 0:
+        plan = get_fk_plan(nx, ns, g.device)
+        plan.set_mask_normalised(g)                                             # dsp.py:945, folded into the mask upload
+        x = dev.to_device_f32(data, plan.device)
+        return dev.like_input(plan.apply(x), data)
     with torch.cuda.device(g.device):
         check(lib.d4w_minmax_normalise_f32(dev.ptr(g), g.numel(), dev.stream_ptr(g)))        # dsp.py:945
     return _fk_apply(data, DeviceMask(g), False)

@@ -78,6 +78,11 @@ int d4w_fk_set_mask_dense_pruned_f32(d4w_fk_plan* plan, const float* mask_shifte
  * 2 dsp.hybrid_ninf_filter_design (dsp.py:308-454); arguments as d4w_design_mask_f32 below.  The Gaussian-blurred
  * designs (modes 3-5) need the dense grid and are refused.  Saves the nx*ns*4-byte mask (9.6 GB at
  * 20 000 x 120 000) and its write + read.  Synchronises `stream`. */
+/* dsp.fk_filt's min-max normalisation (dsp.py:945) folded into the mask upload: every value enters as
+ * mask * scale + offset (scale = 1 / (max - min), offset = -min * scale, min and max from d4w_minmax_f32), exactly what
+ * d4w_minmax_normalise_f32 followed by d4w_fk_set_mask_dense_f32 leaves, without the extra read and write of the mask. */
+int d4w_fk_set_mask_dense_affine_f32(d4w_fk_plan* plan, const float* mask_shifted, float scale, float offset,
+                                     void* stream);
 int d4w_fk_set_mask_design_f32(d4w_fk_plan* plan, int mode, double k_spacing, double t_spacing,
                                const double* params8_host, int i0, int i1, const double* hrow_dev,
                                double prune_eps, void* stream);

@@ -127,3 +127,36 @@ def test_design_folded_straight_into_the_plan(emu, nx, ns, opts):
     assert emu.d4w_fk_set_mask_design_f32(plan, 3, step, 1.0 / fs, vp(p8), 0, 0, None, 0.0, None) != 0    # blurred designs: refused
     assert b"closed form" in emu.d4w_last_error()
     emu.d4w_fk_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("nx,ns,opts", [(40, 480, None), (18, 48, None), (38, 406, [19, 2, 7, 29, 4, 4]), (100, 600, None)])
+def test_normalisation_folded_into_the_mask_upload(emu, nx, ns, opts):
+    """d4w_minmax_f32 (image.hip) + d4w_fk_set_mask_dense_affine_f32 == d4w_minmax_normalise_f32 + d4w_fk_set_mask_dense_f32, bit for
+    bit (dsp.fk_filt's (g - min) / (max - min), dsp.py:945, without the separate pass over the mask)."""
+    cv, ci = ctypes.c_void_p, ctypes.c_int
+    emu.d4w_minmax_f32.argtypes = [cv, ctypes.c_size_t, cv, cv]
+    emu.d4w_fk_set_mask_dense_affine_f32.argtypes = [cv, cv, ctypes.c_float, ctypes.c_float, cv]
+    rng = np.random.default_rng(nx + ns)
+    g = (rng.random((nx, ns)) * 3.0 - 0.7).astype(np.float32)
+    x = rng.standard_normal((nx, ns)).astype(np.float32)
+    o = (ci * 6)(*opts) if opts else None
+    lohi = np.zeros(2, dtype=np.float32)
+    assert emu.d4w_minmax_f32(vp(g), g.size, vp(lohi), None) == 0
+    assert lohi[0] == g.min() and lohi[1] == g.max()
+    a = np.float32(1.0) / (lohi[1] - lohi[0])
+    b = -lohi[0] * a
+    ys = []
+    for fused in (False, True):
+        plan = cv()
+        assert emu.d4w_fk_plan_create_ex(nx, ns, o, ctypes.byref(plan)) == 0, emu.d4w_last_error()
+        if fused:
+            assert emu.d4w_fk_set_mask_dense_affine_f32(plan, vp(g), ctypes.c_float(a), ctypes.c_float(b), None) == 0
+        else:
+            gn = g.copy()
+            assert emu.d4w_minmax_normalise_f32(vp(gn), gn.size, None) == 0
+            assert emu.d4w_fk_set_mask_dense_f32(plan, vp(gn), None) == 0
+        y = np.empty_like(x)
+        assert emu.d4w_fk_apply_f32(plan, vp(x), vp(y), 0, None) == 0, emu.d4w_last_error()
+        emu.d4w_fk_plan_destroy(plan)
+        ys.append(y)
+    assert np.array_equal(ys[0], ys[1])
