@@ -122,5 +122,34 @@ static inline void host_fft_pow2(std::vector<double>& re, std::vector<double>& i
     }
 }
 
+// in-place forward DFT of ANY length (double precision, plan-time tables only): a power of two directly, anything else as
+// a chirp convolution through power-of-two transforms
+static inline void host_dft_any(std::vector<double>& re, std::vector<double>& im) {
+    const int n = (int)re.size();
+    if ((n & (n - 1)) == 0) { host_fft_pow2(re, im); return; }
+    int P = 1;
+    while (P < 2 * n - 1) P *= 2;
+    std::vector<double> wr(n), wi(n), ar(P, 0.0), ai(P, 0.0), br(P, 0.0), bi(P, 0.0);
+    for (int k = 0; k < n; ++k) {
+        const double ph = M_PI * (double)(((long long)k * k) % (2LL * n)) / (double)n;
+        wr[k] = cos(ph); wi[k] = -sin(ph);                      // w[k] = exp(-i pi k^2 / n)
+        ar[k] = re[k] * wr[k] - im[k] * wi[k];
+        ai[k] = re[k] * wi[k] + im[k] * wr[k];
+        br[k] = wr[k]; bi[k] = -wi[k];                          // conj(w), wrapped
+        if (k) { br[P - k] = wr[k]; bi[P - k] = -wi[k]; }
+    }
+    host_fft_pow2(ar, ai);
+    host_fft_pow2(br, bi);
+    for (int p = 0; p < P; ++p) {                               // conj(A B): the inverse transform as conj(FFT(conj(.))) / P
+        const double cr = ar[p] * br[p] - ai[p] * bi[p], ci = ar[p] * bi[p] + ai[p] * br[p];
+        ar[p] = cr; ai[p] = -ci;
+    }
+    host_fft_pow2(ar, ai);
+    for (int k = 0; k < n; ++k) {
+        const double cr = ar[k] / P, ci = -ai[k] / P;
+        re[k] = cr * wr[k] - ci * wi[k];
+        im[k] = cr * wi[k] + ci * wr[k];
+    }
+}
 
 }  // namespace d4w

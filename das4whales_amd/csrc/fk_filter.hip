@@ -652,8 +652,17 @@ static const std::vector<FkFastEntry>& fast_shapes() {
 
 using namespace d4w;
 
+struct d4w_fkd_plan;
+// the distributed plan's generic form at world 1 carries the channel counts whose part with prime factors > 31 does not
+// fit the LDS Bluestein tile (its channel phase is a Bluestein convolution in global memory, fkd_bz_*)
+extern "C" {
+static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d4w_fkd_plan** out);
+}
+static int fkd_set_mask_dense_affine(d4w_fkd_plan* pl, const float* mask_shifted, float a, float b, int on, void* stream);
+
 struct d4w_fk_plan {
     FkDev dev;
+    d4w_fkd_plan* big = nullptr;           // set: every call goes through this world-1 distributed plan
     std::vector<void*> allocs;
     int* d_rowk = nullptr;
     int* d_k1 = nullptr;
@@ -767,6 +776,7 @@ int d4w_fk_register_shape(const void* entry, size_t entry_size) {
 }
 
 int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
+    if (pl && pl->big) { d4w_fkd_plan_destroy(pl->big); pl->big = nullptr; }
     if (!pl) return D4W_OK;
     for (void* p : pl->allocs) (void)hipFree(p);
     delete pl;
@@ -858,9 +868,23 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             while (C1 % f == 0 && (long)C1 * n1_min > kMaxTile && 2L * C2 * f - 1 <= kMaxTile) { C2 *= f; C1 /= f; }
         bs_L = 1;
         while (bs_L < 2 * C2 - 1) bs_L *= 2;
-        if (bs_L > kMaxTile)
-            return fail(D4W_EINVAL, "nx = %d: the part with prime factors > 31 (%d) is too long for the Bluestein tile (limit %d); "
-                        "dsp.supported_length(n) gives the nearest shorter length with a direct kernel", nx, C2, kMaxTile / 2);
+        if (bs_L > kMaxTile) {
+            // too long for the Bluestein tile of pass C: the global-memory form (any channel count; the time axis
+            // must factor into primes <= 31 there)
+            if (fast_only) return fail(D4W_EINVAL, "no shape-specialised kernels for %d x %d", nx, ns);
+            d4w_fkd_plan* big = nullptr;
+            int rcb = fkd_plan_build(nx, ns, 1, 0, true, &big);
+            if (rcb) return rcb;
+            int info[12];
+            (void)d4w_fkd_plan_info(big, info);
+            d4w_fk_plan* pl = new d4w_fk_plan();
+            memset(&pl->dev, 0, sizeof(pl->dev));
+            pl->dev.d = FkDims{nx, ns, M, info[9], info[10], info[6], info[7], 1, 1};
+            pl->big = big;
+            pl->live_rows = nx;
+            *out = pl;
+            return D4W_OK;
+        }
     }
     // --- split the time axis.  Pass A's cost falls like 1 / (C1 N1) until its tile holds ~100 columns, pass B's
     //     grows with N1 (shorter rows): N1 ~ sqrt(1000 / C1), at least the smallest admissible one
@@ -1166,8 +1190,13 @@ int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
 static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream);
 
 static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream, FkAffine aff = FkAffine{1.f, 0.f, 0}) {
-    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
+    if (pl && pl->big) {                            // (no dead-row pruning on this path: prune_eps has nothing to act on)
+        int rc = fkd_set_mask_dense_affine(pl->big, mask_shifted, aff.a, aff.b, aff.on, stream);
+        if (rc == D4W_OK) pl->has_mask = true;
+        return rc;
+    }
+    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     const FkDims& d = pl->dev.d;
     hipStream_t st = (hipStream_t)stream;
     D4W_HIP(hipMemsetAsync(pl->d_rowmax, 0, (size_t)d.nx * sizeof(unsigned), st));
@@ -1267,6 +1296,12 @@ int d4w_fk_set_mask_dense_affine_f32(d4w_fk_plan* pl, const float* mask_shifted,
 
 int d4w_fk_set_mask_design_f32(d4w_fk_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
                                int i0, int i1, const double* hrow_dev, double prune_eps, void* stream) {
+    if (pl && pl->big) {
+        if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
+        int rc = d4w_fkd_set_mask_design_f32(pl->big, mode, k_spacing, t_spacing, params8_host, i0, i1, hrow_dev, stream);
+        if (rc == D4W_OK) pl->has_mask = true;
+        return rc;
+    }
     if (!pl || !params8_host || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     if (mode < 0 || mode > 2)
         return fail(D4W_EINVAL, "mode %d has no closed form (the Gaussian-blurred designs go through d4w_design_mask_f32)", mode);
@@ -1289,6 +1324,20 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
     if ((row_mean == nullptr) != (row_maxabs == nullptr)) return fail(D4W_EINVAL, "row_mean and row_maxabs go together");
     if (!pl->has_mask) return fail(D4W_EINVAL, "no mask set on this plan");
+    if (pl->big) {
+        // time phase of all rows into y (as the packed half spectrum), channel phase on it in place, time phase back
+        hipStream_t sb = (hipStream_t)stream;
+        int rc;
+        if (ev) D4W_HIP(hipEventRecord(ev[0], sb));
+        if ((rc = d4w_fkd_time_fwd_f32(pl->big, x, y, taper, stream))) return rc;
+        if (ev) { D4W_HIP(hipEventRecord(ev[1], sb)); D4W_HIP(hipEventRecord(ev[2], sb)); }
+        if ((rc = d4w_fkd_chan_apply_f32(pl->big, y, stream))) return rc;
+        if (ev) { D4W_HIP(hipEventRecord(ev[3], sb)); D4W_HIP(hipEventRecord(ev[4], sb)); }
+        if ((rc = d4w_fkd_time_inv_f32(pl->big, y, stream))) return rc;
+        if (row_mean && (rc = d4w_row_stats_f32(y, pl->dev.d.nx, pl->dev.d.ns, row_mean, row_maxabs, stream))) return rc;
+        if (ev) D4W_HIP(hipEventRecord(ev[5], sb));
+        return D4W_OK;
+    }
     const FkDev& P = pl->dev;
     const FkDims& d = P.d;
     const float2* src = reinterpret_cast<const float2*>(x);
@@ -1566,6 +1615,198 @@ __global__ __launch_bounds__(kThreads) void fkd_pair_slab(FkdSlab S, float2* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channel transform of ANY length (a channel count with a prime factor > 31) as a Bluestein convolution in global
+// memory: column by column,
+//   a[n] = z[n] w[n] (n < nx, zero up to L = 2^a 3^b 5^c >= 2 nx - 1),  A = FFT_L(a),  A *= FFT_L(conj w, wrapped) / L,
+//   c = IFFT_L(A),  Z[k] = w[k] c[k] (k < nx),  w[n] = exp(-i pi n^2 / nx);  the inverse conjugates w and the filter.
+// The two length-L transforms are passes A and C of the generic kernels on a scratch [L][Wc] (a chunk of Wc slab columns
+// at a time) with the elementwise steps folded into them: three launches per direction, 5 sweeps of the scratch.  Rows come
+// out in natural wavenumber order.  Tiles and pipelining as fk_passA_fwd / fk_passC / fk_passA_inv with N1 = 1.
+// ---------------------------------------------------------------------------------------------
+//   fkd_bz_passA_fwd : slab rows x chirp (zero beyond nx / beyond the chunk's columns) -> c1 transform, x W_L -> scratch
+//   fkd_bz_passC     : c2 transform, x filter at the row position, inverse c2 transform, in place on the scratch
+//   fkd_bz_passA_inv : x conj W_L, inverse c1 transform, x chirp x scale -> slab rows < nx
+struct FkdBz {
+    const float2* chirp;      // [nx]
+    const float2* filt;       // [L] at row positions
+    size_t pitch;             // slab row pitch (complex)
+    int nx, ncol, inv;        // rows of the slab, valid columns of this chunk, 1: conjugated tables
+    float scale;
+};
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_bz_passA_fwd(FkDev P, FkdBz Z, const float2* __restrict__ slab,
+                                                                float2* __restrict__ S, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TA = d.TA;
+    const int nelem = d.C1 * TA;
+    const int ntx = (d.N2 + TA - 1) / TA;
+    const FDiv dTA(TA), dntx(ntx);
+    const TwLds tw_c1 = tw_stage(P.ax_c1, tile + nelem, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int c1 = dTA.div(w), tt = w - c1 * TA;
+                const int row = c1 * d.C2 + c2, col = b0 + tt;
+                if (row < Z.nx && col < Z.ncol) {
+                    float2 ch = Z.chirp[row];
+                    if (Z.inv) ch.y = -ch.y;
+                    v = c_mul(slab[(size_t)row * Z.pitch + col], ch);
+                }
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) tile[w] = pf[it];
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<false, true, GENERIC>(tile, P.ax_c1, tw_c1, TA, TA, 1, 1, 0, tid, nthr);
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int q = dTA.div(w), tt = w - q * TA;
+            if (tt < ncol) {
+                const size_t row = (size_t)q * d.C2 + c2;
+                S[row * d.M + b0 + tt] = c_mul(tile[w], P.twc[q * d.C2 + c2]);
+            }
+        }
+        lds_barrier();
+        t = next;
+    }
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_bz_passA_inv(FkDev P, FkdBz Z, const float2* __restrict__ S,
+                                                                float2* __restrict__ slab, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TA = d.TA;
+    const int nelem = d.C1 * TA;
+    const int ntx = (d.N2 + TA - 1) / TA;
+    const FDiv dTA(TA), dntx(ntx);
+    const TwLds tw_c1 = tw_stage(P.ax_c1, tile + nelem, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int q = dTA.div(w), tt = w - q * TA;
+                if (tt < ncol) v = S[((size_t)q * d.C2 + c2) * d.M + b0 + tt];
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+        const int c2 = dntx.div(t), b0 = (t - c2 * ntx) * TA;
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) {
+                const int q = dTA.div(w);
+                tile[w] = c_mulc(pf[it], P.twc[q * d.C2 + c2]);
+            }
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<true, true, GENERIC>(tile, P.ax_c1, tw_c1, TA, TA, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int c1 = dTA.div(w), tt = w - c1 * TA;
+            const int row = c1 * d.C2 + c2, col = b0 + tt;
+            if (row < Z.nx && col < Z.ncol) {
+                float2 ch = Z.chirp[row];
+                if (Z.inv) ch.y = -ch.y;
+                slab[(size_t)row * Z.pitch + col] = c_mul(tile[w], c_scale(ch, Z.scale));
+            }
+        }
+        lds_barrier();
+        t = next;
+    }
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_bz_passC(FkDev P, FkdBz Z, float2* __restrict__ S, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TC = d.TC;
+    const int nelem = d.C2 * TC;
+    const int ntx = (d.M + TC - 1) / TC;
+    const FDiv dTC(TC), dntx(ntx);
+    const TwLds tw = tw_stage(P.ax_c2, tile + nelem, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int q = dntx.div(t), p0 = (t - q * ntx) * TC;
+        const int ncol = min(TC, d.M - p0);
+        const float2* base = S + ((size_t)q * d.C2) * d.M + p0;
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int c2 = dTC.div(w), tt = w - c2 * TC;
+                if (tt < ncol) v = base[(size_t)c2 * d.M + tt];
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) tile[w] = pf[it];
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<false, true, GENERIC>(tile, P.ax_c2, tw, TC, TC, 1, 1, 0, tid, nthr);
+        const int q = dntx.div(t), p0 = (t - q * ntx) * TC;
+        for (int w = tid; w < nelem; w += nthr) {
+            float2 f = Z.filt[q * d.C2 + dTC.div(w)];
+            if (Z.inv) f.y = -f.y;
+            tile[w] = c_mul(tile[w], f);
+        }
+        lds_barrier();
+        lds_fft<true, true, GENERIC>(tile, P.ax_c2, tw, TC, TC, 1, 1, 0, tid, nthr);
+        const int ncol = min(TC, d.M - p0);
+        float2* base = S + ((size_t)q * d.C2) * d.M + p0;
+        for (int w = tid; w < nelem; w += nthr) {
+            const int c2 = dTC.div(w), tt = w - c2 * TC;
+            if (tt < ncol) base[(size_t)c2 * d.M + tt] = tile[w];
+        }
+        lds_barrier();
+        t = next;
+    }
+}
+
 // folded mask of the owned sub-rows (fk_fold_mask restricted to a q1 subset)
 __global__ __launch_bounds__(kThreads) void fkd_fold_mask(int nx, int ns, int N1, int N2, int nq,
                                                            const float* __restrict__ ms,
@@ -1573,7 +1814,7 @@ __global__ __launch_bounds__(kThreads) void fkd_fold_mask(int nx, int ns, int N1
                                                            const int* __restrict__ q1_of,
                                                            const int* __restrict__ k1_of_q1,
                                                            const int* __restrict__ k2_of_i,
-                                                           float* __restrict__ mask, float* __restrict__ nyq) {
+                                                           float* __restrict__ mask, float* __restrict__ nyq, FkAffine aff) {
     const int r = blockIdx.y;
     const int k = rowk[r];
     const int km = (nx - k) % nx;
@@ -1584,10 +1825,10 @@ __global__ __launch_bounds__(kThreads) void fkd_fold_mask(int nx, int ns, int N1
         const int jq = p / N2, i = p - jq * N2;
         const int f = k1_of_q1[q1_of[jq]] + N1 * k2_of_i[i];
         const int fm = (ns - f) % ns;
-        mask[(size_t)r * nq * N2 + p] = 0.5f * (ms[rowp + (f + st) % ns] + ms[rowm + (fm + st) % ns]);
+        mask[(size_t)r * nq * N2 + p] = 0.5f * (aff(ms[rowp + (f + st) % ns]) + aff(ms[rowm + (fm + st) % ns]));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        nyq[r] = 0.5f * (ms[rowp + (M + st) % ns] + ms[rowm + ((ns - M) + st) % ns]);
+        nyq[r] = 0.5f * (aff(ms[rowp + (M + st) % ns]) + aff(ms[rowm + ((ns - M) + st) % ns]));
 }
 
 // ... evaluated in closed form instead of read (fk_fold_design restricted to a q1 subset): a rank never holds the
@@ -1618,6 +1859,7 @@ struct FkdMaskSrc {
     const float* dense = nullptr;
     DesignArgs A{};
     int mode = -1;
+    FkAffine aff{1.f, 0.f, 0};           // dense only, generic plan only: a * m + b applied while folding
 };
 
 }  // namespace d4w
@@ -1636,6 +1878,11 @@ struct d4w_fkd_plan {
     float* d_mask = nullptr; float* d_nyq = nullptr;
     bool has_mask = false;
     int num_cu = 256;
+    // ---- channel count with a prime factor > 31: Bluestein convolution of length bz_L in global memory (fkd_bz_*)
+    int bz_L = 0, bz_W = 0;                 // transform length (0: off), columns per scratch chunk
+    float2* bz_S = nullptr;                 // [bz_L][bz_W]
+    const float2* bz_chirp = nullptr;       // [nx]    exp(-i pi n^2 / nx)
+    const float2* bz_filt = nullptr;        // [bz_L]  FFT of the wrapped conjugate chirp / bz_L at the row positions of cp
     // ---- packed path: the shape has specialised kernels (fk_fast.h, FkGeo).  The exchange buffers need no repacking:
     //      the time phase writes sub-row q1 of local row l at  blk_off[owner[q1]] + l * nq[owner] * N2 + jq(q1) * N2
     //      (destination rank major), so that the all-to-all delivers the slab [nx][nq][N2] as it stands.
@@ -1806,8 +2053,25 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     }
     if (N1 == 0) return fail(D4W_EINVAL, "ns/2 = %d has no factorisation with N2 <= %d", M, kMaxTile / 2);
     const int N2 = M / N1;
-    int C2 = largest_divisor_le(nx, kMaxTile / 8);
-    int C1 = nx / C2;
+    // a channel count with a prime factor > 31: the channel transform is a Bluestein convolution of length bz_L = 2^a 3^b 5^c
+    // in global memory (fkd_bz_*), and the channel-phase descriptor below is the one of that length
+    int bz_L = 0;
+    if (want_mask && rough_part(nx) > 1) {
+        // the shortest length >= 2 nx - 1 of the form 2^a 3^b 5^c (the unrolled radices; a power of two can be ~2x longer)
+        const char* p2 = getenv("D4W_FKD_BZ_POW2");
+        long best = 1;
+        while (best < 2L * nx - 1) best *= 2;
+        if (!(p2 && atoi(p2) > 0))
+            for (long a = 1; a < best; a *= 2)
+                for (long b = a; b < best; b *= 3)
+                    for (long c = b; c < best; c *= 5)
+                        if (c >= 2L * nx - 1 && c < best) best = c;
+        bz_L = (int)best;
+    }
+    // (no mask = the time phase only, d4w_analytic_long_f32: any row count, the channel descriptor stays a dummy)
+    const int Lc = !want_mask ? 1 : (bz_L ? bz_L : nx);
+    int C2 = largest_divisor_le(Lc, kMaxTile / 8);
+    int C1 = Lc / C2;
     if (C1 > kMaxTile) return fail(D4W_EINVAL, "nx = %d does not factor into C1 <= %d, C2 <= %d", nx, kMaxTile, kMaxTile / 8);
     d4w_fkd_plan* pl = new d4w_fkd_plan();
     pl->nx = nx; pl->ns = ns; pl->M = M; pl->world = world; pl->rank = rank;
@@ -1870,21 +2134,55 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     d4w_fk_plan& cp = pl->cp;
     memset(&cp.dev, 0, sizeof(cp.dev));
     int TC = 16, TAc = 512;
+    // Bluestein: the scratch [bz_L][Wc] holds a chunk of Wc slab columns at a time (<= 1 GiB; D4W_FKD_BZ_CHUNK pins Wc)
+    int Wc = W;
+    if (bz_L) {
+        const char* ch = getenv("D4W_FKD_BZ_CHUNK");
+        int lim = (ch && atoi(ch) > 0) ? atoi(ch) : std::max(16, (int)(((size_t)1 << 27) / (size_t)bz_L) & ~15);
+        Wc = std::min(W, lim);
+    }
     while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
-    while (TAc > 1 && ((long)C1 * TAc > kMaxTile || TAc > W)) TAc /= 2;
+    while (TAc > 1 && ((long)C1 * TAc > kMaxTile || TAc > Wc)) TAc /= 2;
     pl->TC = TC; pl->TA_c = TAc;
-    cp.dev.d = FkDims{nx, 2 * W, W, C1, C2, 1, W, TAc, TC};
-    cp.dev.scale = (float)(1.0 / ((double)nx * (double)M));
+    cp.dev.d = FkDims{Lc, 2 * Wc, Wc, C1, C2, 1, Wc, TAc, TC};
+    // Bluestein: 1 / bz_L sits in the filter table and 1 / (nx M) in fkd_bz_out of the inverse transform
+    cp.dev.scale = bz_L ? 1.0f : (float)(1.0 / ((double)nx * (double)M));
     D4W_TRY(make_axis(&cp, C1, &cp.dev.ax_c1, &f_c1));
     D4W_TRY(make_axis(&cp, C2, &cp.dev.ax_c2, &f_c2));
     D4W_TRY(make_axis(&cp, 1, &cp.dev.ax_n1, &f_one));
     D4W_TRY(make_axis(&cp, 1, &cp.dev.ax_n2, &f_one));
     {
-        std::vector<float2> twc((size_t)C1 * C2), ones((size_t)W, make_float2(1.f, 0.f));
+        std::vector<float2> twc((size_t)C1 * C2), ones((size_t)Wc, make_float2(1.f, 0.f));
         for (int q = 0; q < C1; ++q)
-            for (int c2 = 0; c2 < C2; ++c2) twc[(size_t)q * C2 + c2] = wexp((long long)c2 * f_c1[q], nx);
+            for (int c2 = 0; c2 < C2; ++c2) twc[(size_t)q * C2 + c2] = wexp((long long)c2 * f_c1[q], Lc);
         D4W_TRY(upload(&cp, twc, &cp.dev.twc));
         D4W_TRY(upload(&cp, ones, &cp.dev.twt));
+    }
+    if (bz_L) {
+        std::vector<float2> chirp(nx), filt(bz_L);
+        std::vector<double> bre(bz_L, 0.0), bim(bz_L, 0.0);
+        for (int n = 0; n < nx; ++n) {
+            const double ph = M_PI * (double)(((long long)n * n) % (2LL * nx)) / (double)nx;
+            chirp[n] = make_float2((float)cos(ph), (float)-sin(ph));
+            bre[n] = cos(ph); bim[n] = sin(ph);                               // conj(chirp)
+            if (n) { bre[bz_L - n] = cos(ph); bim[bz_L - n] = sin(ph); }
+        }
+        host_dft_any(bre, bim);
+        for (int q = 0; q < C1; ++q)
+            for (int p2 = 0; p2 < C2; ++p2) {
+                const int f = f_c1[q] + C1 * f_c2[p2];                        // frequency at row position q C2 + p2
+                filt[(size_t)q * C2 + p2] = make_float2((float)(bre[f] / bz_L), (float)(bim[f] / bz_L));
+            }
+        D4W_TRY(upload(&cp, chirp, &pl->bz_chirp));
+        D4W_TRY(upload(&cp, filt, &pl->bz_filt));
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)bz_L * Wc * sizeof(float2)) != hipSuccess) {
+            d4w_fkd_plan_destroy(pl);
+            return fail(D4W_ENOMEM, "hipMalloc of the Bluestein scratch (%d x %d complex) failed", bz_L, Wc);
+        }
+        cp.allocs.push_back(p);
+        pl->bz_S = (float2*)p;
+        pl->bz_L = bz_L; pl->bz_W = Wc;
     }
     pl->gen_c1 = axis_needs_generic(cp.dev.ax_c1);
     pl->gen_c2 = axis_needs_generic(cp.dev.ax_c2);
@@ -1896,11 +2194,15 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     for (int p = 0; p < C1; ++p) p_c1[f_c1[p]] = p;
     for (int p = 0; p < C2; ++p) p_c2[f_c2[p]] = p;
     for (int p = 0; p < N2; ++p) p_n2[f_n2[p]] = p;
-    for (int q = 0; q < C1; ++q)
-        for (int p2 = 0; p2 < C2; ++p2) rowk[q * C2 + p2] = f_c1[q] + C1 * f_c2[p2];
-    for (int r = 0; r < nx; ++r) {
-        const int km = (nx - rowk[r]) % nx;
-        rowpart[r] = p_c1[km % C1] * C2 + p_c2[km / C1];
+    if (bz_L || !want_mask) {                      // Bluestein: natural wavenumber order
+        for (int r = 0; r < nx; ++r) { rowk[r] = r; rowpart[r] = (nx - r) % nx; }
+    } else {
+        for (int q = 0; q < C1; ++q)
+            for (int p2 = 0; p2 < C2; ++p2) rowk[q * C2 + p2] = f_c1[q] + C1 * f_c2[p2];
+        for (int r = 0; r < nx; ++r) {
+            const int km = (nx - rowk[r]) % nx;
+            rowpart[r] = p_c1[km % C1] * C2 + p_c2[km / C1];
+        }
     }
     for (int i = 0; i < N2; ++i) mirror0[i] = p_n2[(N2 - f_n2[i]) % N2];
     for (int j = 0; j < nq; ++j)
@@ -1949,7 +2251,10 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
             (const void*)fk_passC<false, true>, (const void*)fk_passC<false, false>,
             (const void*)fk_passC<true, true>, (const void*)fk_passC<true, false>,
             (const void*)fkd_rows_n2<false, true>, (const void*)fkd_rows_n2<false, false>,
-            (const void*)fkd_rows_n2<true, true>, (const void*)fkd_rows_n2<true, false>};
+            (const void*)fkd_rows_n2<true, true>, (const void*)fkd_rows_n2<true, false>,
+            (const void*)fkd_bz_passA_fwd<true>, (const void*)fkd_bz_passA_fwd<false>,
+            (const void*)fkd_bz_passA_inv<true>, (const void*)fkd_bz_passA_inv<false>,
+            (const void*)fkd_bz_passC<true>, (const void*)fkd_bz_passC<false>};
         for (const void* f : fns)
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
@@ -1983,7 +2288,7 @@ static int fkd_launch_fold(const FkdMaskSrc& src, int nx, int ns, int N1, int N2
                            const int* k1, const int* k2, float* mask, float* nyq, void* stream) {
     dim3 grid(std::min(ceil_div(nq * N2, kThreads), 64), nx);
     if (src.dense)
-        D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, nx, ns, N1, N2, nq, src.dense, rowk, q1of, k1, k2, mask, nyq);
+        D4W_LAUNCH(fkd_fold_mask, grid, dim3(kThreads), 0, stream, nx, ns, N1, N2, nq, src.dense, rowk, q1of, k1, k2, mask, nyq, src.aff);
     else
         D4W_LAUNCH(fkd_fold_design, grid, dim3(kThreads), 0, stream, nx, ns, N1, N2, nq, src.A, src.mode, rowk, q1of, k1, k2,
                    mask, nyq);
@@ -2067,6 +2372,17 @@ int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void
     src.dense = mask_shifted;
     return fkd_set_mask_src(pl, src, stream);
 }
+
+}  // extern "C"
+static int fkd_set_mask_dense_affine(d4w_fkd_plan* pl, const float* mask_shifted, float a, float b, int on, void* stream) {
+    if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
+    if (on && pl->sp) return fail(D4W_EINVAL, "the packed distributed plan folds no affine map");
+    FkdMaskSrc src;
+    src.dense = mask_shifted;
+    src.aff = FkAffine{a, b, on};
+    return fkd_set_mask_src(pl, src, stream);
+}
+extern "C" {
 
 int d4w_fkd_set_mask_design_f32(d4w_fkd_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
                                 int i0, int i1, const double* hrow_dev, void* stream) {
@@ -2213,6 +2529,28 @@ int d4w_fkd_chan_apply_f32(d4w_fkd_plan* pl, float* slab, void* stream) {
     float2* d2 = reinterpret_cast<float2*>(slab);
     const dim3 blk(kMaxThreads);
     int rc;
+    if (pl->bz_L) {
+        // channel DFT, pair operation with the folded mask, inverse channel DFT -- each DFT a Bluestein convolution
+        // through the scratch, a chunk of columns at a time (the columns are independent)
+        if (pl->nx > 65535 || nq > 65535) return fail(D4W_EINVAL, "slab %d x %d exceeds the pair-op grid", pl->nx, nq);
+        const int W = nq * pl->N2, Wc = pl->bz_W, L = pl->bz_L;
+        float2* S = pl->bz_S;
+        (void)L;
+        for (int inv = 0; inv < 2; ++inv) {
+            for (int c0 = 0; c0 < W; c0 += Wc) {
+                FkdBz Z;
+                Z.chirp = pl->bz_chirp; Z.filt = pl->bz_filt; Z.pitch = (size_t)W; Z.nx = pl->nx;
+                Z.ncol = std::min(Wc, W - c0); Z.inv = inv;
+                Z.scale = inv ? (float)(1.0 / ((double)pl->nx * (double)pl->M)) : 1.0f;
+                if ((rc = launch_k(pl->gen_c1 ? fkd_bz_passA_fwd<true> : fkd_bz_passA_fwd<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, Z, (const float2*)(d2 + c0), S, ntA))) return rc;
+                if ((rc = launch_k(pl->gen_c2 ? fkd_bz_passC<true> : fkd_bz_passC<false>, dim3(std::min(ntC, persist)), blk, pl->lds_c2, stream, P, Z, S, ntC))) return rc;
+                if ((rc = launch_k(pl->gen_c1 ? fkd_bz_passA_inv<true> : fkd_bz_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, Z, (const float2*)S, d2 + c0, ntA))) return rc;
+            }
+            if (!inv && (rc = launch_k(fkd_pair_slab, dim3(std::min(ceil_div(pl->N2, kThreads), 8), pl->nx, nq), dim3(kThreads), 0,
+                                        stream, pl->slab, d2))) return rc;
+        }
+        return D4W_OK;
+    }
     if ((rc = launch_k(pl->gen_c1 ? fk_passA_fwd<false, true> : fk_passA_fwd<false, false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, (const float2*)d2, d2, ntA))) return rc;
     if ((rc = launch_k(pl->gen_c2 ? fk_passC<false, true> : fk_passC<false, false>, dim3(std::min(ntC, persist)), blk, pl->lds_c2, stream, P, d2, ntC))) return rc;
     if (pl->nx > 65535 || nq > 65535) return fail(D4W_EINVAL, "slab %d x %d exceeds the pair-op grid", pl->nx, nq);

@@ -158,8 +158,8 @@ class FkPlan:
 
 def supported_length(n, even=False):
     """Largest length <= n whose prime factors are all <= 31 (what the mixed-radix kernels carry), optionally
-    even.  The f-k filter accepts ANY channel count whose part with prime factors > 31 is <= 4096 (that
-    sub-transform runs as a Bluestein convolution, slower); the time axis (ns / 2) and the row transforms
+    even.  The f-k filter accepts ANY channel count (prime factors > 31 run as Bluestein convolutions, slower --
+    several times slower when that part of the count exceeds 4096); the time axis (ns / 2) and the row transforms
     (hilbert, spectrogram window, get_fx) need smooth lengths.  Use this to trim a record or a selection,
     e.g. 12002 samples -> 12000."""
     n = int(n)

@@ -157,10 +157,43 @@ def test_channel_count_with_large_prime_factor(emu, nx, ns):
     assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
 
 
-def test_channel_count_too_long_for_bluestein_tile(emu):
+def test_channel_count_too_long_for_bluestein_tile(emu, monkeypatch):
+    """A prime channel count > 4096 does not fit pass C's Bluestein tile: the plan runs the global-memory form (the generic
+    distributed plan at world 1 behind the same entry points: dense / affine / designed masks, taper, row statistics)."""
+    monkeypatch.setenv("D4W_FKD_BZ_CHUNK", "6")
+    nx, ns = 4099, 16
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    ref = orc.fk_filter_filt(x, m)
+    assert rel(fk_emu(emu, x, m), ref) < TOL
+    assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
     plan = ctypes.c_void_p()
-    assert emu.d4w_fk_plan_create(4099, 16, ctypes.byref(plan)) != 0           # prime > 4096
-    assert b"supported_length" in emu.d4w_last_error()
+    assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
+    info = (ctypes.c_int * 8)()
+    assert emu.d4w_fk_plan_info(plan, info) == 0 and list(info)[:2] == [nx, ns]
+    assert emu.d4w_fk_plan_live_rows(plan) == nx
+    xf = x.astype(np.float32)
+    y = np.empty_like(xf)
+    assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) != 0 and b"no mask" in emu.d4w_last_error()
+    # the affine fold (dsp.fk_filt's normalisation) and the row statistics
+    mf = m.astype(np.float32)
+    a, b = np.float32(0.75), np.float32(0.125)
+    assert emu.d4w_fk_set_mask_dense_affine_f32(plan, vp(mf), ctypes.c_float(a), ctypes.c_float(b), None) == 0
+    mean = np.empty(nx, dtype=np.float32)
+    mx = np.empty(nx, dtype=np.float32)
+    assert emu.d4w_fk_apply_stats_f32(plan, vp(xf), vp(y), 0, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
+    ref2 = orc.fk_filter_filt(x, (mf * a + b).astype(np.float64))
+    assert rel(y, ref2) < TOL
+    assert np.max(np.abs(mean - y.astype(np.float64).mean(axis=1))) < 1e-6 * np.abs(y).max()
+    assert np.allclose(mx, np.abs(y.astype(np.float64)).max(axis=1), rtol=1e-6)
+    # in place
+    buf = xf.copy()
+    assert emu.d4w_fk_apply_f32(plan, vp(buf), vp(buf), 0, None) == 0
+    assert rel(buf, ref2) < TOL
+    emu.d4w_fk_plan_destroy(plan)
+    # rough on both axes: the global-memory form needs a time axis of primes <= 31
+    assert emu.d4w_fk_plan_create(4099, 2 * 37, ctypes.byref(plan)) != 0
 
 
 @pytest.mark.parametrize("nx,ns", [(2, 5), (6, 15), (9, 27)])

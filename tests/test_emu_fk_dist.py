@@ -117,6 +117,23 @@ def test_dist_matches_single_gpu_path(emu):
         assert rel(y, orc.fk_filter_filt(x, m)) < TOL
 
 
+@pytest.mark.parametrize("nx,ns,world,chunk", [(37, 48, 1, 0), (37, 48, 2, 0), (74, 120, 3, 0), (2 * 43, 96, 2, 16),
+                                                (131, 40, 1, 5), (211, 24, 4, 0)])
+def test_dist_channel_count_with_large_prime_factor(emu, nx, ns, world, chunk, monkeypatch):
+    """A channel count with a prime factor > 31 on the generic distributed plan: the channel transform of the slab runs as a
+    Bluestein convolution in global memory (fkd_bz_in / passes A, C of the padded length / fkd_bz_filter / ... / fkd_bz_out),
+    a chunk of slab columns at a time (D4W_FKD_BZ_CHUNK pins a chunk narrower than the slab, with a ragged last one)."""
+    if chunk:
+        monkeypatch.setenv("D4W_FKD_BZ_CHUNK", str(chunk))
+    rng = np.random.default_rng(nx + world)
+    x = rng.standard_normal((nx, ns))
+    m = rng.uniform(0, 1, (nx, ns))
+    assert rel(fk_sharded_emu(emu, x, m, world), orc.fk_filter_filt(x, m)) < TOL
+    if world == 2:
+        assert rel(fk_sharded_emu(emu, x, m, world, taper=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+        assert rel(fk_sharded_emu(emu, x, np.ones((nx, ns)), world), x) < TOL
+
+
 def test_dist_plan_errors(emu):
     h = ctypes.c_void_p()
     assert emu.d4w_fkd_plan_create(40, 481, 2, 0, ctypes.byref(h)) == -1

@@ -201,14 +201,34 @@ def test_spectrogram_windows_with_large_prime_factors(dw):
     assert sc.shape == ref.shape and rel(sc, ref) < TOL
 
 
+def test_any_channel_count(dw):
+    """Channel counts whose part with prime factors > 31 exceeds 4096 (the LDS Bluestein tile of pass C): the plan runs the
+    global-memory Bluestein form of the channel transform (fk_filter.hip: fkd_bz_*) -- numpy.fft.fft2 (dsp.py:748) takes any
+    shape.  Dense, designed and fk_filt masks, taper, in several scratch chunks."""
+    rng = np.random.default_rng(111)
+    for nx, ns in ((4099, 64), (2 * 5003, 240), (10007, 1200)):
+        x = rng.standard_normal((nx, ns))
+        m = rng.random((nx, ns))
+        assert rel(dw.dsp.fk_filter_filt(x, m), orc.fk_filter_filt(x, m)) < TOL, (nx, ns)
+    assert rel(dw.dsp.fk_filter_filt(x, m, tapering=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+    nx, ns = 8209, 1200
+    sel = [0, nx, 1]
+    x = rng.standard_normal((nx, ns))
+    kw = dict(cs_min=1350., cp_min=1450., cp_max=3300, cs_max=3450, fmin=14., fmax=30.)
+    mask = dw.dsp.hybrid_ninf_filter_design((nx, ns), sel, 2.04, FS, **kw)
+    ref = orc.fk_filter_filt(x, orc.hybrid_ninf_filter_design((nx, ns), sel, 2.04, FS, **kw))
+    assert rel(dw.dsp.fk_filter_sparsefilt(x, mask), ref) < TOL
+    assert rel(dw.dsp.fk_filt(x, 1, FS, 1, 2.04, 1400., 3500.), orc.fk_filt(x, 1, FS, 1, 2.04, 1400., 3500.)) < TOL
+
+
 def test_unsupported_length_is_a_clear_error(dw):
-    """What has no kernel: a time axis whose part with prime factors > 31 exceeds 2048 (ns / 2 = 4099), a channel count
-    whose part with prime factors > 31 exceeds 4096.  ValueError naming the remedy.  (Smaller primes run Bluestein passes.)"""
+    """What has no kernel: a time axis whose part with prime factors > 31 exceeds 2048 (ns / 2 = 4099).  ValueError naming
+    the remedy.  (Smaller primes run Bluestein passes; the channel axis takes any count.)"""
     assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
     x = np.random.default_rng(0).standard_normal((8, 2 * 37))
     m = np.random.default_rng(1).uniform(size=x.shape)
     assert np.max(np.abs(dw.dsp.fk_filter_filt(x, m) - orc.fk_filter_filt(x, m))) < 1e-5 * np.max(np.abs(x))
-    for shape in ((8, 2 * 4099), (4099, 16)):
+    for shape in ((8, 2 * 4099),):
         x = np.zeros(shape)
         with pytest.raises(ValueError, match="supported_length"):
             dw.dsp.fk_filter_filt(x, np.ones_like(x))
