@@ -821,6 +821,22 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         }
     }
     if (fast_only && !fast) return fail(D4W_EINVAL, "no shape-specialised kernels for %d x %d", nx, ns);
+    // An axis whose part with prime factors > 31 does not fit the Bluestein tiles of passes C / B: the global-memory forms
+    // (fkd_bz_* / fkd_bt_*) of the generic distributed plan at world 1, behind this plan's entry points
+    auto make_big = [&]() -> int {
+        d4w_fkd_plan* big = nullptr;
+        int rcb = fkd_plan_build(nx, ns, 1, 0, true, &big);
+        if (rcb) return rcb;
+        int info[12];
+        (void)d4w_fkd_plan_info(big, info);
+        d4w_fk_plan* bp = new d4w_fk_plan();
+        memset(&bp->dev, 0, sizeof(bp->dev));
+        bp->dev.d = FkDims{nx, ns, M, info[9], info[10], info[6], info[7], 1, 1};
+        bp->big = big;
+        bp->live_rows = nx;
+        *out = bp;
+        return D4W_OK;
+    };
     // A prime factor > 31 of ns / 2 goes into N2, whose sub-transforms (pass B) then run as Bluestein convolutions of
     // length bn_L = 2^k >= 2 N2 - 1 inside the tile (two rows of bn_L); N1 keeps the smooth part.
     int bn_L = 0, bn_N2 = 0;
@@ -828,9 +844,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         bn_N2 = rough_part(M);
         bn_L = 1;
         while (bn_L < 2 * bn_N2 - 1) bn_L *= 2;
-        if (2L * bn_L > kMaxTile)
-            return fail(D4W_EINVAL, "ns / 2 = %d: the part with prime factors > 31 (%d) is too long for the Bluestein tile (limit %d); "
-                        "dsp.supported_length(n) gives the nearest shorter length with a direct kernel", M, bn_N2, kMaxTile / 4);
+        if (2L * bn_L > kMaxTile) return make_big();
     }
     // admissible time splits: N1 | M with N2 = M / N1 fitting one LDS row pair
     int n1_min = 0;
@@ -869,21 +883,8 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         bs_L = 1;
         while (bs_L < 2 * C2 - 1) bs_L *= 2;
         if (bs_L > kMaxTile) {
-            // too long for the Bluestein tile of pass C: the global-memory form (any channel count; the time axis
-            // must factor into primes <= 31 there)
-            if (fast_only) return fail(D4W_EINVAL, "no shape-specialised kernels for %d x %d", nx, ns);
-            d4w_fkd_plan* big = nullptr;
-            int rcb = fkd_plan_build(nx, ns, 1, 0, true, &big);
-            if (rcb) return rcb;
-            int info[12];
-            (void)d4w_fkd_plan_info(big, info);
-            d4w_fk_plan* pl = new d4w_fk_plan();
-            memset(&pl->dev, 0, sizeof(pl->dev));
-            pl->dev.d = FkDims{nx, ns, M, info[9], info[10], info[6], info[7], 1, 1};
-            pl->big = big;
-            pl->live_rows = nx;
-            *out = pl;
-            return D4W_OK;
+            // too long for the Bluestein tile of pass C: the global-memory form
+            return make_big();
         }
     }
     // --- split the time axis.  Pass A's cost falls like 1 / (C1 N1) until its tile holds ~100 columns, pass B's
@@ -897,8 +898,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             while (N1 % f == 0 && (long)C1 * N1 > kMaxTile && 2L * (2L * N2 * f - 1) <= kMaxTile) { N2 *= f; N1 /= f; }
         bn_L = 1;
         while (bn_L < 2 * N2 - 1) bn_L *= 2;
-        if (2L * bn_L > kMaxTile || (long)C1 * N1 > kMaxTile)
-            return fail(D4W_EINVAL, "shape %d x %d does not fit the LDS tiling with a Bluestein time axis (C1=%d N1=%d N2=%d)", nx, ns, C1, N1, N2);
+        if (2L * bn_L > kMaxTile || (long)C1 * N1 > kMaxTile) return make_big();
     } else if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
         N1 = n1_min;
         const double target = sqrt(1000.0 / (double)C1);
@@ -1807,6 +1807,166 @@ __global__ __launch_bounds__(kMaxThreads) void fkd_bz_passC(FkDev P, FkdBz Z, fl
     }
 }
 
+// The time transform of the packed rows (length M = ns / 2 with a prime factor > 31) the same way, row by row: a chunk
+// of rows in a scratch [R][L], L = 2^a 3^b 5^c >= 2 M - 1, and per direction
+//   fkd_bt_passA_fwd : row x (window) x chirp, zero beyond M -> n1 transform, x W_L -> scratch   (fk_passA_fwd, C1 = 1)
+//   fkd_bt_rows      : n2 transform, x filter at the position, inverse n2 transform             (fkd_rows_n2 twice)
+//   fkd_bt_passA_inv : x conj W_L, inverse n1 transform, x chirp x scale -> the row's first M elements
+struct FkdBt {
+    const float2* chirp;      // [M]
+    const float2* filt;       // [L] at positions [q1][i]
+    const float2* win;        // [M] packed window, or NULL
+    size_t pitch;             // row pitch of the rows outside the scratch (complex) = M
+    int m, inv;               // M; 1: conjugated tables
+    float scale;
+};
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_bt_passA_fwd(FkDev P, FkdBt Z, const float2* __restrict__ rows,
+                                                                float2* __restrict__ S, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TA = d.TA;
+    const int nelem = d.N1 * TA;
+    const int ntx = (d.N2 + TA - 1) / TA;
+    const FDiv dTA(TA), dntx(ntx);
+    const TwLds tw_n1 = tw_stage(P.ax_n1, tile + nelem, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int row = dntx.div(t), b0 = (t - row * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int n1 = dTA.div(w), tt = w - n1 * TA;
+                const int col = n1 * d.N2 + b0 + tt;
+                if (tt < ncol && col < Z.m) {
+                    v = rows[(size_t)row * Z.pitch + col];
+                    if (Z.win) {
+                        const float2 wv = Z.win[col];
+                        v.x *= wv.x;
+                        v.y *= wv.y;
+                    }
+                    float2 ch = Z.chirp[col];
+                    if (Z.inv) ch.y = -ch.y;
+                    v = c_mul(v, ch);
+                }
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) tile[w] = pf[it];
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<false, true, GENERIC>(tile, P.ax_n1, tw_n1, TA, TA, 1, 1, d.N1 * TA, tid, nthr);
+        const int row = dntx.div(t), b0 = (t - row * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int q1 = dTA.div(w), tt = w - q1 * TA;
+            if (tt < ncol) S[(size_t)row * d.M + q1 * d.N2 + b0 + tt] = c_mul(tile[w], P.twt[q1 * d.N2 + b0 + tt]);
+        }
+        lds_barrier();
+        t = next;
+    }
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_bt_passA_inv(FkDev P, FkdBt Z, const float2* __restrict__ S,
+                                                                float2* __restrict__ rows, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TA = d.TA;
+    const int nelem = d.N1 * TA;
+    const int ntx = (d.N2 + TA - 1) / TA;
+    const FDiv dTA(TA), dntx(ntx);
+    const TwLds tw_n1 = tw_stage(P.ax_n1, tile + nelem, tid, nthr);
+    float2 pf[kPF];
+    auto issue = [&](int t) {
+        const int row = dntx.div(t), b0 = (t - row * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const int q1 = dTA.div(w), tt = w - q1 * TA;
+                if (tt < ncol) v = S[(size_t)row * d.M + q1 * d.N2 + b0 + tt];
+            }
+            pf[it] = v;
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+        const int row = dntx.div(t), b0 = (t - row * ntx) * TA;
+        const int ncol = min(TA, d.N2 - b0);
+#pragma unroll
+        for (int it = 0; it < kPF; ++it) {
+            const int w = tid + it * nthr;
+            if (w < nelem) {
+                const int q1 = dTA.div(w), tt = w - q1 * TA;
+                float2 v = pf[it];
+                if (tt < ncol) v = c_mulc(v, P.twt[q1 * d.N2 + b0 + tt]);
+                tile[w] = v;
+            }
+        }
+        lds_barrier();
+        const int next = t + gridDim.x;
+        if (next < ntiles) issue(next);
+        lds_fft<true, true, GENERIC>(tile, P.ax_n1, tw_n1, TA, TA, 1, 1, d.N1 * TA, tid, nthr);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int n1 = dTA.div(w), tt = w - n1 * TA;
+            const int col = n1 * d.N2 + b0 + tt;
+            if (tt < ncol && col < Z.m) {
+                float2 ch = Z.chirp[col];
+                if (Z.inv) ch.y = -ch.y;
+                rows[(size_t)row * Z.pitch + col] = c_mul(tile[w], c_scale(ch, Z.scale));
+            }
+        }
+        lds_barrier();
+        t = next;
+    }
+}
+
+template <bool GENERIC>
+__global__ __launch_bounds__(kMaxThreads) void fkd_bt_rows(FkDev P, FkdBt Z, float2* __restrict__ S, int nsub) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N2 = P.d.N2, N1 = P.d.N1;
+    const TwLds tw = tw_stage(P.ax_n2, tile + N2, tid, nthr);
+    for (int t = blockIdx.x; t < nsub; t += gridDim.x) {
+        float2* row = S + (size_t)t * N2;
+        const float2* f = Z.filt + (size_t)(t % N1) * N2;
+        for (int w = tid; w < N2; w += nthr) tile[w] = row[w];
+        lds_barrier();
+        lds_fft<false, false, GENERIC>(tile, P.ax_n2, tw, 1, 1, 0, 1, 0, tid, nthr);
+        for (int w = tid; w < N2; w += nthr) {
+            float2 fv = f[w];
+            if (Z.inv) fv.y = -fv.y;
+            tile[w] = c_mul(tile[w], fv);
+        }
+        lds_barrier();
+        lds_fft<true, false, GENERIC>(tile, P.ax_n2, tw, 1, 1, 0, 1, 0, tid, nthr);
+        for (int w = tid; w < N2; w += nthr) row[w] = tile[w];
+        lds_barrier();
+    }
+}
+
 // folded mask of the owned sub-rows (fk_fold_mask restricted to a q1 subset)
 __global__ __launch_bounds__(kThreads) void fkd_fold_mask(int nx, int ns, int N1, int N2, int nq,
                                                            const float* __restrict__ ms,
@@ -1883,6 +2043,13 @@ struct d4w_fkd_plan {
     float2* bz_S = nullptr;                 // [bz_L][bz_W]
     const float2* bz_chirp = nullptr;       // [nx]    exp(-i pi n^2 / nx)
     const float2* bz_filt = nullptr;        // [bz_L]  FFT of the wrapped conjugate chirp / bz_L at the row positions of cp
+    // ---- ns / 2 with a prime factor > 31: the same for the time transform of the packed rows (fkd_bt_*); the half
+    //      spectrum then comes out in natural order, N1 = 1, N2 = ns / 2, while tp describes the length-bt_L transform
+    int bt_L = 0, bt_R = 0;                 // transform length (0: off), rows per scratch chunk
+    float2* bt_S = nullptr;                 // [bt_R][bt_L]
+    const float2* bt_chirp = nullptr;       // [M]     exp(-i pi m^2 / M)
+    const float2* bt_filt = nullptr;        // [bt_L]  at the positions [q1][i] of tp
+    const float2* bt_win = nullptr;         // [M]     packed tukey(ns, 0.03)
     // ---- packed path: the shape has specialised kernels (fk_fast.h, FkGeo).  The exchange buffers need no repacking:
     //      the time phase writes sub-row q1 of local row l at  blk_off[owner[q1]] + l * nq[owner] * N2 + jq(q1) * N2
     //      (destination rank major), so that the all-to-all delivers the slab [nx][nq][N2] as it stands.
@@ -2042,32 +2209,37 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     if (world < 1 || rank < 0 || rank >= world || world > nx) return fail(D4W_EINVAL, "bad world %d / rank %d", world, rank);
     if (want_mask && fkd_plan_build_packed(nx, ns, world, rank, want_mask, out) == D4W_OK) return D4W_OK;
     const int M = ns / 2;
-    // time axis M = N1 * N2: N2 in one LDS row, and enough n1-positions (Hermitian classes) to balance the ranks
-    int N1 = 0;
-    for (int cand = 1; cand <= M; ++cand) {
-        if (M % cand) continue;
-        if (M / cand > kMaxTile / 2) continue;
-        if (N1 == 0) N1 = cand;                              // smallest admissible
-        if (cand >= 4 * world && cand <= 512) { N1 = cand; break; }
-        if (cand > 512) break;
-    }
-    if (N1 == 0) return fail(D4W_EINVAL, "ns/2 = %d has no factorisation with N2 <= %d", M, kMaxTile / 2);
-    const int N2 = M / N1;
-    // a channel count with a prime factor > 31: the channel transform is a Bluestein convolution of length bz_L = 2^a 3^b 5^c
-    // in global memory (fkd_bz_*), and the channel-phase descriptor below is the one of that length
-    int bz_L = 0;
-    if (want_mask && rough_part(nx) > 1) {
-        // the shortest length >= 2 nx - 1 of the form 2^a 3^b 5^c (the unrolled radices; a power of two can be ~2x longer)
+    // the shortest length >= n of the form 2^a 3^b 5^c (the unrolled radices; a power of two can be ~2x longer)
+    auto smooth_len = [](long n) {
         const char* p2 = getenv("D4W_FKD_BZ_POW2");
         long best = 1;
-        while (best < 2L * nx - 1) best *= 2;
+        while (best < n) best *= 2;
         if (!(p2 && atoi(p2) > 0))
             for (long a = 1; a < best; a *= 2)
                 for (long b = a; b < best; b *= 3)
                     for (long c = b; c < best; c *= 5)
-                        if (c >= 2L * nx - 1 && c < best) best = c;
-        bz_L = (int)best;
+                        if (c >= n && c < best) best = c;
+        return (int)best;
+    };
+    // ns / 2 with a prime factor > 31: the time transform of the packed rows is a Bluestein convolution of length bt_L in
+    // global memory (fkd_bt_*); tp describes that length and the half spectrum comes out in natural order (N1 = 1)
+    const int bt_L = (rough_part(M) > 1) ? smooth_len(2L * M - 1) : 0;
+    const int Mt = bt_L ? bt_L : M;
+    // time axis Mt = tN1 * tN2: tN2 in one LDS row, and enough n1-positions (Hermitian classes) to balance the ranks
+    int tN1 = 0;
+    for (int cand = 1; cand <= Mt; ++cand) {
+        if (Mt % cand) continue;
+        if (Mt / cand > kMaxTile / 2) continue;
+        if (tN1 == 0) tN1 = cand;                            // smallest admissible
+        if (cand >= 4 * (bt_L ? 1 : world) && cand <= 512) { tN1 = cand; break; }
+        if (cand > 512) break;
     }
+    if (tN1 == 0) return fail(D4W_EINVAL, "ns/2 = %d has no factorisation with N2 <= %d", M, kMaxTile / 2);
+    const int tN2 = Mt / tN1;
+    const int N1 = bt_L ? 1 : tN1, N2 = bt_L ? M : tN2;      // layout of the half spectrum: [row][N1][N2]
+    // a channel count with a prime factor > 31: the channel transform is a Bluestein convolution of length bz_L = 2^a 3^b 5^c
+    // in global memory (fkd_bz_*), and the channel-phase descriptor below is the one of that length
+    const int bz_L = (want_mask && rough_part(nx) > 1) ? smooth_len(2L * nx - 1) : 0;
     // (no mask = the time phase only, d4w_analytic_long_f32: any row count, the channel descriptor stays a dummy)
     const int Lc = !want_mask ? 1 : (bz_L ? bz_L : nx);
     int C2 = largest_divisor_le(Lc, kMaxTile / 8);
@@ -2085,31 +2257,67 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     memset(&tp.dev, 0, sizeof(tp.dev));
     // one degenerate axis leaves the whole LDS tile to the other: long contiguous strips
     int TA = 512;
-    while (TA > 1 && ((long)N1 * TA > kMaxTile || TA > N2)) TA /= 2;
-    if ((long)N1 * TA > kMaxTile) { d4w_fkd_plan_destroy(pl); return fail(D4W_EINVAL, "N1 = %d exceeds the LDS tile", N1); }
+    while (TA > 1 && ((long)tN1 * TA > kMaxTile || TA > tN2)) TA /= 2;
+    if ((long)tN1 * TA > kMaxTile) { d4w_fkd_plan_destroy(pl); return fail(D4W_EINVAL, "N1 = %d exceeds the LDS tile", tN1); }
     pl->TA_t = TA;
-    tp.dev.d = FkDims{nxl, ns, M, 1, nxl, N1, N2, TA, 1};
+    tp.dev.d = FkDims{nxl, 2 * Mt, Mt, 1, nxl, tN1, tN2, TA, 1};
     tp.dev.scale = 1.0f;
-    std::vector<int> f_one, f_n1, f_n2, f_c1, f_c2;
+    std::vector<int> f_one, tf_n1, tf_n2, f_n1, f_n2, f_c1, f_c2;
     D4W_TRY(make_axis(&tp, 1, &tp.dev.ax_c1, &f_one));
     D4W_TRY(make_axis(&tp, 1, &tp.dev.ax_c2, &f_one));
-    D4W_TRY(make_axis(&tp, N1, &tp.dev.ax_n1, &f_n1));
-    D4W_TRY(make_axis(&tp, N2, &tp.dev.ax_n2, &f_n2));
+    D4W_TRY(make_axis(&tp, tN1, &tp.dev.ax_n1, &tf_n1));
+    D4W_TRY(make_axis(&tp, tN2, &tp.dev.ax_n2, &tf_n2));
     {
-        std::vector<float2> ones((size_t)nxl, make_float2(1.f, 0.f)), twt((size_t)N1 * N2);
-        for (int q1 = 0; q1 < N1; ++q1)
-            for (int b = 0; b < N2; ++b) twt[(size_t)q1 * N2 + b] = wexp((long long)b * f_n1[q1], M);
+        std::vector<float2> ones((size_t)nxl, make_float2(1.f, 0.f)), twt((size_t)tN1 * tN2);
+        for (int q1 = 0; q1 < tN1; ++q1)
+            for (int b = 0; b < tN2; ++b) twt[(size_t)q1 * tN2 + b] = wexp((long long)b * tf_n1[q1], Mt);
         D4W_TRY(upload(&tp, ones, &tp.dev.twc));
         D4W_TRY(upload(&tp, twt, &tp.dev.twt));
         std::vector<float> win = tukey_window(ns, 0.03);
         std::vector<float2> winp(M);
         for (int m = 0; m < M; ++m) winp[m] = make_float2(win[2 * m], win[2 * m + 1]);
         D4W_TRY(upload(&tp, winp, &tp.dev.win));
+        pl->bt_win = tp.dev.win;
     }
     pl->gen_t = axis_needs_generic(tp.dev.ax_n1);
     pl->gen_n2 = axis_needs_generic(tp.dev.ax_n2);
-    pl->lds_t = ((size_t)N1 * TA + 2 * kTwLo + tp.dev.ax_c1.nhi + tp.dev.ax_n1.nhi) * sizeof(float2);
-    pl->lds_n2 = ((size_t)N2 + kTwLo + tp.dev.ax_n2.nhi) * sizeof(float2);
+    pl->lds_t = ((size_t)tN1 * TA + 2 * kTwLo + tp.dev.ax_c1.nhi + tp.dev.ax_n1.nhi) * sizeof(float2);
+    pl->lds_n2 = ((size_t)tN2 + kTwLo + tp.dev.ax_n2.nhi) * sizeof(float2);
+    if (bt_L) {
+        f_n1.assign(1, 0);
+        f_n2.resize(M);
+        for (int i = 0; i < M; ++i) f_n2[i] = i;
+        std::vector<float2> chirp(M), filt(bt_L);
+        std::vector<double> bre(bt_L, 0.0), bim(bt_L, 0.0);
+        for (int n = 0; n < M; ++n) {
+            const double ph = M_PI * (double)(((long long)n * n) % (2LL * M)) / (double)M;
+            chirp[n] = make_float2((float)cos(ph), (float)-sin(ph));
+            bre[n] = cos(ph); bim[n] = sin(ph);                               // conj(chirp)
+            if (n) { bre[bt_L - n] = cos(ph); bim[bt_L - n] = sin(ph); }
+        }
+        host_dft_any(bre, bim);
+        for (int q1 = 0; q1 < tN1; ++q1)
+            for (int i = 0; i < tN2; ++i) {
+                const int f = tf_n1[q1] + tN1 * tf_n2[i];                     // frequency at position [q1][i]
+                filt[(size_t)q1 * tN2 + i] = make_float2((float)(bre[f] / bt_L), (float)(bim[f] / bt_L));
+            }
+        D4W_TRY(upload(&tp, chirp, &pl->bt_chirp));
+        D4W_TRY(upload(&tp, filt, &pl->bt_filt));
+        const char* ch = getenv("D4W_FKD_BT_CHUNK");
+        const int lim = (ch && atoi(ch) > 0) ? atoi(ch) : std::max(1, (int)(((size_t)1 << 27) / (size_t)bt_L));
+        const int R = std::min(nxl, lim);
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)R * bt_L * sizeof(float2)) != hipSuccess) {
+            d4w_fkd_plan_destroy(pl);
+            return fail(D4W_ENOMEM, "hipMalloc of the Bluestein scratch (%d x %d complex) failed", R, bt_L);
+        }
+        tp.allocs.push_back(p);
+        pl->bt_S = (float2*)p;
+        pl->bt_L = bt_L; pl->bt_R = R;
+    } else {
+        f_n1 = tf_n1;
+        f_n2 = tf_n2;
+    }
 
     // ---------------- ownership of the n1-positions: Hermitian classes {q1, q1'} dealt round-robin
     std::vector<int> p_n1(N1), q1part(N1);
@@ -2254,7 +2462,10 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
             (const void*)fkd_rows_n2<true, true>, (const void*)fkd_rows_n2<true, false>,
             (const void*)fkd_bz_passA_fwd<true>, (const void*)fkd_bz_passA_fwd<false>,
             (const void*)fkd_bz_passA_inv<true>, (const void*)fkd_bz_passA_inv<false>,
-            (const void*)fkd_bz_passC<true>, (const void*)fkd_bz_passC<false>};
+            (const void*)fkd_bz_passC<true>, (const void*)fkd_bz_passC<false>,
+            (const void*)fkd_bt_passA_fwd<true>, (const void*)fkd_bt_passA_fwd<false>,
+            (const void*)fkd_bt_passA_inv<true>, (const void*)fkd_bt_passA_inv<false>,
+            (const void*)fkd_bt_rows<true>, (const void*)fkd_bt_rows<false>};
         for (const void* f : fns)
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
@@ -2485,9 +2696,36 @@ static int fkd_chan_apply_packed(d4w_fkd_plan* pl, float* slab, void* stream) {
     return launch_k(F.Ac_inv, gA, dim3(F.thrA), F.ldsA, stream, pl->dev_c, d2, 0, ntA, nblkA, 0, pl->geo_c, (const float2*)nullptr);
 }
 
+}  // extern "C"
+// time transform of the local rows as a Bluestein convolution through the scratch, a chunk of rows at a time
+// (inv = 0: packed real rows -> half spectrum in natural order; inv = 1: back, x tp.dev.scale)
+static int fkd_time_bluestein(d4w_fkd_plan* pl, const float2* src, float2* dst, int inv, int taper, void* stream) {
+    FkDev P = pl->tp.dev;
+    P.scale = 1.0f;
+    const int nxl = P.d.nx, L = pl->bt_L, R = pl->bt_R;
+    const int persist = pl->num_cu * 4;
+    const dim3 blk(kMaxThreads);
+    FkdBt Z;
+    Z.chirp = pl->bt_chirp; Z.filt = pl->bt_filt; Z.win = (taper && !inv) ? pl->bt_win : nullptr;
+    Z.pitch = (size_t)pl->M; Z.m = pl->M; Z.inv = inv;
+    Z.scale = inv ? pl->tp.dev.scale : 1.0f;
+    (void)L;
+    for (int r0 = 0; r0 < nxl; r0 += R) {
+        const int nr = std::min(R, nxl - r0);
+        const int ntA = ceil_div(P.d.N2, P.d.TA) * nr, nsub = nr * P.d.N1;
+        int rc;
+        if ((rc = launch_k(pl->gen_t ? fkd_bt_passA_fwd<true> : fkd_bt_passA_fwd<false>, dim3(std::min(ntA, persist)), blk, pl->lds_t, stream, P, Z, src + (size_t)r0 * pl->M, pl->bt_S, ntA))) return rc;
+        if ((rc = launch_k(pl->gen_n2 ? fkd_bt_rows<true> : fkd_bt_rows<false>, dim3(std::min(nsub, persist)), blk, pl->lds_n2, stream, P, Z, pl->bt_S, nsub))) return rc;
+        if ((rc = launch_k(pl->gen_t ? fkd_bt_passA_inv<true> : fkd_bt_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_t, stream, P, Z, (const float2*)pl->bt_S, dst + (size_t)r0 * pl->M, ntA))) return rc;
+    }
+    return D4W_OK;
+}
+extern "C" {
+
 int d4w_fkd_time_fwd_f32(d4w_fkd_plan* pl, const float* x_loc, float* z_loc, int taper, void* stream) {
     if (!pl || !x_loc || !z_loc) return fail(D4W_EINVAL, "NULL argument");
     if (pl->sp) return fail(D4W_EINVAL, "this shape runs the packed distributed plan: d4w_fkd_time_fwd_packed_f32");
+    if (pl->bt_L) return fkd_time_bluestein(pl, reinterpret_cast<const float2*>(x_loc), reinterpret_cast<float2*>(z_loc), 0, taper, stream);
     const FkDev& P = pl->tp.dev;
     const int nxl = P.d.nx;
     const int ntA = ceil_div(P.d.N2, P.d.TA) * nxl, nsub = nxl * pl->N1;
@@ -2505,6 +2743,7 @@ int d4w_fkd_time_fwd_f32(d4w_fkd_plan* pl, const float* x_loc, float* z_loc, int
 int d4w_fkd_time_inv_f32(d4w_fkd_plan* pl, float* z_loc, void* stream) {
     if (!pl || !z_loc) return fail(D4W_EINVAL, "NULL argument");
     if (pl->sp) return fail(D4W_EINVAL, "this shape runs the packed distributed plan: d4w_fkd_time_inv_packed_f32");
+    if (pl->bt_L) return fkd_time_bluestein(pl, reinterpret_cast<const float2*>(z_loc), reinterpret_cast<float2*>(z_loc), 1, 0, stream);
     const FkDev& P = pl->tp.dev;
     const int nxl = P.d.nx;
     const int ntA = ceil_div(P.d.N2, P.d.TA) * nxl, nsub = nxl * pl->N1;

@@ -158,10 +158,10 @@ class FkPlan:
 
 def supported_length(n, even=False):
     """Largest length <= n whose prime factors are all <= 31 (what the mixed-radix kernels carry), optionally
-    even.  The f-k filter accepts ANY channel count (prime factors > 31 run as Bluestein convolutions, slower --
-    several times slower when that part of the count exceeds 4096); the time axis (ns / 2) and the row transforms
-    (hilbert, spectrogram window, get_fx) need smooth lengths.  Use this to trim a record or a selection,
-    e.g. 12002 samples -> 12000."""
+    even.  Everything runs at other lengths too, slower: the f-k filter takes any shape (prime factors > 31 run as
+    Bluestein convolutions -- several times slower when that part exceeds 4096 channels / 2048 of ns / 2), so do
+    hilbert / spectrogram windows / get_fx up to their LDS limits.  Use this to trim a record or a selection onto
+    the direct kernels, e.g. 12002 samples -> 12000."""
     n = int(n)
     while n > 1:
         m = n

@@ -40,10 +40,10 @@ const char* d4w_version(void);
  * also the apply half of dsp.fk_filt (dsp.py:919,948-953).
  *
  * A plan owns the factorisation of the packed 2-D transform (nx x ns/2 complex), its twiddle /
- * index tables and the folded, permuted mask.  Requirements: ns even.  nx: any (prime factors > 31
- * run Bluestein convolutions: inside pass C's LDS tile while that part of nx is <= 4096, in global
- * memory -- scratch <= 1 GiB owned by the plan, several times slower -- beyond; the latter needs ns/2
- * to factor into primes <= 31); ns/2: its part with prime factors > 31 must be <= 2048.  Plans are immutable after set_mask and may be shared by streams that serialise
+ * index tables and the folded, permuted mask.  Requirements: ns even.  nx, ns / 2: any (prime factors
+ * > 31 run Bluestein convolutions: inside the LDS tiles of passes C / B while that part of nx is
+ * <= 4096 and that part of ns / 2 <= 2048, in global memory -- scratch <= 1 GiB per axis owned by the
+ * plan, several times slower -- beyond).  Plans are immutable after set_mask and may be shared by streams that serialise
  * their own calls.
  * ------------------------------------------------------------------------------------------ */
 typedef struct d4w_fk_plan d4w_fk_plan;
@@ -147,9 +147,10 @@ int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* plan, const float* x, float* y, in
  *                                 inverse n2, inverse c2, inverse c1    (five launches of the fk_fast.h kernels)
  *   d4w_fkd_time_inv_packed_f32   packed -> y_loc [nxl][ns]
  * Seven block passes per rank over its share instead of the single-device five; the generic plan (any other
- * shape) keeps the z_loc / index-packing protocol above.  Generic plan: nx any (a prime factor > 31 turns the
- * slab's channel transform into a Bluestein convolution in global memory: scratch <= 1 GiB owned by the plan,
- * D4W_FKD_BZ_CHUNK = columns per chunk), ns / 2 factoring into primes <= 31.
+ * shape) keeps the z_loc / index-packing protocol above.  Generic plan: nx, ns / 2 any (a prime factor > 31 turns
+ * the slab's channel transform / the rows' time transform into a Bluestein convolution in global memory: scratch
+ * <= 1 GiB each owned by the plan, D4W_FKD_BZ_CHUNK = columns / D4W_FKD_BT_CHUNK = rows per chunk; with such an
+ * ns / 2 the half spectrum is one natural-order class, N1 = 1, owned by rank 0).
  * ------------------------------------------------------------------------------------------ */
 typedef struct d4w_fkd_plan d4w_fkd_plan;
 int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** plan);

@@ -159,15 +159,14 @@ def test_channel_count_with_large_prime_factor(emu, nx, ns):
 
 def test_channel_count_too_long_for_bluestein_tile(emu, monkeypatch):
     """A prime channel count > 4096 does not fit pass C's Bluestein tile: the plan runs the global-memory form (the generic
-    distributed plan at world 1 behind the same entry points: dense / affine / designed masks, taper, row statistics)."""
-    monkeypatch.setenv("D4W_FKD_BZ_CHUNK", "6")
-    nx, ns = 4099, 16
+    distributed plan at world 1 behind the same entry points; here: affine mask fold, taper, row statistics in ONE apply --
+    the emulator walks 4099 workgroups per pass; both axes beyond their tiles at once:
+    tests/test_emu_fk_dist.py::test_dist_record_length_with_large_prime_factor, tests/test_fuzz_gpu.py)."""
+    monkeypatch.setenv("D4W_FKD_BZ_CHUNK", "3")
+    nx, ns = 4099, 8
     rng = np.random.default_rng(5)
     x = rng.standard_normal((nx, ns))
     m = rng.random((nx, ns))
-    ref = orc.fk_filter_filt(x, m)
-    assert rel(fk_emu(emu, x, m), ref) < TOL
-    assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
     plan = ctypes.c_void_p()
     assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
     info = (ctypes.c_int * 8)()
@@ -176,24 +175,17 @@ def test_channel_count_too_long_for_bluestein_tile(emu, monkeypatch):
     xf = x.astype(np.float32)
     y = np.empty_like(xf)
     assert emu.d4w_fk_apply_f32(plan, vp(xf), vp(y), 0, None) != 0 and b"no mask" in emu.d4w_last_error()
-    # the affine fold (dsp.fk_filt's normalisation) and the row statistics
     mf = m.astype(np.float32)
     a, b = np.float32(0.75), np.float32(0.125)
     assert emu.d4w_fk_set_mask_dense_affine_f32(plan, vp(mf), ctypes.c_float(a), ctypes.c_float(b), None) == 0
     mean = np.empty(nx, dtype=np.float32)
     mx = np.empty(nx, dtype=np.float32)
-    assert emu.d4w_fk_apply_stats_f32(plan, vp(xf), vp(y), 0, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
-    ref2 = orc.fk_filter_filt(x, (mf * a + b).astype(np.float64))
-    assert rel(y, ref2) < TOL
+    assert emu.d4w_fk_apply_stats_f32(plan, vp(xf), vp(y), 1, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
+    emu.d4w_fk_plan_destroy(plan)
+    ref = orc.fk_filter_filt(x, (mf * a + b).astype(np.float64), tapering=True)
+    assert rel(y, ref) < TOL
     assert np.max(np.abs(mean - y.astype(np.float64).mean(axis=1))) < 1e-6 * np.abs(y).max()
     assert np.allclose(mx, np.abs(y.astype(np.float64)).max(axis=1), rtol=1e-6)
-    # in place
-    buf = xf.copy()
-    assert emu.d4w_fk_apply_f32(plan, vp(buf), vp(buf), 0, None) == 0
-    assert rel(buf, ref2) < TOL
-    emu.d4w_fk_plan_destroy(plan)
-    # rough on both axes: the global-memory form needs a time axis of primes <= 31
-    assert emu.d4w_fk_plan_create(4099, 2 * 37, ctypes.byref(plan)) != 0
 
 
 @pytest.mark.parametrize("nx,ns", [(2, 5), (6, 15), (9, 27)])
@@ -300,7 +292,17 @@ def test_record_length_with_large_prime_factor(emu, nx, ns):
     assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
 
 
-def test_record_length_too_long_for_bluestein_tile(emu):
-    plan = ctypes.c_void_p()
-    assert emu.d4w_fk_plan_create(8, 2 * 4099, ctypes.byref(plan)) != 0        # prime > 2048 in ns / 2
-    assert b"supported_length" in emu.d4w_last_error()
+@pytest.mark.parametrize("nx,ns,chunk", [(8, 2 * 4099, 0), (5, 2 * 2 * 2053, 3), (6, 2 * 6007, 4)])
+def test_record_length_too_long_for_bluestein_tile(emu, nx, ns, chunk, monkeypatch):
+    """ns / 2 whose part with prime factors > 31 exceeds 2048 (pass B's Bluestein tile): the time transform of the packed rows
+    runs as a Bluestein convolution in global memory (fkd_bt_*), a chunk of rows at a time (D4W_FKD_BT_CHUNK pins a chunk
+    smaller than the block, with a ragged last one); 12014 = 2 x 6007 is a 60-s file cut 14 samples long."""
+    if chunk:
+        monkeypatch.setenv("D4W_FKD_BT_CHUNK", str(chunk))
+    rng = np.random.default_rng(nx + ns)
+    x = rng.standard_normal((nx, ns))
+    m = rng.random((nx, ns))
+    assert rel(fk_emu(emu, x, m), orc.fk_filter_filt(x, m)) < TOL
+    assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+    if chunk == 3:
+        assert rel(fk_emu(emu, x, np.ones((nx, ns))), x) < TOL

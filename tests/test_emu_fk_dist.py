@@ -134,6 +134,17 @@ def test_dist_channel_count_with_large_prime_factor(emu, nx, ns, world, chunk, m
         assert rel(fk_sharded_emu(emu, x, np.ones((nx, ns)), world), x) < TOL
 
 
+@pytest.mark.parametrize("nx,ns,world", [(12, 74, 1), (10, 2 * 41 * 3, 2), (37, 2 * 43, 3)])
+def test_dist_record_length_with_large_prime_factor(emu, nx, ns, world):
+    """ns / 2 with a prime factor > 31 on the generic distributed plan: the local rows' time transform is the global-memory
+    Bluestein form (fkd_bt_*), the half spectrum a single natural-order class (one rank runs the channel phase)."""
+    rng = np.random.default_rng(ns + world)
+    x = rng.standard_normal((nx, ns))
+    m = rng.uniform(0, 1, (nx, ns))
+    assert rel(fk_sharded_emu(emu, x, m, world), orc.fk_filter_filt(x, m)) < TOL
+    assert rel(fk_sharded_emu(emu, x, m, world, taper=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+
+
 def test_dist_plan_errors(emu):
     h = ctypes.c_void_p()
     assert emu.d4w_fkd_plan_create(40, 481, 2, 0, ctypes.byref(h)) == -1

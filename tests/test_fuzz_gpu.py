@@ -221,14 +221,28 @@ def test_any_channel_count(dw):
     assert rel(dw.dsp.fk_filt(x, 1, FS, 1, 2.04, 1400., 3500.), orc.fk_filt(x, 1, FS, 1, 2.04, 1400., 3500.)) < TOL
 
 
+def test_any_record_length(dw):
+    """ns / 2 whose part with prime factors > 31 exceeds 2048 (pass B's Bluestein tile), odd record lengths that zero
+    interleaving turns into such, and both axes at once: the global-memory Bluestein form of the time transform (fkd_bt_*)."""
+    rng = np.random.default_rng(112)
+    for nx, ns in ((8, 2 * 4099), (300, 12014), (64, 6007), (4099, 2 * 2053)):      # 12014 = 2 x 6007; 6007 odd and prime
+        x = rng.standard_normal((nx, ns))
+        m = rng.random((nx, ns))
+        assert rel(dw.dsp.fk_filter_filt(x, m), orc.fk_filter_filt(x, m)) < TOL, (nx, ns)
+    assert rel(dw.dsp.fk_filter_filt(x, m, tapering=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+    # long analytic rows (beyond one workgroup's LDS) with a prime factor > 31, any row count
+    x = rng.standard_normal((37, 2 * 20011))
+    z = orc.hilbert(x)
+    assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL
+    assert rel(dw.dsp.hilbert_imag(x), z.imag) < TOL
+
+
 def test_unsupported_length_is_a_clear_error(dw):
-    """What has no kernel: a time axis whose part with prime factors > 31 exceeds 2048 (ns / 2 = 4099).  ValueError naming
-    the remedy.  (Smaller primes run Bluestein passes; the channel axis takes any count.)"""
+    """What is left without a kernel: single-row transforms (get_fx, odd analytic rows) whose Bluestein tile exceeds a
+    workgroup's LDS.  ValueError, not a wrong answer.  (The f-k filter takes any shape.)"""
     assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
     x = np.random.default_rng(0).standard_normal((8, 2 * 37))
     m = np.random.default_rng(1).uniform(size=x.shape)
     assert np.max(np.abs(dw.dsp.fk_filter_filt(x, m) - orc.fk_filter_filt(x, m))) < 1e-5 * np.max(np.abs(x))
-    for shape in ((8, 2 * 4099),):
-        x = np.zeros(shape)
-        with pytest.raises(ValueError, match="supported_length"):
-            dw.dsp.fk_filter_filt(x, np.ones_like(x))
+    with pytest.raises(ValueError):
+        dw.dsp.envelope(np.zeros((2, 20011)))
