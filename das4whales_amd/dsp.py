@@ -399,18 +399,43 @@ def _sosfiltfilt_fft(x, sos, padlen):
         return None
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
+        # the row ends: the left and the right piece of every row as one [2 nx, P] block (filtfilt's edge rule is not
+        # symmetric under time reversal, so the right pieces stay in natural order and keep their LAST E outputs).  The
+        # recursion on them is a chain of dependent steps on a few waves per CU: it runs on a side stream underneath the
+        # bandwidth-bound overlap-save pass (D4W_BP_OVERLAP=0: one stream, one after the other)
+        cur = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device) if os.environ.get("D4W_BP_OVERLAP", "1") != "0" else cur
+        if side is not cur:
+            side.wait_stream(cur)
+            x.record_stream(side)
+        with torch.cuda.stream(side):
+            ends = torch.cat((x[:, :P], x[:, ns - P:]), dim=0)
+            ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
         first = x[:, 0].contiguous()
         ent = _fir_workspace(t, x.device)
         check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, None if ent[1] else dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
                                   dev.ptr(ent[0]), dev.stream_ptr(x)))
         ent[1] = True
-        # the row ends: the left and the right piece of every row as one [2 nx, P] block (filtfilt's edge rule is not
-        # symmetric under time reversal, so the right pieces stay in natural order and keep their LAST E outputs)
-        ends = torch.cat((x[:, :P], x[:, ns - P:]), dim=0)
-        ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
+        if side is not cur:
+            cur.wait_stream(side)
+            ye.record_stream(cur)
         y[:, :E] = ye[:nx, :E]
         y[:, ns - E:] = ye[nx:, P - E:]
     return y
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One extra stream per (device, calling stream) for latency-bound work that runs underneath a bandwidth-bound kernel."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    st = _side_streams.get(key)
+    if st is None:
+        if len(_side_streams) > 32:
+            _side_streams.clear()
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _zero_phase_taps(sos, device):
