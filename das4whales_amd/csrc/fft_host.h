@@ -1,6 +1,7 @@
 // Host-side FFT planning shared by the translation units: radix factorisation, the DIF
 // digit-order position <-> frequency maps and the two-level twiddle tables of fft_lds.h.
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -120,6 +121,27 @@ static inline void host_fft_pow2(std::vector<double>& re, std::vector<double>& i
                 re[a] += tr; im[a] += ti;
             }
     }
+}
+
+// Length of a Bluestein convolution that must hold n values: of the form 2^a 3^b 5^c (every factor an unrolled radix) between
+// n and the next power of two, the one with the least length x stages (the next power of two can be almost twice as long;
+// a length made of many small factors pays in LDS round trips).  D4W_BLUESTEIN_POW2=1 keeps powers of two.
+static inline int smooth_len_235(long n) {
+    const char* p2 = getenv("D4W_BLUESTEIN_POW2");
+    long pow2 = 1;
+    while (pow2 < n) pow2 *= 2;
+    if (p2 && atoi(p2) > 0) return (int)pow2;
+    std::vector<int> rad;
+    long best = pow2;
+    double best_cost = factor_radices((int)pow2, rad) ? (double)pow2 * (double)std::max<size_t>(rad.size(), 1) : 1e300;
+    for (long a = 1; a < pow2; a *= 2)
+        for (long b = a; b < pow2; b *= 3)
+            for (long c = b; c < pow2; c *= 5) {
+                if (c < n || !factor_radices((int)c, rad)) continue;
+                const double cost = (double)c * (double)std::max<size_t>(rad.size(), 1);
+                if (cost < best_cost) { best_cost = cost; best = c; }
+            }
+    return (int)best;
 }
 
 // in-place forward DFT of ANY length (double precision, plan-time tables only): a power of two directly, anything else as

@@ -26,7 +26,7 @@ struct FkDev {  // kernel argument block (by value)
     const int2* pairs;        // pass-B work list (keyA, keyB)
     float scale;              // 1 / (nx * M)
     // Bluestein form of the c2 sub-transform (C2 has a prime factor > 31): a length-C2 DFT as a circular
-    // convolution of length bs_L = 2^k >= 2 C2 - 1 with the chirp exp(-i pi n^2 / C2); bs_L = 0: off
+    // convolution of length bs_L = 2^a 3^b 5^c >= 2 C2 - 1 with the chirp exp(-i pi n^2 / C2); bs_L = 0: off
     int bs_L;
     AxisDesc ax_bs;           // the length-bs_L transform
     const float2* bs_chirp;   // [C2]    exp(-i pi n^2 / C2)

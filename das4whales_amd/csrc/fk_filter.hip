@@ -838,12 +838,11 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         return D4W_OK;
     };
     // A prime factor > 31 of ns / 2 goes into N2, whose sub-transforms (pass B) then run as Bluestein convolutions of
-    // length bn_L = 2^k >= 2 N2 - 1 inside the tile (two rows of bn_L); N1 keeps the smooth part.
+    // length bn_L = 2^a 3^b 5^c >= 2 N2 - 1 inside the tile (two rows of bn_L); N1 keeps the smooth part.
     int bn_L = 0, bn_N2 = 0;
     if (!fast && rough_part(M) > 1) {
         bn_N2 = rough_part(M);
-        bn_L = 1;
-        while (bn_L < 2 * bn_N2 - 1) bn_L *= 2;
+        bn_L = smooth_len_235(2L * bn_N2 - 1);
         if (2L * bn_L > kMaxTile) return make_big();
     }
     // admissible time splits: N1 | M with N2 = M / N1 fitting one LDS row pair
@@ -871,8 +870,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
     if (fast && fast->C2X > 1) {                       // specialised passes A and B around the generic Bluestein pass C
         C2 = fast->C2X;
         C1 = nx / C2;
-        bs_L = 1;
-        while (bs_L < 2 * C2 - 1) bs_L *= 2;
+        bs_L = smooth_len_235(2L * C2 - 1);
         if (bs_L > kMaxTile) return fail(D4W_EINVAL, "registered configuration: Bluestein factor %d too long", C2);
     }
     if (!fast && rough_part(nx) > 1) {
@@ -880,8 +878,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         C1 = nx / C2;
         for (int f = 2; f <= 31 && (long)C1 * n1_min > kMaxTile; ++f)      // pass A's tile must hold C1 x N1 columns
             while (C1 % f == 0 && (long)C1 * n1_min > kMaxTile && 2L * C2 * f - 1 <= kMaxTile) { C2 *= f; C1 /= f; }
-        bs_L = 1;
-        while (bs_L < 2 * C2 - 1) bs_L *= 2;
+        bs_L = smooth_len_235(2L * C2 - 1);
         if (bs_L > kMaxTile) {
             // too long for the Bluestein tile of pass C: the global-memory form
             return make_big();
@@ -896,8 +893,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         N1 = M / bn_N2; N2 = bn_N2;
         for (int f = 2; f <= 31 && (long)C1 * N1 > kMaxTile; ++f)
             while (N1 % f == 0 && (long)C1 * N1 > kMaxTile && 2L * (2L * N2 * f - 1) <= kMaxTile) { N2 *= f; N1 /= f; }
-        bn_L = 1;
-        while (bn_L < 2 * N2 - 1) bn_L *= 2;
+        bn_L = smooth_len_235(2L * N2 - 1);
         if (2L * bn_L > kMaxTile || (long)C1 * N1 > kMaxTile) return make_big();
     } else if (N1 <= 0 || N2 <= 0 || N1 * N2 != M) {
         N1 = n1_min;
@@ -950,7 +946,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             bre[n] = cos(ph); bim[n] = sin(ph);                               // conj(chirp)
             if (n) { bre[bs_L - n] = cos(ph); bim[bs_L - n] = sin(ph); }
         }
-        host_fft_pow2(bre, bim);
+        host_dft_any(bre, bim);
         for (int p = 0; p < bs_L; ++p)
             filt[p] = make_float2((float)(bre[f_L[p]] / bs_L), (float)(bim[f_L[p]] / bs_L));
         D4W_TRY(upload(pl, chirp, &pl->dev.bs_chirp));
@@ -973,7 +969,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             bre[n] = cos(ph); bim[n] = sin(ph);                               // conj(chirp)
             if (n) { bre[bn_L - n] = cos(ph); bim[bn_L - n] = sin(ph); }
         }
-        host_fft_pow2(bre, bim);
+        host_dft_any(bre, bim);
         for (int p = 0; p < bn_L; ++p)
             filt[p] = make_float2((float)(bre[f_L[p]] / bn_L), (float)(bim[f_L[p]] / bn_L));
         D4W_TRY(upload(pl, chirp, &pl->dev.bn_chirp));
@@ -2209,21 +2205,9 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     if (world < 1 || rank < 0 || rank >= world || world > nx) return fail(D4W_EINVAL, "bad world %d / rank %d", world, rank);
     if (want_mask && fkd_plan_build_packed(nx, ns, world, rank, want_mask, out) == D4W_OK) return D4W_OK;
     const int M = ns / 2;
-    // the shortest length >= n of the form 2^a 3^b 5^c (the unrolled radices; a power of two can be ~2x longer)
-    auto smooth_len = [](long n) {
-        const char* p2 = getenv("D4W_FKD_BZ_POW2");
-        long best = 1;
-        while (best < n) best *= 2;
-        if (!(p2 && atoi(p2) > 0))
-            for (long a = 1; a < best; a *= 2)
-                for (long b = a; b < best; b *= 3)
-                    for (long c = b; c < best; c *= 5)
-                        if (c >= n && c < best) best = c;
-        return (int)best;
-    };
     // ns / 2 with a prime factor > 31: the time transform of the packed rows is a Bluestein convolution of length bt_L in
     // global memory (fkd_bt_*); tp describes that length and the half spectrum comes out in natural order (N1 = 1)
-    const int bt_L = (rough_part(M) > 1) ? smooth_len(2L * M - 1) : 0;
+    const int bt_L = (rough_part(M) > 1) ? smooth_len_235(2L * M - 1) : 0;
     const int Mt = bt_L ? bt_L : M;
     // time axis Mt = tN1 * tN2: tN2 in one LDS row, and enough n1-positions (Hermitian classes) to balance the ranks
     int tN1 = 0;
@@ -2239,7 +2223,7 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     const int N1 = bt_L ? 1 : tN1, N2 = bt_L ? M : tN2;      // layout of the half spectrum: [row][N1][N2]
     // a channel count with a prime factor > 31: the channel transform is a Bluestein convolution of length bz_L = 2^a 3^b 5^c
     // in global memory (fkd_bz_*), and the channel-phase descriptor below is the one of that length
-    const int bz_L = (want_mask && rough_part(nx) > 1) ? smooth_len(2L * nx - 1) : 0;
+    const int bz_L = (want_mask && rough_part(nx) > 1) ? smooth_len_235(2L * nx - 1) : 0;
     // (no mask = the time phase only, d4w_analytic_long_f32: any row count, the channel descriptor stays a dummy)
     const int Lc = !want_mask ? 1 : (bz_L ? bz_L : nx);
     int C2 = largest_divisor_le(Lc, kMaxTile / 8);

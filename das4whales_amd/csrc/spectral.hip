@@ -32,7 +32,7 @@ struct RowFftDev {
     const float* hann;    // [L] periodic Hann window (scipy get_window('hann', L, fftbins=True))
     const float2* wfull;  // [L] exp(-2 pi i m / L)
     // Bluestein form for a length with a prime factor > 31 (single-row transforms only): the L-point DFT as a
-    // circular convolution of length bs_L = 2^k >= 2 L - 1 with the chirp exp(-i pi n^2 / L); pos / p2f are the
+    // circular convolution of length bs_L = 2^a 3^b 5^c >= 2 L - 1 with the chirp exp(-i pi n^2 / L); pos / p2f are the
     // identity then.  bs_L = 0: the mixed-radix transform of `ax`.
     int bs_L;
     AxisDesc ax_bs;
@@ -69,8 +69,7 @@ static int row_fft_get(int L, const RowFftHost** out) {
     const bool bluestein = !factor_radices(L, rad);
     int bs_L = 0;
     if (bluestein) {
-        bs_L = 1;
-        while (bs_L < 2 * L - 1) bs_L *= 2;
+        bs_L = smooth_len_235(2L * L - 1);
         if (((size_t)bs_L + kTwLo + (size_t)(bs_L + kTwLo - 1) / kTwLo) * sizeof(float2) > kSpLdsMax)
             return fail(D4W_EINVAL, "transform length %d has a prime factor > 31 and is too long for the Bluestein form "
                         "(dsp.supported_length(n) gives the nearest shorter length with a direct kernel)", L);
@@ -109,7 +108,7 @@ static int row_fft_get(int L, const RowFftHost** out) {
             bre[n] = cos(ph); bim[n] = sin(ph);
             if (n) { bre[bs_L - n] = cos(ph); bim[bs_L - n] = sin(ph); }
         }
-        host_fft_pow2(bre, bim);
+        host_dft_any(bre, bim);
         for (int q = 0; q < bs_L; ++q) filt[q] = make_float2((float)(bre[fL[q]] / bs_L), (float)(bim[fL[q]] / bs_L));
         rc = sp_upload(h, twiddle_table2(bs_L, &ab.nhi), &ab.tw2);
         if (!rc) rc = sp_upload(h, chirp, &h->dev.bs_chirp);
