@@ -2223,7 +2223,15 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     const int N1 = bt_L ? 1 : tN1, N2 = bt_L ? M : tN2;      // layout of the half spectrum: [row][N1][N2]
     // a channel count with a prime factor > 31: the channel transform is a Bluestein convolution of length bz_L = 2^a 3^b 5^c
     // in global memory (fkd_bz_*), and the channel-phase descriptor below is the one of that length
-    const int bz_L = (want_mask && rough_part(nx) > 1) ? smooth_len_235(2L * nx - 1) : 0;
+    // (D4W_FKD_BZ_MINPRIME = p: also channel counts with a prime factor >= p, whose loop-based radix stages are slow)
+    auto largest_prime = [](int n) {
+        int lp = 1;
+        for (int p = 2; (long)p * p <= n; ++p)
+            while (n % p == 0) { lp = p; n /= p; }
+        return std::max(lp, n);
+    };
+    static const int bz_minprime = [] { const char* v = getenv("D4W_FKD_BZ_MINPRIME"); return (v && atoi(v) > 1) ? atoi(v) : 32; }();
+    const int bz_L = (want_mask && largest_prime(nx) >= bz_minprime) ? smooth_len_235(2L * nx - 1) : 0;
     // (no mask = the time phase only, d4w_analytic_long_f32: any row count, the channel descriptor stays a dummy)
     const int Lc = !want_mask ? 1 : (bz_L ? bz_L : nx);
     int C2 = largest_divisor_le(Lc, kMaxTile / 8);
@@ -2332,6 +2340,11 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
         const char* ch = getenv("D4W_FKD_BZ_CHUNK");
         int lim = (ch && atoi(ch) > 0) ? atoi(ch) : std::max(16, (int)(((size_t)1 << 27) / (size_t)bz_L) & ~15);
         Wc = std::min(W, lim);
+        if (Wc < W && !(ch && atoi(ch) > 0)) {
+            // equal chunks: the passes sweep the scratch's full width whatever the last chunk holds
+            const int nchunk = ceil_div(W, Wc);
+            Wc = std::min(Wc, (ceil_div(W, nchunk) + 15) & ~15);
+        }
     }
     while (TC > 1 && (long)C2 * TC > kMaxTile) TC /= 2;
     while (TAc > 1 && ((long)C1 * TAc > kMaxTile || TAc > Wc)) TAc /= 2;

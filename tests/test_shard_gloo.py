@@ -122,18 +122,19 @@ def _fk_worker(rank, world, port, q):
             y_chunked = shard.fk_filter_sharded(x[a:b], None, nx, plan=plan)
             res[key + "_chunked"] = 0.0 if torch.equal(y_chunked, y_loc) else 1.0
             res[key + "_gathered"] = float(np.max(np.abs(y_all.numpy() - ref)) / np.max(np.abs(ref)))
-        # a channel count with a prime factor > 31 (2 x 37): the slab's channel transform is the global-memory Bluestein form
+        # a channel count with a prime factor > 31 (2 x 37): the slab's channel transform is the global-memory Bluestein form;
+        # ns / 2 = 43 as well: the rows' time transform too, and the half spectrum is one class owned by rank 0
         from oracle import d4w_oracle as orc
         rng = np.random.default_rng(3)
-        nx2, ns2 = 74, 48
-        x2 = rng.standard_normal((nx2, ns2))
-        m2 = rng.uniform(0, 1, (nx2, ns2))
-        a2, b2 = shard.channel_block(nx2, world, rank)
-        plan = shard.ShardedFkPlan(nx2, ns2, native=(emu, check))
-        plan.set_mask(torch.from_numpy(m2).float())
-        y_all = shard.fk_filter_sharded(torch.from_numpy(x2[a2:b2]).float(), None, nx2, gather=True, plan=plan)
-        ref = orc.fk_filter_filt(x2, m2)
-        res["rough_gathered"] = float(np.max(np.abs(y_all.numpy() - ref)) / np.max(np.abs(ref)))
+        for tag, nx2, ns2 in (("rough_nx", 74, 48), ("rough_both", 74, 86)):
+            x2 = rng.standard_normal((nx2, ns2))
+            m2 = rng.uniform(0, 1, (nx2, ns2))
+            a2, b2 = shard.channel_block(nx2, world, rank)
+            plan = shard.ShardedFkPlan(nx2, ns2, native=(emu, check))
+            plan.set_mask(torch.from_numpy(m2).float())
+            y_all = shard.fk_filter_sharded(torch.from_numpy(x2[a2:b2]).float(), None, nx2, gather=True, plan=plan)
+            ref = orc.fk_filter_filt(x2, m2)
+            res[tag + "_gathered"] = float(np.max(np.abs(y_all.numpy() - ref)) / np.max(np.abs(ref)))
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
