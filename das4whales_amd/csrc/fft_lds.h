@@ -173,6 +173,91 @@ __device__ __attribute__((noinline)) void lds_stage_prime(int R, float2* buf, in
     }
 }
 
+// The same stage for one prime R, unrolled in registers: every butterfly loads its R inputs once, pairs them into
+// s_q = x_q + x_(R-q), d_q = x_q - x_(R-q), and forms the outputs k and R - k together from the real sums
+//   A_k = x_0 + sum_q cos(2 pi q k / R) s_q,  B_k = sum_q sin(2 pi q k / R) d_q:   y_k = A_k -/+ i B_k,  y_(R-k) = A_k +/- i B_k
+// -- (R - 1)^2 real FMAs instead of R^2 complex ones with an LDS twiddle lookup each (the OOI channel counts 5510 = 2 5 19 29
+// and 11020 on blocks too small for compiled kernels run through here).  noinline: one copy per (R, direction, order).
+template <int R, bool INV, bool BATCH_FAST>
+__device__ __attribute__((noinline)) void lds_stage_prime_t(float2* buf, int L, int Ls, int es,
+                                                            int nb0, int bs0, int nb1, int bs1,
+                                                            const TwLds tw, int tid, int nthr) {
+    constexpr int H = (R - 1) / 2;
+    const int m = Ls / R;
+    const int nbf = L / R;
+    const int nb = nb0 * nb1;
+    const int total = nbf * nb;
+    const int twstep = L / Ls;
+    const int wr = L / R;          // W_R^a = tw[a * wr]
+    const int qs = m * es;
+    float cs[H], sn[H];            // cos / sin (2 pi a / R), a = 1..H
+    static_for<H>([&](auto aa) {
+        constexpr int a = decltype(aa)::value;
+        const float2 t = tw.get((a + 1) * wr);
+        cs[a] = t.x;
+        sn[a] = -t.y;
+    });
+    for (int w = tid; w < total; w += nthr) {
+        int bf, b;
+        if (BATCH_FAST) {
+            bf = w / nb;
+            b = w - bf * nb;
+        } else {
+            b = w / nbf;
+            bf = w - b * nbf;
+        }
+        const int g = bf / m;
+        const int j = bf - g * m;
+        const int b1 = b / nb0;
+        const int b0 = b - b1 * nb0;
+        float2* p = buf + b0 * bs0 + b1 * bs1 + (g * Ls + j) * es;
+        float2 x[R];
+        static_for<R>([&](auto qq) { constexpr int q = decltype(qq)::value; x[q] = p[q * qs]; });
+        if (INV && m > 1)
+            static_for<R - 1>([&](auto qq) {
+                constexpr int q = decltype(qq)::value + 1;
+                x[q] = c_mulc(x[q], tw.get(j * q * twstep));
+            });
+        float2 y0 = x[0];
+        static_for<H>([&](auto qq) {
+            constexpr int q = decltype(qq)::value + 1;
+            const float2 a = x[q], c = x[R - q];
+            x[q] = c_add(a, c);
+            x[R - q] = c_sub(a, c);
+            y0 = c_add(y0, x[q]);
+        });
+        p[0] = y0;
+        static_for<H>([&](auto kk) {
+            constexpr int k = decltype(kk)::value + 1;
+            float2 A = x[0], B = make_float2(0.f, 0.f);
+            static_for<H>([&](auto qq) {
+                constexpr int q = decltype(qq)::value + 1;
+                constexpr int a = (q * k) % R;
+                constexpr int ai = (a <= H) ? a : R - a;
+                const float c = cs[ai - 1], sg = (a <= H) ? sn[ai - 1] : -sn[ai - 1];
+                A.x = fmaf(c, x[q].x, A.x);
+                A.y = fmaf(c, x[q].y, A.y);
+                B.x = fmaf(sg, x[R - q].x, B.x);
+                B.y = fmaf(sg, x[R - q].y, B.y);
+            });
+            float2 yk = make_float2(A.x + B.y, A.y - B.x);      // A - i B
+            float2 yr = make_float2(A.x - B.y, A.y + B.x);      // A + i B
+            if (INV) {
+                const float2 t = yk;
+                yk = yr;
+                yr = t;
+            } else if (m > 1) {
+                yk = c_mul(yk, tw.get(j * k * twstep));
+                yr = c_mul(yr, tw.get(j * (R - k) * twstep));
+            }
+            p[k * qs] = yk;
+            p[(R - k) * qs] = yr;
+        });
+    }
+}
+
+#define D4W_FOR_EACH_PRIME_RADIX(X) X(7) X(11) X(13) X(17) X(19) X(23) X(29) X(31)
+
 // Radices the planner may emit.  FAST kernels carry only the fully unrolled small set (what the
 // benchmark shapes 4000/20000 x 12000/120000 need); GENERIC kernels add the loop-based primes.
 #define D4W_FOR_EACH_FAST_RADIX(X) X(2) X(3) X(4) X(5) X(6) X(8) X(10)
@@ -185,6 +270,10 @@ __device__ __forceinline__ void lds_stage_dispatch(int R, float2* buf, int L, in
 #define D4W_CASE(RR) \
     case RR: lds_stage<RR, INV, BATCH_FAST>(buf, L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr); break;
         D4W_FOR_EACH_FAST_RADIX(D4W_CASE)
+#undef D4W_CASE
+#define D4W_CASE(RR) \
+    case RR: if (GENERIC) lds_stage_prime_t<RR, INV, BATCH_FAST>(buf, L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr); break;
+        D4W_FOR_EACH_PRIME_RADIX(D4W_CASE)
 #undef D4W_CASE
         default:
             if (GENERIC) lds_stage_prime<INV, BATCH_FAST>(R, buf, L, Ls, es, nb0, bs0, nb1, bs1, tw, tid, nthr);

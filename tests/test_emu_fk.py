@@ -45,7 +45,9 @@ def test_golden_masks(emu, golden):
 
 def test_odd_channels_and_prime_radices(emu):
     rng = np.random.default_rng(0)
-    for nx, ns, opts in [(38, 406, [19, 2, 7, 29, 4, 4]), (7, 14, None), (1, 64, None), (64, 2, None)]:
+    # every prime radix 7..31 of the generic kernels (fft_lds.h lds_stage_prime_t), forward and inverse, on both axes
+    for nx, ns, opts in [(38, 406, [19, 2, 7, 29, 4, 4]), (7, 14, None), (1, 64, None), (64, 2, None), (26, 102, None),
+                         (46, 62, None), (62, 52, None), (34, 46, None), (11 * 23, 2 * 13 * 17, None), (31 * 3, 2 * 29 * 2, None)]:
         x = rng.standard_normal((nx, ns))
         m = rng.random((nx, ns))
         assert rel(fk_emu(emu, x, m, opts), orc.fk_filter_filt(x, m)) < TOL
