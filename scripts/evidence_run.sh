@@ -17,6 +17,12 @@ timeout 900 python bench.py --shard channel --steps 5 --warmup 2 --force-replica
 timeout 600 python scripts/time_bp.py 2>/dev/null | grep "^{" > $O/time_bp.txt; cat $O/time_bp.txt
 timeout 600 python scripts/pipeline_bench.py 2>/dev/null | grep "^{" > $O/pipeline_11020x12000.json; cat $O/pipeline_11020x12000.json
 timeout 600 python scripts/time_shapes.py 13223x12000 8000x12000 11020x12000 5510x12000 4000x12000 2>/dev/null | grep "^{" > $O/time_shapes.txt; cat $O/time_shapes.txt
+# shapes beyond the direct kernels: prime channel counts / record lengths (Bluestein forms), loop-free prime radices (generic kernels)
+timeout 600 python scripts/time_shapes.py 4099x12000 10007x12000 19997x12000 11020x12014 11020x12002 10007x12014 2>/dev/null | grep "^{" > $O/time_any_shape.txt; cut -c1-60,180-330 $O/time_any_shape.txt
+timeout 300 python scripts/time_bluestein_rows.py 2>/dev/null | grep "^{" > $O/time_bluestein_rows.txt; cat $O/time_bluestein_rows.txt
+(NX=4000 timeout 250 python scripts/time_long_rows.py; NX=20000 timeout 250 python scripts/time_long_rows.py) 2>/dev/null | grep "^{" > $O/time_long_rows.txt
+timeout 250 python scripts/time_fk_filt.py 2>/dev/null | grep "^{" > $O/time_fk_filt.txt
+(timeout 300 python scripts/time_api_sweep.py; NX=11020 NS=12000 timeout 300 python scripts/time_api_sweep.py) 2>/dev/null | grep "^{" > $O/time_api_sweep.txt
 NX=11020 timeout 600 python scripts/time_spectral.py 2>/dev/null | grep "^{" > $O/time_spectral_11020x12000.json
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o fk -- python $R/bench.py --steps 5 --warmup 2 --no-cpu > $R/$O/rocprof_bench.log 2>&1
 cd $R
