@@ -80,7 +80,19 @@ class ShardedFkPlan:
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self._h = ctypes.c_void_p()
-        self.check(self.lib.d4w_fkd_plan_create(int(nx), int(ns), self.world, self.rank, ctypes.byref(self._h)))
+        force_generic = False if native is not None else self._specialise(int(nx), int(ns))
+        import os
+        old_env = os.environ.get("D4W_FKD_GENERIC")
+        if force_generic:
+            os.environ["D4W_FKD_GENERIC"] = "1"
+        try:
+            self.check(self.lib.d4w_fkd_plan_create(int(nx), int(ns), self.world, self.rank, ctypes.byref(self._h)))
+        finally:
+            if force_generic:
+                if old_env is None:
+                    del os.environ["D4W_FKD_GENERIC"]
+                else:
+                    os.environ["D4W_FKD_GENERIC"] = old_env
         info = (ctypes.c_int * 12)()
         self.check(self.lib.d4w_fkd_plan_info(self._h, info))
         (self.nx, self.ns, _, _, self.row_begin, self.row_end, self.N1, self.N2, self.nq, self.C1, _, packed) = list(info)
@@ -91,6 +103,31 @@ class ShardedFkPlan:
         self.qidx = [torch.nonzero(owner == s).flatten() for s in range(self.world)]
         self.blocks = [channel_block(self.nx, self.world, r) for r in range(self.world)]
         assert self.blocks[self.rank] == (self.row_begin, self.row_end)
+
+    def _specialise(self, nx, ns):
+        """A new large shape gets its own kernels, as in dsp.get_fk_plan (das4whales_amd/fkjit.py: ~15 s once, cached on disk):
+        rank 0 compiles, the others pick the cached object up.  The ranks must agree on the plan type (the packed and the
+        generic plan exchange different layouts), so the outcome is reduced over the group; returns True when this rank must
+        hold back to the generic plan because some rank has no specialised kernels."""
+        import os
+        if os.environ.get("D4W_FK_JIT", "1") == "0" or nx * ns < (1 << 24):
+            return False
+        from . import fkjit
+
+        def attempt():
+            try:
+                return int(bool(fkjit.compile_fk_shape(nx, ns)))
+            except Exception:
+                return 0
+        ok = attempt() if self.rank == 0 else 0
+        if self.world > 1:
+            dist.barrier(self.group)
+            if self.rank != 0:
+                ok = attempt()
+            flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(ok) and int(flag.item()) == 0
+        return False
 
     def set_mask(self, mask):
         """mask: dense float32 [nx, ns] tensor on this rank's device, fftshift-ed grid (what the

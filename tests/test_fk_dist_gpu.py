@@ -66,6 +66,25 @@ def test_sharded_config1_block_matches_single_device(pg):
     assert float((y3 - x).abs().max()) / float(x.abs().max()) < TOL
 
 
+def test_sharded_plan_of_a_shape_without_built_in_kernels(pg):
+    """ShardedFkPlan asks das4whales_amd/fkjit.py for kernels of a new large shape like dsp.get_fk_plan does (8000 x 12000 is
+    compiled by __graft_entry__.build(), so this finds the cached object) and runs the packed plan; prime channel counts and
+    record lengths run the generic plan's global-memory Bluestein forms.  Both equal the single-device filter."""
+    import das4whales_amd as dw
+    from das4whales_amd import shard
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    for nx, ns, packed in ((8000, 12000, True), (2 * 4099, 2 * 2053 * 2, False)):
+        x = torch.randn((nx, ns), device="cuda", generator=gen)
+        m = torch.rand((nx, ns), device="cuda", generator=gen)
+        plan = shard.ShardedFkPlan(nx, ns)
+        assert plan.packed == packed
+        plan.set_mask(m)
+        y2 = shard.fk_filter_sharded(x, None, nx, plan=plan)
+        y1 = dw.dsp.fk_filter_filt(x, m)
+        assert float((y1 - y2).abs().max()) / float(y1.abs().max()) < 3e-6, (nx, ns)
+        del plan
+
+
 def test_sharded_bench_shape_identity(pg):
     """20 000 x 120 000 (BASELINE configs[3] block on one rank): an all-ones mask returns the input."""
     from das4whales_amd import shard
