@@ -86,6 +86,32 @@ def test_bp_full_size_rows_vs_oracle(dw):
     assert e < TOL
 
 
+def test_bp_row_ends_on_a_side_stream(dw, monkeypatch):
+    """Long rows: the recursion on the row ends runs on a side stream underneath the overlap-save pass (dsp._sosfiltfilt_fft).
+    Same answer, bit for bit, as with everything on the calling stream -- repeatedly, on the default stream and on a user
+    stream, with the input freed right after the call."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(12)
+    nx, ns = 256, 60000
+    x = torch.randn((nx, ns), dtype=torch.float32, device="cuda", generator=gen)
+    monkeypatch.setenv("D4W_BP_OVERLAP", "0")
+    y0 = dw.dsp.bp_filt(x, FS, 14, 30)
+    monkeypatch.setenv("D4W_BP_OVERLAP", "1")
+    for _ in range(3):
+        assert torch.equal(dw.dsp.bp_filt(x, FS, 14, 30), y0)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        outs = []
+        for _ in range(3):
+            xc = x.clone()
+            outs.append(dw.dsp.bp_filt(xc, FS, 14, 30))
+            del xc
+    torch.cuda.current_stream().wait_stream(st)
+    assert all(torch.equal(o, y0) for o in outs)
+    assert rel(y0[:4].cpu().numpy(), orc.bp_filt(x[:4].cpu().numpy().astype(np.float64), FS, 14, 30)) < TOL
+
+
 # ------------------------------------------------------------------------------------------
 # matched filter
 # ------------------------------------------------------------------------------------------
