@@ -2826,6 +2826,47 @@ __global__ __launch_bounds__(kThreads) void analytic_combine(const float* __rest
         yr[i] = v;
     }
 }
+// Odd row lengths on the long-row path: the row as a COMPLEX sequence of its own length (no packing), the one-sided
+// multiplier of scipy.signal.hilbert on its spectrum, the inverse transform = the analytic signal itself.
+__global__ __launch_bounds__(kThreads) void analytic_widen(const float* __restrict__ x, float2* __restrict__ z, int ns) {
+    const size_t base = (size_t)blockIdx.y * ns;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x)
+        z[base + i] = make_float2(x[base + i], 0.f);
+}
+
+// Z[row][q1][i] holds frequency k1[q1] + N1 k2[i]: x 1 at f = 0, x 2 for 0 < f <= (ns - 1) / 2, x 0 above (odd ns)
+__global__ __launch_bounds__(kThreads) void analytic_onesided(float2* __restrict__ z, int ns, int N1, int N2,
+                                                               const int* __restrict__ k1, const int* __restrict__ k2) {
+    const size_t base = (size_t)blockIdx.y * ns;
+    const int half = (ns - 1) / 2;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < ns; p += gridDim.x * blockDim.x) {
+        const int q1 = p / N2, i = p - q1 * N2;
+        const int f = k1[q1] + N1 * k2[i];
+        const float g = (f == 0) ? 1.f : (f <= half ? 2.f : 0.f);
+        z[base + p] = c_scale(z[base + p], g);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void analytic_combine_z(const float2* __restrict__ z, float* __restrict__ y, int ns,
+                                                                int mode, const float* __restrict__ var, float fscale) {
+    const size_t base = (size_t)blockIdx.y * ns;
+    const int nout = (mode == 3) ? ns - 1 : ns;
+    float* yr = y + (size_t)blockIdx.y * nout;
+    const float inv_var = (mode == 2 || mode == 4) ? 1.0f / var[blockIdx.y] : 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += gridDim.x * blockDim.x) {
+        const float2 a = z[base + i];
+        float v;
+        if (mode == 0) v = sqrtf(fmaf(a.x, a.x, a.y * a.y));
+        else if (mode == 1) v = a.y;
+        else if (mode == 2) v = 10.0f * log10f(fmaf(a.x, a.x, a.y * a.y) * inv_var);
+        else if (mode == 4) v = sqrtf(fmaf(a.x, a.x, a.y * a.y) * inv_var);
+        else {
+            const float2 p = c_mulc(z[base + i + 1], a);
+            v = atan2f(p.y, p.x) * fscale;
+        }
+        yr[i] = v;
+    }
+}
 }  // namespace d4w
 
 static std::mutex g_long_mu;
@@ -2834,18 +2875,47 @@ static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_fast;     // pa
 
 extern "C" {
 
-size_t d4w_analytic_long_ws_bytes(int nx, int ns) { return (nx > 0 && ns > 0) ? (size_t)nx * ns * sizeof(float) : 0; }
+/* even ns: [nx][ns] float32 (the Hilbert transform); odd ns: [nx][ns] complex (the row as a complex sequence) */
+size_t d4w_analytic_long_ws_bytes(int nx, int ns) {
+    return (nx > 0 && ns > 0) ? (size_t)nx * ns * sizeof(float) * ((ns & 1) ? 2 : 1) : 0;
+}
 
 int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
                           void* ws, void* stream) {
     if (!x || !y || !ws || nx < 1 || ns < 2) return fail(D4W_EINVAL, "bad argument");
-    if (ns & 1) return fail(D4W_EINVAL, "ns = %d must be even on the long-row path", ns);
     if (mode < 0 || mode > 4) return fail(D4W_EINVAL, "mode = %d not in 0..4", mode);
     if ((mode == 2 || mode == 4) && !var) return fail(D4W_EINVAL, "modes 2 and 4 need the row variances");
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
     int devid = 0;
     D4W_HIP(hipGetDevice(&devid));
     float* h = (float*)ws;
+    if (ns & 1) {
+        // odd rows: "packed rows" of 2 ns floats = complex rows of length ns through the time phase of the generic plan
+        // (any length: a prime factor > 31 of ns runs the global-memory Bluestein form)
+        d4w_fkd_plan* pl = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_long_mu);
+            auto key = std::make_tuple(devid, nx, -ns);
+            auto it = g_long_plans.find(key);
+            if (it == g_long_plans.end()) {
+                int rc = fkd_plan_build(nx, 2 * ns, 1, 0, false, &pl);
+                if (rc) return rc;
+                pl->tp.dev.scale = (float)(1.0 / (double)ns);
+                g_long_plans[key] = pl;
+            } else {
+                pl = it->second;
+            }
+        }
+        float2* z = reinterpret_cast<float2*>(ws);
+        const dim3 grid(std::min(ceil_div(ns, kThreads), 128), nx);
+        D4W_LAUNCH(analytic_widen, grid, dim3(kThreads), 0, stream, x, z, ns);
+        int rc = d4w_fkd_time_fwd_f32(pl, h, h, 0, stream);
+        if (rc) return rc;
+        D4W_LAUNCH(analytic_onesided, grid, dim3(kThreads), 0, stream, z, ns, pl->N1, pl->N2, (const int*)pl->d_k1, (const int*)pl->d_k2);
+        if ((rc = d4w_fkd_time_inv_f32(pl, h, stream))) return rc;
+        D4W_LAUNCH(analytic_combine_z, grid, dim3(kThreads), 0, stream, (const float2*)z, y, ns, mode, var, (float)(fs / (2.0 * M_PI)));
+        return D4W_OK;
+    }
     // Shapes with specialised f-k kernels: the time phase of the packed plan (pass A MODE 1: n1 transform of the real rows),
     // pass B with the Hilbert pair operation on the work list "sub-row q1 of a row pairs with sub-row N1 - q1 of the SAME
     // row", the inverse time phase in place, the combine pass -- 36 B per sample on the fast kernels instead of 52 through

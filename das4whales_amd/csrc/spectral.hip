@@ -1270,11 +1270,7 @@ int d4w_analytic_row_fits_lds(int ns) {
     if (ns < 2) return 0;
     int L = (ns % 2 == 0) ? ns / 2 : ns;
     std::vector<int> rad;
-    if (!factor_radices(L, rad)) {                      // Bluestein tile
-        int b = 1;
-        while (b < 2 * L - 1) b *= 2;
-        L = b;
-    }
+    if (!factor_radices(L, rad)) L = smooth_len_235(2L * L - 1);      // Bluestein tile
     return ((size_t)L + kTwLo + (size_t)(L + kTwLo - 1) / kTwLo) * sizeof(float2) <= kSpLdsMax ? 1 : 0;
 }
 

@@ -796,10 +796,11 @@ def _analytic(x2d, mode, fs=0.0, var=None):
     nx, ns = x2d.shape
     y = torch.empty((nx, ns - 1 if mode == 3 else ns), dtype=torch.float32, device=x2d.device)
     with torch.cuda.device(x2d.device):
-        if lib.d4w_analytic_row_fits_lds(ns) or ns % 2:
+        if lib.d4w_analytic_row_fits_lds(ns):
             check(lib.d4w_analytic_f32(dev.ptr(x2d), dev.ptr(y), nx, ns, int(mode),
                                        dev.ptr(var) if var is not None else None, float(fs), dev.stream_ptr(x2d)))
-        else:                                        # long rows: four-step time-axis transform through HBM
+        else:                                        # long rows: four-step time-axis transform through HBM (odd lengths as
+                                                     # complex rows, lengths with a prime factor > 31 by Bluestein)
             import os
             if nx <= 65535 and os.environ.get("D4W_FK_JIT", "1") != "0" and nx * ns >= (1 << 24):
                 try:                                 # shapes with specialised f-k kernels run their time phase + a Hilbert pass B
@@ -846,7 +847,7 @@ def snr_tr_array(trace, env=False):
     y = torch.empty_like(x)
     var = torch.empty(nx, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        if env and not (lib.d4w_analytic_row_fits_lds(ns) or ns % 2):
+        if env and not lib.d4w_analytic_row_fits_lds(ns):
             check(lib.d4w_row_var_f32(dev.ptr(x), nx, ns, dev.ptr(var), dev.stream_ptr(x)))
             y = _analytic(x, 2, var=var)
         else:

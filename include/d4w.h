@@ -330,8 +330,9 @@ int d4w_minmax_normalise_f32(float* x, size_t n, void* stream);
  *   mode 2  y = 10 log10(|z|^2 / var[c]) var = DEVICE [nx] row variances   (dsp.py:975)
  *   mode 3  y[c][i] = diff(unwrap(angle z))[i] / (2 pi) * fs, [nx][ns-1]   (dsp.instant_freq, dsp.py:830-856)
  *   mode 4  y = |z| / sqrt(var[c])       improcess.trace2image before scaling   (improcess.py:60)
- *   Row length limit: ns <= ~37 000 (even) / ~18 000 (odd); ns/2 (even) or ns (odd) must factor
- *   into primes <= 31.  D4W_EINVAL otherwise.
+ *   Rows whose transform (ns / 2 packed values for even ns, ns for odd; the Bluestein convolution
+ *   length when that has a prime factor > 31) fits one workgroup's LDS: d4w_analytic_row_fits_lds(ns);
+ *   D4W_EINVAL otherwise -- those rows go through d4w_analytic_long_f32.
  * d4w_row_var_f32: var[c] = np.std(x[c])**2 (population).
  * d4w_snr_f32: dsp.snr_tr_array (dsp.py:956-976): 10 log10(x^2 / std^2) (env = 0) or the envelope
  *   form (env != 0); var_ws = DEVICE [nx] scratch.
@@ -342,8 +343,10 @@ int d4w_analytic_f32(const float* x, float* y, int nx, int ns, int mode, const f
                      void* stream);
 /* Rows too long for one workgroup's LDS (d4w_analytic_row_fits_lds(ns) == 0, e.g. 120 000 samples):
  * same modes through the four-step time-axis transform of the distributed f-k plan (two passes
- * each way over HBM) + the Hilbert pair op + one combine pass; ns even; ws = DEVICE scratch of
- * d4w_analytic_long_ws_bytes(nx, ns) bytes.  Shapes [nx][ns] with shape-specialised f-k kernels (built in or registered
+ * each way over HBM) + the Hilbert pair op + one combine pass; any ns (odd ns: the rows as complex
+ * sequences of their own length, scipy's one-sided multiplier on the spectrum; a prime factor > 31
+ * of the transform length: the global-memory Bluestein form); ws = DEVICE scratch of
+ * d4w_analytic_long_ws_bytes(nx, ns) bytes (4 nx ns for even ns, 8 nx ns for odd).  Shapes [nx][ns] with shape-specialised f-k kernels (built in or registered
  * through d4w_fk_register_shape) run that plan's time phase, its pass B with the Hilbert pair operation on real rows and
  * the inverse time phase instead (three fast passes + the combine pass; the ns / 2 prime-factor limit applies). */
 int d4w_analytic_row_fits_lds(int ns);

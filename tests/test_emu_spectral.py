@@ -261,12 +261,13 @@ def test_argument_errors(emu):
     assert emu.d4w_stft_mag_f32(vp(x), vp(y), vp(y), 2, 64, 16, 4, 0, 9, None) == -1                # bin range
 
 
-@pytest.mark.parametrize("nx,ns", [(3, 480), (2, 2 * 3 * 5 * 7 * 11), (5, 96), (37, 2 * 41), (7, 2 * 3 * 67), (18, 48), (100, 600),
-                                   (8, 480), (154, 48), (1102, 48)])
+@pytest.mark.parametrize("nx,ns", [(3, 480), (2, 2 * 3 * 5 * 7 * 11), (5, 96), (37, 2 * 41), (7, 2 * 3 * 67), (3, 481), (5, 405), (2, 83),
+                                   (4, 1091), (18, 48), (100, 600), (8, 480), (154, 48), (1102, 48)])
 def test_analytic_long_row_path(emu, nx, ns):
     """The HBM four-step path (used for rows beyond one workgroup's LDS) on small rows: all four
     modes agree with the single-workgroup kernel and the oracle.  Row lengths with a prime factor > 31 (2 x 41, 2 x 3 x 67)
-    run the global-memory Bluestein form of the time transform (fkd_bt_*); the row count is free (37).  The last three
+    run the global-memory Bluestein form of the time transform (fkd_bt_*); the row count is free (37).  Odd lengths (481 = 13 x 37,
+    405 = 3^4 x 5, the primes 83 and 1091) go through as complex rows of their own length with scipy's one-sided multiplier.  The last three
     shapes have shape-specialised f-k kernels: their time phase + pass B with the Hilbert pair operation (every row its own
     Hermitian partner) runs instead of the generic kernels."""
     rng = np.random.default_rng(ns)

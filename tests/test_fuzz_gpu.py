@@ -235,14 +235,24 @@ def test_any_record_length(dw):
     z = orc.hilbert(x)
     assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL
     assert rel(dw.dsp.hilbert_imag(x), z.imag) < TOL
+    # ... and odd ones (complex rows of their own length): a prime, 60 s + 1 sample (12001 = 11 x 1091), 10 min + 1 sample
+    for nx, ns in ((3, 20011), (5, 12001), (2, 120001)):
+        x = rng.standard_normal((nx, ns))
+        z = orc.hilbert(x)
+        assert rel(dw.dsp.envelope(x), np.abs(z)) < TOL, ns
+        assert rel(dw.dsp.hilbert_imag(x), z.imag) < TOL, ns
+    x = rng.standard_normal((4, 12001)) + 0.3
+    ref = 10 * np.log10(np.abs(orc.hilbert(x)) ** 2 / np.var(x, axis=1)[:, None])
+    got = dw.dsp.snr_tr_array(x, env=True)
+    assert np.max(np.abs(10.0 ** (got / 10) - 10.0 ** (ref / 10))) / np.max(10.0 ** (ref / 10)) < TOL
 
 
 def test_unsupported_length_is_a_clear_error(dw):
-    """What is left without a kernel: single-row transforms (get_fx, odd analytic rows) whose Bluestein tile exceeds a
-    workgroup's LDS.  ValueError, not a wrong answer.  (The f-k filter takes any shape.)"""
+    """What is left without a kernel: get_fx / spectrogram transforms whose Bluestein tile exceeds a workgroup's LDS.
+    ValueError, not a wrong answer.  (The f-k filter and the analytic signal take any shape.)"""
     assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
     x = np.random.default_rng(0).standard_normal((8, 2 * 37))
     m = np.random.default_rng(1).uniform(size=x.shape)
     assert np.max(np.abs(dw.dsp.fk_filter_filt(x, m) - orc.fk_filter_filt(x, m))) < 1e-5 * np.max(np.abs(x))
     with pytest.raises(ValueError):
-        dw.dsp.envelope(np.zeros((2, 20011)))
+        dw.dsp.get_fx(np.zeros((2, 400)), 2 * 10007)
