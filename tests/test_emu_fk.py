@@ -308,3 +308,22 @@ def test_record_length_too_long_for_bluestein_tile(emu, nx, ns, chunk, monkeypat
     assert rel(fk_emu(emu, x, m, taper=1), orc.fk_filter_filt(x, m, tapering=True)) < TOL
     if chunk == 3:
         assert rel(fk_emu(emu, x, np.ones((nx, ns))), x) < TOL
+
+
+def test_fuzz_generic_kernels_with_prime_radices(emu):
+    """Random shapes whose axes are products of the radices 2..31 through the generic kernels (opts[0] = -1), with and without
+    the taper: every lds_stage_prime_t<R> in forward and inverse direction, batch-fast and contiguous order."""
+    rng = np.random.default_rng(7)
+    small = [2, 3, 4, 5, 6, 7, 8, 10, 11, 13, 17, 19, 23, 29, 31]
+    done = 0
+    while done < 16:
+        nx = int(np.prod(rng.choice(small, size=int(rng.integers(1, 4)))))
+        M = int(np.prod(rng.choice(small, size=int(rng.integers(1, 4)))))
+        if nx > 1200 or M > 1200:
+            continue
+        x = rng.standard_normal((nx, 2 * M))
+        m = rng.uniform(0, 1, (nx, 2 * M))
+        taper = int(rng.integers(0, 2))
+        y = fk_emu(emu, x, m, opts=[-1, 0, 0, 0, 0, 0], taper=taper)
+        assert rel(y, orc.fk_filter_filt(x, m, tapering=bool(taper))) < TOL, (nx, 2 * M)
+        done += 1

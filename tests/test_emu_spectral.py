@@ -371,3 +371,28 @@ def test_find_peaks_more_candidates_than_one_list(emu, ns):
             ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
             assert cnt[c] == len(ref), (thr, c, cnt[c], len(ref))
             assert np.array_equal(idx[c, :cnt[c]], ref)
+
+
+def test_fuzz_analytic_any_row_length(emu):
+    """Random row lengths (even and odd, prime factors up to 43) through the single-workgroup kernel and through the long-row
+    path: envelope and Hilbert transform against the oracle."""
+    emu.d4w_analytic_long_ws_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(9)
+    small = [2, 3, 4, 5, 6, 7, 8, 10, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43]
+    done = 0
+    while done < 14:
+        L = int(np.prod(rng.choice(small, size=int(rng.integers(1, 4)))))
+        if L > 3000:
+            continue
+        ns = 2 * L if rng.random() < 0.5 else (L if L % 2 else L + 1)
+        nx = int(rng.integers(1, 4))
+        x = (rng.standard_normal((nx, ns)) + 0.1).astype(np.float32)
+        z = orc.hilbert(x)
+        for mode in (0, 1):
+            ref = np.abs(z) if mode == 0 else z.imag
+            assert rel(analytic(emu, x, mode), ref) < TOL, ("single workgroup", ns, mode)
+            ws = np.empty(emu.d4w_analytic_long_ws_bytes(nx, ns), dtype=np.uint8)
+            y = np.empty((nx, ns), dtype=np.float32)
+            ok(emu, emu.d4w_analytic_long_f32(vp(x), vp(y), nx, ns, mode, None, ctypes.c_double(200.0), vp(ws), None))
+            assert rel(y, ref) < TOL, ("long-row path", ns, mode)
+        done += 1
