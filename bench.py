@@ -34,43 +34,50 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PASS_NAMES = ["fk_passA_fwd", "fk_passC_fwd", "fk_passB_mid", "fk_passC_inv", "fk_passA_inv"]
 
 
+def _best_of(fn, n=3):
+    """BASELINE.md section 3 protocol: one warm-up call, then the best of n timed calls."""
+    fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts)
+
+
 def cpu_baseline(sample_nx, sample_ns, stages):
-    """NumPy float64 restatement of the reference path (oracle) on a bounded sample: each stage is
-    timed on its own sample and the per-sample times are added (same composition as a GPU step)."""
+    """the NumPy / SciPy float64 restatement of the reference path (oracle; /root/reference does
+    not exist on the GPU box) on ONE block of BASELINE configs[0] shape (4000 x 12 000) IN FULL, time.perf_counter,
+    one warm-up + best of 3 per stage, design time excluded; the stage times are added like a GPU step's."""
     from oracle import d4w_oracle as orc
+    fs, dx = 200.0, 2.0419046878814697
     rng = np.random.default_rng(1234)
     x = rng.standard_normal((sample_nx, sample_ns))
-    per_sample, notes = 0.0, []
+    total, notes = 0.0, []
     if "bp" in stages:
-        rows = min(sample_nx, 1000)
-        t0 = time.perf_counter()
-        orc.bp_filt(x[:rows], 200.0, 14, 30)
-        dt = time.perf_counter() - t0
-        per_sample += dt / (rows * sample_ns)
-        notes.append("bp_filt %d x %d %.1f s" % (rows, sample_ns, dt))
+        dt = _best_of(lambda: orc.bp_filt(x, fs, 14, 30), 1 if sample_nx * sample_ns > 6e7 else 3)
+        total += dt
+        notes.append("bp_filt %.2f s" % dt)
     if "fk" in stages:
-        mask = np.ascontiguousarray(orc.fk_filter_design((sample_nx, sample_ns), [0, sample_nx, 1],
-                                                         2.0419046878814697, 200.0))
-        t0 = time.perf_counter()
-        orc.fk_filter_filt(x, mask)
-        dt = time.perf_counter() - t0
-        per_sample += dt / (sample_nx * sample_ns)
-        notes.append("fk_filter_filt %d x %d %.1f s" % (sample_nx, sample_ns, dt))
+        # the mask every reference script uses (scripts/main_mfdetect.py:46-55) at the scripts' 8.17 m channel spacing
+        mask = np.ascontiguousarray(orc.hybrid_ninf_filter_design((sample_nx, sample_ns), [0, 4 * sample_nx, 4], dx, fs,
+                                                                  1350., 1450., 3300, 3450, 14., 30.))
+        dt = _best_of(lambda: orc.fk_filter_filt(x, mask))
+        total += dt
+        notes.append("fk_filter_filt %.2f s" % dt)
     if "mf" in stages:
-        rows = min(sample_nx, 1500)
-        tt = np.arange(sample_ns) / 200.0
-        hf = orc.gen_template_fincall(tt, 200.0, 17.8, 28.8, 0.68)
-        lf = orc.gen_template_fincall(tt, 200.0, 14.7, 21.8, 0.78)
-        t0 = time.perf_counter()
-        for r0 in range(0, rows, 250):
-            orc.compute_cross_correlogram(x[r0:r0 + 250], hf)
-            orc.compute_cross_correlogram(x[r0:r0 + 250], lf)
-        dt = time.perf_counter() - t0
-        per_sample += dt / (rows * sample_ns)
-        notes.append("compute_cross_correlogram x2 %d x %d %.1f s" % (rows, sample_ns, dt))
-    out = {"value": 1.0 / per_sample, "unit": "channel-samples/s", "cores": 1, "kind": "port",
-           "sample": "oracle (numpy.fft / scipy float64, single thread): " + "; ".join(notes)}
-    # second column (SURVEY 8d): the same math as a CPU would best run it -- float32, half spectrum,
+        tt = np.arange(sample_ns) / fs
+        hf = orc.gen_template_fincall(tt, fs, 17.8, 28.8, 0.68)
+        lf = orc.gen_template_fincall(tt, fs, 14.7, 21.8, 0.78)
+        dt = _best_of(lambda: (orc.compute_cross_correlogram(x, hf), orc.compute_cross_correlogram(x, lf)))
+        total += dt
+        notes.append("compute_cross_correlogram x2 %.2f s" % dt)
+    samples = float(sample_nx) * sample_ns
+    out = {"value": samples / total, "unit": "channel-samples/s", "cores": 1, "kind": "port",
+           "cores_available": len(os.sched_getaffinity(0)),
+           "sample": "oracle (numpy.fft / scipy.signal float64, single thread as the reference runs) on one %d x %d block in "
+                     "full, 1 warm-up + best of 3 per stage: %s" % (sample_nx, sample_ns, "; ".join(notes))}
+    # second column (SURVEY 8d / BASELINE.md 3): the same math as a CPU would best run it -- float32, half spectrum,
     # scipy.fft on every core, one transform of the block shared by both templates
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -78,22 +85,17 @@ def cpu_baseline(sample_nx, sample_ns, stages):
         be, bnotes = 0.0, []
         if "fk" in stages:
             mh = orc.fold_mask_half(mask).astype(np.float32)
-            orc.fk_filter_filt_best_effort(x32[:64], mh[:64])
-            t0 = time.perf_counter()
-            orc.fk_filter_filt_best_effort(x32, mh)
-            dt = time.perf_counter() - t0
-            be += dt / x32.size
-            bnotes.append("rfft2 f-k %d x %d %.2f s" % (x32.shape[0], x32.shape[1], dt))
+            dt = _best_of(lambda: orc.fk_filter_filt_best_effort(x32, mh))
+            be += dt
+            bnotes.append("rfft2 f-k %.3f s" % dt)
         if "mf" in stages:
-            rows = min(sample_nx, 4000)
-            t0 = time.perf_counter()
-            orc.compute_cross_correlogram_best_effort(x32[:rows], [hf[:136], lf[:156]])
-            dt = time.perf_counter() - t0
-            be += dt / (rows * sample_ns)
-            bnotes.append("batched rfft matched filter x2 %d x %d %.2f s" % (rows, sample_ns, dt))
+            dt = _best_of(lambda: orc.compute_cross_correlogram_best_effort(x32, [hf[:136], lf[:156]]))
+            be += dt
+            bnotes.append("batched rfft matched filter x2 %.3f s" % dt)
         if be > 0:
-            out["best_effort"] = {"value": 1.0 / be, "unit": "channel-samples/s", "cores": ncores,
-                                  "sample": "scipy.fft float32, workers = all cores: " + "; ".join(bnotes)}
+            out["best_effort"] = {"value": samples / be, "unit": "channel-samples/s", "cores": ncores,
+                                  "sample": "scipy.fft float32, workers = all cores, same block, 1 warm-up + best of 3: "
+                                            + "; ".join(bnotes)}
     except Exception as e:                       # the second column must never break the bench line
         out["best_effort"] = {"error": repr(e)}
     return out
@@ -191,6 +193,8 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    nranks = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(nranks)                       # every rank that took part counts itself (RCCL)
     # per-stage times of rank 0 (HIP events on the launch stream; transfers are waited on there), a few extra steps
     stage_ms = {}
     for _ in range(3):
@@ -228,10 +232,10 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         ms = dt / args.steps * 1e3
         gbs = 24.0 * samples / (ms * 1e-3) / 1e9 / world           # per-GPU algorithmic f-k bytes over the whole step
         out = {"metric": "channel-samples/sec through f-k filter + matched-filter", "value": samples / (dt / args.steps),
-               "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "channel-samples/s", "n_gpus": world, "rccl_ranks": int(nranks.item()), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": "ONE %d channels x %d samples float32 block sharded by channel block over %d GPU(s), "
+               "config": {"workload": "BASELINE configs[3]: ONE %d channels x %d samples float32 block sharded by channel block over %d GPU(s), "
                                       "classic f-k fan mask, stages %s%s" % (nx, ns, world, "+".join(stages),
                                                                              ", all-gather of the t-x output" if args.gather else ""),
                           "plan": plan_info,
@@ -362,8 +366,107 @@ def bench_stream(args, world, rank, device, dist):
         dist.destroy_process_group()
 
 
+def _self_launch(n, backend):
+    """Re-run this command line under torch.distributed.run with n ranks on this node (127.0.0.1 rendezvous, a free
+    port); returns the launcher's exit code.  Fails loudly when the node has fewer than n GPUs."""
+    import socket
+    import subprocess
+    if backend == "nccl" and torch.cuda.device_count() < n:
+        print("[bench] --gpus %d requested but %d GPU(s) visible; refusing to print a smaller line" % (n, torch.cuda.device_count()),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
+
+
+def bench_gloo_emulated(args, stages, world, rank):
+    """--backend gloo: the launch path and the channel-sharded f-k step of the N > 1 bench on CPU ranks -- the same
+    shard.ShardedFkPlan exchange code over gloo with the emulator build of the kernel sources (tests/emu) standing in for
+    libd4w.so.  Test infrastructure for tests/test_bench_launch.py (no GPU in the build container); prints the same JSON
+    line shape with "data": "synthetic (emulated, CPU)" so that it can never be mistaken for a measurement."""
+    import ctypes
+    import importlib.util
+    import torch.distributed as dist
+    from tests.emu_util import load_emu
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    emu = load_emu()
+    vp_, ci = ctypes.c_void_p, ctypes.c_int
+    emu.d4w_fkd_plan_create.argtypes = [ci] * 4 + [ctypes.POINTER(vp_)]
+    emu.d4w_fkd_plan_destroy.argtypes = [vp_]
+    emu.d4w_fkd_plan_info.argtypes = [vp_, ctypes.POINTER(ci)]
+    emu.d4w_fkd_plan_q1_owner.argtypes = [vp_, ctypes.POINTER(ci)]
+    emu.d4w_fkd_set_mask_dense_f32.argtypes = [vp_] * 3
+    emu.d4w_fkd_time_fwd_f32.argtypes = [vp_] * 3 + [ci, vp_]
+    emu.d4w_fkd_chan_apply_f32.argtypes = [vp_] * 3
+    emu.d4w_fkd_time_inv_f32.argtypes = [vp_] * 3
+    emu.d4w_fkd_time_fwd_packed_f32.argtypes = [vp_] * 3 + [ci, vp_]
+    emu.d4w_fkd_time_inv_packed_f32.argtypes = [vp_] * 4
+    emu.d4w_fkd_time_fwd_packed_rows_f32.argtypes = [vp_] * 3 + [ci, ci, ci, vp_]
+    emu.d4w_fkd_time_inv_packed_rows_f32.argtypes = [vp_] * 3 + [ci, ci, vp_]
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(emu.d4w_last_error())
+    spec = importlib.util.spec_from_file_location("d4w_shard", os.path.join(ROOT, "das4whales_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
+    nx, ns = args.nx or 100, args.ns or 600
+    a, b = shard.channel_block(nx, world, rank)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn((nx, ns), generator=g)
+    m = torch.rand((nx, ns), generator=g)
+    plan = shard.ShardedFkPlan(nx, ns, native=(emu, check))
+    plan.set_mask(m)
+    x_loc = x[a:b].contiguous()
+
+    def step():
+        y = plan.apply(x_loc)
+        return shard.all_gather_rows(y, nx) if args.gather is not False else y
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y_all = step()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ranks = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ranks)
+    err = None
+    if rank == 0 and nx * ns <= 1 << 20:
+        from oracle import d4w_oracle as orc
+        ref = orc.fk_filter_filt(x.double().numpy(), m.double().numpy())
+        err = float(np.max(np.abs(y_all.numpy() - ref)) / np.max(np.abs(ref)))
+    if rank == 0:
+        dt = float(tt.item())
+        print(json.dumps({"metric": "channel-samples/sec through f-k filter", "value": float(nx) * ns * args.steps / dt,
+                          "unit": "channel-samples/s", "n_gpus": world, "ranks": int(ranks.item()), "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic (emulated, CPU)",
+                          "config": {"workload": "ONE %d x %d block sharded by channel block over %d CPU rank(s), gloo, emulator "
+                                                 "kernels -- launch-path test, not a measurement" % (nx, ns, world),
+                                     "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
+                          "rel_err_vs_oracle": err}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", type=str, default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one rank per GPU (the bench); gloo = CPU ranks with the emulator kernels (launch-path test only)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -374,7 +477,7 @@ def main():
                          "BASELINE configs[4]: consecutive 60-s files through the whole detection chain, files/s and detections/s")
     ap.add_argument("--files", type=int, default=8, help="--config stream: consecutive files per GPU")
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
-    ap.add_argument("--cpu-sample", type=str, default="8000x24000")
+    ap.add_argument("--cpu-sample", type=str, default="4000x12000", help="CPU baseline block (BASELINE configs[0] shape, run in full)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask / hybrid_ninf f-k timings")
     ap.add_argument("--prune-eps", type=float, default=4e-6,
@@ -396,11 +499,24 @@ def main():
     stages = [t for t in args.stages.split(",") if t]
     assert set(stages) <= {"bp", "fk", "mf"} and stages, "--stages: comma list of bp, fk, mf"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run) instead of printing an n_gpus = 1 line; the children's rank 0 prints the JSON line
+        return _self_launch(args.gpus, args.backend)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        if args.gpus > 1 or world > 1:
+            print("[bench] --gpus %d but the launcher started %d rank(s): reporting n_gpus = %d" % (args.gpus, world, world),
+                  file=sys.stderr, flush=True)
         args.gpus = world
+    if args.backend == "gloo":
+        return bench_gloo_emulated(args, stages, world, rank)
+    if torch.cuda.device_count() < max(1, min(world, local_rank + 1)):
+        print("[bench] rank %d: local rank %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
     if args.shard == "auto":
         args.shard = "channel" if world > 1 else "replicas"
     if args.gather is None:
@@ -561,7 +677,7 @@ def main():
         alg_bytes["mf_xcorr_fft_fused"] = 12.0 * samples           # read the block once, write two correlograms
     if "bp" in stages:
         cand["bp_sosfiltfilt"] = stage_ms["bp_sosfiltfilt"]
-        alg_bytes["bp_sosfiltfilt"] = 16.0 * samples
+        alg_bytes["bp_sosfiltfilt"] = 8.0 * samples         # read once, write once
     dom = max(cand, key=cand.get)
     achieved = alg_bytes[dom] / (cand[dom] * 1e-3) / 1e9
     traffic = None
@@ -607,6 +723,20 @@ def main():
             roofline["fk_hybrid_ninf"] = time_mask(hm)
             roofline["fk_hybrid_ninf_pruned"] = dict(time_mask(hm, prune_eps=args.prune_eps), prune_eps=args.prune_eps)
             del hm
+            # the geometry the reference scripts run: every 4th channel of the cable (8.17 m spacing,
+            # scripts/main_mfdetect.py:25-30, DAS4Whales_ExampleNotebook.md:256) -- |k| only reaches 0.061 1/m, so the
+            # classic fan keeps every wavenumber row alive
+            sel4 = [0, 4 * nx, 4]
+            roofline["fk_classic_step4"] = dict(time_mask(dw.dsp.fk_filter_design((nx, ns), sel4, dx, fs)), selected_channels=sel4)
+            roofline["fk_hybrid_ninf_step4"] = dict(time_mask(
+                dw.dsp.hybrid_ninf_filter_design((nx, ns), sel4, dx, fs, 1350., 1450., 3300, 3450, 14., 30.)), selected_channels=sel4)
+        if "bp" not in stages and not args.no_dense:
+            # the zero-phase band-pass (dsp.bp_filt, 14-30 Hz) on the same block, outside the timed step: 8 B/sample
+            # algorithmic (read once, write once)
+            ddsp._sosfiltfilt_device(x, sos_bp, 51)
+            tb = sum(ev_time(lambda: ddsp._sosfiltfilt_device(x, sos_bp, 51)) for _ in range(3)) / 3
+            roofline["bp"] = {"bp_filt_ms": tb, "algorithmic_bytes": 8.0 * samples,
+                              "frac": 8.0 * samples / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         out = {"metric": "channel-samples/sec through " + " + ".join(
