@@ -75,3 +75,48 @@ def assert_picks_match(got, ref_signal, thr, what=""):
         prom = float(sps.peak_prominences(ref_signal, [i])[0][0])
         assert abs(prom - thr) <= 1e-4 * thr, (what, i, "differing pick is not marginal: prominence %.9g vs threshold %.9g" % (prom, thr))
     return len(diff), len(ref)
+
+
+def synth_block_device(nx, ns, device, fs=200.0, dx=2.0419046878814697, step=1, seed=1234, n_calls=6, n_waves=40,
+                       noise=1e-9, ocean_amp=1e-8, call_amp=5e-9):
+    """SURVEY 8(d) S-large recipe on the device in float32: white noise `noise` + `n_waves` slow "ocean-wave" plane waves
+    (f ~ U(0.5, 8) Hz, apparent speed ~ U(5, 300) m/s, amplitude `ocean_amp` EACH) + `n_calls` fin-whale notes (HF / LF
+    alternated, hyperbolic moveout at 1500 m/s, amplitude `call_amp`).  Same recipe as oracle.synth_block (which divides the
+    ocean amplitude by sqrt(n_waves)); returns the block and the list of (template index, channel of closest approach,
+    arrival sample there)."""
+    import torch
+    from oracle import d4w_oracle as orc
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn((nx, ns), dtype=torch.float32, device=device, generator=g) * noise
+    t = np.arange(ns) / fs
+    xpos = np.arange(nx) * step * dx
+    f = rng.uniform(0.5, 8.0, n_waves)
+    c = rng.uniform(5.0, 300.0, n_waves) * rng.choice([-1.0, 1.0], n_waves)
+    ph = rng.uniform(0, 2 * np.pi, n_waves)
+    alpha = -2 * np.pi * (f / c)[None, :] * xpos[:, None] + ph[None, :]            # cos(alpha_c + beta_n)
+    beta = 2 * np.pi * f[:, None] * t[None, :]
+    A = torch.from_numpy(np.concatenate((np.cos(alpha), -np.sin(alpha)), axis=1).astype(np.float32)).to(device)
+    B = torch.from_numpy(np.concatenate((np.cos(beta), np.sin(beta)), axis=0).astype(np.float32)).to(device)
+    rows = 2000
+    for r0 in range(0, nx, rows):
+        x[r0:r0 + rows] += ocean_amp * (A[r0:r0 + rows] @ B)
+    del A, B
+    tpls = [orc.gen_template_fincall(t, fs, 17.8, 28.8, 0.68), orc.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)]
+    calls = []
+    flat = x.view(-1)
+    for i in range(n_calls):
+        tpl = tpls[i % 2]
+        L = int(np.max(np.nonzero(tpl)[0])) + 1
+        x0 = rng.uniform(xpos[0], xpos[-1])
+        r = rng.uniform(1000.0, 5000.0)
+        t0 = rng.uniform(0.05, 0.7) * ns / fs
+        idx = np.round((t0 + np.sqrt(r * r + (xpos - x0) ** 2) / 1500.0) * fs).astype(np.int64)
+        ok = np.nonzero((idx >= 0) & (idx < ns - L))[0]
+        base = torch.from_numpy(ok * ns + idx[ok]).to(device)
+        tp = torch.from_numpy((call_amp * tpl[:L]).astype(np.float32)).to(device)
+        pos = (base[:, None] + torch.arange(L, device=device)[None, :]).reshape(-1)
+        flat.index_add_(0, pos, tp.repeat(len(ok)))
+        c0 = int(np.argmin(np.abs(xpos - x0)))
+        calls.append((i % 2, c0, int(idx[c0])))
+    return x, calls

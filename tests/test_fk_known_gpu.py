@@ -148,3 +148,51 @@ def test_mask_edited_in_place_is_refolded(dw):
     mt.mul_(2.0)
     y4 = dw.dsp.fk_filter_filt(xt, mt)
     assert float((y4 - 2.0 * y3).abs().max()) < TOL * float(y4.abs().max())
+
+
+def test_pruned_mode_on_ocean_wave_block(dw):
+    """Opt-in tail pruning (FkPlan.set_mask(m, prune_eps=4e-6), the only non-exact mode of the filter) against the exact
+    filter on SURVEY 8(d)'s S-large recipe at 20 000 x 120 000: white noise 1e-9 + 40 ocean-wave plane waves of 1e-8 EACH
+    + six fin-whale notes of 5e-9, the scripts' hybrid_ninf mask.  What the pruned mode drops is bounded by
+    prune_eps * max|M_h| times the spectral L1 content of the input in the dropped rows; on this input (the ocean waves sit
+    below 8 Hz, where the exact mask is zero outside the fan anyway) that is far below the 1e-5 budget -- asserted here --
+    and a tone placed INSIDE the dropped region comes back as prune_eps-sized gain x amplitude, which the second half pins."""
+    shape, sel = (20000, 120000), [0, 20000, 1]
+    mask, at = _design(dw, "hybrid_ninf", shape, sel)
+    x, calls = ka.synth_block_device(shape[0], shape[1], "cuda", ocean_amp=1e-8)
+    plan = dw.dsp.get_fk_plan(*shape)
+    plan.set_mask(mask)
+    y_exact = plan.apply(x)
+    plan.set_mask(mask, prune_eps=4e-6)
+    live = plan.live_rows()
+    y_pruned = plan.apply(x)
+    scale = float(y_exact.abs().max())
+    err = float((y_pruned - y_exact).abs().max()) / scale
+    print("S-large, hybrid_ninf: pruned (eps 4e-6, %d live rows) vs exact: %.3e of max|y| = %.3e (input max %.3e)"
+          % (live, err, scale, float(x.abs().max())))
+    assert live < shape[0] // 4
+    assert err < TOL
+    # the calls survive, the ocean waves do not: the filtered block stays far below the 40 x 1e-8 of the input
+    assert 1e-9 < scale < 0.25 * float(x.abs().max())
+    del x, y_exact, y_pruned
+    # a plane wave inside the dropped rows (|k| = 0.1 1/m, 46 Hz: gain 2 |H(46 Hz)|^2 ~ 1e-6) next to a pass-band wave
+    nx, ns = shape
+    dk, df = 1.0 / (nx * sel[2] * DX), FS / ns
+    kx = np.array([int(round(20.0 / 2000.0 / dk)), int(round(0.1 / dk))])
+    kt = np.array([int(round(20.0 / df)), int(round(46.0 / df))])
+    g = orc.folded_gain_at(at, shape, kx, kt)
+    assert g[0] > 0.5 and 0 < g[1] < 4e-6 * 2.0
+    amp, ph = np.array([1.0, 10.0]), np.array([0.3, 1.1])
+    A, B = ka.wave_factors(nx, ns, kx, kt, ph)
+    Ad, Bd = torch.from_numpy(A.astype(np.float32)).cuda(), torch.from_numpy(B.astype(np.float32)).cuda()
+    xw = (Ad * torch.from_numpy(np.tile(amp, 2).astype(np.float32)).cuda()) @ Bd
+    yw = plan.apply(xw)                                     # pruned
+    ref_exact = (Ad * torch.from_numpy(np.tile(amp * g, 2).astype(np.float32)).cuda()) @ Bd
+    ref_pruned = (Ad * torch.from_numpy(np.tile(amp * g * np.array([1.0, 0.0]), 2).astype(np.float32)).cuda()) @ Bd
+    sc = float(ref_exact.abs().max())
+    e_pruned = float((yw - ref_pruned).abs().max()) / sc
+    e_exact = float((yw - ref_exact).abs().max()) / sc
+    print("tone in the dropped rows: pruned output vs (exact answer without that tone) %.3e; vs exact answer %.3e; "
+          "bound gain x amplitude = %.3e" % (e_pruned, e_exact, g[1] * amp[1] / sc))
+    assert e_pruned < TOL
+    assert e_exact <= g[1] * amp[1] / sc + TOL            # the documented bound: dropped gain x amplitude of what sits there
