@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PASS_NAMES = ["fk_passA_fwd", "fk_passC_fwd", "fk_passB_mid", "fk_passC_inv", "fk_passA_inv"]
+PASS_NAMES = ["fk_passA_fwd", "fk_passC_fwd", "fk_passB_mid", "fk_passC_inv", "fk_passA_inv"]      # channel-first order
+PASS_NAMES_TF = ["fk_passA_fwd", "fk_passBf_time_fwd", "fk_passCm_channel", "fk_passBi_time_inv", "fk_passA_inv"]   # time-first
 
 
 def _best_of(fn, n=3):
@@ -561,6 +562,7 @@ def main():
     mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)
     plan.set_mask(mask)
     live_rows = plan.live_rows()
+    main_order = plan.order()
     del mask
     torch.cuda.empty_cache()
 
@@ -654,13 +656,14 @@ def main():
             mf_k["mf_xcorr_fft_blocks_1tpl"] += one / len(tpl)
     acc /= args.steps
     stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
-    kernel_ms = {PASS_NAMES[i]: float(acc[i]) for i in range(5)} if "fk" in stages else {}
+    pass_names = PASS_NAMES_TF if main_order["order"] == "time-first" else PASS_NAMES
+    kernel_ms = {pass_names[i]: float(acc[i]) for i in range(5)} if "fk" in stages else {}
     if "fk" in stages:
         stage_ms["fk_filter"] = float(acc.sum())
     # algorithmic bytes per launch: an f-k pass reads and writes the block once
     # (8 B/sample); row_stats reads it once (4 B/sample); the fused matched-filter launch reads it once
     # and writes two correlograms (12 B/sample); band-pass stage 2 x (4+4) B/sample
-    alg_bytes = {n: 8.0 * samples for n in PASS_NAMES}
+    alg_bytes = {n: 8.0 * samples for n in PASS_NAMES + PASS_NAMES_TF}
     cand = dict(kernel_ms)
     if "mf" in stages:
         for k in mf_k:
@@ -697,7 +700,7 @@ def main():
         fk_gbs = 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9
         roofline.update({"fk_algorithmic_GBps": fk_gbs, "fk_algorithmic_frac": fk_gbs / HBM_PEAK_GBS,
                          "fk_only_samples_per_s": samples / (float(acc.sum()) * 1e-3),
-                         "fk_live_wavenumber_rows": live_rows})
+                         "fk_live_wavenumber_rows": live_rows, "fk_order": main_order})
         def time_mask(m, **set_kw):
             """The same filter with another mask: five pass times (HIP events) and the 24 B/sample fraction."""
             plan.set_mask(m, **set_kw)
@@ -708,8 +711,10 @@ def main():
                 _, ms = plan.apply_timed(x, out=y)
                 accm += np.array(ms)
             accm /= nrep
-            return {"fk_filter_ms": float(accm.sum()), "live_wavenumber_rows": plan.live_rows(),
-                    "kernel_ms": {PASS_NAMES[i]: float(accm[i]) for i in range(5)},
+            od = plan.order()
+            names = PASS_NAMES_TF if od["order"] == "time-first" else PASS_NAMES
+            return {"fk_filter_ms": float(accm.sum()), "live_wavenumber_rows": plan.live_rows(), "order": od,
+                    "kernel_ms": {names[i]: float(accm[i]) for i in range(5)},
                     "fk_algorithmic_frac": 24.0 * samples / (float(accm.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
         if not args.no_dense:

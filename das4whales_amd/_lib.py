@@ -40,6 +40,7 @@ def _load():
         "d4w_fk_set_mask_design_f32": (c_int, [c_void_p, c_int, ctypes.c_double, ctypes.c_double, P(ctypes.c_double),
                                                c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_fk_plan_live_rows": (c_int, [c_void_p]),
+        "d4w_fk_plan_order": (c_int, [c_void_p, P(c_int), P(ctypes.c_double)]),
         "d4w_fk_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_fk_apply_timed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, P(ctypes.c_float)]),
         "d4w_fkd_plan_create": (c_int, [c_int, c_int, c_int, c_int, P(c_void_p)]),

@@ -41,6 +41,7 @@ struct FkDev {  // kernel argument block (by value)
 }  // namespace d4w
 
 #include "fk_fast.h"
+#include "fk_tf.h"
 
 namespace d4w {
 
@@ -71,6 +72,11 @@ struct FkFastEntry {
     void (*Cs_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
     void (*Bs_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);                       // pass B on the slab
     void (*Bs_hilb)(FkDev, FkFastDev, float2*, int, int, FkGeo);                      // ... with the Hilbert pair operation (real rows)
+    // time-first order (fk_tf.h)
+    size_t ldsBt;
+    void (*Bt_fwd)(FkDev, FkFastDev, FkTfDev, float2*, int, int);                     // Bf: n2 forward + untangle -> W
+    void (*Bt_inv)(FkDev, FkFastDev, FkTfDev, float2*, int, int);                     // Bi: W -> re-tangle + n2 inverse
+    void (*C_mid)(FkDev, FkFastDev, FkTfDev, int, int);                               // Cm: c2 forward x mask x c2 inverse on W
 };
 
 template <class G>
@@ -100,6 +106,14 @@ static inline FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0)
     e.Cs_inv = fkf_passC<G, true, 1>;
     e.Bs_mid = fkf_passB<G, 1>;
     e.Bs_hilb = fkf_passB<G, 1, true>;
+    e.ldsBt = G::ldsB + (size_t)G::NC * G::NB * sizeof(int2);
+    if constexpr (G::C2X == 1) {
+        e.Bt_fwd = fkf_passBt<G, 1>;
+        e.Bt_inv = fkf_passBt<G, 2>;
+        e.C_mid = fkf_passCm<G>;
+    } else {
+        e.Bt_fwd = nullptr; e.Bt_inv = nullptr; e.C_mid = nullptr;
+    }
     return e;
 }
 

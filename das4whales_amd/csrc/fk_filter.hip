@@ -20,6 +20,8 @@
 //   C' inv, A' inv (+ 1/(nx*M) scale).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -583,6 +585,42 @@ __global__ __launch_bounds__(kFoldThreads) void fk_fold_mask_tiled(FkDims d, int
     if ((threadIdx.x & 63) == 0 && vbits) atomicMax(rowmaxbits + r, vbits);
 }
 
+// Column statistics of the folded mask (time-first order, fk_tf.h): min and max over all wavenumber rows of every
+// half-spectrum column, as order-preserving unsigned keys (a NaN gain lands above +inf in the max key).  One thread per
+// column position (coalesced along the row), row chunks combined by atomics.
+__device__ __forceinline__ unsigned fk_ord_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(kThreads) void fk_col_minmax(FkDims d, const float* __restrict__ mask, int rows_per_block,
+                                                           unsigned* __restrict__ kmin, unsigned* __restrict__ kmax) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.M) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(d.nx, r0 + rows_per_block);
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (int r = r0; r < r1; ++r) {
+        const unsigned k = fk_ord_key(mask[(size_t)r * d.M + p]);
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    if (r1 > r0) {
+        atomicMin(kmin + p, lo);
+        atomicMax(kmax + p, hi);
+    }
+}
+
+// Band columns of the folded mask in the compact column order of the time-first passes: cmask[r][col] = mask[r][src[col]]
+// (src = -2: the Nyquist column nyq[r]; -1: padding).
+__global__ __launch_bounds__(kThreads) void fk_gather_cmask(FkDims d, const float* __restrict__ mask, const float* __restrict__ nyq,
+                                                             const int* __restrict__ src, int Lband, float* __restrict__ cmask) {
+    const int r = blockIdx.y;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < Lband; c += gridDim.x * blockDim.x) {
+        const int sp = src[c];
+        cmask[(size_t)r * Lband + c] = (sp >= 0) ? mask[(size_t)r * d.M + sp] : (sp == -2 ? nyq[r] : 0.f);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void taper_rows(float* __restrict__ x, const float* __restrict__ win,
                                                         size_t total, int ns) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -691,6 +729,19 @@ struct d4w_fk_plan {
     int live_rows = 0;
     int wgA = 1, wgC = 1, wgB = 1;
     int slab_sw = 0;                       // > 0: passes A/C and C'/A' run slab by slab, sw column blocks per slab
+    // time-first order (fk_tf.h): chosen per mask by fk_mask_finish when it moves fewer bytes than dead-row skipping
+    bool tf = false;
+    FkTfDev tfdev;
+    int npairsT = 0;
+    unsigned* d_colkeys = nullptr;         // [2][M] min / max keys of the mask columns
+    float* d_tgain = nullptr;              // [M]
+    int2* d_ctab = nullptr;                // [NC][NB]
+    int* d_colsrc = nullptr;               // [M + TC] gather table of the band columns
+    float* d_cmask = nullptr;              // [nx][Lband]   (capacity cap_cmask floats)
+    float2* d_W = nullptr;                 // [nx][Lc]      (capacity cap_W elements)
+    size_t cap_cmask = 0, cap_W = 0;
+    int tf_band_cols = 0, tf_tail_cols = 0;   // per row: band (incl. Nyquist) and tail columns kept
+    double bytes_cf = 42.0, bytes_tf = 42.0;  // modelled bytes per channel-sample of the two orders for the current mask
 };
 
 template <typename T>
@@ -779,6 +830,8 @@ int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
     if (pl && pl->big) { d4w_fkd_plan_destroy(pl->big); pl->big = nullptr; }
     if (!pl) return D4W_OK;
     for (void* p : pl->allocs) (void)hipFree(p);
+    if (pl->d_cmask) (void)hipFree(pl->d_cmask);
+    if (pl->d_W) (void)hipFree(pl->d_W);
     delete pl;
     return D4W_OK;
 }
@@ -1044,6 +1097,32 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             pl->allocs.push_back(q); pl->d_pairs_live = (int2*)q;
         }
     }
+    if (fast && !bs_L && fast->Bt_fwd) {
+        // time-first order: work list of passes Bf / Bi.  BEFORE the c2 transform the Hermitian partner of row
+        // (q, c2) is (q', c2), kc1(q') = -kc1(q) (fk_tf.h); the partner sub-row is the same q1' as in pass B.
+        std::vector<int2> pairsT;
+        pairsT.reserve((size_t)nx * N1 / 2 + 4);
+        for (int r = 0; r < nx; ++r) {
+            const int q = r / C2, c2 = r - q * C2;
+            const int rb = p_c1[(C1 - f_c1[q]) % C1] * C2 + c2;
+            for (int q1 = 0; q1 < N1; ++q1) {
+                const long keyA = (long)r * N1 + q1, keyB = (long)rb * N1 + q1part[q1];
+                if (keyB >= keyA) pairsT.push_back(make_int2((int)keyA, (int)keyB));
+            }
+        }
+        pl->npairsT = (int)pairsT.size();
+        D4W_TRY(upload(pl, pairsT, &pl->tfdev.pairs));
+        void* q = nullptr;
+        const size_t nctab = (size_t)fast->NC * fast->NB;
+        if (hipMalloc(&q, 2 * (size_t)M * sizeof(unsigned)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        pl->allocs.push_back(q); pl->d_colkeys = (unsigned*)q;
+        if (hipMalloc(&q, (size_t)M * sizeof(float)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        pl->allocs.push_back(q); pl->d_tgain = (float*)q;
+        if (hipMalloc(&q, nctab * sizeof(int2)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        pl->allocs.push_back(q); pl->d_ctab = (int2*)q;
+        if (hipMalloc(&q, ((size_t)M + 64) * sizeof(int)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
+        pl->allocs.push_back(q); pl->d_colsrc = (int*)q;
+    }
     D4W_TRY(upload(pl, rowpart, &pl->dev.row_partner));
     D4W_TRY(upload(pl, q1part, &pl->dev.q1_partner));
     D4W_TRY(upload(pl, mirror0, &pl->dev.mirror0));
@@ -1145,6 +1224,11 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             (void)hipFuncSetAttribute((const void*)fast->Cs_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->Bs_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
             (void)hipFuncSetAttribute((const void*)fast->Bs_hilb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
+            if (fast->Bt_fwd) {
+                (void)hipFuncSetAttribute((const void*)fast->Bt_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
+                (void)hipFuncSetAttribute((const void*)fast->Bt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
+                (void)hipFuncSetAttribute((const void*)fast->C_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+            }
         }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
         if (!fast && lds_max > 64 * 1024) {
@@ -1216,7 +1300,144 @@ static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double p
     return fk_mask_finish(pl, prune_eps, stream);
 }
 
-// after a fold (d_mask, d_nyq, d_rowmax written on `stream`): liveness of the wavenumber rows
+// Gains the filter treats as zero.  Opt-in: prune_eps * max|M_h| (approximate, FkPlan.set_mask(m, prune_eps=...)).
+// Always: D4W_FK_ROUND_EPS (default 2^-24) / sqrt(nx ns) * max|M_h| -- what such gains add to ANY output sample is at
+// most  g ||x||_F  =  2^-24 max|M_h| rms(x)  (Cauchy-Schwarz over the spectrum): half a float32 ulp of the input's RMS,
+// below the rounding noise of the float32 transforms themselves, whatever the input.
+static double fk_zero_gain(const FkDims& d, double prune_eps, double gmax) {
+    static const double round_eps = [] {
+        const char* v = getenv("D4W_FK_ROUND_EPS");
+        return v ? atof(v) : 5.9604644775390625e-8;
+    }();
+    return std::max(prune_eps, round_eps / sqrt((double)d.nx * (double)d.ns)) * gmax;
+}
+
+static inline float fk_key_value(unsigned k) {
+    const unsigned b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float v;
+    memcpy(&v, &b, sizeof(v));
+    return v;
+}
+
+// Time-first order for the mask just folded (fk_tf.h): classify the half-spectrum columns, lay the kept ones out,
+// model the bytes of both orders; when time-first wins, build the pass tables, the compact band mask and the workspace.
+static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
+    const FkDims& d = pl->dev.d;
+    const FkFastEntry& F = *pl->fast;
+    hipStream_t st = (hipStream_t)stream;
+    const int NA = F.NA, NB = F.NB, NC = F.NC, N1 = d.N1, N2 = d.N2, M = d.M, TC = d.TC;
+    pl->tf = false;
+    pl->bytes_cf = 24.0 + 18.0 * (double)pl->live_rows / d.nx;
+    pl->bytes_tf = 42.0;
+    const char* ord = getenv("D4W_FK_ORDER");
+    if (ord && !strcmp(ord, "cf")) return D4W_OK;
+    D4W_HIP(hipMemsetAsync(pl->d_colkeys, 0xFF, (size_t)M * sizeof(unsigned), st));
+    D4W_HIP(hipMemsetAsync(pl->d_colkeys + M, 0, (size_t)M * sizeof(unsigned), st));
+    const int rpb = 512;
+    D4W_LAUNCH(fk_col_minmax, dim3(ceil_div(M, kThreads), ceil_div(d.nx, rpb)), dim3(kThreads), 0, stream, d,
+               (const float*)pl->d_mask, rpb, pl->d_colkeys, pl->d_colkeys + M);
+    std::vector<unsigned> keys(2 * (size_t)M);
+    std::vector<float> nyq(d.nx);
+    D4W_HIP(hipMemcpyAsync(keys.data(), pl->d_colkeys, keys.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    D4W_HIP(hipMemcpyAsync(nyq.data(), pl->d_nyq, (size_t)d.nx * sizeof(float), hipMemcpyDeviceToHost, st));
+    D4W_HIP(hipStreamSynchronize(st));
+    // column classes at the positions p = q1 N2 + e: 0 dead, 1 band, 2 tail (gain the same for every wavenumber)
+    std::vector<unsigned char> ccls(M);
+    std::vector<float> cgain(M);
+    for (int p = 0; p < M; ++p) {
+        const float lo = fk_key_value(keys[p]), hi = fk_key_value(keys[M + p]);
+        const double amax = std::max(fabs((double)lo), fabs((double)hi));
+        cgain[p] = 0.5f * (lo + hi);
+        if (!(lo == lo) || !(hi == hi) || std::isinf(lo) || std::isinf(hi)) ccls[p] = 1;        // NaN / inf gains: as NumPy, through the product
+        else if (amax <= zero_gain) ccls[p] = 0;
+        else if ((double)hi - (double)lo <= zero_gain) ccls[p] = 2;
+        else ccls[p] = 1;
+    }
+    bool nyq_live = false;
+    for (int r = 0; r < d.nx; ++r) nyq_live |= !(fabs((double)nyq[r]) <= zero_gain);
+    // cells (d2, d1): the strongest class of their N1 NA columns; position e = d0 NB NC + d1 NC + d2
+    std::vector<int> cell(NC * NB, 0);
+    for (int q1 = 0; q1 < N1; ++q1)
+        for (int e = 0; e < N2; ++e) {
+            const int c = ccls[(size_t)q1 * N2 + e];
+            if (!c) continue;
+            const int d1 = (e / NC) % NB, d2 = e % NC;
+            int& cc = cell[d2 * NB + d1];
+            if (c == 1) cc = 1;
+            else if (cc == 0) cc = 2;
+        }
+    std::vector<int2> ctab(NC * NB);
+    int rw[3] = {0, 0, 0};
+    for (int d2 = 0; d2 < NC; ++d2) {
+        int cnt[3] = {0, 0, 0};
+        for (int d1 = 0; d1 < NB; ++d1) cnt[cell[d2 * NB + d1]]++;
+        int rank[3] = {0, 0, 0};
+        for (int d1 = 0; d1 < NB; ++d1) {
+            const int c = cell[d2 * NB + d1];
+            ctab[d2 * NB + d1] = c ? make_int2(rw[c] + rank[c], cnt[c] | (c << 28)) : make_int2(0, 0);
+            rank[c]++;
+        }
+        rw[1] += NA * cnt[1];
+        rw[2] += NA * cnt[2];
+    }
+    const int nb_cols = N1 * rw[1] + (nyq_live ? 1 : 0);
+    const int Lband = ceil_div(nb_cols, TC) * TC, Ltail = N1 * rw[2];
+    const int Lc = std::max(16, ceil_div(Lband + Ltail, 16) * 16);
+    pl->tf_band_cols = nb_cols;
+    pl->tf_tail_cols = Ltail;
+    pl->bytes_tf = 24.0 + 18.0 * (double)Lband / M + 8.0 * (double)Ltail / M;
+    const bool force = ord && !strcmp(ord, "tf");
+    if (!force && !(pl->bytes_tf < 0.97 * pl->bytes_cf)) return D4W_OK;
+    // tables
+    std::vector<float> tgain(M, 0.f);
+    std::vector<int> colsrc((size_t)Lband + 1, -1);
+    for (int q1 = 0; q1 < N1; ++q1)
+        for (int e = 0; e < N2; ++e) {
+            const int d0 = e / (NB * NC), d1 = (e / NC) % NB, d2 = e % NC;
+            const int c = cell[d2 * NB + d1];
+            const size_t p = (size_t)q1 * N2 + e;
+            if (c == 1) {
+                tgain[p] = 1.f;
+                const int2 ct = ctab[d2 * NB + d1];
+                colsrc[(size_t)q1 * rw[1] + ct.x + d0 * (ct.y & 0x0FFFFFFF)] = (int)p;
+            } else if (c == 2)
+                tgain[p] = cgain[p] * (float)d.C2;      // the band columns pick up C2 from the unnormalised c2 forward + inverse of Cm
+
+        }
+    if (nyq_live) colsrc[(size_t)N1 * rw[1]] = -2;
+    D4W_HIP(hipMemcpyAsync(pl->d_tgain, tgain.data(), (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
+    D4W_HIP(hipMemcpyAsync(pl->d_ctab, ctab.data(), ctab.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    if (Lband > 0) D4W_HIP(hipMemcpyAsync(pl->d_colsrc, colsrc.data(), (size_t)Lband * sizeof(int), hipMemcpyHostToDevice, st));
+    const size_t need_m = (size_t)d.nx * std::max(Lband, 1), need_w = (size_t)d.nx * Lc;
+    if (need_m > pl->cap_cmask) {
+        if (pl->d_cmask) (void)hipFree(pl->d_cmask);
+        pl->d_cmask = nullptr; pl->cap_cmask = 0;
+        if (hipMalloc((void**)&pl->d_cmask, need_m * sizeof(float)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte band mask failed", need_m * sizeof(float));
+        pl->cap_cmask = need_m;
+    }
+    if (need_w > pl->cap_W) {
+        if (pl->d_W) (void)hipFree(pl->d_W);
+        pl->d_W = nullptr; pl->cap_W = 0;
+        if (hipMalloc((void**)&pl->d_W, need_w * sizeof(float2)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte compact spectrum failed", need_w * sizeof(float2));
+        pl->cap_W = need_w;
+    }
+    D4W_HIP(hipMemsetAsync(pl->d_W, 0, need_w * sizeof(float2), st));        // padding columns stay finite
+    if (Lband > 0) {
+        if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
+        D4W_LAUNCH(fk_gather_cmask, dim3(std::min(ceil_div(Lband, kThreads), 64), d.nx), dim3(kThreads), 0, stream, d,
+                   (const float*)pl->d_mask, (const float*)pl->d_nyq, (const int*)pl->d_colsrc, Lband, pl->d_cmask);
+    }
+    D4W_HIP(hipStreamSynchronize(st));          // the host tables above are temporaries
+    FkTfDev& T = pl->tfdev;
+    T.tgain = pl->d_tgain; T.ctab = pl->d_ctab; T.cmask = pl->d_cmask; T.W = pl->d_W;
+    T.rb1 = 0; T.rw1 = rw[1]; T.rb2 = Lband; T.rw2 = rw[2];
+    T.col_nyq = nyq_live ? N1 * rw[1] : -1;
+    T.Lc = Lc; T.Lband = Lband;
+    pl->tf = true;
+    return D4W_OK;
+}
+
+// after a fold (d_mask, d_nyq, d_rowmax written on `stream`): liveness of the wavenumber rows, order of the passes
 static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
     const FkDims& d = pl->dev.d;
     hipStream_t st = (hipStream_t)stream;
@@ -1226,12 +1447,13 @@ static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
     pl->live_rows = d.nx;
     pl->fdev.pairs = pl->dev.pairs;
     pl->fdev.live = nullptr;
+    pl->tf = false;
     const char* np = getenv("D4W_FK_NOPRUNE");
     if (pl->fast && !pl->dev.bs_L && !(np && atoi(np) > 0)) {
-        // Dead rows: a wavenumber row whose folded gains (and whose Hermitian partner's) are all zero -- exact -- or,
-        // opt-in, all below prune_eps * max |M_h| (the Butterworth tails of hybrid_ninf_filter_design, dsp.py:348-349,
-        // never reach zero: 7.7e-7 at fmax + 14 Hz; treating them as zero changes the output by at most that gain
-        // times the energy the input holds there)
+        // Dead rows: a wavenumber row whose folded gains (and whose Hermitian partner's) are all zero -- or below the
+        // zero-gain threshold above: rounding level always, prune_eps * max |M_h| opt-in (the Butterworth tails of
+        // hybrid_ninf_filter_design, dsp.py:348-349, never reach zero: 7.7e-7 at fmax + 14 Hz; treating them as zero
+        // changes the output by at most that gain times the spectral content the input holds there)
         std::vector<unsigned> rmax(d.nx);
         D4W_HIP(hipMemcpyAsync(rmax.data(), pl->d_rowmax, (size_t)d.nx * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         D4W_HIP(hipStreamSynchronize(st));
@@ -1239,9 +1461,10 @@ static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
         std::vector<float> rm(d.nx);
         for (int r = 0; r < d.nx; ++r) {
             memcpy(&rm[r], &rmax[r], sizeof(float));
-            if (rm[r] == rm[r] && rm[r] > gmax) gmax = rm[r];
+            if (rm[r] == rm[r] && !std::isinf(rm[r]) && rm[r] > gmax) gmax = rm[r];
         }
-        const float thr = (float)(prune_eps * (double)gmax);
+        const double zero_gain = fk_zero_gain(d, prune_eps, gmax);
+        const float thr = (float)zero_gain;
         std::vector<int> live(d.nx);
         for (int r = 0; r < d.nx; ++r) live[r] = !(rm[r] <= thr);             // NaN rows stay alive
         const int N1 = d.N1;
@@ -1274,7 +1497,23 @@ static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
             pl->npairs_run = (int)run.size();
             pl->live_rows = nlive;
         }
+        if (pl->fast->Bt_fwd && pl->d_colkeys) {
+            int rc = fk_tf_setup(pl, zero_gain, stream);
+            if (rc != D4W_OK) return rc;
+        }
     }
+    return D4W_OK;
+}
+
+/* Order and modelled traffic of the passes for the current mask: info[0] = 1 time-first / 0 channel-first,
+ * info[1] = band columns kept per row (incl. the Nyquist column), info[2] = tail columns, info[3] = ns / 2,
+ * info[4] = live wavenumber rows, info[5] = nx; bytes[0], bytes[1] = modelled bytes per channel-sample of the
+ * channel-first and of the time-first order. */
+int d4w_fk_plan_order(const d4w_fk_plan* pl, int* info6, double* bytes2) {
+    if (!pl || !info6 || !bytes2) return fail(D4W_EINVAL, "NULL argument");
+    info6[0] = pl->tf ? 1 : 0; info6[1] = pl->tf_band_cols; info6[2] = pl->tf_tail_cols; info6[3] = pl->dev.d.M;
+    info6[4] = pl->live_rows; info6[5] = pl->dev.d.nx;
+    bytes2[0] = pl->bytes_cf; bytes2[1] = pl->bytes_tf;
     return D4W_OK;
 }
 
@@ -1391,6 +1630,28 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
                 } else if ((rc = launch_k(F.A_inv, gsA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, nA, sw, sl * sw, FkGeo(), (const float2*)nullptr))) return rc;
             }
             D4W_MARK(4);
+            D4W_MARK(5);
+            return D4W_OK;
+        }
+        if (pl->tf) {
+            // time-first order (fk_tf.h): A, Bf (-> W), Cm (on W), Bi (W ->), A'
+            const FkTfDev& T = pl->tfdev;
+            const int ntCm = (T.Lband / d.TC) * d.C1;
+            const dim3 gBt(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgB))), gCm(std::max(1, std::min(ntCm, pl->num_cu * pl->wgC)));
+            D4W_MARK(0);
+            if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0, FkGeo()))) return rc;
+            D4W_MARK(1);
+            if ((rc = launch_k(F.Bt_fwd, gBt, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
+            D4W_MARK(2);
+            if (ntCm > 0 && (rc = launch_k(F.C_mid, gCm, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, T, 0, ntCm))) return rc;
+            D4W_MARK(3);
+            if ((rc = launch_k(F.Bt_inv, gBt, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
+            D4W_MARK(4);
+            if (row_mean) {
+                const int run = stats_run(NBX), nruns = fA / run;
+                if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
+                                   dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0, FkGeo(), (const float2*)nullptr, 0))) return rc;
+            } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0, FkGeo(), (const float2*)nullptr))) return rc;
             D4W_MARK(5);
             return D4W_OK;
         }

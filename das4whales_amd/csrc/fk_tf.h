@@ -1,0 +1,441 @@
+// TIME-FIRST order of the shape-specialised f-k passes.
+//
+// The c2 (channel) and n2 (time) sub-transforms commute, so the five passes of fk_fast.h can also run as
+//     A (c1, n1)  ->  Bf (n2 forward + real-spectrum untangle)  ->  Cm (c2 forward x mask x c2 inverse)  ->  Bi  ->  A'
+// with the HALF SPECTRUM COMPACTED between Bf and Bi: Bf writes only the frequency columns the mask needs into the
+// workspace W [nx][Lc]; Cm runs on the columns whose gain depends on the wavenumber ("band" columns); columns whose gain
+// is the same for every wavenumber ("tail" columns -- the Butterworth skirts hybrid_ninf_filter_design leaves outside its
+// looped columns, dsp.py:348-360) are scaled by Bf and skip the channel transform altogether; columns whose gain is zero
+// are never written.  Bytes per channel-sample: 24 + 18 f_band + 8 f_tail, against 24 + 18 f_live_rows in channel-first
+// order (42 when nothing is dead) -- the planner picks the order per mask (fk_filter.hip, fk_mask_finish).
+//
+// Frequencies come in CELLS of NA consecutive n2 frequencies: k2 = d0 + NA (d1 + NB d2), d0 < NA, cell (d2, d1) -- exactly
+// the digits the MID item of pass B holds (thread Gi = d0 NB + d1 owns digit d2 = 0 .. NC-1 of group Gi).  A cell is band,
+// tail or dead for all N1 sub-rows alike.  Compact column of (q1, d0, d1, d2), R = region of the cell:
+//     rb[R] + q1 rw[R] + ctab[d2][d1].x + d0 cnt,      cnt = cells of region R in digit d2
+// so the lanes of a wave (consecutive Gi) write consecutive columns.  The Nyquist column f = M is col_nyq.
+//
+// Before the c2 transform the Hermitian partner of row (q, c2) is the row (q', c2) with kc1(q') = -kc1(q); as sequences
+// in time  row_B = omega conj(row_A),  omega = twc[rA] twc[rB]  (the four-step twiddles W_nx^(c2 kc1) the two rows carry):
+// one wave-uniform factor per pair in the untangle / re-tangle algebra of fkf_passB.
+#pragma once
+#include "fk_fast.h"
+
+namespace d4w {
+
+struct FkTfDev {
+    const int2* pairs;     // work list of passes Bf / Bi: (keyA, keyB), key = row * N1 + q1
+    const float* tgain;    // [N1 pos q1][N2 pos e]: 1 band, the wavenumber-independent gain of a tail column, 0 dead
+    const int2* ctab;      // [NC][NB] {x = offset of the cell inside its sub-row block, y = cnt | region << 28}
+    const float* cmask;    // [nx pos r][Lband] folded mask of the band columns (incl. the Nyquist column)
+    float2* W;             // [nx][Lc] compact half spectrum
+    int rb1, rw1, rb2, rw2;   // region 1 = band, 2 = tail: first column, columns per sub-row
+    int col_nyq;           // column of f = M, -1: dead
+    int Lc, Lband;         // row pitch of W, band columns (a multiple of TC)
+};
+
+// PHASE 1 = Bf: n2 forward of a sub-row pair, untangle, x tail gain -> W.
+// PHASE 2 = Bi: W -> re-tangle, n2 inverse of the pair -> data.
+// Stages, LDS layout and special cases (a row that is its own partner, the k1 = 0 sub-row, the (0, Nyquist) pair) are
+// those of fkf_passB, whose MID step this kernel cuts in two.
+template <class G, int PHASE>
+__global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFastDev F, FkTfDev T, float2* __restrict__ data,
+                                                                  int tbase, int npairs) {
+    D4W_DYN_LDS(smem_raw);
+    constexpr int N2 = G::N2, NA = G::NA, NB = G::NB, NC = G::NC, M1 = NB * NC, NG = NA * NB, ROWP = G::ROWP;
+    constexpr int THR = G::THRB;
+    float2* rows = reinterpret_cast<float2*>(smem_raw);
+    float2* tw1 = rows + 2 * ROWP;          // [M1]      W_N2^j
+    float2* tw2 = tw1 + M1;                 // [NB][NC]  W_M1^(j2 b)
+    int2* ctab = reinterpret_cast<int2*>(tw2 + M1);     // [NC][NB]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < M1; i += THR) {
+        tw1[i] = F.twB1[i];
+        tw2[i] = F.twB2[i];
+    }
+    for (int i = tid; i < NC * NB; i += THR) ctab[i] = T.ctab[i];
+    __syncthreads();
+    auto ad = [](int e) { return e + e / NC; };
+    // compact column of frequency (q1; d0, d1, d2), -1: not kept
+    auto colof = [&](int q1, int dd0, int dd1, int dd2) -> int {
+        const int2 c = ctab[dd2 * NB + dd1];
+        const int reg = c.y >> 28;
+        const int cnt = c.y & 0x0FFFFFFF;
+        const int base = (reg == 1) ? T.rb1 + q1 * T.rw1 : T.rb2 + q1 * T.rw2;
+        return reg ? base + c.x + dd0 * cnt : -1;
+    };
+
+    const int r1 = tid / M1, j1 = tid % M1;              // S1 / S1' item
+    const bool it1 = tid < 2 * M1;
+    const int Gi = tid;                                  // MID item
+    const bool midrange = Gi < NG;
+    const int d0 = Gi / NB, d1 = Gi % NB;
+    int PGz = 0;
+    float2 wc[NC];
+    if (midrange) {
+        PGz = P.mirror0[Gi * NC] / NC;
+        const float2* wcp = P.wcol + Gi * NC;
+        static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; wc[d] = wcp[d]; });
+    }
+    int t = tbase + blockIdx.x;
+    const int gstep = gridDim.x;
+    int2 pr_cur = make_int2(0, 0), pr_nxt = make_int2(0, 0);
+    if (t < npairs) pr_cur = T.pairs[t];
+    if (t + gstep < npairs) pr_nxt = T.pairs[t + gstep];
+
+    if constexpr (PHASE == 1) {
+        float2 pf[NA];
+        auto issue = [&](int2 pr) {
+            if (it1 && (r1 == 0 || pr.x != pr.y)) {
+                const float2* p = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    pf[a] = p[a * M1];
+                });
+            }
+        };
+        struct MidOps {
+            float ma[NC], mbr[NC];
+            float2 wr, om;
+        };
+        MidOps cur, nxt;
+        auto issue_mid = [&](MidOps& O, int2 pr) {
+            if (!midrange) return;
+            const int rA = pr.x / G::N1, q1A = pr.x - rA * G::N1;
+            const int rB = pr.y / G::N1, q1B = pr.y - rB * G::N1;
+            const int PG = (q1A == 0) ? PGz : (NG - 1 - Gi);
+            const float* mA = T.tgain + (size_t)q1A * N2 + Gi * NC;
+            const float* mB = T.tgain + (size_t)q1B * N2 + PG * NC;
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                O.ma[d] = mA[d];
+                O.mbr[d] = mB[d];
+            });
+            O.wr = P.wrow[q1A];
+            O.om = c_mul(P.twc[rA], P.twc[rB]);
+        };
+        if (t < npairs) {
+            issue_mid(cur, pr_cur);
+            issue(pr_cur);
+        }
+        for (; t < npairs; t += gstep) {
+            const int2 pr = pr_cur;
+            int2 pr_nn = pr_cur;
+            if (t + 2 * gstep < npairs) pr_nn = T.pairs[t + 2 * gstep];
+            const bool same = (pr.x == pr.y);
+            const int nrows = same ? 1 : 2;
+            const int rA = pr.x / G::N1, q1A = pr.x - rA * G::N1;
+            const int rB = pr.y / G::N1, q1B = pr.y - rB * G::N1;
+            const bool k1zero = (q1A == 0);
+            // ---------------- S1
+            if (it1 && r1 < nrows) {
+                dft<NA>(pf);
+                float2 pw[NA];
+                pw_tree<NA>(tw1[j1], pw);
+                float2* row = rows + r1 * ROWP;
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    row[ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+                });
+            }
+            lds_barrier();
+            if (t + gstep < npairs) issue(pr_nxt);
+            // ---------------- S2 (in place)
+            for (int it = tid; it < nrows * NA * NC; it += THR) {
+                const int r = it / (NA * NC), rem = it - r * (NA * NC);
+                const int g = rem / NC, j2 = rem - g * NC;
+                float2* row = rows + r * ROWP;
+                float2 v[NB];
+                static_for<NB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    v[b] = row[ad(g * M1 + j2 + b * NC)];
+                });
+                dft<NB>(v);
+                static_for<NB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    row[ad(g * M1 + j2 + b * NC)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
+                });
+            }
+            lds_barrier();
+            // ---------------- MID, first half: radix NC, untangle, x gain -> W
+            const int PG = k1zero ? PGz : (NG - 1 - Gi);
+            if (midrange && (!same || PG >= Gi)) {
+                const bool selfg = same && (PG == Gi);
+                const bool rev0 = k1zero && (Gi == 0);
+                const float2* ga = rows + ad(Gi * NC);
+                const float2* gb = rows + (same ? 0 : ROWP) + ad(PG * NC);
+                float2 a[NC], b[NC];
+                static_for<NC>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    a[d] = ga[d];
+                    b[d] = gb[d];
+                });
+                dft<NC>(a);
+                dft<NC>(b);
+                const float2 om = cur.om, wr = cur.wr;
+                float2* WA = T.W + (size_t)rA * T.Lc;
+                float2* WB = T.W + (size_t)rB * T.Lc;
+                const int pd0 = PG / NB, pd1 = PG - pd0 * NB;
+                static_for<NC>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    constexpr int pn = NC - 1 - d, pz = (NC - d) % NC;
+                    const float2 bs = rev0 ? b[pz] : b[pn];
+                    const float gB = rev0 ? cur.mbr[pz] : cur.mbr[pn];
+                    const float2 Bc = c_mul(om, c_conj(bs));
+                    const float2 w = c_mul(wr, wc[d]);
+                    const float2 E = c_scale(c_add(a[d], Bc), 0.5f);
+                    const float2 O = c_mul_mi(c_scale(c_sub(a[d], Bc), 0.5f));
+                    const float2 tO = c_mul(w, O);
+                    const float2 Yp = c_add(E, tO);              // X_A[f],      f = k1 + N1 k2(Gi, d)
+                    const float2 Ym = c_sub(E, tO);              // X_A[f - M];  X_B[M - f] = omega conj(Ym)
+                    const int colA = colof(q1A, d0, d1, d);
+                    if (colA >= 0) WA[colA] = c_scale(Yp, cur.ma[d]);
+                    if (d == 0 && rev0) {                        // f = 0 and the Nyquist column of row A (and of row B)
+                        if (T.col_nyq >= 0) WA[T.col_nyq] = Ym;
+                        if (!same) {
+                            if (colA >= 0) WB[colA] = c_scale(c_mul(om, c_conj(Yp)), cur.ma[d]);
+                            if (T.col_nyq >= 0) WB[T.col_nyq] = c_mul(om, c_conj(Ym));
+                        }
+                    } else if (!selfg) {
+                        const int colB = colof(q1B, pd0, pd1, rev0 ? pz : pn);
+                        if (colB >= 0) WB[colB] = c_scale(c_mul(om, c_conj(Ym)), gB);
+                    }
+                });
+            }
+            if (t + gstep < npairs) issue_mid(nxt, pr_nxt);
+            lds_barrier();
+            pr_cur = pr_nxt;
+            pr_nxt = pr_nn;
+            cur = nxt;
+        }
+    } else {
+        // ---------------------------------------------------------------- PHASE 2
+        float2 Wp[NC], Wm[NC];
+        float2 wr_n = make_float2(1.f, 0.f), om_n = make_float2(1.f, 0.f);
+        auto issue_w = [&](int2 pr) {
+            if (!midrange) return;
+            const int rA = pr.x / G::N1, q1A = pr.x - rA * G::N1;
+            const int rB = pr.y / G::N1, q1B = pr.y - rB * G::N1;
+            const bool k1z = (q1A == 0);
+            const int PG = k1z ? PGz : (NG - 1 - Gi);
+            const bool rev0 = k1z && (Gi == 0);
+            const float2* WA = T.W + (size_t)rA * T.Lc;
+            const float2* WB = T.W + (size_t)rB * T.Lc;
+            const int pd0 = PG / NB, pd1 = PG - pd0 * NB;
+            static_for<NC>([&](auto dd) {
+                constexpr int d = decltype(dd)::value;
+                constexpr int pn = NC - 1 - d, pz = (NC - d) % NC;
+                const int colA = colof(q1A, d0, d1, d);
+                Wp[d] = (colA >= 0) ? WA[colA] : make_float2(0.f, 0.f);
+                if (d == 0 && rev0) {
+                    Wm[d] = (T.col_nyq >= 0) ? WA[T.col_nyq] : make_float2(0.f, 0.f);      // Y_A[M] itself
+                } else {
+                    const int colB = colof(q1B, pd0, pd1, rev0 ? pz : pn);
+                    Wm[d] = (colB >= 0) ? WB[colB] : make_float2(0.f, 0.f);
+                }
+            });
+            wr_n = P.wrow[q1A];
+            om_n = c_mul(P.twc[rA], P.twc[rB]);
+        };
+        if (t < npairs) issue_w(pr_cur);
+        for (; t < npairs; t += gstep) {
+            const int2 pr = pr_cur;
+            int2 pr_nn = pr_cur;
+            if (t + 2 * gstep < npairs) pr_nn = T.pairs[t + 2 * gstep];
+            const bool same = (pr.x == pr.y);
+            const int nrows = same ? 1 : 2;
+            const bool k1zero = (pr.x % G::N1 == 0);
+            const int PG = k1zero ? PGz : (NG - 1 - Gi);
+            // ---------------- MID, second half: re-tangle, inverse radix NC -> LDS
+            if (midrange && (!same || PG >= Gi)) {
+                const bool selfg = same && (PG == Gi);
+                const bool rev0 = k1zero && (Gi == 0);
+                float2* ga = rows + ad(Gi * NC);
+                float2* gb = rows + (same ? 0 : ROWP) + ad(PG * NC);
+                const float2 om = om_n, wr = wr_n;
+                float2 a[NC], b[NC], na[NC], nb[NC];
+                static_for<NC>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    const float2 Yp = Wp[d];
+                    const float2 Ym = (d == 0 && rev0) ? Wm[d] : c_mul(om, c_conj(Wm[d]));
+                    const float2 w = c_mul(wr, wc[d]);
+                    const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
+                    const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
+                    na[d] = c_add(S, D);
+                    nb[d] = c_mul(om, c_conj(c_sub(S, D)));
+                });
+                if (!selfg) {
+                    static_for<NC>([&](auto dd) {                 // un-permute the partner results
+                        constexpr int e = decltype(dd)::value;
+                        constexpr int pn = NC - 1 - e, pz = (NC - e) % NC;
+                        a[e] = na[e];
+                        b[e] = rev0 ? nb[pz] : nb[pn];
+                    });
+                    idft<NC>(a);
+                    idft<NC>(b);
+                    static_for<NC>([&](auto dd) {
+                        constexpr int d = decltype(dd)::value;
+                        ga[d] = a[d];
+                        gb[d] = b[d];
+                    });
+                } else {
+                    static_for<NC>([&](auto dd) {
+                        constexpr int e = decltype(dd)::value;
+                        constexpr int pn = NC - 1 - e, pz = (NC - e) % NC;
+                        const float2 vn = (e < pn) ? na[e] : nb[pn];
+                        const float2 vz = (e < pz) ? na[e] : nb[pz];
+                        a[e] = rev0 ? vz : vn;
+                    });
+                    idft<NC>(a);
+                    static_for<NC>([&](auto dd) {
+                        constexpr int d = decltype(dd)::value;
+                        ga[d] = a[d];
+                    });
+                }
+            }
+            lds_barrier();
+            if (t + gstep < npairs) issue_w(pr_nxt);          // next pair's spectrum, ahead of this pair's stores
+            // ---------------- S2'
+            for (int it = tid; it < nrows * NA * NC; it += THR) {
+                const int r = it / (NA * NC), rem = it - r * (NA * NC);
+                const int g = rem / NC, j2 = rem - g * NC;
+                float2* row = rows + r * ROWP;
+                float2 v[NB];
+                static_for<NB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    const float2 x = row[ad(g * M1 + j2 + b * NC)];
+                    v[b] = (b == 0) ? x : c_mulc(x, tw2[b * NC + j2]);
+                });
+                idft<NB>(v);
+                static_for<NB>([&](auto bb) {
+                    constexpr int b = decltype(bb)::value;
+                    row[ad(g * M1 + j2 + b * NC)] = v[b];
+                });
+            }
+            lds_barrier();
+            // ---------------- S1' -> global
+            if (it1 && r1 < nrows) {
+                float2 v[NA], pw[NA];
+                pw_tree<NA>(tw1[j1], pw);
+                const float2* row = rows + r1 * ROWP;
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const float2 x = row[ad(j1 + a * M1)];
+                    v[a] = (a == 0) ? x : c_mulc(x, pw[a]);
+                });
+                idft<NA>(v);
+                float2* o = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    o[a * M1] = v[a];
+                });
+            }
+            lds_barrier();
+            pr_cur = pr_nxt;
+            pr_nxt = pr_nn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass Cm: c2 forward, x folded mask, c2 inverse of TC contiguous BAND columns of W for one c1-position q, in one visit
+// (passes C and C' of the channel-first order fused; the radix-RB item multiplies its own outputs and transforms them
+// back, so the tile needs two barriers instead of four).  Tile layout and twiddles as fkf_passC.
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(G::THRC) void fkf_passCm(FkDev P, FkFastDev F, FkTfDev T, int tbase, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = tile + G::C2A * (G::C2B + 1) * G::TC;
+    constexpr int RA = G::C2A, RB = G::C2B, TC = G::TC;
+    const int tid = threadIdx.x;
+    const int hi = tid / TC, tt = tid % TC;            // hi = j (radix-RA items) or g (radix-RB items)
+    const bool actA = hi < RB;                         // items of the radix-RA steps
+    const bool actB = hi < RA;                         // items of the radix-RB step
+    for (int i = tid; i < (G::CTREE ? RB : RA * RB); i += G::THRC) twl[i] = F.twC[(G::CTREE ? RB : 0) + i];
+    __syncthreads();
+    const int nblk = T.Lband / TC;
+    const size_t LC = (size_t)T.Lc, LB = (size_t)T.Lband;
+    float2 pfA[RA], pfB[RA];
+    float mk[RB];
+    auto issue = [&](float2 (&pf)[RA], int t) {
+        const int q = t / nblk, p0 = (t - q * nblk) * TC;
+        const float2* bh = T.W + ((size_t)q * G::C2 + hi) * LC + p0 + tt;
+        static_for<RA>([&](auto aa) {
+            constexpr int a = decltype(aa)::value;
+            pf[a] = bh[(size_t)(a * RB) * LC];
+        });
+    };
+    auto issue_mask = [&](int t) {
+        const int q = t / nblk, p0 = (t - q * nblk) * TC;
+        const float* mp = T.cmask + ((size_t)q * G::C2 + (size_t)hi * RB) * LB + p0 + tt;
+        static_for<RB>([&](auto bb) {
+            constexpr int b = decltype(bb)::value;
+            mk[b] = mp[(size_t)b * LB];
+        });
+    };
+    const int gstep = gridDim.x;
+    auto body = [&](float2 (&pf)[RA], int t) {
+        const int q = t / nblk, p0 = (t - q * nblk) * TC;
+        float2* bh = T.W + ((size_t)q * G::C2 + hi) * LC + p0 + tt;
+        if (actA) {
+            dft<RA>(pf);
+            float2 pw[RA];
+            if constexpr (G::CTREE) pw_tree<RA>(twl[hi], pw);
+            static_for<RA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                const float2 w = G::CTREE ? pw[a] : twl[a * RB + hi];
+                tile[(hi + a * (RB + 1)) * TC + tt] = (a == 0) ? pf[0] : c_mul(pf[a], w);
+            });
+        }
+        lds_barrier();
+        if (t + 2 * gstep < ntiles && actA) issue(pf, t + 2 * gstep);     // pf is free: S1 consumed it
+        if (actB) {
+            float2 v[RB];
+            static_for<RB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                v[b] = tile[(hi * (RB + 1) + b) * TC + tt];
+            });
+            dft<RB>(v);
+            static_for<RB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                v[b] = c_scale(v[b], mk[b]);
+            });
+            idft<RB>(v);
+            static_for<RB>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                tile[(hi * (RB + 1) + b) * TC + tt] = v[b];
+            });
+            if (t + gstep < ntiles) issue_mask(t + gstep);                // mk is free; ahead of this tile's stores
+        }
+        lds_barrier();
+        if (actA) {
+            float2 v[RA];
+            static_for<RA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                v[a] = tile[(hi + a * (RB + 1)) * TC + tt];
+            });
+            float2 pw[RA];
+            if constexpr (G::CTREE) pw_tree<RA>(twl[hi], pw);
+            static_for<RA - 1>([&](auto aa) {
+                constexpr int a = decltype(aa)::value + 1;
+                v[a] = c_mulc(v[a], G::CTREE ? pw[a] : twl[a * RB + hi]);
+            });
+            idft<RA>(v);
+            static_for<RA>([&](auto aa) {
+                constexpr int a = decltype(aa)::value;
+                bh[(size_t)(a * RB) * LC] = v[a];
+            });
+        }
+    };
+    int t = tbase + blockIdx.x;
+    if (t < ntiles && actA) issue(pfA, t);
+    if (t + gstep < ntiles && actA) issue(pfB, t + gstep);
+    if (t < ntiles && actB) issue_mask(t);
+    for (; t < ntiles; t += 2 * gstep) {
+        body(pfA, t);
+        if (t + gstep < ntiles) body(pfB, t + gstep);
+    }
+}
+
+}  // namespace d4w

@@ -42,6 +42,16 @@ class FkPlan:
         """Wavenumber rows the current mask keeps alive (nx = nothing is skipped), include/d4w.h."""
         return int(lib.d4w_fk_plan_live_rows(self._h))
 
+    def order(self):
+        """Order of the passes for the current mask and the modelled traffic of both orders (include/d4w.h
+        d4w_fk_plan_order): time-first (half spectrum compacted to the frequency columns the mask needs) or
+        channel-first (dead wavenumber rows skipped)."""
+        v, b = (ctypes.c_int * 6)(), (ctypes.c_double * 2)()
+        check(lib.d4w_fk_plan_order(self._h, v, b))
+        return {"order": "time-first" if v[0] else "channel-first", "band_columns": v[1], "tail_columns": v[2],
+                "half_spectrum_columns": v[3], "live_wavenumber_rows": v[4], "nx": v[5],
+                "model_bytes_per_sample": {"channel-first": b[0], "time-first": b[1]}}
+
     def set_mask(self, fk_filter_matrix, prune_eps=0.0):
         """Dense ndarray (any order / float dtype), sparse.COO-like (.todense()) or CUDA tensor,
         on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return.

@@ -96,6 +96,19 @@ int d4w_fk_set_mask_design_f32(d4w_fk_plan* plan, int mode, double k_spacing, do
  * that runs the generic kernels).  D4W_FK_NOPRUNE=1 in the environment disables the skipping. */
 int d4w_fk_plan_live_rows(const d4w_fk_plan* plan);
 
+/* Order of the five passes for the current mask (shape-specialised kernels).  The c2 and n2 sub-transforms commute, so
+ * besides the channel-first order A, C, B, C', A' (which skips dead WAVENUMBER rows) the filter can run time-first:
+ * A, Bf, Cm, Bi, A' with the half spectrum compacted between Bf and Bi -- frequency columns whose folded gain is zero are
+ * never written, columns whose gain is the same for every wavenumber (the Butterworth skirts hybrid_ninf_filter_design
+ * keeps outside its looped columns, dsp.py:348-360) are scaled in Bf and skip the channel transform, the others go
+ * through Cm (c2 forward x mask x c2 inverse in one visit).  Exact like the channel-first order: both treat as zero only
+ * gains below max(prune_eps, 2^-24 / sqrt(nx ns)) * max|M_h| -- at prune_eps = 0 at most half a float32 ulp of the
+ * input's RMS in any output sample (D4W_FK_ROUND_EPS=0: exact zeros only).  The plan picks the order that moves fewer
+ * bytes (D4W_FK_ORDER=cf|tf forces one).  info6 = {1 time-first / 0 channel-first, band columns kept per row, tail
+ * columns kept per row, ns / 2, live wavenumber rows, nx}; bytes2 = modelled bytes per channel-sample {channel-first,
+ * time-first}. */
+int d4w_fk_plan_order(const d4w_fk_plan* plan, int* info6_host, double* bytes2_host);
+
 /* x -> y (may alias).  taper != 0 multiplies x by tukey(ns, 0.03) first (dsp.taper_data,
  * dsp.py:705-722, fused into the first pass; x itself is not modified). */
 int d4w_fk_apply_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, void* stream);
