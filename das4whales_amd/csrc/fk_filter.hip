@@ -736,10 +736,10 @@ struct d4w_fk_plan {
     unsigned* d_colkeys = nullptr;         // [2][M] min / max keys of the mask columns
     float* d_tgain = nullptr;              // [M]
     int2* d_ctab = nullptr;                // [NC][NB]
-    int* d_colsrc = nullptr;               // [M + TC] gather table of the band columns
-    float* d_cmask = nullptr;              // [nx][Lband]   (capacity cap_cmask floats)
-    float2* d_W = nullptr;                 // [nx][Lc]      (capacity cap_W elements)
-    size_t cap_cmask = 0, cap_W = 0;
+    int* d_colsrc = nullptr;               // [Lc] gather table: mask position of every column of W (-1 none, -2 Nyquist)
+    float* d_cmask = nullptr;              // [nx][Lc] folded mask at the band columns
+    float2* d_W = nullptr;                 // [nx][Lc] compact half spectrum (capacity cap_W elements, shared by the three)
+    size_t cap_W = 0;
     int tf_band_cols = 0, tf_tail_cols = 0;   // per row: band (incl. Nyquist) and tail columns kept
     double bytes_cf = 42.0, bytes_tf = 42.0;  // modelled bytes per channel-sample of the two orders for the current mask
 };
@@ -832,6 +832,7 @@ int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
     for (void* p : pl->allocs) (void)hipFree(p);
     if (pl->d_cmask) (void)hipFree(pl->d_cmask);
     if (pl->d_W) (void)hipFree(pl->d_W);
+    if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
     delete pl;
     return D4W_OK;
 }
@@ -1120,8 +1121,6 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         pl->allocs.push_back(q); pl->d_tgain = (float*)q;
         if (hipMalloc(&q, nctab * sizeof(int2)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
         pl->allocs.push_back(q); pl->d_ctab = (int2*)q;
-        if (hipMalloc(&q, ((size_t)M + 64) * sizeof(int)) != hipSuccess) { d4w_fk_plan_destroy(pl); return fail(D4W_ENOMEM, "hipMalloc failed"); }
-        pl->allocs.push_back(q); pl->d_colsrc = (int*)q;
     }
     D4W_TRY(upload(pl, rowpart, &pl->dev.row_partner));
     D4W_TRY(upload(pl, q1part, &pl->dev.q1_partner));
@@ -1366,31 +1365,35 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
             if (c == 1) cc = 1;
             else if (cc == 0) cc = 2;
         }
+    // layout of a row of W: N1 sub-row blocks of RW columns, [band cells (bw, a multiple of TC) | tail cells] each, then one
+    // strip for the Nyquist column
     std::vector<int2> ctab(NC * NB);
-    int rw[3] = {0, 0, 0};
+    int rw[3] = {0, 0, 0}, ncell[3] = {0, 0, 0};
+    for (int c : cell) ncell[c]++;
+    const int bw = ceil_div(NA * ncell[1], TC) * TC;
     for (int d2 = 0; d2 < NC; ++d2) {
         int cnt[3] = {0, 0, 0};
         for (int d1 = 0; d1 < NB; ++d1) cnt[cell[d2 * NB + d1]]++;
         int rank[3] = {0, 0, 0};
         for (int d1 = 0; d1 < NB; ++d1) {
             const int c = cell[d2 * NB + d1];
-            ctab[d2 * NB + d1] = c ? make_int2(rw[c] + rank[c], cnt[c] | (c << 28)) : make_int2(0, 0);
+            ctab[d2 * NB + d1] = c ? make_int2((c == 2 ? bw : 0) + rw[c] + rank[c], cnt[c] | (c << 28)) : make_int2(0, 0);
             rank[c]++;
         }
         rw[1] += NA * cnt[1];
         rw[2] += NA * cnt[2];
     }
-    const int nb_cols = N1 * rw[1] + (nyq_live ? 1 : 0);
-    const int Lband = ceil_div(nb_cols, TC) * TC, Ltail = N1 * rw[2];
-    const int Lc = std::max(16, ceil_div(Lband + Ltail, 16) * 16);
-    pl->tf_band_cols = nb_cols;
-    pl->tf_tail_cols = Ltail;
-    pl->bytes_tf = 24.0 + 18.0 * (double)Lband / M + 8.0 * (double)Ltail / M;
+    const int RW = std::max(TC, ceil_div(bw + rw[2], TC) * TC);
+    const int Lc = ceil_div(N1 * RW + (nyq_live ? TC : 0), 16) * 16;
+    pl->tf_band_cols = N1 * rw[1] + (nyq_live ? 1 : 0);
+    pl->tf_tail_cols = N1 * rw[2];
+    pl->bytes_tf = 24.0 + 18.0 * (double)(N1 * bw + (nyq_live ? TC : 0)) / M + 8.0 * (double)(N1 * rw[2]) / M;
     const bool force = ord && !strcmp(ord, "tf");
     if (!force && !(pl->bytes_tf < 0.97 * pl->bytes_cf)) return D4W_OK;
+    if ((size_t)Lc * sizeof(float2) >= ((size_t)1 << 31)) return D4W_OK;      // 32-bit column offsets inside a row
     // tables
     std::vector<float> tgain(M, 0.f);
-    std::vector<int> colsrc((size_t)Lband + 1, -1);
+    std::vector<int> colsrc((size_t)Lc, -1);
     for (int q1 = 0; q1 < N1; ++q1)
         for (int e = 0; e < N2; ++e) {
             const int d0 = e / (NB * NC), d1 = (e / NC) % NB, d2 = e % NC;
@@ -1399,40 +1402,35 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
             if (c == 1) {
                 tgain[p] = 1.f;
                 const int2 ct = ctab[d2 * NB + d1];
-                colsrc[(size_t)q1 * rw[1] + ct.x + d0 * (ct.y & 0x0FFFFFFF)] = (int)p;
+                colsrc[(size_t)q1 * RW + ct.x + d0 * (ct.y & 0x0FFFFFFF)] = (int)p;
             } else if (c == 2)
                 tgain[p] = cgain[p] * (float)d.C2;      // the band columns pick up C2 from the unnormalised c2 forward + inverse of Cm
-
         }
-    if (nyq_live) colsrc[(size_t)N1 * rw[1]] = -2;
+    if (nyq_live) colsrc[(size_t)N1 * RW] = -2;
+    const size_t need = (size_t)d.nx * Lc;
+    if (need > pl->cap_W) {
+        if (pl->d_W) (void)hipFree(pl->d_W);
+        if (pl->d_cmask) (void)hipFree(pl->d_cmask);
+        if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
+        pl->d_W = nullptr; pl->d_cmask = nullptr; pl->d_colsrc = nullptr; pl->cap_W = 0;
+        if (hipMalloc((void**)&pl->d_W, need * sizeof(float2)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte compact spectrum failed", need * sizeof(float2));
+        if (hipMalloc((void**)&pl->d_cmask, need * sizeof(float)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte band mask failed", need * sizeof(float));
+        if (hipMalloc((void**)&pl->d_colsrc, ((size_t)M + 64 * (size_t)N1 + 64) * sizeof(int)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc failed");
+        pl->cap_W = need;
+    }
     D4W_HIP(hipMemcpyAsync(pl->d_tgain, tgain.data(), (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
     D4W_HIP(hipMemcpyAsync(pl->d_ctab, ctab.data(), ctab.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-    if (Lband > 0) D4W_HIP(hipMemcpyAsync(pl->d_colsrc, colsrc.data(), (size_t)Lband * sizeof(int), hipMemcpyHostToDevice, st));
-    const size_t need_m = (size_t)d.nx * std::max(Lband, 1), need_w = (size_t)d.nx * Lc;
-    if (need_m > pl->cap_cmask) {
-        if (pl->d_cmask) (void)hipFree(pl->d_cmask);
-        pl->d_cmask = nullptr; pl->cap_cmask = 0;
-        if (hipMalloc((void**)&pl->d_cmask, need_m * sizeof(float)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte band mask failed", need_m * sizeof(float));
-        pl->cap_cmask = need_m;
-    }
-    if (need_w > pl->cap_W) {
-        if (pl->d_W) (void)hipFree(pl->d_W);
-        pl->d_W = nullptr; pl->cap_W = 0;
-        if (hipMalloc((void**)&pl->d_W, need_w * sizeof(float2)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte compact spectrum failed", need_w * sizeof(float2));
-        pl->cap_W = need_w;
-    }
-    D4W_HIP(hipMemsetAsync(pl->d_W, 0, need_w * sizeof(float2), st));        // padding columns stay finite
-    if (Lband > 0) {
-        if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
-        D4W_LAUNCH(fk_gather_cmask, dim3(std::min(ceil_div(Lband, kThreads), 64), d.nx), dim3(kThreads), 0, stream, d,
-                   (const float*)pl->d_mask, (const float*)pl->d_nyq, (const int*)pl->d_colsrc, Lband, pl->d_cmask);
-    }
+    D4W_HIP(hipMemcpyAsync(pl->d_colsrc, colsrc.data(), (size_t)Lc * sizeof(int), hipMemcpyHostToDevice, st));
+    D4W_HIP(hipMemsetAsync(pl->d_W, 0, need * sizeof(float2), st));        // padding columns stay finite
+    if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
+    D4W_LAUNCH(fk_gather_cmask, dim3(std::min(ceil_div(Lc, kThreads), 64), d.nx), dim3(kThreads), 0, stream, d,
+               (const float*)pl->d_mask, (const float*)pl->d_nyq, (const int*)pl->d_colsrc, Lc, pl->d_cmask);
     D4W_HIP(hipStreamSynchronize(st));          // the host tables above are temporaries
     FkTfDev& T = pl->tfdev;
     T.tgain = pl->d_tgain; T.ctab = pl->d_ctab; T.cmask = pl->d_cmask; T.W = pl->d_W;
-    T.rb1 = 0; T.rw1 = rw[1]; T.rb2 = Lband; T.rw2 = rw[2];
-    T.col_nyq = nyq_live ? N1 * rw[1] : -1;
-    T.Lc = Lc; T.Lband = Lband;
+    T.RW = RW; T.bw = bw;
+    T.col_nyq = nyq_live ? N1 * RW : -1;
+    T.Lc = Lc;
     pl->tf = true;
     return D4W_OK;
 }
@@ -1636,7 +1634,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
         if (pl->tf) {
             // time-first order (fk_tf.h): A, Bf (-> W), Cm (on W), Bi (W ->), A'
             const FkTfDev& T = pl->tfdev;
-            const int ntCm = (T.Lband / d.TC) * d.C1;
+            const int ntCm = (d.N1 * (T.bw / d.TC) + (T.col_nyq >= 0 ? 1 : 0)) * d.C1;
             const dim3 gBt(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgB))), gCm(std::max(1, std::min(ntCm, pl->num_cu * pl->wgC)));
             D4W_MARK(0);
             if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0, FkGeo()))) return rc;

@@ -11,9 +11,10 @@
 //
 // Frequencies come in CELLS of NA consecutive n2 frequencies: k2 = d0 + NA (d1 + NB d2), d0 < NA, cell (d2, d1) -- exactly
 // the digits the MID item of pass B holds (thread Gi = d0 NB + d1 owns digit d2 = 0 .. NC-1 of group Gi).  A cell is band,
-// tail or dead for all N1 sub-rows alike.  Compact column of (q1, d0, d1, d2), R = region of the cell:
-//     rb[R] + q1 rw[R] + ctab[d2][d1].x + d0 cnt,      cnt = cells of region R in digit d2
-// so the lanes of a wave (consecutive Gi) write consecutive columns.  The Nyquist column f = M is col_nyq.
+// tail or dead for all N1 sub-rows alike.  A row of W is N1 sub-row blocks of RW columns, [band cells | tail cells] each,
+// + one block for the Nyquist column f = M:   column of (q1, d0, d1, d2) = q1 RW + ctab[d2][d1].x + d0 cnt,
+// cnt = cells of that class in digit d2 -- the lanes of a wave (consecutive Gi) write consecutive columns, and a thread's
+// NC column offsets inside a sub-row block are constants it computes once (the sub-row block's base is wave-uniform).
 //
 // Before the c2 transform the Hermitian partner of row (q, c2) is the row (q', c2) with kc1(q') = -kc1(q); as sequences
 // in time  row_B = omega conj(row_A),  omega = twc[rA] twc[rB]  (the four-step twiddles W_nx^(c2 kc1) the two rows carry):
@@ -25,13 +26,14 @@ namespace d4w {
 
 struct FkTfDev {
     const int2* pairs;     // work list of passes Bf / Bi: (keyA, keyB), key = row * N1 + q1
-    const float* tgain;    // [N1 pos q1][N2 pos e]: 1 band, the wavenumber-independent gain of a tail column, 0 dead
-    const int2* ctab;      // [NC][NB] {x = offset of the cell inside its sub-row block, y = cnt | region << 28}
-    const float* cmask;    // [nx pos r][Lband] folded mask of the band columns (incl. the Nyquist column)
+    const float* tgain;    // [N1 pos q1][N2 pos e]: 1 band, C2 x the wavenumber-independent gain of a tail column, 0 dead
+    const int2* ctab;      // [NC][NB] {x = first column of the cell inside a sub-row block, y = cnt | class << 28}
+    const float* cmask;    // [nx pos r][Lc] folded mask at the band columns (same indexing as W)
     float2* W;             // [nx][Lc] compact half spectrum
-    int rb1, rw1, rb2, rw2;   // region 1 = band, 2 = tail: first column, columns per sub-row
-    int col_nyq;           // column of f = M, -1: dead
-    int Lc, Lband;         // row pitch of W, band columns (a multiple of TC)
+    int RW;                // columns of a sub-row block (a multiple of TC)
+    int bw;                // band columns of a sub-row block, rounded up to a multiple of TC (they come first)
+    int col_nyq;           // column of f = M (= N1 RW), -1: dead
+    int Lc;                // row pitch of W and cmask
 };
 
 // PHASE 1 = Bf: n2 forward of a sub-row pair, untangle, x tail gain -> W.
@@ -56,13 +58,10 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
     for (int i = tid; i < NC * NB; i += THR) ctab[i] = T.ctab[i];
     __syncthreads();
     auto ad = [](int e) { return e + e / NC; };
-    // compact column of frequency (q1; d0, d1, d2), -1: not kept
-    auto colof = [&](int q1, int dd0, int dd1, int dd2) -> int {
+    // column of frequency digits (d0, d1, d2) inside a sub-row block, -1: not kept
+    auto cellcol = [&](int dd0, int dd1, int dd2) -> int {
         const int2 c = ctab[dd2 * NB + dd1];
-        const int reg = c.y >> 28;
-        const int cnt = c.y & 0x0FFFFFFF;
-        const int base = (reg == 1) ? T.rb1 + q1 * T.rw1 : T.rb2 + q1 * T.rw2;
-        return reg ? base + c.x + dd0 * cnt : -1;
+        return (c.y >> 28) ? c.x + dd0 * (c.y & 0x0FFFFFFF) : -1;
     };
 
     const int r1 = tid / M1, j1 = tid % M1;              // S1 / S1' item
@@ -72,10 +71,17 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
     const int d0 = Gi / NB, d1 = Gi % NB;
     int PGz = 0;
     float2 wc[NC];
+    int cxA[NC], cxB[NC];          // columns of the thread's own digits / of its partner group's (PG = NG-1-Gi) digits
     if (midrange) {
         PGz = P.mirror0[Gi * NC] / NC;
         const float2* wcp = P.wcol + Gi * NC;
-        static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; wc[d] = wcp[d]; });
+        const int PGn = NG - 1 - Gi;
+        static_for<NC>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;
+            wc[d] = wcp[d];
+            cxA[d] = cellcol(d0, d1, d);
+            cxB[d] = cellcol(PGn / NB, PGn % NB, d);
+        });
     }
     int t = tbase + blockIdx.x;
     const int gstep = gridDim.x;
@@ -104,12 +110,12 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             const int rA = pr.x / G::N1, q1A = pr.x - rA * G::N1;
             const int rB = pr.y / G::N1, q1B = pr.y - rB * G::N1;
             const int PG = (q1A == 0) ? PGz : (NG - 1 - Gi);
-            const float* mA = T.tgain + (size_t)q1A * N2 + Gi * NC;
-            const float* mB = T.tgain + (size_t)q1B * N2 + PG * NC;
+            const float* mA = T.tgain + q1A * N2;
+            const float* mB = T.tgain + q1B * N2;
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
-                O.ma[d] = mA[d];
-                O.mbr[d] = mB[d];
+                O.ma[d] = mA[(unsigned)(Gi * NC + d)];
+                O.mbr[d] = mB[(unsigned)(PG * NC + d)];
             });
             O.wr = P.wrow[q1A];
             O.om = c_mul(P.twc[rA], P.twc[rB]);
@@ -173,9 +179,14 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                 dft<NC>(a);
                 dft<NC>(b);
                 const float2 om = cur.om, wr = cur.wr;
-                float2* WA = T.W + (size_t)rA * T.Lc;
-                float2* WB = T.W + (size_t)rB * T.Lc;
-                const int pd0 = PG / NB, pd1 = PG - pd0 * NB;
+                float2* WA = T.W + (size_t)rA * T.Lc + q1A * T.RW;          // the pair's sub-row blocks: wave-uniform bases
+                float2* WB = T.W + (size_t)rB * T.Lc + q1B * T.RW;
+                int cb[NC];
+                if (k1zero) {                                               // the k1 = 0 sub-row mirrors its groups differently
+                    const int pd0 = PGz / NB, pd1 = PGz - pd0 * NB;
+                    static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; cb[d] = cellcol(pd0, pd1, d); });
+                } else
+                    static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; cb[d] = cxB[d]; });
                 static_for<NC>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     constexpr int pn = NC - 1 - d, pz = (NC - d) % NC;
@@ -188,17 +199,16 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                     const float2 tO = c_mul(w, O);
                     const float2 Yp = c_add(E, tO);              // X_A[f],      f = k1 + N1 k2(Gi, d)
                     const float2 Ym = c_sub(E, tO);              // X_A[f - M];  X_B[M - f] = omega conj(Ym)
-                    const int colA = colof(q1A, d0, d1, d);
-                    if (colA >= 0) WA[colA] = c_scale(Yp, cur.ma[d]);
+                    if (cxA[d] >= 0) WA[(unsigned)cxA[d]] = c_scale(Yp, cur.ma[d]);
                     if (d == 0 && rev0) {                        // f = 0 and the Nyquist column of row A (and of row B)
-                        if (T.col_nyq >= 0) WA[T.col_nyq] = Ym;
+                        if (T.col_nyq >= 0) (T.W + (size_t)rA * T.Lc)[T.col_nyq] = Ym;
                         if (!same) {
-                            if (colA >= 0) WB[colA] = c_scale(c_mul(om, c_conj(Yp)), cur.ma[d]);
-                            if (T.col_nyq >= 0) WB[T.col_nyq] = c_mul(om, c_conj(Ym));
+                            if (cxA[d] >= 0) WB[(unsigned)cxA[d]] = c_scale(c_mul(om, c_conj(Yp)), cur.ma[d]);
+                            if (T.col_nyq >= 0) (T.W + (size_t)rB * T.Lc)[T.col_nyq] = c_mul(om, c_conj(Ym));
                         }
                     } else if (!selfg) {
-                        const int colB = colof(q1B, pd0, pd1, rev0 ? pz : pn);
-                        if (colB >= 0) WB[colB] = c_scale(c_mul(om, c_conj(Ym)), gB);
+                        const int cB = rev0 ? cb[pz] : cb[pn];
+                        if (cB >= 0) WB[(unsigned)cB] = c_scale(c_mul(om, c_conj(Ym)), gB);
                     }
                 });
             }
@@ -219,19 +229,23 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             const bool k1z = (q1A == 0);
             const int PG = k1z ? PGz : (NG - 1 - Gi);
             const bool rev0 = k1z && (Gi == 0);
-            const float2* WA = T.W + (size_t)rA * T.Lc;
-            const float2* WB = T.W + (size_t)rB * T.Lc;
-            const int pd0 = PG / NB, pd1 = PG - pd0 * NB;
+            const float2* WA = T.W + (size_t)rA * T.Lc + q1A * T.RW;
+            const float2* WB = T.W + (size_t)rB * T.Lc + q1B * T.RW;
+            int cb[NC];
+            if (k1z) {
+                const int pd0 = PG / NB, pd1 = PG - pd0 * NB;
+                static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; cb[d] = cellcol(pd0, pd1, d); });
+            } else
+                static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; cb[d] = cxB[d]; });
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
                 constexpr int pn = NC - 1 - d, pz = (NC - d) % NC;
-                const int colA = colof(q1A, d0, d1, d);
-                Wp[d] = (colA >= 0) ? WA[colA] : make_float2(0.f, 0.f);
+                Wp[d] = (cxA[d] >= 0) ? WA[(unsigned)cxA[d]] : make_float2(0.f, 0.f);
                 if (d == 0 && rev0) {
-                    Wm[d] = (T.col_nyq >= 0) ? WA[T.col_nyq] : make_float2(0.f, 0.f);      // Y_A[M] itself
+                    Wm[d] = (T.col_nyq >= 0) ? (T.W + (size_t)rA * T.Lc)[T.col_nyq] : make_float2(0.f, 0.f);      // Y_A[M] itself
                 } else {
-                    const int colB = colof(q1B, pd0, pd1, rev0 ? pz : pn);
-                    Wm[d] = (colB >= 0) ? WB[colB] : make_float2(0.f, 0.f);
+                    const int cB = rev0 ? cb[pz] : cb[pn];
+                    Wm[d] = (cB >= 0) ? WB[(unsigned)cB] : make_float2(0.f, 0.f);
                 }
             });
             wr_n = P.wrow[q1A];
@@ -354,12 +368,23 @@ __global__ __launch_bounds__(G::THRC) void fkf_passCm(FkDev P, FkFastDev F, FkTf
     const bool actB = hi < RA;                         // items of the radix-RB step
     for (int i = tid; i < (G::CTREE ? RB : RA * RB); i += G::THRC) twl[i] = F.twC[(G::CTREE ? RB : 0) + i];
     __syncthreads();
-    const int nblk = T.Lband / TC;
-    const size_t LC = (size_t)T.Lc, LB = (size_t)T.Lband;
+    // tile t -> (q, column block): per q the N1 sub-row blocks' band columns (nb1 strips each), then the Nyquist strip
+    const int nb1 = T.bw / TC, tq = G::N1 * nb1 + (T.col_nyq >= 0 ? 1 : 0);
+    const size_t LC = (size_t)T.Lc;
+    auto tile_qp = [&](int t, int& q, int& p0) {
+        q = t / tq;
+        const int u = t - q * tq;
+        if (u < G::N1 * nb1) {
+            const int q1 = u / nb1;
+            p0 = q1 * T.RW + (u - q1 * nb1) * TC;
+        } else
+            p0 = T.col_nyq;
+    };
     float2 pfA[RA], pfB[RA];
     float mk[RB];
     auto issue = [&](float2 (&pf)[RA], int t) {
-        const int q = t / nblk, p0 = (t - q * nblk) * TC;
+        int q, p0;
+        tile_qp(t, q, p0);
         const float2* bh = T.W + ((size_t)q * G::C2 + hi) * LC + p0 + tt;
         static_for<RA>([&](auto aa) {
             constexpr int a = decltype(aa)::value;
@@ -367,16 +392,18 @@ __global__ __launch_bounds__(G::THRC) void fkf_passCm(FkDev P, FkFastDev F, FkTf
         });
     };
     auto issue_mask = [&](int t) {
-        const int q = t / nblk, p0 = (t - q * nblk) * TC;
-        const float* mp = T.cmask + ((size_t)q * G::C2 + (size_t)hi * RB) * LB + p0 + tt;
+        int q, p0;
+        tile_qp(t, q, p0);
+        const float* mp = T.cmask + ((size_t)q * G::C2 + (size_t)hi * RB) * LC + p0 + tt;
         static_for<RB>([&](auto bb) {
             constexpr int b = decltype(bb)::value;
-            mk[b] = mp[(size_t)b * LB];
+            mk[b] = mp[(size_t)b * LC];
         });
     };
     const int gstep = gridDim.x;
     auto body = [&](float2 (&pf)[RA], int t) {
-        const int q = t / nblk, p0 = (t - q * nblk) * TC;
+        int q, p0;
+        tile_qp(t, q, p0);
         float2* bh = T.W + ((size_t)q * G::C2 + hi) * LC + p0 + tt;
         if (actA) {
             dft<RA>(pf);
