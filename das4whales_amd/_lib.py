@@ -93,6 +93,7 @@ def _load():
                                          c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
         "d4w_analytic_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_analytic_row_fits_lds": (c_int, [c_int]),
+        "d4w_analytic_long_clear": (c_int, []),
         "d4w_analytic_long_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),
         "d4w_analytic_long_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_void_p, c_void_p]),
         "d4w_row_var_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

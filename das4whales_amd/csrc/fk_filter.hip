@@ -3130,9 +3130,27 @@ __global__ __launch_bounds__(kThreads) void analytic_combine_z(const float2* __r
 
 static std::mutex g_long_mu;
 static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_plans;
-static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_fast;     // packed plans of specialised shapes (NULL: none)
+static std::map<std::tuple<int, int, int>, d4w_fkd_plan*> g_long_fast;     // packed plans of specialised shapes (successes only)
+constexpr size_t kLongPlansMax = 16;   // a stream of varying channel selections must not keep adding device tables
+
+// drop every cached long-row plan (g_long_mu held): kernels still in flight may read their tables, so the device drains first
+static void long_plans_drop_locked() {
+    (void)hipDeviceSynchronize();
+    for (auto& kv : g_long_plans) if (kv.second) d4w_fkd_plan_destroy(kv.second);
+    for (auto& kv : g_long_fast) if (kv.second) d4w_fkd_plan_destroy(kv.second);
+    g_long_plans.clear();
+    g_long_fast.clear();
+}
 
 extern "C" {
+
+/* Frees the plans d4w_analytic_long_f32 caches per (device, nx, ns) (synchronises the device).  They are also dropped
+ * automatically once more than 16 shapes have been seen. */
+int d4w_analytic_long_clear(void) {
+    std::lock_guard<std::mutex> lk(g_long_mu);
+    long_plans_drop_locked();
+    return D4W_OK;
+}
 
 /* even ns: [nx][ns] float32 (the Hilbert transform); odd ns: [nx][ns] complex (the row as a complex sequence) */
 size_t d4w_analytic_long_ws_bytes(int nx, int ns) {
@@ -3157,6 +3175,7 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
             auto key = std::make_tuple(devid, nx, -ns);
             auto it = g_long_plans.find(key);
             if (it == g_long_plans.end()) {
+                if (g_long_plans.size() + g_long_fast.size() >= kLongPlansMax) long_plans_drop_locked();
                 int rc = fkd_plan_build(nx, 2 * ns, 1, 0, false, &pl);
                 if (rc) return rc;
                 pl->tp.dev.scale = (float)(1.0 / (double)ns);
@@ -3210,7 +3229,12 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
                 } else {
                     fp = nullptr;
                 }
-                g_long_fast[key] = fp;                            // NULL: no specialised kernels for this shape
+                // only successes are remembered: a shape registered later (d4w_fk_register_shape, fkjit) is picked up by
+                // the next call; the failed attempt costs a table lookup
+                if (fp) {
+                    if (g_long_plans.size() + g_long_fast.size() >= kLongPlansMax) long_plans_drop_locked();
+                    g_long_fast[key] = fp;
+                }
             }
         }
         if (fp) {
@@ -3247,6 +3271,7 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
         auto key = std::make_tuple(devid, nx, ns);
         auto it = g_long_plans.find(key);
         if (it == g_long_plans.end()) {
+            if (g_long_plans.size() + g_long_fast.size() >= kLongPlansMax) long_plans_drop_locked();
             int rc = fkd_plan_build(nx, ns, 1, 0, false, &pl);
             if (rc) return rc;
             pl->slab.hilbert = 1;

@@ -5,8 +5,11 @@ HIP library (include/d4w.h: d4w_row_stats_f32, d4w_xcorr_f32)."""
 import numpy as np
 import torch
 
+import collections.abc
+
 from . import _device as dev
 from ._lib import lib, check
+from .dsp import _cache_lock
 
 
 # ---------------------------------------------------------------------------------------------
@@ -65,13 +68,14 @@ def _xf_prepared(grp, device):
     in d4w_xcorr_fft_cont_f32) and uploads nothing."""
     key = (tuple(np.asarray(t, dtype=np.float64).tobytes() for t in grp), str(device),
            int(torch.cuda.current_stream(device).cuda_stream))
-    ent = _xf_tables.get(key)
-    if ent is None:
-        if len(_xf_tables) > 32:
-            _xf_tables.clear()
-        taps, lt = _taps_tensor(grp, device)
-        ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device)
-        ent = _xf_tables[key] = [taps, lt, ws, False]
+    with _cache_lock:
+        ent = _xf_tables.get(key)
+        if ent is None:
+            if len(_xf_tables) > 32:
+                _xf_tables.clear()
+            taps, lt = _taps_tensor(grp, device)
+            ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device)
+            ent = _xf_tables[key] = [taps, lt, ws, False]
     return ent
 
 
@@ -222,11 +226,31 @@ def compute_cross_correlogram(data, template, exact_tail=None):
 # ---------------------------------------------------------------------------------------------
 # peak picking (d4w_find_peaks_f32; the envelope of the *_env variants is d4w_analytic_f32)
 # ---------------------------------------------------------------------------------------------
-class PickRows:
-    """The picks of every channel: behaves like the list of per-channel int64 index arrays the reference returns
-    (detect.py:169-274: len(), indexing, iteration, in channel order), backed by ONE packed 2 x K table on the
-    device (`packed`: row 0 = channel, row 1 = time index = detect.convert_pick_times' output) and `counts`.
-    Nothing is copied to the host until a row (or the table) is asked for."""
+class PickRows(collections.abc.Sequence):
+    """The picks of every channel: a read-only Sequence that behaves like the list of per-channel int64 index arrays the
+    reference returns (detect.py:169-274: len(), indexing, slicing, iteration, `in`, reversed(), in channel order), backed
+    by ONE packed 2 x K table on the device (`packed`: row 0 = channel, row 1 = time index = detect.convert_pick_times'
+    output) and `counts`.  Nothing is copied to the host until a row (or the table) is asked for; the first access copies
+    the whole table once.  Deviation from the reference: it is not a `list` instance -- code that needs one (isinstance
+    checks, `+`, append, np.asarray(..., dtype=object)) calls .tolist()."""
+
+    def tolist(self):
+        """A plain Python list of per-channel int64 ndarrays, exactly the reference's return type."""
+        return list(self)
+
+    def __add__(self, other):
+        return self.tolist() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.tolist()
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(np.array_equal(a, b) for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    __hash__ = None
 
     def __init__(self, packed, counts):
         self.packed, self.counts = packed, counts

@@ -186,14 +186,34 @@ def supported_length(n, even=False):
 
 _plans = {}
 _plans_lock = threading.Lock()
+# one lock for the small per-(device, stream) caches of this package (side streams, zero-phase responses, overlap-save
+# workspaces, template spectra): look-up-or-create is atomic, entries are keyed by the calling stream, so two Python
+# threads on two streams never share a workspace (SURVEY 8b "threading")
+_cache_lock = threading.RLock()
 
 
-def compile_fk_shape(nx, ns, verbose=False):
+def compile_fk_shape(nx, ns, verbose=False, warn=False):
     """Compile (once, cached on disk) shape-specialised f-k kernels for [nx, ns] -- any shape whose axes factor into
     parts <= 32; see das4whales_amd/fkjit.py.  Returns True when the shape runs specialised kernels afterwards.
-    Plans created before the call keep the kernels they were planned with (drop them with dsp.clear_fk_plans())."""
+    Plans created before the call keep the kernels they were planned with (drop them with dsp.clear_fk_plans()).
+    warn=True: a RuntimeWarning names the reason when the shape stays on the generic kernels."""
     from . import fkjit
-    return fkjit.compile_fk_shape(nx, ns, verbose=verbose)
+    return fkjit.compile_fk_shape(nx, ns, verbose=verbose, warn=warn)
+
+
+def _auto_specialise(nx, ns):
+    """A new large block (>= 2^24 samples) gets its own f-k kernels (~15-40 s once, cached on disk).  Never raises: when it
+    cannot (no configuration, no compiler, a failed build -- remembered, not retried) the generic kernels run, 3-8x slower
+    at this size, and a RuntimeWarning says why."""
+    import os
+    if os.environ.get("D4W_FK_JIT", "1") == "0" or int(nx) * int(ns) < (1 << 24):
+        return
+    try:
+        compile_fk_shape(nx, ns, warn=True)
+    except Exception as e:                      # e.g. an unwritable cache directory
+        import warnings
+        warnings.warn("das4whales_amd: compiling f-k kernels for %d x %d failed (%r); the generic kernels run 3-8x slower "
+                      "at this size" % (nx, ns, e), RuntimeWarning, stacklevel=3)
 
 
 def clear_fk_plans():
@@ -209,14 +229,12 @@ def get_fk_plan(nx, ns, device=None):
     device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
     key = (str(device), int(nx), int(ns))
     with _plans_lock:
+        known = key in _plans
+    if not known:
+        _auto_specialise(nx, ns)          # outside the lock: a compile takes tens of seconds (fkjit has its own lock)
+    with _plans_lock:
         p = _plans.pop(key, None)
         if p is None:
-            import os
-            if os.environ.get("D4W_FK_JIT", "1") != "0" and int(nx) * int(ns) >= (1 << 24):
-                try:
-                    compile_fk_shape(nx, ns)  # a new large shape gets its own kernels (~15 s once, cached on disk);
-                except Exception:             # without a configuration or a compiler it runs the generic passes
-                    pass
             if len(_plans) >= 4:          # plans hold an nx*ns/2 float mask each: keep few, drop the least recently used
                 _plans.pop(next(iter(_plans)))
             p = FkPlan(nx, ns, device=device)
@@ -440,11 +458,12 @@ _side_streams = {}
 def _side_stream(device):
     """One extra stream per (device, calling stream) for latency-bound work that runs underneath a bandwidth-bound kernel."""
     key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    st = _side_streams.get(key)
-    if st is None:
-        if len(_side_streams) > 32:
-            _side_streams.clear()
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    with _cache_lock:
+        st = _side_streams.get(key)
+        if st is None:
+            if len(_side_streams) > 32:
+                _side_streams.clear()
+            st = _side_streams[key] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -452,16 +471,17 @@ def _zero_phase_taps(sos, device):
     """(taps tensor, K, E, dc gain) of the truncated zero-phase response of `sos` on `device`, cached; None when the
     response is too long for one FFT block."""
     key = (sos.tobytes(), sos.shape, str(device))
-    zp = _zp_cache.get(key)
-    if zp is None:
-        if len(_zp_cache) > 16:
-            _zp_cache.clear()
-        r = _zero_phase_response(sos, tol_taps=1e-7)
-        if r is not None:
-            taps, K, E = r
-            r = (torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(device), K, E,
-                 float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2)
-        zp = _zp_cache[key] = r or ()
+    with _cache_lock:
+        zp = _zp_cache.get(key)
+        if zp is None:
+            if len(_zp_cache) > 16:
+                _zp_cache.clear()
+            r = _zero_phase_response(sos, tol_taps=1e-7)
+            if r is not None:
+                taps, K, E = r
+                r = (torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(device), K, E,
+                     float(np.prod(sos[:, :3].sum(axis=1) / sos[:, 3:].sum(axis=1))) ** 2)
+            zp = _zp_cache[key] = r or ()
     if not zp or zp[1] > int(lib.d4w_fir_fft_max_halfwidth()):
         return None
     return zp
@@ -474,11 +494,12 @@ def _fir_workspace(t, device):
     """Overlap-save workspace of a cached taps tensor per stream: after the first call it holds the taps' block spectrum
     and the next calls pass taps = NULL (include/d4w.h)."""
     key = (id(t), int(torch.cuda.current_stream(device).cuda_stream))
-    ent = _fir_ws.get(key)
-    if ent is None or ent[2] is not t:
-        if len(_fir_ws) > 32:
-            _fir_ws.clear()
-        ent = _fir_ws[key] = [torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device), False, t]
+    with _cache_lock:
+        ent = _fir_ws.get(key)
+        if ent is None or ent[2] is not t:
+            if len(_fir_ws) > 32:
+                _fir_ws.clear()
+            ent = _fir_ws[key] = [torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device), False, t]
     return ent
 
 
@@ -811,12 +832,8 @@ def _analytic(x2d, mode, fs=0.0, var=None):
                                        dev.ptr(var) if var is not None else None, float(fs), dev.stream_ptr(x2d)))
         else:                                        # long rows: four-step time-axis transform through HBM (odd lengths as
                                                      # complex rows, lengths with a prime factor > 31 by Bluestein)
-            import os
-            if nx <= 65535 and os.environ.get("D4W_FK_JIT", "1") != "0" and nx * ns >= (1 << 24):
-                try:                                 # shapes with specialised f-k kernels run their time phase + a Hilbert pass B
-                    compile_fk_shape(nx, ns)         # (once per shape, cached on disk; the f-k filter of the block uses the same)
-                except Exception:
-                    pass
+            if nx <= 65535:                          # shapes with specialised f-k kernels run their time phase + a Hilbert pass B
+                _auto_specialise(nx, ns)             # (once per shape, cached on disk; the f-k filter of the block uses the same)
             for a in range(0, nx, 65535):
                 xb, yb = x2d[a:a + 65535], y[a:a + 65535]
                 ws = torch.empty(int(lib.d4w_analytic_long_ws_bytes(xb.shape[0], ns)), dtype=torch.uint8, device=x2d.device)

@@ -125,21 +125,56 @@ def is_specialised(nx, ns):
     return bool(lib.d4w_fk_shape_is_specialised(int(nx), int(ns)))
 
 
-def compile_fk_shape(nx, ns, verbose=False):
+_failed = {}      # (nx, ns, header hash) -> reason: a build that failed is not attempted again in this process
+
+
+def failure_reason(nx, ns):
+    """Why compile_fk_shape(nx, ns) returned False in this process (None: it did not, or has not been asked)."""
+    return _failed.get((int(nx), int(ns), _header_hash()))
+
+
+def compile_fk_shape(nx, ns, verbose=False, warn=False):
     """Make sure [nx, ns] runs shape-specialised f-k kernels; returns True when it does (built in, cached or freshly
-    compiled), False when the shape has no admissible configuration or no compiler is available (generic kernels)."""
+    compiled), False when the shape has no admissible configuration or no compiler is available (generic kernels).
+    A failure is remembered per process (and as a .failed marker next to the cached objects, keyed by the kernel headers'
+    hash) so that the ~40 s compile is not repeated on every call; warn=True raises a RuntimeWarning when the shape falls
+    back to the generic kernels."""
     nx, ns = int(nx), int(ns)
+
+    def failed(reason, marker=None):
+        _failed[(nx, ns, _header_hash())] = reason
+        if marker:
+            try:
+                with open(marker, "w") as f:
+                    f.write(reason[-4000:])
+            except OSError:
+                pass
+        if warn:
+            import warnings
+            warnings.warn("das4whales_amd: no shape-specialised f-k kernels for %d x %d (%s); the generic kernels run "
+                          "3-8x slower at this size" % (nx, ns, reason.splitlines()[0][:200]), RuntimeWarning, stacklevel=3)
+        return False
+
     with _lock:
         if is_specialised(nx, ns):
             return True
+        prev = _failed.get((nx, ns, _header_hash()))
+        if prev is not None:
+            return failed(prev)
         cfg = choose_config(nx, ns)
         if cfg is None:
-            return False
+            return failed("no admissible configuration: an axis has a prime factor > 31 beyond what the Bluestein pass carries")
         path = _lib_path(nx, ns, cfg)
+        marker = path[:-3] + ".failed"
         if not os.path.exists(path):
+            if os.path.exists(marker):
+                try:
+                    return failed("an earlier build of this configuration failed: " + open(marker).read())
+                except OSError:
+                    return failed("an earlier build of this configuration failed")
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             if not os.path.exists(hipcc):
-                return False
+                return failed("no hipcc at %s" % hipcc)
             os.makedirs(_JITDIR, exist_ok=True)
             src = "%s.%d.hip" % (path[:-3], os.getpid())
             with open(src, "w") as f:
@@ -154,17 +189,20 @@ def compile_fk_shape(nx, ns, verbose=False):
             if verbose:
                 print("[fkjit]", " ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
+            for leftover in ((src, tmp) if r.returncode != 0 else (src,)):
+                try:
+                    os.remove(leftover)
+                except OSError:
+                    pass
             if r.returncode != 0:
                 if verbose:
                     print(r.stderr[-2000:], flush=True)
-                return False
+                return failed("hipcc failed: " + (r.stderr.strip() or "exit code %d" % r.returncode), marker)
             os.replace(tmp, path)
-            try:
-                os.remove(src)
-            except OSError:
-                pass
         _register(path)
-        return is_specialised(nx, ns)
+        if not is_specialised(nx, ns):
+            return failed("the compiled configuration did not register")
+        return True
 
 
 def prune_stale():
@@ -172,7 +210,7 @@ def prune_stale():
     tag = "_" + _header_hash() + ".so"
     n = 0
     for path in glob.glob(os.path.join(_JITDIR, "fk_*")):
-        if not path.endswith(tag) and ".so." not in os.path.basename(path) and not path.endswith(".hip"):
+        if not path.endswith(tag) and not path.endswith(tag[:-3] + ".failed") and ".so." not in os.path.basename(path) and not path.endswith(".hip"):
             try:
                 os.remove(path)
                 n += 1

@@ -105,29 +105,39 @@ class ShardedFkPlan:
         assert self.blocks[self.rank] == (self.row_begin, self.row_end)
 
     def _specialise(self, nx, ns):
-        """A new large shape gets its own kernels, as in dsp.get_fk_plan (das4whales_amd/fkjit.py: ~15 s once, cached on disk):
-        rank 0 compiles, the others pick the cached object up.  The ranks must agree on the plan type (the packed and the
-        generic plan exchange different layouts), so the outcome is reduced over the group; returns True when this rank must
-        hold back to the generic plan because some rank has no specialised kernels."""
+        """The ranks must agree on the plan type -- the packed plan (shape-specialised kernels) and the generic plan exchange
+        different layouts -- whatever their environments and kernel caches say.  A new large shape first gets its kernels as
+        in dsp.get_fk_plan (das4whales_amd/fkjit.py: ~15 s once, cached on disk): rank 0 compiles, the others pick the
+        cached object up.  Then EVERY rank reports whether the shape is specialised in its process and the outcome is
+        min-reduced over the group (always, also for small shapes and with D4W_FK_JIT=0: each rank could otherwise decide
+        from its own cache and skip the collective the others wait in).  Returns True when this rank must hold back to the
+        generic plan because some rank has no specialised kernels."""
         import os
-        if os.environ.get("D4W_FK_JIT", "1") == "0" or nx * ns < (1 << 24):
-            return False
-        from . import fkjit
+        want_jit = os.environ.get("D4W_FK_JIT", "1") != "0" and nx * ns >= (1 << 24)
+        if self.world > 1:                                   # the decision to compile must be the same everywhere, too
+            w = torch.tensor([int(want_jit)], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(w, op=dist.ReduceOp.MIN, group=self.group)
+            want_jit = bool(int(w.item()))
 
         def attempt():
             try:
-                return int(bool(fkjit.compile_fk_shape(nx, ns)))
+                from . import fkjit
+                fkjit.compile_fk_shape(nx, ns)
             except Exception:
-                return 0
-        ok = attempt() if self.rank == 0 else 0
-        if self.world > 1:
-            dist.barrier(self.group)
-            if self.rank != 0:
-                ok = attempt()
-            flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            return bool(ok) and int(flag.item()) == 0
-        return False
+                pass
+        if want_jit:
+            if self.rank == 0:
+                attempt()
+            if self.world > 1:
+                dist.barrier(self.group)
+                if self.rank != 0:
+                    attempt()
+        if self.world == 1:
+            return False
+        mine = int(bool(self.lib.d4w_fk_shape_is_specialised(int(nx), int(ns))))
+        flag = torch.tensor([mine], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(mine) and int(flag.item()) == 0
 
     def set_mask(self, mask):
         """mask: dense float32 [nx, ns] tensor on this rank's device, fftshift-ed grid (what the
@@ -239,7 +249,9 @@ class ShardedFkPlan:
             time_inv(send, y, 0, nxl)
             return (y, mean, mx) if stats else y
         slab = self._scratch("slab", self.nx * self.nq * per, dev_)
-        nch = max(1, min(self.CHUNKS, -(-nxl // self.C1)))
+        # the same chunk count on every rank (uneven channel blocks differ by a row: a count derived from this rank's own
+        # block could differ between ranks, and the grouped send / recv lists would then not match)
+        nch = max(1, min([self.CHUNKS] + [-(-(b - a) // self.C1) for a, b in self.blocks]))
         chunks = [self._chunks(r, nch) for r in range(self.world)]
         works = []
         self._mark("start")

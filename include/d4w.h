@@ -366,6 +366,9 @@ int d4w_analytic_row_fits_lds(int ns);
 size_t d4w_analytic_long_ws_bytes(int nx, int ns);
 int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, const float* var, double fs,
                           void* ws, void* stream);
+/* Frees the plans d4w_analytic_long_f32 keeps per (device, nx, ns) (it synchronises the device first; they are also dropped
+ * once more than 16 shapes have been seen, so a stream of varying channel selections does not accumulate device tables). */
+int d4w_analytic_long_clear(void);
 int d4w_row_var_f32(const float* x, int nx, int ns, float* var, void* stream);
 int d4w_snr_f32(const float* x, float* y, int nx, int ns, int env, float* var_ws, void* stream);
 int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream);

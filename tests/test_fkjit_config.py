@@ -44,3 +44,44 @@ def test_chooser_declines_shapes_without_a_configuration(fkjit):
     assert fkjit.choose_config(300, 12002) is None            # 6001 = 17 x 353
     assert fkjit.choose_config(40, 481) is None
     assert fkjit.is_specialised(20000, 120000) and not fkjit.is_specialised(20001, 120000)
+
+
+def test_failed_configuration_is_remembered_and_warns(fkjit):
+    """A shape with no admissible configuration (both axes carry huge primes): compile_fk_shape returns False, says why,
+    remembers it (no second attempt in this process) and -- with warn=True, as the automatic path of dsp.get_fk_plan /
+    dsp._analytic asks -- raises a RuntimeWarning instead of degrading silently."""
+    import time
+    import warnings
+    nx, ns = 2 * 10007, 2 * 2 * 60013
+    assert fkjit.choose_config(nx, ns) is None
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert fkjit.compile_fk_shape(nx, ns, warn=True) is False
+    assert any(issubclass(x.category, RuntimeWarning) and "generic kernels" in str(x.message) for x in w)
+    assert "configuration" in fkjit.failure_reason(nx, ns)
+    t0 = time.perf_counter()
+    assert fkjit.compile_fk_shape(nx, ns) is False                # remembered: no second search, no compiler run
+    assert time.perf_counter() - t0 < 0.5
+
+
+def test_failed_build_leaves_no_files_and_a_marker(fkjit, tmp_path, monkeypatch):
+    """A compiler that fails: the generated source and the partial object are removed, a .failed marker keyed by the kernel
+    headers' hash stops further attempts across processes, and the reason is reported."""
+    fake = tmp_path / "hipcc"
+    fake.write_text("#!/bin/sh\necho 'error: simulated' >&2\nexit 1\n")
+    fake.chmod(0o755)
+    jitdir = tmp_path / "jit"
+    monkeypatch.setenv("HIPCC", str(fake))
+    monkeypatch.setattr(fkjit, "_JITDIR", str(jitdir))
+    nx, ns = 640, 9600                                            # has a configuration, is not built in
+    assert fkjit.choose_config(nx, ns) is not None and not fkjit.is_specialised(nx, ns)
+    fkjit._failed.clear()
+    assert fkjit.compile_fk_shape(nx, ns) is False
+    left = sorted(os.listdir(jitdir))
+    assert len(left) == 1 and left[0].endswith(".failed"), left
+    assert "simulated" in fkjit.failure_reason(nx, ns)
+    fkjit._failed.clear()                                         # "another process": the marker alone stops the retry
+    fake.write_text("#!/bin/sh\ntouch %s\nexit 1\n" % (tmp_path / "ran_again"))
+    assert fkjit.compile_fk_shape(nx, ns) is False
+    assert not (tmp_path / "ran_again").exists()
+    fkjit._failed.clear()

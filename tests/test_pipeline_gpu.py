@@ -1,0 +1,132 @@
+"""End-to-end detection chain on SURVEY 8(d)'s S-small recipe and the per-file f-k step of the stream with the scripts'
+mask: band-pass -> f-k (hybrid_ninf) -> HF / LF matched filter -> envelope picks must give the
+oracle chain's picks, find the six injected fin-whale notes, and be safe to run from two Python threads on two streams.
+
+Reference: scripts/main_mfdetect.py:46-103 (design -> dsp.bp_filt -> dsp.fk_filter_sparsefilt -> detect.compute_cross_correlogram
+x2 -> detect.pick_times_env)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import d4w_oracle as orc
+from tests import known_answers as ka
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+FS, DX = 200.0, 2.0419046878814697
+NINF = (1350., 1450., 3300, 3450, 14., 30.)
+
+
+def rel(y, ref):
+    return float(np.max(np.abs(np.asarray(y, dtype=np.float64) - ref)) / np.max(np.abs(ref)))
+
+
+def test_detection_chain_on_s_small_with_injected_calls():
+    import das4whales_amd as dw
+    nx, ns, step = 600, 12000, 4
+    sel = [0, nx * step, step]
+    x, calls = ka.synth_block_device(nx, ns, "cuda", step=step, seed=1234, ocean_amp=1e-8 / np.sqrt(40))
+    x64 = x.cpu().numpy().astype(np.float64)
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    lf = orc.gen_template_fincall(t, FS, 14.7, 21.8, 0.78)
+    # --- the oracle chain (float64)
+    m_ref = np.asarray(orc.hybrid_ninf_filter_design((nx, ns), sel, DX, FS, *NINF))
+    b_ref = orc.bp_filt(x64, FS, 14, 30)
+    f_ref = orc.fk_filter_filt(b_ref, m_ref)
+    c_ref = [orc.compute_cross_correlogram(f_ref, hf), orc.compute_cross_correlogram(f_ref, lf)]
+    # --- the product chain, device resident
+    mask = dw.dsp.hybrid_ninf_filter_design((nx, ns), sel, DX, FS, *NINF)
+    b = dw.dsp.bp_filt(x, FS, 14, 30)
+    f = dw.dsp.fk_filter_sparsefilt(b, mask)
+    c = dw.detect.compute_cross_correlograms(f, [hf, lf])
+    assert rel(b.cpu().numpy(), b_ref) < TOL
+    assert rel(f.cpu().numpy(), f_ref) < 3 * TOL            # two float32 stages in a row against the float64 chain
+    for got, ref in zip(c, c_ref):
+        assert rel(got.cpu().numpy(), ref) < 3 * TOL
+    # --- picks: the same index sets as scipy on the float64 chain (marginal peaks per the 8(a) rule), calls found
+    found = 0
+    for k, (got, ref) in enumerate(zip(c, c_ref)):
+        thr = 0.45 * float(np.max(ref))
+        picks = dw.detect.pick_times_env(got, thr)
+        env_ref = np.abs(__import__("scipy.signal", fromlist=["hilbert"]).hilbert(ref, axis=1))
+        ndiff = 0
+        for r in range(0, nx, 7):
+            nd, _ = ka.assert_picks_match(picks[r], env_ref[r], thr, what="template %d row %d" % (k, r))
+            ndiff += nd
+        assert ndiff <= 2
+        for tpl, c0, arr in calls:
+            if tpl != k:
+                continue
+            row = np.asarray(picks[c0])
+            if row.size and np.min(np.abs(row - arr)) <= 8:
+                found += 1
+    print("injected notes found at their channel of closest approach: %d of %d" % (found, len(calls)))
+    assert found >= len(calls) - 1                            # a note arriving within a template length of the block end may be cut
+
+
+def test_stream_per_file_fk_with_the_scripts_mask():
+    """stream.FileStream's per-file f-k step with hybrid_ninf_filter_design (round 2 only ran it with an all-ones mask):
+    every file's filtered output = oracle f-k filter of that file's slice of the band-passed CONCATENATED record."""
+    from das4whales_amd import stream
+    rng = np.random.default_rng(5)
+    nx, ns, nfiles, step = 100, 3000, 3, 4
+    rec = rng.standard_normal((nx, ns * nfiles)) + 0.1
+    mask = np.asarray(orc.hybrid_ninf_filter_design((nx, ns), [0, nx * step, step], DX, FS, *NINF))
+    st = stream.FileStream(FS, 14, 30, templates=[], fk_mask=mask, halo=1024)
+    results = []
+    for i in range(nfiles):
+        results += st.push(rec[:, i * ns:(i + 1) * ns])
+    results += st.flush()
+    F = orc.bp_filt(rec, FS, 14, 30)
+    for r in results:
+        i = r["index"]
+        ref = orc.fk_filter_filt(F[:, i * ns:(i + 1) * ns], mask)
+        e = rel(r["filtered"].cpu().numpy(), ref)
+        assert e < 2 * TOL, (i, e)
+
+
+def test_two_python_threads_on_two_streams():
+    """SURVEY 8(b) threading: the chain called from two Python threads, each on its own HIP stream with its own data,
+    gives bit-identical results to the same calls made one after the other (per-stream workspaces, locked caches)."""
+    import das4whales_amd as dw
+    nx, ns = 400, 12000
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    lf = orc.gen_template_fincall(t, FS, 14.7, 21.8, 0.78)
+    mask = dw.dsp.hybrid_ninf_filter_design((nx, ns), [0, nx * 4, 4], DX, FS, *NINF)
+    gens = [torch.Generator(device="cuda").manual_seed(s) for s in (1, 2)]
+    xs = [torch.randn((nx, ns), device="cuda", generator=g) for g in gens]
+
+    def chain(x):
+        b = dw.dsp.bp_filt(x, FS, 14, 30)
+        f = dw.dsp.fk_filter_sparsefilt(b, mask)
+        c = dw.detect.compute_cross_correlograms(f, [hf, lf])
+        e = dw.dsp.envelope(c[0])
+        p = dw.detect.pick_times_env(c[1], 0.45 * float(c[1].max()))
+        return [b, f, c[0], c[1], e, p.packed]
+    serial = [chain(x) for x in xs]
+    torch.cuda.synchronize()
+    out, errs = [None, None], []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(s):
+                for _ in range(4):
+                    out[i] = chain(xs[i])
+            s.synchronize()
+        except Exception as e:                                # surfaces in the main thread
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for w in th:
+        w.start()
+    for w in th:
+        w.join()
+    assert not errs, errs
+    for i in range(2):
+        for a, b in zip(serial[i], out[i]):
+            assert torch.equal(a, b)
