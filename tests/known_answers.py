@@ -82,8 +82,8 @@ def synth_block_device(nx, ns, device, fs=200.0, dx=2.0419046878814697, step=1, 
     """SURVEY 8(d) S-large recipe on the device in float32: white noise `noise` + `n_waves` slow "ocean-wave" plane waves
     (f ~ U(0.5, 8) Hz, apparent speed ~ U(5, 300) m/s, amplitude `ocean_amp` EACH) + `n_calls` fin-whale notes (HF / LF
     alternated, hyperbolic moveout at 1500 m/s, amplitude `call_amp`).  Same recipe as oracle.synth_block (which divides the
-    ocean amplitude by sqrt(n_waves)); returns the block and the list of (template index, channel of closest approach,
-    arrival sample there)."""
+    ocean amplitude by sqrt(n_waves)); returns the block and one dict per note: template index, source position / range /
+    emission time, and `flank` = [(channel, arrival sample)] on the flanks of its moveout."""
     import torch
     from oracle import d4w_oracle as orc
     rng = np.random.default_rng(seed)
@@ -117,6 +117,10 @@ def synth_block_device(nx, ns, device, fs=200.0, dx=2.0419046878814697, step=1, 
         tp = torch.from_numpy((call_amp * tpl[:L]).astype(np.float32)).to(device)
         pos = (base[:, None] + torch.arange(L, device=device)[None, :]).reshape(-1)
         flat.index_add_(0, pos, tp.repeat(len(ok)))
-        c0 = int(np.argmin(np.abs(xpos - x0)))
-        calls.append((i % 2, c0, int(idx[c0])))
+        # where to look for the note: a channel on the FLANK of the moveout (offset ~ range: apparent speed ~ 2100 m/s).  At the
+        # apex the apparent speed is infinite and hybrid_ninf_filter_design removes the arrival by design (dsp.py:372-395).
+        cands = [int(np.argmin(np.abs(xpos - (x0 + sg * r)))) for sg in (-1.0, 1.0)]
+        cands = [c for c in cands if abs(abs(xpos[c] - x0) - r) < 0.25 * r and 0 <= idx[c] < ns - 2 * L]
+        calls.append({"template": i % 2, "x0": float(x0), "range": float(r), "t0": float(t0),
+                      "flank": [(c, int(idx[c])) for c in cands]})
     return x, calls

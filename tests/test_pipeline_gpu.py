@@ -57,14 +57,17 @@ def test_detection_chain_on_s_small_with_injected_calls():
             nd, _ = ka.assert_picks_match(picks[r], env_ref[r], thr, what="template %d row %d" % (k, r))
             ndiff += nd
         assert ndiff <= 2
-        for tpl, c0, arr in calls:
-            if tpl != k:
+        for call in calls:
+            if call["template"] != k:
                 continue
-            row = np.asarray(picks[c0])
-            if row.size and np.min(np.abs(row - arr)) <= 8:
-                found += 1
-    print("injected notes found at their channel of closest approach: %d of %d" % (found, len(calls)))
-    assert found >= len(calls) - 1                            # a note arriving within a template length of the block end may be cut
+            hit = False
+            for ch, arr in call["flank"]:                     # the flanks of the moveout (the apex is removed by the non-infinite fan)
+                row = np.asarray(picks[ch])
+                hit |= bool(row.size and np.min(np.abs(row - arr)) <= 8)
+            found += int(hit)
+    nlook = sum(1 for call in calls if call["flank"])
+    print("injected notes found on a flank of their moveout: %d of %d (%d with a flank inside the block)" % (found, len(calls), nlook))
+    assert nlook >= 4 and found >= nlook - 1
 
 
 def test_stream_per_file_fk_with_the_scripts_mask():
