@@ -36,8 +36,11 @@ if "--traffic" in sys.argv:
             # generic kernel: fk_passC<INV, GENERIC>; specialised: fkf_passC<FkFastCfg<...>, INV, MODE>
             targ = k[k.rindex(">, ") + 3:] if name == "fkf_passC" and ">, " in k else k[k.index("<") + 1:]
             name = "fk_passC_inv" if targ.strip().startswith("true") else "fk_passC_fwd"
+        if name == "fkf_passBt":                        # time-first order: fkf_passBt<FkFastCfg<...>, PHASE>
+            targ = k[k.rindex(">, ") + 3:] if ">, " in k else "1"
+            name = "fk_passBi_time_inv" if targ.strip().startswith("2") else "fk_passBf_time_fwd"
         name = {"fkf_passA_fwd": "fk_passA_fwd", "fkf_passA_inv": "fk_passA_inv", "fkf_passA_inv_stats": "fk_passA_inv",
-                "fkf_passB": "fk_passB"}.get(name, name)
+                "fkf_passB": "fk_passB", "fkf_passCm": "fk_passCm_channel"}.get(name, name)
         if (name == "xcorr_fft_blocks" and "<1, true" in k) or name == "xcorr_fft_fused4":
             name = "xcorr_fft_fused"                    # the two-template launch (one read, two correlograms)
         name = alias.get(name, name)
