@@ -73,29 +73,92 @@ __device__ __forceinline__ void dftp<4>(c2 (&x)[4]) {
     x[3] = c2_add_pi(b, d);
 }
 
-// composite radices (8, 16) via one Cooley-Tukey split in registers: n = R2 n1 + n2, k = k1 + R1 k2
+// a * s + c with a real literal s (both halves)
+__device__ __forceinline__ c2 c2_fmas(c2 a, float s, c2 c) { return c2{v2_fma(a.re, s, c.re), v2_fma(a.im, s, c.im)}; }
+
+template <>
+__device__ __forceinline__ void dftp<1>(c2 (&)[1]) {}
+
+template <>
+__device__ __forceinline__ void dftp<3>(c2 (&x)[3]) {
+    constexpr float s60 = (float)ct_sin2pi(1, 3);
+    const c2 t1 = c2_add(x[1], x[2]);
+    const c2 t2 = c2_fmas(t1, -0.5f, x[0]);
+    const c2 t3 = c2_scale(c2_sub(x[1], x[2]), s60);
+    x[0] = c2_add(x[0], t1);
+    x[1] = c2_add_mi(t2, t3);
+    x[2] = c2_add_pi(t2, t3);
+}
+
+template <>
+__device__ __forceinline__ void dftp<5>(c2 (&x)[5]) {
+    constexpr float c1 = (float)ct_cos2pi(1, 5), cc2 = (float)ct_cos2pi(2, 5);
+    constexpr float s1 = (float)ct_sin2pi(1, 5), s2 = (float)ct_sin2pi(2, 5);
+    const c2 t1 = c2_add(x[1], x[4]), t2 = c2_add(x[2], x[3]);
+    const c2 t3 = c2_sub(x[1], x[4]), t4 = c2_sub(x[2], x[3]);
+    const c2 a1 = c2_fmas(t1, c1, c2_fmas(t2, cc2, x[0]));
+    const c2 a2 = c2_fmas(t1, cc2, c2_fmas(t2, c1, x[0]));
+    const c2 b1 = c2_fmas(t3, s1, c2_scale(t4, s2));
+    const c2 b2 = c2_fmas(t3, s2, c2_scale(t4, -s1));
+    x[0] = c2_add(x[0], c2_add(t1, t2));
+    x[1] = c2_add_mi(a1, b1);
+    x[4] = c2_add_pi(a1, b1);
+    x[2] = c2_add_mi(a2, b2);
+    x[3] = c2_add_pi(a2, b2);
+}
+
+// every other radix, mirroring dft<R> of fft_radix.h: composite via one Cooley-Tukey split in registers
+// (n = R2 n1 + n2, k = k1 + R1 k2), odd primes by the paired cosine / sine sums
 template <int R>
 __device__ __forceinline__ void dftp(c2 (&x)[R]) {
-    constexpr int R1 = 4, R2 = R / 4;
-    static_assert(R == 8 || R == 16, "paired butterflies exist for radix 2, 4, 8, 16");
-    c2 u[R2][R1];
-    static_for<R2>([&](auto nn2) {
-        constexpr int n2 = decltype(nn2)::value;
-        c2 col[R1];
-        static_for<R1>([&](auto nn1) { col[decltype(nn1)::value] = x[R2 * decltype(nn1)::value + n2]; });
-        dftp<R1>(col);
+    constexpr int R1 = split_r1(R);
+    if constexpr (R1 == R) {
+        static_assert(R % 2 == 1, "prime radix 2 has its own butterfly");
+        constexpr int H = (R - 1) / 2;
+        c2 sq[H], dq[H];
+        static_for<H>([&](auto qq) {
+            constexpr int q = decltype(qq)::value + 1;
+            sq[q - 1] = c2_add(x[q], x[R - q]);
+            dq[q - 1] = c2_sub(x[q], x[R - q]);
+        });
+        const c2 x0 = x[0];
+        c2 sum = x0;
+        static_for<H>([&](auto qq) { sum = c2_add(sum, sq[decltype(qq)::value]); });
+        x[0] = sum;
+        static_for<H>([&](auto kk) {
+            constexpr int k = decltype(kk)::value + 1;
+            c2 A = x0, B = c2{v2_make(0.f, 0.f), v2_make(0.f, 0.f)};
+            static_for<H>([&](auto qq) {
+                constexpr int q = decltype(qq)::value + 1;
+                constexpr float c = (float)ct_cos2pi((q * k) % R, R);
+                constexpr float sn = (float)ct_sin2pi((q * k) % R, R);
+                A = c2_fmas(sq[q - 1], c, A);
+                B = c2_fmas(dq[q - 1], sn, B);
+            });
+            x[k] = c2_add_mi(A, B);
+            x[R - k] = c2_add_pi(A, B);
+        });
+    } else {
+        constexpr int R2 = R / R1;
+        c2 u[R2][R1];
+        static_for<R2>([&](auto nn2) {
+            constexpr int n2 = decltype(nn2)::value;
+            c2 col[R1];
+            static_for<R1>([&](auto nn1) { col[decltype(nn1)::value] = x[R2 * decltype(nn1)::value + n2]; });
+            dftp<R1>(col);
+            static_for<R1>([&](auto kk1) {
+                constexpr int k1 = decltype(kk1)::value;
+                u[n2][k1] = c2_rot<n2 * k1, R>(col[k1]);
+            });
+        });
         static_for<R1>([&](auto kk1) {
             constexpr int k1 = decltype(kk1)::value;
-            u[n2][k1] = c2_rot<n2 * k1, R>(col[k1]);
+            c2 row[R2];
+            static_for<R2>([&](auto nn2) { row[decltype(nn2)::value] = u[decltype(nn2)::value][k1]; });
+            dftp<R2>(row);
+            static_for<R2>([&](auto kk2) { x[k1 + R1 * decltype(kk2)::value] = row[decltype(kk2)::value]; });
         });
-    });
-    static_for<R1>([&](auto kk1) {
-        constexpr int k1 = decltype(kk1)::value;
-        c2 row[R2];
-        static_for<R2>([&](auto nn2) { row[decltype(nn2)::value] = u[decltype(nn2)::value][k1]; });
-        dftp<R2>(row);
-        static_for<R2>([&](auto kk2) { x[k1 + R1 * decltype(kk2)::value] = row[decltype(kk2)::value]; });
-    });
+    }
 }
 
 // unnormalised inverse by the swap trick: exchanging re and im is a renaming here
