@@ -1,3 +1,15 @@
+// EXPERIMENT, measured and NOT adopted (round 3) -- kept for the record, not part of the build.
+// Row-pair packed pass B (v_pk_* butterflies for a sub-row and its Hermitian partner at once): correct on the emulator
+// and on the GPU (all f-k tests), but SLOWER than the scalar kernels on MI355X at 20 000 x 120 000:
+//     dense fused pass B 8.0 ms (scalar 5.9), Bf 9.4 / 7.3 ms (3.8), Bi 6.1 / 4.9 ms (3.5)   [3 / 2 workgroups per CU asked]
+// Packing halves the VALU instructions but not the state: a 128-thread workgroup must hold the same 38 KB pair in prefetch
+// registers (75 per thread) and a packed radix-20 butterfly needs 160 transient registers -- 256 VGPRs + up to 128 AGPRs,
+// one wave per SIMD, four waves per CU, and the stage chain (LDS round trips, barriers) is then latency-bound.  The scalar
+// kernels run eight waves per CU at ~87 % VALU issue.  What would work is a FOUR-radix split (10 x 8 x 6 x 5: 40 prefetch
+// registers, every stage ~240 items of 256 threads), which changes the position order of the n2 axis and with it every
+// pass-B table of the plan -- not done.  To try it again: wire FkPbCfg / fkf_passBp into fk_entry.h and launch the regular
+// pairs (two distinct sub-rows, k1 != 0, sorted first in the work lists) through it, the rest through fkf_passB / fkf_passBt.
+//
 // Row-pair PACKED pass B of the shape-specialised f-k filter (all three forms: the fused middle pass of the channel-first
 // order and the two halves Bf / Bi of the time-first order, fk_fast.h / fk_tf.h).
 //
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(kPbThreads) void fkf_passBp(FkDev P, FkFastDev F, F
     // MID item: groups Gi and PG = NG - 1 - Gi (the same group for the middle item of an odd NG)
     const int Gi = tid, PG = NG - 1 - tid;
     const bool mid = tid < NI;
-    const bool selfg = (Gi == PG);
+    const bool selfg = (NG % 2 == 1) && (Gi == PG);
     float2 wc[NC];                 // W_ns^(N1 k2) of group Gi's positions; group PG's are c0 conj(wc[NC-1-d]), c0 = W_ns^(M - N1)
     int colG[NC], colP[NC];        // time-first: columns of the two groups' positions inside a sub-row block, -1 = not kept
     if (mid) {
@@ -83,10 +95,8 @@ __global__ __launch_bounds__(kPbThreads) void fkf_passBp(FkDev P, FkFastDev F, F
             }
         });
     }
-    const float2 c0 = P.wcol[(N2 - 1) == 0 ? 0 : P.mirror0[1 % N2]];      // placeholder, replaced below
-    (void)c0;
-    // W_ns^(M - N1) = W_ns^(N1 (N2 - 1)): the column twiddle of the position holding k2 = N2 - 1, the mirror of k2 = 0 (position 0)
-    const float2 cm = P.wcol[NG * NC - 1 - 0 >= 0 ? (NG - 1) * NC + (NC - 1) : 0];
+    // W_ns^(N1 (N2 - 1)): the column twiddle of the last position, which holds k2 = N2 - 1 (every digit of position 0 mirrored)
+    const float2 cm = P.wcol[N2 - 1];
 
     int t = tbase + blockIdx.x;
     const int gstep = gridDim.x;
@@ -243,7 +253,8 @@ __global__ __launch_bounds__(kPbThreads) void fkf_passBp(FkDev P, FkFastDev F, F
                 na = c_add(S, D);
                 nb = (PHASE == 0) ? c_conj(c_sub(S, D)) : c_mul(om, c_conj(c_sub(S, D)));
             };
-            c2 Pn[NC], Qn[NC];
+            // new values: row A at (Gi, d) / (PG, e), row B at (Gi, d) / (PG, e)
+            float2 naG[NC], naP[NC], nbG[NC], nbP[NC];
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
                 constexpr int pn = NC - 1 - d;
@@ -256,21 +267,11 @@ __global__ __launch_bounds__(kPbThreads) void fkf_passBp(FkDev P, FkFastDev F, F
                     untangle(c2_a(Pg[d]), c2_b(qsrc), w1, Yp1, Ym1);
                     if (!selfg) untangle(c2_a(qsrc), c2_b(Pg[d]), w2, Yp2, Ym2);
                 }
+                naP[pn] = make_float2(0.f, 0.f);
+                nbG[d] = make_float2(0.f, 0.f);
                 if constexpr (PHASE == 0) {
-                    float2 na1, nb1, na2 = make_float2(0.f, 0.f), nb2 = make_float2(0.f, 0.f);
-                    retangle(c_scale(Yp1, gcur.aG[d]), c_scale(Ym1, gcur.bP[pn]), w1, na1, nb1);
-                    if (!selfg) retangle(c_scale(Yp2, gcur.aP[pn]), c_scale(Ym2, gcur.bG[d]), w2, na2, nb2);
-                    // new row A / row B values at (Gi, d) and at (PG, pn)
-                    if (!selfg) {
-                        Pn[d] = c2_make(na1, nb2);
-                        Qn[pn] = c2_make(na2, nb1);
-                    } else {
-                        // the middle group pairs with itself: A's value at d comes from this d, B's value at pn too
-                        Pn[d].re = v2_make(na1.x, v2_y(Pn[d].re));
-                        Pn[d].im = v2_make(na1.y, v2_y(Pn[d].im));
-                        Pn[pn].re = v2_make(v2_x(Pn[pn].re), nb1.x);
-                        Pn[pn].im = v2_make(v2_x(Pn[pn].im), nb1.y);
-                    }
+                    retangle(c_scale(Yp1, gcur.aG[d]), c_scale(Ym1, gcur.bP[pn]), w1, naG[d], nbP[pn]);
+                    if (!selfg) retangle(c_scale(Yp2, gcur.aP[pn]), c_scale(Ym2, gcur.bG[d]), w2, naP[pn], nbG[d]);
                 } else if constexpr (PHASE == 1) {
                     // X_A[f] = Yp, X_B[M - f] = omega conj(Ym)
                     if (colG[d] >= 0) WA[(unsigned)colG[d]] = c_scale(Yp1, gcur.aG[d]);
@@ -280,20 +281,18 @@ __global__ __launch_bounds__(kPbThreads) void fkf_passBp(FkDev P, FkFastDev F, F
                         if (colG[d] >= 0) WB[(unsigned)colG[d]] = c_scale(c_mul(om, c_conj(Ym2)), gcur.bG[d]);
                     }
                 } else {
-                    float2 na1, nb1, na2 = make_float2(0.f, 0.f), nb2 = make_float2(0.f, 0.f);
-                    retangle(WaG[d], c_mul(om, c_conj(WbP[pn])), w1, na1, nb1);
-                    if (!selfg) {
-                        retangle(WaP[pn], c_mul(om, c_conj(WbG[d])), w2, na2, nb2);
-                        Pn[d] = c2_make(na1, nb2);
-                        Qn[pn] = c2_make(na2, nb1);
-                    } else {
-                        Pn[d].re = v2_make(na1.x, v2_y(Pn[d].re));
-                        Pn[d].im = v2_make(na1.y, v2_y(Pn[d].im));
-                        Pn[pn].re = v2_make(v2_x(Pn[pn].re), nb1.x);
-                        Pn[pn].im = v2_make(v2_x(Pn[pn].im), nb1.y);
-                    }
+                    retangle(WaG[d], c_mul(om, c_conj(WbP[pn])), w1, naG[d], nbP[pn]);
+                    if (!selfg) retangle(WaP[pn], c_mul(om, c_conj(WbG[d])), w2, naP[pn], nbG[d]);
                 }
             });
+            c2 Pn[NC], Qn[NC];
+            if constexpr (PHASE != 1) {
+                static_for<NC>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    Pn[d] = c2_make(naG[d], selfg ? nbP[d] : nbG[d]);      // the middle group of an odd NG mirrors onto itself
+                    Qn[d] = c2_make(naP[d], nbP[d]);
+                });
+            }
             if constexpr (PHASE != 1) {
                 idftp<NC>(Pn);
                 if (!selfg) idftp<NC>(Qn);
