@@ -406,9 +406,15 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
     const bool act1 = hi < G::C1, act2 = hi < G::N1;
     const int myruns = (nruns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nseq = max(myruns, 0) * run;              // tiles this workgroup walks, in order
+    // Run r of a c2 row group takes the column blocks r, r + R, r + 2 R, ... (R = sw / run runs per group): the R workgroups
+    // that walk one group side by side then touch ADJACENT 128-byte strips of the same rows at the same time (DRAM page
+    // locality), instead of strips a whole run apart
+    const int R = max(sw / max(run, 1), 1);
     auto tile_of = [&](int sq) {
         const int k = sq / run, j = sq - k * run;
-        return tile0 + ((int)blockIdx.x + k * (int)gridDim.x) * run + j;
+        const int rid = (int)blockIdx.x + k * (int)gridDim.x;
+        const int grp = rid / R, r = rid - grp * R;
+        return tile0 + grp * (R * run) + r + j * R;
     };
     int* qtab = reinterpret_cast<int*>(twl + 2 * STRIP);
     if constexpr (MODE == 1) {
