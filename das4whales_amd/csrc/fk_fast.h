@@ -721,10 +721,10 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         tw2[i] = F.twB2[i];
     }
     __syncthreads();
-    auto ad = [](int e) { return e + e / NC; };
 
     // S1 / S1' item
     const int r1 = tid / M1, j1 = tid % M1;
+    const int aj1 = j1 + j1 / NC;                                // padded position of j1; of j1 + a M1: aj1 + a (M1 + NB)
     const bool it1 = tid < 2 * M1;
     float2 pf[NA];
     auto issue = [&](int2 pr) {
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
             float2* row = rows + r1 * ROWP;
             static_for<NA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
-                row[ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+                row[aj1 + a * (M1 + NB)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
             });
         }
         lds_barrier();
@@ -835,16 +835,17 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         for (int it = tid; it < nrows * NA * NC; it += THR) {
             const int r = it / (NA * NC), rem = it - r * (NA * NC);
             const int g = rem / NC, j2 = rem - g * NC;
+            const int gj2 = g * (M1 + NB) + j2;                  // padded position of (g, j2, b = 0): e + e / NC, j2 < NC
             float2* row = rows + r * ROWP;
             float2 v[NB];
             static_for<NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                v[b] = row[ad(g * M1 + j2 + b * NC)];
+                v[b] = row[gj2 + b * (NC + 1)];
             });
             dft<NB>(v);
             static_for<NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                row[ad(g * M1 + j2 + b * NC)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
+                row[gj2 + b * (NC + 1)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
             });
         }
         lds_barrier();
@@ -852,8 +853,8 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         if (midrange && (!same || PG >= Gi)) {
             const bool selfg = same && (PG == Gi);
             const bool rev0 = k1zero && (Gi == 0);           // partner digit (NC - d) % NC instead of NC-1-d
-            float2* ga = rows + ad(Gi * NC);
-            float2* gb = rows + (same ? 0 : ROWP) + ad(PG * NC);
+            float2* ga = rows + Gi * (NC + 1);
+            float2* gb = rows + (same ? 0 : ROWP) + PG * (NC + 1);
             float2 a[NC], b[NC];
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
@@ -925,17 +926,18 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         for (int it = tid; it < nrows * NA * NC; it += THR) {
             const int r = it / (NA * NC), rem = it - r * (NA * NC);
             const int g = rem / NC, j2 = rem - g * NC;
+            const int gj2 = g * (M1 + NB) + j2;                  // padded position of (g, j2, b = 0): e + e / NC, j2 < NC
             float2* row = rows + r * ROWP;
             float2 v[NB];
             static_for<NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                const float2 x = row[ad(g * M1 + j2 + b * NC)];
+                const float2 x = row[gj2 + b * (NC + 1)];
                 v[b] = (b == 0) ? x : c_mulc(x, tw2[b * NC + j2]);
             });
             idft<NB>(v);
             static_for<NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                row[ad(g * M1 + j2 + b * NC)] = v[b];
+                row[gj2 + b * (NC + 1)] = v[b];
             });
         }
         lds_barrier();
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
             const float2* row = rows + r1 * ROWP;
             static_for<NA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
-                const float2 x = row[ad(j1 + a * M1)];
+                const float2 x = row[aj1 + a * (M1 + NB)];
                 v[a] = (a == 0) ? x : c_mulc(x, pw[a]);
             });
             idft<NA>(v);

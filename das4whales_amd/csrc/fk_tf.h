@@ -57,7 +57,6 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
     }
     for (int i = tid; i < NC * NB; i += THR) ctab[i] = T.ctab[i];
     __syncthreads();
-    auto ad = [](int e) { return e + e / NC; };
     // column of frequency digits (d0, d1, d2) inside a sub-row block, -1: not kept
     auto cellcol = [&](int dd0, int dd1, int dd2) -> int {
         const int2 c = ctab[dd2 * NB + dd1];
@@ -65,6 +64,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
     };
 
     const int r1 = tid / M1, j1 = tid % M1;              // S1 / S1' item
+    const int aj1 = j1 + j1 / NC;                        // padded position of j1; of j1 + a M1: aj1 + a (M1 + NB)
     const bool it1 = tid < 2 * M1;
     const int Gi = tid;                                  // MID item
     const bool midrange = Gi < NG;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                 float2* row = rows + r1 * ROWP;
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    row[ad(j1 + a * M1)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+                    row[aj1 + a * (M1 + NB)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
                 });
             }
             lds_barrier();
@@ -150,16 +150,17 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             for (int it = tid; it < nrows * NA * NC; it += THR) {
                 const int r = it / (NA * NC), rem = it - r * (NA * NC);
                 const int g = rem / NC, j2 = rem - g * NC;
+                const int gj2 = g * (M1 + NB) + j2;              // padded position of (g, j2, b = 0): e + e / NC, j2 < NC
                 float2* row = rows + r * ROWP;
                 float2 v[NB];
                 static_for<NB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    v[b] = row[ad(g * M1 + j2 + b * NC)];
+                    v[b] = row[gj2 + b * (NC + 1)];
                 });
                 dft<NB>(v);
                 static_for<NB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    row[ad(g * M1 + j2 + b * NC)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
+                    row[gj2 + b * (NC + 1)] = (b == 0) ? v[0] : c_mul(v[b], tw2[b * NC + j2]);
                 });
             }
             lds_barrier();
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             if (midrange && (!same || PG >= Gi)) {
                 const bool selfg = same && (PG == Gi);
                 const bool rev0 = k1zero && (Gi == 0);
-                const float2* ga = rows + ad(Gi * NC);
-                const float2* gb = rows + (same ? 0 : ROWP) + ad(PG * NC);
+                const float2* ga = rows + Gi * (NC + 1);
+                const float2* gb = rows + (same ? 0 : ROWP) + PG * (NC + 1);
                 float2 a[NC], b[NC];
                 static_for<NC>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             if (midrange && (!same || PG >= Gi)) {
                 const bool selfg = same && (PG == Gi);
                 const bool rev0 = k1zero && (Gi == 0);
-                float2* ga = rows + ad(Gi * NC);
-                float2* gb = rows + (same ? 0 : ROWP) + ad(PG * NC);
+                float2* ga = rows + Gi * (NC + 1);
+                float2* gb = rows + (same ? 0 : ROWP) + PG * (NC + 1);
                 const float2 om = om_n, wr = wr_n;
                 float2 a[NC], b[NC], na[NC], nb[NC];
                 static_for<NC>([&](auto dd) {
@@ -313,17 +314,18 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             for (int it = tid; it < nrows * NA * NC; it += THR) {
                 const int r = it / (NA * NC), rem = it - r * (NA * NC);
                 const int g = rem / NC, j2 = rem - g * NC;
+                const int gj2 = g * (M1 + NB) + j2;              // padded position of (g, j2, b = 0): e + e / NC, j2 < NC
                 float2* row = rows + r * ROWP;
                 float2 v[NB];
                 static_for<NB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    const float2 x = row[ad(g * M1 + j2 + b * NC)];
+                    const float2 x = row[gj2 + b * (NC + 1)];
                     v[b] = (b == 0) ? x : c_mulc(x, tw2[b * NC + j2]);
                 });
                 idft<NB>(v);
                 static_for<NB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    row[ad(g * M1 + j2 + b * NC)] = v[b];
+                    row[gj2 + b * (NC + 1)] = v[b];
                 });
             }
             lds_barrier();
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                 const float2* row = rows + r1 * ROWP;
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    const float2 x = row[ad(j1 + a * M1)];
+                    const float2 x = row[aj1 + a * (M1 + NB)];
                     v[a] = (a == 0) ? x : c_mulc(x, pw[a]);
                 });
                 idft<NA>(v);
