@@ -727,7 +727,7 @@ struct d4w_fk_plan {
     int2* d_pairs_live = nullptr;          // [npairs] compacted list
     int npairs_run = 0;                    // pairs the specialised pass B runs
     int live_rows = 0;
-    int wgA = 1, wgC = 1, wgB = 1;
+    int wgA = 1, wgC = 1, wgB = 1, wgBi = 1;
     int slab_sw = 0;                       // > 0: passes A/C and C'/A' run slab by slab, sw column blocks per slab
     // time-first order (fk_tf.h): chosen per mask by fk_mask_finish when it moves fewer bytes than dead-row skipping
     bool tf = false;
@@ -1200,6 +1200,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         pl->wgA = env_int("D4W_FK_WG_A", fast->wgA);
         pl->wgC = env_int("D4W_FK_WG_C", fast->wgC);
         pl->wgB = env_int("D4W_FK_WG_B", fast->wgB);
+        pl->wgBi = pl->wgB;
         pl->slab_sw = env_int("D4W_FK_SLAB", 0);
     }
 #ifndef D4W_EMU
@@ -1227,6 +1228,17 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
                 (void)hipFuncSetAttribute((const void*)fast->Bt_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
                 (void)hipFuncSetAttribute((const void*)fast->Bt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
                 (void)hipFuncSetAttribute((const void*)fast->C_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+                // pass Bi holds no forward stage: fewer registers than B / Bf, so a CU may take one more workgroup of it than
+                // of those (20 000 x 120 000: 163 VGPRs -> three 4-wave workgroups, 3.54 -> 3.23 ms = the part's copy rate).
+                // Resident workgroups = what registers (512 per SIMD lane, granules of 8) and LDS (160 KiB) allow, at most 3 (4 measured slower).
+                hipFuncAttributes fa;
+                if (hipFuncGetAttributes(&fa, (const void*)fast->Bt_inv) == hipSuccess && fa.numRegs > 0) {
+                    const int waves_simd = 512 / (((int)fa.numRegs + 7) / 8 * 8);
+                    const int by_regs = waves_simd * 4 / std::max(1, (fast->thrB + 63) / 64);
+                    const int by_lds = (int)((160 * 1024) / std::max<size_t>(fast->ldsBt, 1));
+                    pl->wgBi = std::max(pl->wgB, std::min(3, std::min(by_regs, by_lds)));
+                }
+                pl->wgBi = env_int("D4W_FK_WG_BI", pl->wgBi);
             }
         }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
@@ -1643,7 +1655,8 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
             D4W_MARK(2);
             if (ntCm > 0 && (rc = launch_k(F.C_mid, gCm, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, T, 0, ntCm))) return rc;
             D4W_MARK(3);
-            if ((rc = launch_k(F.Bt_inv, gBt, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
+            const dim3 gBi(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgBi)));
+            if ((rc = launch_k(F.Bt_inv, gBi, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
             D4W_MARK(4);
             if (row_mean) {
                 const int run = stats_run(NBX), nruns = fA / run;
