@@ -91,6 +91,31 @@ __device__ __forceinline__ void pw_tree(float2 w1, float2 (&pw)[R]) {
     });
 }
 
+// The same powers handed to `f(a, w^a)`, a = 1 .. R-1, one at a time: w^a = (w^4)^(a / 4) w^(a % 4) from seven kept values
+// instead of an array of R (the tree above keeps all R powers live across the butterfly stores: 2 R registers; this form
+// 14, products at most three deep like the tree's).
+template <int R, class F>
+__device__ __forceinline__ void pw_each(float2 w1, F&& f) {
+    constexpr int NH = (R + 3) / 4;
+    float2 lo[4], hi[NH > 0 ? NH : 1];
+    lo[0] = make_float2(1.f, 0.f);
+    lo[1] = w1;
+    lo[2] = c_mul(w1, w1);
+    lo[3] = c_mul(lo[2], w1);
+    hi[0] = make_float2(1.f, 0.f);
+    if constexpr (NH > 1) hi[1] = c_mul(lo[2], lo[2]);
+    static_for<(NH > 2 ? NH - 2 : 0)>([&](auto kk) {
+        constexpr int k = decltype(kk)::value + 2;
+        hi[k] = c_mul(hi[k / 2], hi[k - k / 2]);
+    });
+    static_for<(R > 1 ? R - 1 : 0)>([&](auto aa) {
+        constexpr int a = decltype(aa)::value + 1;
+        if constexpr (a < 4) f(aa, lo[a]);
+        else if constexpr (a % 4 == 0) f(aa, hi[a / 4]);
+        else f(aa, c_mul(hi[a / 4], lo[a % 4]));
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass A forward: tile = (all c1) x (all n1) x TA columns of one c2.
 //   S1 item (n1, tt): DFT over c1 in the prefetch registers                       -> LDS
@@ -743,11 +768,12 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
     const int Gi = tid;
     const bool midrange = Gi < NG;
     int PGz = 0;
-    float2 wc[NC];
+    // column twiddle W_ns^(N1 k2) of the group's first position; digit d of the group adds NA NB d to k2, i.e. the literal
+    // rotation exp(-2 pi i d / (2 NC)) -- no per-thread table of NC twiddles
+    float2 wc0 = make_float2(1.f, 0.f);
     if (midrange) {
         PGz = P.mirror0[Gi * NC] / NC;
-        const float2* wcp = P.wcol + Gi * NC;
-        static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; wc[d] = wcp[d]; });
+        wc0 = P.wcol[Gi * NC];
     }
     struct MidOps {
         float ma[NC], mbr[NC];
@@ -816,12 +842,11 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         // ---------------- S1
         if (it1 && r1 < nrows) {
             dft<NA>(pf);
-            float2 pw[NA];
-            pw_tree<NA>(tw1[j1], pw);
             float2* row = rows + r1 * ROWP;
-            static_for<NA>([&](auto aa) {
-                constexpr int a = decltype(aa)::value;
-                row[aj1 + a * (M1 + NB)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+            row[aj1] = pf[0];
+            pw_each<NA>(tw1[j1], [&](auto aa, float2 w) {
+                constexpr int a = decltype(aa)::value + 1;
+                row[aj1 + a * (M1 + NB)] = c_mul(pf[a], w);
             });
         }
         lds_barrier();
@@ -863,6 +888,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
             });
             dft<NC>(a);
             dft<NC>(b);
+            const float2 w0 = c_mul(wr, wc0);
             float2 na[NC], nb[NC];                           // new A[d], new B[partner(d)]
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
@@ -871,7 +897,7 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
                 float mb = rev0 ? mbr[pz] : mbr[pn];
                 if (d == 0 && rev0) mb = nyq;
                 const float2 Bc = c_conj(bs);
-                const float2 w = c_mul(wr, wc[d]);
+                const float2 w = rot_const<d, 2 * NC>(w0);
                 const float2 E = c_scale(c_add(a[d], Bc), 0.5f);
                 const float2 O = c_mul_mi(c_scale(c_sub(a[d], Bc), 0.5f));
                 const float2 tO = c_mul(w, O);
@@ -944,13 +970,12 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passB(FkDev P, FkFast
         if (t + gstep < npairs) issue_mid(nxt, pr_nxt);       // next pair's MID operands, ahead of this pair's stores
         // ---------------- S1' -> global
         if (it1 && r1 < nrows) {
-            float2 v[NA], pw[NA];
-            pw_tree<NA>(tw1[j1], pw);
+            float2 v[NA];
             const float2* row = rows + r1 * ROWP;
-            static_for<NA>([&](auto aa) {
-                constexpr int a = decltype(aa)::value;
-                const float2 x = row[aj1 + a * (M1 + NB)];
-                v[a] = (a == 0) ? x : c_mulc(x, pw[a]);
+            v[0] = row[aj1];
+            pw_each<NA>(tw1[j1], [&](auto aa, float2 w) {
+                constexpr int a = decltype(aa)::value + 1;
+                v[a] = c_mulc(row[aj1 + a * (M1 + NB)], w);
             });
             idft<NA>(v);
             float2* o = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;

@@ -727,7 +727,7 @@ struct d4w_fk_plan {
     int2* d_pairs_live = nullptr;          // [npairs] compacted list
     int npairs_run = 0;                    // pairs the specialised pass B runs
     int live_rows = 0;
-    int wgA = 1, wgC = 1, wgB = 1, wgBi = 1;
+    int wgA = 1, wgC = 1, wgB = 1, wgBi = 1, wgBf = 1;
     int slab_sw = 0;                       // > 0: passes A/C and C'/A' run slab by slab, sw column blocks per slab
     // time-first order (fk_tf.h): chosen per mask by fk_mask_finish when it moves fewer bytes than dead-row skipping
     bool tf = false;
@@ -1111,6 +1111,8 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
                 if (keyB >= keyA) pairsT.push_back(make_int2((int)keyA, (int)keyB));
             }
         }
+        // sorted by sub-row: a workgroup's consecutive pairs then share the tail gains of their sub-row (fkf_passBt PHASE 1)
+        std::stable_sort(pairsT.begin(), pairsT.end(), [N1](const int2& a, const int2& b) { return a.x % N1 < b.x % N1; });
         pl->npairsT = (int)pairsT.size();
         D4W_TRY(upload(pl, pairsT, &pl->tfdev.pairs));
         void* q = nullptr;
@@ -1200,7 +1202,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         pl->wgA = env_int("D4W_FK_WG_A", fast->wgA);
         pl->wgC = env_int("D4W_FK_WG_C", fast->wgC);
         pl->wgB = env_int("D4W_FK_WG_B", fast->wgB);
-        pl->wgBi = pl->wgB;
+        pl->wgBi = pl->wgBf = pl->wgB;
         pl->slab_sw = env_int("D4W_FK_SLAB", 0);
     }
 #ifndef D4W_EMU
@@ -1228,18 +1230,25 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
                 (void)hipFuncSetAttribute((const void*)fast->Bt_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
                 (void)hipFuncSetAttribute((const void*)fast->Bt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
                 (void)hipFuncSetAttribute((const void*)fast->C_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
-                // pass Bi holds no forward stage: fewer registers than B / Bf, so a CU may take one more workgroup of it than
-                // of those (20 000 x 120 000: 163 VGPRs -> three 4-wave workgroups, 3.54 -> 3.23 ms = the part's copy rate).
-                // Resident workgroups = what registers (512 per SIMD lane, granules of 8) and LDS (160 KiB) allow, at most 3 (4 measured slower).
-                hipFuncAttributes fa;
-                if (hipFuncGetAttributes(&fa, (const void*)fast->Bt_inv) == hipSuccess && fa.numRegs > 0) {
-                    const int waves_simd = 512 / (((int)fa.numRegs + 7) / 8 * 8);
-                    const int by_regs = waves_simd * 4 / std::max(1, (fast->thrB + 63) / 64);
-                    const int by_lds = (int)((160 * 1024) / std::max<size_t>(fast->ldsBt, 1));
-                    pl->wgBi = std::max(pl->wgB, std::min(3, std::min(by_regs, by_lds)));
-                }
-                pl->wgBi = env_int("D4W_FK_WG_BI", pl->wgBi);
+                // (below) resident workgroups of the pass-B forms from what their registers and LDS allow
             }
+            // Pass B in its three forms is bound by VALU issue AND by what its few waves can overlap: a CU takes as many
+            // workgroups of each form as that form's registers (512 per SIMD lane, granules of 8) and LDS (160 KiB) allow,
+            // at most 3 (4 measured slower) -- at 20 000 x 120 000: fused B 161 VGPRs and Bi 150 -> three 4-wave workgroups
+            // (Bi 3.54 -> 3.2 ms, the part's copy rate), Bf 210 -> two.  The table's wgB is the floor.
+            auto resident = [&](const void* fn, size_t lds) {
+                hipFuncAttributes fa;
+                if (!fn || hipFuncGetAttributes(&fa, fn) != hipSuccess || fa.numRegs <= 0) return pl->wgB;
+                const int waves_simd = 512 / (((int)fa.numRegs + 7) / 8 * 8);
+                const int by_regs = waves_simd * 4 / std::max(1, (fast->thrB + 63) / 64);
+                const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
+                return std::max(pl->wgB, std::min(3, std::min(by_regs, by_lds)));
+            };
+            const int wg_floor = pl->wgB;
+            pl->wgBi = env_int("D4W_FK_WG_BI", resident((const void*)fast->Bt_inv, fast->ldsBt));
+            pl->wgBf = env_int("D4W_FK_WG_BF", resident((const void*)fast->Bt_fwd, fast->ldsBt));
+            if (!getenv("D4W_FK_WG_B")) pl->wgB = resident((const void*)fast->B_mid, fast->ldsB);
+            (void)wg_floor;
         }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
         if (!fast && lds_max > 64 * 1024) {
@@ -1647,11 +1656,12 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
             // time-first order (fk_tf.h): A, Bf (-> W), Cm (on W), Bi (W ->), A'
             const FkTfDev& T = pl->tfdev;
             const int ntCm = (d.N1 * (T.bw / d.TC) + (T.col_nyq >= 0 ? 1 : 0)) * d.C1;
-            const dim3 gBt(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgB))), gCm(std::max(1, std::min(ntCm, pl->num_cu * pl->wgC)));
+            const dim3 gCm(std::max(1, std::min(ntCm, pl->num_cu * pl->wgC)));
             D4W_MARK(0);
             if ((rc = launch_k(taper ? F.A_fwd_taper : F.A_fwd, gA, dim3(F.thrA), F.ldsA, stream, P, src, dst, 0, fA, NBX, 0, FkGeo()))) return rc;
             D4W_MARK(1);
-            if ((rc = launch_k(F.Bt_fwd, gBt, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
+            const dim3 gBf(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgBf)));
+            if ((rc = launch_k(F.Bt_fwd, gBf, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
             D4W_MARK(2);
             if (ntCm > 0 && (rc = launch_k(F.C_mid, gCm, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, T, 0, ntCm))) return rc;
             D4W_MARK(3);

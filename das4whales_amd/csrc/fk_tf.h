@@ -70,15 +70,15 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
     const bool midrange = Gi < NG;
     const int d0 = Gi / NB, d1 = Gi % NB;
     int PGz = 0;
-    float2 wc[NC];
+    // column twiddle W_ns^(N1 k2) of the group's first position; digit d adds the literal rotation exp(-2 pi i d / (2 NC))
+    float2 wc0 = make_float2(1.f, 0.f);
     int cxA[NC], cxB[NC];          // columns of the thread's own digits / of its partner group's (PG = NG-1-Gi) digits
     if (midrange) {
         PGz = P.mirror0[Gi * NC] / NC;
-        const float2* wcp = P.wcol + Gi * NC;
+        wc0 = P.wcol[Gi * NC];
         const int PGn = NG - 1 - Gi;
         static_for<NC>([&](auto dd) {
             constexpr int d = decltype(dd)::value;
-            wc[d] = wcp[d];
             cxA[d] = cellcol(d0, d1, d);
             cxB[d] = cellcol(PGn / NB, PGn % NB, d);
         });
@@ -100,30 +100,22 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                 });
             }
         };
-        struct MidOps {
-            float ma[NC], mbr[NC];
-            float2 wr, om;
-        };
-        MidOps cur, nxt;
-        auto issue_mid = [&](MidOps& O, int2 pr) {
+        // tail gains of the pair's two sub-rows at the thread's positions: the work list is sorted by sub-row, so a workgroup's
+        // consecutive pairs share them -- loaded when the sub-row changes (once in ~ nx / (2 grid) pairs), not per pair
+        float ma[NC], mbr[NC];
+        int q1_loaded = -1;
+        auto load_gains = [&](int q1A, int q1B) {
             if (!midrange) return;
-            const int rA = pr.x / G::N1, q1A = pr.x - rA * G::N1;
-            const int rB = pr.y / G::N1, q1B = pr.y - rB * G::N1;
             const int PG = (q1A == 0) ? PGz : (NG - 1 - Gi);
             const float* mA = T.tgain + q1A * N2;
             const float* mB = T.tgain + q1B * N2;
             static_for<NC>([&](auto dd) {
                 constexpr int d = decltype(dd)::value;
-                O.ma[d] = mA[(unsigned)(Gi * NC + d)];
-                O.mbr[d] = mB[(unsigned)(PG * NC + d)];
+                ma[d] = mA[(unsigned)(Gi * NC + d)];
+                mbr[d] = mB[(unsigned)(PG * NC + d)];
             });
-            O.wr = P.wrow[q1A];
-            O.om = c_mul(P.twc[rA], P.twc[rB]);
         };
-        if (t < npairs) {
-            issue_mid(cur, pr_cur);
-            issue(pr_cur);
-        }
+        if (t < npairs) issue(pr_cur);
         for (; t < npairs; t += gstep) {
             const int2 pr = pr_cur;
             int2 pr_nn = pr_cur;
@@ -136,12 +128,11 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             // ---------------- S1
             if (it1 && r1 < nrows) {
                 dft<NA>(pf);
-                float2 pw[NA];
-                pw_tree<NA>(tw1[j1], pw);
                 float2* row = rows + r1 * ROWP;
-                static_for<NA>([&](auto aa) {
-                    constexpr int a = decltype(aa)::value;
-                    row[aj1 + a * (M1 + NB)] = (a == 0) ? pf[0] : c_mul(pf[a], pw[a]);
+                row[aj1] = pf[0];
+                pw_each<NA>(tw1[j1], [&](auto aa, float2 w) {
+                    constexpr int a = decltype(aa)::value + 1;
+                    row[aj1 + a * (M1 + NB)] = c_mul(pf[a], w);
                 });
             }
             lds_barrier();
@@ -166,6 +157,10 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             lds_barrier();
             // ---------------- MID, first half: radix NC, untangle, x gain -> W
             const int PG = k1zero ? PGz : (NG - 1 - Gi);
+            if (q1A != q1_loaded) {
+                load_gains(q1A, q1B);
+                q1_loaded = q1A;
+            }
             if (midrange && (!same || PG >= Gi)) {
                 const bool selfg = same && (PG == Gi);
                 const bool rev0 = k1zero && (Gi == 0);
@@ -179,45 +174,41 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                 });
                 dft<NC>(a);
                 dft<NC>(b);
-                const float2 om = cur.om, wr = cur.wr;
+                const float2 om = c_mul(P.twc[rA], P.twc[rB]), wr = P.wrow[q1A];
+                const float2 w0 = c_mul(wr, wc0);
                 float2* WA = T.W + (size_t)rA * T.Lc + q1A * T.RW;          // the pair's sub-row blocks: wave-uniform bases
                 float2* WB = T.W + (size_t)rB * T.Lc + q1B * T.RW;
-                int cb[NC];
-                if (k1zero) {                                               // the k1 = 0 sub-row mirrors its groups differently
-                    const int pd0 = PGz / NB, pd1 = PGz - pd0 * NB;
-                    static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; cb[d] = cellcol(pd0, pd1, d); });
-                } else
-                    static_for<NC>([&](auto dd) { constexpr int d = decltype(dd)::value; cb[d] = cxB[d]; });
+                const int pd0 = PGz / NB, pd1 = PGz - pd0 * NB;            // the k1 = 0 sub-row mirrors its groups differently
                 static_for<NC>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     constexpr int pn = NC - 1 - d, pz = (NC - d) % NC;
                     const float2 bs = rev0 ? b[pz] : b[pn];
-                    const float gB = rev0 ? cur.mbr[pz] : cur.mbr[pn];
+                    const float gB = rev0 ? mbr[pz] : mbr[pn];
                     const float2 Bc = c_mul(om, c_conj(bs));
-                    const float2 w = c_mul(wr, wc[d]);
+                    const float2 w = rot_const<d, 2 * NC>(w0);
                     const float2 E = c_scale(c_add(a[d], Bc), 0.5f);
                     const float2 O = c_mul_mi(c_scale(c_sub(a[d], Bc), 0.5f));
                     const float2 tO = c_mul(w, O);
                     const float2 Yp = c_add(E, tO);              // X_A[f],      f = k1 + N1 k2(Gi, d)
                     const float2 Ym = c_sub(E, tO);              // X_A[f - M];  X_B[M - f] = omega conj(Ym)
-                    if (cxA[d] >= 0) WA[(unsigned)cxA[d]] = c_scale(Yp, cur.ma[d]);
+                    if (cxA[d] >= 0) WA[(unsigned)cxA[d]] = c_scale(Yp, ma[d]);
                     if (d == 0 && rev0) {                        // f = 0 and the Nyquist column of row A (and of row B)
                         if (T.col_nyq >= 0) (T.W + (size_t)rA * T.Lc)[T.col_nyq] = Ym;
                         if (!same) {
-                            if (cxA[d] >= 0) WB[(unsigned)cxA[d]] = c_scale(c_mul(om, c_conj(Yp)), cur.ma[d]);
+                            if (cxA[d] >= 0) WB[(unsigned)cxA[d]] = c_scale(c_mul(om, c_conj(Yp)), ma[d]);
                             if (T.col_nyq >= 0) (T.W + (size_t)rB * T.Lc)[T.col_nyq] = c_mul(om, c_conj(Ym));
                         }
                     } else if (!selfg) {
-                        const int cB = rev0 ? cb[pz] : cb[pn];
+                        int cB;
+                        if (k1zero) cB = cellcol(pd0, pd1, rev0 ? pz : pn);    // wave-uniform branch, 1 / N1 of the pairs
+                        else cB = cxB[pn];
                         if (cB >= 0) WB[(unsigned)cB] = c_scale(c_mul(om, c_conj(Ym)), gB);
                     }
                 });
             }
-            if (t + gstep < npairs) issue_mid(nxt, pr_nxt);
             lds_barrier();
             pr_cur = pr_nxt;
             pr_nxt = pr_nn;
-            cur = nxt;
         }
     } else {
         // ---------------------------------------------------------------- PHASE 2
@@ -268,12 +259,13 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
                 float2* ga = rows + Gi * (NC + 1);
                 float2* gb = rows + (same ? 0 : ROWP) + PG * (NC + 1);
                 const float2 om = om_n, wr = wr_n;
+                const float2 w0 = c_mul(wr, wc0);
                 float2 a[NC], b[NC], na[NC], nb[NC];
                 static_for<NC>([&](auto dd) {
                     constexpr int d = decltype(dd)::value;
                     const float2 Yp = Wp[d];
                     const float2 Ym = (d == 0 && rev0) ? Wm[d] : c_mul(om, c_conj(Wm[d]));
-                    const float2 w = c_mul(wr, wc[d]);
+                    const float2 w = rot_const<d, 2 * NC>(w0);
                     const float2 S = c_scale(c_add(Yp, Ym), 0.5f);
                     const float2 D = c_mul_pi(c_mulc(c_scale(c_sub(Yp, Ym), 0.5f), w));
                     na[d] = c_add(S, D);
@@ -331,13 +323,12 @@ __global__ __launch_bounds__(G::THRB, G::WAVES_B) void fkf_passBt(FkDev P, FkFas
             lds_barrier();
             // ---------------- S1' -> global
             if (it1 && r1 < nrows) {
-                float2 v[NA], pw[NA];
-                pw_tree<NA>(tw1[j1], pw);
+                float2 v[NA];
                 const float2* row = rows + r1 * ROWP;
-                static_for<NA>([&](auto aa) {
-                    constexpr int a = decltype(aa)::value;
-                    const float2 x = row[aj1 + a * (M1 + NB)];
-                    v[a] = (a == 0) ? x : c_mulc(x, pw[a]);
+                v[0] = row[aj1];
+                pw_each<NA>(tw1[j1], [&](auto aa, float2 w) {
+                    constexpr int a = decltype(aa)::value + 1;
+                    v[a] = c_mulc(row[aj1 + a * (M1 + NB)], w);
                 });
                 idft<NA>(v);
                 float2* o = data + (size_t)(r1 ? pr.y : pr.x) * N2 + j1;
