@@ -196,3 +196,42 @@ def test_pruned_mode_on_ocean_wave_block(dw):
           "bound gain x amplitude = %.3e" % (e_pruned, e_exact, g[1] * amp[1] / sc))
     assert e_pruned < TOL
     assert e_exact <= g[1] * amp[1] / sc + TOL            # the documented bound: dropped gain x amplitude of what sits there
+
+
+def test_pass_order_is_chosen_per_mask(dw):
+    """The planner models the bytes of both pass orders for every mask (include/d4w.h d4w_fk_plan_order): the scripts'
+    hybrid_ninf design runs time-first (band 4-44 Hz through the channel transform, Butterworth skirts as tail columns, the
+    rest never written) at ANY channel spacing; the classic fan and the sine-taper hybrid run channel-first with their dead
+    wavenumber rows skipped; with the opt-in tail pruning hybrid_ninf has dead rows too and goes back to channel-first; a
+    dense random mask stays channel-first.  Both orders give the same filter (the forced orders agree to float32 rounding)."""
+    import os
+    shape = (4000, 12000)
+    plan = dw.dsp.get_fk_plan(*shape)
+    x = torch.randn(shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    for step in (1, 4):
+        sel = [0, shape[0] * step, step]
+        ninf, _ = _design(dw, "hybrid_ninf", shape, sel)
+        plan.set_mask(ninf)
+        od = plan.order()
+        assert od["order"] == "time-first" and od["tail_columns"] > 0 and od["band_columns"] < 0.5 * od["half_spectrum_columns"], od
+        assert od["model_bytes_per_sample"]["time-first"] < 35.0 and od["model_bytes_per_sample"]["channel-first"] == 42.0
+        y_tf = plan.apply(x)
+        os.environ["D4W_FK_ORDER"] = "cf"
+        try:
+            plan.set_mask(ninf.tensor.clone())                    # a new tensor: not the cached fold
+            assert plan.order()["order"] == "channel-first"
+            y_cf = plan.apply(x)
+        finally:
+            del os.environ["D4W_FK_ORDER"]
+        assert float((y_tf - y_cf).abs().max()) < 2e-6 * float(y_cf.abs().max())
+    plan.set_mask(ninf, prune_eps=4e-6)
+    assert plan.order()["order"] == "channel-first" and plan.live_rows() < shape[0]
+    classic, _ = _design(dw, "classic", shape, [0, shape[0], 1])
+    plan.set_mask(classic)
+    assert plan.order()["order"] == "channel-first" and plan.live_rows() < shape[0] // 2
+    hyb = dw.dsp.hybrid_filter_design(shape, [0, shape[0], 1], DX, FS, 1350., 1450., 14., 30.)
+    plan.set_mask(hyb)
+    od = plan.order()
+    assert od["order"] == ("time-first" if od["model_bytes_per_sample"]["time-first"] < 0.97 * od["model_bytes_per_sample"]["channel-first"] else "channel-first")
+    plan.set_mask(torch.rand(shape, device="cuda"))
+    assert plan.order()["order"] == "channel-first" and plan.live_rows() == shape[0]
