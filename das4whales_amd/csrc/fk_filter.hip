@@ -621,6 +621,31 @@ __global__ __launch_bounds__(kThreads) void fk_gather_cmask(FkDims d, const floa
     }
 }
 
+// Liveness words of pass Cm (fk_tf.h): for tile (q, strip p0 .. p0 + TC) and radix-RB item g, bit b = the band mask of row
+// q C2 + g RB + b has a non-zero (or NaN) value in the strip.  One thread per (tile, g).
+__global__ __launch_bounds__(kThreads) void fk_cm_livebits(const float* __restrict__ cmask, int Lc, int C2, int RA, int RB, int TC, int N1,
+                                                            int nb1, int RW, int col_nyq, int ntiles, unsigned* __restrict__ live) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntiles * RA) return;
+    const int t = i / RA, g = i - t * RA;
+    const int tq = N1 * nb1 + (col_nyq >= 0 ? 1 : 0);
+    const int q = t / tq, u = t - q * tq;
+    int p0;
+    if (u < N1 * nb1) {
+        const int q1 = u / nb1;
+        p0 = q1 * RW + (u - q1 * nb1) * TC;
+    } else
+        p0 = col_nyq;
+    unsigned bits = 0u;
+    for (int b = 0; b < RB; ++b) {
+        const float* mp = cmask + ((size_t)q * C2 + (size_t)g * RB + b) * Lc + p0;
+        bool any = false;
+        for (int c = 0; c < TC; ++c) any |= !(mp[c] == 0.f);
+        if (any) bits |= 1u << b;
+    }
+    live[i] = bits;
+}
+
 __global__ __launch_bounds__(kThreads) void taper_rows(float* __restrict__ x, const float* __restrict__ win,
                                                         size_t total, int ns) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
@@ -739,6 +764,7 @@ struct d4w_fk_plan {
     int* d_colsrc = nullptr;               // [Lc] gather table: mask position of every column of W (-1 none, -2 Nyquist)
     float* d_cmask = nullptr;              // [nx][Lc] folded mask at the band columns
     float2* d_W = nullptr;                 // [nx][Lc] compact half spectrum (capacity cap_W elements, shared by the three)
+    unsigned* d_cmlive = nullptr;          // [Cm tiles][C2A] liveness words of the band mask
     size_t cap_W = 0;
     int tf_band_cols = 0, tf_tail_cols = 0;   // per row: band (incl. Nyquist) and tail columns kept
     double bytes_cf = 42.0, bytes_tf = 42.0;  // modelled bytes per channel-sample of the two orders for the current mask
@@ -833,6 +859,7 @@ int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
     if (pl->d_cmask) (void)hipFree(pl->d_cmask);
     if (pl->d_W) (void)hipFree(pl->d_W);
     if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
+    if (pl->d_cmlive) (void)hipFree(pl->d_cmlive);
     delete pl;
     return D4W_OK;
 }
@@ -1433,10 +1460,13 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
         if (pl->d_W) (void)hipFree(pl->d_W);
         if (pl->d_cmask) (void)hipFree(pl->d_cmask);
         if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
-        pl->d_W = nullptr; pl->d_cmask = nullptr; pl->d_colsrc = nullptr; pl->cap_W = 0;
+        if (pl->d_cmlive) (void)hipFree(pl->d_cmlive);
+        pl->d_W = nullptr; pl->d_cmask = nullptr; pl->d_colsrc = nullptr; pl->d_cmlive = nullptr; pl->cap_W = 0;
         if (hipMalloc((void**)&pl->d_W, need * sizeof(float2)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte compact spectrum failed", need * sizeof(float2));
         if (hipMalloc((void**)&pl->d_cmask, need * sizeof(float)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte band mask failed", need * sizeof(float));
         if (hipMalloc((void**)&pl->d_colsrc, ((size_t)M + 64 * (size_t)N1 + 64) * sizeof(int)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc failed");
+        // Cm tiles: at most C1 (N1 (N2 / TC + 2) + 1) whatever the mask
+        if (hipMalloc((void**)&pl->d_cmlive, (size_t)d.C1 * ((size_t)N1 * (N2 / TC + 2) + 1) * F.C2A * sizeof(unsigned)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc failed");
         pl->cap_W = need;
     }
     D4W_HIP(hipMemcpyAsync(pl->d_tgain, tgain.data(), (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1446,9 +1476,15 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
     if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
     D4W_LAUNCH(fk_gather_cmask, dim3(std::min(ceil_div(Lc, kThreads), 64), d.nx), dim3(kThreads), 0, stream, d,
                (const float*)pl->d_mask, (const float*)pl->d_nyq, (const int*)pl->d_colsrc, Lc, pl->d_cmask);
+    {
+        const int nb1 = bw / TC, ntCm = (N1 * nb1 + (nyq_live ? 1 : 0)) * d.C1;
+        if (ntCm > 0)
+            D4W_LAUNCH(fk_cm_livebits, dim3(ceil_div(ntCm * F.C2A, kThreads)), dim3(kThreads), 0, stream, (const float*)pl->d_cmask, Lc,
+                       d.C2, F.C2A, F.C2B, TC, N1, nb1, RW, nyq_live ? N1 * RW : -1, ntCm, pl->d_cmlive);
+    }
     D4W_HIP(hipStreamSynchronize(st));          // the host tables above are temporaries
     FkTfDev& T = pl->tfdev;
-    T.tgain = pl->d_tgain; T.ctab = pl->d_ctab; T.cmask = pl->d_cmask; T.W = pl->d_W;
+    T.tgain = pl->d_tgain; T.ctab = pl->d_ctab; T.cmask = pl->d_cmask; T.W = pl->d_W; T.cmlive = pl->d_cmlive;
     T.RW = RW; T.bw = bw;
     T.col_nyq = nyq_live ? N1 * RW : -1;
     T.Lc = Lc;

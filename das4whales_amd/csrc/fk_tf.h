@@ -30,6 +30,7 @@ struct FkTfDev {
     const int2* ctab;      // [NC][NB] {x = first column of the cell inside a sub-row block, y = cnt | class << 28}
     const float* cmask;    // [nx pos r][Lc] folded mask at the band columns (same indexing as W)
     float2* W;             // [nx][Lc] compact half spectrum
+    const unsigned* cmlive; // [Cm tiles][C2A] bit b = the band mask of row q C2 + g C2B + b is non-zero somewhere in the tile's strip
     int RW;                // columns of a sub-row block (a multiple of TC)
     int bw;                // band columns of a sub-row block, rounded up to a multiple of TC (they come first)
     int col_nyq;           // column of f = M (= N1 RW), -1: dead
@@ -384,13 +385,17 @@ __global__ __launch_bounds__(G::THRC) void fkf_passCm(FkDev P, FkFastDev F, FkTf
             pf[a] = bh[(size_t)(a * RB) * LC];
         });
     };
-    auto issue_mask = [&](int t) {
+    // The band mask of a tile is mostly zeros for the speed-fan designs (inside the band only the wavenumbers of the fan pass:
+    // ~6 of a thread's 32 rows): one word per (tile, g) says which rows to read, loaded a tile before the mask values
+    unsigned bits_nxt = 0xFFFFFFFFu;
+    auto issue_bits = [&](int t) { bits_nxt = T.cmlive[(size_t)t * RA + hi]; };
+    auto issue_mask = [&](int t, unsigned bits) {
         int q, p0;
         tile_qp(t, q, p0);
         const float* mp = T.cmask + ((size_t)q * G::C2 + (size_t)hi * RB) * LC + p0 + tt;
         static_for<RB>([&](auto bb) {
             constexpr int b = decltype(bb)::value;
-            mk[b] = mp[(size_t)b * LC];
+            mk[b] = ((bits >> b) & 1u) ? mp[(size_t)b * LC] : 0.f;
         });
     };
     const int gstep = gridDim.x;
@@ -426,7 +431,8 @@ __global__ __launch_bounds__(G::THRC) void fkf_passCm(FkDev P, FkFastDev F, FkTf
                 constexpr int b = decltype(bb)::value;
                 tile[(hi * (RB + 1) + b) * TC + tt] = v[b];
             });
-            if (t + gstep < ntiles) issue_mask(t + gstep);                // mk is free; ahead of this tile's stores
+            if (t + gstep < ntiles) issue_mask(t + gstep, bits_nxt);      // mk is free; ahead of this tile's stores
+            if (t + 2 * gstep < ntiles) issue_bits(t + 2 * gstep);
         }
         lds_barrier();
         if (actA) {
@@ -451,7 +457,11 @@ __global__ __launch_bounds__(G::THRC) void fkf_passCm(FkDev P, FkFastDev F, FkTf
     int t = tbase + blockIdx.x;
     if (t < ntiles && actA) issue(pfA, t);
     if (t + gstep < ntiles && actA) issue(pfB, t + gstep);
-    if (t < ntiles && actB) issue_mask(t);
+    if (t < ntiles && actB) {
+        issue_bits(t);
+        issue_mask(t, bits_nxt);
+        if (t + gstep < ntiles) issue_bits(t + gstep);
+    }
     for (; t < ntiles; t += 2 * gstep) {
         body(pfA, t);
         if (t + gstep < ntiles) body(pfB, t + gstep);

@@ -224,8 +224,15 @@ def test_pass_order_is_chosen_per_mask(dw):
         finally:
             del os.environ["D4W_FK_ORDER"]
         assert float((y_tf - y_cf).abs().max()) < 2e-6 * float(y_cf.abs().max())
+    # opt-in tail pruning: at 2.04 m spacing the fan leaves most wavenumber rows dead -> channel-first wins; at 8.17 m half
+    # of them stay alive and dropping the skirt columns time-first is cheaper -- whichever the model says
+    ninf1, _ = _design(dw, "hybrid_ninf", shape, [0, shape[0], 1])
+    plan.set_mask(ninf1, prune_eps=4e-6)
+    assert plan.order()["order"] == "channel-first" and plan.live_rows() < shape[0] // 4
     plan.set_mask(ninf, prune_eps=4e-6)
-    assert plan.order()["order"] == "channel-first" and plan.live_rows() < shape[0]
+    od = plan.order()
+    mb = od["model_bytes_per_sample"]
+    assert od["order"] == ("time-first" if mb["time-first"] < 0.97 * mb["channel-first"] else "channel-first") and od["tail_columns"] == 0
     classic, _ = _design(dw, "classic", shape, [0, shape[0], 1])
     plan.set_mask(classic)
     assert plan.order()["order"] == "channel-first" and plan.live_rows() < shape[0] // 2
