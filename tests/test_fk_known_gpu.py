@@ -242,3 +242,44 @@ def test_pass_order_is_chosen_per_mask(dw):
     assert od["order"] == ("time-first" if od["model_bytes_per_sample"]["time-first"] < 0.97 * od["model_bytes_per_sample"]["channel-first"] else "channel-first")
     plan.set_mask(torch.rand(shape, device="cuda"))
     assert plan.order()["order"] == "channel-first" and plan.live_rows() == shape[0]
+
+
+@pytest.mark.parametrize("nx,ns", [(96, 480), (4000, 12000), (5510, 12000), (11020, 12000), (8000, 12000), (600, 120000)])
+def test_time_first_equals_channel_first_on_every_kernel_configuration(dw, nx, ns):
+    """Built-in and compiled-on-demand configurations (different radix triples, even and odd N1, prime c2 radices): a mask
+    with band, wavenumber-independent skirt and zero columns through both pass orders -- same output to float32 rounding,
+    and against the float64 oracle where it is cheap."""
+    import os
+    dw.dsp.compile_fk_shape(nx, ns)
+    g = torch.Generator(device="cuda").manual_seed(nx + ns)
+    x = torch.randn((nx, ns), device="cuda", generator=g)
+    fb = torch.abs(torch.arange(ns, device="cuda") - ns // 2)                    # |f bin| of the shifted columns
+    lo, hi, tail_to = ns // 20, ns // 7, ns // 4
+    m = torch.zeros((nx, ns), device="cuda")
+    band = (fb >= lo) & (fb < hi)
+    m[:, band] = torch.rand((nx, int(band.sum())), device="cuda", generator=g)
+    tail = (fb >= hi) & (fb < tail_to)
+    m[:, tail] = (1e-3 * torch.exp(-(fb[tail] - hi).float() / (0.02 * ns)))[None, :]
+    plan = dw.dsp.FkPlan(nx, ns)
+    outs = {}
+    for order in ("tf", "cf"):
+        os.environ["D4W_FK_ORDER"] = order
+        try:
+            plan.set_mask(m.clone())
+            od = plan.order()
+            outs[order] = plan.apply(x, taper=True)
+        finally:
+            del os.environ["D4W_FK_ORDER"]
+        if order == "tf":
+            assert od["order"] == "time-first" and od["tail_columns"] > 0 and od["band_columns"] + od["tail_columns"] < ns // 2, od
+        else:
+            assert od["order"] == "channel-first"
+    scale = float(outs["cf"].abs().max())
+    err = float((outs["tf"] - outs["cf"]).abs().max()) / scale
+    print("%d x %d: time-first vs channel-first %.3e" % (nx, ns, err))
+    assert err < 3e-6
+    if nx * ns <= 4000 * 12000:
+        ref = orc.fk_filter_filt(x.cpu().numpy().astype(np.float64), m.cpu().numpy().astype(np.float64), tapering=True)
+        e2 = float(np.max(np.abs(outs["tf"].cpu().numpy() - ref)) / np.max(np.abs(ref)))
+        print("%d x %d: time-first vs oracle %.3e" % (nx, ns, e2))
+        assert e2 < TOL
