@@ -218,6 +218,21 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         ev[3].synchronize()
         for k, (a_, b_) in {"fk_filter": (0, 1), "matched_filter": (1, 2), "all_gather": (2, 3)}.items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ev[a_].elapsed_time(ev[b_]) / 3
+        if "mf" in stages:
+            # what a deployment would gather instead of the 9.6-GB t-x matrix: the envelope picks of the local
+            # correlograms, reassembled with global channel indices on every rank -- timed beside the step, not inside it
+            cg = ddet._xcorr_device(y, tpl, normalize=True, stats=st)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            pk = [ddet.pick_times_env(c_, 0.45 * float(c_.max())) for c_ in cg]
+            e1.record()
+            tabs = [shard.all_gather_picks(p_.packed, a) for p_ in pk]
+            e2.record()
+            e2.synchronize()
+            stage_ms["picks_env_local"] = stage_ms.get("picks_env_local", 0.0) + e0.elapsed_time(e1) / 3
+            stage_ms["all_gather_picks"] = stage_ms.get("all_gather_picks", 0.0) + e1.elapsed_time(e2) / 3
+            stage_ms["picks_gathered"] = int(sum(t_.shape[1] for t_ in tabs))
+            del cg, pk, tabs
         for (l0, e0), (l1, e1) in zip(plan.marks[:-1], plan.marks[1:]):
             stage_ms["fk:" + l1] = stage_ms.get("fk:" + l1, 0.0) + e0.elapsed_time(e1) / 3
     plan.marks = None

@@ -65,6 +65,46 @@ def test_all_gather_rows_world2(nx, ns):
     assert blocks[0][0] == 0 and blocks[0][1] == blocks[1][0] and blocks[1][1] == nx
 
 
+def _picks_worker(rank, world, port, nx, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        shard = _load_shard()
+        rng = np.random.default_rng(11)                             # same picks on every rank
+        rows = [np.sort(rng.choice(5000, size=int(rng.integers(0, 9)), replace=False)) for _ in range(nx)]
+        if rank == 1:
+            pass
+        a, b = shard.channel_block(nx, world, rank)
+        loc = rows[a:b]
+        ch = np.concatenate([np.full(len(p), i, dtype=np.int64) for i, p in enumerate(loc)]) if loc else np.zeros(0, dtype=np.int64)
+        tt = np.concatenate(loc) if loc else np.zeros(0, dtype=np.int64)
+        got = shard.all_gather_picks(torch.from_numpy(np.stack((ch, tt)).astype(np.int64)), a)
+        ref_ch = np.concatenate([np.full(len(p), i, dtype=np.int64) for i, p in enumerate(rows)])
+        ref = np.stack((ref_ch, np.concatenate(rows)))
+        q.put((rank, bool(np.array_equal(got.numpy(), ref))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nx", [(2, 11), (3, 7)])
+def test_all_gather_picks(world, nx):
+    """The picks of a channel-sharded block reassembled with global channel indices, in channel order (uneven blocks,
+    ranks without picks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_picks_worker, args=(r, world, port, nx, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def test_channel_block_partition():
     shard = _load_shard()
     for nx in (1, 7, 8, 20000, 11020):
