@@ -66,6 +66,7 @@ struct FkFastEntry {
     void (*T_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);          // pass A MODE 1 (time phase)
     void (*T_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
     void (*T_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
+    void (*T_inv_env)(FkDev, float2*, int, int, int, int, FkGeo, const float2*, const float2*, int, const float*);   // + analytic-signal epilogue
     void (*Ac_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);         // pass A MODE 2 (c1 transform on the slab)
     void (*Ac_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
     void (*Cs_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);             // pass C on the slab
@@ -100,6 +101,7 @@ static inline FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0)
     e.T_fwd = fkf_passA_fwd<G, false, 1>;
     e.T_fwd_taper = fkf_passA_fwd<G, true, 1>;
     e.T_inv = fkf_passA_inv<G, 1>;
+    e.T_inv_env = fkf_passA_inv_env<G>;
     e.Ac_fwd = fkf_passA_fwd<G, false, 2>;
     e.Ac_inv = fkf_passA_inv<G, 2>;
     e.Cs_fwd = fkf_passC<G, false, 1>;

@@ -408,6 +408,129 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
     }
 }
 
+// Inverse time phase of REAL rows (fkf_passA_inv MODE 1: C1 consecutive local rows per tile, input from the packed buffer, no
+// channel transform) whose epilogue forms the analytic-signal quantity from H[x] and x instead of storing H[x] for a separate
+// combine pass (d4w_analytic_long_f32: 36 -> 28 bytes per sample).  mode 0: |x + i H|; 2: 10 log10(|z|^2 / var[row]);
+// 4: |z| / sqrt(var[row]).  The tile's x samples are loaded ONE TILE AHEAD, after the current tile's values are formed and
+// before its stores go out (a load issued after the stores would wait for their acknowledgement).
+template <class G>
+__global__ __launch_bounds__(G::THRA) void fkf_passA_inv_env(FkDev P, float2* __restrict__ out, int tbase, int ntiles, int sw, int sbase,
+                                                             FkGeo geo, const float2* __restrict__ packed, const float2* __restrict__ xsrc,
+                                                             int mode, const float* __restrict__ var) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    float2* twl = tile + G::C1 * G::N1 * G::TA;
+    constexpr int STRIP = G::N1 * G::TA;
+    const int tid = threadIdx.x;
+    const int hi = tid / G::TA, tt = tid % G::TA;      // hi = row within the tile (S1') or n1 (S2'); also q1 for the strip
+    const bool act1 = hi < G::C1, act2 = hi < G::N1;
+    const int gstep = gridDim.x;
+    typedef FkPrefetchA<G::N1> Pre;
+    Pre A, B;
+    int* qtab = reinterpret_cast<int*>(twl + 2 * STRIP);
+    for (int i = tid; i < G::N1; i += G::THRA) {
+        qtab[i] = geo.q1_off[i];
+        qtab[G::N1 + i] = geo.q1_pitch[i];
+    }
+    __syncthreads();
+    auto issue = [&](Pre& R, int t) {
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
+        if (act2) R.tw = P.twt[hi * G::N2 + b0 + tt];
+        if (act1) {
+            const int row = c2 * G::C1 + hi;
+            const bool ok = row < geo.nrows;
+            static_for<G::N1>([&](auto kk) {
+                constexpr int q1 = decltype(kk)::value;
+                R.pf[q1] = ok ? packed[(size_t)qtab[q1] + (size_t)row * qtab[G::N1 + q1] + b0 + tt] : make_float2(0.f, 0.f);
+            });
+        }
+    };
+    float2 xv[G::C1];                                   // x of the tile's output positions (S2' item: n1 = hi, column tt)
+    auto issue_x = [&](int t) {
+        if (!act2) return;
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
+        const float2* xp = xsrc + (size_t)c2 * G::C1 * G::M + hi * G::N2 + b0 + tt;
+        static_for<G::C1>([&](auto cc) {
+            constexpr int c1 = decltype(cc)::value;
+            xv[c1] = (c2 * G::C1 + c1 < geo.nrows) ? xp[(size_t)c1 * G::M] : make_float2(0.f, 0.f);
+        });
+    };
+    int par = 0;
+    auto body = [&](Pre& R, Pre& Rn, int t, bool first) {
+        const int c2 = t / sw, b0 = (sbase + t % sw) * G::TA;
+        const float2* tw_cur = twl + par * STRIP;
+        const bool more = (t + gstep < ntiles);
+        if (first) {
+            if (act2) twl[par * STRIP + hi * G::TA + tt] = R.tw;
+            __syncthreads();
+        }
+        if (more && act2) twl[(par ^ 1) * STRIP + hi * G::TA + tt] = Rn.tw;
+        if (act1) {
+            static_for<G::N1>([&](auto kk) {
+                constexpr int q1 = decltype(kk)::value;
+                R.pf[q1] = c_mulc(R.pf[q1], tw_cur[q1 * G::TA + tt]);
+            });
+            idft<G::N1>(R.pf);
+            static_for<G::N1>([&](auto kk) {
+                constexpr int n1 = decltype(kk)::value;
+                tile[(hi * G::N1 + n1) * G::TA + tt] = R.pf[n1];
+            });
+        }
+        lds_barrier();
+        if (t + 2 * gstep < ntiles) issue(R, t + 2 * gstep);
+        float2 v[G::C1];
+        if (act2) {
+            static_for<G::C1>([&](auto cc) {
+                constexpr int q = decltype(cc)::value;
+                v[q] = tile[(q * G::N1 + hi) * G::TA + tt];
+            });
+        }
+        lds_barrier();
+        if (act2) {
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                const float2 h = c_scale(v[c1], P.scale);
+                const float2 x2 = xv[c1];
+                float ex = fmaf(x2.x, x2.x, h.x * h.x), ey = fmaf(x2.y, x2.y, h.y * h.y);
+                if (mode == 0) {
+                    ex = sqrtf(ex);
+                    ey = sqrtf(ey);
+                } else {
+                    const int row = min(c2 * G::C1 + c1, geo.nrows - 1);
+                    const float iv = 1.0f / var[row];
+                    if (mode == 2) {
+                        ex = 10.0f * log10f(ex * iv);
+                        ey = 10.0f * log10f(ey * iv);
+                    } else {
+                        ex = sqrtf(ex * iv);
+                        ey = sqrtf(ey * iv);
+                    }
+                }
+                v[c1] = make_float2(ex, ey);
+            });
+            if (more) issue_x(t + gstep);                 // xv is free: next tile's x, ahead of this tile's stores
+            float2* o = out + (size_t)c2 * G::C1 * G::M + hi * G::N2 + b0 + tt;
+            static_for<G::C1>([&](auto cc) {
+                constexpr int c1 = decltype(cc)::value;
+                if (c2 * G::C1 + c1 < geo.nrows) o[(size_t)c1 * G::M] = v[c1];
+            });
+        }
+        par ^= 1;
+    };
+    int t = tbase + blockIdx.x;
+    if (t < ntiles) {
+        issue(A, t);
+        issue_x(t);
+    }
+    if (t + gstep < ntiles) issue(B, t + gstep);
+    bool first = true;
+    for (; t < ntiles; t += 2 * gstep) {
+        body(A, B, t, first);
+        first = false;
+        if (t + gstep < ntiles) body(B, A, t + gstep, false);
+    }
+}
+
 // pass A inverse with the row statistics of the filtered block in its epilogue (what the matched filter
 // normalises by, detect.py:157: mean and max|.| of every output row), so the consumer does not re-read
 // the block for them.  A thread's S2' item holds one packed sample of every c1 row; the tile order is

@@ -1247,7 +1247,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             (void)hipFuncSetAttribute((const void*)fast->C_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->B_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsB);
             const void* fa[] = {(const void*)fast->T_fwd, (const void*)fast->T_fwd_taper, (const void*)fast->T_inv, (const void*)fast->T_inv_stats,
-                                (const void*)fast->Ac_fwd, (const void*)fast->Ac_inv};
+                                (const void*)fast->Ac_fwd, (const void*)fast->Ac_inv, (const void*)fast->T_inv_env};
             for (const void* f : fa) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsA);
             (void)hipFuncSetAttribute((const void*)fast->Cs_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
             (void)hipFuncSetAttribute((const void*)fast->Cs_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
@@ -3317,6 +3317,12 @@ int d4w_analytic_long_f32(const float* x, float* y, int nx, int ns, int mode, co
             gb.nq = d.N1;
             const dim3 gB(std::max(1, std::min(fp->npairs_self, fp->num_cu * fp->sp->wgB)));
             if ((rc = launch_k(F.Bs_hilb, gB, dim3(F.thrB), F.ldsB, stream, dv, fd, h2, 0, fp->npairs_self, gb))) return rc;
+            static const int fuse_env = [] { const char* v = getenv("D4W_LONG_FUSE"); return v ? atoi(v) : 1; }();
+            if (mode == 1)                                         // H[x] itself: the inverse pass writes it where it belongs
+                return launch_k(F.T_inv, gA, dim3(F.thrA), F.ldsA, stream, dv, reinterpret_cast<float2*>(y), 0, nt, NBX, 0, geo, (const float2*)h2);
+            if (mode != 3 && fuse_env)                             // |z|, SNR, |z| / std: formed in the inverse pass's epilogue (28 B / sample)
+                return launch_k(F.T_inv_env, gA, dim3(F.thrA), F.ldsA, stream, dv, reinterpret_cast<float2*>(y), 0, nt, NBX, 0, geo,
+                                (const float2*)h2, reinterpret_cast<const float2*>(x), mode, var);
             if ((rc = launch_k(F.T_inv, gA, dim3(F.thrA), F.ldsA, stream, dv, h2, 0, nt, NBX, 0, geo, (const float2*)h2))) return rc;
             const float fscale = (float)(fs / (2.0 * M_PI));
             D4W_LAUNCH(analytic_combine, dim3(std::min(ceil_div(ns, kThreads), 128), nx), dim3(kThreads), 0, stream, x,
