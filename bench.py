@@ -733,6 +733,9 @@ def main():
                     "fk_algorithmic_frac": 24.0 * samples / (float(accm.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
         if not args.no_dense:
+            # the step's own mask once more WITHOUT the row-statistics epilogue the matched filter asks of the last pass
+            # (fk_algorithmic_frac above includes it): the f-k filter alone, like the blocks that follow
+            roofline["fk_classic"] = time_mask(dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs))
             # a fully dense mask (nothing skipped) and the design every reference script uses,
             # hybrid_ninf_filter_design(1350, 1450, 3300, 3450, 14, 30) (scripts/main_mfdetect.py:46-47), exact and
             # with the opt-in tail pruning (rows whose folded gain stays below prune_eps * max are treated as dead)
