@@ -1024,272 +1024,6 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
     }
 }
 
-// The same transform with the two templates ONE AFTER THE OTHER in a single row buffer: 256 threads run the forward stages,
-// read their middle-stage groups of the block spectrum into registers (two groups of 4 packed values: 32 VGPRs kept), and
-// then carry template 0 and template 1 in turn through pair op, inverse stages and stores, in place.  One 37-KiB buffer
-// instead of two: FOUR workgroups per CU instead of two, none of them with an idle half during the forward stages
-// (twelve 256-thread phases per block instead of eight 512-thread ones of which three run half empty).
-template <bool CONT>
-__global__ __launch_bounds__(kX4Items, 4) void xcorr_fft_seq4(X4Tables T, const float* __restrict__ x, int nx, int ns,
-                                                                    const float* __restrict__ mean,
-                                                                    const float* __restrict__ maxabs,
-                                                                    float* __restrict__ y0, float* __restrict__ y1,
-                                                                    const float* __restrict__ xnext, int ld_next, int n_next) {
-    constexpr int MB = kXfMB, ROWP = kX4RowP;
-    D4W_DYN_LDS(smem_raw);
-    float4* buf = reinterpret_cast<float4*>(smem_raw);            // [ROWP] block spectrum, then each template's correlation in turn
-    float2* tw2 = reinterpret_cast<float2*>(buf + ROWP);          // [8][32]
-    float2* tw3 = tw2 + 256;                                      // [8][4]
-    const int tid = (int)threadIdx.x;
-    constexpr bool fwd = true;
-    float4* mine = buf;
-    tw2[tid] = T.tw2[tid];
-    if (tid < 32) tw3[tid] = T.tw3[tid];
-    const int rowA = 2 * blockIdx.y;
-    const bool hasB = rowA + 1 < nx;
-    const int rowB = hasB ? rowA + 1 : rowA;
-    const int k0 = blockIdx.x * kXfStep;
-    const float* xa = x + (size_t)rowA * ns;
-    const float* xb = x + (size_t)rowB * ns;
-    const float mua = mean ? mean[rowA] : 0.f, mub = mean ? mean[rowB] : 0.f;
-    float ga_ = 1.f, gb_ = 1.f;
-    if (maxabs) {
-        const float a = maxabs[rowA], b = maxabs[rowB];
-        ga_ = (a > 0.f) ? 1.0f / a : 0.f;
-        gb_ = (b > 0.f) ? 1.0f / b : 0.f;
-    }
-    const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
-    const bool veca = ((((size_t)rowA * ns + k0) & 1) == 0), vecb = ((((size_t)rowB * ns + k0) & 1) == 0);
-    const bool interior = (k0 + kXfB <= ns) && veca && vecb;
-    // ---------------- S1: radix 8 on the packed samples z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = tid + 256 q
-    c2 pf[8];
-    float2 pw[8];
-    if (fwd) {
-        // beyond the row: the first n_next samples of the record's continuation (the next file's rows, pitch ld_next),
-        // de-meaned like the row's own samples, then zeros
-        auto sample = [&](const float* xr, const float* xn, float mu, int i) -> float {
-            if (i < ns) return xr[i] - mu;
-            if (CONT && i - ns < n_next) return xn[i - ns] - mu;
-            return 0.f;
-        };
-        auto fetch = [&](const float* xr, const float* xn, float mu, bool vec, int i) -> float2 {
-            if (vec && i + 1 < ns) {
-                float2 v = *reinterpret_cast<const float2*>(xr + i);
-                v.x -= mu;
-                v.y -= mu;
-                return v;
-            }
-            return make_float2(sample(xr, xn, mu, i), sample(xr, xn, mu, i + 1));
-        };
-        const float* xna = CONT ? xnext + (size_t)rowA * ld_next : nullptr;
-        const float* xnb = CONT ? xnext + (size_t)rowB * ld_next : nullptr;
-        if (interior) {
-            const float2* pa = reinterpret_cast<const float2*>(xa + k0) + tid;
-            const float2* pb = reinterpret_cast<const float2*>(xb + k0) + tid;
-            const v2f mu2 = v2_make(mua, mub);
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const float2 va = pa[q * 256], vb = pb[q * 256];
-                pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
-            });
-        } else if (veca && vecb && ns >= 4) {
-            // the last block of a row (a quarter of all blocks for 12 000-sample rows): the samples still inside the row go out
-            // as 8-byte loads together (clamped addresses), the ones beyond it are fetched one by one afterwards
-            const v2f mu2 = v2_make(mua, mub);
-            const int par = k0 & 1;
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const int i = k0 + 2 * (tid + q * 256), ic = par + (min(max(i - par, 0), ns - 2 - par) & ~1);
-                const float2 va = *reinterpret_cast<const float2*>(xa + ic);
-                const float2 vb = *reinterpret_cast<const float2*>(xb + ic);
-                pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
-            });
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const int i = k0 + 2 * (tid + q * 256);
-                if (i + 1 >= ns) pf[q] = c2_make(fetch(xa, xna, mua, veca, i), fetch(xb, xnb, mub, vecb, i));
-            });
-        } else {
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const int i = k0 + 2 * (tid + q * 256);
-                pf[q] = c2_make(fetch(xa, xna, mua, veca, i), fetch(xb, xnb, mub, vecb, i));
-            });
-        }
-        static_for<7>([&](auto qq) {
-            constexpr int q = decltype(qq)::value + 1;
-            pw[q] = T.tw1[q * 256 + tid];
-        });
-    }
-    __syncthreads();                                              // LDS twiddle tables visible
-    if (fwd) {
-        dftp<8>(pf);
-        static_for<8>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            xf_st(buf + x4_ad(tid + q * 256), (q == 0) ? pf[0] : c2_mulw(pf[q], pw[q]));
-        });
-    }
-    const int2 grp = T.pairs[tid];
-    const int Gi = grp.x, PG = grp.y;
-    const bool selfitem = (tid == kX4Items - 1);
-    const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];
-    lds_barrier();
-    // ---------------- S2: radix 8 inside every block of 256, x W_256^(j q)
-    if (fwd) {
-        const int e0 = (tid >> 5) * 256 + (tid & 31), j = tid & 31;
-        c2 v[8];
-        static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; v[q] = xf_ld(buf + x4_ad(e0 + q * 32)); });
-        dftp<8>(v);
-        static_for<8>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            xf_st(buf + x4_ad(e0 + q * 32), (q == 0) ? v[0] : c2_mulw(v[q], tw2[q * 32 + j]));
-        });
-    }
-    lds_barrier();
-    // ---------------- S3: radix 8 inside every block of 32, x W_32^(j q)
-    if (fwd) {
-        const int e0 = (tid >> 2) * 32 + (tid & 3), j = tid & 3;
-        c2 v[8];
-        static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; v[q] = xf_ld(buf + x4_ad(e0 + q * 4)); });
-        dftp<8>(v);
-        static_for<8>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            xf_st(buf + x4_ad(e0 + q * 4), (q == 0) ? v[0] : c2_mulw(v[q], tw3[q * 4 + j]));
-        });
-    }
-    lds_barrier();
-    // ---------------- MID: radix 4 on a group and its Hermitian partner group -- kept for both templates
-    c2 a[4], b[4];
-    static_for<4>([&](auto dd) {
-        constexpr int d = decltype(dd)::value;
-        a[d] = xf_ld(buf + x4_ad(Gi * 4 + d));
-        b[d] = xf_ld(buf + x4_ad(PG * 4 + d));
-    });
-    dftp<4>(a);
-    dftp<4>(b);
-    lds_barrier();                                                // every read of the spectrum precedes the in-place writes
-#pragma unroll 1
-    for (int tsel = 0; tsel < 2; ++tsel) {                        // one pass per template, NOT unrolled: the two passes must not
-        float2 GA[4], GB[4];                                      // interleave (registers), and the code stays half the size
-        {
-            const float2* gpa = T.gp + (size_t)tsel * MB + Gi * 4;
-            const float2* gpb = T.gp + (size_t)tsel * MB + PG * 4;
-            static_for<4>([&](auto dd) {
-                constexpr int d = decltype(dd)::value;
-                GA[d] = gpa[d];
-                GB[d] = gpb[d];
-            });
-        }
-        const float gny = T.gn[tsel];
-        {
-            c2 ra[4], rb[4];
-            if (!selfitem) {
-                static_for<4>([&](auto dd) {
-                    constexpr int d = decltype(dd)::value;
-                    constexpr int pn = 3 - d;
-                    xf_pair(a[d], b[pn], rot_const<d, 8>(wa0), GA[d], GB[pn], ra[d], rb[pn]);
-                });
-            } else {
-                // group 0 (array a): partner digit (4 - d) % 4, f = 0 pairs with the Nyquist bin; group 4 (array b): 3 - d
-                static_for<3>([&](auto dd) {
-                    constexpr int d = decltype(dd)::value;
-                    constexpr int pz = (4 - d) % 4;
-                    const float2 gm = (d == 0) ? make_float2(gny, 0.f) : GA[pz];
-                    c2 na;
-                    xf_pair(a[d], a[pz], rot_const<d, 8>(wa0), GA[d], gm, na, ra[pz]);
-                    if constexpr (pz != d) ra[d] = na;
-                });
-                static_for<2>([&](auto dd) {
-                    constexpr int d = decltype(dd)::value;
-                    constexpr int pn = 3 - d;
-                    xf_pair(b[d], b[pn], rot_const<d, 8>(wb0), GB[d], GB[pn], rb[d], rb[pn]);
-                });
-            }
-            idftp<4>(ra);
-            idftp<4>(rb);
-            static_for<4>([&](auto dd) {
-                constexpr int d = decltype(dd)::value;
-                xf_st(mine + x4_ad(Gi * 4 + d), ra[d]);
-                xf_st(mine + x4_ad(PG * 4 + d), rb[d]);
-            });
-        }
-        lds_barrier();
-        float2 pwi[8];
-        static_for<7>([&](auto qq) {
-            constexpr int q = decltype(qq)::value + 1;
-            pwi[q] = T.tw1[q * 256 + tid];                       // for S1', in flight across S3' / S2'
-        });
-        // ---------------- S3', S2': inverse radix 8
-        {
-            const int e0 = (tid >> 2) * 32 + (tid & 3), j = tid & 3;
-            c2 v[8];
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const c2 xv = xf_ld(mine + x4_ad(e0 + q * 4));
-                v[q] = (q == 0) ? xv : c2_mulwc(xv, tw3[q * 4 + j]);
-            });
-            idftp<8>(v);
-            static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; xf_st(mine + x4_ad(e0 + q * 4), v[q]); });
-        }
-        lds_barrier();
-        {
-            const int e0 = (tid >> 5) * 256 + (tid & 31), j = tid & 31;
-            c2 v[8];
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const c2 xv = xf_ld(mine + x4_ad(e0 + q * 32));
-                v[q] = (q == 0) ? xv : c2_mulwc(xv, tw2[q * 32 + j]);
-            });
-            idftp<8>(v);
-            static_for<8>([&](auto qq) { constexpr int q = decltype(qq)::value; xf_st(mine + x4_ad(e0 + q * 32), v[q]); });
-        }
-        lds_barrier();
-        // ---------------- S1': inverse radix 8 -> lags k0 + 2m, k0 + 2m + 1 (m = tid + 256 q), the first kXfStep of them
-        {
-            c2 v[8];
-            static_for<8>([&](auto qq) {
-                constexpr int q = decltype(qq)::value;
-                const c2 xv = xf_ld(mine + x4_ad(tid + q * 256));
-                v[q] = (q == 0) ? xv : c2_mulwc(xv, pwi[q]);
-            });
-            idftp<8>(v);
-            float* ya = (tsel == 0 ? y0 : y1) + (size_t)rowA * ns;
-            float* yb = (tsel == 0 ? y0 : y1) + (size_t)rowB * ns;
-            if (interior) {
-                float2* oa = reinterpret_cast<float2*>(ya + k0) + tid;
-                float2* ob = reinterpret_cast<float2*>(yb + k0) + tid;
-                static_for<8>([&](auto qq) {
-                    constexpr int q = decltype(qq)::value;
-                    if (2 * (tid + q * 256) < kXfStep) {
-                        const c2 o = c2_scale2(v[q], sc);
-                        st_stream(oa + q * 256, c2_a(o));
-                        if (hasB) st_stream(ob + q * 256, c2_b(o));
-                    }
-                });
-            } else {
-                auto put = [&](float* yr, bool vec, int k, float2 o) {
-                    if (k >= ns) return;
-                    if (vec && k + 1 < ns) *reinterpret_cast<float2*>(yr + k) = o;
-                    else {
-                        yr[k] = o.x;
-                        if (k + 1 < ns) yr[k + 1] = o.y;
-                    }
-                };
-                static_for<8>([&](auto qq) {
-                    constexpr int q = decltype(qq)::value;
-                    const int m = tid + q * 256;
-                    if (2 * m < kXfStep) {
-                        const c2 o = c2_scale2(v[q], sc);
-                        put(ya, veca, k0 + 2 * m, c2_a(o));
-                        if (hasB) put(yb, vecb, k0 + 2 * m, c2_b(o));
-                    }
-                });
-            }
-        }
-        lds_barrier();                                           // S1' has read the buffer before the next template writes it
-    }
-}
-
 // extra tables of the four-stage kernel: gp [2][MB] + tw1 [8][256] + tw2 [8][32] + tw3 [8][4] + wg [512] (float2), pairs [256] (int2)
 constexpr size_t kX4WsFloats = 2 * (2 * kXfMB + 8 * 256 + 8 * 32 + 8 * 4 + kX4NG + kX4Items);
 
@@ -1365,7 +1099,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     // both templates off one read and one forward transform of every block
     // (D4W_XF_FUSED: 1 = four-stage 512-thread kernel [default], 2 = three-stage 256-thread kernel, 0 = one launch per template)
     static const int fusedmode = [] { const char* v = getenv("D4W_XF_FUSED"); return v ? atoi(v) : 1; }();
-    if (ntpl == 2 && (fusedmode == 1 || fusedmode == 3)) {        // four-stage kernels: 1 = 512 threads, both templates side by side; 3 = 256 threads, one after the other
+    if (ntpl == 2 && fusedmode == 1) {                            // four-stage, 512-thread kernel (default)
         float2* f4 = reinterpret_cast<float2*>(w + kXfWsFloats);
         X4Tables Q;
         float2* gp4 = f4;
@@ -1387,15 +1121,6 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
             attr4 = true;
         }
 #endif
-        if (fusedmode == 3) {
-            const size_t lds3 = (size_t)kX4RowP * sizeof(float4) + (256 + 32) * sizeof(float2);
-            if (xnext)
-                D4W_LAUNCH(xcorr_fft_seq4<true>, grid, dim3(kX4Items), lds3, stream, Q, x, nx, ns, mean, maxabs, y0, y1, xnext, ld_next, n_next);
-            else
-                D4W_LAUNCH(xcorr_fft_seq4<false>, grid, dim3(kX4Items), lds3, stream, Q, x, nx, ns, mean, maxabs, y0, y1,
-                           (const float*)nullptr, 0, 0);
-            return D4W_OK;
-        }
         if (xnext)
             D4W_LAUNCH(xcorr_fft_fused4<true>, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1, xnext,
                        ld_next, n_next);
