@@ -198,7 +198,7 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     dist.all_reduce(nranks)                       # every rank that took part counts itself (RCCL)
     # per-stage times of rank 0 (HIP events on the launch stream; transfers are waited on there), a few extra steps
     stage_ms = {}
-    for _ in range(3):
+    for rep_i in range(3):
         plan.marks = []
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
@@ -218,21 +218,34 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         ev[3].synchronize()
         for k, (a_, b_) in {"fk_filter": (0, 1), "matched_filter": (1, 2), "all_gather": (2, 3)}.items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ev[a_].elapsed_time(ev[b_]) / 3
-        if "mf" in stages:
+        if "mf" in stages and "picks_error" not in stage_ms:
             # what a deployment would gather instead of the 9.6-GB t-x matrix: the envelope picks of the local
             # correlograms, reassembled with global channel indices on every rank -- timed beside the step, not inside it
-            cg = ddet._xcorr_device(y, tpl, normalize=True, stats=st)
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record()
-            pk = [ddet.pick_times_env(c_, 0.45 * float(c_.max())) for c_ in cg]
-            e1.record()
-            tabs = [shard.all_gather_picks(p_.packed, a) for p_ in pk]
-            e2.record()
-            e2.synchronize()
-            stage_ms["picks_env_local"] = stage_ms.get("picks_env_local", 0.0) + e0.elapsed_time(e1) / 3
-            stage_ms["all_gather_picks"] = stage_ms.get("all_gather_picks", 0.0) + e1.elapsed_time(e2) / 3
-            stage_ms["picks_gathered"] = int(sum(t_.shape[1] for t_ in tabs))
-            del cg, pk, tabs
+            # (the first repetition is a warm-up: the envelope of a new long-row shape compiles its kernels once).  Every rank
+            # takes the same branch: a failure is agreed on over the group before anyone enters the collective.
+            try:
+                cg = ddet._xcorr_device(y, tpl, normalize=True, stats=st)
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                pk = [ddet.pick_times_env(c_, 0.45 * float(c_.max())) for c_ in cg]
+                e1.record()
+                ok_local = 1
+            except Exception as e:                                   # the main line must survive this side measurement
+                ok_local, err_local = 0, repr(e)
+            okt = torch.tensor([ok_local], dtype=torch.int32, device=device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                stage_ms["picks_error"] = err_local if not ok_local else "another rank failed"
+            else:
+                tabs = [shard.all_gather_picks(p_.packed, a) for p_ in pk]
+                e2.record()
+                e2.synchronize()
+                if rep_i > 0:
+                    stage_ms["picks_env_local"] = stage_ms.get("picks_env_local", 0.0) + e0.elapsed_time(e1) / 2
+                    stage_ms["all_gather_picks"] = stage_ms.get("all_gather_picks", 0.0) + e1.elapsed_time(e2) / 2
+                stage_ms["picks_gathered"] = int(sum(t_.shape[1] for t_ in tabs))
+                del tabs
+            cg = pk = None
         for (l0, e0), (l1, e1) in zip(plan.marks[:-1], plan.marks[1:]):
             stage_ms["fk:" + l1] = stage_ms.get("fk:" + l1, 0.0) + e0.elapsed_time(e1) / 3
     plan.marks = None
