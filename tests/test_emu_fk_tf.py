@@ -45,7 +45,7 @@ def run(lib, x, mask, order=None, taper=0, stats=False):
         # a second call on the same plan (workspace reuse)
         y2 = np.empty_like(xf)
         assert lib.d4w_fk_apply_f32(plan, vp(xf), vp(y2), taper, None) == 0
-        assert np.array_equal(y, y2)
+        assert np.array_equal(y, y2, equal_nan=True)
         lib.d4w_fk_plan_destroy(plan)
     finally:
         if order:
@@ -150,3 +150,40 @@ def test_hybrid_ninf_design_runs_time_first(emu):
     assert rel(y, ref) < TOL
     y_tf, info_tf, _ = run(emu, x, m, order="tf")
     assert info_tf[0] == 1 and info_tf[2] > 0 and rel(y_tf, ref) < TOL
+
+
+def test_degenerate_masks(emu):
+    """All-zero mask (nothing kept in either order: the output is exactly zero), a single live frequency column, and a
+    mask whose only non-zero entry is the Nyquist column."""
+    rng = np.random.default_rng(17)
+    nx, ns = 100, 600
+    x = rng.standard_normal((nx, ns))
+    m = np.zeros((nx, ns))
+    for order in ("tf", "cf", None):
+        y, info, _ = run(emu, x, m, order=order)
+        assert np.all(y == 0.0)
+    m1 = np.zeros((nx, ns))
+    m1[:, ns // 2 + 37] = rng.random(nx) + 0.5                     # f = +37 bins only (the fold adds the mirrored half)
+    ref = orc.fk_filter_filt(x, m1)
+    y, info, _ = run(emu, x, m1, order="tf")
+    assert info[0] == 1 and info[1] <= 20 and rel(y, ref) < TOL     # one cell of N1 NA = 20 columns kept
+    m2 = np.zeros((nx, ns))
+    m2[:, 0] = rng.random(nx) + 0.5                                # shifted column 0 = the Nyquist frequency
+    ref = orc.fk_filter_filt(x, m2)
+    y, info, _ = run(emu, x, m2, order="tf")
+    assert info[0] == 1 and info[1] == 1 and rel(y, ref) < TOL
+    y, _, _ = run(emu, x, m2)
+    assert rel(y, ref) < TOL
+
+
+def test_nan_gain_spreads_like_numpy(emu):
+    """A NaN in the mask makes the reference's product NaN and the inverse transform spreads it over the block; the
+    column holding it stays a band column here (never dropped as 'zero'), so the output is NaN as well."""
+    rng = np.random.default_rng(19)
+    nx, ns = 18, 48
+    x = rng.standard_normal((nx, ns))
+    m = band_mask(rng, nx, ns, 2, 9, 15)
+    m[3, ns // 2 + 4] = np.nan
+    for order in ("tf", "cf"):
+        y, _, _ = run(emu, x, m, order=order)
+        assert np.isnan(y).any()
