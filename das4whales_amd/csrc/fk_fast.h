@@ -654,6 +654,10 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
             }
         }
         if ((sq % run) == run - 1) {                     // end of a run: its C1 rows are complete for these columns
+            // wave partials -> LDS (the tile is free between the second barrier and the next S1' writes) -> ONE atomic pair per
+            // row and workgroup (per row and wave before: 7 x the atomics, which kept shorter runs from paying)
+            constexpr int NW = (G::THRA + 63) / 64;
+            float* part = reinterpret_cast<float*>(tile);        // [NW][C1][2]
             static_for<G::C1>([&](auto cc) {
                 constexpr int c1 = decltype(cc)::value;
                 float sv = asum[c1], mv = amax[c1];
@@ -663,15 +667,26 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
                     mv = fmaxf(mv, __shfl_xor(mv, off));
                 }
                 if ((tid & 63) == 0) {
-                    const size_t row = (MODE == 0) ? (size_t)c1 * G::C2 + c2 : (size_t)c2 * G::C1 + c1;
-                    if (MODE == 0 || (int)row < geo.nrows) {
-                        atomicAdd(rowmean + row, sv * inv_ns);
-                        atomicMax(rowmaxbits + row, __float_as_uint(mv));      // mv >= 0: bit order = value order
-                    }
+                    part[((tid >> 6) * G::C1 + c1) * 2] = sv;
+                    part[((tid >> 6) * G::C1 + c1) * 2 + 1] = mv;
                 }
                 asum[c1] = 0.f;
                 amax[c1] = 0.f;
             });
+            __syncthreads();
+            if (tid < G::C1) {
+                float sv = 0.f, mv = 0.f;
+                for (int w = 0; w < NW; ++w) {
+                    sv += part[(w * G::C1 + tid) * 2];
+                    mv = fmaxf(mv, part[(w * G::C1 + tid) * 2 + 1]);
+                }
+                const size_t row = (MODE == 0) ? (size_t)tid * G::C2 + c2 : (size_t)c2 * G::C1 + tid;
+                if (MODE == 0 || (int)row < geo.nrows) {
+                    atomicAdd(rowmean + row, sv * inv_ns);
+                    atomicMax(rowmaxbits + row, __float_as_uint(mv));      // mv >= 0: bit order = value order
+                }
+            }
+            __syncthreads();
         }
         par ^= 1;
     };
