@@ -1271,11 +1271,10 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
                 const int by_lds = (int)((160 * 1024) / std::max<size_t>(lds, 1));
                 return std::max(pl->wgB, std::min(3, std::min(by_regs, by_lds)));
             };
-            const int wg_floor = pl->wgB;
             pl->wgBi = env_int("D4W_FK_WG_BI", resident((const void*)fast->Bt_inv, fast->ldsBt));
             pl->wgBf = env_int("D4W_FK_WG_BF", resident((const void*)fast->Bt_fwd, fast->ldsBt));
             if (!getenv("D4W_FK_WG_B")) pl->wgB = resident((const void*)fast->B_mid, fast->ldsB);
-            (void)wg_floor;
+
         }
         const size_t lds_max = std::max(pl->ldsA, std::max(pl->ldsB, pl->ldsC));
         if (!fast && lds_max > 64 * 1024) {
