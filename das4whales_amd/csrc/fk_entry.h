@@ -109,13 +109,10 @@ static inline FkFastEntry fast_entry(int wgA, int wgC, int wgB, int variant = 0)
     e.Bs_mid = fkf_passB<G, 1>;
     e.Bs_hilb = fkf_passB<G, 1, true>;
     e.ldsBt = G::ldsB + (size_t)G::NC * G::NB * sizeof(int2);
-    if constexpr (G::C2X == 1) {
-        e.Bt_fwd = fkf_passBt<G, 1>;
-        e.Bt_inv = fkf_passBt<G, 2>;
-        e.C_mid = fkf_passCm<G>;
-    } else {
-        e.Bt_fwd = nullptr; e.Bt_inv = nullptr; e.C_mid = nullptr;
-    }
+    e.Bt_fwd = fkf_passBt<G, 1>;
+    e.Bt_inv = fkf_passBt<G, 2>;
+    if constexpr (G::C2X == 1) e.C_mid = fkf_passCm<G>;
+    else e.C_mid = nullptr;                 // the c2 axis runs as a Bluestein convolution: fk_passCm_bluestein (fk_filter.hip)
     return e;
 }
 

@@ -292,6 +292,63 @@ __global__ __launch_bounds__(kMaxThreads) void fk_passC_bluestein(FkDev P, float
     }
 }
 
+// Time-first order (fk_tf.h) when the c2 axis is a Bluestein convolution: passes C and C' fused on the BAND strips of the
+// compact spectrum W -- chirp, FFT_L, x filter, IFFT_L, chirp (= the c2 transform, natural order), x band mask, and the same
+// backwards with conjugated tables -- one read and one write of the strip for four length-L transforms.  Tile order as
+// fkf_passCm: per c1 position q the band strips of the N1 sub-row blocks, then the Nyquist strip.
+__global__ __launch_bounds__(kMaxThreads) void fk_passCm_bluestein(FkDev P, FkTfDev T, int ntiles) {
+    D4W_DYN_LDS(smem_raw);
+    float2* tile = reinterpret_cast<float2*>(smem_raw);
+    const FkDims& d = P.d;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int TC = d.TC, L = P.bs_L;
+    const int nelem = d.C2 * TC, ntile = L * TC;
+    const TwLds tw = tw_stage(P.ax_bs, tile + ntile, tid, nthr);
+    const int nb1 = T.bw / TC, tq = d.N1 * nb1 + (T.col_nyq >= 0 ? 1 : 0);
+    const size_t LC = (size_t)T.Lc;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int q = t / tq, u = t - q * tq;
+        int p0;
+        if (u < d.N1 * nb1) {
+            const int q1 = u / nb1;
+            p0 = q1 * T.RW + (u - q1 * nb1) * TC;
+        } else
+            p0 = T.col_nyq;
+        float2* base = T.W + ((size_t)q * d.C2) * LC + p0;
+        const float* mbase = T.cmask + ((size_t)q * d.C2) * LC + p0;
+        for (int w = tid; w < ntile; w += nthr) {
+            const int c2 = w / TC, tt = w - c2 * TC;
+            tile[w] = (w < nelem) ? c_mul(base[(size_t)c2 * LC + tt], P.bs_chirp[c2]) : make_float2(0.f, 0.f);
+        }
+        lds_barrier();
+        lds_fft<false, true, false>(tile, P.ax_bs, tw, TC, TC, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < ntile; w += nthr) tile[w] = c_mul(tile[w], P.bs_filt[w / TC]);
+        lds_barrier();
+        lds_fft<true, true, false>(tile, P.ax_bs, tw, TC, TC, 1, 1, 0, tid, nthr);
+        // spectrum at wavenumber position c2 (natural order): x chirp x mask, then straight into the inverse convolution
+        // (x conj chirp); everything beyond the C2 rows is the zero padding again
+        for (int w = tid; w < ntile; w += nthr) {
+            const int c2 = w / TC, tt = w - c2 * TC;
+            float2 v = make_float2(0.f, 0.f);
+            if (w < nelem) {
+                const float2 ch = P.bs_chirp[c2];
+                v = c_mulc(c_scale(c_mul(tile[w], ch), mbase[(size_t)c2 * LC + tt]), ch);
+            }
+            tile[w] = v;
+        }
+        lds_barrier();
+        lds_fft<false, true, false>(tile, P.ax_bs, tw, TC, TC, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < ntile; w += nthr) tile[w] = c_mulc(tile[w], P.bs_filt[w / TC]);
+        lds_barrier();
+        lds_fft<true, true, false>(tile, P.ax_bs, tw, TC, TC, 1, 1, 0, tid, nthr);
+        for (int w = tid; w < nelem; w += nthr) {
+            const int c2 = w / TC, tt = w - c2 * TC;
+            base[(size_t)c2 * LC + tt] = c_mulc(tile[w], P.bs_chirp[c2]);
+        }
+        lds_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass B : contiguous n2 transform + real-spectrum pair op + mask + inverse
 //
@@ -1125,7 +1182,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             pl->allocs.push_back(q); pl->d_pairs_live = (int2*)q;
         }
     }
-    if (fast && !bs_L && fast->Bt_fwd) {
+    if (fast && fast->Bt_fwd) {
         // time-first order: work list of passes Bf / Bi.  BEFORE the c2 transform the Hermitian partner of row
         // (q, c2) is (q', c2), kc1(q') = -kc1(q) (fk_tf.h); the partner sub-row is the same q1' as in pass B.
         std::vector<int2> pairsT;
@@ -1256,7 +1313,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             if (fast->Bt_fwd) {
                 (void)hipFuncSetAttribute((const void*)fast->Bt_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
                 (void)hipFuncSetAttribute((const void*)fast->Bt_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsBt);
-                (void)hipFuncSetAttribute((const void*)fast->C_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
+                if (fast->C_mid) (void)hipFuncSetAttribute((const void*)fast->C_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast->ldsC);
                 // (below) resident workgroups of the pass-B forms from what their registers and LDS allow
             }
             // Pass B in its three forms is bound by VALU issue AND by what its few waves can overlap: a CU takes as many
@@ -1294,6 +1351,7 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         if (bs_L) {
             (void)hipFuncSetAttribute((const void*)fk_passC_bluestein<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             (void)hipFuncSetAttribute((const void*)fk_passC_bluestein<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute((const void*)fk_passCm_bluestein, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         }
     }
 #else
@@ -1477,7 +1535,7 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
                (const float*)pl->d_mask, (const float*)pl->d_nyq, (const int*)pl->d_colsrc, Lc, pl->d_cmask);
     {
         const int nb1 = bw / TC, ntCm = (N1 * nb1 + (nyq_live ? 1 : 0)) * d.C1;
-        if (ntCm > 0)
+        if (ntCm > 0 && !pl->dev.bs_L)
             D4W_LAUNCH(fk_cm_livebits, dim3(ceil_div(ntCm * F.C2A, kThreads)), dim3(kThreads), 0, stream, (const float*)pl->d_cmask, Lc,
                        d.C2, F.C2A, F.C2B, TC, N1, nb1, RW, nyq_live ? N1 * RW : -1, ntCm, pl->d_cmlive);
     }
@@ -1503,8 +1561,8 @@ static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
     pl->fdev.live = nullptr;
     pl->tf = false;
     const char* np = getenv("D4W_FK_NOPRUNE");
-    if (pl->fast && !pl->dev.bs_L && !(np && atoi(np) > 0)) {
-        // Dead rows: a wavenumber row whose folded gains (and whose Hermitian partner's) are all zero -- or below the
+    if (pl->fast && !(np && atoi(np) > 0)) {
+        // Dead rows (not with a Bluestein pass C, which has no row skipping: only the pass order is chosen there): a wavenumber row whose folded gains (and whose Hermitian partner's) are all zero -- or below the
         // zero-gain threshold above: rounding level always, prune_eps * max |M_h| opt-in (the Butterworth tails of
         // hybrid_ninf_filter_design, dsp.py:348-349, never reach zero: 7.7e-7 at fmax + 14 Hz; treating them as zero
         // changes the output by at most that gain times the spectral content the input holds there)
@@ -1534,7 +1592,7 @@ static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream) {
         }
         int nlive = 0;
         for (int r = 0; r < d.nx; ++r) nlive += lv[r];
-        if (nlive < d.nx) {
+        if (nlive < d.nx && !pl->dev.bs_L) {
             const int RA = pl->fast->C2A, RB = pl->fast->C2B;
             std::vector<unsigned> bits((size_t)d.C1 * RA, 0u);
             for (int r = 0; r < d.nx; ++r)
@@ -1698,7 +1756,11 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
             const dim3 gBf(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgBf)));
             if ((rc = launch_k(F.Bt_fwd, gBf, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
             D4W_MARK(2);
-            if (ntCm > 0 && (rc = launch_k(F.C_mid, gCm, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, T, 0, ntCm))) return rc;
+            if (ntCm > 0) {
+                if (P.bs_L) rc = launch_k(fk_passCm_bluestein, dim3(std::max(1, std::min(ntCm, persist))), blk, pl->ldsC, stream, P, T, ntCm);
+                else rc = launch_k(F.C_mid, gCm, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, T, 0, ntCm);
+                if (rc) return rc;
+            }
             D4W_MARK(3);
             const dim3 gBi(std::max(1, std::min(pl->npairsT, pl->num_cu * pl->wgBi)));
             if ((rc = launch_k(F.Bt_inv, gBi, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;

@@ -244,7 +244,7 @@ def test_pass_order_is_chosen_per_mask(dw):
     assert plan.order()["order"] == "channel-first" and plan.live_rows() == shape[0]
 
 
-@pytest.mark.parametrize("nx,ns", [(96, 480), (4000, 12000), (5510, 12000), (11020, 12000), (8000, 12000), (600, 120000)])
+@pytest.mark.parametrize("nx,ns", [(96, 480), (74, 480), (4000, 12000), (5510, 12000), (11020, 12000), (13223, 12000), (8000, 12000), (600, 120000)])
 def test_time_first_equals_channel_first_on_every_kernel_configuration(dw, nx, ns):
     """Built-in and compiled-on-demand configurations (different radix triples, even and odd N1, prime c2 radices): a mask
     with band, wavenumber-independent skirt and zero columns through both pass orders -- same output to float32 rounding,
