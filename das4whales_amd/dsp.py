@@ -806,14 +806,22 @@ def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
         raise ValueError("data must be a 2-D [channel x time] array")
     nx, ns = data.shape
     device = data.device if dev.is_tensor(data) and data.is_cuda else None
-    # axes: fftfreq(ns, tint/fs), fftfreq(nx, xint*dx) (dsp.py:923-924) -> spacing arguments
-    g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=device)    # dsp.py:930-936
-    g = _gaussian_filter(g, 20)                                                 # dsp.py:940
+    # The reference designs this mask on every call (dsp.py:919-945): wedge, Gaussian blur, min-max normalisation.  It only
+    # depends on the shape and on the six parameters, so the plan remembers which of them its folded mask was built from and a
+    # second call with the same arguments goes straight to the filter (20 000 x 120 000: 52 -> 21 ms)
     if ns % 2 == 0:
-        plan = get_fk_plan(nx, ns, g.device)
-        plan.set_mask_normalised(g)                                             # dsp.py:945, folded into the mask upload
+        plan = get_fk_plan(nx, ns, device)
+        key = ("fk_filt", float(tint), float(fs), float(xint), float(dx), float(c_min), float(c_max))
+        if plan._mask_key != key:
+            # axes: fftfreq(ns, tint/fs), fftfreq(nx, xint*dx) (dsp.py:923-924) -> spacing arguments
+            g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=plan.device)    # dsp.py:930-936
+            g = _gaussian_filter(g, 20)                                         # dsp.py:940
+            plan.set_mask_normalised(g)                                         # dsp.py:945, folded into the mask upload
+            plan._mask_key = key
         x = dev.to_device_f32(data, plan.device)
         return dev.like_input(plan.apply(x), data)
+    g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=device)
+    g = _gaussian_filter(g, 20)
     with torch.cuda.device(g.device):
         check(lib.d4w_minmax_normalise_f32(dev.ptr(g), g.numel(), dev.stream_ptr(g)))        # dsp.py:945
     return _fk_apply(data, DeviceMask(g), False)

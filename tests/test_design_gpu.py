@@ -115,3 +115,22 @@ def test_design_goes_into_the_plan_without_a_dense_mask(dw):
         assert torch.equal(y, y2), name
         print("%s: design -> plan %.1f ms (dense mask -> plan %.1f ms), %d live rows" % (name, ms, ms_dense, live))
         del y, y2, dense, m
+
+
+def test_fk_filt_reuses_its_mask_and_notices_other_masks(dw, golden):
+    """dsp.fk_filt designs its mask from (shape, tint, fs, xint, dx, c_min, c_max) only: a second call with the same arguments
+    reuses the plan's folded mask (bit-identical output), other arguments or another mask on the same plan in between
+    rebuild it."""
+    g = golden("fk_40x480.npz")
+    x = np.asarray(g["x"])
+    fs, dx = float(g["fs"]), float(g["dx"])
+    y1 = dw.dsp.fk_filt(x, 1, fs, 4, dx, 1400., 3400.)
+    y2 = dw.dsp.fk_filt(x, 1, fs, 4, dx, 1400., 3400.)
+    assert np.array_equal(y1, y2)
+    y3 = dw.dsp.fk_filt(x, 1, fs, 4, dx, 1500., 3000.)
+    assert not np.array_equal(y1, y3)
+    dw.dsp.fk_filter_filt(x, np.ones_like(x))                  # another mask through the same cached plan
+    y4 = dw.dsp.fk_filt(x, 1, fs, 4, dx, 1400., 3400.)
+    assert np.array_equal(y1, y4)
+    ref = orc.fk_filt(x, 1, fs, 4, dx, 1400., 3400.)
+    assert rel(y4, ref) < 1e-5
