@@ -17,6 +17,8 @@ timeout 900 python bench.py --shard channel --steps 5 --warmup 2 --force-replica
 timeout 600 python scripts/time_bp.py 2>/dev/null | grep "^{" > $O/time_bp.txt; cat $O/time_bp.txt
 timeout 600 python scripts/pipeline_bench.py 2>/dev/null | grep "^{" > $O/pipeline_11020x12000.json; cat $O/pipeline_11020x12000.json
 timeout 600 python scripts/time_shapes.py 13223x12000 8000x12000 11020x12000 5510x12000 4000x12000 2>/dev/null | grep "^{" > $O/time_shapes.txt; cat $O/time_shapes.txt
+# pass order and pass times per mask (time-first / channel-first), bench shape and the scripts' own 13223-channel selection
+(timeout 300 python scripts/time_fk_masks.py classic ninf hybrid dense step4; NX=13223 NS=12000 timeout 200 python scripts/time_fk_masks.py ninf classic; NX=11020 NS=12000 timeout 200 python scripts/time_fk_masks.py ninf classic) 2>/dev/null | grep "^{" > $O/time_fk_masks.txt; cut -c1-200 $O/time_fk_masks.txt
 # shapes beyond the direct kernels: prime channel counts / record lengths (Bluestein forms), loop-free prime radices (generic kernels)
 timeout 600 python scripts/time_shapes.py 4099x12000 10007x12000 19997x12000 11020x12014 11020x12002 10007x12014 2>/dev/null | grep "^{" > $O/time_any_shape.txt; cut -c1-60,180-330 $O/time_any_shape.txt
 timeout 300 python scripts/time_bluestein_rows.py 2>/dev/null | grep "^{" > $O/time_bluestein_rows.txt; cat $O/time_bluestein_rows.txt
