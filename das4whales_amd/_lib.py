@@ -80,6 +80,9 @@ def _load():
                                        c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_dc_tail_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_double, c_int, c_void_p,
                                           c_void_p]),
+        "d4w_xcorr_mm_max_support": (c_int, []),
+        "d4w_xcorr_mm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_fft_max_support": (c_int, []),
         "d4w_xcorr_fft_ws_bytes": (ctypes.c_size_t, []),
         "d4w_xcorr_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -1,0 +1,387 @@
+// Matched filter as a banded-Toeplitz product on the MI355X matrix cores (gfx950): replaces the per-row
+// scipy.signal.correlate(x, template, 'full', 'fft') of detect.compute_cross_correlogram (reference
+// detect.py:140-166; positive lags, detect.py:111-112) for templates of short support (the fin-whale call
+// templates have 136 / 156 non-zero samples).
+//
+// Why matrix cores.  The correlation costs 2 (L0 + L1) = 584 flop per sample in its direct form -- 8.9 ms of the
+// packed-FMA rate for a 20 000 x 120 000 block, which is why rounds 1-3 ran it as an overlap-save FFT
+// (xcorr_fft.hip, ~90 flop per sample).  That kernel is bound by neither HBM nor VALU issue but by the chain of
+// LDS round trips and barriers of three 2048-point transforms per row block (46 % of the HBM roofline for three
+// rounds).  The direct form IS a matrix product with a banded Toeplitz factor,
+//
+//      y[16 a + i] = sum_u  t[u - i] * x[16 a + u],      i < 16,  u < 16 + L - 1,
+//
+// i.e. C[i][a] = sum_u A[i][u] B[u][a] with A[i][u] = t[u - i] (16 x K, K = 32 ceil((L + 15) / 32), the template's
+// Toeplitz matrix, zero outside the band, resident in registers for the whole launch) and B[u][a] = x[16 a + u]
+// (overlapping windows of the row, read straight out of an LDS copy of the row chunk: lane (a, g) takes the 8
+// consecutive samples 16 a + 32 kk + 8 g .. + 7 as ONE 16-byte LDS read).  v_mfma_f32_16x16x32_f16 does 16 384
+// flop per instruction; 11 k-steps x 3 products per 256 lags leave the matrix pipe ~35 % busy at the HBM rate,
+// the vector ALUs only convert and store, and the kernel is a plain stream: 4 B read + 8 B written per sample.
+//
+// float32 through binary16 factors.  Every operand is split into two binary16 values, v = hi + lo 2^-11
+// (hi = rn16(v), lo = rn16((v - hi) 2^11): 22-23 significant bits), and a product keeps three of the four partial
+// products, hi hi + (hi lo + lo hi) 2^-11 -- each exact in the float32 accumulator of the matrix instruction; the
+// dropped lo lo 2^-22 term is below float32 rounding.  Rows are scaled to |x| <= 2 before the split (1 / max|x| of
+// detect.py:157 when the caller normalises, otherwise a power of two per chunk), templates by a power of two, so
+// nothing leaves the binary16 range.  Measured against the float64 oracle the result is as close as the float32
+// FFT kernel's (tests/test_rowops_gpu.py).
+//
+// Launch shape.  Persistent workgroups (256 threads, 4 waves) walk chunks of 4096 lags of one row; the chunk's
+// 4096 + 192 samples are loaded one chunk AHEAD into registers (17 floats per lane), converted and written to
+// one of two LDS buffers (hi / lo arrays, one 16-byte pad per 256 bytes: the fragment reads of a 16-lane group
+// hit 16 different bank groups), ONE barrier per chunk, then every wave runs four 16 x 16 tiles (256 lags each,
+// both templates) and streams the results out with 16-byte non-temporal stores (lane (a, g) holds lags
+// 16 a + 4 g .. + 3: 1 KiB contiguous per wave and template).  Chunks are dealt to the XCDs in contiguous
+// ranges, so the 192-sample halo of a chunk is an L2 hit.
+#include <cstdlib>
+
+#include "fft_radix.h"
+
+namespace d4w {
+
+constexpr int kMmCH = 4096;                      // lags per chunk
+constexpr int kMmKS = 6;                         // k-steps of 32 -> Toeplitz depth 192
+constexpr int kMmHalo = 32 * kMmKS;              // samples staged beyond the chunk
+constexpr int kMmMaxSupport = kMmHalo - 15;      // 177
+constexpr int kMmThreads = 256;
+constexpr int kMmStage = kMmCH + kMmHalo;        // 4288 samples per chunk
+constexpr int kMmQ = (kMmStage + 4 * kMmThreads - 1) / (4 * kMmThreads);   // 16-byte loads per lane: 5 (the last one lanes < 48)
+constexpr int kMmLastQ = (kMmStage - (kMmQ - 1) * 4 * kMmThreads) / 4;   // lanes that take the last load: 48
+__host__ __device__ constexpr int mm_pidx(int h) { return h + ((h >> 7) << 3); }   // 8 halves of pad per 128
+constexpr int kMmArr = mm_pidx(kMmStage) + 8;    // halves per LDS array (4560 -> 9120 B)
+constexpr float kMmLoScale = 2048.f, kMmLoInv = 1.0f / 2048.f;
+
+#ifdef D4W_EMU
+typedef uint16_t mm_half;
+struct alignas(16) mm_h8 { uint16_t v[8]; };
+struct mm_f4 { float v[4]; };
+__device__ __forceinline__ mm_half mm_to_half(float x) { return hipemu::f32_to_f16(x); }
+__device__ __forceinline__ float mm_to_float(mm_half h) { return hipemu::f16_to_f32(h); }
+__device__ __forceinline__ mm_f4 mm_zero() { return mm_f4{{0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ mm_f4 mm_mfma(const mm_h8& a, const mm_h8& b, mm_f4 c) {
+    hipemu::mfma_f32_16x16x32_f16(a.v, b.v, c.v);
+    return c;
+}
+__device__ __forceinline__ float mm_get(const mm_f4& c, int r) { return c.v[r]; }
+__device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a.v[j] = h; }
+__device__ __forceinline__ int mm_uniform(int v) { return v; }
+__device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+#else
+typedef _Float16 mm_half;
+typedef _Float16 mm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mm_h4 __attribute__((ext_vector_type(4)));
+typedef float mm_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mm_half mm_to_half(float x) { return (_Float16)x; }
+__device__ __forceinline__ float mm_to_float(mm_half h) { return (float)h; }
+__device__ __forceinline__ mm_f4 mm_zero() { mm_f4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ mm_f4 mm_mfma(mm_h8 a, mm_h8 b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float mm_get(const mm_f4& c, int r) { return c[r]; }
+__device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a[j] = h; }
+__device__ __forceinline__ int mm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) {
+    mm_f4 t = {a, b, c, d};
+    __builtin_nontemporal_store(t, reinterpret_cast<mm_f4*>(p));
+}
+#endif
+
+// v = hi + lo / 2048 to 22-23 significant bits
+__device__ __forceinline__ void mm_split(float v, mm_half& hi, mm_half& lo) {
+    hi = mm_to_half(v);
+    lo = mm_to_half((v - mm_to_float(hi)) * kMmLoScale);
+}
+
+// power of two >= a (a >= 0, finite): the scale that keeps a block of values inside [-1, 1] without rounding them
+__device__ __forceinline__ void mm_pow2_scale(float a, float& up, float& down) {
+    int e = 0;
+    if (a > 0.f) (void)frexpf(a, &e);              // a = f 2^e, 0.5 <= f < 1
+    e = min(max(e, -100), 100);
+    up = ldexpf(1.0f, e);
+    down = ldexpf(1.0f, -e);
+}
+
+struct MmArgs {
+    const float* x;         // [nx][ns]
+    const float* xnext;     // [nx][ld_next] or NULL: the record's continuation (first n_next samples of every row)
+    const float* mean;      // [nx] or NULL
+    const float* maxabs;    // [nx] or NULL (then every chunk is scaled by its own power of two)
+    const float* taps;      // [ntpl][ltaps]
+    float* y0;
+    float* y1;
+    int nx, ns, ld_next, n_next, ltaps, len0, len1;
+};
+
+// KS0 / KS1: k-steps of template 0 / 1 (KS1 = 0: one template); WPS: workgroups per compute unit the registers are budgeted for
+template <int KS0, int KS1, int WPS>
+__global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
+    constexpr int KSM = KS0 > KS1 ? KS0 : KS1;
+    D4W_DYN_LDS(smem_raw);
+    mm_half* lds = reinterpret_cast<mm_half*>(smem_raw);           // [2 buffers][hi | lo][kMmArr]
+    float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [4] chunk maxima of the waves (no maxabs)
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wv = mm_uniform(tid >> 6);
+    const int n16 = lane & 15, g = lane >> 4;
+    const int ns = P.ns;
+
+    // ---- the templates' Toeplitz fragments: A_t[kk][i = n16][u = 32 kk + 8 g + j] = t[u - i] / ts_t, split hi / lo
+    mm_h8 a0h[KS0], a0l[KS0];
+    mm_h8 a1h[KS1 ? KS1 : 1], a1l[KS1 ? KS1 : 1];
+    float osc0 = 1.f, osc1 = 1.f;                                   // output scales: the power of two taken out of the taps
+    {
+        // taps -> LDS first (zero outside the support), so that the 8 x KS fragment values of a lane are LDS reads
+        float* tl = reinterpret_cast<float*>(smem_raw);              // [2][16 + kMmHalo] before the row buffers are in use
+        constexpr int TLP = 16 + kMmHalo;
+        for (int i = tid; i < 2 * TLP; i += kMmThreads) {
+            const int t = i / TLP, u = i - t * TLP - 15;
+            const int L = t ? P.len1 : P.len0;
+            tl[i] = (u >= 0 && u < L && (t == 0 || KS1 > 0)) ? P.taps[(size_t)t * P.ltaps + u] : 0.f;
+        }
+        __syncthreads();
+        auto build = [&](const float* tp, int L, auto& ah, auto& al, auto ks, float& osc) {
+            constexpr int KS = decltype(ks)::value;
+            float m = 0.f;
+            for (int i = lane; i < TLP; i += 64) m = fmaxf(m, fabsf(tp[i]));
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float up, down;
+            mm_pow2_scale(m, up, down);
+            osc = up;
+            (void)L;
+            static_for<KS>([&](auto kq) {
+                constexpr int kk = decltype(kq)::value;
+                static_for<8>([&](auto jq) {
+                    constexpr int j = decltype(jq)::value;
+                    const float v = tp[15 + 32 * kk + 8 * g + j - n16] * down;
+                    mm_half hi, lo;
+                    mm_split(v, hi, lo);
+                    mm_set(ah[kk], j, hi);
+                    mm_set(al[kk], j, lo);
+                });
+            });
+        };
+        build(tl, P.len0, a0h, a0l, std::integral_constant<int, KS0>{}, osc0);
+        if constexpr (KS1 > 0) build(tl + TLP, P.len1, a1h, a1l, std::integral_constant<int, KS1>{}, osc1);
+        __syncthreads();                                            // the row buffers take this space over
+    }
+
+    // ---- the chunks of this workgroup: XCD j (workgroup id mod 8) owns the contiguous range [j T / 8, (j + 1) T / 8)
+    const int nchunk = (ns + kMmCH - 1) / kMmCH;
+    const long long total = (long long)P.nx * nchunk;
+    const int nparts = min(8, (int)gridDim.x);
+    const int xcd = (int)blockIdx.x % nparts, wq = (int)blockIdx.x / nparts, nq = ((int)gridDim.x - xcd + nparts - 1) / nparts;
+    const long long lo_c = total * xcd / nparts, hi_c = total * (xcd + 1) / nparts;
+
+    float4 pre[kMmQ];                                               // the chunk being loaded (raw samples)
+    float mu_n = 0.f, g_n = 1.f;                                    // its row's mean and 1 / maxabs
+    long long c_n = lo_c + wq;
+    int row_n = 0, c0_n = 0;
+
+    auto issue = [&](long long c) {                                 // global loads of chunk c into pre[]
+        row_n = (int)(c / nchunk);
+        c0_n = (int)(c - (long long)row_n * nchunk) * kMmCH;
+        mu_n = P.mean ? P.mean[row_n] : 0.f;
+        g_n = 1.f;
+        if (P.maxabs) {
+            const float a = P.maxabs[row_n];
+            g_n = (a > 0.f) ? 1.0f / a : 0.f;
+        }
+        const float* xr = P.x + (size_t)row_n * ns;
+        const bool al = (reinterpret_cast<uintptr_t>(xr + c0_n) & 15) == 0;
+        if (al && c0_n + kMmStage <= ns) {
+            const float4* p = reinterpret_cast<const float4*>(xr + c0_n) + tid;
+            static_for<kMmQ>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                if (q < kMmQ - 1 || tid < kMmLastQ) pre[q] = p[q * kMmThreads];
+            });
+        } else {
+            // a row end, an unaligned row, or the record's continuation.  Clamped addresses and selects instead of branches, so
+            // that a lane's loads go out together; what lies beyond the data is filled with the row mean, which the
+            // de-meaning turns into the exact zero of the zero-padded correlation
+            if (al && (ns & 3) == 0) {                              // every 16-byte group lies inside the row or beyond it
+                static_for<kMmQ>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    if (q < kMmQ - 1 || tid < kMmLastQ) {
+                        const int i = c0_n + 4 * (tid + q * kMmThreads);
+                        const float4 v = *reinterpret_cast<const float4*>(xr + min(i, ns - 4));
+                        pre[q] = (i < ns) ? v : make_float4(mu_n, mu_n, mu_n, mu_n);
+                    }
+                });
+            } else {
+                static_for<kMmQ>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    if (q < kMmQ - 1 || tid < kMmLastQ) {
+                        const int i = c0_n + 4 * (tid + q * kMmThreads);
+                        const float a0 = xr[min(i, ns - 1)], a1 = xr[min(i + 1, ns - 1)], a2 = xr[min(i + 2, ns - 1)], a3 = xr[min(i + 3, ns - 1)];
+                        pre[q] = make_float4(i < ns ? a0 : mu_n, i + 1 < ns ? a1 : mu_n, i + 2 < ns ? a2 : mu_n, i + 3 < ns ? a3 : mu_n);
+                    }
+                });
+            }
+            if (P.xnext && P.n_next > 0 && c0_n + kMmStage > ns) {  // the head of the next file behind the row
+                const float* xn = P.xnext + (size_t)row_n * P.ld_next;
+                const int n_next = P.n_next;
+                static_for<kMmQ>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    if (q < kMmQ - 1 || tid < kMmLastQ) {
+                        const int d = c0_n + 4 * (tid + q * kMmThreads) - ns;
+                        const float b0 = xn[min(max(d, 0), n_next - 1)], b1 = xn[min(max(d + 1, 0), n_next - 1)];
+                        const float b2 = xn[min(max(d + 2, 0), n_next - 1)], b3 = xn[min(max(d + 3, 0), n_next - 1)];
+                        if (d >= 0 && d < n_next) pre[q].x = b0;
+                        if (d + 1 >= 0 && d + 1 < n_next) pre[q].y = b1;
+                        if (d + 2 >= 0 && d + 2 < n_next) pre[q].z = b2;
+                        if (d + 3 >= 0 && d + 3 < n_next) pre[q].w = b3;
+                    }
+                });
+            }
+        }
+    };
+
+    if (c_n < hi_c) issue(c_n);
+    int buf = 0;
+    for (long long c = c_n; c < hi_c; c += nq) {
+        const int row = row_n, c0 = c0_n;
+        const float mu = mu_n;
+        float gsc = g_n, osx = 1.f;                                 // x scale applied before the split, and what undoes it
+        mm_half* bh = lds + (size_t)buf * 2 * kMmArr;
+        mm_half* bl = bh + kMmArr;
+        // ---- convert the loaded chunk: (x - mu) * scale -> hi / lo halves in LDS
+        if (!P.maxabs) {
+            // no row maximum from the caller: this chunk's own power of two
+            float m = 0.f;
+            static_for<kMmQ>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                if (q < kMmQ - 1 || tid < kMmLastQ) {
+                    const float4 v = pre[q];
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x - mu), fabsf(v.y - mu))), fmaxf(fabsf(v.z - mu), fabsf(v.w - mu)));
+                }
+            });
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) red[wv + 4 * buf] = m;
+            lds_barrier();
+            m = fmaxf(fmaxf(red[4 * buf], red[4 * buf + 1]), fmaxf(red[4 * buf + 2], red[4 * buf + 3]));
+            mm_pow2_scale(m, osx, gsc);
+        }
+        static_for<kMmQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            if (q < kMmQ - 1 || tid < kMmLastQ) {
+                const float4 v = pre[q];
+                const float s[4] = {(v.x - mu) * gsc, (v.y - mu) * gsc, (v.z - mu) * gsc, (v.w - mu) * gsc};
+                mm_half h[4], l[4];
+                static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
+                const int at = mm_pidx(4 * (tid + q * kMmThreads));
+#ifdef D4W_EMU
+                for (int e = 0; e < 4; ++e) { bh[at + e] = h[e]; bl[at + e] = l[e]; }
+#else
+                mm_h4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+                *reinterpret_cast<mm_h4*>(bh + at) = hv;
+                *reinterpret_cast<mm_h4*>(bl + at) = lv;
+#endif
+            }
+        });
+        // ---- next chunk's loads fly across the barrier and the matrix phase
+        if (c + nq < hi_c) issue(c + nq);
+        lds_barrier();
+        // ---- 16 tiles of 256 lags, 4 per wave: C[i][a] (+)= A[i][u] B[u][a]
+        float* ya = P.y0 + (size_t)row * ns;
+        float* yb = KS1 ? P.y1 + (size_t)row * ns : nullptr;
+        const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
+        const float o0 = osc0 * osx, o1 = osc1 * osx;
+        for (int ti = 0; ti < kMmCH / 256 / 4; ++ti) {
+            const int T = wv + 4 * ti;
+            if (c0 + 256 * T >= ns) break;
+            mm_f4 c0h = mm_zero(), c0l = mm_zero(), c1h = mm_zero(), c1l = mm_zero();
+            const int gr0 = 32 * T + 2 * n16 + g;                   // 16-byte granule of this lane's first fragment
+            auto frag = [&](const mm_half* arr, int kk) -> mm_h8 {
+                const int gr = gr0 + 4 * kk;
+                return *reinterpret_cast<const mm_h8*>(arr + 8 * (gr + (gr >> 4)));
+            };
+            mm_h8 xh = frag(bh, 0), xl = frag(bl, 0);
+            static_for<KSM>([&](auto kq) {
+                constexpr int kk = decltype(kq)::value;
+                mm_h8 nh = xh, nl = xl;
+                if constexpr (kk + 1 < KSM) {                       // the next k-step's windows are in flight under this one's products
+                    nh = frag(bh, kk + 1);
+                    nl = frag(bl, kk + 1);
+                }
+                if constexpr (kk < KS0) {
+                    c0h = mm_mfma(a0h[kk], xh, c0h);
+                    c0l = mm_mfma(a0h[kk], xl, c0l);
+                }
+                if constexpr (kk < KS1) {
+                    c1h = mm_mfma(a1h[kk], xh, c1h);
+                    c1l = mm_mfma(a1h[kk], xl, c1l);
+                }
+                if constexpr (kk < KS0) c0l = mm_mfma(a0l[kk], xh, c0l);
+                if constexpr (kk < KS1) c1l = mm_mfma(a1l[kk], xh, c1l);
+                xh = nh;
+                xl = nl;
+            });
+            const int k = c0 + 256 * T + 16 * n16 + 4 * g;          // this lane's four lags
+            float r0[4], r1[4];
+            static_for<4>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                r0[r] = fmaf(mm_get(c0l, r), kMmLoInv, mm_get(c0h, r)) * o0;
+                if constexpr (KS1 > 0) r1[r] = fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)) * o1;
+            });
+            if (valign && k + 3 < ns) {
+                mm_store4(ya + k, r0[0], r0[1], r0[2], r0[3]);
+                if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (k + r < ns) {
+                        ya[k + r] = r0[r];
+                        if constexpr (KS1 > 0) yb[k + r] = r1[r];
+                    }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+}  // namespace d4w
+
+using namespace d4w;
+
+extern "C" {
+
+int d4w_xcorr_mm_max_support(void) { return kMmMaxSupport; }
+
+int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const float* mean,
+                     const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0, float* y1,
+                     void* stream) {
+    if (!x || !y0 || !taps || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
+    if (xnext && (n_next < 0 || ld_next < n_next)) return fail(D4W_EINVAL, "a continuation needs 0 <= n_next <= ld_next");
+    if (ntpl == 1) len1 = len0;
+    if (len0 < 1 || len1 < 1 || len0 > ltaps || len1 > ltaps || std::max(len0, len1) > kMmMaxSupport)
+        return fail(D4W_EINVAL, "template supports (%d, %d) must lie in 1..min(ltaps = %d, %d)", len0, len1, ltaps, kMmMaxSupport);
+    MmArgs P;
+    P.x = x; P.xnext = xnext; P.mean = mean; P.maxabs = maxabs; P.taps = taps; P.y0 = y0; P.y1 = y1;
+    P.nx = nx; P.ns = ns; P.ld_next = ld_next; P.n_next = xnext ? n_next : 0; P.ltaps = ltaps; P.len0 = len0; P.len1 = len1;
+    const long long total = (long long)nx * ceil_div(ns, kMmCH);
+    // persistent workgroups: D4W_MM_WGS per compute unit (default 3), never more than there are chunks
+    static const int per_cu = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 3; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
+    int ncu = 256;
+#ifndef D4W_EMU
+    {
+        int devid = 0;
+        D4W_HIP(hipGetDevice(&devid));
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) ncu = v;
+    }
+#else
+    ncu = 2;
+#endif
+    const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
+    const size_t lds = (size_t)4 * kMmArr * sizeof(mm_half) + 8 * sizeof(float);
+    const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
+    if (ntpl == 1)
+        D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+    else if (ks0 <= 5 && per_cu >= 3)
+        D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 3>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+    else if (ks0 <= 5)
+        D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+    else
+        D4W_LAUNCH((xcorr_mm_rows<kMmKS, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+    (void)ks1;
+    return D4W_OK;
+}
+
+}  // extern "C"

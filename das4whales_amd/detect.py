@@ -62,10 +62,10 @@ def _taps_tensor(taps_list, device):
 _xf_tables = {}     # (templates, device, stream) -> [taps tensor, lt, workspace, tables built]
 
 
-def _xf_prepared(grp, device):
+def _xf_prepared(grp, device, ws=True):
     """Device taps + the overlap-save workspace of a template group, kept per (templates, device, stream): the second
     call with the same templates on the same stream finds the template spectra already in the workspace (taps = NULL
-    in d4w_xcorr_fft_cont_f32) and uploads nothing."""
+    in d4w_xcorr_fft_cont_f32) and uploads nothing.  ws=False (the matrix-core form): the taps only."""
     key = (tuple(np.asarray(t, dtype=np.float64).tobytes() for t in grp), str(device),
            int(torch.cuda.current_stream(device).cuda_stream))
     with _cache_lock:
@@ -74,26 +74,43 @@ def _xf_prepared(grp, device):
             if len(_xf_tables) > 32:
                 _xf_tables.clear()
             taps, lt = _taps_tensor(grp, device)
-            ws = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device)
-            ent = _xf_tables[key] = [taps, lt, ws, False]
+            ent = _xf_tables[key] = [taps, lt, None, False]
+        if ws and ent[2] is None:
+            ent[2] = torch.empty(int(lib.d4w_xcorr_fft_ws_bytes()), dtype=torch.uint8, device=device)
     return ent
+
+
+def _xcorr_method(taps_list, ns, method):
+    """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores, supports <= 177 samples, the
+    default), "fft" (overlap-save, supports <= 161, rows >= 1024 samples) or "direct" (any support).  D4W_XCORR_METHOD
+    overrides "auto" (measurements, A/B tests)."""
+    import os
+    if method == "auto":
+        method = os.environ.get("D4W_XCORR_METHOD", "auto")
+    longest = max(len(t) for t in taps_list)
+    if method == "mm" or (method == "auto" and longest <= int(lib.d4w_xcorr_mm_max_support())):
+        if longest > int(lib.d4w_xcorr_mm_max_support()):
+            raise ValueError("the matrix-core correlation takes supports <= %d samples" % int(lib.d4w_xcorr_mm_max_support()))
+        return "mm"
+    if method == "fft" or (method == "auto" and ns >= 1024 and longest <= int(lib.d4w_xcorr_fft_max_support())):
+        return "fft"
+    return "direct"
 
 
 def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None):
     """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
-    method: "fft" (overlap-save, supports <= 161 samples), "direct", or "auto" (fft when it applies).
+    method: "mm" (matrix cores), "fft" (overlap-save), "direct", or "auto" (_xcorr_method).
     stats: optional (mean, maxabs) CUDA tensors of the rows, e.g. from FkPlan.apply_stats.
     cont: optional (tensor [nx, >= n], n): the record continues -- the last lags read the first n samples of these rows
-    instead of zeros (stream.FileStream); exactly two templates and the FFT form (xcorr_continuation_ok)."""
+    instead of zeros (stream.FileStream); the matrix-core form, or exactly two templates on the FFT form."""
     nx, ns = x.shape
     outs = []
-    use_fft = method == "fft" or (method == "auto" and ns >= 1024
-                                  and max(len(t) for t in taps_list) <= int(lib.d4w_xcorr_fft_max_support()))
+    how = _xcorr_method(taps_list, ns, method)
     if cont is not None:
         nxt, n_next = cont
-        if not (use_fft and len(taps_list) == 2 and nxt.is_cuda and nxt.dtype == torch.float32 and nxt.stride(1) == 1
-                and nxt.shape[0] == nx and nxt.shape[1] >= n_next):
-            raise ValueError("a continuation needs two templates, the FFT form and float32 CUDA rows")
+        if not (how in ("mm", "fft") and (how == "mm" or len(taps_list) == 2) and nxt.is_cuda and nxt.dtype == torch.float32
+                and nxt.stride(1) == 1 and nxt.shape[0] == nx and nxt.shape[1] >= n_next):
+            raise ValueError("a continuation needs the matrix-core form (or two templates on the FFT form) and float32 CUDA rows")
     with torch.cuda.device(x.device):
         mean = mx = None
         if normalize and stats is not None:
@@ -105,7 +122,18 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
         for i in range(0, len(taps_list), 2):                      # two templates per read of x
             grp = taps_list[i:i + 2]
             ys = [torch.empty_like(x) for _ in grp]
-            if use_fft:
+            if how == "mm":
+                taps, lt, _, _ = _xf_prepared(grp, x.device, ws=False)
+                check(lib.d4w_xcorr_mm_f32(dev.ptr(x), nx, ns,
+                                           dev.ptr(cont[0]) if cont is not None else None,
+                                           int(cont[0].stride(0)) if cont is not None else 0,
+                                           int(cont[1]) if cont is not None else 0,
+                                           dev.ptr(mean) if normalize else None, dev.ptr(mx) if normalize else None,
+                                           dev.ptr(taps), len(grp), lt, len(grp[0]), len(grp[-1]),
+                                           dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None, dev.stream_ptr(x)))
+                outs.extend(ys)
+                continue
+            if how == "fft":
                 ent = _xf_prepared(grp, x.device)
                 taps, lt, ws, built = ent
                 check(lib.d4w_xcorr_fft_cont_f32(dev.ptr(x), nx, ns,
@@ -131,9 +159,12 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
 
 
 def xcorr_continuation_ok(taps_list, ns):
-    """Whether _xcorr_device(..., cont=...) applies: two templates that run the fused overlap-save kernel."""
+    """Whether _xcorr_device(..., cont=...) applies: the matrix-core form, or two templates that run the fused overlap-save kernel."""
     import os
-    return (len(taps_list) == 2 and ns >= 1024 and max(len(t) for t in taps_list) <= int(lib.d4w_xcorr_fft_max_support())
+    how = _xcorr_method(taps_list, ns, "auto")
+    if how == "mm":
+        return True
+    return (how == "fft" and len(taps_list) == 2
             and os.environ.get("D4W_XF_FUSED", "1") == "1" and os.environ.get("D4W_XF_TPAIR", "0") == "0")
 
 

@@ -1,0 +1,44 @@
+"""Matched filter on the matrix cores (csrc/xcorr_mm.hip) against the overlap-save FFT kernel: HIP-event medians at
+NX x NS (default 20000 x 120000), the error of both against a float64 correlation of a few rows, one JSON line per
+setting.  D4W_MM_WGS (persistent workgroups per compute unit) is read once per process: run it once per value."""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from das4whales_amd import detect as ddet
+nx, ns, fs = int(os.environ.get("NX", 20000)), int(os.environ.get("NS", 120000)), 200.0
+gen = torch.Generator(device="cuda").manual_seed(1)
+x = torch.randn((nx, ns), device="cuda", generator=gen) + 0.25
+t = np.arange(ns) / fs
+tpl = [ddet._normalised_support(ddet.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)),
+       ddet._normalised_support(ddet.gen_template_fincall(t, fs, 14.7, 21.8, 0.78))]
+mean = x.mean(dim=1).contiguous()
+mx = x.abs().amax(dim=1).contiguous()
+
+
+def timeit(method, normalize=True, tl=tpl):
+    ts = []
+    for i in range(10):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ys = ddet._xcorr_device(x, tl, normalize=normalize, method=method, stats=(mean, mx) if normalize else None)
+        b.record(); b.synchronize()
+        ts.append(a.elapsed_time(b)); del ys
+    return float(np.median(ts[3:])), float(np.min(ts[3:]))
+
+
+rows = [0, 1, nx // 2, nx - 1]
+xs = x[rows].double().cpu().numpy()
+xn = (xs - mean[rows].double().cpu().numpy()[:, None]) / mx[rows].double().cpu().numpy()[:, None]
+ref = [np.stack([np.correlate(np.concatenate((r, np.zeros(len(tp) - 1))), tp, "valid") for r in xn]) for tp in tpl]
+out = {"shape": [nx, ns], "wgs": os.environ.get("D4W_MM_WGS", "3")}
+for m in ("mm", "fft"):
+    ys = ddet._xcorr_device(x, tpl, normalize=True, method=m, stats=(mean, mx))
+    out[m + "_err_vs_f64"] = [float(np.max(np.abs(ys[k][rows].double().cpu().numpy() - ref[k])) / np.max(np.abs(ref[k]))) for k in range(2)]
+    del ys
+    out[m + "_ms_median_min"] = timeit(m)
+out["mm_ms_no_normalise"] = timeit("mm", normalize=False)
+out["mm_ms_one_template"] = timeit("mm", tl=tpl[1:])
+gb = 12.0 * nx * ns / 1e9
+out["mm_TBps"] = gb / out["mm_ms_median_min"][0]
+out["fft_TBps"] = gb / out["fft_ms_median_min"][0]
+print(json.dumps(out))

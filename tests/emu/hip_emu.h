@@ -273,3 +273,62 @@ using std::min;
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), ##__VA_ARGS__)
+
+// ------------------------------------------------------------------------------------------
+// binary16 values and the 16x16x32 f16 matrix instruction (csrc/xcorr_mm.hip)
+// ------------------------------------------------------------------------------------------
+namespace hipemu {
+// float -> binary16, round to nearest even, subnormals kept (v_cvt_f16_f32)
+inline uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((x > 0x7F800000u) ? 0x200u : 0u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);              // rounds to infinity
+    if (x < 0x33000001u) return (uint16_t)sign;                           // below half the smallest subnormal
+    const int e = (int)(x >> 23) - 127;
+    uint32_t man = (x & 0x7FFFFFu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }                    // subnormal result
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; man &= 0x7FFFFFu; }
+    uint32_t q = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;                     // a carry into the exponent is the right answer
+    return (uint16_t)(sign | (base + q));
+}
+inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 0x3FFu;
+    float r;
+    if (e == 0) r = ldexpf((float)m, -24);
+    else if (e == 31) r = m ? NAN : INFINITY;
+    else r = ldexpf((float)(m | 0x400u), e - 25);
+    uint32_t x;
+    memcpy(&x, &r, 4);
+    x |= sign;
+    memcpy(&r, &x, 4);
+    return r;
+}
+inline uint16_t g_mfma_a[1024][8], g_mfma_b[1024][8];
+// D = A B + C of v_mfma_f32_16x16x32_f16: lane l holds A[l & 15][8 (l >> 4) + j], B[8 (l >> 4) + j][l & 15], j < 8,
+// and C / D[4 (l >> 4) + r][l & 15], r < 4.  Products are exact in float; the sum is kept in double and rounded once.
+inline void mfma_f32_16x16x32_f16(const uint16_t (&a)[8], const uint16_t (&b)[8], float (&c)[4]) {
+    const int me = g_lin_tid, base = (me / 64) * 64, lane = me & 63;
+    memcpy(g_mfma_a[me], a, 16);
+    memcpy(g_mfma_b[me], b, 16);
+    yield(WAIT_WAVE);
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        double s = 0.0;
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j)
+                s += (double)f16_to_f32(g_mfma_a[base + row + 16 * g][j]) * (double)f16_to_f32(g_mfma_b[base + col + 16 * g][j]);
+        c[r] = (float)((double)c[r] + s);
+    }
+    yield(WAIT_WAVE);                                                     // nobody overwrites the slots before all have read
+}
+}  // namespace hipemu

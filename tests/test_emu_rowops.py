@@ -396,3 +396,110 @@ def test_fir_fft_between_neighbours(emu, nx, ns, K, nl, nr):
                                     K, vp(first), dcg, vp(y), vp(ws), None) != 0
     assert emu.d4w_fir_fft_halo_f32(vp(x), nx, ns, None, 0, 0, vp(right), right.shape[1], nr, vp(taps), K, vp(first), dcg, vp(y),
                                     vp(ws), None) != 0
+
+
+# ------------------------------------------------------------------------------------------
+# matched filter as a Toeplitz product on the matrix cores (csrc/xcorr_mm.hip)
+# ------------------------------------------------------------------------------------------
+def xcorr_mm_emu(lib, x, taps_list, normalize=True, nxt=None, n_next=0, stats=None):
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    lt = max(4, -(-max(len(t) for t in taps_list) // 4) * 4)
+    taps = np.zeros((len(taps_list), lt), dtype=np.float32)
+    for i, t in enumerate(taps_list):
+        taps[i, :len(t)] = t
+    mean = np.empty(nx, dtype=np.float32)
+    mx = np.empty(nx, dtype=np.float32)
+    if stats is not None:
+        mean, mx = stats
+    elif normalize:
+        assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
+    ys = [np.full_like(xf, np.nan) for _ in taps_list]
+    rc = lib.d4w_xcorr_mm_f32(vp(xf), nx, ns, vp(nxt) if nxt is not None else None, nxt.shape[1] if nxt is not None else 0, n_next,
+                              vp(mean) if normalize else None, vp(mx) if normalize else None,
+                              vp(taps), len(taps_list), lt, len(taps_list[0]), len(taps_list[-1]),
+                              vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None, None)
+    assert rc == 0, lib.d4w_last_error()
+    return ys
+
+
+def test_f16_conversions_of_the_emulator():
+    """The emulator's binary16 helpers against NumPy's float16 (round to nearest even, subnormals)."""
+    import subprocess, sys, os, textwrap
+    src = textwrap.dedent("""
+        #include "hip_emu.h"
+        extern "C" void conv(const float* x, unsigned short* h, float* back, int n) {
+            for (int i = 0; i < n; ++i) { h[i] = hipemu::f32_to_f16(x[i]); back[i] = hipemu::f16_to_f32(h[i]); }
+        }""")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    out = os.path.join(here, "_build", "f16conv.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-DD4W_EMU", "-I", here, "-x", "c++", "-", "-o", out],
+                   input=src, text=True, check=True)
+    lib = ctypes.CDLL(out)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.integers(-9, 5, 20000),
+                        [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 6.1e-5, 6.0e-5,
+                         0.333251953125 + 2.0 ** -13]]).astype(np.float32)
+    h = np.empty(x.size, dtype=np.uint16)
+    back = np.empty(x.size, dtype=np.float32)
+    lib.conv(vp(x), vp(h), vp(back), x.size)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16)
+    assert np.array_equal(h, want.view(np.uint16))
+    assert np.array_equal(back, want.astype(np.float32))
+
+
+def test_xcorr_mm_golden(emu, golden):
+    d = golden("detect_12x2000.npz")
+    yh, yl = xcorr_mm_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])])
+    assert rel(yh, d["corr_hf"]) < 2e-6                 # reference detect.compute_cross_correlogram
+    assert rel(yl, d["corr_lf"]) < 2e-6
+    (y1,) = xcorr_mm_emu(emu, d["x"], [norm_taps(d["lf"])])
+    assert rel(y1, d["corr_lf"]) < 2e-6
+    zl, zh = xcorr_mm_emu(emu, d["x"], [norm_taps(d["lf"]), norm_taps(d["hf"])])     # longer template first: the 6 + 6 kernel
+    assert rel(zh, d["corr_hf"]) < 2e-6 and rel(zl, d["corr_lf"]) < 2e-6
+    fh, fl = xcorr_fft_emu(emu, d["x"], [norm_taps(d["hf"]), norm_taps(d["lf"])])
+    assert rel(yh, fh.astype(np.float64)) < 3e-6        # matrix-core and FFT forms agree to rounding
+
+
+@pytest.mark.parametrize("nx,ns,l0,l1", [(3, 9001, 161, 7), (2, 4096, 136, 156), (1, 4289, 1, 177), (4, 1300, 50, 50), (2, 100, 100, 3),
+                                          (1, 8192 + 4288, 136, 156)])
+def test_xcorr_mm_ragged(emu, nx, ns, l0, l1):
+    """Odd row lengths (unaligned rows: the sample-by-sample loads and stores), chunks with a ragged tail, a row shorter
+    than a chunk, the maximum support, rows without normalisation (per-chunk power-of-two scale) and with a large offset."""
+    rng = np.random.default_rng(ns + l0)
+    x = rng.standard_normal((nx, ns)) * 37.0 + 0.5
+    t0, t1 = rng.standard_normal(l0) * 5.0, rng.standard_normal(l1) * 0.01
+    y0, y1 = xcorr_mm_emu(emu, x, [t0, t1], normalize=False)
+    for c in range(nx):
+        assert rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - l0)))) < 2e-6
+        assert rel(y1[c], orc.shift_xcorr(x[c], np.pad(t1, (0, ns - l1)))) < 2e-6
+    assert emu.d4w_xcorr_mm_max_support() == 177
+    xs = (x + 1000.0).astype(np.float32)
+    z0, z1 = xcorr_mm_emu(emu, xs, [t0, t1])
+    xn = (xs.astype(np.float64) - xs.astype(np.float64).mean(axis=1, keepdims=True)) / np.abs(xs).max(axis=1, keepdims=True)
+    for c in range(nx):
+        assert rel(z0[c], orc.shift_xcorr(xn[c], np.pad(t0, (0, ns - l0)))) < 1e-5    # float32 row mean of a 1000x offset
+    assert emu.d4w_xcorr_mm_f32(vp(xs), nx, ns, None, 0, 0, None, None, vp(np.zeros((1, 180), np.float32)), 1, 180, 178, 178,
+                                vp(z0), None, None) != 0
+
+
+@pytest.mark.parametrize("nx,ns", [(3, 4100), (2, 9000), (2, 4096 * 2)])
+def test_xcorr_mm_continuation(emu, nx, ns):
+    """The record continues in xnext: same numbers as correlating [x | head] with x's own statistics."""
+    rng = np.random.default_rng(nx * ns)
+    x = (rng.standard_normal((nx, ns)) + 0.3).astype(np.float32)
+    nxt = (rng.standard_normal((nx, 500)) - 0.2).astype(np.float32)
+    t0, t1 = rng.standard_normal(136) * np.hanning(136), rng.standard_normal(156) * np.hanning(156)
+    L = 156
+    mean, mx = np.empty(nx, dtype=np.float32), np.empty(nx, dtype=np.float32)
+    assert emu.d4w_row_stats_f32(vp(x), nx, ns, vp(mean), vp(mx), None) == 0
+    cont = xcorr_mm_emu(emu, x, [t0, t1], nxt=nxt, n_next=L - 1, stats=(mean, mx))
+    ext = np.ascontiguousarray(np.concatenate((x, nxt[:, :L - 1]), axis=1))
+    ref = xcorr_mm_emu(emu, ext, [t0, t1], stats=(mean, mx))
+    for c, r in zip(cont, ref):
+        assert np.max(np.abs(c - r[:, :ns])) <= 2e-6 * np.max(np.abs(r))
+    xa = (np.concatenate((x[0], nxt[0, :L - 1])).astype(np.float64) - float(mean[0])) / float(mx[0])
+    for k in (ns - 1, ns - 77, ns - L + 1):
+        assert abs(cont[1][0, k] - float(np.dot(xa[k:k + 156], t1))) < 2e-6 * np.max(np.abs(ref[1]))
