@@ -652,7 +652,8 @@ def main():
 
     stage_ms = {}
     acc = np.zeros(5)
-    mf_k = {"mf_row_stats": 0.0, "mf_xcorr_fft_fused": 0.0, "mf_xcorr_fft_blocks_1tpl": 0.0}
+    mf_how = ddet._xcorr_method(tpl, ns, "auto")        # the kernel the step's matched filter runs on ("mm" unless overridden)
+    mf_k = {"mf_row_stats": 0.0, "mf_xcorr_mm": 0.0, "mf_xcorr_fft_fused": 0.0, "mf_xcorr_fft_blocks_1tpl": 0.0}
     for _ in range(args.steps):
         if "bp" in stages:
             stage_ms["bp_sosfiltfilt"] = stage_ms.get("bp_sosfiltfilt", 0.0) + ev_time(
@@ -671,12 +672,13 @@ def main():
             stage_ms["mf_xcorr" if fused else "mf_rowstats_xcorr"] = stage_ms.get(
                 "mf_xcorr" if fused else "mf_rowstats_xcorr", 0.0) + ev_time(
                 lambda: ddet._xcorr_device(src, tpl, normalize=True, stats=st))
-            # the stage's kernels one by one: row_stats, the fused two-template block transform the step
-            # runs (the 30-microsecond spectra kernel + ONE launch), and for reference the one-template form
+            # the stage's kernels one by one: row_stats, the two-template matrix-core kernel the step runs (ONE launch), and
+            # for reference the overlap-save FFT kernels of rounds 1-3 (fused two-template launch, one-template form)
             mean = torch.empty(nx, dtype=torch.float32, device=device)
             mx = torch.empty(nx, dtype=torch.float32, device=device)
             mf_k["mf_row_stats"] += ev_time(lambda: dw._lib.check(dw._lib.lib.d4w_row_stats_f32(
                 src.data_ptr(), nx, ns, mean.data_ptr(), mx.data_ptr(), torch.cuda.current_stream().cuda_stream)))
+            mf_k["mf_xcorr_mm"] += ev_time(lambda: ddet._xcorr_device(src, tpl, normalize=True, method="mm", stats=(mean, mx)))
             mf_k["mf_xcorr_fft_fused"] += ev_time(lambda: ddet._xcorr_device(src, tpl, normalize=False, method="fft"))
             one = 0.0
             for tp in tpl:
@@ -698,14 +700,17 @@ def main():
             kernel_ms[k] = mf_k[k] / args.steps
             if k == "mf_row_stats" and "fk" in stages and not args.no_fused_stats:
                 continue                     # not part of the step: statistics come from the f-k epilogue
-            if k == "mf_xcorr_fft_blocks_1tpl" and len(tpl) == 2:
-                continue                     # not part of the step: two templates run as ONE fused launch
-            if k == "mf_xcorr_fft_fused" and len(tpl) != 2:
+            if k == "mf_xcorr_mm" and mf_how != "mm":
                 continue
+            if k == "mf_xcorr_fft_blocks_1tpl" and (len(tpl) == 2 or mf_how != "fft"):
+                continue                     # not part of the step: two templates run as ONE fused launch
+            if k == "mf_xcorr_fft_fused" and (len(tpl) != 2 or mf_how != "fft"):
+                continue                     # reference only unless D4W_XCORR_METHOD=fft puts it back into the step
             cand[k] = kernel_ms[k]
         alg_bytes["mf_row_stats"] = 4.0 * samples
         alg_bytes["mf_xcorr_fft_blocks_1tpl"] = 8.0 * samples      # read the block, write one correlogram
         alg_bytes["mf_xcorr_fft_fused"] = 12.0 * samples           # read the block once, write two correlograms
+        alg_bytes["mf_xcorr_mm"] = (4.0 + 4.0 * len(tpl)) * samples  # read the block once, write one correlogram per template
     if "bp" in stages:
         cand["bp_sosfiltfilt"] = stage_ms["bp_sosfiltfilt"]
         alg_bytes["bp_sosfiltfilt"] = 8.0 * samples         # read once, write once
@@ -714,7 +719,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by scripts/pmc_summary.py
     tkey = {"mf_row_stats": "row_stats", "mf_xcorr_fft_blocks_1tpl": "xcorr_fft_blocks",
-            "mf_xcorr_fft_fused": "xcorr_fft_fused"}.get(dom, dom)
+            "mf_xcorr_fft_fused": "xcorr_fft_fused", "mf_xcorr_mm": "xcorr_mm_rows"}.get(dom, dom)
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")

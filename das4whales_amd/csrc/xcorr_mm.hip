@@ -65,6 +65,7 @@ __device__ __forceinline__ mm_f4 mm_mfma(const mm_h8& a, const mm_h8& b, mm_f4 c
 __device__ __forceinline__ float mm_get(const mm_f4& c, int r) { return c.v[r]; }
 __device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a.v[j] = h; }
 __device__ __forceinline__ int mm_uniform(int v) { return v; }
+__device__ __forceinline__ void mm_sched_fence() {}
 __device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 #else
 typedef _Float16 mm_half;
@@ -78,14 +79,20 @@ __device__ __forceinline__ mm_f4 mm_mfma(mm_h8 a, mm_h8 b, mm_f4 c) { return __b
 __device__ __forceinline__ float mm_get(const mm_f4& c, int r) { return c[r]; }
 __device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a[j] = h; }
 __device__ __forceinline__ int mm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void mm_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) {
     mm_f4 t = {a, b, c, d};
     __builtin_nontemporal_store(t, reinterpret_cast<mm_f4*>(p));
 }
 #endif
 
-// v = hi + lo / 2048 to 22-23 significant bits
+// v = hi + lo / 2048 to 22-23 significant bits.  v is pinned to ONE float32 value first: left alone, hipcc contracts the
+// caller's multiply into v_fma_mixlo_f16 for the residual (hi rounded once from the exact product) while the stored hi comes
+// from v_cvt_pk_f16_f32 of the rounded product -- the two differ by a binary16 ulp for one sample in ~10^4 (a 1e-4 error).
 __device__ __forceinline__ void mm_split(float v, mm_half& hi, mm_half& lo) {
+#ifndef D4W_EMU
+    asm volatile("" : "+v"(v));
+#endif
     hi = mm_to_half(v);
     lo = mm_to_half((v - mm_to_float(hi)) * kMmLoScale);
 }
@@ -283,54 +290,62 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         float* yb = KS1 ? P.y1 + (size_t)row * ns : nullptr;
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
         const float o0 = osc0 * osx, o1 = osc1 * osx;
-        for (int ti = 0; ti < kMmCH / 256 / 4; ++ti) {
-            const int T = wv + 4 * ti;
-            if (c0 + 256 * T >= ns) break;
-            mm_f4 c0h = mm_zero(), c0l = mm_zero(), c1h = mm_zero(), c1l = mm_zero();
-            const int gr0 = 32 * T + 2 * n16 + g;                   // 16-byte granule of this lane's first fragment
-            auto frag = [&](const mm_half* arr, int kk) -> mm_h8 {
-                const int gr = gr0 + 4 * kk;
-                return *reinterpret_cast<const mm_h8*>(arr + 8 * (gr + (gr >> 4)));
-            };
-            mm_h8 xh = frag(bh, 0), xl = frag(bl, 0);
-            static_for<KSM>([&](auto kq) {
-                constexpr int kk = decltype(kq)::value;
-                mm_h8 nh = xh, nl = xl;
-                if constexpr (kk + 1 < KSM) {                       // the next k-step's windows are in flight under this one's products
-                    nh = frag(bh, kk + 1);
-                    nl = frag(bl, kk + 1);
-                }
-                if constexpr (kk < KS0) {
-                    c0h = mm_mfma(a0h[kk], xh, c0h);
-                    c0l = mm_mfma(a0h[kk], xl, c0l);
-                }
-                if constexpr (kk < KS1) {
-                    c1h = mm_mfma(a1h[kk], xh, c1h);
-                    c1l = mm_mfma(a1h[kk], xl, c1l);
-                }
-                if constexpr (kk < KS0) c0l = mm_mfma(a0l[kk], xh, c0l);
-                if constexpr (kk < KS1) c1l = mm_mfma(a1l[kk], xh, c1l);
-                xh = nh;
-                xl = nl;
-            });
-            const int k = c0 + 256 * T + 16 * n16 + 4 * g;          // this lane's four lags
-            float r0[4], r1[4];
-            static_for<4>([&](auto rr) {
-                constexpr int r = decltype(rr)::value;
-                r0[r] = fmaf(mm_get(c0l, r), kMmLoInv, mm_get(c0h, r)) * o0;
-                if constexpr (KS1 > 0) r1[r] = fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)) * o1;
-            });
-            if (valign && k + 3 < ns) {
-                mm_store4(ya + k, r0[0], r0[1], r0[2], r0[3]);
-                if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
-            } else {
-                for (int r = 0; r < 4; ++r)
-                    if (k + r < ns) {
-                        ya[k + r] = r0[r];
-                        if constexpr (KS1 > 0) yb[k + r] = r1[r];
-                    }
+        // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
+        // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
+        // so an LDS round trip hides under 12 matrix instructions instead of stalling the wave at every k-step
+        constexpr int NTW = kMmCH / 256 / 4, NST = NTW * KSM, PF = 2;
+        auto frag = [&](const mm_half* arr, int T, int kk) -> mm_h8 {
+            const int gr = 32 * T + 2 * n16 + g + 4 * kk;           // 16-byte granule: sample 256 T + 16 n16 + 32 kk + 8 g
+            return *reinterpret_cast<const mm_h8*>(arr + 8 * (gr + (gr >> 4)));
+        };
+        mm_h8 fh[PF + 1], fl[PF + 1];
+        static_for<PF>([&](auto ss) {
+            constexpr int s_ = decltype(ss)::value;
+            fh[s_] = frag(bh, wv + 4 * (s_ / KSM), s_ % KSM);
+            fl[s_] = frag(bl, wv + 4 * (s_ / KSM), s_ % KSM);
+        });
+        mm_f4 c0h = mm_zero(), c0l = mm_zero(), c1h = mm_zero(), c1l = mm_zero();
+        static_for<NST>([&](auto ss) {
+            constexpr int s_ = decltype(ss)::value, ti = s_ / KSM, kk = s_ % KSM;
+            if constexpr (s_ + PF < NST) {
+                fh[(s_ + PF) % (PF + 1)] = frag(bh, wv + 4 * ((s_ + PF) / KSM), (s_ + PF) % KSM);
+                fl[(s_ + PF) % (PF + 1)] = frag(bl, wv + 4 * ((s_ + PF) / KSM), (s_ + PF) % KSM);
             }
-        }
+            mm_sched_fence();
+            const mm_h8 xh = fh[s_ % (PF + 1)], xl = fl[s_ % (PF + 1)];
+            if constexpr (kk < KS0) {
+                c0h = mm_mfma(a0h[kk], xh, c0h);
+                c0l = mm_mfma(a0h[kk], xl, c0l);
+            }
+            if constexpr (kk < KS1) {
+                c1h = mm_mfma(a1h[kk], xh, c1h);
+                c1l = mm_mfma(a1h[kk], xl, c1l);
+            }
+            if constexpr (kk < KS0) c0l = mm_mfma(a0l[kk], xh, c0l);
+            if constexpr (kk < KS1) c1l = mm_mfma(a1l[kk], xh, c1l);
+            mm_sched_fence();
+            if constexpr (kk == KSM - 1) {                          // the tile is complete: scale, combine, stream out
+                const int T = wv + 4 * ti;
+                const int k = c0 + 256 * T + 16 * n16 + 4 * g;      // this lane's four lags
+                float r0[4], r1[4];
+                static_for<4>([&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    r0[r] = fmaf(mm_get(c0l, r), kMmLoInv, mm_get(c0h, r)) * o0;
+                    if constexpr (KS1 > 0) r1[r] = fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)) * o1;
+                });
+                c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
+                if (valign && k + 3 < ns) {
+                    mm_store4(ya + k, r0[0], r0[1], r0[2], r0[3]);
+                    if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
+                } else {                                            // a row end or an unaligned row (tiles beyond the row: nothing)
+                    for (int r = 0; r < 4; ++r)
+                        if (k + r < ns) {
+                            ya[k + r] = r0[r];
+                            if constexpr (KS1 > 0) yb[k + r] = r1[r];
+                        }
+                }
+            }
+        });
         buf ^= 1;
     }
 }
@@ -356,8 +371,11 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
     P.x = x; P.xnext = xnext; P.mean = mean; P.maxabs = maxabs; P.taps = taps; P.y0 = y0; P.y1 = y1;
     P.nx = nx; P.ns = ns; P.ld_next = ld_next; P.n_next = xnext ? n_next : 0; P.ltaps = ltaps; P.len0 = len0; P.len1 = len1;
     const long long total = (long long)nx * ceil_div(ns, kMmCH);
-    // persistent workgroups: D4W_MM_WGS per compute unit (default 3), never more than there are chunks
-    static const int per_cu = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 3; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
+    // persistent workgroups per compute unit: 2 for two templates (207 VGPRs: the Toeplitz fragments of both templates stay
+    // in registers; a 168-register build for three workgroups spills and ran 8.5 ms against 6.6), 3 for one template
+    // (149 VGPRs).  D4W_MM_WGS overrides the count (measurements).
+    static const int env_wgs = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 0; return n < 0 ? 0 : (n > 8 ? 8 : n); }();
+    const int per_cu = env_wgs ? env_wgs : (ntpl == 1 ? 3 : 2);
     int ncu = 256;
 #ifndef D4W_EMU
     {
@@ -374,8 +392,6 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
     const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
     if (ntpl == 1)
         D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds, stream, P);
-    else if (ks0 <= 5 && per_cu >= 3)
-        D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 3>), dim3(grid), dim3(kMmThreads), lds, stream, P);
     else if (ks0 <= 5)
         D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
     else

@@ -190,6 +190,37 @@ def test_correlogram_full_size_rows_vs_oracle(dw):
     assert e1 < TOL and e2 < TOL
 
 
+def test_correlogram_matrix_core_form_is_float32_grade(dw):
+    """The default form (csrc/xcorr_mm.hip: binary16 hi / lo splits on the matrix cores) against the float64 oracle at a
+    tolerance ten times below the north star's, on EVERY sample of a block large enough to meet the rare cases (a hi / lo
+    pair that disagrees by one binary16 ulp is a 1e-4 error on one sample in ~10^4: 3.2 M samples would hold hundreds),
+    and against the two float32 forms (overlap-save FFT, direct FIR)."""
+    nx, ns = 64, 50000
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    x = torch.randn((nx, ns), dtype=torch.float32, device="cuda", generator=gen) * 3.0 + 0.7
+    time = np.arange(ns) / FS
+    tpl = [dw.detect._normalised_support(dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)),
+           dw.detect._normalised_support(dw.detect.gen_template_fincall(time, FS, 14.7, 21.8, 0.78))]
+    ym = dw.detect._xcorr_device(x, tpl, normalize=True, method="mm")
+    yf = dw.detect._xcorr_device(x, tpl, normalize=True, method="fft")
+    yd = dw.detect._xcorr_device(x, tpl, normalize=True, method="direct")
+    xs = x.double().cpu().numpy()
+    mean = x.mean(dim=1).double().cpu().numpy()
+    xn = (xs - mean[:, None]) / np.abs(xs).max(axis=1, keepdims=True)
+    for k in range(2):
+        ref = np.stack([np.correlate(np.concatenate((r, np.zeros(len(tpl[k]) - 1))), tpl[k], "valid") for r in xn])
+        em, ef, ed = (rel(y[k].cpu().numpy(), ref) for y in (ym, yf, yd))
+        print("template %d: matrix cores %.2e, FFT %.2e, direct %.2e vs float64" % (k, em, ef, ed))
+        assert em < 1e-6 and ef < 1e-6 and ed < 2e-6
+    (y1,) = dw.detect._xcorr_device(x, tpl[1:], normalize=True, method="mm")          # the one-template kernel
+    assert float((y1 - ym[1]).abs().max()) <= 1e-6 * float(ym[1].abs().max())
+    # no row statistics from the caller: every chunk scales itself by a power of two
+    yr = dw.detect._xcorr_device(x, tpl, normalize=False, method="mm")
+    rd = dw.detect._xcorr_device(x, tpl, normalize=False, method="direct")
+    assert float((yr[0] - rd[0]).abs().max()) <= 2e-6 * float(rd[0].abs().max())
+
+
 # ------------------------------------------------------------------------------------------
 # fused ingest (SURVEY 8f row f1)
 # ------------------------------------------------------------------------------------------
