@@ -825,6 +825,13 @@ struct d4w_fk_plan {
     size_t cap_W = 0;
     int tf_band_cols = 0, tf_tail_cols = 0;   // per row: band (incl. Nyquist) and tail columns kept
     double bytes_cf = 42.0, bytes_tf = 42.0;  // modelled bytes per channel-sample of the two orders for the current mask
+    // Plan-owned scratch that every apply rewrites (W of the time-first order, the exchange buffers of `big`): applies of
+    // one plan from several host threads / streams are serialised -- a host mutex around the launch sequence, and the next
+    // apply's stream waits for the event the previous one recorded when it ran on another stream.
+    std::mutex apply_mu;
+    hipEvent_t apply_done = nullptr;
+    hipStream_t apply_stream = nullptr;
+    bool apply_used = false;
 };
 
 template <typename T>
@@ -915,6 +922,7 @@ int d4w_fk_plan_destroy(d4w_fk_plan* pl) {
     for (void* p : pl->allocs) (void)hipFree(p);
     if (pl->d_cmask) (void)hipFree(pl->d_cmask);
     if (pl->d_W) (void)hipFree(pl->d_W);
+    if (pl->apply_done) (void)hipEventDestroy(pl->apply_done);
     if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
     if (pl->d_cmlive) (void)hipFree(pl->d_cmlive);
     delete pl;
@@ -1423,6 +1431,15 @@ static inline float fk_key_value(unsigned k) {
     return v;
 }
 
+// the time-first workspace (12 B x nx x Lc, up to 1.3x the data block) goes back to the allocator
+static void fk_tf_release(d4w_fk_plan* pl) {
+    if (pl->d_W) (void)hipFree(pl->d_W);
+    if (pl->d_cmask) (void)hipFree(pl->d_cmask);
+    if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
+    if (pl->d_cmlive) (void)hipFree(pl->d_cmlive);
+    pl->d_W = nullptr; pl->d_cmask = nullptr; pl->d_colsrc = nullptr; pl->d_cmlive = nullptr; pl->cap_W = 0;
+}
+
 // Time-first order for the mask just folded (fk_tf.h): classify the half-spectrum columns, lay the kept ones out,
 // model the bytes of both orders; when time-first wins, build the pass tables, the compact band mask and the workspace.
 static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
@@ -1494,8 +1511,11 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
     pl->tf_tail_cols = N1 * rw[2];
     pl->bytes_tf = 24.0 + 18.0 * (double)(N1 * bw + (nyq_live ? TC : 0)) / M + 8.0 * (double)(N1 * rw[2]) / M;
     const bool force = ord && !strcmp(ord, "tf");
-    if (!force && !(pl->bytes_tf < 0.97 * pl->bytes_cf)) return D4W_OK;
-    if ((size_t)Lc * sizeof(float2) >= ((size_t)1 << 31)) return D4W_OK;      // 32-bit column offsets inside a row
+    // channel-first stays (it needs no workspace): what an earlier mask of this plan allocated for the other order is freed
+    if ((!force && !(pl->bytes_tf < 0.97 * pl->bytes_cf)) || (size_t)Lc * sizeof(float2) >= ((size_t)1 << 31)) {   // 32-bit column offsets inside a row
+        fk_tf_release(pl);
+        return D4W_OK;
+    }
     // tables
     std::vector<float> tgain(M, 0.f);
     std::vector<int> colsrc((size_t)Lc, -1);
@@ -1514,16 +1534,22 @@ static int fk_tf_setup(d4w_fk_plan* pl, double zero_gain, void* stream) {
     if (nyq_live) colsrc[(size_t)N1 * RW] = -2;
     const size_t need = (size_t)d.nx * Lc;
     if (need > pl->cap_W) {
-        if (pl->d_W) (void)hipFree(pl->d_W);
-        if (pl->d_cmask) (void)hipFree(pl->d_cmask);
-        if (pl->d_colsrc) (void)hipFree(pl->d_colsrc);
-        if (pl->d_cmlive) (void)hipFree(pl->d_cmlive);
-        pl->d_W = nullptr; pl->d_cmask = nullptr; pl->d_colsrc = nullptr; pl->d_cmlive = nullptr; pl->cap_W = 0;
-        if (hipMalloc((void**)&pl->d_W, need * sizeof(float2)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte compact spectrum failed", need * sizeof(float2));
-        if (hipMalloc((void**)&pl->d_cmask, need * sizeof(float)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the %zu-byte band mask failed", need * sizeof(float));
-        if (hipMalloc((void**)&pl->d_colsrc, ((size_t)M + 64 * (size_t)N1 + 64) * sizeof(int)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc failed");
-        // Cm tiles: at most C1 (N1 (N2 / TC + 2) + 1) whatever the mask
-        if (hipMalloc((void**)&pl->d_cmlive, (size_t)d.C1 * ((size_t)N1 * (N2 / TC + 2) + 1) * F.C2A * sizeof(unsigned)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc failed");
+        fk_tf_release(pl);
+        // Not enough memory for the workspace is not an error: the channel-first order works in place in the output block
+        // and gives the same result (more bytes moved).  Everything allocated so far goes back; pl->tf stays false.
+        const bool ok = hipMalloc((void**)&pl->d_W, need * sizeof(float2)) == hipSuccess &&
+                        hipMalloc((void**)&pl->d_cmask, need * sizeof(float)) == hipSuccess &&
+                        hipMalloc((void**)&pl->d_colsrc, ((size_t)M + 64 * (size_t)N1 + 64) * sizeof(int)) == hipSuccess &&
+                        // Cm tiles: at most C1 (N1 (N2 / TC + 2) + 1) whatever the mask
+                        hipMalloc((void**)&pl->d_cmlive, (size_t)d.C1 * ((size_t)N1 * (N2 / TC + 2) + 1) * F.C2A * sizeof(unsigned)) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            fk_tf_release(pl);
+            static bool told = false;
+            if (!told && getenv("D4W_VERBOSE")) fprintf(stderr, "das4whales_amd: %zu bytes for the time-first f-k workspace not available, channel-first order kept\n", need * 12);
+            told = true;
+            return D4W_OK;
+        }
         pl->cap_W = need;
     }
     D4W_HIP(hipMemcpyAsync(pl->d_tgain, tgain.data(), (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1666,8 +1692,32 @@ int d4w_fk_set_mask_design_f32(d4w_fk_plan* pl, int mode, double k_spacing, doub
 
 int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
 
+static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, float* row_mean,
+                        float* row_maxabs);
+
 static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev,
                          float* row_mean = nullptr, float* row_maxabs = nullptr) {
+    if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
+    // orders that work in place in the caller's output need no guard; the ones with plan-owned scratch are serialised
+    const bool shared = pl->tf || pl->big;
+    if (!shared) return fk_apply_run(pl, x, y, taper, stream, ev, row_mean, row_maxabs);
+    std::lock_guard<std::mutex> lk(pl->apply_mu);
+    hipStream_t st = (hipStream_t)stream;
+#ifndef D4W_EMU
+    if (pl->apply_used && pl->apply_stream != st) D4W_HIP(hipStreamWaitEvent(st, pl->apply_done, 0));
+#endif
+    const int rc = fk_apply_run(pl, x, y, taper, stream, ev, row_mean, row_maxabs);
+#ifndef D4W_EMU
+    if (!pl->apply_done) D4W_HIP(hipEventCreateWithFlags(&pl->apply_done, hipEventDisableTiming));
+    D4W_HIP(hipEventRecord(pl->apply_done, st));
+    pl->apply_stream = st;
+    pl->apply_used = true;
+#endif
+    return rc;
+}
+
+static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, float* row_mean,
+                        float* row_maxabs) {
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
     if ((row_mean == nullptr) != (row_maxabs == nullptr)) return fail(D4W_EINVAL, "row_mean and row_maxabs go together");
     if (!pl->has_mask) return fail(D4W_EINVAL, "no mask set on this plan");

@@ -23,7 +23,7 @@
 // products, hi hi + (hi lo + lo hi) 2^-11 -- each exact in the float32 accumulator of the matrix instruction; the
 // dropped lo lo 2^-22 term is below float32 rounding.  Rows are scaled to |x| <= 2 before the split (1 / max|x| of
 // detect.py:157 when the caller normalises, otherwise a power of two per chunk), templates by a power of two, so
-// nothing leaves the binary16 range.  Measured against the float64 oracle the result is as close as the float32
+// nothing leaves the binary16 range.  Measured against a float64 correlation the result is as close as the float32
 // FFT kernel's (tests/test_rowops_gpu.py).
 //
 // Launch shape.  Persistent workgroups (256 threads, 4 waves) walk chunks of 4096 lags of one row; the chunk's

@@ -32,6 +32,11 @@ class FkPlan:
             check(lib.d4w_fk_plan_create_ex(self.nx, self.ns, o, ctypes.byref(self._h)))
         self._mask_key = None
         self._mask_ref = None
+        # A plan is shared by every thread that filters this shape on this device (get_fk_plan): the public functions hold
+        # this lock over [check the mask key, design, fold the mask, launch the filter], so that two threads with different
+        # masks cannot interleave.  The launches are asynchronous -- the lock covers host time only -- and the library
+        # orders applies of one plan across streams itself where they share plan-owned scratch (fk_apply_impl).
+        self.lock = threading.RLock()
 
     def info(self):
         v = (ctypes.c_int * 8)()
@@ -56,7 +61,11 @@ class FkPlan:
         """Dense ndarray (any order / float dtype), sparse.COO-like (.todense()) or CUDA tensor,
         on the fftshift-ed grid, shape [nx, ns] -- what the reference designs return.
         prune_eps > 0 (opt-in, not exact): wavenumber rows whose folded gains stay below
-        prune_eps * max are skipped like all-zero rows (include/d4w.h d4w_fk_set_mask_dense_pruned_f32)."""
+        prune_eps * max are skipped like all-zero rows (include/d4w.h d4w_fk_set_mask_dense_pruned_f32).
+        prune_eps = 0 is exact to float32 rounding, not bit for bit: gains below D4W_FK_ROUND_EPS (default 2^-24)
+        / sqrt(nx ns) * max|M_h| count as zero and columns whose gain spread stays below that are taken at their mean
+        (what they add to any output sample is under half an ulp of rms(x) max|M_h|; the threshold follows the LARGEST
+        gain, so one outlier gain raises it for all).  D4W_FK_ROUND_EPS=0 keeps exact zeros only."""
         m = fk_filter_matrix
         if isinstance(m, DesignedMask):
             return self._set_mask_design(m, prune_eps)
@@ -85,9 +94,10 @@ class FkPlan:
             self._mask_ref = weakref.ref(m)
             self._mask_key = key
 
-    def set_mask_normalised(self, g):
+    def set_mask_normalised(self, g, key=None):
         """g: float32 CUDA tensor [nx, ns] on the plan's device; the mask is (g - min) / (max - min) (dsp.fk_filt, reference
-        dsp.py:945), applied while the mask is folded -- no separate normalisation pass over g."""
+        dsp.py:945), applied while the mask is folded -- no separate normalisation pass over g.  key: what the caller wants
+        to recognise this mask by later (FkPlan._mask_key), recorded after the fold."""
         if tuple(g.shape) != (self.nx, self.ns):
             raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s" % (self.nx, self.ns, tuple(g.shape)))
         self._mask_ref, self._mask_key = None, None
@@ -101,6 +111,7 @@ class FkPlan:
             a = np.float32(1.0) / (hi - lo) if hi > lo else np.float32(np.nan)
             b = -lo * a
             check(lib.d4w_fk_set_mask_dense_affine_f32(self._h, dev.ptr(g), float(a), float(b), st))
+        self._mask_key = key
 
     def _set_mask_design(self, m, prune_eps):
         """A closed-form design (immutable) straight into the plan -- no dense mask."""
@@ -256,14 +267,15 @@ def _fk_apply_odd(trace, fk_filter_matrix, tapering):
     plan = get_fk_plan(nx, 2 * ns, device)
     md = dev.to_device_f32(m, plan.device)
     mu = torch.roll(md, shifts=-(ns // 2), dims=1)              # time axis back to the unshifted grid
-    plan.set_mask(torch.cat((mu, mu), dim=1))                    # periodic in f: fftshift by ns leaves it unchanged
     x = dev.to_device_f32(trace, plan.device)
     if tapering:
         x = x.clone()
         check(lib.d4w_taper_f32(dev.ptr(x), nx, ns, dev.stream_ptr(x)))
     x2 = torch.zeros((nx, 2 * ns), dtype=torch.float32, device=x.device)
     x2[:, 0::2] = x
-    y = plan.apply(x2)[:, 0::2].contiguous()
+    with plan.lock:
+        plan.set_mask(torch.cat((mu, mu), dim=1))                # periodic in f: fftshift by ns leaves it unchanged
+        y = plan.apply(x2)[:, 0::2].contiguous()
     return dev.like_input(y, trace)
 
 
@@ -275,9 +287,10 @@ def _fk_apply(trace, fk_filter_matrix, tapering):
         return _fk_apply_odd(trace, fk_filter_matrix, tapering)
     device = trace.device if dev.is_tensor(trace) and trace.is_cuda else None
     plan = get_fk_plan(nx, ns, device)
-    plan.set_mask(fk_filter_matrix)
     x = dev.to_device_f32(trace, plan.device)
-    y = plan.apply(x, taper=tapering)
+    with plan.lock:                                              # the mask this call folds is the mask this call applies
+        plan.set_mask(fk_filter_matrix)
+        y = plan.apply(x, taper=tapering)
     return dev.like_input(y, trace)
 
 
@@ -812,14 +825,16 @@ def fk_filt(data, tint, fs, xint, dx, c_min, c_max):
     if ns % 2 == 0:
         plan = get_fk_plan(nx, ns, device)
         key = ("fk_filt", float(tint), float(fs), float(xint), float(dx), float(c_min), float(c_max))
-        if plan._mask_key != key:
-            # axes: fftfreq(ns, tint/fs), fftfreq(nx, xint*dx) (dsp.py:923-924) -> spacing arguments
-            g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=plan.device)    # dsp.py:930-936
-            g = _gaussian_filter(g, 20)                                         # dsp.py:940
-            plan.set_mask_normalised(g)                                         # dsp.py:945, folded into the mask upload
-            plan._mask_key = key
         x = dev.to_device_f32(data, plan.device)
-        return dev.like_input(plan.apply(x), data)
+        with plan.lock:
+            if plan._mask_key != key:
+                # axes: fftfreq(ns, tint/fs), fftfreq(nx, xint*dx) (dsp.py:923-924) -> spacing arguments
+                g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=plan.device)    # dsp.py:930-936
+                g = _gaussian_filter(g, 20)                                     # dsp.py:940
+                plan.set_mask_normalised(g, key=key)                            # dsp.py:945, folded into the mask upload; the
+                #                                                                 key is set only once the fold has been issued
+            y = plan.apply(x)
+        return dev.like_input(y, data)
     g = _design(5, (nx, ns), [0, 0, xint], dx, fs / tint, [c_min, c_max], device=device)
     g = _gaussian_filter(g, 20)
     with torch.cuda.device(g.device):

@@ -167,11 +167,17 @@ def compile_fk_shape(nx, ns, verbose=False, warn=False):
         path = _lib_path(nx, ns, cfg)
         marker = path[:-3] + ".failed"
         if not os.path.exists(path):
-            if os.path.exists(marker):
+            if os.path.exists(marker) and os.environ.get("D4W_FK_JIT", "") == "retry":
                 try:
-                    return failed("an earlier build of this configuration failed: " + open(marker).read())
+                    os.remove(marker)                 # the user asked for another attempt
                 except OSError:
-                    return failed("an earlier build of this configuration failed")
+                    pass
+            if os.path.exists(marker):
+                hint = " (marker %s: delete it or set D4W_FK_JIT=retry to build again)" % marker
+                try:
+                    return failed("an earlier build of this configuration failed%s: %s" % (hint, open(marker).read()))
+                except OSError:
+                    return failed("an earlier build of this configuration failed" + hint)
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             if not os.path.exists(hipcc):
                 return failed("no hipcc at %s" % hipcc)
@@ -197,7 +203,11 @@ def compile_fk_shape(nx, ns, verbose=False, warn=False):
             if r.returncode != 0:
                 if verbose:
                     print(r.stderr[-2000:], flush=True)
-                return failed("hipcc failed: " + (r.stderr.strip() or "exit code %d" % r.returncode), marker)
+                # Only a compiler diagnostic is remembered on disk.  A compile that was killed (negative return code = signal,
+                # e.g. the OOM killer), ran out of disk or was interrupted says nothing about the configuration: the next
+                # process tries again.
+                transient = (r.returncode < 0 or "No space left" in r.stderr or "error:" not in r.stderr)
+                return failed("hipcc failed: " + (r.stderr.strip() or "exit code %d" % r.returncode), None if transient else marker)
             os.replace(tmp, path)
         _register(path)
         if not is_specialised(nx, ns):

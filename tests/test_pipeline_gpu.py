@@ -133,3 +133,42 @@ def test_two_python_threads_on_two_streams():
     for i in range(2):
         for a, b in zip(serial[i], out[i]):
             assert torch.equal(a, b)
+
+
+def test_two_threads_share_a_time_first_plan():
+    """the time-first order (4000 x 12000 with the scripts' hybrid_ninf mask selects it) keeps its compact half
+    spectrum W in the PLAN, which get_fk_plan hands to every thread filtering this shape: two threads on two streams must
+    still get what serial calls give (the library orders applies of one plan across streams), also when the two threads
+    filter with DIFFERENT masks (the per-plan lock keeps [fold mask, apply] together)."""
+    import das4whales_amd as dw
+    nx, ns = 4000, 12000
+    mask = dw.dsp.hybrid_ninf_filter_design((nx, ns), [0, nx * 4, 4], DX, FS, *NINF)
+    mask2 = dw.dsp.hybrid_ninf_filter_design((nx, ns), [0, nx * 4, 4], DX, FS, 1350., 1450., 3300, 3450, 17., 26.)
+    gens = [torch.Generator(device="cuda").manual_seed(s) for s in (3, 4)]
+    xs = [torch.randn((nx, ns), device="cuda", generator=g) for g in gens]
+    plan = dw.dsp.get_fk_plan(nx, ns)
+    plan.set_mask(mask)
+    assert plan.order()["order"] == "time-first"
+    for masks in ([mask, mask], [mask, mask2]):
+        serial = [dw.dsp.fk_filter_sparsefilt(x, m) for x, m in zip(xs, masks)]
+        torch.cuda.synchronize()
+        out, errs = [None, None], []
+
+        def worker(i):
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.default_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(6):
+                        out[i] = dw.dsp.fk_filter_sparsefilt(xs[i], masks[i])
+                s.synchronize()
+            except Exception as e:
+                errs.append(e)
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for w in th:
+            w.start()
+        for w in th:
+            w.join()
+        assert not errs, errs
+        for i in range(2):
+            assert torch.equal(serial[i], out[i])
