@@ -825,9 +825,11 @@ struct d4w_fk_plan {
     size_t cap_W = 0;
     int tf_band_cols = 0, tf_tail_cols = 0;   // per row: band (incl. Nyquist) and tail columns kept
     double bytes_cf = 42.0, bytes_tf = 42.0;  // modelled bytes per channel-sample of the two orders for the current mask
-    // Plan-owned scratch that every apply rewrites (W of the time-first order, the exchange buffers of `big`): applies of
-    // one plan from several host threads / streams are serialised -- a host mutex around the launch sequence, and the next
-    // apply's stream waits for the event the previous one recorded when it ran on another stream.
+    // One plan, several host threads / streams (dsp.get_fk_plan hands the same plan to every thread filtering a shape): the
+    // folded mask and its tables are rewritten by every set_mask, W of the time-first order and the exchange buffers of
+    // `big` by every apply.  Every operation on the plan (set_mask*, apply*) takes the host mutex for its launch sequence,
+    // makes its stream wait for the event the previous operation recorded if that ran on ANOTHER stream, and records the
+    // event again at its end: a total order on the device, free when everything runs on one stream.
     std::mutex apply_mu;
     hipEvent_t apply_done = nullptr;
     hipStream_t apply_stream = nullptr;
@@ -1381,7 +1383,42 @@ int d4w_fk_plan_info(const d4w_fk_plan* pl, int* info) {
 
 static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream);
 
+// device-side order of the operations on one plan (see d4w_fk_plan::apply_mu); the caller holds pl->apply_mu
+static int fk_plan_enter(d4w_fk_plan* pl, void* stream) {
+#ifndef D4W_EMU
+    hipStream_t st = (hipStream_t)stream;
+    if (pl->apply_used && pl->apply_stream != st) D4W_HIP(hipStreamWaitEvent(st, pl->apply_done, 0));
+#else
+    (void)pl; (void)stream;
+#endif
+    return D4W_OK;
+}
+static int fk_plan_leave(d4w_fk_plan* pl, void* stream) {
+#ifndef D4W_EMU
+    hipStream_t st = (hipStream_t)stream;
+    if (!pl->apply_done) D4W_HIP(hipEventCreateWithFlags(&pl->apply_done, hipEventDisableTiming));
+    D4W_HIP(hipEventRecord(pl->apply_done, st));
+    pl->apply_stream = st;
+    pl->apply_used = true;
+#else
+    (void)pl; (void)stream;
+#endif
+    return D4W_OK;
+}
+
+static int fk_set_mask_run(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream, FkAffine aff);
+
 static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream, FkAffine aff = FkAffine{1.f, 0.f, 0}) {
+    if (!pl) return fail(D4W_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(pl->apply_mu);
+    int rc = fk_plan_enter(pl, stream);
+    if (rc != D4W_OK) return rc;
+    rc = fk_set_mask_run(pl, mask_shifted, prune_eps, stream, aff);
+    const int rl = fk_plan_leave(pl, stream);
+    return rc != D4W_OK ? rc : rl;
+}
+
+static int fk_set_mask_run(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream, FkAffine aff) {
     if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
     if (pl && pl->big) {                            // (no dead-row pruning on this path: prune_eps has nothing to act on)
         int rc = fkd_set_mask_dense_affine(pl->big, mask_shifted, aff.a, aff.b, aff.on, stream);
@@ -1667,8 +1704,22 @@ int d4w_fk_set_mask_dense_affine_f32(d4w_fk_plan* pl, const float* mask_shifted,
     return fk_set_mask_impl(pl, mask_shifted, 0.0, stream, FkAffine{scale, offset, 1});
 }
 
+static int fk_set_mask_design_run(d4w_fk_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
+                                  int i0, int i1, const double* hrow_dev, double prune_eps, void* stream);
+
 int d4w_fk_set_mask_design_f32(d4w_fk_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
                                int i0, int i1, const double* hrow_dev, double prune_eps, void* stream) {
+    if (!pl) return fail(D4W_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(pl->apply_mu);
+    int rc = fk_plan_enter(pl, stream);
+    if (rc != D4W_OK) return rc;
+    rc = fk_set_mask_design_run(pl, mode, k_spacing, t_spacing, params8_host, i0, i1, hrow_dev, prune_eps, stream);
+    const int rl = fk_plan_leave(pl, stream);
+    return rc != D4W_OK ? rc : rl;
+}
+
+static int fk_set_mask_design_run(d4w_fk_plan* pl, int mode, double k_spacing, double t_spacing, const double* params8_host,
+                                  int i0, int i1, const double* hrow_dev, double prune_eps, void* stream) {
     if (pl && pl->big) {
         if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
         int rc = d4w_fkd_set_mask_design_f32(pl->big, mode, k_spacing, t_spacing, params8_host, i0, i1, hrow_dev, stream);
@@ -1698,22 +1749,12 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
 static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev,
                          float* row_mean = nullptr, float* row_maxabs = nullptr) {
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
-    // orders that work in place in the caller's output need no guard; the ones with plan-owned scratch are serialised
-    const bool shared = pl->tf || pl->big;
-    if (!shared) return fk_apply_run(pl, x, y, taper, stream, ev, row_mean, row_maxabs);
     std::lock_guard<std::mutex> lk(pl->apply_mu);
-    hipStream_t st = (hipStream_t)stream;
-#ifndef D4W_EMU
-    if (pl->apply_used && pl->apply_stream != st) D4W_HIP(hipStreamWaitEvent(st, pl->apply_done, 0));
-#endif
-    const int rc = fk_apply_run(pl, x, y, taper, stream, ev, row_mean, row_maxabs);
-#ifndef D4W_EMU
-    if (!pl->apply_done) D4W_HIP(hipEventCreateWithFlags(&pl->apply_done, hipEventDisableTiming));
-    D4W_HIP(hipEventRecord(pl->apply_done, st));
-    pl->apply_stream = st;
-    pl->apply_used = true;
-#endif
-    return rc;
+    int rc = fk_plan_enter(pl, stream);
+    if (rc != D4W_OK) return rc;
+    rc = fk_apply_run(pl, x, y, taper, stream, ev, row_mean, row_maxabs);
+    const int rl = fk_plan_leave(pl, stream);
+    return rc != D4W_OK ? rc : rl;
 }
 
 static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, float* row_mean,

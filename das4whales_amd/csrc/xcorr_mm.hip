@@ -28,8 +28,8 @@
 //
 // Launch shape.  Persistent workgroups (256 threads, 4 waves) walk chunks of 4096 lags of one row; the chunk's
 // 4096 + 192 samples are loaded one chunk AHEAD into registers (17 floats per lane), converted and written to
-// one of two LDS buffers (hi / lo arrays, one 16-byte pad per 256 bytes: the fragment reads of a 16-lane group
-// hit 16 different bank groups), ONE barrier per chunk, then every wave runs four 16 x 16 tiles (256 lags each,
+// one of two LDS buffers (hi / lo arrays in sample order: the four lane groups of a fragment read hit 16 different
+// 16-byte slots each), ONE barrier per chunk, then every wave runs four 16 x 16 tiles (256 lags each,
 // both templates) and streams the results out with 16-byte non-temporal stores (lane (a, g) holds lags
 // 16 a + 4 g .. + 3: 1 KiB contiguous per wave and template).  Chunks are dealt to the XCDs in contiguous
 // ranges, so the 192-sample halo of a chunk is an L2 hit.
@@ -47,8 +47,12 @@ constexpr int kMmThreads = 256;
 constexpr int kMmStage = kMmCH + kMmHalo;        // 4288 samples per chunk
 constexpr int kMmQ = (kMmStage + 4 * kMmThreads - 1) / (4 * kMmThreads);   // 16-byte loads per lane: 5 (the last one lanes < 48)
 constexpr int kMmLastQ = (kMmStage - (kMmQ - 1) * 4 * kMmThreads) / 4;   // lanes that take the last load: 48
-__host__ __device__ constexpr int mm_pidx(int h) { return h + ((h >> 7) << 3); }   // 8 halves of pad per 128
-constexpr int kMmArr = mm_pidx(kMmStage) + 8;    // halves per LDS array (4560 -> 9120 B)
+// LDS index of sample h of the chunk: the plain order.  ds_read_b128 is served in four NON-contiguous 16-lane groups
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: MI355X_MICROARCH.md, LDS), and with lane (a, g) reading the 16-byte
+// slot 2 a + g (+ const) every group touches 16 different slots: no bank conflict.  (Round 4's first build padded 16 B
+// per 256 B for contiguous groups: 61 % of its LDS cycles were conflicts, profiles/r04a/pmc_sq_matched_filter.txt.)
+__host__ __device__ constexpr int mm_pidx(int h) { return h; }
+constexpr int kMmArr = mm_pidx(kMmStage) + 8;    // halves per LDS array (4296 -> 8592 B)
 constexpr float kMmLoScale = 2048.f, kMmLoInv = 1.0f / 2048.f;
 
 #ifdef D4W_EMU
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         constexpr int NTW = kMmCH / 256 / 4, NST = NTW * KSM, PF = 2;
         auto frag = [&](const mm_half* arr, int T, int kk) -> mm_h8 {
             const int gr = 32 * T + 2 * n16 + g + 4 * kk;           // 16-byte granule: sample 256 T + 16 n16 + 32 kk + 8 g
-            return *reinterpret_cast<const mm_h8*>(arr + 8 * (gr + (gr >> 4)));
+            return *reinterpret_cast<const mm_h8*>(arr + mm_pidx(8 * gr));
         };
         mm_h8 fh[PF + 1], fl[PF + 1];
         static_for<PF>([&](auto ss) {
