@@ -74,10 +74,26 @@ def cpu_baseline(sample_nx, sample_ns, stages):
         total += dt
         notes.append("compute_cross_correlogram x2 %.2f s" % dt)
     samples = float(sample_nx) * sample_ns
+    # the matched filter in the reference's own form (detect.py:156-166: a Python row loop over
+    # scipy.signal.correlate(row, full-length template, 'full', 'fft')), on a bounded row sample, next to the batched port
+    ref_form = None
+    if "mf" in stages:
+        rows = min(sample_nx, 1000)
+        dtr = _best_of(lambda: (orc.compute_cross_correlogram_reference_form(x[:rows], hf),
+                                orc.compute_cross_correlogram_reference_form(x[:rows], lf)), 1)
+        ref_form = {"compute_cross_correlogram_x2_s_per_block": dtr * sample_nx / rows,
+                    "sample": "row loop over scipy.signal.correlate(method='fft') as detect.py:163-164, %d of %d rows timed once, "
+                              "scaled to the block" % (rows, sample_nx)}
+        if "fk" in stages:
+            fk_s = [float(n.split()[1]) for n in notes if n.startswith("fk_filter_filt")][0]
+            ref_form["value"] = samples / (fk_s + ref_form["compute_cross_correlogram_x2_s_per_block"])
+            ref_form["unit"] = "channel-samples/s"
     out = {"value": samples / total, "unit": "channel-samples/s", "cores": 1, "kind": "port",
            "cores_available": len(os.sched_getaffinity(0)),
            "sample": "oracle (numpy.fft / scipy.signal float64, single thread as the reference runs) on one %d x %d block in "
                      "full, 1 warm-up + best of 3 per stage: %s" % (sample_nx, sample_ns, "; ".join(notes))}
+    if ref_form is not None:
+        out["reference_form"] = ref_form
     # second column (SURVEY 8d / BASELINE.md 3): the same math as a CPU would best run it -- float32, half spectrum,
     # scipy.fft on every core, one transform of the block shared by both templates
     try:
@@ -302,16 +318,42 @@ def bench_stream(args, world, rank, device, dist):
     lmax = max(len(ddet._normalised_support(hf)), len(ddet._normalised_support(lf)))
     kernel = {"f0": 27., "f1": 17., "dur": 0.8, "bdwidth": 4.}
 
-    def raw_file(i):                                   # synthetic raw int32 file i of the record (same on whichever rank makes it)
-        g = torch.Generator(device=device).manual_seed(1000 + i)
-        return (torch.randn((nx, ns), device=device, generator=g) * 3e4).to(torch.int32)
+    tap_hf, tap_lf = ddet._normalised_support(hf), ddet._normalised_support(lf)
+    ncall, span = 6, 160                               # notes injected per file, channels a note is seen on
 
-    def strain(raw):
-        x, _, _ = data_handle.load_das_data_array(raw, sel, meta)
-        return x
+    def raw_file(i):
+        """Synthetic raw int32 file i of the record (same on whichever rank makes it): white noise (sigma 3e4 counts) plus
+        `ncall` fin-whale notes (HF / LF alternating) seen on `span` adjacent channels each with the linear moveout of a
+        2 km/s apparent speed at the mask's 8.17 m spacing -- inside the f-k pass band, so that the matched filter has
+        something to find and "detections" are detections, not threshold crossings of noise."""
+        g = torch.Generator(device=device).manual_seed(1000 + i)
+        x = torch.randn((nx, ns), device=device, generator=g) * 3e4
+        rs = np.random.default_rng(1000 + i)
+        for k in range(ncall):
+            tp = torch.from_numpy(np.ascontiguousarray(tap_hf if k % 2 == 0 else tap_lf, dtype=np.float32)).to(device)
+            rc = int(rs.integers(span, max(span + 1, nx - span)))
+            t0 = int(rs.integers(200, ns - 600))
+            rows = torch.arange(max(0, rc - span // 2), min(nx, rc + span // 2), device=device)
+            start = t0 + torch.round((rows - rc).abs().float() * (8.17 / 2000.0 * fs)).long()
+            cols = start[:, None] + torch.arange(tp.numel(), device=device)[None, :]
+            x[rows[:, None], cols] += 3e4 * tp[None, :]
+        return x.to(torch.int32)
 
     first_file = rank * F
     raws = [raw_file(first_file + j) for j in range(F)]
+    ingest = host_raws = None
+    h2d_gbs = None
+    if args.from_host:
+        # the files start in PINNED HOST memory (what a reader that fills data_handle.PinnedIngest.host_array, or its own
+        # pinned pool, leaves behind; the read itself is I/O and not timed): file i + 1 crosses PCIe on the side stream
+        # while file i is processed
+        ingest = data_handle.PinnedIngest((nx, ns), np.int32, device=device, depth=2)
+        host_raws = [r.cpu().pin_memory() for r in raws]
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ingest.upload(0, host_raws[0]); ingest.raw(0)
+        e0.record(); ingest.upload(1, host_raws[1 % F]); ingest.raw(1); e1.record(); e1.synchronize()
+        h2d_gbs = nx * ns * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     # raw halos across the run boundaries (set-up, not timed: the raw record is resident)
     prev_tail = next_head = None
     if world > 1:
@@ -353,8 +395,16 @@ def bench_stream(args, world, rank, device, dist):
                     n += ddet.pick_times_env(c, thr).total
                 ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)
             return n
-        for raw in raws:
-            npicks += detect_on(st.push(strain(raw)))
+        if ingest is not None:
+            ingest.upload(0, host_raws[0])
+            for j in range(F):
+                if j + 1 < F:
+                    ingest.upload((j + 1) & 1, host_raws[j + 1])         # waits (on the device) for the slot's last consumer
+                x, _, _ = ingest.strain(j & 1, sel, meta)
+                npicks += detect_on(st.push(x))
+        else:
+            for raw in raws:
+                npicks += detect_on(st.push(strain(raw)))
         npicks += detect_on(st.flush(next_head=next_head, next_filtered_head=filtered_head if nxt_filt is not None else None))
         if "send" in pend:
             pend["send"].wait()
@@ -387,6 +437,11 @@ def bench_stream(args, world, rank, device, dist):
                "value": nfiles * float(nx) * ns / dt, "unit": "channel-samples/s", "n_gpus": world, "steps": reps * F, "warmup": args.warmup,
                "ms_per_step": dt / (reps * F) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic", "files_per_s": nfiles / dt, "detections_per_s": npicks / dt, "detections": npicks,
+               "injected_notes_per_file": ncall, "channels_per_note": span,
+               "ingest": ({"from": "pinned host memory, double-buffered upload on a side stream (data_handle.PinnedIngest)",
+                           "h2d_GBps_one_file": h2d_gbs, "file_bytes": nx * ns * 4,
+                           "pcie_bound_files_per_s": h2d_gbs * 1e9 / (nx * ns * 4)} if ingest is not None
+                          else {"from": "device-resident raw files"}),
                "config": {"workload": "%d consecutive 60-s files of %d channels x %d samples per GPU (int32 raw), halo %d samples, "
                                       "hybrid_ninf f-k mask, HF+LF templates, envelope picks at 0.45 max, spectrogram correlation"
                                       % (F, nx, ns, halo), "parallelism": "runs of consecutive files x%d, halo hand-off between neighbours" % world}}
@@ -505,6 +560,9 @@ def main():
                     help="block = the f-k + matched-filter step on one resident block (BASELINE configs[2] / [3]); stream = "
                          "BASELINE configs[4]: consecutive 60-s files through the whole detection chain, files/s and detections/s")
     ap.add_argument("--files", type=int, default=8, help="--config stream: consecutive files per GPU")
+    ap.add_argument("--from-host", action="store_true",
+                    help="--config stream: the raw files start in pinned host memory and cross PCIe double-buffered on a side "
+                         "stream (data_handle.PinnedIngest) instead of being device-resident")
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="4000x12000", help="CPU baseline block (BASELINE configs[0] shape, run in full)")
     ap.add_argument("--no-cpu", action="store_true")

@@ -18,6 +18,91 @@ def is_tensor(x):
     return isinstance(x, torch.Tensor)
 
 
+# Host <-> device staging for the NumPy-in / NumPy-out calls (SURVEY.md 8d "H2D / D2H reported separately").  A notebook
+# hands over pageable float64 arrays (reference data_handle.py:213): converting them with ndarray.astype is single-threaded
+# (~1 GB/s) and a pageable hipMemcpy is synchronous.  Blocks above _STAGE_MIN bytes therefore cross PCIe in row chunks
+# through two pinned float32 buffers: torch's multi-threaded copy_ converts chunk k into one buffer while chunk k - 1 is
+# still on the wire out of the other, and only float32 crosses the link.  Same in the other direction.
+_STAGE_MIN = 32 << 20
+_STAGE_BYTES = 64 << 20
+_stage = {}            # (device index, thread id) -> [two pinned float32 buffers, two events]
+
+
+def _staging(device):
+    import threading
+    key = (torch.device(device).index or 0, threading.get_ident())
+    ent = _stage.get(key)
+    if ent is None:
+        if len(_stage) > 16:
+            _stage.clear()
+        bufs = [torch.empty(_STAGE_BYTES // 4, dtype=torch.float32).pin_memory() for _ in range(2)]
+        ent = _stage[key] = [bufs, [torch.cuda.Event(), torch.cuda.Event()]]
+    return ent
+
+
+def upload_f32(a, device=None):
+    """Host ndarray (any real dtype, C-contiguous or not) -> contiguous float32 CUDA tensor, pipelined through pinned
+    staging buffers on the current stream."""
+    require_gpu()
+    device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+    a = np.asarray(a)
+    if a.dtype.kind not in "fiu" or a.dtype == np.float16:
+        a = a.astype(np.float64)
+    if not a.flags.writeable:                    # torch.from_numpy wants a writeable buffer; it is only read here
+        a = a.copy()
+    staged_ok = a.dtype in (np.float32, np.float64, np.int16, np.int32, np.int64)      # what torch.from_numpy takes as is
+    if a.nbytes < _STAGE_MIN or a.ndim != 2 or a.shape[1] * 4 > _STAGE_BYTES or not staged_ok:
+        if a.dtype != np.float32:
+            a = a.astype(np.float32)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    src = torch.from_numpy(a)
+    nx, ns = a.shape
+    out = torch.empty((nx, ns), dtype=torch.float32, device=device)
+    bufs, evs = _staging(device)
+    rows = max(1, (_STAGE_BYTES // 4) // ns)
+    with torch.cuda.device(device):
+        k = 0
+        for r0 in range(0, nx, rows):
+            r1 = min(nx, r0 + rows)
+            if k >= 2:
+                evs[k & 1].synchronize()         # the copy that last read this staging buffer has left the host
+            st = bufs[k & 1][:(r1 - r0) * ns].view(r1 - r0, ns)
+            st.copy_(src[r0:r1])                 # dtype conversion + gather of a strided source, on the host threads
+            out[r0:r1].copy_(st, non_blocking=True)
+            evs[k & 1].record()
+            k += 1
+        for e in evs[:min(k, 2)]:
+            e.synchronize()                      # the staging buffers may be reused by the next call right away
+    return out
+
+
+def download(y, dtype=np.float32):
+    """float32 CUDA tensor -> host ndarray of `dtype`, pipelined through the pinned staging buffers."""
+    dtype = np.dtype(dtype)
+    if (y.numel() * 4 < _STAGE_MIN or y.dim() != 2 or y.shape[1] * 4 > _STAGE_BYTES or not y.is_contiguous()
+            or y.dtype != torch.float32 or dtype not in (np.float16, np.float32, np.float64)):
+        out = y.cpu().numpy()
+        return out if out.dtype == dtype else out.astype(dtype)
+    nx, ns = y.shape
+    out = np.empty((nx, ns), dtype=dtype)
+    dst = torch.from_numpy(out)
+    bufs, evs = _staging(y.device)
+    rows = max(1, (_STAGE_BYTES // 4) // ns)
+    chunks = [(r0, min(nx, r0 + rows)) for r0 in range(0, nx, rows)]
+    with torch.cuda.device(y.device):
+        def issue(k):
+            r0, r1 = chunks[k]
+            bufs[k & 1][:(r1 - r0) * ns].view(r1 - r0, ns).copy_(y[r0:r1], non_blocking=True)
+            evs[k & 1].record()
+        issue(0)
+        for k, (r0, r1) in enumerate(chunks):
+            if k + 1 < len(chunks):
+                issue(k + 1)                     # the next chunk crosses the link while this one is converted
+            evs[k & 1].synchronize()
+            dst[r0:r1].copy_(bufs[k & 1][:(r1 - r0) * ns].view(r1 - r0, ns))
+    return out
+
+
 def to_device_f32(x, device=None):
     """Return a contiguous float32 CUDA tensor holding x (copying only when needed)."""
     require_gpu()
@@ -27,11 +112,7 @@ def to_device_f32(x, device=None):
         elif device is not None and x.device != torch.device(device):
             x = x.to(device)              # a tensor on another GPU: the kernels run on `device`
         return x.to(torch.float32).contiguous()
-    a = np.asarray(x)
-    if a.dtype != np.float32:
-        a = a.astype(np.float32)
-    a = np.ascontiguousarray(a)
-    return torch.from_numpy(a).to(device or "cuda")
+    return upload_f32(x, device)
 
 
 def like_input(y, template):
@@ -39,12 +120,7 @@ def like_input(y, template):
     if is_tensor(template):
         return y if template.is_cuda else y.to(template.device)
     t = np.asarray(template)
-    out = y.cpu().numpy()
-    if t.dtype.kind == "f" and t.dtype != np.float32:
-        out = out.astype(t.dtype)
-    elif t.dtype.kind != "f":
-        out = out.astype(np.float64)
-    return out
+    return download(y, t.dtype if t.dtype.kind == "f" else np.float64)
 
 
 def stream_ptr(t):

@@ -46,6 +46,77 @@ def load_das_data_array(raw_data, selected_channels, metadata):
     return y, tx, dist
 
 
+class PinnedIngest:
+    """Raw files from host memory to strain on the GPU with the upload hidden behind the previous file's processing
+    (reference contract: data_handle.load_das_data, data_handle.py:181-230, whose h5py read lands in
+    host memory).  `depth` pinned host buffers of one file's selected rows [nx, ns] (raw dtype: int32 OptaSense RawData,
+    int16, float32 or float64) and as many device buffers; a side HIP stream carries the copies:
+
+        ing = PinnedIngest((nx, ns), np.int32)
+        dset.read_direct(ing.host_array(0), np.s_[c0:c1:step, :])     # the caller's reader fills pinned memory in place
+        ing.upload(0)
+        for i in range(nfiles):
+            if i + 1 < nfiles:                                          # file i + 1 is read and uploaded while file i is
+                ing.wait_host((i + 1) % 2)                              # processed on the device
+                dset_next.read_direct(ing.host_array((i + 1) % 2), ...)
+                ing.upload((i + 1) % 2)
+            x, tx, dist = ing.strain(i % 2, [0, nx, 1], metadata)       # current stream waits for the copy only
+            ...
+
+    A 11 020 x 12 000 int32 file is 529 MB: ~10 ms of PCIe against ~7 ms of device work per file, so a stream of files
+    runs at the link rate when the reader keeps up (bench.py --config stream --from-host)."""
+
+    def __init__(self, shape, dtype=np.int32, device=None, depth=2):
+        dev.require_gpu()
+        self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32,
+               np.dtype(np.float64): torch.float64}.get(np.dtype(dtype))
+        if tdt is None:
+            raise ValueError("raw dtype must be int32, int16, float32 or float64")
+        self.shape = (int(shape[0]), int(shape[1]))
+        self._host = [torch.empty(self.shape, dtype=tdt).pin_memory() for _ in range(depth)]
+        self._dev = [torch.empty(self.shape, dtype=tdt, device=self.device) for _ in range(depth)]
+        self._copy = torch.cuda.Stream(self.device)
+        self._ready = [torch.cuda.Event() for _ in range(depth)]        # the upload of slot s has completed
+        self._free = [torch.cuda.Event() for _ in range(depth)]         # the device copy of slot s has been consumed
+        self._uploaded = [False] * depth
+        self._consumed = [False] * depth
+
+    def host_array(self, slot):
+        """NumPy view of pinned buffer `slot` for the reader to fill (h5py read_direct, np.copyto, file.readinto)."""
+        return self._host[slot].numpy()
+
+    def wait_host(self, slot):
+        """Block the host until the last upload out of `slot` has left host memory (before refilling it)."""
+        if self._uploaded[slot]:
+            self._ready[slot].synchronize()
+
+    def upload(self, slot, src=None):
+        """Start the copy of host buffer `slot` (or of `src`, a pinned host tensor of the same shape and dtype that a
+        reader with its own buffer pool filled) to device buffer `slot` on the side stream; returns immediately."""
+        if src is not None and (tuple(src.shape) != self.shape or src.dtype != self._dev[slot].dtype or not src.is_pinned()):
+            raise ValueError("src must be a pinned host tensor of shape %s and dtype %s" % (self.shape, self._dev[slot].dtype))
+        with torch.cuda.device(self.device):
+            if self._consumed[slot]:
+                self._copy.wait_event(self._free[slot])                 # the kernel that read the previous content is done
+            with torch.cuda.stream(self._copy):
+                self._dev[slot].copy_(self._host[slot] if src is None else src, non_blocking=True)
+                self._ready[slot].record(self._copy)
+        self._uploaded[slot] = True
+
+    def raw(self, slot):
+        """The device copy of `slot` (raw dtype), ordered after its upload on the current stream."""
+        torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
+        return self._dev[slot]
+
+    def strain(self, slot, selected_channels, metadata):
+        """load_das_data_array of the uploaded slot: (strain float32 CUDA tensor, tx, dist)."""
+        out = load_das_data_array(self.raw(slot), selected_channels, metadata)
+        self._free[slot].record(torch.cuda.current_stream(self.device))
+        self._consumed[slot] = True
+        return out
+
+
 def raw2strain(trace, metadata):
     """trace - mean(trace, axis=1), times metadata['scale_factor'] -- data_handle.py:157-176.
     Returns a new array (the reference works in place on its float64 copy)."""

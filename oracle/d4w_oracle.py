@@ -538,6 +538,24 @@ def compute_cross_correlogram(data, template):
     return c[:, : x.shape[1]]
 
 
+def compute_cross_correlogram_reference_form(data, template):
+    """detect.compute_cross_correlogram in the reference's OWN form, statement by statement (detect.py:156-166 and
+    shift_xcorr, detect.py:111-112): a Python loop over the rows, scipy.signal.correlate(row, template, 'full', 'fft') with
+    the full-length zero-padded template, lags len(x) - 1 onwards.  compute_cross_correlogram above is the batched
+    restatement the parity tests use (same numbers to 1e-12, tests/test_oracle_golden.py); this one exists so that the
+    CPU baseline can time what a user of the reference actually runs (bench.py cpu_baseline.reference_form)."""
+    import scipy.signal as sp
+    data = np.asarray(data, dtype=float)
+    norm_data = (data - np.mean(data, axis=1, keepdims=True)) / np.max(np.abs(data), axis=1, keepdims=True)   # detect.py:157
+    template = np.asarray(template, dtype=float)
+    template = (template - np.mean(template)) / np.max(np.abs(template))                                      # detect.py:158
+    cross_correlogram = np.empty_like(data)                                                                   # detect.py:161
+    for i in range(data.shape[0]):                                                                            # detect.py:163
+        corr = sp.correlate(norm_data[i, :], template, mode="full", method="fft")                             # detect.py:111
+        cross_correlogram[i, :] = corr[len(norm_data[i, :]) - 1:]                                             # detect.py:112,164
+    return cross_correlogram
+
+
 # --------------------------------------------------------------------------------------------
 # peak picking
 # --------------------------------------------------------------------------------------------

@@ -124,3 +124,121 @@ def synth_block_device(nx, ns, device, fs=200.0, dx=2.0419046878814697, step=1, 
         calls.append({"template": i % 2, "x0": float(x0), "range": float(r), "t0": float(t0),
                       "flank": [(c, int(idx[c])) for c in cands]})
     return x, calls
+
+
+# ------------------------------------------------------------------------------------------
+# OpenCV pieces of the Gabor image pipeline (f3), pinned WITHOUT the restatement on both sides.
+# cv2 is absent here, so the pins are the library's documented definitions written out as plain
+# loops (reference call sites: improcess.py:116-123 cv2.getGaborKernel, scripts/main_gabordetect.py:109,132
+# cv2.filter2D), independent of oracle/d4w_oracle.py (NumPy closed form / scipy.ndimage) and of the HIP kernels:
+#   * cv::borderInterpolate, BORDER_REFLECT_101 ("gfedcb|abcdefgh|gfedcba"):  i < 0 -> -i,  i >= n -> 2 n - 2 - i
+#   * cv::filter2D: dst(x, y) = sum_{x', y'} kernel(x', y') src(x + x' - anchor.x, y + y' - anchor.y), a CORRELATION,
+#     anchor = kernel centre (ksize / 2), borderType = BORDER_DEFAULT = BORDER_REFLECT_101
+#   * cv::getGaborKernel (imgproc/src/gabor.cpp): xmax = ksize.width / 2, ymax = ksize.height / 2; for y in -ymax..ymax,
+#     x in -xmax..xmax: xr = x cos t + y sin t, yr = -x sin t + y cos t,
+#     v = exp(-xr^2 / (2 sigma^2) - yr^2 / (2 (sigma / gamma)^2)) cos(2 pi xr / lambd + psi), stored at
+#     kernel[ymax - y][xmax - x]
+# ------------------------------------------------------------------------------------------
+def reflect101(i, n):
+    if n == 1:
+        return 0
+    while i < 0 or i >= n:
+        i = -i if i < 0 else 2 * n - 2 - i
+    return i
+
+
+def filter2d_loops(img, ker):
+    """cv::filter2D by definition (quadruple loop; small images only)."""
+    img = np.asarray(img, dtype=np.float64)
+    ker = np.asarray(ker, dtype=np.float64)
+    h, w = img.shape
+    kh, kw = ker.shape
+    ay, ax = kh // 2, kw // 2
+    out = np.zeros((h, w))
+    for y in range(h):
+        for x in range(w):
+            acc = 0.0
+            for j in range(kh):
+                yy = reflect101(y + j - ay, h)
+                for i in range(kw):
+                    acc += ker[j, i] * img[yy, reflect101(x + i - ax, w)]
+            out[y, x] = acc
+    return out
+
+
+def gabor_kernel_loops(ksize, sigma, theta, lambd, gamma, psi):
+    """cv::getGaborKernel by definition (double loop, math module only)."""
+    import math
+    xmax, ymax = ksize[0] // 2, ksize[1] // 2
+    sx, sy = sigma, sigma / gamma
+    c, s = math.cos(theta), math.sin(theta)
+    k = np.zeros((2 * ymax + 1, 2 * xmax + 1))
+    for y in range(-ymax, ymax + 1):
+        for x in range(-xmax, xmax + 1):
+            xr = x * c + y * s
+            yr = -x * s + y * c
+            k[ymax - y, xmax - x] = math.exp(-0.5 * xr * xr / (sx * sx) - 0.5 * yr * yr / (sy * sy)) * math.cos(2 * math.pi / lambd * xr + psi)
+    return k
+
+
+def check_filter2d(filter2d, tol):
+    """Known answers any cv2.filter2D stand-in must give; filter2d(img, kernel) -> ndarray."""
+    rng = np.random.default_rng(42)
+    # 1. impulse image -> the kernel flipped about its anchor (a correlation, not a convolution), also for an EVEN size
+    for kh, kw in ((5, 3), (4, 6)):
+        ker = rng.standard_normal((kh, kw))
+        img = np.zeros((21, 19))
+        img[10, 9] = 1.0
+        out = np.asarray(filter2d(img, ker), dtype=np.float64)
+        ay, ax = kh // 2, kw // 2
+        want = np.zeros_like(img)
+        for j in range(kh):
+            for i in range(kw):
+                want[10 - (j - ay), 9 - (i - ax)] = ker[j, i]
+        assert np.max(np.abs(out - want)) <= tol * np.max(np.abs(ker)), ("impulse", kh, kw)
+    # 2. constant image -> sum of the kernel everywhere, borders included (reflect-101 of a constant is the constant)
+    ker = rng.standard_normal((7, 9))
+    out = np.asarray(filter2d(np.full((12, 15), 2.5), ker), dtype=np.float64)
+    assert np.max(np.abs(out - 2.5 * ker.sum())) <= tol * 2.5 * np.abs(ker).sum()
+    # 3. a border worked by hand: row a b c d e with kernel [1 2 4] -> out[0] = 1 b + 2 a + 4 b (index -1 reflects to 1)
+    row = np.array([[1.0, 10.0, 100.0, 1000.0, 10000.0]])
+    out = np.asarray(filter2d(row, np.array([[1.0, 2.0, 4.0]])), dtype=np.float64)
+    assert np.allclose(out[0], [1 * 10 + 2 * 1 + 4 * 10, 1 * 1 + 2 * 10 + 4 * 100, 1 * 10 + 2 * 100 + 4 * 1000,
+                                1 * 100 + 2 * 1000 + 4 * 10000, 1 * 1000 + 2 * 10000 + 4 * 1000], rtol=tol)
+    # 4. the definition as loops, kernels LARGER than the image (the reflections wrap more than once), ragged sizes
+    for (h, w, kh, kw) in ((7, 9, 5, 3), (4, 5, 9, 11), (6, 3, 3, 7), (1, 8, 3, 5)):
+        img, ker = rng.standard_normal((h, w)), rng.standard_normal((kh, kw))
+        out = np.asarray(filter2d(img, ker), dtype=np.float64)
+        want = filter2d_loops(img, ker)
+        assert np.max(np.abs(out - want)) <= tol * np.max(np.abs(want)), (h, w, kh, kw)
+
+
+def check_gabor_kernel(get_gabor_kernel, tol=1e-12):
+    """Known answers any cv2.getGaborKernel stand-in must give; get_gabor_kernel(ksize, sigma, theta, lambd, gamma, psi)."""
+    import math
+    # centre sample = cos(psi); shape 2 (k // 2) + 1 per axis (100 -> 101 as improcess.py:116,123 relies on)
+    for psi in (0.0, 0.3, math.pi / 2):
+        k = np.asarray(get_gabor_kernel((100, 100), 4, 1.2, 20, 0.15, psi))
+        assert k.shape == (101, 101) and abs(k[50, 50] - math.cos(psi)) <= tol
+    # theta = 0: xr = x, yr = y -> closed form per sample, written MIRRORED: kernel[ymax - y][xmax - x]
+    sigma, lambd, gamma, psi = 2.0, 5.0, 0.5, 0.3
+    k = np.asarray(get_gabor_kernel((9, 7), sigma, 0.0, lambd, gamma, psi))
+    assert k.shape == (7, 9)
+    for (x, y) in ((1, 2), (-3, 1), (4, -3), (0, 0), (-4, 3)):
+        want = math.exp(-x * x / (2 * sigma ** 2) - (y * gamma) ** 2 / (2 * sigma ** 2)) * math.cos(2 * math.pi * x / lambd + psi)
+        assert abs(k[3 - y, 4 - x] - want) <= tol, (x, y)
+    # theta = pi / 2: xr = y, yr = -x
+    k = np.asarray(get_gabor_kernel((9, 7), sigma, math.pi / 2, lambd, gamma, psi))
+    for (x, y) in ((1, 2), (-3, 1), (4, -3)):
+        c, s = math.cos(math.pi / 2), math.sin(math.pi / 2)
+        xr, yr = x * c + y * s, -x * s + y * c
+        want = math.exp(-xr * xr / (2 * sigma ** 2) - (yr * gamma) ** 2 / (2 * sigma ** 2)) * math.cos(2 * math.pi * xr / lambd + psi)
+        assert abs(k[3 - y, 4 - x] - want) <= tol, (x, y)
+    # psi = 0: an even function of (x, y) -> the mirrored write is invisible; psi = pi / 2 at theta = 0: odd in x
+    k = np.asarray(get_gabor_kernel((11, 11), 3.0, 0.7, 6.0, 0.4, 0.0))
+    assert np.max(np.abs(k - k[::-1, ::-1])) <= tol
+    k = np.asarray(get_gabor_kernel((11, 11), 3.0, 0.0, 6.0, 0.4, math.pi / 2))
+    assert np.max(np.abs(k + k[:, ::-1])) <= 1e-12 and np.max(np.abs(k - k[::-1, :])) <= tol
+    # the scripts' own kernel (improcess.py:116-123) sample by sample against the loops
+    th = math.pi / 2 + math.radians(37.0)
+    assert np.max(np.abs(np.asarray(get_gabor_kernel((100, 100), 4, th, 20, 0.15, 0)) - gabor_kernel_loops((100, 100), 4, th, 20, 0.15, 0))) <= tol

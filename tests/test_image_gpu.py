@@ -107,3 +107,11 @@ def test_errors(dw):
         dw.improcess.apply_smooth_mask(np.zeros((4, 4)), np.zeros((4, 5), dtype=bool))
     with pytest.raises(ValueError):                                        # int(1101.99..) * 10 != 11020-like mismatch
         dw.improcess.gabor_mask(np.random.default_rng(0).standard_normal((25, 95)), 200., 2.04, [0, 100, 4])
+
+
+def test_cv2_stand_ins_against_the_documented_definitions(dw):
+    """The product's filter2d (HIP) and get_gabor_kernel against OpenCV's documented definitions written as loops
+    (tests/known_answers.py) -- not against the restatement."""
+    from tests import known_answers as ka
+    ka.check_filter2d(dw.improcess.filter2d, 2e-6)
+    ka.check_gabor_kernel(dw.improcess.get_gabor_kernel, 1e-12)

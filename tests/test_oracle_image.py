@@ -60,3 +60,13 @@ def test_filter2d_reflect101_known_answer():
     k[1, 0] = 1                                                       # out[y][x] = img[y][x-1]; x = 0 reads img[y][1]
     out = orc.filter2d(img, k)
     assert np.array_equal(out[:, 1:], img[:, :-1]) and np.array_equal(out[:, 0], img[:, 1])
+
+
+def test_cv2_stand_ins_against_the_documented_definitions():
+    """f3's cv2 pieces pinned independently of the restatement: OpenCV's documented definitions of
+    filter2D / BORDER_REFLECT_101 / getGaborKernel written out as loops (tests/known_answers.py) -- impulse -> flipped kernel,
+    constant -> sum of the kernel, a hand-worked border, kernels larger than the image, closed-form Gabor samples and the
+    mirrored write."""
+    from tests import known_answers as ka
+    ka.check_filter2d(orc.filter2d, 1e-12)
+    ka.check_gabor_kernel(orc.get_gabor_kernel)

@@ -98,3 +98,56 @@ def test_stream_at_the_ooi_file_shape():
         e = rel(c[rows].cpu().numpy(), ref)
         print("stream 11020x12000, middle file: correlogram (continued) %.3e" % e)
         assert e < TOL
+
+
+def test_pinned_ingest_double_buffered_upload():
+    """data_handle.PinnedIngest (reference contract data_handle.py:181-230): files that start in pinned host memory reach
+    the device through two buffers on a side stream and give the strain data_handle.load_das_data_array gives for the same
+    raw matrix; the slots are recycled in order over more files than slots, from the ingest's own buffers and from a
+    reader's pinned pool."""
+    import das4whales_amd as dw
+    from das4whales_amd import data_handle
+    nx, ns = 300, 6000
+    meta = {"scale_factor": 1.7e-2, "fs": 200.0, "dx": 2.04}
+    rng = np.random.default_rng(11)
+    files = [rng.integers(-30000, 30000, size=(nx, ns)).astype(np.int32) for _ in range(5)]
+    ing = data_handle.PinnedIngest((nx, ns), np.int32, depth=2)
+    np.copyto(ing.host_array(0), files[0])
+    ing.upload(0)
+    outs = []
+    for i in range(len(files)):
+        if i + 1 < len(files):
+            s = (i + 1) % 2
+            ing.wait_host(s)
+            np.copyto(ing.host_array(s), files[i + 1])
+            ing.upload(s)
+        x, tx, dist = ing.strain(i % 2, [0, nx, 1], meta)
+        outs.append(x.clone())
+    torch.cuda.synchronize()
+    for f, x in zip(files, outs):
+        ref, _, _ = data_handle.load_das_data_array(f, [0, nx, 1], meta)
+        assert torch.equal(x, ref)
+    pool = [torch.from_numpy(f).pin_memory() for f in files]
+    for i, p in enumerate(pool):
+        ing.upload(i % 2, p)
+        x, _, _ = ing.strain(i % 2, [0, nx, 2], meta)
+        ref, _, _ = data_handle.load_das_data_array(files[i], [0, nx, 2], meta)
+        assert torch.equal(x, ref)
+    with pytest.raises(ValueError):
+        ing.upload(0, torch.zeros((nx, ns), dtype=torch.int32))              # pageable: refused
+
+
+def test_staged_host_transfers_match_plain_copies():
+    """_device.upload_f32 / download (pinned, chunked, dtype conversion on the host threads) against plain copies, for the
+    dtypes and layouts the NumPy-in / NumPy-out calls meet: float64 / float32 / int32, C and Fortran order, a strided view."""
+    from das4whales_amd import _device as dev
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((3000, 6000))                                    # 144 MB as float64: the staged path
+    for src in (a, a.astype(np.float32), np.asfortranarray(a), a[::2, ::3], (a * 1000).astype(np.int32)):
+        got = dev.upload_f32(src)
+        assert got.dtype == torch.float32 and got.is_contiguous()
+        assert torch.equal(got.cpu(), torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)))
+    y = torch.randn((3000, 6000), device="cuda")
+    for dt in (np.float64, np.float32):
+        h = dev.download(y, dt)
+        assert h.dtype == dt and np.array_equal(h, y.cpu().numpy().astype(dt))
