@@ -339,6 +339,10 @@ def bench_stream(args, world, rank, device, dist):
             x[rows[:, None], cols] += 3e4 * tp[None, :]
         return x.to(torch.int32)
 
+    def strain(raw):
+        x, _, _ = data_handle.load_das_data_array(raw, sel, meta)
+        return x
+
     first_file = rank * F
     raws = [raw_file(first_file + j) for j in range(F)]
     ingest = host_raws = None
@@ -413,6 +417,8 @@ def bench_stream(args, world, rank, device, dist):
     for _ in range(max(1, args.warmup // 2)):
         run()
     torch.cuda.synchronize()
+    if ingest is not None:
+        ingest.timing = []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -440,6 +446,7 @@ def bench_stream(args, world, rank, device, dist):
                "injected_notes_per_file": ncall, "channels_per_note": span,
                "ingest": ({"from": "pinned host memory, double-buffered upload on a side stream (data_handle.PinnedIngest)",
                            "h2d_GBps_one_file": h2d_gbs, "file_bytes": nx * ns * 4,
+                           "h2d_ms_per_file_under_load": float(np.mean([a_.elapsed_time(b_) for a_, b_ in ingest.timing])) if ingest.timing else None,
                            "pcie_bound_files_per_s": h2d_gbs * 1e9 / (nx * ns * 4)} if ingest is not None
                           else {"from": "device-resident raw files"}),
                "config": {"workload": "%d consecutive 60-s files of %d channels x %d samples per GPU (int32 raw), halo %d samples, "

@@ -19,13 +19,15 @@ def is_tensor(x):
 
 
 # Host <-> device staging for the NumPy-in / NumPy-out calls (SURVEY.md 8d "H2D / D2H reported separately").  A notebook
-# hands over pageable float64 arrays (reference data_handle.py:213): converting them with ndarray.astype is single-threaded
-# (~1 GB/s) and a pageable hipMemcpy is synchronous.  Blocks above _STAGE_MIN bytes therefore cross PCIe in row chunks
-# through two pinned float32 buffers: torch's multi-threaded copy_ converts chunk k into one buffer while chunk k - 1 is
-# still on the wire out of the other, and only float32 crosses the link.  Same in the other direction.
+# hands over pageable float64 arrays (reference data_handle.py:213).  Blocks above _STAGE_MIN bytes cross PCIe in row
+# chunks through two pinned float32 buffers: a few host threads convert chunk k into one buffer (np.copyto releases the
+# GIL) while chunk k - 1 is still on the wire out of the other, so the call costs about max(conversion, transfer) instead
+# of their sum plus a pageable staging copy, and only float32 crosses the link.  Same in the other direction.
 _STAGE_MIN = 32 << 20
 _STAGE_BYTES = 64 << 20
+_STAGE_THREADS = 8
 _stage = {}            # (device index, thread id) -> [two pinned float32 buffers, two events]
+_pool = None
 
 
 def _staging(device):
@@ -40,22 +42,32 @@ def _staging(device):
     return ent
 
 
+def _convert(dst, src):
+    """dst[...] = src with dtype conversion, rows split over a small thread pool (NumPy copies release the GIL)."""
+    global _pool
+    n = dst.shape[0]
+    if n < 2 * _STAGE_THREADS or dst.size < (1 << 20):
+        np.copyto(dst, src, casting="unsafe")
+        return
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=_STAGE_THREADS, thread_name_prefix="d4w-stage")
+    step = -(-n // _STAGE_THREADS)
+    futs = [_pool.submit(np.copyto, dst[r:r + step], src[r:r + step], "unsafe") for r in range(0, n, step)]
+    for f in futs:
+        f.result()
+
+
 def upload_f32(a, device=None):
-    """Host ndarray (any real dtype, C-contiguous or not) -> contiguous float32 CUDA tensor, pipelined through pinned
-    staging buffers on the current stream."""
+    """Host ndarray (any real dtype, any strides) -> contiguous float32 CUDA tensor, pipelined through pinned staging
+    buffers on the current stream."""
     require_gpu()
     device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
     a = np.asarray(a)
-    if a.dtype.kind not in "fiu" or a.dtype == np.float16:
+    if a.dtype.kind not in "fiub":
         a = a.astype(np.float64)
-    if not a.flags.writeable:                    # torch.from_numpy wants a writeable buffer; it is only read here
-        a = a.copy()
-    staged_ok = a.dtype in (np.float32, np.float64, np.int16, np.int32, np.int64)      # what torch.from_numpy takes as is
-    if a.nbytes < _STAGE_MIN or a.ndim != 2 or a.shape[1] * 4 > _STAGE_BYTES or not staged_ok:
-        if a.dtype != np.float32:
-            a = a.astype(np.float32)
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    src = torch.from_numpy(a)
+    if a.nbytes < _STAGE_MIN or a.ndim != 2 or a.shape[1] * 4 > _STAGE_BYTES:
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
     nx, ns = a.shape
     out = torch.empty((nx, ns), dtype=torch.float32, device=device)
     bufs, evs = _staging(device)
@@ -67,7 +79,7 @@ def upload_f32(a, device=None):
             if k >= 2:
                 evs[k & 1].synchronize()         # the copy that last read this staging buffer has left the host
             st = bufs[k & 1][:(r1 - r0) * ns].view(r1 - r0, ns)
-            st.copy_(src[r0:r1])                 # dtype conversion + gather of a strided source, on the host threads
+            _convert(st.numpy(), a[r0:r1])
             out[r0:r1].copy_(st, non_blocking=True)
             evs[k & 1].record()
             k += 1
@@ -80,12 +92,11 @@ def download(y, dtype=np.float32):
     """float32 CUDA tensor -> host ndarray of `dtype`, pipelined through the pinned staging buffers."""
     dtype = np.dtype(dtype)
     if (y.numel() * 4 < _STAGE_MIN or y.dim() != 2 or y.shape[1] * 4 > _STAGE_BYTES or not y.is_contiguous()
-            or y.dtype != torch.float32 or dtype not in (np.float16, np.float32, np.float64)):
+            or y.dtype != torch.float32):
         out = y.cpu().numpy()
         return out if out.dtype == dtype else out.astype(dtype)
     nx, ns = y.shape
     out = np.empty((nx, ns), dtype=dtype)
-    dst = torch.from_numpy(out)
     bufs, evs = _staging(y.device)
     rows = max(1, (_STAGE_BYTES // 4) // ns)
     chunks = [(r0, min(nx, r0 + rows)) for r0 in range(0, nx, rows)]
@@ -99,7 +110,7 @@ def download(y, dtype=np.float32):
             if k + 1 < len(chunks):
                 issue(k + 1)                     # the next chunk crosses the link while this one is converted
             evs[k & 1].synchronize()
-            dst[r0:r1].copy_(bufs[k & 1][:(r1 - r0) * ns].view(r1 - r0, ns))
+            _convert(out[r0:r1], bufs[k & 1][:(r1 - r0) * ns].view(r1 - r0, ns).numpy())
     return out
 
 

@@ -81,6 +81,7 @@ class PinnedIngest:
         self._free = [torch.cuda.Event() for _ in range(depth)]         # the device copy of slot s has been consumed
         self._uploaded = [False] * depth
         self._consumed = [False] * depth
+        self.timing = None            # set to a list: every upload appends its (start, end) events on the copy stream
 
     def host_array(self, slot):
         """NumPy view of pinned buffer `slot` for the reader to fill (h5py read_direct, np.copyto, file.readinto)."""
@@ -100,7 +101,13 @@ class PinnedIngest:
             if self._consumed[slot]:
                 self._copy.wait_event(self._free[slot])                 # the kernel that read the previous content is done
             with torch.cuda.stream(self._copy):
+                if self.timing is not None:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(self._copy)
                 self._dev[slot].copy_(self._host[slot] if src is None else src, non_blocking=True)
+                if self.timing is not None:
+                    t1.record(self._copy)
+                    self.timing.append((t0, t1))
                 self._ready[slot].record(self._copy)
         self._uploaded[slot] = True
 

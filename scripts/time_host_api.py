@@ -29,6 +29,11 @@ out["upload_f64_to_f32_ms"] = wall(lambda: dev.upload_f32(xh))
 out["download_f32_to_f64_ms"] = wall(lambda: dev.download(xd, np.float64))
 out["naive_astype_then_to_ms"] = wall(lambda: torch.from_numpy(xh.astype(np.float32)).to("cuda"), reps=2)
 out["naive_cpu_then_astype_ms"] = wall(lambda: xd.cpu().numpy().astype(np.float64), reps=2)
+pin = torch.empty((nx, ns), dtype=torch.float32).pin_memory()
+pag = np.empty((nx, ns), dtype=np.float32)
+out["convert_f64_to_pinned_f32_ms"] = wall(lambda: dev._convert(pin.numpy(), xh))
+out["convert_f64_to_pageable_f32_ms"] = wall(lambda: dev._convert(pag, xh))
+out["numpy_astype_f32_ms"] = wall(lambda: xh.astype(np.float32), reps=3)
 xp = torch.from_numpy(xh.astype(np.float32)).pin_memory()
 out["pinned_f32_h2d_ms"] = wall(lambda: xp.to("cuda", non_blocking=True))
 out["pinned_f32_h2d_GBps"] = round(xp.numel() * 4 / out["pinned_f32_h2d_ms"] / 1e6, 1)

@@ -143,10 +143,12 @@ def test_staged_host_transfers_match_plain_copies():
     from das4whales_amd import _device as dev
     rng = np.random.default_rng(3)
     a = rng.standard_normal((3000, 6000))                                    # 144 MB as float64: the staged path
-    for src in (a, a.astype(np.float32), np.asfortranarray(a), a[::2, ::3], (a * 1000).astype(np.int32)):
+    for src in (a, a.astype(np.float32), np.asfortranarray(a), a[::2, ::3], a[::-1, ::-1], (a * 1000).astype(np.int32), a > 0):
         got = dev.upload_f32(src)
         assert got.dtype == torch.float32 and got.is_contiguous()
         assert torch.equal(got.cpu(), torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)))
+    big = np.concatenate((a, a), axis=0)[::-1]                                # 288 MB, negative row stride: several chunks
+    assert torch.equal(dev.upload_f32(big).cpu(), torch.from_numpy(np.ascontiguousarray(big, dtype=np.float32)))
     y = torch.randn((3000, 6000), device="cuda")
     for dt in (np.float64, np.float32):
         h = dev.download(y, dt)
