@@ -18,7 +18,7 @@
 //     v_pk_* instruction for both rows;
 //   * one launch per template (xcorr_fft_blocks); xcorr_fft_tpair is the one-read alternative that
 //     packs the two TEMPLATES of one row through a single inverse transform (D4W_XF_TPAIR=1).
-// Spectra and twiddle tables are built per call by xcf_spectra (~30 us).  DESIGN.md 3.3 has the
+// Spectra and twiddle tables are built per call by xcf_spectra (~30 us).  docs/LAB_NOTEBOOK.md 3.3 has the
 // measurements and the variants that were tried.
 #include <cstdlib>
 

@@ -1,6 +1,6 @@
 """Two-template matched filter at 20000 x 120000 for the kernel selected by D4W_XF_FUSED (1 = four-stage fused kernel [default],
 2 = three-stage fused kernel, 0 = one launch per template): HIP-event median and the difference to the direct form on 64 rows.
-(Round 3 also timed a sequential-template variant with it)"""
+(Round 3 also timed a sequential-template variant with it, docs/LAB_NOTEBOOK.md section 9.)"""
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
