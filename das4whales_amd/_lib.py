@@ -104,6 +104,8 @@ def _load():
         "d4w_fx_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
         "d4w_stft_frames": (c_int, [c_int, c_int]),
         "d4w_stft_mag_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+        "d4w_stft_mm_eligible": (c_int, [c_int, c_int, c_int, c_int]),
+        "d4w_stft_mag_mm_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
         "d4w_scale_rows_f32": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_int, c_void_p]),
         "d4w_row_median_f32": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p, c_void_p]),
         "d4w_spectrocorr_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,

@@ -1,0 +1,68 @@
+// Split-binary16 operands for the matrix cores (gfx950 v_mfma_f32_16x16x32_f16), shared by the kernels that run a
+// float32 contraction as matrix products: xcorr_mm.hip (matched filter as a banded-Toeplitz product) and stft_mm.hip
+// (short-time Fourier transform as frames x DFT-rows).  A float32 value v is carried as hi + lo / 2048 (hi = rn16(v),
+// lo = rn16((v - hi) 2048): 22-23 significant bits); a product keeps hi hi + (hi lo + lo hi) / 2048, each exact in the
+// instruction's float32 accumulator.  On the CPU emulator (tests/emu/hip_emu.h) the same names map to software binary16.
+#pragma once
+#include "fft_radix.h"
+
+namespace d4w {
+
+constexpr float kMmLoScale = 2048.f, kMmLoInv = 1.0f / 2048.f;
+
+#ifdef D4W_EMU
+typedef uint16_t mm_half;
+struct alignas(16) mm_h8 { uint16_t v[8]; };
+struct mm_f4 { float v[4]; };
+__device__ __forceinline__ mm_half mm_to_half(float x) { return hipemu::f32_to_f16(x); }
+__device__ __forceinline__ float mm_to_float(mm_half h) { return hipemu::f16_to_f32(h); }
+__device__ __forceinline__ mm_f4 mm_zero() { return mm_f4{{0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ mm_f4 mm_mfma(const mm_h8& a, const mm_h8& b, mm_f4 c) {
+    hipemu::mfma_f32_16x16x32_f16(a.v, b.v, c.v);
+    return c;
+}
+__device__ __forceinline__ float mm_get(const mm_f4& c, int r) { return c.v[r]; }
+__device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a.v[j] = h; }
+__device__ __forceinline__ int mm_uniform(int v) { return v; }
+__device__ __forceinline__ void mm_sched_fence() {}
+__device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+#else
+typedef _Float16 mm_half;
+typedef _Float16 mm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mm_h4 __attribute__((ext_vector_type(4)));
+typedef float mm_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mm_half mm_to_half(float x) { return (_Float16)x; }
+__device__ __forceinline__ float mm_to_float(mm_half h) { return (float)h; }
+__device__ __forceinline__ mm_f4 mm_zero() { mm_f4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ mm_f4 mm_mfma(mm_h8 a, mm_h8 b, mm_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float mm_get(const mm_f4& c, int r) { return c[r]; }
+__device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a[j] = h; }
+__device__ __forceinline__ int mm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void mm_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) {
+    mm_f4 t = {a, b, c, d};
+    __builtin_nontemporal_store(t, reinterpret_cast<mm_f4*>(p));
+}
+#endif
+
+// v = hi + lo / 2048 to 22-23 significant bits.  v is pinned to ONE float32 value first: left alone, hipcc contracts the
+// caller's multiply into v_fma_mixlo_f16 for the residual (hi rounded once from the exact product) while the stored hi comes
+// from v_cvt_pk_f16_f32 of the rounded product -- the two differ by a binary16 ulp for one sample in ~10^4 (a 1e-4 error).
+__device__ __forceinline__ void mm_split(float v, mm_half& hi, mm_half& lo) {
+#ifndef D4W_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    hi = mm_to_half(v);
+    lo = mm_to_half((v - mm_to_float(hi)) * kMmLoScale);
+}
+
+// power of two >= a (a >= 0, finite): the scale that keeps a block of values inside [-1, 1] without rounding them
+__device__ __forceinline__ void mm_pow2_scale(float a, float& up, float& down) {
+    int e = 0;
+    if (a > 0.f) (void)frexpf(a, &e);              // a = f 2^e, 0.5 <= f < 1
+    e = min(max(e, -100), 100);
+    up = ldexpf(1.0f, e);
+    down = ldexpf(1.0f, -e);
+}
+
+}  // namespace d4w

@@ -1339,6 +1339,10 @@ int d4w_stft_frames(int ns, int hop) { return (hop > 0 && ns >= 0) ? 1 + ns / ho
 int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, int n_fft, int hop, int bin_lo,
                      int bin_hi, void* stream) {
     if (!x || !S || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    // a few kept bins of a heavily overlapped transform and no row maximum wanted (the detector's call): frames x DFT rows
+    // as a matrix product on the matrix cores (stft_mm.hip) instead of one FFT per frame
+    if (!rowmax && d4w_stft_mm_eligible(n_fft, hop, bin_lo, bin_hi))
+        return d4w_stft_mag_mm_f32(x, S, nx, ns, n_fft, hop, bin_lo, bin_hi, stream);
     if (n_fft < 2 || (n_fft & 1) || hop < 1) return fail(D4W_EINVAL, "n_fft = %d must be even and >= 2, hop = %d >= 1", n_fft, hop);
     if (bin_lo < 0 || bin_hi > n_fft / 2 || bin_lo > bin_hi) return fail(D4W_EINVAL, "bin range [%d, %d] outside 0..%d", bin_lo, bin_hi, n_fft / 2);
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);

@@ -410,6 +410,15 @@ int d4w_fx_f32(const float* x, float* y, int nx, int ns, int nfft, void* stream)
 int d4w_stft_frames(int ns, int hop);
 int d4w_stft_mag_f32(const float* x, float* S, float* rowmax, int nx, int ns, int n_fft, int hop,
                      int bin_lo, int bin_hi, void* stream);
+/* The same magnitudes for the detector's call shape -- a few kept bins of a heavily overlapped transform, no row maximum
+ * (detect.compute_cross_correlogram_spectrocorr, detect.py:650-709: n_fft = 160, hop = 8, the 13 bins between 14 and 30 Hz) --
+ * as ONE matrix product per 16 frames on the matrix cores: X[b][t] = sum_u (w[u] e^{-2 pi i b u / N}) x[hop t - N/2 + u],
+ * operands as binary16 hi / lo pairs with float32 accumulation (das4whales_amd/csrc/stft_mm.hip).  d4w_stft_mag_f32 takes this
+ * route by itself when rowmax == NULL and d4w_stft_mm_eligible(...) = 1: n_fft % 32 == 0 <= 160, hop % 8 == 0 <= 32, at most
+ * 16 kept bins (D4W_STFT_MM=0 switches it off). */
+int d4w_stft_mm_eligible(int n_fft, int hop, int bin_lo, int bin_hi);
+int d4w_stft_mag_mm_f32(const float* x, float* S, int nx, int ns, int n_fft, int hop, int bin_lo, int bin_hi,
+                        void* stream);
 int d4w_scale_rows_f32(float* S, int nx, size_t per_row, const float* denom, int mode, void* stream);
 int d4w_row_median_f32(const float* v, int nx, size_t per_row, float* med, void* stream);
 int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, int nk, int off,

@@ -116,10 +116,35 @@ def test_stft_magnitude(emu, n_fft, hop, ns):
     xf = np.ascontiguousarray(x, dtype=np.float32)
     S3 = np.full_like(S2, np.nan)
     rc = emu.d4w_stft_mag_f32(vp(xf), vp(S3), None, 3, ns, n_fft, hop, 5, 17, None)
-    if n_fft in (128, 160, 256, 512):
+    if emu.d4w_stft_mm_eligible(n_fft, hop, 5, 17):                # the matrix-core form (stft_mm.hip): its own rounding
+        assert rc == 0 and rel(S3, S2.astype(np.float64)) < 2e-6
+    elif n_fft in (128, 160, 256, 512):
         assert rc == 0 and np.array_equal(S3, S2)
     else:
         assert rc != 0
+
+
+@pytest.mark.parametrize("n_fft,hop,ns,lo,hi", [(160, 8, 12000, 12, 24), (160, 8, 4999, 0, 15), (128, 16, 3001, 60, 64), (96, 24, 2500, 3, 3),
+                                                (32, 8, 700, 1, 16), (160, 32, 9000, 70, 80), (64, 8, 100, 1, 9)])
+def test_stft_on_the_matrix_cores(emu, n_fft, hop, ns, lo, hi):
+    """d4w_stft_mag_f32 without a row maximum for the detector's call shapes runs as frames x DFT rows on the matrix cores:
+    several chunks of 256 frames per row, rows of odd length (unaligned rows: sample-by-sample loads), the first / last frames
+    hanging over the row ends (zero padding), 1-16 kept bins incl. DC and Nyquist, a large offset (power-of-two chunk scale)."""
+    if hi > n_fft // 2:
+        hi = n_fft // 2
+    assert emu.d4w_stft_mm_eligible(n_fft, hop, lo, hi) == 1
+    rng = np.random.default_rng(ns)
+    x = rng.standard_normal((3, ns)) * np.array([[1.0], [300.0], [1e-3]]) + np.array([[0.0], [50.0], [0.0]])
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nt = emu.d4w_stft_frames(ns, hop)
+    S = np.full((3, hi - lo + 1, nt), np.nan, dtype=np.float32)
+    ok(emu, emu.d4w_stft_mag_f32(vp(xf), vp(S), None, 3, ns, n_fft, hop, lo, hi, None))
+    for c in range(3):
+        ref = np.abs(orc.librosa_stft(xf[c].astype(np.float64), n_fft=n_fft, hop_length=hop))
+        assert rel(S[c], ref[lo:hi + 1]) < 2e-6 * (np.abs(ref).max() / np.abs(ref[lo:hi + 1]).max())
+    assert emu.d4w_stft_mm_eligible(256, 8, 0, 5) == 0 and emu.d4w_stft_mm_eligible(160, 7, 0, 5) == 0
+    assert emu.d4w_stft_mm_eligible(160, 8, 0, 16) == 0 and emu.d4w_stft_mm_eligible(160, 40, 0, 5) == 0
+    assert emu.d4w_stft_mag_mm_f32(vp(xf), vp(S), 3, ns, 256, 8, 0, 5, None) != 0
 
 
 def test_spectrogram_and_nspectrogram_golden(emu, golden):
