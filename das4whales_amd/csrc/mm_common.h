@@ -26,6 +26,11 @@ __device__ __forceinline__ void mm_set(mm_h8& a, int j, mm_half h) { a.v[j] = h;
 __device__ __forceinline__ int mm_uniform(int v) { return v; }
 __device__ __forceinline__ void mm_sched_fence() {}
 __device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+__device__ __forceinline__ void mm_store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void mm_put4(mm_half* p, const mm_half (&h)[4]) { p[0] = h[0]; p[1] = h[1]; p[2] = h[2]; p[3] = h[3]; }
+__device__ __forceinline__ float mm_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ void mm_wave_sync() { (void)__shfl_xor(0, 1); }     // every lane of the wave arrives before any goes on
+static inline int mm_num_cus() { return 2; }
 #else
 typedef _Float16 mm_half;
 typedef _Float16 mm_h8 __attribute__((ext_vector_type(8)));
@@ -42,6 +47,25 @@ __device__ __forceinline__ void mm_sched_fence() { __builtin_amdgcn_sched_barrie
 __device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) {
     mm_f4 t = {a, b, c, d};
     __builtin_nontemporal_store(t, reinterpret_cast<mm_f4*>(p));
+}
+__device__ __forceinline__ void mm_store1(float* p, float v) { __builtin_nontemporal_store(v, p); }     // write-once outputs: streaming
+__device__ __forceinline__ void mm_put4(mm_half* p, const mm_half (&h)[4]) {                            // one 8-byte LDS store
+    mm_h4 v = {h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<mm_h4*>(p) = v;
+}
+// v_sqrt_f32 (1 ulp) without the denormal rescaling and refinement sqrtf() wraps around it
+__device__ __forceinline__ float mm_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+// orders a wave's LDS stores before its own later LDS loads (and the other way round): the LDS serves a wave's accesses in
+// order, this only keeps the compiler from moving them across
+__device__ __forceinline__ void mm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+static inline int mm_num_cus() {
+    int devid = 0, v = 0;
+    if (hipGetDevice(&devid) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) return v;
+    return 256;
 }
 #endif
 

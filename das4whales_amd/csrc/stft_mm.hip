@@ -49,34 +49,6 @@ __device__ __forceinline__ void sm_pow2_scale(float a, float& up, float& down) {
     down = ldexpf(1.0f, -e);
 }
 
-// v_sqrt_f32 (1 ulp) without the denormal rescaling and refinement sqrtf() wraps around it: four per lane and tile, the
-// magnitudes are nowhere near the subnormal range after the chunk scaling; write-once output: streaming stores
-__device__ __forceinline__ float sm_sqrt(float v) {
-#ifdef D4W_EMU
-    return sqrtf(v);
-#else
-    return __builtin_amdgcn_sqrtf(v);
-#endif
-}
-// orders a wave's LDS stores before its own later LDS loads (and the other way round) -- the LDS serves a wave's accesses in
-// order, this only keeps the compiler from moving them across (and yields to the other lanes on the emulator)
-__device__ __forceinline__ void sm_wave_sync() {
-#ifdef D4W_EMU
-    (void)__shfl_xor(0, 1);
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-__device__ __forceinline__ void sm_store(float* p, float v) {
-#ifdef D4W_EMU
-    *p = v;
-#else
-    __builtin_nontemporal_store(v, p);
-#endif
-}
-
 template <int KS>                                 // n_fft = 32 KS
 __global__ __launch_bounds__(kSmThreads, 3) void stft_mm_rows(SmArgs P) {
     D4W_DYN_LDS(smem_raw);
@@ -173,13 +145,8 @@ __global__ __launch_bounds__(kSmThreads, 3) void stft_mm_rows(SmArgs P) {
                 const float s[4] = {v[q].x * down, v[q].y * down, v[q].z * down, v[q].w * down};
                 mm_half h[4], l[4];
                 static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
-#ifdef D4W_EMU
-                for (int e = 0; e < 4; ++e) { bh[i + e] = h[e]; bl[i + e] = l[e]; }
-#else
-                mm_h4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-                *reinterpret_cast<mm_h4*>(bh + i) = hv;
-                *reinterpret_cast<mm_h4*>(bl + i) = lv;
-#endif
+                mm_put4(bh + i, h);
+                mm_put4(bl + i, l);
             }
         });
         lds_barrier();
@@ -212,10 +179,10 @@ __global__ __launch_bounds__(kSmThreads, 3) void stft_mm_rows(SmArgs P) {
                     constexpr int r = decltype(rr)::value;
                     const float re = fmaf(mm_get(cra, r) + mm_get(crb, r), kMmLoInv, mm_get(crh, r));
                     const float im = fmaf(mm_get(cia, r) + mm_get(cib, r), kMmLoInv, mm_get(cih, r));
-                    tile[(4 * g + r) * kSmTileP + 16 * q + n16] = sm_sqrt(fmaf(re, re, im * im)) * up;
+                    tile[(4 * g + r) * kSmTileP + 16 * q + n16] = mm_sqrt(fmaf(re, re, im * im)) * up;
                 });
             });
-            sm_wave_sync();                                         // the run's tile is complete (one wave wrote it, the same wave reads it)
+            mm_wave_sync();                                         // the run's tile is complete (one wave wrote it, the same wave reads it)
             const int f = f0 + 64 * R + lane;
             float* srow = P.S + (size_t)row * P.nbins * nt + f;
             if (f < nt) {
@@ -223,10 +190,10 @@ __global__ __launch_bounds__(kSmThreads, 3) void stft_mm_rows(SmArgs P) {
                 static_for<16>([&](auto bb) { constexpr int b_ = decltype(bb)::value; o[b_] = tile[b_ * kSmTileP + lane]; });   // all reads, then all stores
                 static_for<16>([&](auto bb) {
                     constexpr int b_ = decltype(bb)::value;
-                    if (b_ < P.nbins) sm_store(srow + (size_t)b_ * nt, o[b_]);
+                    if (b_ < P.nbins) mm_store1(srow + (size_t)b_ * nt, o[b_]);
                 });
             }
-            sm_wave_sync();                                         // before the next run overwrites the tile
+            mm_wave_sync();                                         // before the next run overwrites the tile
         }
     }
 }
@@ -252,16 +219,7 @@ extern "C" int d4w_stft_mag_mm_f32(const float* x, float* S, int nx, int ns, int
     P.nt = 1 + ns / hop;
     const int FC = sm_frames_per_chunk(n_fft, hop);
     const long long total = (long long)nx * ceil_div(P.nt, FC);
-    int ncu = 256;
-#ifndef D4W_EMU
-    {
-        int devid = 0, v = 0;
-        D4W_HIP(hipGetDevice(&devid));
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) ncu = v;
-    }
-#else
-    ncu = 2;
-#endif
+    const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * 3);
     const int staged = (FC - 1) * hop + n_fft, arr = (staged + 7) & ~7;
     const size_t lds = (size_t)2 * arr * sizeof(mm_half) + 4 * sizeof(float) + (size_t)4 * 16 * kSmTileP * sizeof(float);

@@ -221,13 +221,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 mm_half h[4], l[4];
                 static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
                 const int at = mm_pidx(4 * (tid + q * kMmThreads));
-#ifdef D4W_EMU
-                for (int e = 0; e < 4; ++e) { bh[at + e] = h[e]; bl[at + e] = l[e]; }
-#else
-                mm_h4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-                *reinterpret_cast<mm_h4*>(bh + at) = hv;
-                *reinterpret_cast<mm_h4*>(bl + at) = lv;
-#endif
+                mm_put4(bh + at, h);
+                mm_put4(bl + at, l);
             }
         });
         // ---- next chunk's loads fly across the barrier and the matrix phase
@@ -324,17 +319,7 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
     // (149 VGPRs).  D4W_MM_WGS overrides the count (measurements).
     static const int env_wgs = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 0; return n < 0 ? 0 : (n > 8 ? 8 : n); }();
     const int per_cu = env_wgs ? env_wgs : (ntpl == 1 ? 3 : 2);
-    int ncu = 256;
-#ifndef D4W_EMU
-    {
-        int devid = 0;
-        D4W_HIP(hipGetDevice(&devid));
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) ncu = v;
-    }
-#else
-    ncu = 2;
-#endif
+    const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
     const size_t lds = (size_t)4 * kMmArr * sizeof(mm_half) + 8 * sizeof(float);
     const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);

@@ -13,12 +13,20 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | grep "^{" > $O/bench_line.json; cut -c1-300 $O/bench_line.json
 timeout 900 python bench.py --stages bp,fk,mf --steps 10 --warmup 3 --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_bp_fk_mf.json; cut -c1-200 $O/bench_bp_fk_mf.json
 timeout 900 python bench.py --config stream --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_1gpu.json; cut -c1-600 $O/bench_stream_1gpu.json
+# the same chain with the raw files in pinned host memory (double-buffered upload on a side stream): 8 files per run as above, and
+# 24 files per run (the first upload and the drain weigh less: the steady-state rate against the PCIe bound)
+timeout 900 python bench.py --config stream --from-host --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_from_host.json; cut -c1-300 $O/bench_stream_from_host.json
+timeout 900 python bench.py --config stream --from-host --files 24 --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_from_host_24files.json; cut -c1-300 $O/bench_stream_from_host_24files.json
+# matched filter: matrix-core kernel against the FFT kernel, errors against float64 (bench shape and the file shape)
+(timeout 300 python scripts/time_xcorr_mm.py; NX=11020 NS=12000 timeout 300 python scripts/time_xcorr_mm.py) 2>/dev/null | grep "^{" > $O/time_xcorr_mm.txt; cut -c1-400 $O/time_xcorr_mm.txt
+# what a notebook call costs: host float64 in -> host float64 out, upload / kernel / download
+timeout 600 python scripts/time_host_api.py 2>/dev/null | grep "^{" > $O/time_host_api.txt; cat $O/time_host_api.txt
 timeout 900 python bench.py --shard channel --steps 5 --warmup 2 --force-replicas 2>/dev/null | grep "^{" > $O/bench_shard_channel_1rank.json; cut -c1-200 $O/bench_shard_channel_1rank.json
 timeout 600 python scripts/time_bp.py 2>/dev/null | grep "^{" > $O/time_bp.txt; cat $O/time_bp.txt
 timeout 600 python scripts/pipeline_bench.py 2>/dev/null | grep "^{" > $O/pipeline_11020x12000.json; cat $O/pipeline_11020x12000.json
 timeout 600 python scripts/time_shapes.py 13223x12000 8000x12000 11020x12000 5510x12000 4000x12000 2>/dev/null | grep "^{" > $O/time_shapes.txt; cat $O/time_shapes.txt
 # pass order and pass times per mask (time-first / channel-first), bench shape and the scripts' own 13223-channel selection
-(timeout 300 python scripts/time_fk_masks.py classic ninf hybrid dense step4; NX=13223 NS=12000 timeout 200 python scripts/time_fk_masks.py ninf classic; NX=11020 NS=12000 timeout 200 python scripts/time_fk_masks.py ninf classic) 2>/dev/null | grep "^{" > $O/time_fk_masks.txt; cut -c1-200 $O/time_fk_masks.txt
+(timeout 400 python scripts/time_fk_masks.py classic ninf hybrid dense step4; NX=13223 NS=12000 timeout 200 python scripts/time_fk_masks.py ninf classic; NX=11020 NS=12000 timeout 200 python scripts/time_fk_masks.py ninf classic) 2>/dev/null | grep "^{" > $O/time_fk_masks.txt; cut -c1-200 $O/time_fk_masks.txt
 # shapes beyond the direct kernels: prime channel counts / record lengths (Bluestein forms), loop-free prime radices (generic kernels)
 timeout 600 python scripts/time_shapes.py 4099x12000 10007x12000 19997x12000 11020x12014 11020x12002 10007x12014 2>/dev/null | grep "^{" > $O/time_any_shape.txt; cut -c1-60,180-330 $O/time_any_shape.txt
 timeout 300 python scripts/time_bluestein_rows.py 2>/dev/null | grep "^{" > $O/time_bluestein_rows.txt; cat $O/time_bluestein_rows.txt
