@@ -40,19 +40,24 @@
 namespace d4w {
 
 constexpr int kMmCH = 4096;                      // lags per chunk
-constexpr int kMmKS = 6;                         // k-steps of 32 -> Toeplitz depth 192
-constexpr int kMmHalo = 32 * kMmKS;              // samples staged beyond the chunk
-constexpr int kMmMaxSupport = kMmHalo - 15;      // 177
+constexpr int kMmKS = 6;                         // k-steps of 32 of the two-template kernels -> Toeplitz depth 192, supports <= 177
+constexpr int kMmKSLong = 8;                     // ... of the one-template kernel for longer supports: depth 256, supports <= 241
+constexpr int kMmMaxSupport = 32 * kMmKSLong - 15;
 constexpr int kMmThreads = 256;
-constexpr int kMmStage = kMmCH + kMmHalo;        // 4288 samples per chunk
-constexpr int kMmQ = (kMmStage + 4 * kMmThreads - 1) / (4 * kMmThreads);   // 16-byte loads per lane: 5 (the last one lanes < 48)
-constexpr int kMmLastQ = (kMmStage - (kMmQ - 1) * 4 * kMmThreads) / 4;   // lanes that take the last load: 48
+// geometry of a chunk for a Toeplitz depth of KSM k-steps
+template <int KSM>
+struct MmGeom {
+    static constexpr int Halo = 32 * KSM;                        // samples staged beyond the chunk
+    static constexpr int Stage = kMmCH + Halo;                   // samples per chunk (4288 at KSM = 6)
+    static constexpr int Q = (Stage + 4 * kMmThreads - 1) / (4 * kMmThreads);      // 16-byte loads per lane: 5
+    static constexpr int LastQ = (Stage - (Q - 1) * 4 * kMmThreads) / 4;         // lanes that take the last load (48 at KSM = 6)
+    static constexpr int Arr = Stage + 8;                        // halves per LDS array
+};
 // LDS index of sample h of the chunk: the plain order.  ds_read_b128 is served in four NON-contiguous 16-lane groups
 // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: MI355X_MICROARCH.md, LDS), and with lane (a, g) reading the 16-byte
 // slot 2 a + g (+ const) every group touches 16 different slots: no bank conflict.  (Round 4's first build padded 16 B
 // per 256 B for contiguous groups: 61 % of its LDS cycles were conflicts, profiles/r04a/pmc_sq_matched_filter.txt.)
 __host__ __device__ constexpr int mm_pidx(int h) { return h; }
-constexpr int kMmArr = mm_pidx(kMmStage) + 8;    // halves per LDS array (4296 -> 8592 B)
 
 struct MmArgs {
     const float* x;         // [nx][ns]
@@ -69,6 +74,8 @@ struct MmArgs {
 template <int KS0, int KS1, int WPS>
 __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     constexpr int KSM = KS0 > KS1 ? KS0 : KS1;
+    using GEO = MmGeom<KSM>;
+    constexpr int kMmHalo = GEO::Halo, kMmStage = GEO::Stage, kMmQ = GEO::Q, kMmLastQ = GEO::LastQ, kMmArr = GEO::Arr;
     D4W_DYN_LDS(smem_raw);
     mm_half* lds = reinterpret_cast<mm_half*>(smem_raw);           // [2 buffers][hi | lo][kMmArr]
     float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [4] chunk maxima of the waves (no maxabs)
@@ -321,9 +328,22 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
     const int per_cu = env_wgs ? env_wgs : (ntpl == 1 ? 3 : 2);
     const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
-    const size_t lds = (size_t)4 * kMmArr * sizeof(mm_half) + 8 * sizeof(float);
     const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
-    if (ntpl == 1)
+    auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
+    if (ntpl == 2 && std::max(ks0, ks1) > kMmKS) {
+        // a support beyond 177 samples: the two templates one after the other through the one-template kernel (its Toeplitz
+        // fragments alone fill the registers the fused kernel splits between two templates)
+        MmArgs P1 = P;
+        P1.taps = taps + ltaps; P1.len0 = len1; P1.y0 = y1; P1.y1 = nullptr;
+        P.y1 = nullptr;
+        D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, P);
+        D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, P1);
+        return D4W_OK;
+    }
+    const size_t lds = lds_of(MmGeom<kMmKS>::Arr);
+    if (ntpl == 1 && ks0 > kMmKS)
+        D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, P);
+    else if (ntpl == 1)
         D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds, stream, P);
     else if (ks0 <= 5)
         D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);

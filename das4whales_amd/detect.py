@@ -81,7 +81,7 @@ def _xf_prepared(grp, device, ws=True):
 
 
 def _xcorr_method(taps_list, ns, method):
-    """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores, supports <= 177 samples, the
+    """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores, supports <= 241 samples, the
     default), "fft" (overlap-save, supports <= 161, rows >= 1024 samples) or "direct" (any support).  D4W_XCORR_METHOD
     overrides "auto" (measurements, A/B tests)."""
     import os

@@ -923,7 +923,10 @@ def _stft_mag(x2d, n_fft, hop, bin_lo, bin_hi, want_max=True):
     nx, ns = x2d.shape
     nt = int(lib.d4w_stft_frames(ns, int(hop)))
     S = torch.empty((nx, bin_hi - bin_lo + 1, nt), dtype=torch.float32, device=x2d.device)
-    want_max = want_max or int(n_fft) not in (128, 160, 256, 512)
+    # without the row maximum: the matrix-core form (stft_mm.hip: few kept bins, hop a multiple of 8) or the two-factor
+    # register transforms; every other frame length needs it
+    want_max = want_max or not (int(n_fft) in (128, 160, 256, 512)
+                                or lib.d4w_stft_mm_eligible(int(n_fft), int(hop), int(bin_lo), int(bin_hi)))
     mx = torch.empty(nx, dtype=torch.float32, device=x2d.device) if want_max else None
     with torch.cuda.device(x2d.device):
         check(lib.d4w_stft_mag_f32(dev.ptr(x2d), dev.ptr(S), dev.ptr(mx) if want_max else None, nx, ns, int(n_fft), int(hop),

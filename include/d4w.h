@@ -293,7 +293,8 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
  *   C[i][a] = sum_u t[u - i] x[16 a + u]  per 256 lags, v_mfma_f32_16x16x32_f16 on binary16 hi / lo splits of the float32
  *   operands (three of the four partial products, float32 accumulation; agreement with d4w_xcorr_lens_f32 and a float64
  *   correlation to float32 rounding), one read of x and one write per correlogram, no workspace.
- * supports <= d4w_xcorr_mm_max_support() = 177; ntpl = 1 or 2 (fused); taps DEVICE [ntpl][ltaps], always needed (the
+ * supports <= d4w_xcorr_mm_max_support() = 241; ntpl = 1 or 2 (fused into one launch while both supports are <= 177, one
+ * launch per template beyond); taps DEVICE [ntpl][ltaps], always needed (the
  * Toeplitz fragments are built in the kernel); mean / maxabs as d4w_xcorr_lens_f32 (maxabs == NULL: every 4096-lag chunk
  * is scaled by its own power of two); xnext / ld_next / n_next as d4w_xcorr_fft_cont_f32 (NULL, 0, 0: zeros behind the row). */
 int d4w_xcorr_mm_max_support(void);

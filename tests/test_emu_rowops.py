@@ -464,10 +464,11 @@ def test_xcorr_mm_golden(emu, golden):
 
 
 @pytest.mark.parametrize("nx,ns,l0,l1", [(3, 9001, 161, 7), (2, 4096, 136, 156), (1, 4289, 1, 177), (4, 1300, 50, 50), (2, 100, 100, 3),
-                                          (1, 8192 + 4288, 136, 156)])
+                                          (1, 8192 + 4288, 136, 156), (2, 4500, 241, 20), (1, 5000, 60, 200)])
 def test_xcorr_mm_ragged(emu, nx, ns, l0, l1):
     """Odd row lengths (unaligned rows: the sample-by-sample loads and stores), chunks with a ragged tail, a row shorter
-    than a chunk, the maximum support, rows without normalisation (per-chunk power-of-two scale) and with a large offset."""
+    than a chunk, the maximum support of the fused kernel (177) and of the one-template kernel (241: two templates then run
+    one after the other), rows without normalisation (per-chunk power-of-two scale) and with a large offset."""
     rng = np.random.default_rng(ns + l0)
     x = rng.standard_normal((nx, ns)) * 37.0 + 0.5
     t0, t1 = rng.standard_normal(l0) * 5.0, rng.standard_normal(l1) * 0.01
@@ -475,13 +476,13 @@ def test_xcorr_mm_ragged(emu, nx, ns, l0, l1):
     for c in range(nx):
         assert rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - l0)))) < 2e-6
         assert rel(y1[c], orc.shift_xcorr(x[c], np.pad(t1, (0, ns - l1)))) < 2e-6
-    assert emu.d4w_xcorr_mm_max_support() == 177
+    assert emu.d4w_xcorr_mm_max_support() == 241
     xs = (x + 1000.0).astype(np.float32)
     z0, z1 = xcorr_mm_emu(emu, xs, [t0, t1])
     xn = (xs.astype(np.float64) - xs.astype(np.float64).mean(axis=1, keepdims=True)) / np.abs(xs).max(axis=1, keepdims=True)
     for c in range(nx):
         assert rel(z0[c], orc.shift_xcorr(xn[c], np.pad(t0, (0, ns - l0)))) < 1e-5    # float32 row mean of a 1000x offset
-    assert emu.d4w_xcorr_mm_f32(vp(xs), nx, ns, None, 0, 0, None, None, vp(np.zeros((1, 180), np.float32)), 1, 180, 178, 178,
+    assert emu.d4w_xcorr_mm_f32(vp(xs), nx, ns, None, 0, 0, None, None, vp(np.zeros((1, 244), np.float32)), 1, 244, 242, 242,
                                 vp(z0), None, None) != 0
 
 

@@ -92,6 +92,57 @@ def test_matched_filter_random_shapes(dw):
         assert rel(dw.detect.shift_nxcorr(x[0], y), orc.shift_nxcorr(x[0], y)) < TOL
 
 
+def test_matrix_core_correlator_random_cases(dw):
+    """csrc/xcorr_mm.hip over random shapes: supports 1..241 (fused two-template kernel up to 177, the one-template kernel
+    beyond), template pairs in both orders, single templates, rows of any length and alignment, rows with a large offset,
+    all three forms against a float64 correlation."""
+    import torch
+    rng = np.random.default_rng(2024)
+    for it in range(10):
+        nx, ns = int(rng.integers(1, 60)), int(rng.integers(30, 20000))
+        lmax = min(241, ns)
+        L0, L1 = int(rng.integers(1, lmax + 1)), int(rng.integers(1, lmax + 1))
+        x = rng.standard_normal((nx, ns)) * float(10.0 ** rng.integers(-3, 4)) + float(rng.standard_normal()) * 5.0
+        taps = [rng.standard_normal(L0) * np.hanning(L0 + 2)[1:-1], rng.standard_normal(L1)]
+        if it % 3 == 0:
+            taps = taps[:1]
+        xd = torch.from_numpy(x.astype(np.float32)).cuda()
+        ym = dw.detect._xcorr_device(xd, taps, normalize=True, method="mm")
+        x64 = xd.double().cpu().numpy()
+        mean = xd.mean(dim=1).double().cpu().numpy()                 # the statistics the kernel was given, in float64
+        xn = (x64 - mean[:, None]) / np.abs(x64).max(axis=1, keepdims=True)
+        for k, tp in enumerate(taps):
+            ref = np.stack([np.correlate(np.concatenate((r, np.zeros(len(tp) - 1))), tp, "valid") for r in xn])
+            e = rel(ym[k].cpu().numpy(), ref)
+            assert e < 3e-6, (nx, ns, L0, L1, k, e)
+        yr = dw.detect._xcorr_device(xd, taps, normalize=False, method="mm")          # per-chunk power-of-two scale
+        for k, tp in enumerate(taps):
+            ref = np.stack([np.correlate(np.concatenate((r, np.zeros(len(tp) - 1))), tp, "valid") for r in x64])
+            assert rel(yr[k].cpu().numpy(), ref) < 3e-6, (nx, ns, L0, L1, k, "raw")
+    with pytest.raises(ValueError):
+        dw.detect._xcorr_device(xd, [rng.standard_normal(242)], normalize=True, method="mm")
+
+
+def test_detector_stft_random_cases(dw):
+    """csrc/stft_mm.hip (the detector's STFT on the matrix cores) over random rows: eligible (n_fft, hop, bins) against the
+    float64 restatement of librosa.stft; ineligible parameters keep running the FFT kernels."""
+    import torch
+    rng = np.random.default_rng(77)
+    for n_fft, hop in ((160, 8), (128, 8), (160, 16), (96, 24), (64, 32), (160, 8)):
+        nx, ns = int(rng.integers(1, 40)), int(rng.integers(n_fft, 15000))
+        nb = int(rng.integers(1, 17))
+        lo = int(rng.integers(0, n_fft // 2 + 2 - nb))
+        hi = lo + nb - 1
+        x = rng.standard_normal((nx, ns)) * float(10.0 ** rng.integers(-2, 3))
+        xd = torch.from_numpy(x.astype(np.float32)).cuda()
+        S, mx = dw.dsp._stft_mag(xd, n_fft, hop, lo, hi, want_max=False)
+        assert mx is None
+        S = S.cpu().numpy()
+        for c in range(0, nx, max(1, nx // 4)):
+            ref = np.abs(orc.librosa_stft(xd[c].double().cpu().numpy(), n_fft=n_fft, hop_length=hop))
+            assert np.max(np.abs(S[c] - ref[lo:hi + 1])) < 3e-6 * np.abs(ref).max(), (n_fft, hop, lo, hi, ns)
+
+
 def test_analytic_and_snr_random_shapes(dw):
     rng = np.random.default_rng(104)
     for ns in smooth_lengths(rng, 4, 16, 30000, even=True) + smooth_lengths(rng, 2, 15, 15000) + [120000 // 2, 2 * 3 * 5 * 7 * 11 * 13]:
