@@ -23,7 +23,7 @@
 // products, hi hi + (hi lo + lo hi) 2^-11 -- each exact in the float32 accumulator of the matrix instruction; the
 // dropped lo lo 2^-22 term is below float32 rounding.  Rows are scaled to |x| <= 2 before the split (1 / max|x| of
 // detect.py:157 when the caller normalises, otherwise a power of two per chunk), templates by a power of two, so
-// nothing leaves the binary16 range.  Measured against a float64 correlation the result is as close as the float32
+// nothing overflows binary16; small values use its subnormals, which the conversions and the matrix instruction keep.  Measured against a float64 correlation the result is as close as the float32
 // FFT kernel's (tests/test_rowops_gpu.py).
 //
 // Launch shape.  Persistent workgroups (256 threads, 4 waves) walk chunks of 4096 lags of one row; the chunk's
@@ -63,7 +63,7 @@ struct MmArgs {
     const float* x;         // [nx][ns]
     const float* xnext;     // [nx][ld_next] or NULL: the record's continuation (first n_next samples of every row)
     const float* mean;      // [nx] or NULL
-    const float* maxabs;    // [nx] or NULL (then every chunk is scaled by its own power of two)
+    const float* maxabs;    // [nx] or NULL: the 1 / max|x| of the normalisation (output scale only)
     const float* taps;      // [ntpl][ltaps]
     float* y0;
     float* y1;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     constexpr int kMmHalo = GEO::Halo, kMmStage = GEO::Stage, kMmQ = GEO::Q, kMmLastQ = GEO::LastQ, kMmArr = GEO::Arr;
     D4W_DYN_LDS(smem_raw);
     mm_half* lds = reinterpret_cast<mm_half*>(smem_raw);           // [2 buffers][hi | lo][kMmArr]
-    float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [4] chunk maxima of the waves (no maxabs)
+    float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [2][4] chunk maxima of the waves
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = mm_uniform(tid >> 6);
     const int n16 = lane & 15, g = lane >> 4;
@@ -205,7 +205,10 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         mm_half* bl = bh + kMmArr;
         // ---- convert the loaded chunk: (x - mu) * scale -> hi / lo halves in LDS
         if (!P.maxabs) {
-            // no row maximum from the caller: this chunk's own power of two
+            // no row maximum from the caller: this chunk's own power of two.  (With a row maximum the rows are scaled by
+            // 1 / max|x| alone: a row whose signal is small against its offset then sits low in the binary16 range, which is
+            // harmless -- v_cvt_f16_f32 and the matrix instruction keep binary16 subnormals, scripts/probe/denorm_probe.py:
+            // taps at 1e-7 of the largest one still come out at 3e-7 -- and the per-chunk reduction costs a barrier, 3 %.)
             float m = 0.f;
             static_for<kMmQ>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;

@@ -107,9 +107,13 @@ def test_matrix_core_correlator_random_cases(dw):
         if it % 3 == 0:
             taps = taps[:1]
         xd = torch.from_numpy(x.astype(np.float32)).cuda()
-        ym = dw.detect._xcorr_device(xd, taps, normalize=True, method="mm")
+        # the row statistics are handed over, so that kernel and reference de-mean by the SAME float32 mean: with an offset a
+        # thousand times the signal, one ulp of the mean is 1e-5 of the de-meaned row (a property of float32 statistics, not
+        # of the correlator)
+        mean32, mx32 = xd.mean(dim=1).contiguous(), xd.abs().amax(dim=1).contiguous()
+        ym = dw.detect._xcorr_device(xd, taps, normalize=True, method="mm", stats=(mean32, mx32))
         x64 = xd.double().cpu().numpy()
-        mean = xd.mean(dim=1).double().cpu().numpy()                 # the statistics the kernel was given, in float64
+        mean = mean32.double().cpu().numpy()
         xn = (x64 - mean[:, None]) / np.abs(x64).max(axis=1, keepdims=True)
         for k, tp in enumerate(taps):
             ref = np.stack([np.correlate(np.concatenate((r, np.zeros(len(tp) - 1))), tp, "valid") for r in xn])
