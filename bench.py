@@ -266,7 +266,7 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
             stage_ms["fk:" + l1] = stage_ms.get("fk:" + l1, 0.0) + e0.elapsed_time(e1) / 3
     plan.marks = None
     rep_ms = None
-    plan_info = {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "packed": bool(plan.packed), "exchange_row_chunks": plan.CHUNKS}
+    plan_info = {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "packed": bool(plan.packed), "exchange_row_chunks": plan.exchange_chunks() if plan.packed else None}
     kernels = "shape-specialised" if plan.packed else "generic"
     if (world > 1 or args.force_replicas) and stages == ["fk", "mf"] and not args.no_replicas:
         del x_loc, plan

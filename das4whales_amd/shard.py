@@ -211,8 +211,20 @@ class ShardedFkPlan:
         else:
             dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
 
-    # row chunks of the packed exchanges (transfer of chunk i overlaps the time-axis transform of chunk i + 1)
-    CHUNKS = 4
+    # Row chunks of the packed exchanges (transfer of chunk i overlaps the time-axis transform of chunk i + 1).  None = from
+    # the bytes a rank sends to one peer per exchange: messages of >= 16 MiB (0.1 ms on one 153-GB/s xGMI link -- below that the
+    # per-message cost of a grouped isend / irecv shows), at most 8 chunks; every rank derives the same count from the plan's
+    # shape (20 000 x 120 000 over 8 ranks: 131 MB per peer -> 8 chunks; over 2 ranks: 2.4 GB -> 8).  An integer pins it.
+    CHUNKS = None
+
+    def exchange_chunks(self):
+        """Number of row chunks per exchange (the same on every rank)."""
+        if self.CHUNKS is not None:
+            want = int(self.CHUNKS)
+        else:
+            per_peer = (self.nx / max(self.world, 1)) * self.ns * 4.0 / max(self.world, 1)
+            want = int(min(8, max(1, per_peer // (16 << 20))))
+        return max(1, min([want] + [-(-(b - a) // self.C1) for a, b in self.blocks]))
 
     def _chunks(self, r, nch):
         """Local row ranges [l0, l1) of rank r's nch chunks: boundaries at multiples of C1 (the time-phase tile)."""
@@ -274,7 +286,7 @@ class ShardedFkPlan:
         slab = self._scratch("slab", self.nx * self.nq * per, dev_)
         # the same chunk count on every rank (uneven channel blocks differ by a row: a count derived from this rank's own
         # block could differ between ranks, and the grouped send / recv lists would then not match)
-        nch = max(1, min([self.CHUNKS] + [-(-(b - a) // self.C1) for a, b in self.blocks]))
+        nch = self.exchange_chunks()
         chunks = [self._chunks(r, nch) for r in range(self.world)]
         works = []
         self._mark("start")
