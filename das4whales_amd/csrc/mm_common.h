@@ -27,6 +27,7 @@ __device__ __forceinline__ int mm_uniform(int v) { return v; }
 __device__ __forceinline__ void mm_sched_fence() {}
 __device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 __device__ __forceinline__ void mm_store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float4 mm_load4_stream(const float4* p) { return *p; }
 __device__ __forceinline__ void mm_put4(mm_half* p, const mm_half (&h)[4]) { p[0] = h[0]; p[1] = h[1]; p[2] = h[2]; p[3] = h[3]; }
 __device__ __forceinline__ float mm_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ void mm_wave_sync() { (void)__shfl_xor(0, 1); }     // every lane of the wave arrives before any goes on
@@ -49,6 +50,10 @@ __device__ __forceinline__ void mm_store4(float* p, float a, float b, float c, f
     __builtin_nontemporal_store(t, reinterpret_cast<mm_f4*>(p));
 }
 __device__ __forceinline__ void mm_store1(float* p, float v) { __builtin_nontemporal_store(v, p); }     // write-once outputs: streaming
+__device__ __forceinline__ float4 mm_load4_stream(const float4* p) {                                   // read-once inputs
+    const mm_f4 v = __builtin_nontemporal_load(reinterpret_cast<const mm_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void mm_put4(mm_half* p, const mm_half (&h)[4]) {                            // one 8-byte LDS store
     mm_h4 v = {h[0], h[1], h[2], h[3]};
     *reinterpret_cast<mm_h4*>(p) = v;

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             const float4* p = reinterpret_cast<const float4*>(xr + c0_n) + tid;
             static_for<kMmQ>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
-                if (q < kMmQ - 1 || tid < kMmLastQ) pre[q] = p[q * kMmThreads];
+                if (q < kMmQ - 1 || tid < kMmLastQ) pre[q] = mm_load4_stream(p + q * kMmThreads);
             });
         } else {
             // a row end, an unaligned row, or the record's continuation.  Clamped addresses and selects instead of branches, so

@@ -80,6 +80,32 @@ def _xf_prepared(grp, device, ws=True):
     return ent
 
 
+_row_stats_memo = {}        # (data_ptr, shape, device) -> (weakref to the tensor, its version, (mean, maxabs))
+
+
+def _row_stats_cached(x):
+    """(mean, max|.|) of the rows of a CUDA tensor, remembered while the SAME tensor (identity and version counter) is asked
+    again: the reference's scripts call compute_cross_correlogram once per template on one block
+    (scripts/main_mfdetect.py:79-80), which would read it twice just for the normalisation."""
+    import weakref
+    nx, ns = x.shape
+    # per stream: statistics formed on one stream are not ordered before a kernel of another
+    key = (x.data_ptr(), nx, ns, str(x.device), int(torch.cuda.current_stream(x.device).cuda_stream))
+    with _cache_lock:
+        ent = _row_stats_memo.get(key)
+        if ent is not None and ent[0]() is x and ent[1] == x._version:
+            return ent[2]
+    with torch.cuda.device(x.device):
+        mean = torch.empty(nx, dtype=torch.float32, device=x.device)
+        mx = torch.empty(nx, dtype=torch.float32, device=x.device)
+        check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))
+    with _cache_lock:
+        if len(_row_stats_memo) > 8:
+            _row_stats_memo.clear()
+        _row_stats_memo[key] = (weakref.ref(x), x._version, (mean, mx))
+    return mean, mx
+
+
 def _xcorr_method(taps_list, ns, method):
     """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores, supports <= 241 samples, the
     default), "fft" (overlap-save, supports <= 161, rows >= 1024 samples) or "direct" (any support).  D4W_XCORR_METHOD
@@ -116,9 +142,7 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
         if normalize and stats is not None:
             mean, mx = stats
         elif normalize:
-            mean = torch.empty(nx, dtype=torch.float32, device=x.device)
-            mx = torch.empty(nx, dtype=torch.float32, device=x.device)
-            check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))
+            mean, mx = _row_stats_cached(x)
         for i in range(0, len(taps_list), 2):                      # two templates per read of x
             grp = taps_list[i:i + 2]
             ys = [torch.empty_like(x) for _ in grp]
@@ -231,11 +255,7 @@ def compute_cross_correlograms(data, templates, exact_tail=None):
     need_tail = [exact_tail if exact_tail is not None else abs(c) * np.sqrt(ns) > TAIL_THRESHOLD for c in coefs]
     stats = None
     if any(need_tail):
-        with torch.cuda.device(xd.device):
-            mean = torch.empty(nx, dtype=torch.float32, device=xd.device)
-            mx = torch.empty(nx, dtype=torch.float32, device=xd.device)
-            check(lib.d4w_row_stats_f32(dev.ptr(xd), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(xd)))
-        stats = (mean, mx)
+        stats = _row_stats_cached(xd)
     outs = _xcorr_device(xd, taps, normalize=True, stats=stats)
     for o, tp, c, need in zip(outs, taps, coefs, need_tail):
         if need and c != 0.0:

@@ -221,6 +221,26 @@ def test_correlogram_matrix_core_form_is_float32_grade(dw):
     assert float((yr[0] - rd[0]).abs().max()) <= 2e-6 * float(rd[0].abs().max())
 
 
+def test_row_statistics_are_remembered_per_tensor_version(dw):
+    """Two correlogram calls on the SAME CUDA block (scripts/main_mfdetect.py:79-80: HF, then LF) form the row statistics once;
+    an in-place edit of the block (version counter) or another tensor at the same address forms them again."""
+    from das4whales_amd import detect as ddet
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    x = torch.randn((50, 6000), device="cuda", generator=gen) + 0.3
+    time = np.arange(6000) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)
+    a = dw.detect.compute_cross_correlogram(x, hf)
+    m1 = ddet._row_stats_cached(x)
+    assert ddet._row_stats_cached(x)[0] is m1[0]                          # remembered
+    x.mul_(2.0).add_(1.0)                                                  # same storage, new version
+    m2 = ddet._row_stats_cached(x)
+    assert m2[0] is not m1[0] and torch.allclose(m2[0], x.mean(dim=1), atol=1e-5)
+    b = dw.detect.compute_cross_correlogram(x, hf)
+    ref = orc.compute_cross_correlogram(x.cpu().numpy().astype(np.float64), hf)
+    assert rel(b.cpu().numpy(), ref) < TOL and not torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------
 # fused ingest (SURVEY 8f row f1)
 # ------------------------------------------------------------------------------------------
