@@ -39,7 +39,10 @@
 
 namespace d4w {
 
-constexpr int kMmCH = 4096;                      // lags per chunk
+#ifndef D4W_MM_CH
+#define D4W_MM_CH 4096
+#endif
+constexpr int kMmCH = D4W_MM_CH;                 // lags per chunk (8192 measured: see DESIGN 3.3)
 constexpr int kMmKS = 6;                         // k-steps of 32 of the two-template kernels -> Toeplitz depth 192, supports <= 177
 constexpr int kMmKSLong = 8;                     // ... of the one-template kernel for longer supports: depth 256, supports <= 241
 constexpr int kMmMaxSupport = 32 * kMmKSLong - 15;
