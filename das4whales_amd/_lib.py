@@ -120,6 +120,9 @@ def _load():
         "d4w_resize_bilinear_aa_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
         "d4w_filter2d_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),
         "d4w_filter2d_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+        "d4w_filter2d_mm_eligible": (c_int, [c_int, c_int]),
+        "d4w_filter2d_mm_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),
+        "d4w_filter2d_mm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly

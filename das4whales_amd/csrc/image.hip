@@ -315,7 +315,9 @@ int d4w_minmax_f32(const float* x, size_t n, float* minmax, void* stream) {
     if (!x || !minmax || n < 1) return fail(D4W_EINVAL, "bad argument");
     unsigned* keys = reinterpret_cast<unsigned*>(minmax);
     D4W_LAUNCH(minmax_init, dim3(1), dim3(1), 0, stream, keys);
-    D4W_LAUNCH(minmax_reduce, dim3(im_grid(n)), dim3(kImThreads), 0, stream, x, n, keys);
+    // >= 4096 values per workgroup: every workgroup ends with two atomics on the same pair of words, and 4096 workgroups of
+    // them took 0.1 ms on a 5-MB image (12 ns per contended atomic) where the read itself takes a few microseconds
+    D4W_LAUNCH(minmax_reduce, dim3((int)std::min<size_t>(std::max<size_t>(n / 4096, 1), 2048)), dim3(kImThreads), 0, stream, x, n, keys);
     D4W_LAUNCH(minmax_decode, dim3(1), dim3(1), 0, stream, keys);
     return D4W_OK;
 }
@@ -355,14 +357,21 @@ int d4w_resize_bilinear_aa_f32(const float* x, int h, int w, float* y, int oh, i
     return D4W_OK;
 }
 
+static size_t f2_direct_ws_bytes(int kh, int kw) { return ((size_t)kw * f2_kp(kh) * sizeof(float) + 255) & ~(size_t)255; }
+
 size_t d4w_filter2d_ws_bytes(int kh, int kw) {
-    return (kh > 0 && kw > 0) ? (size_t)kw * f2_kp(kh) * sizeof(float) : 0;
+    if (kh <= 0 || kw <= 0) return 0;
+    // the padded kernel of the direct form, then (kernels of <= 113 columns) the Toeplitz fragment table of the matrix-core form
+    return f2_direct_ws_bytes(kh, kw) + (d4w_filter2d_mm_eligible(kh, kw) ? d4w_filter2d_mm_ws_bytes(kh, kw) : 0);
 }
 
 int d4w_filter2d_f32(const float* img, int h, int w, const float* kernel, int kh, int kw, float* out, int accumulate,
                      void* ws, void* stream) {
     if (!img || !kernel || !out || !ws || h < 1 || w < 1 || kh < 1 || kw < 1) return fail(D4W_EINVAL, "bad argument");
     if (img == out) return fail(D4W_EINVAL, "filter2d cannot run in place");
+    // kernels of <= 113 columns (the detector's 101 x 101 Gabor pair): row-by-row Toeplitz products on the matrix cores
+    if (d4w_filter2d_mm_eligible(kh, kw))
+        return d4w_filter2d_mm_f32(img, h, w, kernel, kh, kw, out, accumulate, (char*)ws + f2_direct_ws_bytes(kh, kw), stream);
     const size_t patch = (size_t)(kF2TileW + kw - 1) * (kF2TileH - kF2Rows + f2_walk(kh)) * sizeof(float);
     const size_t lds = std::max(patch, (size_t)kF2Split * kF2TileH * kF2TileW * sizeof(float));
     if (lds > 160 * 1024) return fail(D4W_EINVAL, "kernel %d x %d needs %zu bytes of LDS (limit 163840)", kh, kw, lds);

@@ -471,6 +471,15 @@ int d4w_resize_bilinear_aa_f32(const float* x, int h, int w, float* y, int oh, i
 size_t d4w_filter2d_ws_bytes(int kh, int kw);
 int d4w_filter2d_f32(const float* img, int h, int w, const float* kernel, int kh, int kw, float* out,
                      int accumulate, void* ws, void* stream);
+/* The same correlation on the matrix cores for kernels of <= 113 columns (the detector's 101 x 101 Gabor kernels): kernel row
+ * by kernel row a banded-Toeplitz product, out[y][16 a + i] += sum_u K[j][u - i] P[y + j][16 a + u], operands as binary16
+ * hi / lo pairs with float32 accumulation (das4whales_amd/csrc/filter2d_mm.hip).  d4w_filter2d_f32 takes this route by itself
+ * when d4w_filter2d_mm_eligible(kh, kw) = 1 (D4W_F2D_MM=0 switches it off); ws of the stand-alone entry point: DEVICE scratch of
+ * d4w_filter2d_mm_ws_bytes(kh, kw) bytes. */
+int d4w_filter2d_mm_eligible(int kh, int kw);
+size_t d4w_filter2d_mm_ws_bytes(int kh, int kw);
+int d4w_filter2d_mm_f32(const float* img, int h, int w, const float* kernel, int kh, int kw, float* out,
+                        int accumulate, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

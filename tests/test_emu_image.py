@@ -54,8 +54,11 @@ def test_resize_bilinear_aa(emu, h, w, oh, ow):
     assert rel(y, orc.resize_bilinear_aa(x.astype(np.float64), oh, ow)) < TOL
 
 
-@pytest.mark.parametrize("h,w,kh,kw", [(24, 160, 101, 101), (70, 130, 5, 9), (3, 4, 7, 7), (33, 65, 1, 1), (40, 70, 4, 6)])
+@pytest.mark.parametrize("h,w,kh,kw", [(24, 160, 101, 101), (70, 130, 5, 9), (3, 4, 7, 7), (33, 65, 1, 1), (40, 70, 4, 6), (9, 600, 3, 113),
+                                       (21, 300, 5, 115), (6, 2100, 2, 33)])
 def test_filter2d(emu, h, w, kh, kw):
+    """Kernels of <= 113 columns run on the matrix cores (filter2d_mm.hip: one wave per 256 columns, 4 output rows per
+    workgroup, ragged tiles, more than 8 tiles per row -> several workgroups per row block), wider ones the direct form."""
     rng = np.random.default_rng(kh * 100 + kw)
     img = f32(rng.standard_normal((h, w)))
     ker = f32(rng.standard_normal((kh, kw)))
