@@ -998,6 +998,185 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
     }
 }
 
+// Rows too long for LDS, after the summary sweep: the maxima that can reach the threshold at all (v - thr not below the
+// row minimum) are looked for in a second sweep that passes the row through LDS in windows of kFpSegW samples (a core of
+// kFpSegS plus kFpSegH either side, in the space the candidate list occupies later; the next windows are already in
+// registers while this one is worked on).  A window with a handful of such maxima (an envelope with thr a fraction of its
+// strongest peak) just marks them in T.cand for the summary walks of fp_scan.  A window full of them (a raw correlogram
+// has a maximum every ~9 samples, 14 000 per 120 000-sample row, and its minimum is as deep as its maximum is high) is
+// settled on the spot: the window is COMPACTED to its turning points E (samples not below both or not above both
+// neighbours -- the minimum of any stretch and the first sample above any level survive the compaction, so a walk over E
+// decides exactly what a walk over the samples decides), the maxima of the core are listed, and lane t takes side t & 1 of
+// maximum t >> 1 and walks E: two entries per oscillation instead of its ~9 samples, both sides of a maximum at once, one
+// maximum per lane, LDS reads only; almost all are settled within two or three periods.  Accepted peaks go to T.bits
+// directly; a maximum whose walk leaves the window or runs past kFpSegSteps entries, a plateau, and every maximum of a
+// window with more turning points than the lists hold is marked in T.cand.  Samples outside the row read as +inf: a walk
+// stops there, as at the row end.
+constexpr int kFpSegH = 64;
+constexpr int kFpSegW = 2048;
+constexpr int kFpSegS = kFpSegW - 2 * kFpSegH;          // 1920 samples
+constexpr int kFpSegE = 1024;                           // turning points held per window
+constexpr int kFpSegC = 512;                            // maxima held per window
+constexpr int kFpSegSteps = 8;                          // entries of E a side may walk
+constexpr int kFpSegFew = 24;                           // lanes with a maximum up to which a window is not worth compacting
+constexpr int kFpSegMax = (kFpMaxBlocks * 32 + kFpSegS - 1) / kFpSegS;   // windows of the longest row with 32-sample blocks
+static_assert(kFpSegS % 32 == 0, "a window core is whole summary blocks");
+static_assert(kFpSegW == 4 * kFpThreads && kFpSegH % 4 == 0, "window geometry: one 16-byte load per lane");
+
+// one side of maximum v over the turning points: 2 = the running minimum reached lim before a higher entry, 1 = a higher
+// entry (or the row end) came first, 0 = not decided inside the window
+template <int DIR>
+__device__ __forceinline__ int fp_turning_side(const float* __restrict__ E, int nE, int idx, float v, float lim) {
+    float lmin = INFINITY;
+    for (int done = 0; done < kFpSegSteps; done += 4) {
+        float e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = E[min(max(idx + DIR * k, 0), nE - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = idx + DIR * k;
+            if (j < 0 || j >= nE) return 0;
+            if (e[k] > v) return 1;
+            lmin = fminf(lmin, e[k]);
+            if (lmin <= lim) return 2;
+        }
+        idx += DIR * 4;
+    }
+    return 0;
+}
+
+// Returns the row position from which the maxima have NOT been looked at: the first two windows with something in them
+// decide for the row -- when both hold only a handful of maxima the rest is left to the barrier-free marking sweep of fp_scan.
+__device__ __forceinline__ int fp_sweep_segments(const float* __restrict__ rg, const FpLds& T, int ns, int nb, double thr,
+                                                 float gmin, int* wave_tot, unsigned char* hot, int tid) {
+    float* seg = reinterpret_cast<float*>(T.clist);
+    float4* l4 = reinterpret_cast<float4*>(T.clist);
+    float* E = seg + kFpSegW;                                              // [kFpSegE]
+    unsigned* C = reinterpret_cast<unsigned*>(E + kFpSegE);               // [kFpSegC]  window position | plateau << 15 | index in E << 16
+    unsigned char* res = reinterpret_cast<unsigned char*>(C + kFpSegC);   // [2 kFpSegC]
+    int* seg_tot = reinterpret_cast<int*>(res + 2 * kFpSegC);             // [kFpThreads / 64]
+    const float4* g4 = reinterpret_cast<const float4*>(rg);
+    const int ns4 = ns >> 2, lane = tid & 63, wave = tid >> 6;
+    const int nseg = (ns + kFpSegS - 1) / kFpSegS;
+    const float4 inf4 = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    // windows whose core holds no sample that could reach the threshold are neither loaded nor looked at
+    for (int k = tid; k < kFpSegMax; k += kFpThreads) hot[k] = 0;
+    __syncthreads();
+    for (int bk = tid; bk < nb; bk += kFpThreads)
+        if (!((double)T.s1[bk].x - thr < (double)gmin)) hot[bk / (kFpSegS / 32)] = 1;
+    __syncthreads();
+    auto fetch = [&](int s) -> float4 {
+        const int v4 = (s * kFpSegS - kFpSegH) / 4 + tid;
+        return (s < nseg && hot[s] && v4 >= 0 && v4 < ns4) ? g4[v4] : inf4;
+    };
+    float4 r0 = fetch(0), r1 = fetch(1), r2 = fetch(2);        // three windows in flight per lane
+    int few = 0, full = 0, resume = ns;
+    for (int s = 0; s < nseg; ++s) {
+        const int w0 = s * kFpSegS - kFpSegH;                  // row position of the window's first sample
+        const float4 cur = r0;
+        r0 = r1;
+        r1 = r2;
+        r2 = fetch(s + 3);
+        if (!hot[s]) continue;
+        const int c = 4 * tid, i0 = w0 + c;
+        const bool core = tid >= kFpSegH / 4 && tid < (kFpSegH + kFpSegS) / 4;
+        l4[tid] = cur;
+        __syncthreads();
+        // maxima worth a walk among the lane's four samples
+        const float u[6] = {c ? seg[c - 1] : INFINITY, cur.x, cur.y, cur.z, cur.w, (c + 4 < kFpSegW) ? seg[c + 4] : INFINITY};
+        unsigned m = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            const float v = u[k + 1];
+            if (core && i >= 1 && i < ns - 1 && u[k] < v && !(u[k + 2] > v) && !((double)v - thr < (double)gmin)) m |= 1u << k;
+        }
+        const unsigned long long busy = __ballot(m != 0u);
+        if (lane == 0) wave_tot[wave] = __popcll(busy);
+        __syncthreads();
+        int nbusy = 0;
+        for (int k = 0; k < kFpThreads / 64; ++k) nbusy += wave_tot[k];
+        if (nbusy <= kFpSegFew) {                                // (uniform) nothing to gain from the lists
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((m >> k) & 1u) atomicOr(&T.cand[(i0 + k) >> 5], 1u << ((i0 + k) & 31));
+            if (++few == 2 && !full) {
+                resume = (s + 1) * kFpSegS;
+                break;
+            }
+            continue;                                            // (the window and wave_tot are next written behind a barrier each)
+        }
+        ++full;
+        unsigned em = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            const float v = u[k + 1];
+            const bool hi = v >= u[k] && v >= u[k + 2], lo = v <= u[k] && v <= u[k + 2];
+            if (hi || lo || i == 0 || i == ns - 1) em |= 1u << k;
+        }
+        const int mine = __popc(em) | (__popc(m) << 16);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int n = __shfl_up(incl, off);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) seg_tot[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < kFpThreads / 64; ++k) {
+            if (k < wave) before += seg_tot[k];
+            total += seg_tot[k];
+        }
+        const int nE = total & 0xFFFF, nC = total >> 16;
+        const bool listed = nE <= kFpSegE && nC <= kFpSegC;
+        if (listed) {
+            int pe = (before + incl - mine) & 0xFFFF, pc = (before + incl - mine) >> 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((em >> k) & 1u) {
+                    if ((m >> k) & 1u) C[pc++] = (unsigned)(c + k) | ((unsigned)pe << 16) | ((u[k + 2] == u[k + 1]) ? 0x8000u : 0u);
+                    E[pe++] = u[k + 1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((m >> k) & 1u) atomicOr(&T.cand[(i0 + k) >> 5], 1u << ((i0 + k) & 31));
+        }
+        __syncthreads();
+        if (listed) {
+            for (int t = tid; t < 2 * nC; t += kFpThreads) {
+                const unsigned cd = C[t >> 1];
+                const int e = (int)(cd >> 16);
+                int r = 0;
+                if (!(cd & 0x8000u)) {                               // plateaus are left to fp_scan
+                    const float v = E[e];
+                    const double dl = (double)v - thr;               // as in fp_scan: lim = the largest float u with v - u >= thr
+                    float lim = (float)dl;
+                    if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
+                    r = (t & 1) ? fp_turning_side<+1>(E, nE, e + 1, v, lim) : fp_turning_side<-1>(E, nE, e - 1, v, lim);
+                }
+                res[t] = (unsigned char)r;
+            }
+        }
+        __syncthreads();
+        if (listed) {
+            for (int q = tid; q < nC; q += kFpThreads) {
+                const int a = res[2 * q], b = res[2 * q + 1];
+                if (a == 1 || b == 1) continue;                      // a higher sample before a deep enough base: not prominent
+                const int i = w0 + (int)(C[q] & 0x7FFFu);
+                if (a == 2 && b == 2) atomicOr(&T.bits[i >> 5], 1u << (i & 31));
+                else atomicOr(&T.cand[i >> 5], 1u << (i & 31));
+            }
+        }
+        // no barrier here: the window, the counts and the lists are each next written behind a later barrier than their last read
+    }
+    __syncthreads();
+    return min(resume, ns);
+}
+
 // candidates -> accepted-peak bitmap, in two phases so that the prominence walks run with every lane busy:
 //   (1) every thread marks the rising edges of maxima that can reach the threshold at all in the `cand` bitmap -- no
 //       base can lie below the row minimum, so a maximum with v - thr below it is rejected here, without a walk (with
@@ -1007,21 +1186,27 @@ __device__ __forceinline__ void fp_stage_rows4(const float* __restrict__ rg, con
 //       walking, 63 masked): 0.72 of 0.97 ms at 11020 x 12000 with ~15 picks per row.
 // r: the row (LDS or global).  Ends with the accepted peaks in T.bits; the last barrier is the caller's.
 constexpr int kFpList = 4096;          // candidates per walk round
+static_assert(kFpSegW + kFpSegE + kFpSegC + kFpSegC / 2 + kFpThreads / 64 <= kFpList, "the window and its lists live in the candidate list");
 
 __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds& T, int ns, int nb, int nb2, int bshift,
-                                        double thr, int nwords, int* wave_tot, unsigned* cfail, bool vec4, int tid) {
+                                        double thr, int nwords, int* wave_tot, unsigned* cfail, bool vec4, int mark_from,
+                                        int tid) {
+    // mark_from: first sample whose maxima are still to be marked (0: the whole row; > 0: fp_sweep_segments has dealt with
+    // the samples before it -- a multiple of 4 -- and left in T.cand only the maxima it could not settle inside their window)
     const int lane = tid & 63, wave = tid >> 6;
     float gmin = INFINITY;
     for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
-    for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
-    __syncthreads();
+    if (mark_from == 0) {
+        for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
+        __syncthreads();
+    }
     if (vec4) {
         // four samples per lane: one 16-byte read and the two neighbours instead of three reads per sample; four such
         // groups in flight per lane (rows too long for LDS are read from global memory here)
         const float4* r4 = reinterpret_cast<const float4*>(r);
         constexpr int kAhead = 4;
         const int ns4 = ns >> 2;
-        for (int g0 = tid; g0 < ns4; g0 += kAhead * kFpThreads) {
+        for (int g0 = tid + (mark_from >> 2); g0 < ns4; g0 += kAhead * kFpThreads) {
             float4 q[kAhead];
             float lo[kAhead], hi[kAhead];
 #pragma unroll
@@ -1048,7 +1233,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             }
         }
     } else {
-        for (int i = 1 + tid; i < ns - 1; i += kFpThreads) {
+        for (int i = max(1, mark_from) + tid; i < ns - 1; i += kFpThreads) {
             const float v = r[i];
             if (r[i - 1] < v && !(r[i + 1] > v) && !((double)v - thr < (double)gmin)) atomicOr(&T.cand[i >> 5], 1u << (i & 31));
         }
@@ -1067,7 +1252,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             const float v = r[i];
             int ia = i + 1;
             while (ia < ns - 1 && r[ia] == v) ++ia;                  // plateau: reported at its middle sample
-            bool ok = r[ia] < v;
+            bool ok = r[ia] < v && !((double)v - thr < (double)gmin);     // (the second test: maxima fp_sweep_segments passed on)
             if (ok) {
                 // float64 like scipy (float32 samples are exact in float64, a float32 subtraction is not):
                 // lim = the largest float u with (double)v - (double)u >= thr
@@ -1200,6 +1385,7 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     D4W_DYN_LDS(smem_raw);
     __shared__ int wave_tot[kFpThreads / 64 + 1];              // + the candidate counter of fp_scan
     __shared__ unsigned cfail[kFpList / 32];
+    __shared__ unsigned char hot[kFpSegMax];                   // fp_sweep_segments: windows worth loading
     const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
     const int nwords = (ns + 31) >> 5;
     const FpLds T = fp_lds(smem_raw, nb, nb2, nwords);
@@ -1208,6 +1394,7 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     for (int w = tid; w < nwords; w += kFpThreads) T.bits[w] = 0u;
     const bool al16 = (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
     const bool vec4 = bshift == 5 && al16;
+    const bool sweep = !STAGED && vec4;
     if (vec4) {
         fp_stage_rows4<STAGED>(rg, T, ns, nb, tid);
     } else {
@@ -1219,8 +1406,17 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     }
     __syncthreads();
     fp_summaries2(T, nb, nb2, tid);
+    if (sweep)
+        for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
     __syncthreads();
-    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, cfail, STAGED ? (ns & 3) == 0 : al16, tid);
+    int mark_from = 0;
+    if (sweep) {
+        float gmin = INFINITY;
+        for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
+        mark_from = fp_sweep_segments(rg, T, ns, nb, thr, gmin, wave_tot, hot, tid);
+    }
+    fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, cfail, STAGED ? (ns & 3) == 0 : al16,
+            mark_from, tid);
     __syncthreads();
     fp_emit(T, nwords, idx + (size_t)blockIdx.x * cap, counts + blockIdx.x, cap, wave_tot, tid);
 }

@@ -340,11 +340,20 @@ class PickRows(collections.abc.Sequence):
         return self.packed.cpu().numpy()
 
 
+_PICK_CAP = {}                       # (nx, ns) -> index slots per row worth allocating up front
+_PICK_CAP_BYTES = 8 << 30            # ... while the index table stays below this
+
+
 def _find_peaks_device(c, threshold, cap0=1024):
     """c: float32 CUDA [nx, ns] -> PickRows.  One host synchronisation per call (total and largest per-row count);
     the ragged result is compacted on the device."""
     nx, ns = c.shape
-    cap = max(1, min(ns // 2 + 1, int(cap0)))
+    # the widest row of the last call on this shape is the first guess of the next one: a stream of blocks with dense picks
+    # (raw correlograms: thousands per row) would otherwise run the picker twice per block
+    hint = _PICK_CAP.get((nx, ns), 0)
+    if nx * hint * 4 > _PICK_CAP_BYTES:
+        hint = 0
+    cap = max(1, min(ns // 2 + 1, max(int(cap0), hint)))
     with torch.cuda.device(c.device):
         while True:
             idx = torch.empty((nx, cap), dtype=torch.int32, device=c.device)
@@ -353,6 +362,7 @@ def _find_peaks_device(c, threshold, cap0=1024):
                                          dev.stream_ptr(c)))
             off = torch.cumsum(cnt, 0, dtype=torch.int64)
             need, total = (int(v) for v in torch.stack((cnt.max().to(torch.int64), off[-1])).cpu())
+            _PICK_CAP[(nx, ns)] = need + need // 4 + 16 if need > cap0 else 0
             if need <= cap:
                 break
             cap = min(ns // 2 + 1, max(need, 2 * cap))          # rare: a row with more peaks than the first guess

@@ -223,6 +223,20 @@ inline T wave_exchange(T v, int src_lane_rel /* lane within wave to read from */
     (void)me;
     return out;
 }
+// predicate of every lane of the wave as a 64-bit mask (all lanes of the wave must be alive and call it)
+inline unsigned long long wave_ballot(int pred) {
+    int wave = g_lin_tid / 64;
+    int base = wave * 64;
+    unsigned gen = g_shfl_gen[wave] & 1u;
+    g_exch[gen][g_lin_tid] = pred ? 1u : 0u;
+    yield(WAIT_WAVE);
+    if ((g_shfl_gen[wave] & 1u) == gen) g_shfl_gen[wave]++;
+    unsigned nthreads = g_blockDim.x * g_blockDim.y * g_blockDim.z;
+    unsigned long long out = 0ull;
+    for (int l = 0; l < 64; ++l)
+        if ((unsigned)(base + l) < nthreads && g_exch[gen][base + l]) out |= 1ull << l;
+    return out;
+}
 }  // namespace hipemu
 
 #define threadIdx hipemu::g_threadIdx
@@ -259,6 +273,8 @@ template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline unsigned long long __ballot(int pred) { return hipemu::wave_ballot(pred); }
 
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

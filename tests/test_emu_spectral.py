@@ -379,6 +379,40 @@ def test_pack_picks_table(emu):
     assert total == want.shape[1] and np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("ns", [16388, 20000, 1920 * 9, 1920 * 9 + 4, 40004])
+def test_find_peaks_long_rows_window_sweep(emu, ns):
+    """Rows beyond the LDS staging limit pass through LDS in windows of 1920 + 2 x 64 samples and settle their maxima
+    there (fp_sweep_segments): oscillating rows (a maximum every ~9 samples, the raw correlograms of detect.pick_times,
+    detect.py:249-274), plateaus lying across window edges and at the row ends, maxima whose walks leave the window,
+    a row of white noise, lengths that end on / just after a window edge -- vs SciPy."""
+    rng = np.random.default_rng(ns)
+    t = np.arange(ns)
+    osc = np.sin(2 * np.pi * t * 23.0 / 200.0) * np.abs(sps.hilbert(rng.standard_normal(ns))) * 0.3
+    plat = (np.sin(t * 0.11) * (1.0 + 0.5 * np.sin(t * 0.0031))).astype(np.float32)
+    plat = np.round(plat * 4.0) / 4.0                                    # quantised: plateaus everywhere
+    for e in (1920, 2 * 1920, 3 * 1920 - 64, 4 * 1920 + 64, 7 * 1920 + 1):             # plateaus across the core / halo edges
+        plat[e - 3:e + 3] = 3.0
+        plat[e - 70:e - 60] = 2.5
+    plat[:5] = 9.0                                                       # plateaus touching the row ends are no peaks
+    plat[-5:] = 9.0
+    slow = np.sin(t * 0.0009) + 0.2 * np.sin(t * 0.7)                    # walks of thousands of samples
+    env = np.abs(sps.hilbert(np.convolve(rng.standard_normal(ns), np.hanning(24), "same")))    # a handful of maxima per window
+    half = ns // 2
+    x = np.ascontiguousarray(np.stack([osc, plat, slow, rng.standard_normal(ns), env,
+                                       np.concatenate([env[:half] * 0.2, osc[half:] + 0.5]),  # quiet first: left to the marking sweep
+                                       np.concatenate([osc[:half] + 0.5, env[half:] * 0.2])]), dtype=np.float32)
+    nx = x.shape[0]
+    for thr in (0.0, 0.2, 0.45 * float(x[0].max()), 0.45 * float(env.max()), 1.5, 1e30):
+        cap = ns // 2 + 1
+        idx = np.empty((nx, cap), dtype=np.int32)
+        cnt = np.empty(nx, dtype=np.int32)
+        ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
+        for c in range(nx):
+            ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+            assert cnt[c] == len(ref), (thr, c, cnt[c], len(ref))
+            assert np.array_equal(idx[c, :cnt[c]], ref)
+
+
 @pytest.mark.parametrize("ns", [12000, 16384, 10001])
 def test_find_peaks_more_candidates_than_one_list(emu, ns):
     """Rows with more maxima than the 4096-entry candidate list (white noise has ~ns/3): thr = 0 sends the scan through

@@ -168,6 +168,37 @@ def test_picks_random_rows_vs_scipy(dw):
             assert np.array_equal(got[c], ref), (thr, c)
 
 
+def test_picks_long_rows_window_sweep_vs_scipy(dw):
+    """Rows beyond the LDS staging limit (detect.pick_times on raw 120 000-sample correlograms, detect.py:249-274): the
+    windowed sweep over turning points (spectral.hip fp_sweep_segments) -- raw correlograms of noise (a maximum every ~9
+    samples), their envelopes (a handful per window: the row falls back to the marking sweep), rows that change character
+    half way, quantised rows (plateaus) -- every row against SciPy, with enough rows to have several workgroups per CU."""
+    import scipy.signal as sps
+    nx, ns = 640, 120000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((nx, ns), device="cuda", generator=g)
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    c = dw.detect.compute_cross_correlogram(x, hf)
+    env = dw.dsp._analytic(c, 0)
+    half = ns // 2
+    c[1] = torch.round(c[1] * 8) / 8
+    c[2, :half] = env[2, :half] * 0.2
+    c[3, half:] = env[3, half:] * 0.2
+    c[4] = env[4]
+    c[5, 100:200] = 0.0
+    cpu = c.cpu().numpy()
+    rows = list(range(8)) + list(range(8, nx, 79))
+    for frac in (0.45, 0.15, 0.9):
+        thr = frac * float(c[6].max())
+        got = dw.detect.pick_times(c, thr)
+        for ch in rows:
+            ref = sps.find_peaks(cpu[ch].astype(np.float64), prominence=thr)[0]
+            assert np.array_equal(got[ch], ref), (frac, ch, len(got[ch]), len(ref))
+    got = dw.detect.pick_times(c, 1e30)
+    assert got.total == 0
+
+
 def test_pick_pipeline_config1(dw):
     """f-k -> matched filter -> envelope picks on a 1000 x 12000 synthetic block: same picks as the
     float64 oracle pipeline except at prominences within 1e-4 of the threshold."""
