@@ -228,7 +228,7 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         if "mf" in stages:
             ddet._xcorr_device(y, tpl, normalize=True, stats=st)
         ev[2].record()
-        if args.gather:
+        if args.gather or world > 1:                     # timed beside the step when it is not part of it
             shard.all_gather_rows(y, nx)
         ev[3].record()
         ev[3].synchronize()
@@ -266,7 +266,13 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
             stage_ms["fk:" + l1] = stage_ms.get("fk:" + l1, 0.0) + e0.elapsed_time(e1) / 3
     plan.marks = None
     rep_ms = None
-    plan_info = {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "packed": bool(plan.packed), "exchange_row_chunks": plan.exchange_chunks() if plan.packed else None}
+    plan_info = {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "sub_rows_per_rank": plan.sub_rows_per_rank(),
+                 "channel_phase_balance": round(plan.channel_phase_balance(), 4), "packed": bool(plan.packed),
+                 "exchange_row_chunks": plan.exchange_chunks() if plan.packed else None}
+    gather_info = {"in_timed_step": "t-x matrix (all_gather_rows)" if args.gather else "none: outputs stay sharded",
+                   "all_gather_tx_ms": stage_ms.get("all_gather"), "tx_bytes_into_every_gpu": 4.0 * nx * ns * (world - 1) / world,
+                   "picks_env_local_ms": stage_ms.get("picks_env_local"), "all_gather_picks_ms": stage_ms.get("all_gather_picks"),
+                   "picks_gathered": stage_ms.get("picks_gathered")}
     kernels = "shape-specialised" if plan.packed else "generic"
     if (world > 1 or args.force_replicas) and stages == ["fk", "mf"] and not args.no_replicas:
         del x_loc, plan
@@ -287,7 +293,8 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
                           "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
                "roofline": {"bound": "hbm", "kernel": "distributed step (%s pass kernels + exchange)" % kernels,
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": None, "stage_ms_rank0": stage_ms}}
+                            "traffic": None, "stage_ms_rank0": stage_ms},
+               "gather": gather_info}
         if rep_ms is not None:
             out["replicas"] = {"note": "second line: one independent block per GPU, no collective in the data path (weak scaling)",
                                "ms_per_step": rep_ms, "value": samples * world / (rep_ms * 1e-3), "unit": "channel-samples/s",
@@ -523,19 +530,26 @@ def bench_gloo_emulated(args, stages, world, rank):
     x_loc = x[a:b].contiguous()
 
     def step():
-        y = plan.apply(x_loc)
-        return shard.all_gather_rows(y, nx) if args.gather is not False else y
+        return plan.apply(x_loc)
     for _ in range(args.warmup):
         step()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        y_all = step()
+        y = step()
     dist.barrier()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ranks = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(ranks)
+    # the two ways of collecting the result, timed beside the step as in the GPU line: the filtered t-x matrix, or picks
+    # (here: the samples above 3 sigma of the local rows, as a packed 2 x K (local row, time index) table)
+    t1 = time.perf_counter()
+    y_all = shard.all_gather_rows(y, nx)
+    t2 = time.perf_counter()
+    hit = torch.nonzero(y > 3.0 * y.std()).t().contiguous()
+    tab = shard.all_gather_picks(hit, a)
+    t3 = time.perf_counter()
     err = None
     if rank == 0 and nx * ns <= 1 << 20:
         from oracle import d4w_oracle as orc
@@ -549,7 +563,11 @@ def bench_gloo_emulated(args, stages, world, rank):
                           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic (emulated, CPU)",
                           "config": {"workload": "ONE %d x %d block sharded by channel block over %d CPU rank(s), gloo, emulator "
                                                  "kernels -- launch-path test, not a measurement" % (nx, ns, world),
-                                     "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world},
+                                     "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world,
+                                     "plan": {"N1": plan.N1, "N2": plan.N2, "sub_rows_per_rank": plan.sub_rows_per_rank(),
+                                              "channel_phase_balance": round(plan.channel_phase_balance(), 4)}},
+                          "gather": {"in_timed_step": "none: outputs stay sharded", "all_gather_tx_ms": (t2 - t1) * 1e3,
+                                     "all_gather_picks_ms": (t3 - t2) * 1e3, "picks_gathered": int(tab.shape[1])},
                           "rel_err_vs_oracle": err}), flush=True)
     dist.destroy_process_group()
 
@@ -585,7 +603,9 @@ def main():
                          "BASELINE configs[3], strong scaling, the default for N > 1; 'replicas' = one independent block "
                          "per GPU (no collective, weak scaling); auto = single-device step at N = 1, 'channel' otherwise")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
-                    help="--shard channel: all-gather the filtered t-x matrix each step (default when N > 1)")
+                    help="--shard channel: all-gather the filtered t-x matrix inside every timed step (default: the filtered rows and "
+                         "their correlograms stay with their rank; the t-x all-gather and the gather of the picks are timed "
+                         "separately and reported under roofline.stage_ms_rank0 / gather)")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the second (replicas, weak-scaling) measurement")
     ap.add_argument("--force-replicas", action="store_true", help="run the second measurement at N = 1 as well (exercises the N > 1 code path)")
@@ -614,7 +634,7 @@ def main():
     if args.shard == "auto":
         args.shard = "channel" if world > 1 else "replicas"
     if args.gather is None:
-        args.gather = world > 1
+        args.gather = False          # outputs stay sharded, as they stay on the device at N = 1; both gathers are timed beside the step
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

@@ -127,6 +127,15 @@ class ShardedFkPlan:
         self.blocks = [channel_block(self.nx, self.world, r) for r in range(self.world)]
         assert self.blocks[self.rank] == (self.row_begin, self.row_end)
 
+    def sub_rows_per_rank(self):
+        """Time-axis sub-rows (of N1) each rank transforms in the channel phase."""
+        return [int(q.numel()) for q in self.qidx]
+
+    def channel_phase_balance(self):
+        """Mean over busiest rank of the channel-phase work: N1 / (world * max sub-rows of a rank).  A sub-row and its
+        Hermitian partner stay together, so 25 sub-rows over 8 ranks cannot do better than 4 on the busiest (0.78)."""
+        return self.N1 / float(self.world * max(1, max(self.sub_rows_per_rank())))
+
     def _specialise(self, nx, ns):
         """The ranks must agree on the plan type -- the packed plan (shape-specialised kernels) and the generic plan exchange
         different layouts -- whatever their environments and kernel caches say.  A new large shape first gets its kernels as

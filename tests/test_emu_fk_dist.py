@@ -242,3 +242,28 @@ def test_dist_design_straight_into_the_plans(emu, world):
     y_dense = fk_sharded_emu(emu, x, dense, world)
     assert np.array_equal(y_design, y_dense)
     assert rel(y_design, orc.fk_filter_filt(x, dense.astype(np.float64))) < TOL
+
+
+def test_dist_plan_geometry_of_the_bench_block_over_8_ranks(emu):
+    """BASELINE configs[3] on 8 ranks (20 000 x 120 000, N1 = 25 sub-rows of 2400): every rank derives the same owner map,
+    a sub-row and its Hermitian partner (q1, N1 - q1) live on one rank, every sub-row has exactly one owner, the channel
+    blocks tile the channels, and the busiest rank holds 4 of the 25 sub-rows -- the 0.78 balance of the channel phase
+    DESIGN.md section 6 quotes (13 Hermitian classes cannot be dealt more evenly over 8 ranks)."""
+    nx, ns, world = 20000, 120000, 8
+    ranks = [Rank(emu, nx, ns, world, r) for r in range(world)]
+    try:
+        N1, owner = ranks[0].N1, ranks[0].owner
+        assert N1 * ranks[0].N2 == ns // 2
+        assert all(rk.N1 == N1 and np.array_equal(rk.owner, owner) for rk in ranks)
+        assert ranks[0].a == 0 and ranks[-1].b == nx and all(ranks[i].b == ranks[i + 1].a for i in range(world - 1))
+        assert all(rk.b - rk.a == nx // world for rk in ranks)
+        for q in range(1, N1):
+            assert owner[q] == owner[N1 - q], q
+        per = [int(np.sum(owner == r)) for r in range(world)]
+        assert per == [rk.nq for rk in ranks] and sum(per) == N1
+        classes = N1 // 2 + 1
+        assert max(per) == 2 * -(-classes // world) or max(per) == 2 * -(-classes // world) - 1
+        assert max(per) == 4 and min(per) >= 2                       # 25 / (8 x 4) = 0.78
+    finally:
+        for rk in ranks:
+            rk.close()
