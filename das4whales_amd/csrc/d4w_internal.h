@@ -41,11 +41,15 @@ inline int fail(int code, const char* fmt, ...) {
         D4W_HIP(hipGetLastError());                                                            \
     } while (0)
 
-// dynamic LDS declaration usable by both hipcc and the emulator
+// dynamic LDS declaration usable by both hipcc and the emulator.  (The switches between the gfx950 build and the CPU test
+// build of the same sources -- tests/emu, -DD4W_EMU -- live in this header and in mm_common.h only; the kernels and their
+// launch code are the same text in both, the test build supplying the HIP runtime calls and builtins they use.)
 #ifdef D4W_EMU
 #define D4W_DYN_LDS(name) unsigned char* name = hipemu::dyn_smem
+#define D4W_BUILD_TAG "d4w 0.1 emu"
 #else
 #define D4W_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define D4W_BUILD_TAG "d4w 0.1 gfx950"
 #endif
 
 // ---------------------------------------------------------------------------------------------

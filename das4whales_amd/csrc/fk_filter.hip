@@ -886,11 +886,7 @@ extern "C" {
 const char* d4w_last_error(void) { return d4w::g_err; }
 
 const char* d4w_version(void) {
-#ifdef D4W_EMU
-    return "d4w 0.1 emu";
-#else
-    return "d4w 0.1 gfx950";
-#endif
+    return D4W_BUILD_TAG;
 }
 
 /* 1 when the shape runs shape-specialised kernels (built in or registered), 0 when it runs the generic passes */
@@ -1299,7 +1295,6 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
         pl->wgBi = pl->wgBf = pl->wgB;
         pl->slab_sw = env_int("D4W_FK_SLAB", 0);
     }
-#ifndef D4W_EMU
     {
         int devid = 0;
         hipDeviceProp_t prop;
@@ -1364,9 +1359,6 @@ static int fk_plan_build(int nx, int ns, const int* opts, bool alloc_mask, bool 
             (void)hipFuncSetAttribute((const void*)fk_passCm_bluestein, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         }
     }
-#else
-    pl->num_cu = 3;
-#endif
     *out = pl;
     return D4W_OK;
 }
@@ -1385,24 +1377,16 @@ static int fk_mask_finish(d4w_fk_plan* pl, double prune_eps, void* stream);
 
 // device-side order of the operations on one plan (see d4w_fk_plan::apply_mu); the caller holds pl->apply_mu
 static int fk_plan_enter(d4w_fk_plan* pl, void* stream) {
-#ifndef D4W_EMU
     hipStream_t st = (hipStream_t)stream;
     if (pl->apply_used && pl->apply_stream != st) D4W_HIP(hipStreamWaitEvent(st, pl->apply_done, 0));
-#else
-    (void)pl; (void)stream;
-#endif
     return D4W_OK;
 }
 static int fk_plan_leave(d4w_fk_plan* pl, void* stream) {
-#ifndef D4W_EMU
     hipStream_t st = (hipStream_t)stream;
     if (!pl->apply_done) D4W_HIP(hipEventCreateWithFlags(&pl->apply_done, hipEventDisableTiming));
     D4W_HIP(hipEventRecord(pl->apply_done, st));
     pl->apply_stream = st;
     pl->apply_used = true;
-#else
-    (void)pl; (void)stream;
-#endif
     return D4W_OK;
 }
 
@@ -1433,10 +1417,8 @@ static int fk_set_mask_run(d4w_fk_plan* pl, const float* mask_shifted, double pr
     if (pl->fold_IB > 0 && !(gather && atoi(gather) > 0)) {
         const int N2r = d.N2 / pl->fold_R0;
         const size_t lds = (size_t)d.N1 * pl->fold_R0 * (pl->fold_IB + 1) * sizeof(float);
-#ifndef D4W_EMU
         static std::once_flag once;
         std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)fk_fold_mask_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); });
-#endif
         if (d.nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", d.nx);
         D4W_LAUNCH(fk_fold_mask_tiled, dim3(ceil_div(N2r, pl->fold_IB), d.nx), dim3(kFoldThreads), lds, stream, d, pl->fold_R0,
                    pl->fold_IB, mask_shifted, (const int*)pl->d_rowk, (const int*)pl->d_q1_of_k1, (const int*)pl->d_k2,
@@ -2913,7 +2895,6 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     }
     S.mask = pl->d_mask; S.nyq = pl->d_nyq;
 #undef D4W_TRY
-#ifndef D4W_EMU
     {
         int devid = 0;
         hipDeviceProp_t prop;
@@ -2936,9 +2917,6 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
         for (const void* f : fns)
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
-#else
-    pl->num_cu = 3;
-#endif
     *out = pl;
     return D4W_OK;
 }

@@ -258,11 +258,7 @@ __global__ __launch_bounds__(kF2Threads) void filter2d_tile(const float* __restr
         tile[e] = (ty < ph) ? img[(size_t)reflect101(y0 + ty, h) * w + reflect101(x0 + tx, w)] : 0.f;
     }
     __syncthreads();
-#ifdef D4W_EMU
-    const int tx = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#else
     const int tx = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: taps via SMEM
-#endif
     const int ty = (wid & 3) * kF2Rows, split = wid >> 2;
     float acc[kF2Rows];
 #pragma unroll
@@ -378,12 +374,10 @@ int d4w_filter2d_f32(const float* img, int h, int w, const float* kernel, int kh
     float* Kp = (float*)ws;
     D4W_LAUNCH(f2_pad_kernel, dim3(64), dim3(kImThreads), 0, stream, kernel, kh, kw, Kp);
     const dim3 grid((w + kF2TileW - 1) / kF2TileW, (h + kF2TileH - 1) / kF2TileH);
-#ifndef D4W_EMU
     if (lds > 64 * 1024) {
         (void)hipFuncSetAttribute((const void*)filter2d_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)filter2d_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-#endif
     if (accumulate) D4W_LAUNCH(filter2d_tile<true>, grid, dim3(kF2Threads), lds, stream, img, h, w, (const float*)Kp, kh, kw, out);
     else D4W_LAUNCH(filter2d_tile<false>, grid, dim3(kF2Threads), lds, stream, img, h, w, (const float*)Kp, kh, kw, out);
     return D4W_OK;

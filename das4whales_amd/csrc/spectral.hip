@@ -1442,11 +1442,7 @@ using namespace d4w;
 
 template <typename K>
 static void sp_allow_lds(K kern, size_t lds) {
-#ifndef D4W_EMU
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#else
-    (void)kern; (void)lds;
-#endif
 }
 
 extern "C" {

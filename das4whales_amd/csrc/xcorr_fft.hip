@@ -163,11 +163,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     float4* buf = reinterpret_cast<float4*>(smem_raw);          // [ROWP] block spectra of both rows, then each template's correlation
     float2* tw1 = reinterpret_cast<float2*>(buf + (FUSED ? 2 : 1) * ROWP);        // [M1]
     float2* tw2 = tw1 + M1;                                     // [NB][NC]
-#ifdef D4W_EMU
-    const int tsel = FUSED ? (int)(threadIdx.x >> 7) : 0;        // template carried by this half of the workgroup
-#else
     const int tsel = FUSED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
-#endif
     const int tid = FUSED ? (int)(threadIdx.x & (kXfThreads - 1)) : (int)threadIdx.x;
     const bool fwd = !FUSED || tsel == 0;                         // this wave runs the forward stages
     float4* mine = FUSED ? (tsel ? buf : buf + ROWP) : buf;       // row buffer of this wave's template
@@ -770,11 +766,7 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
     float4* buf = reinterpret_cast<float4*>(smem_raw);            // [ROWP] block spectrum, then template 1's correlation
     float2* tw2 = reinterpret_cast<float2*>(buf + 2 * ROWP);      // [8][32]
     float2* tw3 = tw2 + 256;                                      // [8][4]
-#ifdef D4W_EMU
-    const int tsel = (int)(threadIdx.x >> 8);
-#else
     const int tsel = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-#endif
     const int tid = (int)(threadIdx.x & (kX4Items - 1));
     const bool fwd = tsel == 0;
     float4* mine = tsel ? buf : buf + ROWP;
@@ -1071,14 +1063,12 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
                    ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
-#ifndef D4W_EMU
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
-#endif
     // D4W_XF_TPAIR=1: both templates off ONE read of x (one row per workgroup, the two correlations
     // packed through one inverse transform).  Measured at 20000 x 120000: 8.96 ms against 8.93 ms for the
     // two row-pair launches -- both forms are bound by VALU issue (~2000 packed instructions per row
@@ -1086,13 +1076,11 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     // that has the simpler forward stage.
     static const int pairmode = [] { const char* v = getenv("D4W_XF_TPAIR"); return v ? atoi(v) : 0; }();
     if (ntpl == 2 && pairmode && nx <= 65535) {
-#ifndef D4W_EMU
         static bool attr2 = false;
         if (!attr2) {
             (void)hipFuncSetAttribute((const void*)xcorr_fft_tpair, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             attr2 = true;
         }
-#endif
         D4W_LAUNCH(xcorr_fft_tpair, dim3(grid.x, nx), dim3(kXfThreads), lds, stream, T, x, ns, mean, maxabs, y0, y1);
         return D4W_OK;
     }
@@ -1113,14 +1101,12 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
             D4W_LAUNCH(xcf_tables4, dim3(ceil_div(2 * kXfMB, 256)), dim3(256), 0, stream, taps, ltaps, len0, len1, gp4, gn, q1, q2,
                        q3, qg, qp);
         const size_t lds4 = 2 * (size_t)kX4RowP * sizeof(float4) + (256 + 32) * sizeof(float2);
-#ifndef D4W_EMU
         static bool attr4 = false;
         if (!attr4) {
             (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             attr4 = true;
         }
-#endif
         if (xnext)
             D4W_LAUNCH(xcorr_fft_fused4<true>, grid, dim3(2 * kX4Items), lds4, stream, Q, x, nx, ns, mean, maxabs, y0, y1, xnext,
                        ld_next, n_next);
@@ -1175,9 +1161,7 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns - 2 * K, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
-#ifndef D4W_EMU
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-#endif
     D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
                (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain, XfHalo{});
     return D4W_OK;
@@ -1208,9 +1192,7 @@ int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int 
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
-#ifndef D4W_EMU
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-#endif
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
     D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,

@@ -86,6 +86,20 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+// launch attributes, device queries and cross-stream ordering: accepted and ignored (one host thread runs everything in order)
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+struct hipFuncAttributes { int numRegs = 0; size_t sharedSizeBytes = 0; };
+template <typename F> static inline hipError_t hipFuncGetAttributes(hipFuncAttributes*, F) { return hipErrorInvalidValue; }
+struct hipDeviceProp_t { int multiProcessorCount = 3; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+// a value every lane of the wave holds alike
+#define __builtin_amdgcn_readfirstlane(v) (v)
 
 // ------------------------------------------------------------------------------------------
 // fiber scheduler
