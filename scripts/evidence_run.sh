@@ -47,6 +47,9 @@ cp $O/pmc/summary.txt $O/pmc_fetch_write_summary.txt; cp $O/pmc/pmc_traffic.json
 timeout 900 python scripts/cpu_baseline_c1.py > $O/cpu_baseline_c1.json 2>/dev/null; cut -c1-300 $O/cpu_baseline_c1.json
 timeout 300 python scripts/time_picks3.py 2>/dev/null | grep -E "^\{|find_peaks" > $O/time_picks.txt; head -2 $O/time_picks.txt | cut -c1-300
 timeout 300 python scripts/time_stft.py 2>/dev/null | grep "^{" > $O/time_stft.txt; cat $O/time_stft.txt
+# round 4: detect.pick_times on raw long-row correlograms (windowed turning-point sweep), the Gabor image pipeline (filter2d on the matrix cores)
+(timeout 300 python scripts/time_pick_long.py; NX=11020 NS=12000 timeout 200 python scripts/time_pick_long.py) 2>/dev/null | grep "^{" > $O/time_pick_long.txt; cut -c1-300 $O/time_pick_long.txt
+(timeout 300 python scripts/time_image.py --nx 11020 --ns 12000; D4W_F2D_MM=0 timeout 300 python scripts/time_image.py --nx 11020 --ns 12000) 2>/dev/null | grep "^{" > $O/time_image.txt; cut -c1-300 $O/time_image.txt
 timeout 300 python scripts/time_bp_parts.py 2>/dev/null | grep "^{" > $O/time_bp_parts.txt
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o st -- python $R/bench.py --config stream --files 8 --steps 16 --warmup 2 > $R/$O/rocprof_stream.log 2>&1
 cd $R
