@@ -278,6 +278,78 @@ __global__ __launch_bounds__(kStatThreads) void raw2strain_rows(const T* __restr
     for (int i = threadIdx.x; i < ns; i += kStatThreads) out[i] = (float)(((double)row[i] - mu) * scale);
 }
 
+// The same with 16-byte loads, a dozen of them in flight per lane: rows of up to kR2sHold x 256 vectors (12 288 four-byte
+// samples: the 60-s files) stay in registers between the sum and the subtraction -- one read of the raw row --, longer rows
+// are swept twice, a dozen vectors per lane at a time.  Rows must start on 16 bytes (the host checks).
+constexpr int kR2sHold = 12;
+template <typename T>
+__global__ __launch_bounds__(kStatThreads) void raw2strain_rows_vec(const T* __restrict__ raw, int ns, int c0, int cstep,
+                                                                    double scale, float* __restrict__ y) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    struct alignas(16) Vec { T v[VEC]; };
+    __shared__ double red[kStatThreads / 64];
+    __shared__ double s_mean;
+    const Vec* row = reinterpret_cast<const Vec*>(raw + ((size_t)c0 + (size_t)blockIdx.x * cstep) * ns);
+    float* out = y + (size_t)blockIdx.x * ns;
+    const int nvec = ns / VEC, tid = threadIdx.x;
+    const bool held = nvec <= kR2sHold * kStatThreads;
+    Vec q[kR2sHold];
+    double s = 0.0;
+    for (int v0 = 0; v0 < nvec; v0 += kR2sHold * kStatThreads) {
+#pragma unroll
+        for (int k = 0; k < kR2sHold; ++k) {
+            const int i = v0 + k * kStatThreads + tid;
+            if (i < nvec) q[k] = row[i];
+        }
+#pragma unroll
+        for (int k = 0; k < kR2sHold; ++k) {
+            const int i = v0 + k * kStatThreads + tid;
+            if (i < nvec) {
+                double t = 0.0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) t += (double)q[k].v[e];
+                s += t;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((tid & 63) == 0) red[tid / 64] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kStatThreads / 64; ++w) t += red[w];
+        s_mean = t / (double)ns;
+    }
+    __syncthreads();
+    const double mu = s_mean;
+    for (int v0 = 0; v0 < nvec; v0 += kR2sHold * kStatThreads) {
+        if (!held) {
+#pragma unroll
+            for (int k = 0; k < kR2sHold; ++k) {
+                const int i = v0 + k * kStatThreads + tid;
+                if (i < nvec) q[k] = row[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kR2sHold; ++k) {
+            const int i = v0 + k * kStatThreads + tid;
+            if (i < nvec) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = (float)(((double)q[k].v[e] - mu) * scale);
+                if constexpr (VEC >= 4) {
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4)
+                        *reinterpret_cast<float4*>(out + (size_t)i * VEC + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
+                } else {
+                    *reinterpret_cast<float2*>(out + (size_t)i * VEC) = make_float2(o[0], o[1]);
+                }
+            }
+        }
+    }
+}
+
 // =============================================================================================
 // DC tail of the de-meaned zero-padded template (detect.py:158): the reference normalises the template
 // over its zero-padded length, which leaves the constant -mean(t)/max|t| on the padded part.  Its
@@ -593,6 +665,19 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
 int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep, int nx_out, double scale_factor,
                        float* y, void* stream) {
     if (!raw || !y || ns < 1 || nx_out < 1 || c0 < 0 || cstep < 1) return fail(D4W_EINVAL, "bad argument");
+    // 16-byte loads when every selected row (and the output rows) starts on 16 bytes and holds whole vectors
+    const size_t esz = raw_dtype == 1 ? 2 : raw_dtype == 3 ? 8 : 4;
+    const bool vec = raw_dtype >= 0 && raw_dtype <= 3 && ((size_t)ns * esz) % 16 == 0 && (ns & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(raw) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (vec) {
+        switch (raw_dtype) {
+            case 0: D4W_LAUNCH(raw2strain_rows_vec<int32_t>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const int32_t*)raw, ns, c0, cstep, scale_factor, y); break;
+            case 1: D4W_LAUNCH(raw2strain_rows_vec<int16_t>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const int16_t*)raw, ns, c0, cstep, scale_factor, y); break;
+            case 2: D4W_LAUNCH(raw2strain_rows_vec<float>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const float*)raw, ns, c0, cstep, scale_factor, y); break;
+            default: D4W_LAUNCH(raw2strain_rows_vec<double>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const double*)raw, ns, c0, cstep, scale_factor, y); break;
+        }
+        return D4W_OK;
+    }
     switch (raw_dtype) {
         case 0: D4W_LAUNCH(raw2strain_rows<int32_t>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const int32_t*)raw, ns, c0, cstep, scale_factor, y); break;
         case 1: D4W_LAUNCH(raw2strain_rows<int16_t>, dim3(nx_out), dim3(kStatThreads), 0, stream, (const int16_t*)raw, ns, c0, cstep, scale_factor, y); break;

@@ -219,10 +219,12 @@ def test_xcorr_fft_ragged(emu, nx, ns, l0, l1):
     assert emu.d4w_xcorr_fft_max_support() == 161
 
 
-def test_raw2strain_ingest(emu):
-    """data_handle.load_das_data channel selection + raw2strain (data_handle.py:157-176,213-214)."""
+@pytest.mark.parametrize("ns", [1001, 1000, 2056, 12304])
+def test_raw2strain_ingest(emu, ns):
+    """data_handle.load_das_data channel selection + raw2strain (data_handle.py:157-176,213-214): scalar loads (rows that
+    do not start on 16 bytes), 16-byte loads with the row held in registers, and rows longer than the registers hold."""
     rng = np.random.default_rng(9)
-    nch, ns = 23, 1001
+    nch = 23
     raw = (rng.standard_normal((nch, ns)) * 3e4 + 1.5e5).astype(np.int32)
     scale = 2.3e-11
     c0, c1, step = 3, 21, 4
