@@ -74,6 +74,7 @@ def _load():
         "d4w_fk_set_mask_dense_affine_f32": (c_int, [c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p]),
         "d4w_raw2strain_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
         "d4w_row_stats_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+        "d4w_copy_cols_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t, c_int, c_int, c_void_p]),
         "d4w_xcorr_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_lens_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -51,6 +51,15 @@ __device__ __forceinline__ float sos_fetch_bwd(const float* __restrict__ row, co
     return (i >= ns) ? edge[i - ns] : row[i];
 }
 
+// dst[r][0..ncols) = src[r][0..ncols) for nrows rows with their own pitches: the row-end pieces of the band-pass move in one
+// launch each (torch splits a slice copy of a tensor with more than 2^31 elements into ~10 launches of a few microseconds)
+__global__ __launch_bounds__(256) void copy_cols(const float* __restrict__ src, size_t ld_src, float* __restrict__ dst,
+                                                 size_t ld_dst, int ncols) {
+    const float* s = src + (size_t)blockIdx.y * ld_src;
+    float* d = dst + (size_t)blockIdx.y * ld_dst;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) d[c] = s[c];
+}
+
 __global__ __launch_bounds__(256) void sos_first_samples(const float* __restrict__ x, int nx, int ns,
                                                          float* __restrict__ first) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,6 +669,20 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     int rc = sos_launch<false, float>(nsec, grid, stream, A, x, nullptr, t, edge, nx, ns, padlen, S, W, first, 0.f);
     if (rc) return rc;
     return sos_launch<true, float>(nsec, grid, stream, A, t, edge, y, nullptr, nx, ns, padlen, S, W, first, (float)dcg2);
+}
+
+int d4w_copy_cols_f32(const float* src, size_t ld_src, float* dst, size_t ld_dst, int nrows, int ncols, void* stream) {
+    if (!src || !dst || nrows < 1 || ncols < 1) return fail(D4W_EINVAL, "bad argument");
+    if (nrows > 65535) {                                          // grid.y limit: rows in slabs
+        for (int r0 = 0; r0 < nrows; r0 += 65535) {
+            const int nr = std::min(65535, nrows - r0);
+            D4W_LAUNCH(copy_cols, dim3(std::min(8, ceil_div(ncols, 256)), nr), dim3(256), 0, stream, src + (size_t)r0 * ld_src,
+                       ld_src, dst + (size_t)r0 * ld_dst, ld_dst, ncols);
+        }
+        return D4W_OK;
+    }
+    D4W_LAUNCH(copy_cols, dim3(std::min(8, ceil_div(ncols, 256)), nrows), dim3(256), 0, stream, src, ld_src, dst, ld_dst, ncols);
+    return D4W_OK;
 }
 
 int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep, int nx_out, double scale_factor,

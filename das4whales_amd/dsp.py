@@ -446,22 +446,34 @@ def _sosfiltfilt_fft(x, sos, padlen):
         # bandwidth-bound overlap-save pass (D4W_BP_OVERLAP=0: one stream, one after the other)
         cur = torch.cuda.current_stream(x.device)
         side = _side_stream(x.device) if os.environ.get("D4W_BP_OVERLAP", "1") != "0" else cur
+        ready = None
         if side is not cur:
-            side.wait_stream(cur)
-            x.record_stream(side)
-        with torch.cuda.stream(side):
-            ends = torch.cat((x[:, :P], x[:, ns - P:]), dim=0)
-            ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
-        first = x[:, 0].contiguous()
+            ready = torch.cuda.Event()
+            ready.record(cur)                        # x is complete here: what the side stream has to wait for
+        # the long kernel goes out FIRST: the device starts on it while the host is still preparing the row-end launches
+        def cols(src, src_off, ld_src, dst, dst_off, ld_dst, ncols, stream):
+            # one launch per strided piece (a torch slice copy of a > 2^31-element tensor is split into ~10)
+            check(lib.d4w_copy_cols_f32(dev.ptr(src) + 4 * src_off, ld_src, dev.ptr(dst) + 4 * dst_off, ld_dst, nx, ncols,
+                                        ctypes.c_void_p(stream.cuda_stream)))
+        first = torch.empty(nx, dtype=torch.float32, device=x.device)
+        cols(x, 0, ns, first, 0, 1, 1, cur)
         ent = _fir_workspace(t, x.device)
         check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, None if ent[1] else dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
                                   dev.ptr(ent[0]), dev.stream_ptr(x)))
         ent[1] = True
         if side is not cur:
+            side.wait_event(ready)
+            x.record_stream(side)
+        with torch.cuda.stream(side):
+            ends = torch.empty((2 * nx, P), dtype=torch.float32, device=x.device)
+            cols(x, 0, ns, ends, 0, P, P, side)
+            cols(x, ns - P, ns, ends, nx * P, P, P, side)
+            ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
+        if side is not cur:
             cur.wait_stream(side)
             ye.record_stream(cur)
-        y[:, :E] = ye[:nx, :E]
-        y[:, ns - E:] = ye[nx:, P - E:]
+        cols(ye, 0, P, y, 0, ns, E, cur)
+        cols(ye, nx * P + P - E, P, y, ns - E, ns, E, cur)
     return y
 
 

@@ -248,6 +248,10 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
  * separate entry point, d4w_xcorr_dc_tail_f32.
  * ------------------------------------------------------------------------------------------ */
 int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream);
+
+/* dst[r][0 .. ncols) = src[r][0 .. ncols), r < nrows, rows ld_src / ld_dst floats apart (DEVICE pointers): the strided piece
+ * copies around the band-pass (row ends to the recursion and back, dsp.py:859-880) in one launch each. */
+int d4w_copy_cols_f32(const float* src, size_t ld_src, float* dst, size_t ld_dst, int nrows, int ncols, void* stream);
 int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
                   const float* taps, int ntpl, int ltaps, float* y0, float* y1, void* stream);
 /* Same, with the true support of each template (len_t <= ltaps, taps[t][len_t..ltaps) == 0): taps
