@@ -589,8 +589,13 @@ __global__ __launch_bounds__(kSpThreads) void scale_rows(float* __restrict__ S, 
 
 // ---------------------------------------------------------------------------------------------
 // np.median of every row (detect.py:600 divides by the median of the sliced spectrogram):
-// 4-pass 8-bit radix select on order-preserving keys with an LDS histogram; for an even count the
-// upper middle is the smallest key above the lower one unless duplicates cover it.
+// radix select on order-preserving keys in THREE sweeps of the row -- digits of 11, 11 and 10 bits with an LDS histogram of
+// 2048 bins (8 per thread).  The sweeps are what the kernel costs: the detector's rows (13 bins x 1501 frames, 78 KB) do
+// not stay in L2 between sweeps (FETCH_SIZE of the former 4 x 8-bit + 1 form: 3.4 GB for an 857-MB spectrogram,
+// profiles/r04h/pmc_stream_11020x12000.txt; staging the row in LDS, a sampled one-sweep form and one wave per row were
+// all slower, profiles/r04h/README.txt).  For an even count the upper middle value comes out of the last sweep as well: it
+// is the lower one again when duplicates cover the next rank, else the next non-empty bin of the last histogram, else the
+// smallest key above the selected 22-bit prefix, which the last sweep tracks.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned med_key(float v) {
     const unsigned b = __float_as_uint(v);
@@ -600,114 +605,118 @@ __device__ __forceinline__ float med_unkey(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+constexpr int kMedBins = 2048, kMedPer = kMedBins / kSpThreads;
 __global__ __launch_bounds__(kSpThreads) void row_median(const float* __restrict__ v, size_t n,
                                                          float* __restrict__ med) {
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[kMedBins];
     __shared__ unsigned wtot[kSpThreads / 64];
-    __shared__ unsigned s_prefix, s_k, s_cnt, s_min;
-    static_assert(kSpThreads == 256, "one histogram bin per thread");
+    __shared__ unsigned s_bin, s_k, s_excl, s_next, s_above;
+    static_assert(kMedPer * kSpThreads == kMedBins, "whole bins per thread");
     const float* row = v + (size_t)blockIdx.x * n;
     const int tid = threadIdx.x;
-    if (tid == 0) { s_prefix = 0u; s_k = (unsigned)((n - 1) / 2); }
-    unsigned mask = 0u;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0u;
+    unsigned prefix = 0u, mask = 0u, kk = (unsigned)((n - 1) / 2);
+    unsigned above = 0xFFFFFFFFu;                                  // smallest key beyond the selected prefix (last sweep)
+    unsigned bin = 0u, excl_sel = 0u, h_sel = 0u;
+    constexpr int kAhead = 8;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = (pass == 0) ? 21 : (pass == 1) ? 10 : 0;
+        const unsigned dmask = (pass == 2) ? 1023u : 2047u;
+        for (int i = tid; i < kMedBins; i += kSpThreads) hist[i] = 0u;
+        if (tid == 0) { s_next = 0xFFFFFFFFu; s_above = 0xFFFFFFFFu; }
         __syncthreads();
-        const unsigned prefix = s_prefix;
-        if (shift == 24) {
-            // first sweep: every value takes part and the top byte (sign + upper exponent bits) of a row of magnitudes
-            // falls into two or three bins -- as LDS atomics that is a 64-way same-address conflict per wave.  Four
-            // bins around the first value's are counted in registers and added once per wave.
-            const unsigned hot = (med_key(row[0]) >> 24) - 1u;
-            unsigned priv[4] = {0u, 0u, 0u, 0u};
-            constexpr int kAhead = 4;
-            for (size_t i0 = tid; i0 < n; i0 += (size_t)kAhead * kSpThreads) {
-                float q[kAhead];
+        // first sweep: every value takes part and the top digit (sign, exponent, two mantissa bits) of a row of magnitudes
+        // falls into a handful of bins -- as LDS atomics a many-way same-address conflict per wave.  Four bins around the first
+        // value's are counted in registers and added once per wave.
+        const unsigned hot = (pass == 0) ? (med_key(row[0]) >> 21) - 1u : 0xFFFFF000u;
+        unsigned priv[4] = {0u, 0u, 0u, 0u};
+        for (size_t i0 = tid; i0 < n; i0 += (size_t)kAhead * kSpThreads) {
+            float q[kAhead];
 #pragma unroll
-                for (int j = 0; j < kAhead; ++j) {
-                    const size_t i = i0 + (size_t)j * kSpThreads;
-                    q[j] = (i < n) ? row[i] : 0.f;
-                }
+            for (int j = 0; j < kAhead; ++j) {
+                const size_t i = i0 + (size_t)j * kSpThreads;
+                q[j] = (i < n) ? row[i] : 0.f;
+            }
 #pragma unroll
-                for (int j = 0; j < kAhead; ++j) {
-                    if (i0 + (size_t)j * kSpThreads < n) {
-                        const unsigned b = med_key(q[j]) >> 24, d = b - hot;
+            for (int j = 0; j < kAhead; ++j) {
+                if (i0 + (size_t)j * kSpThreads < n) {
+                    const unsigned k = med_key(q[j]);
+                    if ((k & mask) == prefix) {
+                        const unsigned bq = (k >> shift) & dmask, d = bq - hot;
                         if (d < 4u) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) priv[t] += (d == (unsigned)t) ? 1u : 0u;
                         } else {
-                            atomicAdd(&hist[b], 1u);
+                            atomicAdd(&hist[bq], 1u);
                         }
+                    } else if (pass == 2 && (k & mask) > prefix) {
+                        above = min(above, k);
                     }
                 }
             }
+        }
+        if (pass == 0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 unsigned c = priv[t];
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-                if ((tid & 63) == 0 && c && hot + (unsigned)t < 256u) atomicAdd(&hist[hot + (unsigned)t], c);
-            }
-        } else {
-            constexpr int kAhead = 4;
-            for (size_t i0 = tid; i0 < n; i0 += (size_t)kAhead * kSpThreads) {
-                float q[kAhead];
-#pragma unroll
-                for (int j = 0; j < kAhead; ++j) {
-                    const size_t i = i0 + (size_t)j * kSpThreads;
-                    q[j] = (i < n) ? row[i] : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < kAhead; ++j) {
-                    const unsigned k = med_key(q[j]);
-                    if (i0 + (size_t)j * kSpThreads < n && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-                }
+                if ((tid & 63) == 0 && c && hot + (unsigned)t < (unsigned)kMedBins) atomicAdd(&hist[hot + (unsigned)t], c);
             }
         }
         __syncthreads();
-        // the bin holding rank s_k: one bin per thread, inclusive scan (wave shuffles + the four wave totals) -- a serial
-        // walk of the 256 bins by one thread was a fifth of the kernel
-        {
-            const unsigned kk = s_k, h = hist[tid];
-            unsigned incl = h;
+        // the bin holding rank kk: kMedPer bins per thread, inclusive scan of the threads' sums
+        unsigned h[kMedPer], sum = 0u;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned up = __shfl_up(incl, off);
-                if ((tid & 63) >= off) incl += up;
-            }
-            if ((tid & 63) == 63) wtot[tid >> 6] = incl;
-            __syncthreads();
-            unsigned before = 0u;
-            for (int w = 0; w < (tid >> 6); ++w) before += wtot[w];
-            incl += before;
-            const unsigned excl = incl - h;
-            if (kk >= excl && kk < incl) {             // exactly one thread: the counts sum to more than s_k
-                s_k = kk - excl;
-                s_prefix = prefix | ((unsigned)tid << shift);
-            }
+        for (int t = 0; t < kMedPer; ++t) { h[t] = hist[kMedPer * tid + t]; sum += h[t]; }
+        unsigned incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off);
+            if ((tid & 63) >= off) incl += up;
         }
-        mask |= 255u << shift;
+        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+        __syncthreads();
+        unsigned before = 0u;
+        for (int w = 0; w < (tid >> 6); ++w) before += wtot[w];
+        unsigned run = incl + before - sum;                        // keys in the bins before this thread's
+#pragma unroll
+        for (int t = 0; t < kMedPer; ++t) {
+            if (kk >= run && kk < run + h[t]) {                   // exactly one (thread, t): the counts sum to more than kk
+                s_bin = (unsigned)(kMedPer * tid + t);
+                s_k = kk - run;
+                s_excl = run;
+            }
+            run += h[t];
+        }
+        __syncthreads();
+        bin = s_bin;
+        if (pass == 2) {
+            excl_sel = s_excl;
+            h_sel = hist[bin];
+            // the next non-empty bin of the last digit, and the smallest key beyond the prefix
+#pragma unroll
+            for (int t = 0; t < kMedPer; ++t) {
+                const unsigned bq = (unsigned)(kMedPer * tid + t);
+                if (bq > bin && h[t]) atomicMin(&s_next, bq);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) above = min(above, __shfl_xor(above, off));
+            if ((tid & 63) == 0) atomicMin(&s_above, above);
+        }
+        kk = s_k;
+        prefix |= bin << shift;
+        mask |= dmask << shift;
         __syncthreads();
     }
-    const unsigned a = s_prefix;
-    if (n & 1) {
-        if (tid == 0) med[blockIdx.x] = med_unkey(a);
-        return;
-    }
-    if (tid == 0) { s_cnt = 0u; s_min = 0xFFFFFFFFu; }
-    __syncthreads();
-    unsigned cnt = 0u, mn = 0xFFFFFFFFu;
-    for (size_t i = tid; i < n; i += kSpThreads) {
-        const unsigned k = med_key(row[i]);
-        if (k <= a) ++cnt;
-        else mn = min(mn, k);
-    }
-    atomicAdd(&s_cnt, cnt);
-    atomicMin(&s_min, mn);
-    __syncthreads();
     if (tid == 0) {
-        const unsigned b = (s_cnt > (unsigned)(n / 2)) ? a : s_min;
-        med[blockIdx.x] = 0.5f * (med_unkey(a) + med_unkey(b));
+        const unsigned a = prefix;
+        unsigned b = a;
+        if ((n & 1) == 0) {
+            // rank (n - 1) / 2 is key a, the kk-th of its h_sel copies; rank n / 2 is a again unless that was the last copy
+            (void)excl_sel;
+            if (kk + 1 >= h_sel) b = (s_next != 0xFFFFFFFFu) ? ((prefix & ~1023u) | s_next) : s_above;
+        }
+        med[blockIdx.x] = (n & 1) ? med_unkey(a) : 0.5f * (med_unkey(a) + med_unkey(b));
     }
 }
 
