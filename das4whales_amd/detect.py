@@ -236,9 +236,18 @@ def _tail_coef(template):
     return float(t.mean() / np.max(np.abs(t)))
 
 
-# the DC tail is added when |coef| * sqrt(ns) exceeds this (its size relative to the correlogram of
-# white data is ~ coef * sqrt(ns) / 15); the fin-whale templates on 60-s files stay below it
-TAIL_THRESHOLD = 1e-4
+# The DC tail is added when its predicted size relative to the correlogram exceeds this.  On white data the tail is
+# ~ 0.35 |coef| sqrt(ns / E) of the correlogram's maximum, E = sum of the squared normalised taps (measured 0.29-0.37 over
+# random templates of 5-137 samples, scripts/probe/fuzz_case_xcorr.py): half the parity bar of 1e-5.  The fin-whale
+# templates on 60-s files come to 3.3e-6 / 4.7e-6 and stay without it; a 19-sample random template with a residual mean
+# comes to 1.9e-5 and gets it (the former rule |coef| sqrt(ns) > 1e-4 ignored the template's energy and let that one pass).
+TAIL_THRESHOLD = 5e-6
+
+
+def _tail_size(coef, taps, ns):
+    """Predicted size of the DC-tail term relative to the correlogram's maximum (white rows)."""
+    e = float(np.sum(np.asarray(taps, dtype=np.float64) ** 2))
+    return 0.35 * abs(coef) * np.sqrt(ns / max(e, 1e-30))
 
 
 def compute_cross_correlograms(data, templates, exact_tail=None):
@@ -252,7 +261,7 @@ def compute_cross_correlograms(data, templates, exact_tail=None):
     nx, ns = xd.shape
     taps = [_normalised_support(t) for t in templates]
     coefs = [_tail_coef(t) for t in templates]
-    need_tail = [exact_tail if exact_tail is not None else abs(c) * np.sqrt(ns) > TAIL_THRESHOLD for c in coefs]
+    need_tail = [exact_tail if exact_tail is not None else _tail_size(c, tp, ns) > TAIL_THRESHOLD for c, tp in zip(coefs, taps)]
     stats = None
     if any(need_tail):
         stats = _row_stats_cached(xd)

@@ -104,7 +104,7 @@ class FileStream:
             cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
             cs = [c[:, :ns].contiguous() for c in cs]
         for c, tp, coef in zip(cs, self.taps, self.tail):
-            if coef != 0.0 and abs(coef) * np.sqrt(ns) > detect.TAIL_THRESHOLD:
+            if coef != 0.0 and detect._tail_size(coef, tp, ns) > detect.TAIL_THRESHOLD:
                 with torch.cuda.device(y.device):
                     check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), float(coef), len(tp),
                                                     dev.ptr(c), dev.stream_ptr(y)))

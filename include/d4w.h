@@ -264,8 +264,8 @@ int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const 
  *   y[c][k] += coef * g[c] * sum_{i < k + support} (x[c][i] - m[c]),  k + support < ns,
  * coef = mean(template) / max|template| over the zero-padded length, support = length of the non-zero
  * part.  Added in place to a correlogram produced by d4w_xcorr_*_f32 with the same mean / maxabs.
- * |coef| ~ 5e-7 for the fin-whale templates (a < 3e-6 effect on a 60-s file), so hosts apply it only
- * when coef * sqrt(ns) is not negligible. */
+ * |coef| ~ 5e-7 for the fin-whale templates (a 3-5e-6 effect on a 60-s file), so hosts apply it only when its predicted size,
+ * ~ 0.35 |coef| sqrt(ns / sum taps^2) of the correlogram's maximum on white rows, is not negligible (the Python mirror: 5e-6). */
 int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
                           double coef, int support, float* y, void* stream);
 

@@ -1,6 +1,8 @@
 """Seeded random-shape sweep of every row of SURVEY 8(a) on the GPU against SciPy / the oracle:
 ragged and odd shapes, prime factors, tiny inputs, rows of zeros / constants.  Complements the
 golden-vector and full-size tests with breadth."""
+import os
+
 import numpy as np
 import pytest
 import scipy.signal as sps
@@ -8,6 +10,7 @@ import torch
 
 from oracle import d4w_oracle as orc
 
+SEED = int(os.environ.get("D4W_FUZZ_SEED", "0"))      # a different seed offset = a different set of random cases (stress runs)
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 FS = 200.0
@@ -43,7 +46,7 @@ def smooth_lengths(rng, n, lo, hi, even=False):
 
 
 def test_fk_filter_random_shapes(dw):
-    rng = np.random.default_rng(101)
+    rng = np.random.default_rng(101 + SEED)
     for nx, ns in zip(smooth_lengths(rng, 6, 2, 400), smooth_lengths(rng, 6, 4, 3000, even=True)):
         x = rng.standard_normal((nx, ns))
         m = rng.random((nx, ns)) * (rng.random((nx, 1)) > 0.3)          # some all-zero wavenumber rows
@@ -53,7 +56,7 @@ def test_fk_filter_random_shapes(dw):
 
 
 def test_bandpass_random_shapes(dw):
-    rng = np.random.default_rng(102)
+    rng = np.random.default_rng(102 + SEED)
     for _ in range(5):
         nx, ns = int(rng.integers(1, 300)), int(rng.integers(60, 20000))
         x = rng.standard_normal((nx, ns)) + rng.standard_normal((nx, 1)) * 3
@@ -65,13 +68,14 @@ def test_bandpass_random_shapes(dw):
         sos = sps.butter(8, [lo / (FS / 2), hi / (FS / 2)], "bp", output="sos")
         truth = sps.sosfiltfilt(sos, x, axis=1, padlen=51)
         assert rel(dw.dsp.bp_filt(x, FS, lo, hi), truth) < TOL, (nx, ns, lo, hi)
-        assert rel(orc.bp_filt(x, FS, lo, hi), truth) < 2e-4
+        if SEED == 0:       # the reference's own `ba` form: fine for the pinned cases, unstable for some random narrow low bands
+            assert rel(orc.bp_filt(x, FS, lo, hi), truth) < 2e-4     # (other seeds: 3.7e-4, and 0.2 for a 5-Hz-wide band at 6 Hz)
         sos = dw.dsp.butterworth_filter([int(rng.integers(1, 6)), float(rng.uniform(2, 40)), "hp"], FS)
         assert rel(dw.dsp.sosfiltfilt(sos, x, axis=1), sps.sosfiltfilt(sos, x, axis=1)) < TOL
 
 
 def test_matched_filter_random_shapes(dw):
-    rng = np.random.default_rng(103)
+    rng = np.random.default_rng(103 + SEED)
     for _ in range(6):
         nx, ns = int(rng.integers(1, 200)), int(rng.integers(200, 30000))
         x = rng.standard_normal((nx, ns)) + 0.2
@@ -97,7 +101,7 @@ def test_matrix_core_correlator_random_cases(dw):
     beyond), template pairs in both orders, single templates, rows of any length and alignment, rows with a large offset,
     all three forms against a float64 correlation."""
     import torch
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + SEED)
     for it in range(10):
         nx, ns = int(rng.integers(1, 60)), int(rng.integers(30, 20000))
         lmax = min(241, ns)
@@ -131,7 +135,7 @@ def test_detector_stft_random_cases(dw):
     """csrc/stft_mm.hip (the detector's STFT on the matrix cores) over random rows: eligible (n_fft, hop, bins) against the
     float64 restatement of librosa.stft; ineligible parameters keep running the FFT kernels."""
     import torch
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     for n_fft, hop in ((160, 8), (128, 8), (160, 16), (96, 24), (64, 32), (160, 8)):
         nx, ns = int(rng.integers(1, 40)), int(rng.integers(n_fft, 15000))
         nb = int(rng.integers(1, 17))
@@ -148,7 +152,7 @@ def test_detector_stft_random_cases(dw):
 
 
 def test_analytic_and_snr_random_shapes(dw):
-    rng = np.random.default_rng(104)
+    rng = np.random.default_rng(104 + SEED)
     for ns in smooth_lengths(rng, 4, 16, 30000, even=True) + smooth_lengths(rng, 2, 15, 15000) + [120000 // 2, 2 * 3 * 5 * 7 * 11 * 13]:
         nx = int(rng.integers(1, 40))
         x = rng.standard_normal((nx, ns))
@@ -161,7 +165,7 @@ def test_analytic_and_snr_random_shapes(dw):
 
 
 def test_spectrogram_random_parameters(dw):
-    rng = np.random.default_rng(105)
+    rng = np.random.default_rng(105 + SEED)
     for _ in range(6):
         ns = int(rng.integers(300, 20000))
         nfft = int(rng.choice([32, 64, 100, 128, 160, 256, 500, 512, 1024, 148, 202]))     # 148 = 4 x 37, 202 = 2 x 101: Bluestein frames
@@ -177,7 +181,7 @@ def test_spectrogram_random_parameters(dw):
 
 
 def test_spectrocorr_random_parameters(dw):
-    rng = np.random.default_rng(106)
+    rng = np.random.default_rng(106 + SEED)
     for _ in range(4):
         nx, ns = int(rng.integers(1, 60)), int(rng.integers(3000, 16000))
         x = rng.standard_normal((nx, ns))
@@ -190,7 +194,7 @@ def test_spectrocorr_random_parameters(dw):
 
 
 def test_picks_random_rows(dw):
-    rng = np.random.default_rng(107)
+    rng = np.random.default_rng(107 + SEED)
     for ns in (3, 4, 64, 65, 1000, 16384, 16385, 50001):
         nx = int(rng.integers(1, 30))
         x = rng.standard_normal((nx, ns)).astype(np.float32)
@@ -208,7 +212,7 @@ def test_picks_random_rows(dw):
 
 def test_channel_counts_with_large_prime_factors(dw):
     """nx with a prime factor > 31 (any channel selection): pass C runs its Bluestein form."""
-    rng = np.random.default_rng(108)
+    rng = np.random.default_rng(108 + SEED)
     for nx, ns in ((4001, 600), (37 * 2, 64), (2 * 3 * 211, 1200), (1009, 256)):
         x = rng.standard_normal((nx, ns))
         m = rng.random((nx, ns))
@@ -224,7 +228,7 @@ def test_channel_counts_with_large_prime_factors(dw):
 
 def test_row_lengths_with_large_prime_factors(dw):
     """Analytic-signal rows whose transform has a prime factor > 31 (12002 = 2 x 6001): Bluestein row transform."""
-    rng = np.random.default_rng(109)
+    rng = np.random.default_rng(109 + SEED)
     for nx, ns in ((5, 12002), (3, 2 * 1009), (4, 1091)):
         x = rng.standard_normal((nx, ns))
         z = orc.hilbert(x)
@@ -242,7 +246,7 @@ def test_row_lengths_with_large_prime_factors(dw):
 
 def test_spectrogram_windows_with_large_prime_factors(dw):
     """STFT windows with a prime factor > 31 (e.g. a 0.74-s window at 200 Hz = 148 samples): Bluestein frame transform."""
-    rng = np.random.default_rng(110)
+    rng = np.random.default_rng(110 + SEED)
     x = rng.standard_normal(9000)
     for nfft, ov in ((148, 0.9), (202, 0.8), (2 * 67, 0.95)):
         p, tt, ff = dw.dsp.get_spectrogram(x, FS, nfft=nfft, overlap_pct=ov)
@@ -260,7 +264,7 @@ def test_any_channel_count(dw):
     """Channel counts whose part with prime factors > 31 exceeds 4096 (the LDS Bluestein tile of pass C): the plan runs the
     global-memory Bluestein form of the channel transform (fk_filter.hip: fkd_bz_*) -- numpy.fft.fft2 (dsp.py:748) takes any
     shape.  Dense, designed and fk_filt masks, taper, in several scratch chunks."""
-    rng = np.random.default_rng(111)
+    rng = np.random.default_rng(111 + SEED)
     for nx, ns in ((4099, 64), (2 * 5003, 240), (10007, 1200)):
         x = rng.standard_normal((nx, ns))
         m = rng.random((nx, ns))
@@ -279,7 +283,7 @@ def test_any_channel_count(dw):
 def test_any_record_length(dw):
     """ns / 2 whose part with prime factors > 31 exceeds 2048 (pass B's Bluestein tile), odd record lengths that zero
     interleaving turns into such, and both axes at once: the global-memory Bluestein form of the time transform (fkd_bt_*)."""
-    rng = np.random.default_rng(112)
+    rng = np.random.default_rng(112 + SEED)
     for nx, ns in ((8, 2 * 4099), (300, 12014), (64, 6007), (4099, 2 * 2053)):      # 12014 = 2 x 6007; 6007 odd and prime
         x = rng.standard_normal((nx, ns))
         m = rng.random((nx, ns))
@@ -306,8 +310,8 @@ def test_unsupported_length_is_a_clear_error(dw):
     """What is left without a kernel: get_fx / spectrogram transforms whose Bluestein tile exceeds a workgroup's LDS.
     ValueError, not a wrong answer.  (The f-k filter and the analytic signal take any shape.)"""
     assert dw.dsp.supported_length(4001) == 4000 and dw.dsp.supported_length(97, even=True) == 96
-    x = np.random.default_rng(0).standard_normal((8, 2 * 37))
-    m = np.random.default_rng(1).uniform(size=x.shape)
+    x = np.random.default_rng(0 + SEED).standard_normal((8, 2 * 37))
+    m = np.random.default_rng(1 + SEED).uniform(size=x.shape)
     assert np.max(np.abs(dw.dsp.fk_filter_filt(x, m) - orc.fk_filter_filt(x, m))) < 1e-5 * np.max(np.abs(x))
     with pytest.raises(ValueError):
         dw.dsp.get_fx(np.zeros((2, 400)), 2 * 10007)
