@@ -68,10 +68,21 @@ def assert_picks_match(got, ref_signal, thr, what=""):
     import scipy.signal as sps
     ref_signal = np.asarray(ref_signal, dtype=np.float64)
     ref = sps.find_peaks(ref_signal, prominence=thr)[0]
-    diff = sorted(set(int(i) for i in got) ^ set(int(i) for i in ref))
+    gs, rs = set(int(i) for i in got), set(int(i) for i in ref)
+    diff = sorted(gs ^ rs)
+    top = float(np.max(np.abs(ref_signal)))
     for i in diff:
         assert 0 < i < len(ref_signal) - 1, (what, i, "differing pick at the row edge")
-        assert ref_signal[i] >= ref_signal[i - 1] and ref_signal[i] >= ref_signal[i + 1], (what, i, "differing pick is not a local maximum of the reference")
+        # a flat top: two neighbouring samples of the reference within float32 resolution of each other, the float32 signal
+        # has its maximum on the other one -- the pick moves by one sample (one index only in `got`, its neighbour only in the
+        # reference picks); both are inspected when their turn comes and both are accepted here
+        swapped = any(0 <= j < len(ref_signal) and ((i in gs) != (j in gs)) and ((i in rs) != (j in rs)) and (j in gs or j in rs)
+                      and abs(ref_signal[i] - ref_signal[j]) <= 2e-6 * top for j in (i - 1, i + 1))
+        if swapped:
+            continue
+        assert ref_signal[i] >= ref_signal[i - 1] and ref_signal[i] >= ref_signal[i + 1], \
+            (what, i, "differing pick is not a local maximum of the reference", ref_signal[i - 2:i + 3].tolist(), top,
+             [j in rs for j in range(i - 2, i + 3)], [j in gs for j in range(i - 2, i + 3)])
         prom = float(sps.peak_prominences(ref_signal, [i])[0][0])
         assert abs(prom - thr) <= 1e-4 * thr, (what, i, "differing pick is not marginal: prominence %.9g vs threshold %.9g" % (prom, thr))
     return len(diff), len(ref)

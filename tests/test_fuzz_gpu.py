@@ -68,7 +68,7 @@ def test_bandpass_random_shapes(dw):
         sos = sps.butter(8, [lo / (FS / 2), hi / (FS / 2)], "bp", output="sos")
         truth = sps.sosfiltfilt(sos, x, axis=1, padlen=51)
         assert rel(dw.dsp.bp_filt(x, FS, lo, hi), truth) < TOL, (nx, ns, lo, hi)
-        if SEED == 0:       # the reference's own `ba` form: fine for the pinned cases, unstable for some random narrow low bands
+        if SEED == 0 and not int(os.environ.get("D4W_SEED_SHIFT", "0")):       # the reference's own `ba` form: fine for the pinned cases, unstable for some random narrow low bands
             assert rel(orc.bp_filt(x, FS, lo, hi), truth) < 2e-4     # (other seeds: 3.7e-4, and 0.2 for a 5-Hz-wide band at 6 Hz)
         sos = dw.dsp.butterworth_filter([int(rng.integers(1, 6)), float(rng.uniform(2, 40)), "hp"], FS)
         assert rel(dw.dsp.sosfiltfilt(sos, x, axis=1), sps.sosfiltfilt(sos, x, axis=1)) < TOL
