@@ -81,7 +81,7 @@ def test_matched_filter_random_shapes(dw):
         x = rng.standard_normal((nx, ns)) + 0.2
         if nx > 2:
             x[1] = 0.0                                                   # all-zero row -> zeros (documented)
-        L = int(rng.integers(2, min(161, ns // 2)))
+        L = int(rng.integers(3, min(161, ns // 2)))                       # (np.hanning(2) is all zeros)
         tpl = np.zeros(ns)
         tpl[:L] = rng.standard_normal(L) * np.hanning(L)
         c = dw.detect.compute_cross_correlogram(x, tpl)
