@@ -34,6 +34,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PASS_NAMES = ["fk_passA_fwd", "fk_passC_fwd", "fk_passB_mid", "fk_passC_inv", "fk_passA_inv"]      # channel-first order
 PASS_NAMES_TF = ["fk_passA_fwd", "fk_passBf_time_fwd", "fk_passCm_channel", "fk_passBi_time_inv", "fk_passA_inv"]   # time-first
 
+# the arithmetic the path computes in: float32 everywhere; the matched filter multiplies binary16 hi / lo splits of its float32
+# operands on the matrix cores and accumulates in float32 (22-23 significant bits per operand)
+DTYPE = "f32 (matched filter: 2 x f16 split operands on the matrix cores, f32 accumulate)"
+
+
 
 def _best_of(fn, n=3):
     """BASELINE.md section 3 protocol: one warm-up call, then the best of n timed calls."""
@@ -179,7 +184,8 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
 
     fused_stats = plan.packed and "fk" in stages and "mf" in stages     # row mean / max|.| from the last f-k pass's epilogue
 
-    def step():
+    def step(gather=None):
+        gather = args.gather if gather is None else gather
         st = None
         if fused_stats:
             y, mean, mx = plan.apply(x_loc, stats=True)
@@ -187,29 +193,34 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         else:
             y = plan.apply(x_loc) if "fk" in stages else x_loc
         # the all-gather of the filtered t-x matrix travels behind the matched filter of the local rows
-        pend = shard.all_gather_rows(y, nx, async_op=True) if (args.gather and nx % world == 0) else None
+        pend = shard.all_gather_rows(y, nx, async_op=True) if (gather and nx % world == 0) else None
         out = ddet._xcorr_device(y, tpl, normalize=True, stats=st) if "mf" in stages else None
         if pend is not None:
             pend[1].wait()
-        elif args.gather:
+        elif gather:
             shard.all_gather_rows(y, nx)
         return out
 
+    def timed(gather):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt = timed(args.gather)
+    # the same step with its outputs left sharded (the t-x all-gather out of the timed region), so that lines of rounds that
+    # defaulted differently stay comparable: reported beside the headline, never in its place
+    dt_sharded = timed(False) if (args.gather and world > 1) else None
     nranks = torch.ones(1, dtype=torch.int64, device=device)
     dist.all_reduce(nranks)                       # every rank that took part counts itself (RCCL)
     # per-stage times of rank 0 (HIP events on the launch stream; transfers are waited on there), a few extra steps
@@ -284,7 +295,7 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         gbs = 24.0 * samples / (ms * 1e-3) / 1e9 / world           # per-GPU algorithmic f-k bytes over the whole step
         out = {"metric": "channel-samples/sec through f-k filter + matched-filter", "value": samples / (dt / args.steps),
                "unit": "channel-samples/s", "n_gpus": world, "rccl_ranks": int(nranks.item()), "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE,
                "data": "synthetic",
                "config": {"workload": "BASELINE configs[3]: ONE %d channels x %d samples float32 block sharded by channel block over %d GPU(s), "
                                       "classic f-k fan mask, stages %s%s" % (nx, ns, world, "+".join(stages),
@@ -295,6 +306,11 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                             "traffic": None, "stage_ms_rank0": stage_ms},
                "gather": gather_info}
+        out["value_note"] = ("value / ms_per_step INCLUDE the RCCL all-gather of the filtered t-x matrix (BASELINE configs[3])"
+                             if args.gather else "value / ms_per_step EXCLUDE the t-x all-gather (outputs stay sharded; --gather puts it in)")
+        if dt_sharded is not None:
+            out["outputs_sharded"] = {"ms_per_step": dt_sharded / args.steps * 1e3, "value": samples / (dt_sharded / args.steps),
+                                      "unit": "channel-samples/s", "note": "same step without the t-x all-gather"}
         if rep_ms is not None:
             out["replicas"] = {"note": "second line: one independent block per GPU, no collective in the data path (weak scaling)",
                                "ms_per_step": rep_ms, "value": samples * world / (rep_ms * 1e-3), "unit": "channel-samples/s",
@@ -448,7 +464,7 @@ def bench_stream(args, world, rank, device, dist):
         nfiles = reps * F * world
         out = {"metric": "channel-samples/sec through the streaming detection chain (ingest + band-pass + f-k + matched filter + picks + spectrogram correlation)",
                "value": nfiles * float(nx) * ns / dt, "unit": "channel-samples/s", "n_gpus": world, "steps": reps * F, "warmup": args.warmup,
-               "ms_per_step": dt / (reps * F) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step": dt / (reps * F) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
                "data": "synthetic", "files_per_s": nfiles / dt, "detections_per_s": npicks / dt, "detections": npicks,
                "injected_notes_per_file": ncall, "channels_per_note": span,
                "ingest": ({"from": "pinned host memory, double-buffered upload on a side stream (data_handle.PinnedIngest)",
@@ -560,7 +576,7 @@ def bench_gloo_emulated(args, stages, world, rank):
         print(json.dumps({"metric": "channel-samples/sec through f-k filter", "value": float(nx) * ns * args.steps / dt,
                           "unit": "channel-samples/s", "n_gpus": world, "ranks": int(ranks.item()), "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
-                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic (emulated, CPU)",
+                          "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic (emulated, CPU)",
                           "config": {"workload": "ONE %d x %d block sharded by channel block over %d CPU rank(s), gloo, emulator "
                                                  "kernels -- launch-path test, not a measurement" % (nx, ns, world),
                                      "parallelism": "channel blocks x%d, pencil f-k (2 all-to-all)" % world,
@@ -634,7 +650,9 @@ def main():
     if args.shard == "auto":
         args.shard = "channel" if world > 1 else "replicas"
     if args.gather is None:
-        args.gather = False          # outputs stay sharded, as they stay on the device at N = 1; both gathers are timed beside the step
+        # BASELINE configs[3] / north star: "a single RCCL all-gather over xGMI to reassemble the filtered t-x matrix" is part
+        # of the sharded step; the step with its outputs left sharded is timed beside it (outputs_sharded)
+        args.gather = world > 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -759,7 +777,7 @@ def main():
                 lambda: ddet._xcorr_device(src, tpl, normalize=True, stats=st))
             # the stage's kernels one by one: row_stats, the two-template matrix-core kernel the step runs (ONE launch), and
             # for reference the overlap-save FFT kernels of rounds 1-3 (fused two-template launch, one-template form)
-            mean = torch.empty(nx, dtype=torch.float32, device=device)
+            mean = torch.empty(nx, dtype=torch.float64, device=device)
             mx = torch.empty(nx, dtype=torch.float32, device=device)
             mf_k["mf_row_stats"] += ev_time(lambda: dw._lib.check(dw._lib.lib.d4w_row_stats_f32(
                 src.data_ptr(), nx, ns, mean.data_ptr(), mx.data_ptr(), torch.cuda.current_stream().cuda_stream)))
@@ -869,7 +887,7 @@ def main():
                    {"bp": "band-pass", "fk": "f-k filter", "mf": "matched-filter"}[t] for t in stages), "value": value,
                "unit": "channel-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                "config": {"workload": "%d channels x %d samples float32 per GPU, classic f-k fan mask "
                                       "(fk_filter_design defaults), stages %s, HF+LF fin-call templates"
                                       % (nx, ns, "+".join(stages)),

@@ -140,3 +140,12 @@ def stream_ptr(t):
 
 def ptr(t):
     return t.data_ptr()
+
+
+def out_ptr(t):
+    """Device pointer of a tensor a kernel is about to WRITE through.  The library writes through raw pointers, which
+    torch does not see: bump the tensor's version counter as an in-place torch op would, so that whatever was remembered
+    about its contents (detect._row_stats_cached keys on identity + version) is dropped -- `plan.apply(x_i, out=y)` in a
+    per-file loop must not find file 0's row statistics on every later file."""
+    torch.autograd.graph.increment_version(t)
+    return t.data_ptr()

@@ -183,5 +183,22 @@ __device__ __forceinline__ v2f v2_muls(v2f a, float s) { v2f sv; sv.x = s; sv.y 
 __device__ __forceinline__ v2f v2_neg(v2f a) { return -a; }
 #endif
 
+// Row mean of the matched filter's normalisation (detect.py:157 de-means in float64).  The producers (d4w_row_stats_f32,
+// the f-k filter's last pass) leave it as a float64 per row; a consumer splits it once per row into a two-float value
+// hi + lo and de-means a float32 sample as (x - hi) - lo: x - hi is exact whenever the row's offset dominates its signal
+// (Sterbenz), so the de-meaned sample is good to float32 rounding of the DEVIATION, not of the offset -- a float32 mean
+// alone leaves an error of |mean| 2^-24 in every sample (rows whose offset is >~ 300 x their signal left the 1e-5 bar).
+struct Mean2 { float hi, lo; };
+__device__ __forceinline__ Mean2 mean2_load(const double* __restrict__ mean, int row) {
+    Mean2 m{0.f, 0.f};
+    if (mean) {
+        const double d = mean[row];
+        m.hi = (float)d;
+        m.lo = (float)(d - (double)m.hi);
+    }
+    return m;
+}
+__device__ __forceinline__ float demean(float v, Mean2 m) { return (v - m.hi) - m.lo; }
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace d4w

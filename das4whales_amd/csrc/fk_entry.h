@@ -57,8 +57,8 @@ struct FkFastEntry {
     void (*A_fwd)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
     void (*A_fwd_taper)(FkDev, const float2*, float2*, int, int, int, int, FkGeo);
     void (*A_inv)(FkDev, float2*, int, int, int, int, FkGeo, const float2*);
-    void (*A_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int, FkGeo, const float2*, int);
-    void (*T_inv_stats)(FkDev, float2*, int, int, float*, unsigned*, int, int, FkGeo, const float2*, int);   // MODE 1
+    void (*A_inv_stats)(FkDev, float2*, int, int, double*, unsigned*, int, int, FkGeo, const float2*, int);
+    void (*T_inv_stats)(FkDev, float2*, int, int, double*, unsigned*, int, int, FkGeo, const float2*, int);   // MODE 1
     void (*C_fwd)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
     void (*C_inv)(FkDev, FkFastDev, float2*, int, int, int, int, FkGeo);
     void (*B_mid)(FkDev, FkFastDev, float2*, int, int, FkGeo);

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_env(FkDev P, float2* __
 // the packed exchange buffer, no channel transform) with the same epilogue; tile0 = first tile of the row chunk.
 template <class G, int MODE = 0>
 __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* __restrict__ data, int run, int nruns,
-                                                               float* __restrict__ rowmean,
+                                                               double* __restrict__ rowmean,
                                                                unsigned* __restrict__ rowmaxbits, int sw, int sbase,
                                                                FkGeo geo = FkGeo(), const float2* __restrict__ packed = nullptr,
                                                                int tile0 = 0) {
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
     };
     float asum[G::C1], amax[G::C1];
     static_for<G::C1>([&](auto cc) { asum[decltype(cc)::value] = 0.f; amax[decltype(cc)::value] = 0.f; });
-    const float inv_ns = 1.0f / (float)P.d.ns;
+    const double inv_ns = 1.0 / (double)P.d.ns;
     int par = 0;
     auto body = [&](Pre& R, Pre& Rn, int sq, bool first) {
         const int t = tile_of(sq);
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
                 }
                 const size_t row = (MODE == 0) ? (size_t)tid * G::C2 + c2 : (size_t)c2 * G::C1 + tid;
                 if (MODE == 0 || (int)row < geo.nrows) {
-                    atomicAdd(rowmean + row, sv * inv_ns);
+                    atomicAdd(rowmean + row, (double)sv * inv_ns);      // float64 mean: d4w_internal.h, Mean2
                     atomicMax(rowmaxbits + row, __float_as_uint(mv));      // mv >= 0: bit order = value order
                 }
             }

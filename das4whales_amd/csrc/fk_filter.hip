@@ -1725,11 +1725,11 @@ static int fk_set_mask_design_run(d4w_fk_plan* pl, int mode, double k_spacing, d
 
 int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
 
-static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, float* row_mean,
+static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, double* row_mean,
                         float* row_maxabs);
 
 static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev,
-                         float* row_mean = nullptr, float* row_maxabs = nullptr) {
+                         double* row_mean = nullptr, float* row_maxabs = nullptr) {
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
     std::lock_guard<std::mutex> lk(pl->apply_mu);
     int rc = fk_plan_enter(pl, stream);
@@ -1739,7 +1739,7 @@ static int fk_apply_impl(d4w_fk_plan* pl, const float* x, float* y, int taper, v
     return rc != D4W_OK ? rc : rl;
 }
 
-static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, float* row_mean,
+static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, double* row_mean,
                         float* row_maxabs) {
     if (!pl || !x || !y) return fail(D4W_EINVAL, "NULL argument");
     if ((row_mean == nullptr) != (row_maxabs == nullptr)) return fail(D4W_EINVAL, "row_mean and row_maxabs go together");
@@ -1786,7 +1786,7 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
             return run;
         };
         if (row_mean) {
-            D4W_HIP(hipMemsetAsync(row_mean, 0, (size_t)d.nx * sizeof(float), st));
+            D4W_HIP(hipMemsetAsync(row_mean, 0, (size_t)d.nx * sizeof(double), st));
             D4W_HIP(hipMemsetAsync(row_maxabs, 0, (size_t)d.nx * sizeof(float), st));
         }
         const int sw = pl->slab_sw;
@@ -1902,20 +1902,20 @@ int d4w_fk_apply_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void*
     return fk_apply_impl(pl, x, y, taper, stream, nullptr);
 }
 
-int d4w_fk_apply_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, float* row_mean, float* row_maxabs,
+int d4w_fk_apply_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, double* row_mean, float* row_maxabs,
                            void* stream) {
     if (!row_mean || !row_maxabs) return fail(D4W_EINVAL, "NULL argument");
     return fk_apply_impl(pl, x, y, taper, stream, nullptr, row_mean, row_maxabs);
 }
 
-int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, float* row_mean,
+int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, double* row_mean,
                                  float* row_maxabs, void* stream, float* ms5);
 
 int d4w_fk_apply_timed_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, float* ms5) {
     return d4w_fk_apply_timed_stats_f32(pl, x, y, taper, nullptr, nullptr, stream, ms5);
 }
 
-int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, float* row_mean,
+int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, double* row_mean,
                                  float* row_maxabs, void* stream, float* ms5) {
     if (!ms5) return fail(D4W_EINVAL, "NULL argument");
     hipEvent_t ev[6];
@@ -3093,7 +3093,7 @@ int d4w_fkd_time_inv_packed_rows_f32(d4w_fkd_plan* pl, const float* packed, floa
 /* ... with the row statistics of the filtered rows (mean, max|.|: what the matched filter normalises by, detect.py:157)
  * from the pass's epilogue; row_mean / row_maxabs [nxl] must be zeroed before the first chunk */
 int d4w_fkd_time_inv_packed_rows_stats_f32(d4w_fkd_plan* pl, const float* packed, float* y_loc, int l0, int l1,
-                                           float* row_mean, float* row_maxabs, void* stream) {
+                                           double* row_mean, float* row_maxabs, void* stream) {
     if (!pl || !packed || !y_loc || !row_mean || !row_maxabs) return fail(D4W_EINVAL, "NULL argument");
     if (!pl->sp) return fail(D4W_EINVAL, "this shape runs the generic distributed plan");
     const FkFastEntry& F = *pl->sp->fast;

@@ -31,6 +31,7 @@ __device__ __forceinline__ float4 mm_load4_stream(const float4* p) { return *p; 
 __device__ __forceinline__ void mm_put4(mm_half* p, const mm_half (&h)[4]) { p[0] = h[0]; p[1] = h[1]; p[2] = h[2]; p[3] = h[3]; }
 __device__ __forceinline__ float mm_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ void mm_wave_sync() { (void)__shfl_xor(0, 1); }     // every lane of the wave arrives before any goes on
+__device__ __forceinline__ float mm_clamp_half(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 static inline int mm_num_cus() { return 2; }
 #else
 typedef _Float16 mm_half;
@@ -67,9 +68,18 @@ __device__ __forceinline__ void mm_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// into binary16's finite range (NaN stays NaN)
+__device__ __forceinline__ float mm_clamp_half(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+// compute units of the current device, asked once per device (two runtime calls per launch before)
 static inline int mm_num_cus() {
+    static int cached[64] = {0};
     int devid = 0, v = 0;
-    if (hipGetDevice(&devid) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) return v;
+    if (hipGetDevice(&devid) != hipSuccess) return 256;
+    if (devid >= 0 && devid < 64 && cached[devid] > 0) return cached[devid];
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) {
+        if (devid >= 0 && devid < 64) cached[devid] = v;
+        return v;
+    }
     return 256;
 }
 #endif

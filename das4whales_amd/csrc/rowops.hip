@@ -214,28 +214,65 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
 
 // =============================================================================================
 // per-row mean and max|x|   (detect.py:157: (x - mean) / max|x|, max of the un-de-meaned row)
-// one workgroup per row, wavefront shuffle reduction, then one LDS hop across the four waves
+// one workgroup per row, wavefront shuffle reduction, then one LDS hop across the four waves.
+// The mean is returned as a FLOAT64 (the reference de-means in float64): the sums run over x - pivot
+// (pivot = the row's first sample, so a row that is all offset sums its small deviations, each exact or
+// rounded relative to the DEVIATION) in float32 lanes and are put together in float64; consumers split
+// the value into a two-float (hi, lo) pair (d4w_internal.h, Mean2).
 // =============================================================================================
 constexpr int kStatThreads = 256;
 
 __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restrict__ x, int ns,
-                                                          float* __restrict__ mean, float* __restrict__ maxabs) {
-    __shared__ float red_s[kStatThreads / 64], red_m[kStatThreads / 64];
+                                                          double* __restrict__ mean, float* __restrict__ maxabs) {
+    __shared__ double red_s[kStatThreads / 64];
+    __shared__ float red_m[kStatThreads / 64];
     const float* row = x + (size_t)blockIdx.x * ns;
+    const float pv = row[0];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, mx = 0.f;
-    int i = threadIdx.x;
-    for (; i + 3 * kStatThreads < ns; i += 4 * kStatThreads) {
-        const float v0 = row[i], v1 = row[i + kStatThreads], v2 = row[i + 2 * kStatThreads],
-                    v3 = row[i + 3 * kStatThreads];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+    double sd = 0.0;                                        // the lane's float32 partial sums, folded every 64 terms
+    if ((reinterpret_cast<uintptr_t>(row) & 15) == 0 && (ns & 3) == 0) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        const int n4 = ns >> 2;
+        int i = threadIdx.x, it = 0;
+        for (; i + 3 * kStatThreads < n4; i += 4 * kStatThreads) {
+            const float4 a = r4[i], b = r4[i + kStatThreads], c = r4[i + 2 * kStatThreads], d = r4[i + 3 * kStatThreads];
+            s0 += ((a.x - pv) + (a.y - pv)) + ((a.z - pv) + (a.w - pv));
+            s1 += ((b.x - pv) + (b.y - pv)) + ((b.z - pv) + (b.w - pv));
+            s2 += ((c.x - pv) + (c.y - pv)) + ((c.z - pv) + (c.w - pv));
+            s3 += ((d.x - pv) + (d.y - pv)) + ((d.z - pv) + (d.w - pv));
+            mx = fmaxf(fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)))),
+                       fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+            mx = fmaxf(fmaxf(mx, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)))),
+                       fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+            if ((++it & 15) == 0) {
+                sd += (double)((s0 + s1) + (s2 + s3));
+                s0 = s1 = s2 = s3 = 0.f;
+            }
+        }
+        for (; i < n4; i += kStatThreads) {
+            const float4 a = r4[i];
+            s0 += ((a.x - pv) + (a.y - pv)) + ((a.z - pv) + (a.w - pv));
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+    } else {
+        int i = threadIdx.x, it = 0;
+        for (; i + 3 * kStatThreads < ns; i += 4 * kStatThreads) {
+            const float v0 = row[i], v1 = row[i + kStatThreads], v2 = row[i + 2 * kStatThreads],
+                        v3 = row[i + 3 * kStatThreads];
+            s0 += v0 - pv; s1 += v1 - pv; s2 += v2 - pv; s3 += v3 - pv;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+            if ((++it & 63) == 0) {
+                sd += (double)((s0 + s1) + (s2 + s3));
+                s0 = s1 = s2 = s3 = 0.f;
+            }
+        }
+        for (; i < ns; i += kStatThreads) {
+            const float v = row[i];
+            s0 += v - pv;
+            mx = fmaxf(mx, fabsf(v));
+        }
     }
-    for (; i < ns; i += kStatThreads) {
-        const float v = row[i];
-        s0 += v;
-        mx = fmaxf(mx, fabsf(v));
-    }
-    float s = (s0 + s1) + (s2 + s3);
+    double s = sd + (double)((s0 + s1) + (s2 + s3));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         s += __shfl_xor(s, off);
@@ -248,12 +285,13 @@ __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restric
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float ts = 0.f, tm = 0.f;
+        double ts = 0.0;
+        float tm = 0.f;
         for (int w = 0; w < kStatThreads / 64; ++w) {
             ts += red_s[w];
             tm = fmaxf(tm, red_m[w]);
         }
-        mean[blockIdx.x] = ts / (float)ns;
+        mean[blockIdx.x] = (double)pv + ts / (double)ns;
         maxabs[blockIdx.x] = tm;
     }
 }
@@ -369,13 +407,13 @@ __global__ __launch_bounds__(kStatThreads) void raw2strain_rows_vec(const T* __r
 // Negligible for the fin-whale templates (|coef| ~ 5e-7) and applied by the host only when it matters.
 // =============================================================================================
 __global__ __launch_bounds__(kStatThreads) void xcorr_dc_tail(const float* __restrict__ x, int ns,
-                                                              const float* __restrict__ mean,
+                                                              const double* __restrict__ mean,
                                                               const float* __restrict__ maxabs, float coef, int L,
                                                               float* __restrict__ y) {
     __shared__ float wsum[kStatThreads / 64];
     const float* row = x + (size_t)blockIdx.x * ns;
     float* out = y + (size_t)blockIdx.x * ns;
-    const float m = mean ? mean[blockIdx.x] : 0.f;
+    const Mean2 m = mean2_load(mean, blockIdx.x);
     float g = 1.f;
     if (maxabs) {
         const float a = maxabs[blockIdx.x];
@@ -389,7 +427,7 @@ __global__ __launch_bounds__(kStatThreads) void xcorr_dc_tail(const float* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = j0 + 4 * tid + k;
-            v[k] = (j < ns) ? row[j] - m : 0.f;
+            v[k] = (j < ns) ? demean(row[j], m) : 0.f;
             loc += v[k];
         }
         float incl = loc;                                    // inclusive scan of the threads' sums
@@ -450,7 +488,7 @@ struct XcGeom {
 
 template <int NT, int R>
 __global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict__ x, int nx, int ns,
-                                                        const float* __restrict__ mean,
+                                                        const double* __restrict__ mean,
                                                         const float* __restrict__ maxabs,
                                                         const float* __restrict__ taps0,
                                                         const float* __restrict__ taps1, int l_both, int l_long,
@@ -466,7 +504,7 @@ __global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict_
     const int k0 = blockIdx.x * G::TILE;
     const float* pa = x + (size_t)rowA * ns;
     const float* pb = x + (size_t)rowB * ns;
-    const float ma = mean ? mean[rowA] : 0.f, mb = mean ? mean[rowB] : 0.f;
+    const Mean2 ma = mean2_load(mean, rowA), mb = mean2_load(mean, rowB);
     float ga = 1.f, gb = 1.f;
     if (maxabs) {
         const float a = maxabs[rowA], b = maxabs[rowB];
@@ -486,7 +524,7 @@ __global__ __launch_bounds__(kXcThreads) void xcorr_fir(const float* __restrict_
         for (int j = tid; j < need; j += kXcThreads) {
             const int i = k0 + n0 + j;
             float2 v = make_float2(0.f, 0.f);                 // beyond the row: zero padding
-            if (i < ns) v = make_float2(pa[i] - ma, pb[i] - mb);
+            if (i < ns) v = make_float2(demean(pa[i], ma), demean(pb[i], mb));
             const int f = j >> 1, q = f / H, rr = f - q * H;
             xs2[2 * (rr * PITCH + q) + (j & 1)] = v;
         }
@@ -597,7 +635,7 @@ static int sos_launch(int nsec, dim3 grid, void* stream, const SosArgsT<T>& A, c
 }
 
 template <int R>
-static int xcorr_launch(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps0,
+static int xcorr_launch(const float* x, int nx, int ns, const double* mean, const float* maxabs, const float* taps0,
                         const float* taps1, int ntpl, int l_both, int l_long, float* y0, float* y1, void* stream) {
     const dim3 grid(ceil_div(ns, XcGeom<R>::TILE), ceil_div(nx, 2));
     if (grid.y > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
@@ -711,7 +749,7 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
     return D4W_OK;
 }
 
-int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, double coef,
+int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs, double coef,
                           int support, float* y, void* stream) {
     if (!x || !y || nx < 1 || ns < 1 || support < 1) return fail(D4W_EINVAL, "bad argument");
     if (coef == 0.0 || support >= ns) return D4W_OK;
@@ -719,13 +757,13 @@ int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, con
     return D4W_OK;
 }
 
-int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream) {
+int d4w_row_stats_f32(const float* x, int nx, int ns, double* mean, float* maxabs, void* stream) {
     if (!x || !mean || !maxabs || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     D4W_LAUNCH(row_stats, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs);
     return D4W_OK;
 }
 
-int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
+int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs, const float* taps,
                        int ntpl, int ltaps, int len0, int len1, float* y0, float* y1, void* stream) {
     if (!x || !taps || !y0 || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
@@ -744,7 +782,7 @@ int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const 
     return xcorr_launch<8>(x, nx, ns, mean, maxabs, t0, t1, ntpl, l0, l1, y0, y1, stream);
 }
 
-int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
+int d4w_xcorr_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs, const float* taps,
                   int ntpl, int ltaps, float* y0, float* y1, void* stream) {
     return d4w_xcorr_lens_f32(x, nx, ns, mean, maxabs, taps, ntpl, ltaps, ltaps, ltaps, y0, y1, stream);
 }

@@ -1445,6 +1445,47 @@ __global__ __launch_bounds__(kSpThreads) void pack_picks(const int* __restrict__
     }
 }
 
+// Inclusive prefix sums of the per-row pick counts (what pack_picks places the rows by), their total and the largest count,
+// in ONE small launch: one workgroup, a run of consecutive rows per thread.  (torch.cumsum + max + stack: a rocprim scan, two
+// reductions and a concatenation per picker call before round 5.)
+constexpr int kOffThreads = 1024;
+__global__ __launch_bounds__(kOffThreads) void pick_offsets(const int* __restrict__ cnt, int nx, long long* __restrict__ off,
+                                                            long long* __restrict__ summary) {
+    __shared__ long long part[kOffThreads];
+    __shared__ int pmax[kOffThreads / 64];
+    const int tid = threadIdx.x;
+    const int per = (nx + kOffThreads - 1) / kOffThreads;
+    const int a = min(tid * per, nx), b = min(a + per, nx);
+    long long s = 0;
+    int m = 0;
+    for (int i = a; i < b; ++i) {
+        const int c = cnt[i];
+        s += c;
+        m = max(m, c);
+    }
+    part[tid] = s;
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) pmax[tid >> 6] = m;
+    __syncthreads();
+    for (int o = 1; o < kOffThreads; o <<= 1) {            // Hillis-Steele over the thread sums
+        const long long v = (tid >= o) ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    long long run = part[tid] - s;                         // exclusive prefix of this thread's rows
+    for (int i = a; i < b; ++i) {
+        run += cnt[i];
+        off[i] = run;
+    }
+    if (tid == 0) {
+        int mm = 0;
+        for (int w = 0; w < kOffThreads / 64; ++w) mm = max(mm, pmax[w]);
+        summary[0] = mm;
+        summary[1] = part[kOffThreads - 1];
+    }
+}
+
 }  // namespace d4w
 
 using namespace d4w;
@@ -1657,6 +1698,12 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
         D4W_LAUNCH(find_peaks_prom<false>, dim3(nx), dim3(kFpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
                    (int*)counts, cap);
     }
+    return D4W_OK;
+}
+
+int d4w_pick_offsets_i64(const int32_t* counts, int nx, int64_t* offsets, int64_t* summary2, void* stream) {
+    if (!counts || !offsets || !summary2 || nx < 1) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(pick_offsets, dim3(1), dim3(kOffThreads), 0, stream, (const int*)counts, nx, (long long*)offsets, (long long*)summary2);
     return D4W_OK;
 }
 

@@ -151,10 +151,13 @@ struct XfHalo {
 
 template <int NT, bool FUSED, bool HALO = false>      // HALO: a separate instantiation, the plain kernels keep their code
 __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
-                                                                  int ns, const float* __restrict__ mean,
+                                                                  int ns, const double* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1,
-                                                                  int step, int yshift, int ns_out, float dcg, XfHalo H) {
+                                                                  int step, int yshift, int ns_out, float dcg, XfHalo H,
+                                                                  const float* __restrict__ pivot) {
+    // mean: the rows' float64 means (matched filter); pivot: instead, a float32 value per row that is taken off the samples
+    // and given back through dcg (the zero-phase FIR's dynamic-range pivot, d4w_fir_fft_f32)
     // step = lags kept per block (B - (support - 1)); lags k < ns_out are stored, lag k at column k + yshift of its row
     // (the zero-phase FIR use, d4w_fir_fft_f32: taps centred at yshift); dcg: mean[row] * dcg is added to every output
     // (the gain the subtracted constant would have had)
@@ -177,7 +180,11 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     const int k0 = blockIdx.x * step;                           // first lag / first sample of the block
     const float* xa = x + (size_t)rowA * ns;
     const float* xb = x + (size_t)rowB * ns;
-    const float mua = mean ? mean[rowA] : 0.f, mub = mean ? mean[rowB] : 0.f;
+    Mean2 mua = mean2_load(mean, rowA), mub = mean2_load(mean, rowB);
+    if (pivot) {
+        mua.hi = pivot[rowA];
+        mub.hi = pivot[rowB];
+    }
     float ga_ = 1.f, gb_ = 1.f;
     if (maxabs) {
         const float a = maxabs[rowA], b = maxabs[rowB];
@@ -210,21 +217,21 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
         {
             const int j1 = tid;
             // sample c of the row in its own coordinates; outside [0, ns) the neighbours' halos (de-meaned alike), then zeros
-            auto sample = [&](const float* xr, int row, float mu, int c) -> float {
+            auto sample = [&](const float* xr, int row, Mean2 mu, int c) -> float {
                 if (HALO && c < 0) {
                     const int l = c + H.n_left;
-                    return (H.left && l >= 0) ? H.left[(size_t)row * H.ld_left + l] - mu : 0.f;
+                    return (H.left && l >= 0) ? demean(H.left[(size_t)row * H.ld_left + l], mu) : 0.f;
                 }
-                if (c < ns) return xr[c] - mu;
+                if (c < ns) return demean(xr[c], mu);
                 const int rr = c - ns;
-                return (HALO && H.right && rr < H.n_right) ? H.right[(size_t)row * H.ld_right + rr] - mu : 0.f;
+                return (HALO && H.right && rr < H.n_right) ? demean(H.right[(size_t)row * H.ld_right + rr], mu) : 0.f;
             };
-            auto fetch = [&](const float* xr, int row, float mu, bool vec, int i) -> float2 {
+            auto fetch = [&](const float* xr, int row, Mean2 mu, bool vec, int i) -> float2 {
                 const int c = HALO ? i + H.v0 - H.n_left : i;
                 if (vec && (!HALO || c >= 0) && c + 1 < ns) {
                     float2 v = *reinterpret_cast<const float2*>(xr + c);
-                    v.x -= mu;
-                    v.y -= mu;
+                    v.x = demean(v.x, mu);
+                    v.y = demean(v.y, mu);
                     return v;
                 }
                 return make_float2(sample(xr, row, mu, c), sample(xr, row, mu, c + 1));
@@ -233,23 +240,23 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
             } else if (interior) {
                 const float2* pa = reinterpret_cast<const float2*>(xa + c0) + j1;
                 const float2* pb = reinterpret_cast<const float2*>(xb + c0) + j1;
-                const v2f mu2 = v2_make(mua, mub);
+                const v2f mu2 = v2_make(mua.hi, mub.hi), mu2l = v2_make(mua.lo, mub.lo);
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
                     const float2 va = pa[a * M1], vb = pb[a * M1];
-                    pf[a] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+                    pf[a] = c2{v2_sub(v2_sub(v2_make(va.x, vb.x), mu2), mu2l), v2_sub(v2_sub(v2_make(va.y, vb.y), mu2), mu2l)};
                 });
             } else if (HALO && veca && vecb && ns >= 4) {
                 // a block that straddles a file boundary: most of its samples are still in the row -- their 8-byte loads
                 // go out together (clamped addresses), the few samples beyond the row are fetched one by one afterwards
-                const v2f mu2 = v2_make(mua, mub);
+                const v2f mu2 = v2_make(mua.hi, mub.hi), mu2l = v2_make(mua.lo, mub.lo);
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
                     // clamped to the row without changing the parity of the index (the pairs stay 8-byte aligned)
                     const int par = c0 & 1, c = c0 + 2 * (j1 + a * M1), cc = par + (min(max(c - par, 0), ns - 2 - par) & ~1);
                     const float2 va = *reinterpret_cast<const float2*>(xa + cc);
                     const float2 vb = *reinterpret_cast<const float2*>(xb + cc);
-                    pf[a] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+                    pf[a] = c2{v2_sub(v2_sub(v2_make(va.x, vb.x), mu2), mu2l), v2_sub(v2_sub(v2_make(va.y, vb.y), mu2), mu2l)};
                 });
                 static_for<NA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
             idftp<NA>(v);
             float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * ns + yshift;
             float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * ns + yshift;
-            const v2f dc = v2_make(mua * dcg, mub * dcg);
+            const v2f dc = v2_make((mua.hi + mua.lo) * dcg, (mub.hi + mub.lo) * dcg);
             // stores: with neighbours (HALO) the block's lags can all lie inside the output although its samples straddle a
             // file boundary -- the wide store path is chosen from the output's own geometry then
             const bool oveca = HALO ? ((((long long)rowA * ns + yshift + k0) & 1) == 0) : veca;
@@ -461,7 +468,7 @@ __device__ __forceinline__ void xf_tpair(float2 A, float2 Bs, float2 w, c2 gf, c
 }
 
 __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, const float* __restrict__ x, int ns,
-                                                                 const float* __restrict__ mean,
+                                                                 const double* __restrict__ mean,
                                                                  const float* __restrict__ maxabs,
                                                                  float* __restrict__ y0, float* __restrict__ y1) {
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, con
     const int row = blockIdx.y;
     const int k0 = blockIdx.x * kXfStep;
     const float* xr = x + (size_t)row * ns;
-    const float mu = mean ? mean[row] : 0.f;
+    const Mean2 mu = mean2_load(mean, row);
     float gain = 1.f;
     if (maxabs) {
         const float a = maxabs[row];
@@ -494,15 +501,15 @@ __global__ __launch_bounds__(kXfThreads, 2) void xcorr_fft_tpair(XfTables T, con
             static_for<NA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
                 const float2 v = pa[a * M1];
-                pf[a] = make_float2(v.x - mu, v.y - mu);
+                pf[a] = make_float2(demean(v.x, mu), demean(v.y, mu));
             });
         } else {
             static_for<NA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
                 const int i = k0 + 2 * (j1 + a * M1);
                 float2 v = make_float2(0.f, 0.f);
-                if (i < ns) v.x = xr[i] - mu;
-                if (i + 1 < ns) v.y = xr[i + 1] - mu;
+                if (i < ns) v.x = demean(xr[i], mu);
+                if (i + 1 < ns) v.y = demean(xr[i + 1], mu);
                 pf[a] = v;
             });
         }
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(256) void xcf_tables4(const float* __restrict__ tap
 
 template <bool CONT>      // CONT: the rows continue in xnext (a separate instantiation: the plain kernel keeps its registers)
 __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, const float* __restrict__ x, int nx, int ns,
-                                                                    const float* __restrict__ mean,
+                                                                    const double* __restrict__ mean,
                                                                     const float* __restrict__ maxabs,
                                                                     float* __restrict__ y0, float* __restrict__ y1,
                                                                     const float* __restrict__ xnext, int ld_next, int n_next) {
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
     const int k0 = blockIdx.x * kXfStep;
     const float* xa = x + (size_t)rowA * ns;
     const float* xb = x + (size_t)rowB * ns;
-    const float mua = mean ? mean[rowA] : 0.f, mub = mean ? mean[rowB] : 0.f;
+    const Mean2 mua = mean2_load(mean, rowA), mub = mean2_load(mean, rowB);
     float ga_ = 1.f, gb_ = 1.f;
     if (maxabs) {
         const float a = maxabs[rowA], b = maxabs[rowB];
@@ -796,16 +803,16 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
     if (fwd) {
         // beyond the row: the first n_next samples of the record's continuation (the next file's rows, pitch ld_next),
         // de-meaned like the row's own samples, then zeros
-        auto sample = [&](const float* xr, const float* xn, float mu, int i) -> float {
-            if (i < ns) return xr[i] - mu;
-            if (CONT && i - ns < n_next) return xn[i - ns] - mu;
+        auto sample = [&](const float* xr, const float* xn, Mean2 mu, int i) -> float {
+            if (i < ns) return demean(xr[i], mu);
+            if (CONT && i - ns < n_next) return demean(xn[i - ns], mu);
             return 0.f;
         };
-        auto fetch = [&](const float* xr, const float* xn, float mu, bool vec, int i) -> float2 {
+        auto fetch = [&](const float* xr, const float* xn, Mean2 mu, bool vec, int i) -> float2 {
             if (vec && i + 1 < ns) {
                 float2 v = *reinterpret_cast<const float2*>(xr + i);
-                v.x -= mu;
-                v.y -= mu;
+                v.x = demean(v.x, mu);
+                v.y = demean(v.y, mu);
                 return v;
             }
             return make_float2(sample(xr, xn, mu, i), sample(xr, xn, mu, i + 1));
@@ -815,23 +822,23 @@ __global__ __launch_bounds__(2 * kX4Items, 4) void xcorr_fft_fused4(X4Tables T, 
         if (interior) {
             const float2* pa = reinterpret_cast<const float2*>(xa + k0) + tid;
             const float2* pb = reinterpret_cast<const float2*>(xb + k0) + tid;
-            const v2f mu2 = v2_make(mua, mub);
+            const v2f mu2 = v2_make(mua.hi, mub.hi), mu2l = v2_make(mua.lo, mub.lo);
             static_for<8>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 const float2 va = pa[q * 256], vb = pb[q * 256];
-                pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+                pf[q] = c2{v2_sub(v2_sub(v2_make(va.x, vb.x), mu2), mu2l), v2_sub(v2_sub(v2_make(va.y, vb.y), mu2), mu2l)};
             });
         } else if (veca && vecb && ns >= 4) {
             // the last block of a row (a quarter of all blocks for 12 000-sample rows): the samples still inside the row go out
             // as 8-byte loads together (clamped addresses), the ones beyond it are fetched one by one afterwards
-            const v2f mu2 = v2_make(mua, mub);
+            const v2f mu2 = v2_make(mua.hi, mub.hi), mu2l = v2_make(mua.lo, mub.lo);
             const int par = k0 & 1;
             static_for<8>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 const int i = k0 + 2 * (tid + q * 256), ic = par + (min(max(i - par, 0), ns - 2 - par) & ~1);
                 const float2 va = *reinterpret_cast<const float2*>(xa + ic);
                 const float2 vb = *reinterpret_cast<const float2*>(xb + ic);
-                pf[q] = c2{v2_sub(v2_make(va.x, vb.x), mu2), v2_sub(v2_make(va.y, vb.y), mu2)};
+                pf[q] = c2{v2_sub(v2_sub(v2_make(va.x, vb.x), mu2), mu2l), v2_sub(v2_sub(v2_make(va.y, vb.y), mu2), mu2l)};
             });
             static_for<8>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
@@ -1031,12 +1038,12 @@ int d4w_xcorr_fft_max_support(void) { return kXfPad + 1; }
 
 size_t d4w_xcorr_fft_ws_bytes(void) { return (kXfWsFloats + kX4WsFloats) * sizeof(float); }
 
-int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs, const float* taps,
+int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs, const float* taps,
                       int ntpl, int ltaps, int len0, int len1, float* y0, float* y1, void* ws, void* stream) {
     return d4w_xcorr_fft_cont_f32(x, nx, ns, nullptr, 0, 0, mean, maxabs, taps, ntpl, ltaps, len0, len1, y0, y1, ws, stream);
 }
 
-int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const float* mean,
+int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
                            const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                            float* y1, void* ws, void* stream) {
     if (!x || !y0 || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
@@ -1119,7 +1126,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,
-                   kXfStep, 0, ns, 0.f, XfHalo{});
+                   kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr);
         return D4W_OK;
     }
     for (int t = 0; t < ntpl; ++t) {
@@ -1127,7 +1134,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
         D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
-                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{});
+                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr);
     }
     return D4W_OK;
 }
@@ -1162,8 +1169,8 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
     const dim3 grid(ceil_div(ns - 2 * K, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
-               (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain, XfHalo{});
+    D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
+               (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain, XfHalo{}, first);
     return D4W_OK;
 }
 
@@ -1195,8 +1202,8 @@ int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int 
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
-    D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, first, (const float*)nullptr, y,
-               (float*)nullptr, step, 0, ns, (float)dc_gain, H);
+    D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
+               (float*)nullptr, step, 0, ns, (float)dc_gain, H, first);
     return D4W_OK;
 }
 

@@ -45,7 +45,10 @@ namespace d4w {
 constexpr int kMmCH = D4W_MM_CH;                 // lags per chunk (8192 measured: see DESIGN 3.3)
 constexpr int kMmKS = 6;                         // k-steps of 32 of the two-template kernels -> Toeplitz depth 192, supports <= 177
 constexpr int kMmKSLong = 8;                     // ... of the one-template kernel for longer supports: depth 256, supports <= 241
+constexpr int kMmKSMax = 16;                     // deepest one-template kernel: depth 512, a SECTION of <= 497 taps (128 VGPRs of fragments)
+constexpr int kMmSection = 32 * kMmKSMax - 16;   // taps per section of a longer template (a multiple of 16: shifted loads stay 16-byte aligned)
 constexpr int kMmMaxSupport = 32 * kMmKSLong - 15;
+constexpr int kMmMaxSections = 16;               // templates of up to 16 x 496 taps run section by section (one accumulate launch each)
 constexpr int kMmThreads = 256;
 // geometry of a chunk for a Toeplitz depth of KSM k-steps
 template <int KSM>
@@ -65,12 +68,14 @@ __host__ __device__ constexpr int mm_pidx(int h) { return h; }
 struct MmArgs {
     const float* x;         // [nx][ns]
     const float* xnext;     // [nx][ld_next] or NULL: the record's continuation (first n_next samples of every row)
-    const float* mean;      // [nx] or NULL
+    const double* mean;     // [nx] float64 row means or NULL (consumed as a two-float value, d4w_internal.h Mean2)
     const float* maxabs;    // [nx] or NULL: the 1 / max|x| of the normalisation (output scale only)
     const float* taps;      // [ntpl][ltaps]
     float* y0;
     float* y1;
     int nx, ns, ld_next, n_next, ltaps, len0, len1;
+    int shift;              // the taps given are taps [shift, shift + len0) of a longer template: lag k reads x[k + shift + n]
+    int accumulate;         // add to y0 instead of overwriting it (the later sections of a long template)
 };
 
 // KS0 / KS1: k-steps of template 0 / 1 (KS1 = 0: one template); WPS: workgroups per compute unit the registers are budgeted for
@@ -135,57 +140,61 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     const long long lo_c = total * xcd / nparts, hi_c = total * (xcd + 1) / nparts;
 
     float4 pre[kMmQ];                                               // the chunk being loaded (raw samples)
-    float mu_n = 0.f, g_n = 1.f;                                    // its row's mean and 1 / maxabs
+    Mean2 mu_n{0.f, 0.f};                                           // its row's mean (hi + lo) ...
+    float g_n = 1.f;                                                // ... and 1 / maxabs
+    bool tail_n = false;                                            // the chunk reaches beyond the row (wave-uniform)
     long long c_n = lo_c + wq;
     int row_n = 0, c0_n = 0;
 
     auto issue = [&](long long c) {                                 // global loads of chunk c into pre[]
         row_n = (int)(c / nchunk);
         c0_n = (int)(c - (long long)row_n * nchunk) * kMmCH;
-        mu_n = P.mean ? P.mean[row_n] : 0.f;
+        mu_n = mean2_load(P.mean, row_n);
         g_n = 1.f;
+        const int s0 = c0_n + P.shift;                              // first sample of the chunk's stage
+        tail_n = s0 + kMmStage > ns;
         if (P.maxabs) {
             const float a = P.maxabs[row_n];
             g_n = (a > 0.f) ? 1.0f / a : 0.f;
         }
         const float* xr = P.x + (size_t)row_n * ns;
-        const bool al = (reinterpret_cast<uintptr_t>(xr + c0_n) & 15) == 0;
-        if (al && c0_n + kMmStage <= ns) {
-            const float4* p = reinterpret_cast<const float4*>(xr + c0_n) + tid;
+        const bool al = (reinterpret_cast<uintptr_t>(xr + s0) & 15) == 0;
+        if (al && s0 + kMmStage <= ns) {
+            const float4* p = reinterpret_cast<const float4*>(xr + s0) + tid;
             static_for<kMmQ>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 if (q < kMmQ - 1 || tid < kMmLastQ) pre[q] = mm_load4_stream(p + q * kMmThreads);
             });
         } else {
             // a row end, an unaligned row, or the record's continuation.  Clamped addresses and selects instead of branches, so
-            // that a lane's loads go out together; what lies beyond the data is filled with the row mean, which the
-            // de-meaning turns into the exact zero of the zero-padded correlation
+            // that a lane's loads go out together; what lies beyond the data (filled with the mean's high part here) is set to
+            // the exact zero of the zero-padded correlation after the de-meaning, by index (tail chunks only)
             if (al && (ns & 3) == 0) {                              // every 16-byte group lies inside the row or beyond it
                 static_for<kMmQ>([&](auto qq) {
                     constexpr int q = decltype(qq)::value;
                     if (q < kMmQ - 1 || tid < kMmLastQ) {
-                        const int i = c0_n + 4 * (tid + q * kMmThreads);
+                        const int i = s0 + 4 * (tid + q * kMmThreads);
                         const float4 v = *reinterpret_cast<const float4*>(xr + min(i, ns - 4));
-                        pre[q] = (i < ns) ? v : make_float4(mu_n, mu_n, mu_n, mu_n);
+                        pre[q] = (i < ns) ? v : make_float4(mu_n.hi, mu_n.hi, mu_n.hi, mu_n.hi);
                     }
                 });
             } else {
                 static_for<kMmQ>([&](auto qq) {
                     constexpr int q = decltype(qq)::value;
                     if (q < kMmQ - 1 || tid < kMmLastQ) {
-                        const int i = c0_n + 4 * (tid + q * kMmThreads);
+                        const int i = s0 + 4 * (tid + q * kMmThreads);
                         const float a0 = xr[min(i, ns - 1)], a1 = xr[min(i + 1, ns - 1)], a2 = xr[min(i + 2, ns - 1)], a3 = xr[min(i + 3, ns - 1)];
-                        pre[q] = make_float4(i < ns ? a0 : mu_n, i + 1 < ns ? a1 : mu_n, i + 2 < ns ? a2 : mu_n, i + 3 < ns ? a3 : mu_n);
+                        pre[q] = make_float4(i < ns ? a0 : mu_n.hi, i + 1 < ns ? a1 : mu_n.hi, i + 2 < ns ? a2 : mu_n.hi, i + 3 < ns ? a3 : mu_n.hi);
                     }
                 });
             }
-            if (P.xnext && P.n_next > 0 && c0_n + kMmStage > ns) {  // the head of the next file behind the row
+            if (P.xnext && P.n_next > 0 && s0 + kMmStage > ns) {    // the head of the next file behind the row
                 const float* xn = P.xnext + (size_t)row_n * P.ld_next;
                 const int n_next = P.n_next;
                 static_for<kMmQ>([&](auto qq) {
                     constexpr int q = decltype(qq)::value;
                     if (q < kMmQ - 1 || tid < kMmLastQ) {
-                        const int d = c0_n + 4 * (tid + q * kMmThreads) - ns;
+                        const int d = s0 + 4 * (tid + q * kMmThreads) - ns;
                         const float b0 = xn[min(max(d, 0), n_next - 1)], b1 = xn[min(max(d + 1, 0), n_next - 1)];
                         const float b2 = xn[min(max(d + 2, 0), n_next - 1)], b3 = xn[min(max(d + 3, 0), n_next - 1)];
                         if (d >= 0 && d < n_next) pre[q].x = b0;
@@ -202,7 +211,9 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     int buf = 0;
     for (long long c = c_n; c < hi_c; c += nq) {
         const int row = row_n, c0 = c0_n;
-        const float mu = mu_n;
+        const Mean2 mu = mu_n;
+        const bool tail = tail_n;
+        const int n_valid = ns + ((P.xnext && P.n_next > 0) ? P.n_next : 0) - c0 - P.shift;     // samples of the stage that exist
         float gsc = g_n, osx = 1.f;                                 // x scale applied before the split, and what undoes it
         mm_half* bh = lds + (size_t)buf * 2 * kMmArr;
         mm_half* bl = bh + kMmArr;
@@ -217,7 +228,15 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 constexpr int q = decltype(qq)::value;
                 if (q < kMmQ - 1 || tid < kMmLastQ) {
                     const float4 v = pre[q];
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x - mu), fabsf(v.y - mu))), fmaxf(fabsf(v.z - mu), fabsf(v.w - mu)));
+                    const int at = 4 * (tid + q * kMmThreads);
+                    float d0 = demean(v.x, mu), d1 = demean(v.y, mu), d2 = demean(v.z, mu), d3 = demean(v.w, mu);
+                    if (tail) {
+                        if (at >= n_valid) d0 = 0.f;
+                        if (at + 1 >= n_valid) d1 = 0.f;
+                        if (at + 2 >= n_valid) d2 = 0.f;
+                        if (at + 3 >= n_valid) d3 = 0.f;
+                    }
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
                 }
             });
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -230,7 +249,14 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             constexpr int q = decltype(qq)::value;
             if (q < kMmQ - 1 || tid < kMmLastQ) {
                 const float4 v = pre[q];
-                const float s[4] = {(v.x - mu) * gsc, (v.y - mu) * gsc, (v.z - mu) * gsc, (v.w - mu) * gsc};
+                float s[4] = {demean(v.x, mu) * gsc, demean(v.y, mu) * gsc, demean(v.z, mu) * gsc, demean(v.w, mu) * gsc};
+                // caller-supplied statistics (or the next file's head) may leave |v| beyond binary16's range: inf - inf would turn
+                // a whole tile into NaN where the float32 forms stay finite; the clamp is one v_med3_f32
+                if (P.maxabs) static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; s[e] = mm_clamp_half(s[e]); });
+                if (tail) {                                          // beyond the data: the zero padding of the correlation
+                    const int a0 = 4 * (tid + q * kMmThreads);
+                    static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; if (a0 + e >= n_valid) s[e] = 0.f; });
+                }
                 mm_half h[4], l[4];
                 static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
                 const int at = mm_pidx(4 * (tid + q * kMmThreads));
@@ -291,12 +317,16 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 });
                 c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
                 if (valign && k + 3 < ns) {
+                    if (KS1 == 0 && P.accumulate) {                 // a later section of a long template
+                        const float4 o = mm_load4_stream(reinterpret_cast<const float4*>(ya + k));
+                        r0[0] += o.x; r0[1] += o.y; r0[2] += o.z; r0[3] += o.w;
+                    }
                     mm_store4(ya + k, r0[0], r0[1], r0[2], r0[3]);
                     if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
                 } else {                                            // a row end or an unaligned row (tiles beyond the row: nothing)
                     for (int r = 0; r < 4; ++r)
                         if (k + r < ns) {
-                            ya[k + r] = r0[r];
+                            ya[k + r] = (KS1 == 0 && P.accumulate) ? ya[k + r] + r0[r] : r0[r];
                             if constexpr (KS1 > 0) yb[k + r] = r1[r];
                         }
                 }
@@ -312,50 +342,74 @@ using namespace d4w;
 
 extern "C" {
 
-int d4w_xcorr_mm_max_support(void) { return kMmMaxSupport; }
+int d4w_xcorr_mm_max_support(void) { return kMmSection * kMmMaxSections; }
 
-int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const float* mean,
+// one template of any support <= d4w_xcorr_mm_max_support(): sections of kMmSection taps, the first one overwriting y, the
+// later ones (x shifted by the section's first tap) accumulating into it
+static int mm_one_template(MmArgs P, const float* taps, int len, float* y, int grid, void* stream) {
+    auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
+    const int nsec = (len <= 32 * kMmKSMax - 15) ? 1 : ceil_div(len, kMmSection);
+    // sections of equal length (a multiple of 16 taps, so that the shifted 16-byte loads stay aligned): 700 taps run as
+    // 352 + 348 through the 12-step kernel twice instead of 496 + 204 through the 16- and the 8-step kernels
+    const int per = (nsec == 1) ? len : 16 * ceil_div(ceil_div(len, nsec), 16);
+    for (int j = 0; j < nsec; ++j) {
+        const int first = j * per;
+        MmArgs Q = P;
+        Q.taps = taps + first;
+        Q.len0 = Q.len1 = std::min(per, len - first);
+        Q.y0 = y;
+        Q.y1 = nullptr;
+        Q.shift = first;
+        Q.accumulate = j > 0;
+        const int ks = ceil_div(Q.len0 + 15, 32);
+        if (ks <= kMmKS)
+            D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr), stream, Q);
+        else if (ks <= kMmKSLong)
+            D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, Q);
+        else if (ks <= 12)
+            D4W_LAUNCH((xcorr_mm_rows<12, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<12>::Arr), stream, Q);
+        else
+            D4W_LAUNCH((xcorr_mm_rows<kMmKSMax, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSMax>::Arr), stream, Q);
+    }
+    return D4W_OK;
+}
+
+int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
                      const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0, float* y1,
                      void* stream) {
     if (!x || !y0 || !taps || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
     if (xnext && (n_next < 0 || ld_next < n_next)) return fail(D4W_EINVAL, "a continuation needs 0 <= n_next <= ld_next");
     if (ntpl == 1) len1 = len0;
-    if (len0 < 1 || len1 < 1 || len0 > ltaps || len1 > ltaps || std::max(len0, len1) > kMmMaxSupport)
-        return fail(D4W_EINVAL, "template supports (%d, %d) must lie in 1..min(ltaps = %d, %d)", len0, len1, ltaps, kMmMaxSupport);
+    if (len0 < 1 || len1 < 1 || len0 > ltaps || len1 > ltaps || std::max(len0, len1) > d4w_xcorr_mm_max_support())
+        return fail(D4W_EINVAL, "template supports (%d, %d) must lie in 1..min(ltaps = %d, %d)", len0, len1, ltaps, d4w_xcorr_mm_max_support());
     MmArgs P;
     P.x = x; P.xnext = xnext; P.mean = mean; P.maxabs = maxabs; P.taps = taps; P.y0 = y0; P.y1 = y1;
     P.nx = nx; P.ns = ns; P.ld_next = ld_next; P.n_next = xnext ? n_next : 0; P.ltaps = ltaps; P.len0 = len0; P.len1 = len1;
+    P.shift = 0; P.accumulate = 0;
     const long long total = (long long)nx * ceil_div(ns, kMmCH);
     // persistent workgroups per compute unit: 2 for two templates (207 VGPRs: the Toeplitz fragments of both templates stay
     // in registers; a 168-register build for three workgroups spills and ran 8.5 ms against 6.6), 3 for one template
-    // (149 VGPRs).  D4W_MM_WGS overrides the count (measurements).
+    // (149 VGPRs), 2 for the deeper one-template kernels.  D4W_MM_WGS overrides the count (measurements).
     static const int env_wgs = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 0; return n < 0 ? 0 : (n > 8 ? 8 : n); }();
-    const int per_cu = env_wgs ? env_wgs : (ntpl == 1 ? 3 : 2);
+    const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
+    const bool fused = ntpl == 2 && std::max(ks0, ks1) <= kMmKS;
+    const int per_cu = env_wgs ? env_wgs : ((ntpl == 1 && ks0 <= kMmKS) ? 3 : 2);
     const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
-    const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
-    auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
-    if (ntpl == 2 && std::max(ks0, ks1) > kMmKS) {
-        // a support beyond 177 samples: the two templates one after the other through the one-template kernel (its Toeplitz
-        // fragments alone fill the registers the fused kernel splits between two templates)
-        MmArgs P1 = P;
-        P1.taps = taps + ltaps; P1.len0 = len1; P1.y0 = y1; P1.y1 = nullptr;
-        P.y1 = nullptr;
-        D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, P);
-        D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, P1);
-        return D4W_OK;
+    if (!fused) {
+        // one template, or a support beyond 177 samples: the templates one after the other through the one-template kernels
+        // (the Toeplitz fragments of one template alone fill the registers the fused kernel splits between two)
+        int rc = mm_one_template(P, taps, len0, y0, grid, stream);
+        if (rc == D4W_OK && ntpl == 2) rc = mm_one_template(P, taps + ltaps, len1, y1, grid, stream);
+        return rc;
     }
+    auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
     const size_t lds = lds_of(MmGeom<kMmKS>::Arr);
-    if (ntpl == 1 && ks0 > kMmKS)
-        D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, P);
-    else if (ntpl == 1)
-        D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds, stream, P);
-    else if (ks0 <= 5)
+    if (ks0 <= 5)
         D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
     else
         D4W_LAUNCH((xcorr_mm_rows<kMmKS, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
-    (void)ks1;
     return D4W_OK;
 }
 

@@ -77,6 +77,9 @@ class PinnedIngest:
         self._host = [torch.empty(self.shape, dtype=tdt).pin_memory() for _ in range(depth)]
         self._dev = [torch.empty(self.shape, dtype=tdt, device=self.device) for _ in range(depth)]
         self._copy = torch.cuda.Stream(self.device)
+        # the device buffers come from the caching allocator on the CURRENT stream: a recycled block may still be read by kernels
+        # queued there, and the first upload of a slot waits on nothing else -- order the copy stream behind them
+        self._copy.wait_stream(torch.cuda.current_stream(self.device))
         self._ready = [torch.cuda.Event() for _ in range(depth)]        # the upload of slot s has completed
         self._free = [torch.cuda.Event() for _ in range(depth)]         # the device copy of slot s has been consumed
         self._uploaded = [False] * depth

@@ -96,7 +96,7 @@ def _row_stats_cached(x):
         if ent is not None and ent[0]() is x and ent[1] == x._version:
             return ent[2]
     with torch.cuda.device(x.device):
-        mean = torch.empty(nx, dtype=torch.float32, device=x.device)
+        mean = torch.empty(nx, dtype=torch.float64, device=x.device)      # float64 (hi + lo for the kernels): d4w.h
         mx = torch.empty(nx, dtype=torch.float32, device=x.device)
         check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))
     with _cache_lock:
@@ -107,18 +107,33 @@ def _row_stats_cached(x):
 
 
 def _xcorr_method(taps_list, ns, method):
-    """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores, supports <= 241 samples, the
+    """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores: two templates of <= 177 samples in
+    one launch, one template of <= 497 per launch, longer ones in 496-tap sections up to d4w_xcorr_mm_max_support(); the
     default), "fft" (overlap-save, supports <= 161, rows >= 1024 samples) or "direct" (any support).  D4W_XCORR_METHOD
     overrides "auto" (measurements, A/B tests)."""
     import os
+    import warnings
+    explicit = method != "auto"
     if method == "auto":
         method = os.environ.get("D4W_XCORR_METHOD", "auto")
+    if method not in ("auto", "mm", "fft", "direct"):
+        raise ValueError("method must be 'auto', 'mm', 'fft' or 'direct', not %r" % (method,))
     longest = max(len(t) for t in taps_list)
-    if method == "mm" or (method == "auto" and longest <= int(lib.d4w_xcorr_mm_max_support())):
-        if longest > int(lib.d4w_xcorr_mm_max_support()):
+    mm_ok = longest <= int(lib.d4w_xcorr_mm_max_support())
+    fft_ok = ns >= 1024 and longest <= int(lib.d4w_xcorr_fft_max_support())
+    if method == "mm" and not mm_ok:
+        if explicit:
             raise ValueError("the matrix-core correlation takes supports <= %d samples" % int(lib.d4w_xcorr_mm_max_support()))
+        warnings.warn("D4W_XCORR_METHOD=mm does not apply to a support of %d samples: choosing the form as 'auto' does" % longest)
+        method = "auto"
+    if method == "fft" and not fft_ok:
+        # an override the shape does not admit falls back like 'auto' instead of surfacing as EINVAL from the C side
+        warnings.warn("the overlap-save FFT correlation needs rows >= 1024 samples and supports <= %d (got %d, %d): "
+                      "choosing the form as 'auto' does" % (int(lib.d4w_xcorr_fft_max_support()), ns, longest))
+        method = "auto"
+    if method == "mm" or (method == "auto" and mm_ok):
         return "mm"
-    if method == "fft" or (method == "auto" and ns >= 1024 and longest <= int(lib.d4w_xcorr_fft_max_support())):
+    if method == "fft" or (method == "auto" and fft_ok):
         return "fft"
     return "direct"
 
@@ -141,6 +156,9 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
         mean = mx = None
         if normalize and stats is not None:
             mean, mx = stats
+            if (mean.dtype != torch.float64 or mx.dtype != torch.float32 or mean.numel() < nx or mx.numel() < nx
+                    or not mean.is_contiguous() or not mx.is_contiguous()):
+                raise ValueError("stats = (float64 row means, float32 row maxima), one contiguous value per row (d4w_row_stats_f32)")
         elif normalize:
             mean, mx = _row_stats_cached(x)
         for i in range(0, len(taps_list), 2):                      # two templates per read of x
@@ -270,7 +288,7 @@ def compute_cross_correlograms(data, templates, exact_tail=None):
         if need and c != 0.0:
             with torch.cuda.device(xd.device):
                 check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(xd), nx, ns, dev.ptr(stats[0]), dev.ptr(stats[1]), c, len(tp),
-                                                dev.ptr(o), dev.stream_ptr(xd)))
+                                                dev.out_ptr(o), dev.stream_ptr(xd)))
     return [dev.like_input(o, data) for o in outs]
 
 
@@ -369,8 +387,10 @@ def _find_peaks_device(c, threshold, cap0=1024):
             cnt = torch.empty(nx, dtype=torch.int32, device=c.device)
             check(lib.d4w_find_peaks_f32(dev.ptr(c), nx, ns, float(threshold), dev.ptr(idx), dev.ptr(cnt), cap,
                                          dev.stream_ptr(c)))
-            off = torch.cumsum(cnt, 0, dtype=torch.int64)
-            need, total = (int(v) for v in torch.stack((cnt.max().to(torch.int64), off[-1])).cpu())
+            off = torch.empty(nx, dtype=torch.int64, device=c.device)
+            summ = torch.empty(2, dtype=torch.int64, device=c.device)
+            check(lib.d4w_pick_offsets_i64(dev.ptr(cnt), nx, dev.ptr(off), dev.ptr(summ), dev.stream_ptr(c)))
+            need, total = (int(v) for v in summ.cpu())           # the call's one host synchronisation (a 16-byte copy)
             _PICK_CAP[(nx, ns)] = need + need // 4 + 16 if need > cap0 else 0
             if need <= cap:
                 break

@@ -136,7 +136,7 @@ class FkPlan:
         if out is None:
             out = torch.empty_like(x)
         with torch.cuda.device(self.device):
-            check(lib.d4w_fk_apply_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.stream_ptr(x)))
+            check(lib.d4w_fk_apply_f32(self._h, dev.ptr(x), dev.out_ptr(out), int(bool(taper)), dev.stream_ptr(x)))
         return out
 
     def apply_stats(self, x, out=None, taper=False, timed=False):
@@ -147,15 +147,15 @@ class FkPlan:
             raise ValueError("trace shape %s does not match the plan (%d, %d)" % (tuple(x.shape), self.nx, self.ns))
         if out is None:
             out = torch.empty_like(x)
-        mean = torch.empty(self.nx, dtype=torch.float32, device=x.device)
+        mean = torch.empty(self.nx, dtype=torch.float64, device=x.device)      # float64: include/d4w.h, d4w_row_stats_f32
         mx = torch.empty(self.nx, dtype=torch.float32, device=x.device)
         with torch.cuda.device(self.device):
             if timed:
                 ms = (ctypes.c_float * 5)()
-                check(lib.d4w_fk_apply_timed_stats_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.ptr(mean),
+                check(lib.d4w_fk_apply_timed_stats_f32(self._h, dev.ptr(x), dev.out_ptr(out), int(bool(taper)), dev.ptr(mean),
                                                        dev.ptr(mx), dev.stream_ptr(x), ms))
                 return out, mean, mx, list(ms)
-            check(lib.d4w_fk_apply_stats_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.ptr(mean),
+            check(lib.d4w_fk_apply_stats_f32(self._h, dev.ptr(x), dev.out_ptr(out), int(bool(taper)), dev.ptr(mean),
                                              dev.ptr(mx), dev.stream_ptr(x)))
         return out, mean, mx
 
@@ -165,7 +165,7 @@ class FkPlan:
             out = torch.empty_like(x)
         ms = (ctypes.c_float * 5)()
         with torch.cuda.device(self.device):
-            check(lib.d4w_fk_apply_timed_f32(self._h, dev.ptr(x), dev.ptr(out), int(bool(taper)), dev.stream_ptr(x), ms))
+            check(lib.d4w_fk_apply_timed_f32(self._h, dev.ptr(x), dev.out_ptr(out), int(bool(taper)), dev.stream_ptr(x), ms))
         return out, list(ms)
 
     def __del__(self):
@@ -312,7 +312,7 @@ fk_filter = fk_filter_filt      # north-star spelling
 def taper_data(trace):
     """trace *= tukey(ns, 0.03) along time, IN PLACE like the reference -- dsp.py:705-722."""
     if dev.is_tensor(trace) and trace.is_cuda and trace.dtype == torch.float32 and trace.is_contiguous():
-        check(lib.d4w_taper_f32(dev.ptr(trace), trace.shape[0], trace.shape[1], dev.stream_ptr(trace)))
+        check(lib.d4w_taper_f32(dev.out_ptr(trace), trace.shape[0], trace.shape[1], dev.stream_ptr(trace)))
         return trace
     x = dev.to_device_f32(trace)
     check(lib.d4w_taper_f32(dev.ptr(x), x.shape[0], x.shape[1], dev.stream_ptr(x)))

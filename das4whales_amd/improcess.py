@@ -38,7 +38,7 @@ def _scale_pixels_device(x, gain, out=None):
     y = torch.empty_like(x) if out is None else out
     with torch.cuda.device(x.device):
         mm = _minmax(x)
-        check(lib.d4w_scale_pixels_f32(dev.ptr(x), dev.ptr(y), _n(x), dev.ptr(mm), float(gain), dev.stream_ptr(x)))
+        check(lib.d4w_scale_pixels_f32(dev.ptr(x), dev.out_ptr(y), _n(x), dev.ptr(mm), float(gain), dev.stream_ptr(x)))
     return y
 
 

@@ -277,7 +277,7 @@ class ShardedFkPlan:
             boff.append(boff[-1] + nxl * nqs[s] * per)
         mean = mx = None
         if stats:
-            mean = torch.zeros(nxl, dtype=torch.float32, device=dev_)
+            mean = torch.zeros(nxl, dtype=torch.float64, device=dev_)
             mx = torch.zeros(nxl, dtype=torch.float32, device=dev_)
 
         def time_inv(buf, y, l0, l1):

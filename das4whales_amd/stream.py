@@ -86,7 +86,7 @@ class FileStream:
         nx, ns = y.shape
         from ._lib import lib, check
         with torch.cuda.device(y.device):
-            mean = torch.empty(nx, dtype=torch.float32, device=y.device)
+            mean = torch.empty(nx, dtype=torch.float64, device=y.device)
             mx = torch.empty(nx, dtype=torch.float32, device=y.device)
             check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
         if next_head is not None and self.lmax > 1 and next_head.is_cuda and next_head.dtype == torch.float32 \

@@ -114,10 +114,11 @@ int d4w_fk_plan_order(const d4w_fk_plan* plan, int* info6_host, double* bytes2_h
 int d4w_fk_apply_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, void* stream);
 
 /* d4w_fk_apply_f32 that also returns what the matched filter normalises the filtered rows by
- * (detect.py:157): row_mean[c] = mean(y[c,:]), row_maxabs[c] = max|y[c,:]|, DEVICE float32 [nx].
+ * (detect.py:157): row_mean[c] = mean(y[c,:]) DEVICE float64 [nx] (the reference de-means in float64; the correlators
+ * take it as a two-float value), row_maxabs[c] = max|y[c,:]| DEVICE float32 [nx].
  * The shape-specialised kernels form them in the epilogue of the last pass (no extra read of y);
  * other shapes run d4w_row_stats_f32 afterwards.  Feed them to d4w_xcorr_fft_f32 / d4w_xcorr_lens_f32. */
-int d4w_fk_apply_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, float* row_mean,
+int d4w_fk_apply_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, double* row_mean,
                            float* row_maxabs, void* stream);
 
 /* Same as d4w_fk_apply_f32 but brackets each of the five passes (A, C, B, C', A') with HIP events
@@ -126,7 +127,7 @@ int d4w_fk_apply_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int tape
 int d4w_fk_apply_timed_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, void* stream,
                            float* ms5_host);
 /* timed variant of d4w_fk_apply_stats_f32 (row_mean / row_maxabs may both be NULL) */
-int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, float* row_mean,
+int d4w_fk_apply_timed_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, double* row_mean,
                                  float* row_maxabs, void* stream, float* ms5_host);
 
 /* ------------------------------------------------------------------------------------------
@@ -191,7 +192,7 @@ int d4w_fkd_time_inv_packed_rows_f32(d4w_fkd_plan* plan, const float* packed, fl
 /* ... also leaving mean and max|.| of the filtered local rows (what detect.compute_cross_correlogram normalises by,
  * detect.py:157) in row_mean / row_maxabs [nxl], which the caller zeroes before the first chunk */
 int d4w_fkd_time_inv_packed_rows_stats_f32(d4w_fkd_plan* plan, const float* packed, float* y_loc, int l0, int l1,
-                                           float* row_mean, float* row_maxabs, void* stream);
+                                           double* row_mean, float* row_maxabs, void* stream);
 
 /* dsp.taper_data (dsp.py:705-722): x *= tukey(ns, 0.03) in place, every row */
 int d4w_taper_f32(float* x, int nx, int ns, void* stream);
@@ -237,7 +238,10 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
  * replaces detect.compute_cross_correlogram (detect.py:140-166), detect.shift_xcorr
  * (detect.py:96-112) and the numerator of detect.shift_nxcorr (detect.py:115-137).
  *
- *   d4w_row_stats_f32:  mean[c] = mean(x[c,:]),  maxabs[c] = max|x[c,:]|   (detect.py:157)
+ *   d4w_row_stats_f32:  mean[c] = mean(x[c,:]) as FLOAT64,  maxabs[c] = max|x[c,:]|   (detect.py:157).  The mean is
+ *       accumulated about a pivot sample and kept in float64; every correlator splits it into hi + lo float32 parts and
+ *       de-means as (x - hi) - lo, so a row whose offset is 10^3..10^5 x its signal is still de-meaned to float32 rounding
+ *       of the signal (a float32 mean leaves |mean| 2^-24 in every sample).
  *   d4w_xcorr_f32:      for each template t < ntpl (1 or 2 per call, fused: x is read once)
  *       y_t[c][k] = g[c] * sum_{n < L_t, n+k < ns} (x[c][n+k] - m[c]) * taps[t][n]
  *       with m = mean (or 0 if mean == NULL) and g = 1/maxabs (or 1 if maxabs == NULL; 0 for an
@@ -247,16 +251,16 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
  * The de-meaned zero-padded template's DC tail (-mean/max on the padded part, detect.py:158) is a
  * separate entry point, d4w_xcorr_dc_tail_f32.
  * ------------------------------------------------------------------------------------------ */
-int d4w_row_stats_f32(const float* x, int nx, int ns, float* mean, float* maxabs, void* stream);
+int d4w_row_stats_f32(const float* x, int nx, int ns, double* mean, float* maxabs, void* stream);
 
 /* dst[r][0 .. ncols) = src[r][0 .. ncols), r < nrows, rows ld_src / ld_dst floats apart (DEVICE pointers): the strided piece
  * copies around the band-pass (row ends to the recursion and back, dsp.py:859-880) in one launch each. */
 int d4w_copy_cols_f32(const float* src, size_t ld_src, float* dst, size_t ld_dst, int nrows, int ncols, void* stream);
-int d4w_xcorr_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+int d4w_xcorr_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs,
                   const float* taps, int ntpl, int ltaps, float* y0, float* y1, void* stream);
 /* Same, with the true support of each template (len_t <= ltaps, taps[t][len_t..ltaps) == 0): taps
  * beyond the shorter support are only applied to the longer template (HF 136 / LF 156 samples). */
-int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs,
                        const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                        float* y1, void* stream);
 
@@ -266,7 +270,7 @@ int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const float* mean, const 
  * part.  Added in place to a correlogram produced by d4w_xcorr_*_f32 with the same mean / maxabs.
  * |coef| ~ 5e-7 for the fin-whale templates (a 3-5e-6 effect on a 60-s file), so hosts apply it only when its predicted size,
  * ~ 0.35 |coef| sqrt(ns / sum taps^2) of the correlogram's maximum on white rows, is not negligible (the Python mirror: 5e-6). */
-int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs,
                           double coef, int support, float* y, void* stream);
 
 /* Overlap-save FFT form of the same correlation for short templates (support <=
@@ -280,7 +284,7 @@ int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const float* mean, con
  * then pay the template spectra once. */
 int d4w_xcorr_fft_max_support(void);
 size_t d4w_xcorr_fft_ws_bytes(void);
-int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const float* maxabs,
+int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs,
                       const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                       float* y1, void* ws, void* stream);
 /* The same for a record that continues: lags whose window runs past sample ns - 1 read the first n_next samples of
@@ -289,7 +293,7 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const float* mean, const f
  * the two files first (no reference counterpart, parity target = the reference run on the concatenated
  * record).  Two templates per call (the fused kernel).  xnext = NULL: identical to d4w_xcorr_fft_f32. */
 int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
-                           const float* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
+                           const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
                            int len0, int len1, float* y0, float* y1, void* ws, void* stream);
 
 /* The same correlation as a banded-Toeplitz product on the matrix cores -- the form detect.compute_cross_correlogram
@@ -297,13 +301,16 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
  *   C[i][a] = sum_u t[u - i] x[16 a + u]  per 256 lags, v_mfma_f32_16x16x32_f16 on binary16 hi / lo splits of the float32
  *   operands (three of the four partial products, float32 accumulation; agreement with d4w_xcorr_lens_f32 and a float64
  *   correlation to float32 rounding), one read of x and one write per correlogram, no workspace.
- * supports <= d4w_xcorr_mm_max_support() = 241; ntpl = 1 or 2 (fused into one launch while both supports are <= 177, one
- * launch per template beyond); taps DEVICE [ntpl][ltaps], always needed (the
+ * supports <= d4w_xcorr_mm_max_support() = 7936; ntpl = 1 or 2 (fused into one launch while both supports are <= 177; beyond,
+ * one launch per template up to 497 taps -- the 450-sample template of scripts/main_mfdetect.py:70 --, and longer templates in
+ * sections of 496 taps, each section one launch that reads x shifted by its first tap and accumulates into y); non-finite samples spread over the 256 lags of their tile in both templates, and scaled
+ * samples beyond binary16's range (caller-supplied statistics of another tensor) are clamped to +-65504;
+ * taps DEVICE [ntpl][ltaps], always needed (the
  * Toeplitz fragments are built in the kernel); mean / maxabs as d4w_xcorr_lens_f32 (maxabs == NULL: every 4096-lag chunk
  * is scaled by its own power of two); xnext / ld_next / n_next as d4w_xcorr_fft_cont_f32 (NULL, 0, 0: zeros behind the row). */
 int d4w_xcorr_mm_max_support(void);
 int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
-                     const float* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
+                     const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
                      int len0, int len1, float* y0, float* y1, void* stream);
 
 /* Zero-phase FIR along time by overlap-save FFT blocks -- the INTERIOR of dsp.bp_filt / scipy.signal.sosfiltfilt
@@ -440,6 +447,9 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
  * ------------------------------------------------------------------------------------------ */
 int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx,
                        int32_t* counts, int cap, void* stream);
+/* offsets[c] = counts[0] + ... + counts[c] (int64, what d4w_pack_picks_i64 places the rows by) and
+ * summary2 = {max_c counts[c], sum_c counts[c]} (DEVICE int64[2]: the capacity check and the table size of one picker call). */
+int d4w_pick_offsets_i64(const int32_t* counts, int nx, int64_t* offsets, int64_t* summary2, void* stream);
 /* The picks of all rows as one packed table out[2][total] int64, row 0 = channel index, row 1 = time index
  * -- what detect.convert_pick_times builds from the ragged lists (detect.py:277-303; the reference's docstring
  * has the two rows swapped, :289 vs :297-299).  offsets[c] = counts[0] + ... + counts[c] (inclusive prefix sum,

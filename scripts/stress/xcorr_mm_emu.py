@@ -8,7 +8,7 @@ worst = 0.0
 for case in range(int(sys.argv[2])):
     nx = int(rng.integers(1, 4)); ns = int(rng.choice([rng.integers(1, 64), rng.integers(64, 4200), rng.integers(4200, 13000)]))
     ntpl = int(rng.integers(1, 3))
-    lens = [int(rng.integers(1, min(242, max(2, ns + 1)))) for _ in range(ntpl)]
+    lens = [int(rng.integers(1, min(1200 if rng.random() < 0.3 else 242, max(2, ns + 1)))) for _ in range(ntpl)]
     taps = [rng.standard_normal(L) * rng.choice([1.0, 1e-3, 50.0]) for L in lens]
     sc_, of_ = rng.choice([1.0, 1e-6, 1e4]), rng.choice([0.0, 3.0, -1e3])
     x = rng.standard_normal((nx, ns)) * sc_ + of_

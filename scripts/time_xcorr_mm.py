@@ -11,8 +11,7 @@ x = torch.randn((nx, ns), device="cuda", generator=gen) + 0.25
 t = np.arange(ns) / fs
 tpl = [ddet._normalised_support(ddet.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)),
        ddet._normalised_support(ddet.gen_template_fincall(t, fs, 14.7, 21.8, 0.78))]
-mean = x.mean(dim=1).contiguous()
-mx = x.abs().amax(dim=1).contiguous()
+mean, mx = ddet._row_stats_cached(x)             # float64 means, float32 maxima (d4w_row_stats_f32)
 
 
 def timeit(method, normalize=True, tl=tpl):

@@ -136,7 +136,7 @@ def test_apply_with_row_statistics(emu, nx, ns, opts):
     assert emu.d4w_fk_plan_create_ex(nx, ns, o, ctypes.byref(plan)) == 0, emu.d4w_last_error()
     assert emu.d4w_fk_set_mask_dense_f32(plan, vp(m), None) == 0
     y0, y1 = np.empty_like(x), np.empty_like(x)
-    mean = np.full(nx, np.nan, dtype=np.float32)
+    mean = np.full(nx, np.nan, dtype=np.float64)          # float64 row means (include/d4w.h)
     mx = np.full(nx, np.nan, dtype=np.float32)
     assert emu.d4w_fk_apply_f32(plan, vp(x), vp(y0), 0, None) == 0
     assert emu.d4w_fk_apply_stats_f32(plan, vp(x), vp(y1), 0, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
@@ -180,7 +180,7 @@ def test_channel_count_too_long_for_bluestein_tile(emu, monkeypatch):
     mf = m.astype(np.float32)
     a, b = np.float32(0.75), np.float32(0.125)
     assert emu.d4w_fk_set_mask_dense_affine_f32(plan, vp(mf), ctypes.c_float(a), ctypes.c_float(b), None) == 0
-    mean = np.empty(nx, dtype=np.float32)
+    mean = np.empty(nx, dtype=np.float64)
     mx = np.empty(nx, dtype=np.float32)
     assert emu.d4w_fk_apply_stats_f32(plan, vp(xf), vp(y), 1, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
     emu.d4w_fk_plan_destroy(plan)
@@ -226,7 +226,7 @@ def test_slab_ordered_passes(emu, nx, ns, sw, monkeypatch):
         assert emu.d4w_fk_plan_create(nx, ns, ctypes.byref(plan)) == 0
         assert emu.d4w_fk_set_mask_dense_f32(plan, vp(m), None) == 0
         y, ys = np.empty_like(x), np.empty_like(x)
-        mean, mx = np.empty(nx, np.float32), np.empty(nx, np.float32)
+        mean, mx = np.empty(nx, np.float64), np.empty(nx, np.float32)
         assert emu.d4w_fk_apply_f32(plan, vp(x), vp(y), 1, None) == 0, emu.d4w_last_error()
         assert emu.d4w_fk_apply_stats_f32(plan, vp(x), vp(ys), 1, vp(mean), vp(mx), None) == 0, emu.d4w_last_error()
         emu.d4w_fk_plan_destroy(plan)

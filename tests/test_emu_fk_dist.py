@@ -195,7 +195,7 @@ def fk_sharded_packed_emu(lib, x, mask, world, taper=False):
         y[rk.a:rk.b] = yl
         # the same pass with the row statistics in its epilogue, in two row chunks
         ys = np.full((nxl, ns), np.nan, dtype=np.float32)
-        mean, mx = np.zeros(nxl, np.float32), np.zeros(nxl, np.float32)
+        mean, mx = np.zeros(nxl, np.float64), np.zeros(nxl, np.float32)          # float64 row means (include/d4w.h)
         cut = min(nxl, rk.C1 * max(1, (nxl // rk.C1) // 2))
         for l0, l1 in ((0, cut), (cut, nxl)):
             if l1 > l0:

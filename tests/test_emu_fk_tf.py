@@ -36,7 +36,7 @@ def run(lib, x, mask, order=None, taper=0, stats=False):
         info, by = (ctypes.c_int * 6)(), (ctypes.c_double * 2)()
         assert lib.d4w_fk_plan_order(plan, info, by) == 0
         if stats:
-            mean = np.empty(nx, dtype=np.float32)
+            mean = np.empty(nx, dtype=np.float64)
             mx = np.empty(nx, dtype=np.float32)
             lib.d4w_fk_apply_stats_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
             assert lib.d4w_fk_apply_stats_f32(plan, vp(xf), vp(y), taper, vp(mean), vp(mx), None) == 0, lib.d4w_last_error()

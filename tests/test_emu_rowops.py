@@ -81,7 +81,7 @@ def xcorr_emu(lib, x, taps_list, normalize=True, lens=True):
     taps = np.zeros((len(taps_list), lt), dtype=np.float32)
     for i, t in enumerate(taps_list):
         taps[i, :len(t)] = t
-    mean = np.empty(nx, dtype=np.float32)
+    mean = np.empty(nx, dtype=np.float64)          # float64 row means (include/d4w.h)
     mx = np.empty(nx, dtype=np.float32)
     if normalize:
         assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
@@ -156,7 +156,7 @@ def xcorr_fft_emu(lib, x, taps_list, normalize=True):
     taps = np.zeros((len(taps_list), lt), dtype=np.float32)
     for i, t in enumerate(taps_list):
         taps[i, :len(t)] = t
-    mean = np.empty(nx, dtype=np.float32)
+    mean = np.empty(nx, dtype=np.float64)          # float64 row means (include/d4w.h)
     mx = np.empty(nx, dtype=np.float32)
     if normalize:
         assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
@@ -337,7 +337,7 @@ def test_xcorr_fft_continuation(emu, nx, ns):
     lt = 156
     taps = np.zeros((2, lt), dtype=np.float32)
     taps[0, :136], taps[1, :156] = t0, t1
-    mean, mx = np.empty(nx, dtype=np.float32), np.empty(nx, dtype=np.float32)
+    mean, mx = np.empty(nx, dtype=np.float64), np.empty(nx, dtype=np.float32)
     assert emu.d4w_row_stats_f32(vp(x), nx, ns, vp(mean), vp(mx), None) == 0
     emu.d4w_xcorr_fft_ws_bytes.restype = ctypes.c_size_t
     ws = np.empty(emu.d4w_xcorr_fft_ws_bytes(), dtype=np.uint8)
@@ -410,7 +410,7 @@ def xcorr_mm_emu(lib, x, taps_list, normalize=True, nxt=None, n_next=0, stats=No
     taps = np.zeros((len(taps_list), lt), dtype=np.float32)
     for i, t in enumerate(taps_list):
         taps[i, :len(t)] = t
-    mean = np.empty(nx, dtype=np.float32)
+    mean = np.empty(nx, dtype=np.float64)          # float64 row means (include/d4w.h)
     mx = np.empty(nx, dtype=np.float32)
     if stats is not None:
         mean, mx = stats
@@ -466,11 +466,14 @@ def test_xcorr_mm_golden(emu, golden):
 
 
 @pytest.mark.parametrize("nx,ns,l0,l1", [(3, 9001, 161, 7), (2, 4096, 136, 156), (1, 4289, 1, 177), (4, 1300, 50, 50), (2, 100, 100, 3),
-                                          (1, 8192 + 4288, 136, 156), (2, 4500, 241, 20), (1, 5000, 60, 200)])
+                                          (1, 8192 + 4288, 136, 156), (2, 4500, 241, 20), (1, 5000, 60, 200),
+                                          (2, 5100, 450, 300), (1, 4097, 497, 498), (1, 9000, 1024, 243), (2, 700, 700, 5)])
 def test_xcorr_mm_ragged(emu, nx, ns, l0, l1):
     """Odd row lengths (unaligned rows: the sample-by-sample loads and stores), chunks with a ragged tail, a row shorter
-    than a chunk, the maximum support of the fused kernel (177) and of the one-template kernel (241: two templates then run
-    one after the other), rows without normalisation (per-chunk power-of-two scale) and with a large offset."""
+    than a chunk, the maximum support of the fused kernel (177) and of the 8-step one-template kernel (241: two templates then
+    run one after the other), the deeper one-template kernels (12 and 16 k-steps: up to 497 taps in one launch -- the reference
+    script's own 450-sample template, scripts/main_mfdetect.py:70 --, longer templates in sections of 496 taps that accumulate),
+    a template longer than the row, rows without normalisation (per-chunk power-of-two scale) and with a large offset."""
     rng = np.random.default_rng(ns + l0)
     x = rng.standard_normal((nx, ns)) * 37.0 + 0.5
     t0, t1 = rng.standard_normal(l0) * 5.0, rng.standard_normal(l1) * 0.01
@@ -478,13 +481,14 @@ def test_xcorr_mm_ragged(emu, nx, ns, l0, l1):
     for c in range(nx):
         assert rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - l0)))) < 2e-6
         assert rel(y1[c], orc.shift_xcorr(x[c], np.pad(t1, (0, ns - l1)))) < 2e-6
-    assert emu.d4w_xcorr_mm_max_support() == 241
+    assert emu.d4w_xcorr_mm_max_support() == 16 * 496
     xs = (x + 1000.0).astype(np.float32)
     z0, z1 = xcorr_mm_emu(emu, xs, [t0, t1])
     xn = (xs.astype(np.float64) - xs.astype(np.float64).mean(axis=1, keepdims=True)) / np.abs(xs).max(axis=1, keepdims=True)
     for c in range(nx):
         assert rel(z0[c], orc.shift_xcorr(xn[c], np.pad(t0, (0, ns - l0)))) < 1e-5    # float32 row mean of a 1000x offset
-    assert emu.d4w_xcorr_mm_f32(vp(xs), nx, ns, None, 0, 0, None, None, vp(np.zeros((1, 244), np.float32)), 1, 244, 242, 242,
+    big = 16 * 496 + 1
+    assert emu.d4w_xcorr_mm_f32(vp(xs), nx, ns, None, 0, 0, None, None, vp(np.zeros((1, big + 3), np.float32)), 1, big + 3, big, big,
                                 vp(z0), None, None) != 0
 
 
@@ -496,7 +500,7 @@ def test_xcorr_mm_continuation(emu, nx, ns):
     nxt = (rng.standard_normal((nx, 500)) - 0.2).astype(np.float32)
     t0, t1 = rng.standard_normal(136) * np.hanning(136), rng.standard_normal(156) * np.hanning(156)
     L = 156
-    mean, mx = np.empty(nx, dtype=np.float32), np.empty(nx, dtype=np.float32)
+    mean, mx = np.empty(nx, dtype=np.float64), np.empty(nx, dtype=np.float32)
     assert emu.d4w_row_stats_f32(vp(x), nx, ns, vp(mean), vp(mx), None) == 0
     cont = xcorr_mm_emu(emu, x, [t0, t1], nxt=nxt, n_next=L - 1, stats=(mean, mx))
     ext = np.ascontiguousarray(np.concatenate((x, nxt[:, :L - 1]), axis=1))
@@ -506,3 +510,31 @@ def test_xcorr_mm_continuation(emu, nx, ns):
     xa = (np.concatenate((x[0], nxt[0, :L - 1])).astype(np.float64) - float(mean[0])) / float(mx[0])
     for k in (ns - 1, ns - 77, ns - L + 1):
         assert abs(cont[1][0, k] - float(np.dot(xa[k:k + 156], t1))) < 2e-6 * np.max(np.abs(ref[1]))
+
+
+@pytest.mark.parametrize("offset", [1e3, 1e4, 1e5])
+def test_offset_heavy_rows_are_demeaned_in_two_floats(emu, offset):
+    """detect.py:157 de-means in float64.  Rows whose OFFSET is 10^3..10^5 x their signal's deviation, a template with a
+    non-zero sum (the mean's error would enter every lag times that sum): the float64 row mean of d4w_row_stats_f32 enters
+    every correlator as a two-float value, (x - hi) - lo, and the three forms hold 1e-5 against a float64 reference where a
+    float32 mean left 1.2e-5 .. 2.8e-5 at 1000 x (round 4's known limit).  Input = the float32 rows both sides see."""
+    rng = np.random.default_rng(int(offset) + 11)
+    nx, ns, L = 3, 9000, 137
+    sigma = 0.37
+    x = (rng.standard_normal((nx, ns)) * sigma + offset * sigma * np.array([1.0, -1.0, 0.731])[:, None]).astype(np.float32)
+    tpl = np.abs(rng.standard_normal(L)) + 0.3                       # sum(tpl) ~ 150: nothing cancels a mean error
+    x64 = x.astype(np.float64)
+    mean = np.empty(nx, dtype=np.float64)
+    mx = np.empty(nx, dtype=np.float32)
+    assert emu.d4w_row_stats_f32(vp(x), nx, ns, vp(mean), vp(mx), None) == 0
+    # the mean itself: float64-grade (1e-9 of the deviation), not float32 of the offset
+    assert np.max(np.abs(mean - x64.mean(axis=1))) < 1e-7 * sigma
+    assert np.array_equal(mx, np.abs(x).max(axis=1))
+    xn = (x64 - x64.mean(axis=1, keepdims=True)) / np.abs(x64).max(axis=1, keepdims=True)
+    ref = np.stack([orc.shift_xcorr(r, np.pad(tpl, (0, ns - L))) for r in xn])
+    (ym,) = xcorr_mm_emu(emu, x, [tpl])
+    (yf,) = xcorr_fft_emu(emu, x, [tpl])
+    (yd,), _, _ = xcorr_emu(emu, x, [tpl])
+    for name, y in (("mm", ym), ("fft", yf), ("direct", yd)):
+        e = max(rel(y[c], ref[c]) for c in range(nx))
+        assert e < 2e-6, (name, offset, e)          # measured 1.6e-7 .. 8.3e-7 (the matrix-core form at 10^5: binary16 subnormals)

@@ -369,7 +369,16 @@ def test_pack_picks_table(emu):
     idx = np.zeros((nx, cap), dtype=np.int32)
     cnt = np.zeros(nx, dtype=np.int32)
     ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
-    off = np.cumsum(cnt).astype(np.int64)
+    # the offsets, the total and the largest count of a picker call come from one launch (d4w_pick_offsets_i64)
+    off = np.full(nx, -1, dtype=np.int64)
+    summ = np.full(2, -1, dtype=np.int64)
+    ok(emu, emu.d4w_pick_offsets_i64(vp(cnt), nx, vp(off), vp(summ), None))
+    assert np.array_equal(off, np.cumsum(cnt)) and summ[0] == cnt.max() and summ[1] == cnt.sum()
+    for n in (1, 63, 1024, 1025, 20000, 131070):      # one row per thread, several, ragged last threads
+        c2 = rng.integers(0, 70000, n).astype(np.int32)
+        o2, s2 = np.empty(n, dtype=np.int64), np.empty(2, dtype=np.int64)
+        ok(emu, emu.d4w_pick_offsets_i64(vp(c2), n, vp(o2), vp(s2), None))
+        assert np.array_equal(o2, np.cumsum(c2.astype(np.int64))) and s2[0] == c2.max() and s2[1] == c2.astype(np.int64).sum()
     total = int(off[-1])
     out = np.full((2, total), -1, dtype=np.int64)
     emu.d4w_pack_picks_i64.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]

@@ -206,8 +206,7 @@ def test_correlogram_matrix_core_form_is_float32_grade(dw):
     yf = dw.detect._xcorr_device(x, tpl, normalize=True, method="fft")
     yd = dw.detect._xcorr_device(x, tpl, normalize=True, method="direct")
     xs = x.double().cpu().numpy()
-    mean = x.mean(dim=1).double().cpu().numpy()
-    xn = (xs - mean[:, None]) / np.abs(xs).max(axis=1, keepdims=True)
+    xn = (xs - xs.mean(axis=1, keepdims=True)) / np.abs(xs).max(axis=1, keepdims=True)
     for k in range(2):
         ref = np.stack([np.correlate(np.concatenate((r, np.zeros(len(tpl[k]) - 1))), tpl[k], "valid") for r in xn])
         em, ef, ed = (rel(y[k].cpu().numpy(), ref) for y in (ym, yf, yd))
@@ -219,6 +218,86 @@ def test_correlogram_matrix_core_form_is_float32_grade(dw):
     yr = dw.detect._xcorr_device(x, tpl, normalize=False, method="mm")
     rd = dw.detect._xcorr_device(x, tpl, normalize=False, method="direct")
     assert float((yr[0] - rd[0]).abs().max()) <= 2e-6 * float(rd[0].abs().max())
+    # a high-dynamic-range block: one spike of 10^4 x the noise per row, so that 1 / max|x| pushes the ordinary samples into
+    # binary16's subnormal range (the hi half keeps ~7 bits there, the lo half the rest: absolute error 2^-24 / 2048 of the
+    # row maximum).  Every sample again, and the lags AWAY from the spike separately -- relative to their own maximum, where
+    # the spike's large correlation values do not hide an error of the small ones
+    xs2 = x.clone()
+    pos = torch.arange(nx, device="cuda") * 613 % (ns - 2000) + 1000
+    xs2[torch.arange(nx, device="cuda"), pos] = 3.0e4
+    ym2 = dw.detect._xcorr_device(xs2, tpl, normalize=True, method="mm")
+    xs = xs2.double().cpu().numpy()
+    xn = (xs - xs.mean(axis=1, keepdims=True)) / np.abs(xs).max(axis=1, keepdims=True)
+    for k in range(2):
+        L = len(tpl[k])
+        ref = np.stack([np.correlate(np.concatenate((r, np.zeros(L - 1))), tpl[k], "valid") for r in xn])
+        got = ym2[k].cpu().numpy()
+        assert rel(got, ref) < 1e-6
+        far = np.ones((nx, ns), dtype=bool)
+        for c, p in enumerate(pos.cpu().numpy()):
+            far[c, max(0, p - L):p + 1] = False
+        e_far = np.max(np.abs(got - ref)[far]) / np.max(np.abs(ref[far]))
+        print("spike block, template %d: lags away from the spike %.2e of their own maximum" % (k, e_far))
+        assert e_far < 1e-5
+
+
+@pytest.mark.parametrize("offset", [1e3, 1e4, 1e5])
+def test_offset_heavy_rows_hold_the_bar_on_every_form(dw, offset):
+    """detect.py:157 de-means in float64 and accepts any row.  Rows whose offset is 10^3 .. 10^5 x their signal's deviation and a
+    template with a non-zero sum (so that an error of the mean enters every lag): the float64 row means of d4w_row_stats_f32
+    enter the correlators as two-float values and all three forms stay inside 1e-5 of a float64 correlation of the same
+    float32 rows -- round 4's known limit (1.2 - 2.8e-5 at 1000 x with a float32 mean).  Also through the public call."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(int(offset) % 1000 + 5)
+    nx, ns, L = 24, 30000, 137
+    sig = 0.37
+    sign = torch.tensor([1.0, -1.0, 0.731] * (nx // 3), device="cuda")[:, None]
+    x = torch.randn((nx, ns), dtype=torch.float32, device="cuda", generator=gen) * sig + float(offset) * sig * sign
+    rng = np.random.default_rng(int(offset))
+    tpl = np.abs(rng.standard_normal(L)) + 0.3
+    xs = x.double().cpu().numpy()
+    xn = (xs - xs.mean(axis=1, keepdims=True)) / np.abs(xs).max(axis=1, keepdims=True)
+    ref = np.stack([np.correlate(np.concatenate((r, np.zeros(L - 1))), tpl, "valid") for r in xn])
+    mean, mx = dw.detect._row_stats_cached(x)
+    assert mean.dtype == torch.float64
+    assert float((mean.cpu() - torch.from_numpy(xs.mean(axis=1))).abs().max()) < 1e-7 * sig
+    for how in ("mm", "fft", "direct"):
+        (y,) = dw.detect._xcorr_device(x, [tpl], normalize=True, method=how)
+        e = rel(y.cpu().numpy(), ref)
+        print("offset %g, %s: %.2e" % (offset, how, e))
+        assert e < TOL, (how, offset, e)
+    # the public call: template zero-padded to the row length (its DC tail, detect.py:158, is added when it matters)
+    tfull = np.zeros(ns)
+    tfull[:L] = tpl
+    got = dw.detect.compute_cross_correlogram(x, tfull).cpu().numpy()
+    assert rel(got, orc.compute_cross_correlogram(xs, tfull)) < TOL
+
+
+def test_row_statistics_are_not_reused_after_a_raw_pointer_write(dw):
+    """the library writes through raw pointers, which torch's version counter does not see -- `plan.apply(x_i,
+    out=y); compute_cross_correlogram(y, tpl)` in a per-file loop must not find file 0's row statistics on file 1.  Every
+    wrapper that writes into a caller's tensor bumps its version (dev.out_ptr)."""
+    from das4whales_amd import detect as ddet
+    nx, ns = 96, 480
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    plan = dw.dsp.get_fk_plan(nx, ns)
+    plan.set_mask(np.ones((nx, ns)))
+    y = torch.empty((nx, ns), dtype=torch.float32, device="cuda")
+    time = np.arange(ns) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)
+    outs = []
+    for k in range(2):
+        x = torch.randn((nx, ns), device="cuda", generator=gen) * (1.0 + 3.0 * k) + 0.5 * k
+        plan.apply(x, out=y)
+        c = dw.detect.compute_cross_correlogram(y, hf)
+        ref = orc.compute_cross_correlogram(y.double().cpu().numpy(), hf)
+        assert rel(c.cpu().numpy(), ref) < TOL, k
+        outs.append(ddet._row_stats_cached(y))
+    assert outs[0][0] is not outs[1][0]
+    v = y._version
+    dw.dsp.taper_data(y)                                                  # in place through a raw pointer
+    assert y._version > v
 
 
 def test_row_statistics_are_remembered_per_tensor_version(dw):
@@ -235,7 +314,7 @@ def test_row_statistics_are_remembered_per_tensor_version(dw):
     assert ddet._row_stats_cached(x)[0] is m1[0]                          # remembered
     x.mul_(2.0).add_(1.0)                                                  # same storage, new version
     m2 = ddet._row_stats_cached(x)
-    assert m2[0] is not m1[0] and torch.allclose(m2[0], x.mean(dim=1), atol=1e-5)
+    assert m2[0] is not m1[0] and m2[0].dtype == torch.float64 and torch.allclose(m2[0], x.double().mean(dim=1), atol=1e-9)
     b = dw.detect.compute_cross_correlogram(x, hf)
     ref = orc.compute_cross_correlogram(x.cpu().numpy().astype(np.float64), hf)
     assert rel(b.cpu().numpy(), ref) < TOL and not torch.equal(a, b)
