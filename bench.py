@@ -417,7 +417,8 @@ def bench_stream(args, world, rank, device, dist):
         def detect_on(done):
             n = 0
             for r in done:
-                thr = 0.45 * float(r["correlograms"][0].max())
+                rm = r.get("row_max")          # per-row maxima from the correlator's epilogue (the last file of a run: one read)
+                thr = 0.45 * ddet.correlogram_max(r["correlograms"][0], rm[0] if rm else None)
                 for c in r["correlograms"]:
                     n += ddet.pick_times_env(c, thr).total
                 ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)

@@ -66,6 +66,9 @@ def _load():
         "d4w_sosfiltfilt_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
         "d4w_sosfiltfilt_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, P(ctypes.c_double), P(ctypes.c_double),
                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+        "d4w_sosfiltfilt_ends_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+        "d4w_sosfiltfilt_ends_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                             c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
         "d4w_design_mask_f32": (c_int, [c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, P(ctypes.c_double),
                                         c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_flip_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -84,6 +87,8 @@ def _load():
         "d4w_xcorr_mm_max_support": (c_int, []),
         "d4w_xcorr_mm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_void_p, c_void_p, c_void_p]),
+        "d4w_xcorr_mm_rowmax_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_fft_max_support": (c_int, []),
         "d4w_xcorr_fft_ws_bytes": (ctypes.c_size_t, []),
         "d4w_xcorr_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -93,6 +98,8 @@ def _load():
         "d4w_fir_fft_max_halfwidth": (c_int, []),
         "d4w_fir_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_double, c_void_p, c_void_p,
                                     c_void_p]),
+        "d4w_fir_fft_cols_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_double, c_void_p, c_int, c_int,
+                                         c_void_p, c_void_p]),
         "d4w_fir_fft_halo_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                          c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
         "d4w_analytic_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_double, c_void_p]),

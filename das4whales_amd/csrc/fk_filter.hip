@@ -1769,6 +1769,19 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
     const int persist = pl->num_cu * pl->wg_per_cu;
     const dim3 gridA(std::min(ntA, persist)), gridC(std::min(ntC, persist)), gridB(std::min(ntB, persist));
     hipStream_t st = (hipStream_t)stream;
+    if (pl->fast && row_mean) {
+        // The epilogue pays where a pass-A tile is large: at 20 000 x 120 000 (C1 N1 = 625 points per strip column) it adds
+        // 0.2 ms to a 3.7-ms pass against 1.7 ms for a separate sweep of y.  At the 60-s file shapes (C1 N1 = 100) the same
+        // epilogue turned a 215-us pass into 390 us (500 us with shorter runs: the per-run reduction is what costs,
+        // profiles/r05d/stream_kernels.txt) against 137 us for d4w_row_stats_f32: small tiles on large blocks take the sweep.
+        static const int epi_env = [] { const char* v = getenv("D4W_FK_STATS_EPILOGUE"); return v ? atoi(v) : -1; }();
+        const bool epilogue = epi_env >= 0 ? epi_env > 0 : (d.C1 * d.N1 >= 256 || (long long)d.nx * d.ns < (1ll << 22));
+        if (!epilogue) {
+            int rc = fk_apply_run(pl, x, y, taper, stream, ev, nullptr, nullptr);
+            if (rc) return rc;
+            return d4w_row_stats_f32(y, d.nx, d.ns, row_mean, row_maxabs, stream);
+        }
+    }
     if (pl->fast) {
         const FkFastEntry& F = *pl->fast;
         const int NBX = d.N2 / d.TA, NBC = d.N2 / d.TC;
@@ -1779,7 +1792,7 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
 #define D4W_MARK(i) do { if (ev) D4W_HIP(hipEventRecord(ev[i], st)); } while (0)
         // row statistics in the epilogue of the last pass: tiles walked in runs of `run` (a divisor of the tiles
         // per c2 of the pass / slab, so that a run stays on the same C1 rows)
-        auto stats_run = [](int per_c2) {
+        auto stats_run = [](int per_c2, long long) {
             static const int run_env = [] { const char* v = getenv("D4W_FK_RUN_A"); return v ? atoi(v) : 30; }();
             int run = 1;
             for (int r = 1; r <= per_c2 && r <= std::max(run_env, 1); ++r) if (per_c2 % r == 0) run = r;
@@ -1806,7 +1819,7 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
             D4W_MARK(2);
             if ((rc = launch_k(F.B_mid, gB, dim3(F.thrB), F.ldsB, stream, P, pl->fdev, dst, 0, pl->npairs_run, FkGeo()))) return rc;
             D4W_MARK(3);
-            const int run = stats_run(sw), nruns = nA / run;
+            const int run = stats_run(sw, nA), nruns = nA / run;
             for (int sl = 0; sl < nslab; ++sl) {
                 if ((rc = launch_k(F.C_inv, gsC, dim3(F.thrC), F.ldsC, stream, P, pl->fdev, dst, 0, nC, sw, sl * sw, FkGeo()))) return rc;
                 if (row_mean) {
@@ -1839,7 +1852,7 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
             if ((rc = launch_k(F.Bt_inv, gBi, dim3(F.thrB), F.ldsBt, stream, P, pl->fdev, T, dst, 0, pl->npairsT))) return rc;
             D4W_MARK(4);
             if (row_mean) {
-                const int run = stats_run(NBX), nruns = fA / run;
+                const int run = stats_run(NBX, fA), nruns = fA / run;
                 if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
                                    dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0, FkGeo(), (const float2*)nullptr, 0))) return rc;
             } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0, FkGeo(), (const float2*)nullptr))) return rc;
@@ -1860,7 +1873,7 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
         if (rc) return rc;
         D4W_MARK(4);
         if (row_mean) {
-            const int run = stats_run(NBX), nruns = fA / run;
+            const int run = stats_run(NBX, fA), nruns = fA / run;
             if ((rc = launch_k(F.A_inv_stats, dim3(std::min(nruns, pl->num_cu * pl->wgA)), dim3(F.thrA), F.ldsA, stream, P,
                                dst, run, nruns, row_mean, (unsigned*)row_maxabs, NBX, 0, FkGeo(), (const float2*)nullptr, 0))) return rc;
         } else if ((rc = launch_k(F.A_inv, gA, dim3(F.thrA), F.ldsA, stream, P, dst, 0, fA, NBX, 0, FkGeo(), (const float2*)nullptr))) return rc;

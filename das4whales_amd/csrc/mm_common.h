@@ -84,6 +84,14 @@ static inline int mm_num_cus() {
 }
 #endif
 
+// *p = max(*p, v) for floats with the two native integer atomics (no float max atomic on this part; no compare-and-swap
+// loop): a non-negative v orders like its bits as a signed integer, a negative one like the REVERSE of its bits as an
+// unsigned integer, and a non-negative value always beats the bit pattern of a negative one in either view.  *p starts at -inf.
+__device__ __forceinline__ void mm_atomic_fmax(float* p, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(p), __float_as_int(v + 0.f));      // -0 enters as +0
+    else if (v == v) atomicMin(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+}
+
 // v = hi + lo / 2048 to 22-23 significant bits.  v is pinned to ONE float32 value first: left alone, hipcc contracts the
 // caller's multiply into v_fma_mixlo_f16 for the residual (hi rounded once from the exact product) while the stored hi comes
 // from v_cvt_pk_f16_f32 of the rounded product -- the two differ by a binary16 ulp for one sample in ~10^4 (a 1e-4 error).

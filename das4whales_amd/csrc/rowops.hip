@@ -6,7 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "d4w_internal.h"
+#include "fft_radix.h"     // static_for (and d4w_internal.h)
 
 namespace d4w {
 
@@ -210,6 +210,198 @@ __global__ __launch_bounds__(kSosRows) void sos_pass(SosArgsT<T> A, const float*
         }
         lds_barrier();          // the chunk's stores stay in flight under the next chunk
     }
+}
+
+// =============================================================================================
+// The same cascade with the SECTIONS of a row spread over adjacent lanes (a systolic line): lane (row rr, section s) of a wave
+// runs section s on sample t - s at step t and hands its output to lane s + 1 through one DPP move, so a wave advances
+// 64 / G rows (G = 8 lanes per row; 16 for 9-10 sections) by one sample per step with ONE biquad per lane instead of the
+// whole cascade per lane.  sos_pass gives a lane a row: rows of a few hundred samples -- the two row-end pieces the
+// overlap-save band-pass leaves to the exact recursion (2 nx pieces of 2 E = 1204 samples: 345 one-wave workgroups on 256
+// compute units, 0.53 ms per direction at 11 020 rows) -- then run ~1.3 waves per compute unit through a chain of 24 dependent
+// operations per sample.  Here the same pieces make 8 x the waves and a step is 4 dependent operations.  Whole rows only (one
+// exact segment: odd extension at both ends, steady-state initial conditions, the right-extension outputs handed to the
+// backward pass), rows x sections = the lanes of a wave.  Input / output pass through LDS in chunks of 64 samples per row
+// (coalesced 256-byte row pieces on the global side); the four waves of a workgroup are independent.
+// =============================================================================================
+constexpr int kSlThreads = 256;
+constexpr int kSlCh = 64;
+
+__device__ __forceinline__ void sl_wave_sync() {
+#ifdef D4W_EMU
+    (void)__shfl_xor(0, 1);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+// The input of a lane's section at one step: the output `v` of the section below -- S lanes down inside the 16-lane DPP row
+// -- or, for the section-0 lanes (the first S lanes of a DPP row, which have no lane S below), the row's next sample `fresh`:
+// ONE v_mov_b32_dpp whose unwritten lanes keep the old value of the destination.
+template <int S>
+__device__ __forceinline__ float sl_input(float fresh, float v, bool sec0) {
+#ifdef D4W_EMU
+    const float below = __shfl_up(v, (unsigned)S);
+    return sec0 ? fresh : below;
+#else
+    (void)sec0;
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fresh), __float_as_int(v), 0x110 + S /* row_shr:S */, 0xf, 0xf, false));
+#endif
+}
+template <int S>
+__device__ __forceinline__ double sl_input(double fresh, double v, bool sec0) {
+#ifdef D4W_EMU
+    const double below = __shfl_up(v, (unsigned)S);
+    return sec0 ? fresh : below;
+#else
+    (void)sec0;
+    const long long f = __double_as_longlong(fresh), b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(f & 0xFFFFFFFFll), (int)(b & 0xFFFFFFFFll), 0x110 + S, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), 0x110 + S, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+#endif
+}
+
+// Where the rows of a pass live: row r < nsplit starts at base + r ld, row r >= nsplit at base + (r - nsplit) ld + off2 --
+// whole rows of a block (nsplit = all rows), or the LEFT pieces of all rows followed by their RIGHT pieces read / written in
+// place in the block (d4w_sosfiltfilt_ends_f32: no gathered copy of the pieces, no scattered copy of the results).
+struct SlRows {
+    const float* base;
+    size_t ld;
+    long long off2;
+    int nsplit;
+    __device__ __forceinline__ const float* row(int r) const {
+        return (r < nsplit) ? base + (size_t)r * ld : base + (size_t)(r - nsplit) * ld + off2;
+    }
+};
+
+template <int G, bool REV, typename T>
+__global__ __launch_bounds__(kSlThreads) void sos_pass_lanes(SosArgsT<T> A, int nsec, SlRows src, const float* __restrict__ edge_in,
+                                                             SlRows dstr, int keep_a0, int keep_a1, int keep_b0, int keep_b1,
+                                                             float* __restrict__ edge_out, int nx, int ns, int padlen,
+                                                             SlRows piv, float dc_gain2) {
+    // src: the pass's input rows of ns samples (forward: the data; backward: the forward outputs); dstr: where outputs
+    // go, of which rows < nsplit keep the samples [keep_a0, keep_a1) and the others [keep_b0, keep_b1); piv: the ORIGINAL rows
+    // (their first sample is taken out before the forward recursion and put back, times the squared DC gain, after the
+    // backward one, as in sos_pass)
+    constexpr int R = 64 / G;                                   // rows per wave
+    constexpr int SH = 16 / G;                                  // rows interleaved inside a 16-lane DPP row = the shift to the section below
+    // row pitches that spread the rows of a wave over the LDS banks: the last sections of the R rows write the same ring slot
+    // of their rows in one instruction (a pitch of 256 floats put all of them on one bank: 75 % of the LDS cycles of the first
+    // build were bank conflicts, profiles/r05d/pmc_bp), and the R rows' 16-byte input reads start 68 floats apart
+    constexpr int kInP = kSlCh + 4, kRingP = 4 * kSlCh + 1;
+    __shared__ __attribute__((aligned(16))) float lin[kSlThreads / 64][R][kInP];
+    __shared__ float lout[kSlThreads / 64][R][kRingP];          // ring of outputs per row (four chunks), indexed by STEP
+    __shared__ float sink[kSlThreads / 64][5 * kSlCh + 64];     // where the lanes of the other sections write (a slot per lane)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // lane -> (row, section): the sections of a row sit SH lanes apart inside one DPP row (G = 8: two rows interleaved), so
+    // that "the section below" is row_shr:SH and the lanes without one are exactly the section-0 lanes
+    const int rr = (lane >> 4) * SH + (lane & (SH - 1)), sec = (lane & 15) / SH;
+    const int row0 = (blockIdx.x * (kSlThreads / 64) + wv) * R;
+    if (row0 >= nx) return;                                     // whole wave (no workgroup barrier below)
+    const int my_row = min(row0 + rr, nx - 1);
+    // this lane's section (static indices into the kernel argument: a per-lane index would go through scratch memory)
+    T b0 = 0, b1 = 0, b2 = 0, a1 = 0, a2 = 0, z1 = 0, z2 = 0;
+#pragma unroll
+    for (int q = 0; q < kSosMaxSec; ++q)
+        if (q == sec) { b0 = A.s[q].b0; b1 = A.s[q].b1; b2 = A.s[q].b2; a1 = A.s[q].a1; a2 = A.s[q].a2; z1 = A.s[q].z1; z2 = A.s[q].z2; }
+    const int i_start = REV ? ns + padlen - 1 : -padlen;
+    const int count = REV ? ns + padlen : ns + 2 * padlen;
+    auto fetch = [&](int row, int m) -> float {                 // input sample m of `row` (virtual index i_start +- m)
+        const int i = REV ? i_start - m : i_start + m;
+        const float* r = src.row(row);
+        return REV ? sos_fetch_bwd(r, edge_in + (size_t)row * padlen, ns, i) : sos_fetch_fwd(r, ns, i);
+    };
+    const float c_mine = piv.row(my_row)[0];
+    const float x0 = fetch(my_row, 0) - (REV ? 0.f : c_mine);
+    T s1 = z1 * (T)x0, s2 = z2 * (T)x0;
+    T y = 0;
+    const bool last_sec = (sec == nsec - 1);
+    const int nchunks = (count + nsec - 1 + kSlCh - 1) / kSlCh;
+    float pv[R];                                                // the pivots of the wave's rows
+#pragma unroll
+    for (int k = 0; k < R; ++k) pv[k] = piv.row(min(row0 + k, nx - 1))[0];
+    auto flush = [&](int c) {                                   // outputs m in [64 c, 64 c + 64) of the wave's rows
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int m = c * kSlCh + lane, row = row0 + k;
+            if (m < count && row < nx) {
+                const int i = REV ? i_start - m : i_start + m;
+                // the last section produced sample m at step m + nsec - 1; the pivot goes back in here (backward pass)
+                const float v = lout[wv][k][(m + nsec - 1) & (4 * kSlCh - 1)] + (REV ? pv[k] * dc_gain2 : 0.f);
+                const bool ta = row < dstr.nsplit;
+                if (i >= (ta ? keep_a0 : keep_b0) && i < (ta ? keep_a1 : keep_b1)) const_cast<float*>(dstr.row(row))[i] = v;
+                else if (!REV && i >= ns) edge_out[(size_t)row * padlen + (i - ns)] = v;
+            }
+        }
+    };
+    // chunk c + 1 is loaded while chunk c runs its 64 steps (the loads' latency, ~2 us under load, would otherwise stand in
+    // front of every 64 steps of ~1 us)
+    float pre[R];
+    auto load_chunk = [&](int c) {                              // lane = sample of the chunk, one coalesced 256-byte piece per row
+        const int m = c * kSlCh + lane;
+        const int lo = REV ? i_start - (c * kSlCh + kSlCh - 1) : i_start + c * kSlCh;       // the chunk's index range
+        if (lo >= 0 && lo + kSlCh <= ns && c * kSlCh + kSlCh <= count) {                    // inside the rows: plain loads
+            const int i = REV ? i_start - m : i_start + m;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int row = min(row0 + k, nx - 1);
+                pre[k] = src.row(row)[i] - (REV ? 0.f : pv[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int row = min(row0 + k, nx - 1);
+                pre[k] = (m < count) ? fetch(row, m) - (REV ? 0.f : pv[k]) : 0.f;
+            }
+        }
+    };
+    if (nchunks > 0) load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int m0 = c * kSlCh;
+        sl_wave_sync();                                         // the previous chunk's reads of lin are done
+#pragma unroll
+        for (int k = 0; k < R; ++k) lin[wv][k][lane] = pre[k];
+        sl_wave_sync();
+        // the row's 64 inputs of this chunk in registers (every lane of a row reads the same addresses: broadcasts), so that
+        // no LDS round trip sits between two steps of the recursion
+        float in[kSlCh];
+#pragma unroll
+        for (int q = 0; q < kSlCh / 4; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(&lin[wv][rr][0])[q];
+            in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+        }
+        // A wave's vector-memory operations retire in order: stores issued AFTER the next chunk's loads would have to be
+        // acknowledged before those loads can be waited for with a count the compiler can know (the stores are conditional:
+        // it waits for everything).  So the outputs go out two chunks late, BEFORE the next loads are issued -- by the time
+        // those loads are waited for, a chunk of steps later, the stores in front of them are long done.
+        if (c > 1) flush(c - 2);
+        if (c + 1 < nchunks) load_chunk(c + 1);                 // in flight under the steps below
+        // ---- 64 steps: section `sec` works on sample t - sec.  Only the first G steps of a row need a predicate (a section
+        // must keep its initial state until its first sample arrives); past the row's end the sections run on, their
+        // outputs land in slots of the ring that are never flushed
+        // the last section's lanes write the row's ring, every other lane a sink slot of its own: no exec-mask switch per step,
+        // and the slot of step t = m0 + j is a constant offset from a per-chunk base
+        float* ring = (last_sec ? &lout[wv][rr][0] : &sink[wv][lane]) + (m0 & (3 * kSlCh));
+        auto step = [&](int j, bool guarded) {
+            const T xin = sl_input<SH>((T)in[j], y, sec == 0);
+            if (!guarded || m0 + j - sec >= 0) {
+                y = sos_fma(b0, xin, s1);
+                s1 = sos_fma(b1, xin, sos_fma(-a1, y, s2));
+                s2 = sos_fma(b2, xin, -a2 * y);
+            }
+            ring[j] = (float)y;
+        };
+        if (c == 0) {
+            static_for<kSlCh>([&](auto jj) { constexpr int j = decltype(jj)::value; step(j, j < G); });
+        } else {
+            static_for<kSlCh>([&](auto jj) { constexpr int j = decltype(jj)::value; step(j, false); });
+        }
+    }
+    sl_wave_sync();
+    if (nchunks > 1) flush(nchunks - 2);
+    if (nchunks > 0 && (nchunks - 1) * kSlCh < count) flush(nchunks - 1);
 }
 
 // =============================================================================================
@@ -648,22 +840,8 @@ static int xcorr_launch(const float* x, int nx, int ns, const double* mean, cons
     return D4W_OK;
 }
 
-extern "C" {
-
-size_t d4w_sosfiltfilt_ws_bytes(int nx, int ns, int padlen) {
-    if (nx < 1 || ns < 1 || padlen < 0) return 0;
-    return ((size_t)nx * ns + (size_t)nx * std::max(padlen, 1) + (size_t)nx) * sizeof(float);
-}
-
-int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi,
-                        int nsec, int padlen, int seg_len, int warm, void* ws, void* stream) {
-    if (!x || !y || !sos || !zi || !ws) return fail(D4W_EINVAL, "NULL argument");
-    if (nx < 1 || ns < 1 || padlen < 0) return fail(D4W_EINVAL, "bad shape %d x %d (padlen %d)", nx, ns, padlen);
-    if (nsec < 1 || nsec > kSosMaxSec) return fail(D4W_EINVAL, "nsec = %d not in 1..%d", nsec, kSosMaxSec);
-    if (ns <= padlen)
-        return fail(D4W_EINVAL, "The length of the input vector x must be greater than padlen, which is %d.", padlen);
-    SosArgs A;
-    SosArgsT<double> Ad;
+// coefficients of the cascade in both precisions, the precision the recursion needs, the squared DC gain
+static int sos_prepare(const double* sos, const double* zi, int nsec, SosArgs& A, SosArgsT<double>& Ad, bool& precise, double& dcg2) {
     memset(&A, 0, sizeof(A));
     memset(&Ad, 0, sizeof(Ad));
     double dmin = 1e30;                                     // smallest |A_s(e^jw)| over the sections and w
@@ -686,8 +864,52 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     // r e^(j theta): low-frequency poles are the ill-conditioned ones).  Order-8 14-30 Hz at 200 Hz:
     // dmin = 0.027, error 1.5e-6 of the output; 5-38 Hz: dmin = 0.0078, 2e-5.  Below 0.015: float64 states.
     static const int f64_env = [] { const char* v = getenv("D4W_SOS_F64"); return v ? atoi(v) : -1; }();
-    const bool precise = (f64_env >= 0) ? (f64_env > 0) : (dmin < 0.015);
-    const double dcg2 = dcg * dcg;                          // forward and backward pass
+    precise = (f64_env >= 0) ? (f64_env > 0) : (dmin < 0.015);
+    dcg2 = dcg * dcg;                                       // forward and backward pass
+    return D4W_OK;
+}
+
+// forward + backward launch of sos_pass_lanes: src rows -> t rows (all outputs, + the right-extension outputs in `edge`),
+// t rows -> the kept windows of the dst rows
+static int sos_lanes_both(int nsec, bool precise, const SosArgs& A, const SosArgsT<double>& Ad, SlRows src, SlRows tr, SlRows dst,
+                          int ka0, int ka1, int kb0, int kb1, float* edge, int nrows, int n, int padlen, SlRows piv, float dcg2,
+                          void* stream, int phase = 0) {
+    const int G = nsec <= 8 ? 8 : 16;
+    const dim3 lgrid(ceil_div(nrows, (kSlThreads / 64) * (64 / G)));
+#define D4W_SL_LAUNCH(GG, TT, AA)                                                                                            \
+    do {                                                                                                                     \
+        if (phase != 2)                                                                                                      \
+            D4W_LAUNCH((sos_pass_lanes<GG, false, TT>), lgrid, dim3(kSlThreads), 0, stream, AA, nsec, src, (const float*)nullptr, tr, \
+                       0, n, 0, n, edge, nrows, n, padlen, piv, 0.f);                                                        \
+        if (phase != 1)                                                                                                      \
+            D4W_LAUNCH((sos_pass_lanes<GG, true, TT>), lgrid, dim3(kSlThreads), 0, stream, AA, nsec, tr, (const float*)edge, dst, \
+                       ka0, ka1, kb0, kb1, (float*)nullptr, nrows, n, padlen, piv, dcg2);                                    \
+    } while (0)
+    if (precise) { if (G == 8) D4W_SL_LAUNCH(8, double, Ad); else D4W_SL_LAUNCH(16, double, Ad); }
+    else { if (G == 8) D4W_SL_LAUNCH(8, float, A); else D4W_SL_LAUNCH(16, float, A); }
+#undef D4W_SL_LAUNCH
+    return D4W_OK;
+}
+
+extern "C" {
+
+size_t d4w_sosfiltfilt_ws_bytes(int nx, int ns, int padlen) {
+    if (nx < 1 || ns < 1 || padlen < 0) return 0;
+    return ((size_t)nx * ns + (size_t)nx * std::max(padlen, 1) + (size_t)nx) * sizeof(float);
+}
+
+int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi,
+                        int nsec, int padlen, int seg_len, int warm, void* ws, void* stream) {
+    if (!x || !y || !sos || !zi || !ws) return fail(D4W_EINVAL, "NULL argument");
+    if (nx < 1 || ns < 1 || padlen < 0) return fail(D4W_EINVAL, "bad shape %d x %d (padlen %d)", nx, ns, padlen);
+    if (nsec < 1 || nsec > kSosMaxSec) return fail(D4W_EINVAL, "nsec = %d not in 1..%d", nsec, kSosMaxSec);
+    if (ns <= padlen)
+        return fail(D4W_EINVAL, "The length of the input vector x must be greater than padlen, which is %d.", padlen);
+    SosArgs A;
+    SosArgsT<double> Ad;
+    bool precise = false;
+    double dcg2 = 1.0;
+    if (int rcp = sos_prepare(sos, zi, nsec, A, Ad, precise, dcg2)) return rcp;
     int S = seg_len, W = warm;
     if (S <= 0 || W <= 0 || S >= ns) { S = ns; W = ns; }           // one exact segment per row
     S = ((S + kSosChunk - 1) / kSosChunk) * kSosChunk;
@@ -699,6 +921,13 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     // by another workgroup, so they are saved in the workspace's edge area tail first
     float* first = edge + (size_t)nx * std::max(padlen, 1);
     D4W_LAUNCH(sos_first_samples, dim3(ceil_div(nx, 256)), dim3(256), 0, stream, x, nx, ns, first);
+    // One exact segment per row: the sections of a row on adjacent lanes (sos_pass_lanes) -- 8 x the waves of the
+    // lane-per-row kernel, a step of a few dependent operations instead of 3 nsec.  D4W_SOS_LANES=0: the lane-per-row kernel.
+    static const int lanes_env = [] { const char* v = getenv("D4W_SOS_LANES"); return v ? atoi(v) : 1; }();
+    if (nseg == 1 && lanes_env) {
+        const SlRows xr{x, (size_t)ns, 0, nx}, tr{t, (size_t)ns, 0, nx}, yr{y, (size_t)ns, 0, nx}, pr{first, 1, 0, nx};
+        return sos_lanes_both(nsec, precise, A, Ad, xr, tr, yr, 0, ns, 0, ns, edge, nx, ns, padlen, pr, (float)dcg2, stream);
+    }
     if (precise) {
         int rcd = sos_launch<false, double>(nsec, grid, stream, Ad, x, nullptr, t, edge, nx, ns, padlen, S, W, first, 0.f);
         if (rcd) return rcd;
@@ -707,6 +936,36 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
     int rc = sos_launch<false, float>(nsec, grid, stream, A, x, nullptr, t, edge, nx, ns, padlen, S, W, first, 0.f);
     if (rc) return rc;
     return sos_launch<true, float>(nsec, grid, stream, A, t, edge, y, nullptr, nx, ns, padlen, S, W, first, (float)dcg2);
+}
+
+size_t d4w_sosfiltfilt_ends_ws_bytes(int nx, int piece, int padlen) {
+    if (nx < 1 || piece < 1 || padlen < 0) return 0;
+    return ((size_t)2 * nx * piece + (size_t)2 * nx * std::max(padlen, 1)) * sizeof(float);
+}
+
+int d4w_sosfiltfilt_ends_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi, int nsec, int padlen,
+                             int piece, int keep, int phase, void* ws, void* stream) {
+    if (!x || !y || !sos || !zi || !ws) return fail(D4W_EINVAL, "NULL argument");
+    if (x == y) return fail(D4W_EINVAL, "the row ends are read from x while y is written: x and y must not alias");
+    if (nx < 1 || ns < 1 || padlen < 0) return fail(D4W_EINVAL, "bad shape %d x %d (padlen %d)", nx, ns, padlen);
+    if (nsec < 1 || nsec > kSosMaxSec) return fail(D4W_EINVAL, "nsec = %d not in 1..%d", nsec, kSosMaxSec);
+    if (phase < 0 || phase > 2) return fail(D4W_EINVAL, "phase = %d (0 both passes, 1 forward, 2 backward)", phase);
+    if (piece <= padlen || piece > ns || keep < 1 || keep > piece)
+        return fail(D4W_EINVAL, "pieces of %d samples (keep %d) need padlen %d < piece <= ns = %d and 1 <= keep <= piece", piece, keep, padlen, ns);
+    SosArgs A;
+    SosArgsT<double> Ad;
+    bool precise = false;
+    double dcg2 = 1.0;
+    if (int rcp = sos_prepare(sos, zi, nsec, A, Ad, precise, dcg2)) return rcp;
+    float* t = (float*)ws;
+    float* edge = t + (size_t)2 * nx * piece;
+    // rows 0 .. nx-1: the left pieces x[r][0 .. piece), rows nx .. 2 nx - 1: the right pieces x[r][ns - piece .. ns); the
+    // forward outputs of all 2 nx pieces side by side in the workspace; the backward pass writes the `keep` outer samples of
+    // each piece straight into y (left: [0, keep), right: piece samples [piece - keep, piece) = y[r][ns - keep .. ns))
+    const SlRows xr{x, (size_t)ns, (long long)ns - piece, nx}, tr{t, (size_t)piece, (long long)nx * piece, nx};
+    const SlRows yr{y, (size_t)ns, (long long)ns - piece, nx};
+    return sos_lanes_both(nsec, precise, A, Ad, xr, tr, yr, 0, keep, piece - keep, piece, edge, 2 * nx, piece, padlen, xr, (float)dcg2,
+                          stream, phase);
 }
 
 int d4w_copy_cols_f32(const float* src, size_t ld_src, float* dst, size_t ld_dst, int nrows, int ncols, void* stream) {

@@ -155,9 +155,10 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1,
                                                                   int step, int yshift, int ns_out, float dcg, XfHalo H,
-                                                                  const float* __restrict__ pivot) {
+                                                                  const float* __restrict__ pivot, int ld) {
     // mean: the rows' float64 means (matched filter); pivot: instead, a float32 value per row that is taken off the samples
-    // and given back through dcg (the zero-phase FIR's dynamic-range pivot, d4w_fir_fft_f32)
+    // and given back through dcg (the zero-phase FIR's dynamic-range pivot, d4w_fir_fft_f32); ld: row pitch of x and y when
+    // the rows handed over are a column window of longer rows (d4w_fir_fft_cols_f32), 0 = ns
     // step = lags kept per block (B - (support - 1)); lags k < ns_out are stored, lag k at column k + yshift of its row
     // (the zero-phase FIR use, d4w_fir_fft_f32: taps centred at yshift); dcg: mean[row] * dcg is added to every output
     // (the gain the subtracted constant would have had)
@@ -178,8 +179,9 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     const bool hasB = rowA + 1 < nx;
     const int rowB = hasB ? rowA + 1 : rowA;
     const int k0 = blockIdx.x * step;                           // first lag / first sample of the block
-    const float* xa = x + (size_t)rowA * ns;
-    const float* xb = x + (size_t)rowB * ns;
+    const size_t pitch = ld ? (size_t)ld : (size_t)ns;
+    const float* xa = x + (size_t)rowA * pitch;
+    const float* xb = x + (size_t)rowB * pitch;
     Mean2 mua = mean2_load(mean, rowA), mub = mean2_load(mean, rowB);
     if (pivot) {
         mua.hi = pivot[rowA];
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     }
     const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
     const int c0 = HALO ? H.v0 + k0 - H.n_left : k0;             // the block's first sample in the row's own coordinates
-    const bool veca = ((((long long)rowA * ns + c0) & 1) == 0), vecb = ((((long long)rowB * ns + c0) & 1) == 0);
+    // 8-byte aligned sample pairs (the base may be a column window of longer rows: the address decides, not the index)
+    const bool veca = ((reinterpret_cast<uintptr_t>(xa + c0) & 7) == 0), vecb = ((reinterpret_cast<uintptr_t>(xb + c0) & 7) == 0);
     const bool interior = (!HALO || c0 >= 0) && (c0 + kXfB <= ns) && veca && vecb;   // whole block inside both rows, 8-byte aligned pairs
     // NT templates per launch: the host launches NT = 1 once per template.  Measured at 20000 x 120000
     // (HF + LF): two NT = 1 launches 9.1 ms; one NT = 2 launch 11.2 ms (57 KiB of straight-line code
@@ -394,14 +397,14 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                 v[aq] = (aq == 0) ? xv : c2_mulwc(xv, pwi[aq]);
             });
             idftp<NA>(v);
-            float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * ns + yshift;
-            float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * ns + yshift;
+            float* ya = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowA * pitch + yshift;
+            float* yb = ((FUSED ? tsel : t) == 0 ? y0 : y1) + (size_t)rowB * pitch + yshift;
             const v2f dc = v2_make((mua.hi + mua.lo) * dcg, (mub.hi + mub.lo) * dcg);
             // stores: with neighbours (HALO) the block's lags can all lie inside the output although its samples straddle a
             // file boundary -- the wide store path is chosen from the output's own geometry then
-            const bool oveca = HALO ? ((((long long)rowA * ns + yshift + k0) & 1) == 0) : veca;
-            const bool ovecb = HALO ? ((((long long)rowB * ns + yshift + k0) & 1) == 0) : vecb;
-            const bool ointerior = HALO ? (k0 + step <= ns_out && oveca && ovecb) : interior;
+            const bool oveca = ((reinterpret_cast<uintptr_t>(ya + k0) & 7) == 0);
+            const bool ovecb = ((reinterpret_cast<uintptr_t>(yb + k0) & 7) == 0);
+            const bool ointerior = HALO ? (k0 + step <= ns_out && oveca && ovecb) : (interior && oveca && ovecb);
             if (ointerior) {
                 float2* oa = reinterpret_cast<float2*>(ya + k0) + j1;
                 float2* ob = reinterpret_cast<float2*>(yb + k0) + j1;
@@ -1126,7 +1129,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,
-                   kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr);
+                   kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0);
         return D4W_OK;
     }
     for (int t = 0; t < ntpl; ++t) {
@@ -1134,7 +1137,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
         D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
-                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr);
+                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0);
     }
     return D4W_OK;
 }
@@ -1148,10 +1151,20 @@ int d4w_fir_fft_max_halfwidth(void) { return (kXfB - 2048) / 2; }
 
 int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
                     float* y, void* ws, void* stream) {
-    if (!x || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    return d4w_fir_fft_cols_f32(x, nx, ns, taps, K, first, dc_gain, y, K, ns - K, ws, stream);
+}
+
+int d4w_fir_fft_cols_f32(const float* x0, int nx, int ns0, const float* taps, int K, const float* first, double dc_gain,
+                         float* y0, int col0, int col1, void* ws, void* stream) {
+    if (!x0 || !y0 || !ws || nx < 1 || ns0 < 1) return fail(D4W_EINVAL, "bad argument");
     if (K < 0 || (K & 1) || K > d4w_fir_fft_max_halfwidth()) return fail(D4W_EINVAL, "half width %d must be even and <= %d", K, d4w_fir_fft_max_halfwidth());
-    if (ns <= 2 * K) return fail(D4W_EINVAL, "rows of %d samples have no interior for a half width of %d", ns, K);
+    if (ns0 <= 2 * K) return fail(D4W_EINVAL, "rows of %d samples have no interior for a half width of %d", ns0, K);
+    if (col0 < K || col1 > ns0 - K || col0 >= col1) return fail(D4W_EINVAL, "output columns [%d, %d) must lie inside the interior [%d, %d)", col0, col1, K, ns0 - K);
     if (nx > 2 * 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 131070", nx);
+    // the window [col0, col1) of the output = the plain interior filter of the rows x[r][col0 - K .. ns0) (pitch ns0)
+    const int sft = col0 - K, ld = ns0, ns = ns0 - sft, ns_out = col1 - col0;
+    const float* x = x0 + sft;
+    float* y = y0 + sft;
     float* w = (float*)ws;
     XfTables T;
     float2* gp = (float2*)w;
@@ -1166,11 +1179,11 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
         D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, 1, L, L, L, gp, gn,
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
-    const dim3 grid(ceil_div(ns - 2 * K, step), ceil_div(nx, 2));
+    const dim3 grid(ceil_div(ns_out, step), ceil_div(nx, 2));
     const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
-               (float*)nullptr, step, K, ns - 2 * K, (float)dc_gain, XfHalo{}, first);
+               (float*)nullptr, step, K, ns_out, (float)dc_gain, XfHalo{}, first, ld);
     return D4W_OK;
 }
 
@@ -1203,7 +1216,7 @@ int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int 
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
     D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
-               (float*)nullptr, step, 0, ns, (float)dc_gain, H, first);
+               (float*)nullptr, step, 0, ns, (float)dc_gain, H, first, 0);
     return D4W_OK;
 }
 

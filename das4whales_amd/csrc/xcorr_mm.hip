@@ -74,6 +74,8 @@ struct MmArgs {
     float* y0;
     float* y1;
     int nx, ns, ld_next, n_next, ltaps, len0, len1;
+    float* rowmax0;         // [nx] or NULL: max over the lags of every row of y0 (y1), formed in the epilogue (float bits,
+    float* rowmax1;         //   initialised to -inf by the host; combined with integer atomics, mm_atomic_fmax)
     int shift;              // the taps given are taps [shift, shift + len0) of a longer template: lag k reads x[k + shift + n]
     int accumulate;         // add to y0 instead of overwriting it (the later sections of a long template)
 };
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
 
     if (c_n < hi_c) issue(c_n);
     int buf = 0;
+    const bool want_max = P.rowmax0 != nullptr;                     // kernel argument: a scalar branch
     for (long long c = c_n; c < hi_c; c += nq) {
         const int row = row_n, c0 = c0_n;
         const Mean2 mu = mu_n;
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             fl[s_] = frag(bl, wv + 4 * (s_ / KSM), s_ % KSM);
         });
         mm_f4 c0h = mm_zero(), c0l = mm_zero(), c1h = mm_zero(), c1l = mm_zero();
+        float vmax0 = -INFINITY, vmax1 = -INFINITY;                 // this lane's largest stored value of the chunk
         static_for<NST>([&](auto ss) {
             constexpr int s_ = decltype(ss)::value, ti = s_ / KSM, kk = s_ % KSM;
             if constexpr (s_ + PF < NST) {
@@ -323,15 +327,34 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                     }
                     mm_store4(ya + k, r0[0], r0[1], r0[2], r0[3]);
                     if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
+                    if (want_max) {
+                        vmax0 = fmaxf(vmax0, fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));
+                        if constexpr (KS1 > 0) vmax1 = fmaxf(vmax1, fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
+                    }
                 } else {                                            // a row end or an unaligned row (tiles beyond the row: nothing)
                     for (int r = 0; r < 4; ++r)
                         if (k + r < ns) {
-                            ya[k + r] = (KS1 == 0 && P.accumulate) ? ya[k + r] + r0[r] : r0[r];
+                            const float v0 = (KS1 == 0 && P.accumulate) ? ya[k + r] + r0[r] : r0[r];
+                            ya[k + r] = v0;
                             if constexpr (KS1 > 0) yb[k + r] = r1[r];
+                            if (want_max) {
+                                vmax0 = fmaxf(vmax0, v0);
+                                if constexpr (KS1 > 0) vmax1 = fmaxf(vmax1, r1[r]);
+                            }
                         }
                 }
             }
         });
+        if (want_max) {                                             // one atomic per wave, chunk and template
+            for (int o = 32; o > 0; o >>= 1) {
+                vmax0 = fmaxf(vmax0, __shfl_xor(vmax0, o));
+                if constexpr (KS1 > 0) vmax1 = fmaxf(vmax1, __shfl_xor(vmax1, o));
+            }
+            if (lane == 0) {
+                mm_atomic_fmax(P.rowmax0 + row, vmax0);
+                if constexpr (KS1 > 0) mm_atomic_fmax(P.rowmax1 + row, vmax1);
+            }
+        }
         buf ^= 1;
     }
 }
@@ -346,7 +369,7 @@ int d4w_xcorr_mm_max_support(void) { return kMmSection * kMmMaxSections; }
 
 // one template of any support <= d4w_xcorr_mm_max_support(): sections of kMmSection taps, the first one overwriting y, the
 // later ones (x shifted by the section's first tap) accumulating into it
-static int mm_one_template(MmArgs P, const float* taps, int len, float* y, int grid, void* stream) {
+static int mm_one_template(MmArgs P, const float* taps, int len, float* y, float* rowmax, int grid, void* stream) {
     auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
     const int nsec = (len <= 32 * kMmKSMax - 15) ? 1 : ceil_div(len, kMmSection);
     // sections of equal length (a multiple of 16 taps, so that the shifted 16-byte loads stay aligned): 700 taps run as
@@ -361,6 +384,8 @@ static int mm_one_template(MmArgs P, const float* taps, int len, float* y, int g
         Q.y1 = nullptr;
         Q.shift = first;
         Q.accumulate = j > 0;
+        Q.rowmax0 = (j == nsec - 1) ? rowmax : nullptr;             // the maxima of the finished sums
+        Q.rowmax1 = nullptr;
         const int ks = ceil_div(Q.len0 + 15, 32);
         if (ks <= kMmKS)
             D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr), stream, Q);
@@ -377,7 +402,15 @@ static int mm_one_template(MmArgs P, const float* taps, int len, float* y, int g
 int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
                      const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0, float* y1,
                      void* stream) {
+    return d4w_xcorr_mm_rowmax_f32(x, nx, ns, xnext, ld_next, n_next, mean, maxabs, taps, ntpl, ltaps, len0, len1, y0, y1, nullptr,
+                                   nullptr, stream);
+}
+
+int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
+                            const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0, float* y1,
+                            float* rowmax0, float* rowmax1, void* stream) {
     if (!x || !y0 || !taps || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    if (ntpl == 2 && ((rowmax0 == nullptr) != (rowmax1 == nullptr))) return fail(D4W_EINVAL, "rowmax0 and rowmax1 go together");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
     if (xnext && (n_next < 0 || ld_next < n_next)) return fail(D4W_EINVAL, "a continuation needs 0 <= n_next <= ld_next");
     if (ntpl == 1) len1 = len0;
@@ -387,6 +420,11 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
     P.x = x; P.xnext = xnext; P.mean = mean; P.maxabs = maxabs; P.taps = taps; P.y0 = y0; P.y1 = y1;
     P.nx = nx; P.ns = ns; P.ld_next = ld_next; P.n_next = xnext ? n_next : 0; P.ltaps = ltaps; P.len0 = len0; P.len1 = len1;
     P.shift = 0; P.accumulate = 0;
+    P.rowmax0 = rowmax0; P.rowmax1 = (ntpl == 2) ? rowmax1 : nullptr;
+    if (rowmax0) {                                                  // -inf: the identity of the epilogue's integer-atomic float max
+        D4W_HIP(hipMemsetD32Async((hipDeviceptr_t)rowmax0, (int)0xFF800000u, (size_t)nx, (hipStream_t)stream));
+        if (ntpl == 2) D4W_HIP(hipMemsetD32Async((hipDeviceptr_t)rowmax1, (int)0xFF800000u, (size_t)nx, (hipStream_t)stream));
+    }
     const long long total = (long long)nx * ceil_div(ns, kMmCH);
     // persistent workgroups per compute unit: 2 for two templates (207 VGPRs: the Toeplitz fragments of both templates stay
     // in registers; a 168-register build for three workgroups spills and ran 8.5 ms against 6.6), 3 for one template
@@ -400,8 +438,8 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
     if (!fused) {
         // one template, or a support beyond 177 samples: the templates one after the other through the one-template kernels
         // (the Toeplitz fragments of one template alone fill the registers the fused kernel splits between two)
-        int rc = mm_one_template(P, taps, len0, y0, grid, stream);
-        if (rc == D4W_OK && ntpl == 2) rc = mm_one_template(P, taps + ltaps, len1, y1, grid, stream);
+        int rc = mm_one_template(P, taps, len0, y0, rowmax0, grid, stream);
+        if (rc == D4W_OK && ntpl == 2) rc = mm_one_template(P, taps + ltaps, len1, y1, rowmax1, grid, stream);
         return rc;
     }
     auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };

@@ -138,12 +138,14 @@ def _xcorr_method(taps_list, ns, method):
     return "direct"
 
 
-def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None):
+def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None, row_max=None):
     """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
     method: "mm" (matrix cores), "fft" (overlap-save), "direct", or "auto" (_xcorr_method).
     stats: optional (mean, maxabs) CUDA tensors of the rows, e.g. from FkPlan.apply_stats.
     cont: optional (tensor [nx, >= n], n): the record continues -- the last lags read the first n samples of these rows
-    instead of zeros (stream.FileStream); the matrix-core form, or exactly two templates on the FFT form."""
+    instead of zeros (stream.FileStream); the matrix-core form, or exactly two templates on the FFT form.
+    row_max: optional list that receives one CUDA tensor [nx] per template, max over the lags of every row, from the
+    matrix-core kernel's epilogue (d4w_xcorr_mm_rowmax_f32); other forms leave it empty."""
     nx, ns = x.shape
     outs = []
     how = _xcorr_method(taps_list, ns, method)
@@ -166,14 +168,19 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
             ys = [torch.empty_like(x) for _ in grp]
             if how == "mm":
                 taps, lt, _, _ = _xf_prepared(grp, x.device, ws=False)
-                check(lib.d4w_xcorr_mm_f32(dev.ptr(x), nx, ns,
-                                           dev.ptr(cont[0]) if cont is not None else None,
-                                           int(cont[0].stride(0)) if cont is not None else 0,
-                                           int(cont[1]) if cont is not None else 0,
-                                           dev.ptr(mean) if normalize else None, dev.ptr(mx) if normalize else None,
-                                           dev.ptr(taps), len(grp), lt, len(grp[0]), len(grp[-1]),
-                                           dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None, dev.stream_ptr(x)))
+                rm = [torch.empty(nx, dtype=torch.float32, device=x.device) for _ in grp] if row_max is not None else None
+                check(lib.d4w_xcorr_mm_rowmax_f32(dev.ptr(x), nx, ns,
+                                                  dev.ptr(cont[0]) if cont is not None else None,
+                                                  int(cont[0].stride(0)) if cont is not None else 0,
+                                                  int(cont[1]) if cont is not None else 0,
+                                                  dev.ptr(mean) if normalize else None, dev.ptr(mx) if normalize else None,
+                                                  dev.ptr(taps), len(grp), lt, len(grp[0]), len(grp[-1]),
+                                                  dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
+                                                  dev.ptr(rm[0]) if rm else None, dev.ptr(rm[1]) if rm and len(rm) > 1 else None,
+                                                  dev.stream_ptr(x)))
                 outs.extend(ys)
+                if rm:
+                    row_max.extend(rm)
                 continue
             if how == "fft":
                 ent = _xf_prepared(grp, x.device)
@@ -198,6 +205,18 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None)
                                          dev.stream_ptr(x)))
             outs.extend(ys)
     return outs
+
+
+def correlogram_max(c, row_max=None):
+    """np.max(corr_m) of a correlogram as a Python float (scripts/main_mfdetect.py:82: the detection threshold is half the
+    largest correlation): from the per-row maxima the matrix-core correlator left in its epilogue when they are given
+    (stream.FileStream results carry them: one 2-value reduction over nx numbers), else one read of the block -- the
+    library's own reduction either way, one 8-byte copy to the host."""
+    src = row_max if row_max is not None else dev.to_device_f32(c)
+    mm = torch.empty(2, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        check(lib.d4w_minmax_f32(dev.ptr(src), int(src.numel()), dev.ptr(mm), dev.stream_ptr(src)))
+    return float(mm.cpu()[1])
 
 
 def xcorr_continuation_ok(taps_list, ns):
@@ -473,14 +492,30 @@ def buildkernel_from_template(fmin, fmax, dur, fs, nperseg, nhop, plotflag=False
     return spectro
 
 
-def _spectrocorr_device(S, K, off, nout, med=None, zero_ends=False):
-    """S: float32 CUDA [nx, nf, nt]; K: host [nf, nk] -> CUDA [nx, nout] (include/d4w.h d4w_spectrocorr_f32)."""
+_kernel_memo = {}       # (kernel bytes, shape, device) -> device copy of a spectrogram-correlation kernel
+
+
+def _kernel_on_device(K, device):
+    key = (K.tobytes(), K.shape, str(device))
+    with _cache_lock:
+        Kd = _kernel_memo.get(key)
+        if Kd is None:
+            if len(_kernel_memo) > 16:
+                _kernel_memo.clear()
+            Kd = _kernel_memo[key] = torch.from_numpy(K).to(device)
+    return Kd
+
+
+def _spectrocorr_device(S, K, off, nout, med=None, zero_ends=False, out=None):
+    """S: float32 CUDA [nx, nf, nt]; K: host [nf, nk] -> CUDA [nx, nout] (include/d4w.h d4w_spectrocorr_f32).
+    out: optional contiguous [nx, nout] float32 CUDA rows to write into (a slice of a larger result)."""
     nx, nf, nt = S.shape
     K = np.ascontiguousarray(K, dtype=np.float32)
     if K.ndim != 2 or K.shape[0] != nf:
         raise ValueError("kernel has %s rows, the spectrogram %d" % (K.shape[:1], nf))
-    Kd = torch.from_numpy(K).to(S.device)
-    out = torch.empty((nx, nout), dtype=torch.float32, device=S.device)
+    Kd = _kernel_on_device(K, S.device)          # the same few hundred values file after file: uploaded once
+    if out is None:
+        out = torch.empty((nx, nout), dtype=torch.float32, device=S.device)
     with torch.cuda.device(S.device):
         if med is None:
             med = torch.empty(nx, dtype=torch.float32, device=S.device)
@@ -575,7 +610,7 @@ def compute_cross_correlogram_spectrocorr(data, fs, flims, kernel, win_size, ove
     step = int(max(1, min(65535, (2 << 30) // per_ch)))          # <= 2 GiB of spectrogram in flight
     for a in range(0, nx, step):
         S, _ = dsp._stft_mag(x[a:a + step], nperseg, nhop, lo, hi, want_max=False)     # the max-normalisation cancels (docstring)
-        out[a:a + step] = _spectrocorr_device(S, ker, ker.shape[1] // 2, nt)
+        _spectrocorr_device(S, ker, ker.shape[1] // 2, nt, out=out[a:a + step])        # rows a.. of the result, in place
     return dev.like_input(out, data)
 
 

@@ -294,6 +294,20 @@ def _fk_apply(trace, fk_filter_matrix, tapering):
     return dev.like_input(y, trace)
 
 
+def _fk_apply_stats(x, fk_filter_matrix, tapering=False):
+    """fk_filter_filt of a float32 CUDA block that also returns (float64 row means, float32 row maxima) of the result from
+    the last pass's epilogue -- what the matched filter that follows normalises by (detect.py:157); None for odd record
+    lengths (the doubled-record form has no such epilogue)."""
+    nx, ns = x.shape
+    if ns % 2:
+        return _fk_apply_odd(x, fk_filter_matrix, tapering), None
+    plan = get_fk_plan(nx, ns, x.device)
+    with plan.lock:
+        plan.set_mask(fk_filter_matrix)
+        y, mean, mx = plan.apply_stats(x, taper=tapering)
+    return y, (mean, mx)
+
+
 def fk_filter_filt(trace, fk_filter_matrix, tapering=False):
     """Apply a pre-computed f-k mask (dense, on the fftshift-ed grid) -- reference dsp.py:725-756.
 
@@ -425,8 +439,11 @@ _zp_cache = {}
 def _sosfiltfilt_fft(x, sos, padlen):
     """Interior by ONE overlap-save FFT pass with the truncated zero-phase response (d4w_fir_fft_f32, 8 B per sample),
     the E columns at either row end by the exact recursion on short row pieces (both ends of all rows in one call).
-    Returns None when the form does not apply (response too long for the FFT block) or does not pay (the recursion is
-    faster on rows shorter than ~24 pieces: measured 0.95 vs 1.8 ms at 4000 x 12000, 10.3 vs 6.7 ms at 20000 x 120000)."""
+    Returns None when the form does not apply (response too long for the FFT block, rows shorter than a few pieces).
+    Until round 5 rows shorter than ~24 pieces stayed with the segmented recursion (0.95 vs 1.8 ms at 4000 x 12000): the
+    row-end pieces ran one row per lane, 0.5 ms per direction at 11 020 rows.  With the sections of a row on adjacent lanes
+    (sos_pass_lanes) the pieces cost a tenth of that and the 60-s file shapes take this form too (D4W_BP_FFT_MINP = rows
+    of at least that many pieces, default 4)."""
     import os
     if os.environ.get("D4W_BP_FFT", "1") == "0":
         return None
@@ -436,7 +453,7 @@ def _sosfiltfilt_fft(x, sos, padlen):
         return None
     t, K, E, dcg = zp
     P = 2 * E                                        # piece length: E kept + E for the artificial cut to decay
-    if ns < 24 * P or P <= padlen:
+    if ns < int(os.environ.get("D4W_BP_FFT_MINP", "4")) * P or P <= padlen:
         return None
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
@@ -458,22 +475,27 @@ def _sosfiltfilt_fft(x, sos, padlen):
         first = torch.empty(nx, dtype=torch.float32, device=x.device)
         cols(x, 0, ns, first, 0, 1, 1, cur)
         ent = _fir_workspace(t, x.device)
-        check(lib.d4w_fir_fft_f32(dev.ptr(x), nx, ns, None if ent[1] else dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
-                                  dev.ptr(ent[0]), dev.stream_ptr(x)))
+        # the interior kernel writes the columns [E, ns - E) only; the row-end columns belong to the pieces
+        check(lib.d4w_fir_fft_cols_f32(dev.ptr(x), nx, ns, None if ent[1] else dev.ptr(t), int(K), dev.ptr(first), dcg, dev.ptr(y),
+                                       int(E), int(ns - E), dev.ptr(ent[0]), dev.stream_ptr(x)))
         ent[1] = True
+        # the row ends (d4w_sosfiltfilt_ends_f32): both pieces of every row read in place from x and their E outer outputs
+        # written in place into y, the sections of a piece on adjacent lanes -- on the side stream, underneath the interior
+        # kernel (disjoint columns of y: no order between the two is needed)
+        zi = _sos_host(sos)["zi"]
+        sos_p = sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        zi_p = zi.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         if side is not cur:
             side.wait_event(ready)
             x.record_stream(side)
+            # (y needs no record_stream: the calling stream waits for the side stream below, before y can be used or freed;
+            # recording it would make the allocator hold the 9.6-GB block back and cudaMalloc a new one per call)
         with torch.cuda.stream(side):
-            ends = torch.empty((2 * nx, P), dtype=torch.float32, device=x.device)
-            cols(x, 0, ns, ends, 0, P, P, side)
-            cols(x, ns - P, ns, ends, nx * P, P, P, side)
-            ye = _sosfiltfilt_recursive(ends, sos, padlen, 0, 0)
+            ws = torch.empty(int(lib.d4w_sosfiltfilt_ends_ws_bytes(nx, P, padlen)), dtype=torch.uint8, device=x.device)
+            check(lib.d4w_sosfiltfilt_ends_f32(dev.ptr(x), dev.ptr(y), nx, ns, sos_p, zi_p, sos.shape[0], int(padlen), int(P), int(E), 0,
+                                               dev.ptr(ws), ctypes.c_void_p(side.cuda_stream)))
         if side is not cur:
             cur.wait_stream(side)
-            ye.record_stream(cur)
-        cols(ye, 0, P, y, 0, ns, E, cur)
-        cols(ye, nx * P + P - E, P, y, ns - E, ns, E, cur)
     return y
 
 
@@ -528,6 +550,33 @@ def _fir_workspace(t, device):
     return ent
 
 
+def _copy_cols(src, dst):
+    """dst[:, :] = src[:, :] for float32 CUDA views [nx, n] whose samples are adjacent in a row (any row pitch): ONE
+    d4w_copy_cols_f32 launch on the current stream instead of a torch slice copy (the halo bookkeeping of stream.py, the
+    row-end pieces of the band-pass)."""
+    nx, n = src.shape
+    if tuple(dst.shape) != (nx, n) or src.dtype != torch.float32 or dst.dtype != torch.float32 \
+            or (n > 1 and (src.stride(1) != 1 or dst.stride(1) != 1)):
+        raise ValueError("_copy_cols: float32 views of one shape with adjacent samples in a row")
+    if nx == 0 or n == 0:
+        return dst
+    with torch.cuda.device(src.device):
+        check(lib.d4w_copy_cols_f32(src.data_ptr(), int(src.stride(0)), dev.out_ptr(dst), int(dst.stride(0)), nx, n,
+                                    dev.stream_ptr(src)))
+    return dst
+
+
+def _concat_cols(parts):
+    """torch.cat(parts, dim=1) of float32 CUDA views [nx, n_i] by one strided-copy launch per part."""
+    nx = parts[0].shape[0]
+    out = torch.empty((nx, sum(p.shape[1] for p in parts)), dtype=torch.float32, device=parts[0].device)
+    a = 0
+    for p_ in parts:
+        _copy_cols(p_, out[:, a:a + p_.shape[1]])
+        a += p_.shape[1]
+    return out
+
+
 def _sosfiltfilt_between(x, left, right, sos):
     """Zero-phase filter of rows that continue on both sides: x [nx, ns] with the samples before (left [nx, >= K], its LAST
     columns adjacent to x) and after (right [nx, >= K]) read in place by ONE overlap-save pass (d4w_fir_fft_halo_f32,
@@ -546,7 +595,8 @@ def _sosfiltfilt_between(x, left, right, sos):
     lv = left[:, left.shape[1] - K:]                     # views: the kernel takes a base pointer and a row pitch
     y = torch.empty_like(x)
     with torch.cuda.device(x.device):
-        first = x[:, 0].contiguous()
+        first = torch.empty((nx, 1), dtype=torch.float32, device=x.device)
+        _copy_cols(x[:, :1], first)
         ent = _fir_workspace(t, x.device)
         check(lib.d4w_fir_fft_halo_f32(dev.ptr(x), nx, ns, lv.data_ptr(), int(left.stride(0)), int(K), right.data_ptr(),
                                        int(right.stride(0)), int(K), None if ent[1] else dev.ptr(t), int(K), dev.ptr(first),

@@ -61,53 +61,68 @@ class FileStream:
             y = dsp._sosfiltfilt_between(cur if cur.is_contiguous() else cur.contiguous(), left, right, self._sos)
             if y is not None:
                 return y
+        # the first / last file of a record (one neighbour only) or a response longer than the halo: the pieces side by
+        # side in one buffer (one strided-copy launch per piece, no torch.cat), filtered with filtfilt's edge rule at the
+        # true record ends, the file's own columns copied out
         parts = [p for p in (left, cur, right) if p is not None]
-        ext = torch.cat(parts, dim=1) if len(parts) > 1 else cur
-        y = dsp._sosfiltfilt_device(ext.contiguous(), self._sos, 51)
+        ext = dsp._concat_cols(parts) if len(parts) > 1 else (cur if cur.is_contiguous() else cur.contiguous())
+        y = dsp._sosfiltfilt_device(ext, self._sos, 51)
+        if len(parts) == 1:
+            return y
         a = left.shape[1] if left is not None else 0
-        return y[:, a:a + cur.shape[1]].contiguous()
+        return dsp._copy_cols(y[:, a:a + cur.shape[1]], torch.empty_like(cur))
 
     def _finish_bandpass(self, right_head):
         """The oldest waiting raw file now has its right halo (or the stream ends): filter it."""
         idx, cur = self._raw.pop(0)
         y = self._bandpass(self._prev_tail, cur, right_head)
-        self._prev_tail = cur[:, -self.halo:].contiguous() if self.halo > 0 else None
+        self._prev_tail = cur[:, -self.halo:] if self.halo > 0 else None     # a view: the kernels take a row pitch
+        stats = None
         if self.fk_mask is not None:
-            y = dsp.fk_filter_filt(y, self.fk_mask)
+            # the row means / maxima the matched filter normalises by come out of the f-k filter's last pass
+            y, stats = dsp._fk_apply_stats(y, self.fk_mask) if self.taps else (dsp.fk_filter_filt(y, self.fk_mask), None)
         if self._on_filtered is not None:
             self._on_filtered(idx, y)
-        return idx, y
+        return idx, y, stats
 
-    def _correlate(self, idx, y, next_head):
-        """Correlograms of filtered file `y`, its last lags completed with `next_head` (or cut short)."""
+    def _correlate(self, idx, y, next_head, stats=None):
+        """Correlograms of filtered file `y`, its last lags completed with `next_head` (or cut short); stats = (row means,
+        row maxima) of y when the f-k filter left them."""
         out = {"index": idx, "filtered": y}
         if not self.taps:
             return out
         nx, ns = y.shape
         from ._lib import lib, check
-        with torch.cuda.device(y.device):
-            mean = torch.empty(nx, dtype=torch.float64, device=y.device)
-            mx = torch.empty(nx, dtype=torch.float32, device=y.device)
-            check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
+        if stats is not None:
+            mean, mx = stats
+        else:
+            with torch.cuda.device(y.device):
+                mean = torch.empty(nx, dtype=torch.float64, device=y.device)
+                mx = torch.empty(nx, dtype=torch.float32, device=y.device)
+                check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
         if next_head is not None and self.lmax > 1 and next_head.is_cuda and next_head.dtype == torch.float32 \
                 and next_head.stride(1) == 1 and detect.xcorr_continuation_ok(self.taps, ns):
             # rows continue into the next file: the kernel reads the head of the next file's rows in place (de-meaned
             # like the file's own samples) -- no concatenated copy, no cropped copies of the correlograms
-            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, self.lmax - 1))
+            rmax = []
+            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, self.lmax - 1), row_max=rmax)
+            if len(rmax) == len(cs):
+                out["row_max"] = rmax        # max over the lags of every row, per template (detect.correlogram_max)
         else:
             if next_head is not None and self.lmax > 1:
                 # the padding must enter de-meaned like the file's own samples (the kernel subtracts the mean from
                 # every sample it reads)
-                ext = torch.cat((y, next_head[:, :self.lmax - 1]), dim=1).contiguous()
+                ext = dsp._concat_cols([y, next_head[:, :self.lmax - 1]])
             else:
                 ext = y
             cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
-            cs = [c[:, :ns].contiguous() for c in cs]
+            cs = [dsp._copy_cols(c[:, :ns], torch.empty_like(y)) if c.shape[1] != ns else c for c in cs]
         for c, tp, coef in zip(cs, self.taps, self.tail):
             if coef != 0.0 and detect._tail_size(coef, tp, ns) > detect.TAIL_THRESHOLD:
                 with torch.cuda.device(y.device):
                     check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), float(coef), len(tp),
-                                                    dev.ptr(c), dev.stream_ptr(y)))
+                                                    dev.out_ptr(c), dev.stream_ptr(y)))
+                out.pop("row_max", None)         # formed before this term was added
         out["correlograms"] = cs
         return out
 
@@ -120,11 +135,11 @@ class FileStream:
         self._n += 1
         done = []
         if len(self._raw) >= 2:                               # the older raw file has its right halo now
-            head = x[:, :self.halo].contiguous() if self.halo > 0 else None
+            head = x[:, :self.halo] if self.halo > 0 else None        # a view of the new file: no copy
             self._filt.append(self._finish_bandpass(head))
         if len(self._filt) >= 2:                              # the older filtered file has its successor
-            idx, y = self._filt.pop(0)
-            done.append(self._correlate(idx, y, self._filt[0][1]))
+            idx, y, stats = self._filt.pop(0)
+            done.append(self._correlate(idx, y, self._filt[0][1], stats))
         return done
 
     def flush(self, next_head=None, next_filtered_head=None):
@@ -133,16 +148,16 @@ class FileStream:
         next_filtered_head = the first lmax - 1 filtered samples of it (a tensor, or a callable returning one -- e.g.
         the wait on a receive posted earlier)."""
         done = []
-        head = dev.to_device_f32(next_head)[:, :self.halo].contiguous() if next_head is not None and self.halo > 0 else None
+        head = dev.to_device_f32(next_head)[:, :self.halo] if next_head is not None and self.halo > 0 else None
         while self._raw:
-            self._filt.append(self._finish_bandpass(head if len(self._raw) == 1 else self._raw[1][1][:, :self.halo].contiguous()))
+            self._filt.append(self._finish_bandpass(head if len(self._raw) == 1 else self._raw[1][1][:, :self.halo]))
             while len(self._filt) >= 2:
-                idx, y = self._filt.pop(0)
-                done.append(self._correlate(idx, y, self._filt[0][1]))
+                idx, y, stats = self._filt.pop(0)
+                done.append(self._correlate(idx, y, self._filt[0][1], stats))
         while self._filt:
-            idx, y = self._filt.pop(0)
+            idx, y, stats = self._filt.pop(0)
             nxt = self._filt[0][1] if self._filt else None
             if nxt is None and next_filtered_head is not None:
                 nxt = next_filtered_head() if callable(next_filtered_head) else next_filtered_head
-            done.append(self._correlate(idx, y, nxt))
+            done.append(self._correlate(idx, y, nxt, stats))
         return done

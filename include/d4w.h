@@ -222,6 +222,18 @@ size_t d4w_sosfiltfilt_ws_bytes(int nx, int ns, int padlen);
 int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* sos_host,
                         const double* zi_host, int nsec, int padlen, int seg_len, int warm,
                         void* ws, void* stream);
+/* The two row-end pieces of every row filtered exactly and written into y -- what the overlap-save form of the band-pass
+ * (d4w_fir_fft_f32: the interior) leaves to the recursion: the left piece x[r][0 .. piece) and the right piece
+ * x[r][ns - piece .. ns) of every row run d4w_sosfiltfilt_f32's arithmetic as rows of `piece` samples (filtfilt's edge rule at
+ * the true row end; the artificial cut at the inner end has decayed after piece - keep samples), read in place from x, and
+ * their `keep` outer outputs go straight to y[r][0 .. keep) and y[r][ns - keep .. ns): no gathered copy of the pieces, no
+ * scattered copy of the results.  The sections of a piece run on adjacent lanes (csrc/rowops.hip: sos_pass_lanes).
+ * phase 0: both passes; 1: the forward pass only (reads x, fills ws); 2: the backward pass only (reads ws, writes y) -- a
+ * caller that runs the interior kernel meanwhile orders phase 2 behind it (the interior writes columns [K, ns - K), the
+ * pieces own [0, keep) and [ns - keep, ns), keep > K).  x and y must not alias; ws: d4w_sosfiltfilt_ends_ws_bytes. */
+size_t d4w_sosfiltfilt_ends_ws_bytes(int nx, int piece, int padlen);
+int d4w_sosfiltfilt_ends_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi, int nsec,
+                             int padlen, int piece, int keep, int phase, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused ingest (the step in front of the path): data_handle.load_das_data's channel selection and
@@ -312,6 +324,12 @@ int d4w_xcorr_mm_max_support(void);
 int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
                      const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
                      int len0, int len1, float* y0, float* y1, void* stream);
+/* The same, also leaving rowmax_t[c] = max_k y_t[c][k] (DEVICE float32 [nx] per template; rowmax1 only with ntpl = 2) from the
+ * kernel's epilogue: what a detection threshold is set from (scripts/main_mfdetect.py:82,95: 0.5 * max of the correlograms)
+ * without reading the correlograms again.  NULL, NULL: d4w_xcorr_mm_f32. */
+int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
+                            const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
+                            int len0, int len1, float* y0, float* y1, float* rowmax0, float* rowmax1, void* stream);
 
 /* Zero-phase FIR along time by overlap-save FFT blocks -- the INTERIOR of dsp.bp_filt / scipy.signal.sosfiltfilt
  * (dsp.py:859-880): away from the row ends a zero-phase IIR filter is the convolution with its two-sided response
@@ -324,6 +342,10 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
 int d4w_fir_fft_max_halfwidth(void);
 int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
                     float* y, void* ws, void* stream);
+/* The same filter writing only the output columns [col0, col1) (K <= col0 < col1 <= ns - K): the interior kernel of a band-pass
+ * whose row-end columns are owned by d4w_sosfiltfilt_ends_f32 then touches none of them, and the two run side by side. */
+int d4w_fir_fft_cols_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first,
+                         double dc_gain, float* y, int col0, int col1, void* ws, void* stream);
 /* The same for a row that has neighbours on both sides (consecutive files of one record, das4whales_amd/stream.py):
  * left [nx][ld_left] holds the n_left samples before every row, right [nx][ld_right] the n_right samples after it
  * (n_left, n_right >= K), read in place -- no concatenated copy -- and ALL ns columns of y are written:

@@ -21,6 +21,20 @@ bench_nocpu)
     timeout 900 python bench.py --no-cpu > $OUT/bench_line_nocpu.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench_line_nocpu.json ;;
 smoke)
     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -5 $OUT/smoke.log ;;
+stream_kernels)
+    timeout 600 python scripts/stream_kernels.py > $OUT/stream_kernels.txt 2>&1; head -60 $OUT/stream_kernels.txt ;;
+bench_stream)
+    timeout 900 python bench.py --config stream --no-cpu > $OUT/bench_stream_1gpu.json 2> $OUT/bench_stream.err; tail -c 1500 $OUT/bench_stream_1gpu.json; tail -3 $OUT/bench_stream.err ;;
+tests_stream)
+    timeout 1500 python -m pytest tests/test_stream_gpu.py tests/test_pipeline_gpu.py tests/test_spectral_gpu.py tests/test_rowops_gpu.py -x -q -m gpu 2>&1 | tail -30 > $OUT/pytest_stream.log; tail -12 $OUT/pytest_stream.log ;;
+time_bp)
+    timeout 600 python scripts/time_bp.py > $OUT/time_bp.txt 2>&1; D4W_SOS_LANES=0 timeout 600 python scripts/time_bp.py > $OUT/time_bp_lane_per_row.txt 2>&1
+    cat $OUT/time_bp.txt; echo "-- D4W_SOS_LANES=0:"; cat $OUT/time_bp_lane_per_row.txt ;;
+tests_bp)
+    timeout 1500 python -m pytest tests/test_rowops_gpu.py tests/test_stream_gpu.py tests/test_fuzz_gpu.py tests/test_reference_suite_gpu.py -x -q -m gpu 2>&1 | tail -30 > $OUT/pytest_bp.log; tail -8 $OUT/pytest_bp.log ;;
+prof_bp)
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_bp -o bp -- python $OLDPWD/scripts/prof_bp.py > $OLDPWD/$OUT/prof_bp.log 2>&1)
+    f=$(find $OUT/prof_bp -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/kernel_stats_bp_file_shape.csv 2>/dev/null; head -12 $OUT/kernel_stats_bp_file_shape.csv | cut -c1-160; rm -rf $OUT/prof_bp ;;
 *) echo "unknown step $what" ;;
 esac
 done

@@ -538,3 +538,70 @@ def test_offset_heavy_rows_are_demeaned_in_two_floats(emu, offset):
     for name, y in (("mm", ym), ("fft", yf), ("direct", yd)):
         e = max(rel(y[c], ref[c]) for c in range(nx))
         assert e < 2e-6, (name, offset, e)          # measured 1.6e-7 .. 8.3e-7 (the matrix-core form at 10^5: binary16 subnormals)
+
+
+@pytest.mark.parametrize("l0,l1", [(136, 156), (450, 20), (700, 3), (1, 1)])
+def test_xcorr_mm_row_maxima_from_the_epilogue(emu, l0, l1):
+    """d4w_xcorr_mm_rowmax_f32: max over the lags of every correlogram row out of the kernel's epilogue (two integer atomics
+    standing in for a float max) = the maximum of what was stored -- fused two-template launch, one-template launches, a
+    template in sections (only the last section's sums count), rows whose correlogram is negative throughout, ragged row ends."""
+    rng = np.random.default_rng(l0 * 7 + l1)
+    nx, ns = 5, 9001
+    x = np.ascontiguousarray(rng.standard_normal((nx, ns)) + 0.3, dtype=np.float32)
+    t0, t1 = rng.standard_normal(l0), rng.standard_normal(l1)
+    if l0 == 1:                                   # x > 0 against a negative tap: every lag is negative
+        x = np.abs(x) + 0.1
+        t0, t1 = np.array([-0.7]), np.array([0.4])
+    lt = max(4, -(-max(l0, l1) // 4) * 4)
+    taps = np.zeros((2, lt), dtype=np.float32)
+    taps[0, :l0], taps[1, :l1] = t0, t1
+    y0, y1 = np.full_like(x, np.nan), np.full_like(x, np.nan)
+    m0, m1 = np.full(nx, np.nan, np.float32), np.full(nx, np.nan, np.float32)
+    rc = emu.d4w_xcorr_mm_rowmax_f32(vp(x), nx, ns, None, 0, 0, None, None, vp(taps), 2, lt, l0, l1, vp(y0), vp(y1), vp(m0), vp(m1), None)
+    assert rc == 0, emu.d4w_last_error()
+    assert np.array_equal(m0, y0.max(axis=1)) and np.array_equal(m1, y1.max(axis=1))
+    if l0 == 1:
+        assert np.all(m0 < 0)
+    z0, z1 = xcorr_mm_emu(emu, x, [t0, t1], normalize=False)
+    assert np.array_equal(z0, y0) and np.array_equal(z1, y1)             # the plain entry point: same values
+    assert emu.d4w_xcorr_mm_rowmax_f32(vp(x), nx, ns, None, 0, 0, None, None, vp(taps), 2, lt, l0, l1, vp(y0), vp(y1), vp(m0), None, None) != 0
+
+
+@pytest.mark.parametrize("order,nx,ns", [(10, 13, 700), (9, 5, 130), (3, 67, 1205), (8, 1, 64)])
+def test_sos_sections_on_adjacent_lanes(emu, order, nx, ns):
+    """sos_pass_lanes (one exact segment per row: the sections of a row on adjacent lanes, outputs handed on by a DPP move):
+    8 lanes per row up to 8 sections, 16 for 9-10; row counts that leave lanes, waves and workgroups ragged; rows shorter
+    than one staged chunk and rows of many chunks -- against scipy.signal.sosfiltfilt (odd extension, steady-state zi)."""
+    rng = np.random.default_rng(order * 100 + nx)
+    fs = 200.0
+    x = rng.standard_normal((nx, ns)) + rng.standard_normal((nx, 1)) * 5
+    sos = sps.butter(order, [20 / (fs / 2), 45 / (fs / 2)], "bp", output="sos")
+    assert sos.shape[0] == order
+    padlen = min(3 * (2 * order + 1), ns - 1)
+    ref = sps.sosfiltfilt(sos, x, axis=1, padlen=padlen)
+    assert rel(sosfiltfilt_emu(emu, x, sos, padlen=padlen), ref) < TOL
+
+
+@pytest.mark.parametrize("phases", [(0,), (1, 2)])
+def test_row_end_pieces_in_place(emu, phases):
+    """d4w_sosfiltfilt_ends_f32: the left and right `piece` samples of every row filtered as rows of their own (filtfilt's edge
+    rule at both ends of a piece) read in place from x, their `keep` outer outputs written in place into y -- equal to
+    scipy.signal.sosfiltfilt of the gathered pieces; everything else of y untouched; as one call or as forward / backward phases."""
+    rng = np.random.default_rng(77)
+    nx, ns, piece, keep, padlen, fs = 11, 1000, 300, 120, 51, 200.0
+    x = np.ascontiguousarray(rng.standard_normal((nx, ns)) + rng.standard_normal((nx, 1)) * 4, dtype=np.float32)
+    sos = np.ascontiguousarray(sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos"))
+    zi = np.ascontiguousarray(sps.sosfilt_zi(sos))
+    y = np.full_like(x, 7.5)
+    emu.d4w_sosfiltfilt_ends_ws_bytes.restype = ctypes.c_size_t
+    ws = np.empty(emu.d4w_sosfiltfilt_ends_ws_bytes(nx, piece, padlen), dtype=np.uint8)
+    for ph in phases:
+        rc = emu.d4w_sosfiltfilt_ends_f32(vp(x), vp(y), nx, ns, vp(sos), vp(zi), sos.shape[0], padlen, piece, keep, ph, vp(ws), None)
+        assert rc == 0, emu.d4w_last_error()
+    left = sps.sosfiltfilt(sos, x[:, :piece].astype(np.float64), axis=1, padlen=padlen)
+    right = sps.sosfiltfilt(sos, x[:, ns - piece:].astype(np.float64), axis=1, padlen=padlen)
+    scale = np.max(np.abs(left))
+    assert np.max(np.abs(y[:, :keep] - left[:, :keep])) < TOL * scale
+    assert np.max(np.abs(y[:, ns - keep:] - right[:, piece - keep:])) < TOL * scale
+    assert np.all(y[:, keep:ns - keep] == 7.5)
+    assert emu.d4w_sosfiltfilt_ends_f32(vp(x), vp(x), nx, ns, vp(sos), vp(zi), sos.shape[0], padlen, piece, keep, 0, vp(ws), None) != 0

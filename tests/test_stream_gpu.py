@@ -57,6 +57,18 @@ def test_stream_equals_concatenated_record(with_fk):
             ref = np.stack([orc.shift_xcorr(xn[k], np.pad(tp, (0, n - L)))[:ns] for k in range(nx)])
             e = rel(c.cpu().numpy(), ref)
             assert e < TOL, ("correlogram", i, e)
+        # the per-row maxima the correlator leaves in its epilogue for files that continue (what a detection threshold is
+        # set from, scripts/main_mfdetect.py:82,95) are the maxima of the stored correlograms, and correlogram_max the block's
+        if "row_max" in r:
+            for c, rm in zip(r["correlograms"], r["row_max"]):
+                assert torch.equal(rm, c.max(dim=1).values)
+                assert dw.detect.correlogram_max(c, rm) == float(c.max()) == dw.detect.correlogram_max(c)
+        else:
+            # absent for the record's last file (no continuation) and whenever the zero-padded template's DC tail
+            # (detect.py:158) was added after the kernel formed them
+            tails = [dw.detect._tail_size(dw.detect._tail_coef(tf), tp, ns) > dw.detect.TAIL_THRESHOLD and dw.detect._tail_coef(tf) != 0.0
+                     for tf, tp in zip((hf, lf), taps)]
+            assert i == nfiles - 1 or any(tails)
     # a stand-alone file (the reference's per-file run) differs from the stream at the file edges
     alone = dw.dsp.bp_filt(rec[:, ns:2 * ns], FS, 14, 30)
     assert rel(alone, F[:, ns:2 * ns]) > 1e-3
