@@ -824,13 +824,18 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by scripts/pmc_summary.py
     tkey = {"mf_row_stats": "row_stats", "mf_xcorr_fft_blocks_1tpl": "xcorr_fft_blocks",
             "mf_xcorr_fft_fused": "xcorr_fft_fused", "mf_xcorr_mm": "xcorr_mm_rows"}.get(dom, dom)
+    traffic_source = None
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(tkey, {}).get("hbm_bytes_per_launch")
+            # NOT counted in this run: PMC counters need their own rocprofv3 passes (one counter group per run).  The value is
+            # the committed result of such a session on this kernel; the session is named so that it can be checked
+            traffic_source = "profiles/pmc_traffic.json <- " + str(tj.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/pmc.sh)"))
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes[dom],
                 "kernel_ms": kernel_ms, "stage_ms": stage_ms}
     if "fk" in stages:

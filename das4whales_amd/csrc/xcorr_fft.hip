@@ -249,7 +249,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                     const float2 va = pa[a * M1], vb = pb[a * M1];
                     pf[a] = c2{v2_sub(v2_sub(v2_make(va.x, vb.x), mu2), mu2l), v2_sub(v2_sub(v2_make(va.y, vb.y), mu2), mu2l)};
                 });
-            } else if (HALO && veca && vecb && ns >= 4) {
+            } else if (veca && vecb && ns >= 4) {        // (without neighbours too: the last block of a row, a quarter of the blocks of a 60-s file)
                 // a block that straddles a file boundary: most of its samples are still in the row -- their 8-byte loads
                 // go out together (clamped addresses), the few samples beyond the row are fetched one by one afterwards
                 const v2f mu2 = v2_make(mua.hi, mub.hi), mu2l = v2_make(mua.lo, mub.lo);

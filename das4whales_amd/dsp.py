@@ -523,7 +523,9 @@ def _zero_phase_taps(sos, device):
         if zp is None:
             if len(_zp_cache) > 16:
                 _zp_cache.clear()
-            r = _zero_phase_response(sos, tol_taps=1e-7)
+            # tol_edge 1e-8 (ten times below the truncation of the taps, a thousand below the parity bar): E = 532 instead of
+            # 602 for the 14-30 Hz Butterworth-8, 12 % shorter row-end pieces
+            r = _zero_phase_response(sos, tol_taps=1e-7, tol_edge=1e-8)
             if r is not None:
                 taps, K, E = r
                 r = (torch.from_numpy(np.ascontiguousarray(taps, dtype=np.float32)).to(device), K, E,

@@ -15,6 +15,8 @@ G[fetch]="FETCH_SIZE"
 G[write]="WRITE_SIZE"
 G[cache]="GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"
 G[tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"
+# matrix-core pipe: busy cycles summed over the SIMDs, f16 math operations / 512, MFMA instructions, and the time base
+G[mfma]="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"
 for g in ${PMC_GROUPS:-fetch write}; do
   timeout 600 rocprofv3 --kernel-trace --pmc ${G[$g]} --output-format csv -d $R/$OUT/$g -o pmc -- ${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no-cpu ${BENCH_ARGS:-}} > $R/$OUT/$g.log 2>&1
   echo "group $g rc=$?"

@@ -52,4 +52,6 @@ if "--traffic" in sys.argv:
         out[name] = {"kernel": k, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
                      "fetch_factor": factor, "hbm_bytes_per_launch": factor * fetch + write,
                      "note": "FETCH_SIZE in KiB; x2 for wide (>=128 B) requests, x1 for 64-byte strips"}
+    # where the numbers come from (bench.py prints it as roofline.traffic_source): PMC_SOURCE, or the directory summarised
+    out["_source"] = os.environ.get("PMC_SOURCE", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes summarised from %s (scripts/pmc.sh)" % root)
     json.dump(out, open(sys.argv[sys.argv.index("--traffic") + 1], "w"), indent=1, sort_keys=True)

@@ -35,6 +35,15 @@ tests_bp)
 prof_bp)
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_bp -o bp -- python $OLDPWD/scripts/prof_bp.py > $OLDPWD/$OUT/prof_bp.log 2>&1)
     f=$(find $OUT/prof_bp -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/kernel_stats_bp_file_shape.csv 2>/dev/null; head -12 $OUT/kernel_stats_bp_file_shape.csv | cut -c1-160; rm -rf $OUT/prof_bp ;;
+pmc_mfma)
+    # matrix-core pipe counters of the three kernels that use it: two-template correlator (bench shape), the
+    # 16-step one-template correlator (450 taps), the detector's STFT (stream), filter2d of the Gabor detector
+    PMC_GROUPS=mfma BENCH_ARGS="--stages mf" bash scripts/pmc.sh $OUT/pmc_mfma_xcorr > /dev/null 2>&1; cp $OUT/pmc_mfma_xcorr/summary.txt $OUT/pmc_mfma_xcorr.txt
+    PMC_GROUPS=mfma PMC_CMD="env LENS=450 python $GRAFT_REPO_ROOT/scripts/time_xcorr_long.py" bash scripts/pmc.sh $OUT/pmc_mfma_xcorr_long > /dev/null 2>&1; cp $OUT/pmc_mfma_xcorr_long/summary.txt $OUT/pmc_mfma_xcorr_long.txt
+    PMC_GROUPS=mfma PMC_CMD="env FILES=5 python $GRAFT_REPO_ROOT/scripts/stream_kernels.py" bash scripts/pmc.sh $OUT/pmc_mfma_stream > /dev/null 2>&1; cp $OUT/pmc_mfma_stream/summary.txt $OUT/pmc_mfma_stream.txt
+    PMC_GROUPS=mfma PMC_CMD="python $GRAFT_REPO_ROOT/scripts/time_image.py" bash scripts/pmc.sh $OUT/pmc_mfma_image > /dev/null 2>&1; cp $OUT/pmc_mfma_image/summary.txt $OUT/pmc_mfma_image.txt
+    rm -rf $OUT/pmc_mfma_xcorr $OUT/pmc_mfma_xcorr_long $OUT/pmc_mfma_stream $OUT/pmc_mfma_image
+    grep -h -A 6 "xcorr_mm_rows\|stft_mm_rows\|filter2d_mm_rows" $OUT/pmc_mfma_*.txt | head -80 ;;
 *) echo "unknown step $what" ;;
 esac
 done
