@@ -19,6 +19,10 @@ timeout 900 python bench.py --config stream --from-host --steps 10 --warmup 2 2>
 timeout 900 python bench.py --config stream --from-host --files 24 --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_from_host_24files.json; cut -c1-300 $O/bench_stream_from_host_24files.json
 # matched filter: matrix-core kernel against the FFT kernel, errors against float64 (bench shape and the file shape)
 (timeout 300 python scripts/time_xcorr_mm.py; NX=11020 NS=12000 timeout 300 python scripts/time_xcorr_mm.py) 2>/dev/null | grep "^{" > $O/time_xcorr_mm.txt; cut -c1-400 $O/time_xcorr_mm.txt
+# round 5: templates beyond 241 samples on the matrix cores (the reference script's 450-sample template) against the direct form
+(timeout 400 python scripts/time_xcorr_long.py; NX=11020 NS=12000 timeout 300 python scripts/time_xcorr_long.py) 2>/dev/null | grep "^{" > $O/time_xcorr_long.txt; cut -c1-300 $O/time_xcorr_long.txt
+# round 5: the kernels one file of the stream chain launches in steady state (every non-d4w row would be glue)
+timeout 300 python scripts/stream_kernels.py 2>/dev/null | grep -v "^$" > $O/stream_kernels.txt; head -3 $O/stream_kernels.txt
 # what a notebook call costs: host float64 in -> host float64 out, upload / kernel / download
 timeout 600 python scripts/time_host_api.py 2>/dev/null | grep "^{" > $O/time_host_api.txt; cat $O/time_host_api.txt
 timeout 900 python bench.py --shard channel --steps 5 --warmup 2 --force-replicas 2>/dev/null | grep "^{" > $O/bench_shard_channel_1rank.json; cut -c1-200 $O/bench_shard_channel_1rank.json
@@ -42,7 +46,7 @@ cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $R
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_bp_fk_mf.csv
 rm -rf $O/prof
-BENCH_ARGS="--stages bp,fk,mf --no-dense" PMC_GROUPS="fetch write" bash scripts/pmc.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
+PMC_SOURCE="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --stages bp,fk,mf (scripts/evidence_run.sh $O, scripts/pmc.sh)" BENCH_ARGS="--stages bp,fk,mf --no-dense" PMC_GROUPS="fetch write" bash scripts/pmc.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
 cp $O/pmc/summary.txt $O/pmc_fetch_write_summary.txt; cp $O/pmc/pmc_traffic.json $O/pmc_traffic.json; rm -rf $O/pmc
 timeout 900 python scripts/cpu_baseline_c1.py > $O/cpu_baseline_c1.json 2>/dev/null; cut -c1-300 $O/cpu_baseline_c1.json
 timeout 300 python scripts/time_picks3.py 2>/dev/null | grep -E "^\{|find_peaks" > $O/time_picks.txt; head -2 $O/time_picks.txt | cut -c1-300
