@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     float4 pre[kMmQ];                                               // the chunk being loaded (raw samples)
     Mean2 mu_n{0.f, 0.f};                                           // its row's mean (hi + lo) ...
     float g_n = 1.f;                                                // ... and 1 / maxabs
+    bool heavy_n = false;                                           // the row is (nearly) all offset: scale it chunk by chunk
     bool tail_n = false;                                            // the chunk reaches beyond the row (wave-uniform)
     long long c_n = lo_c + wq;
     int row_n = 0, c0_n = 0;
@@ -158,6 +159,9 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         if (P.maxabs) {
             const float a = P.maxabs[row_n];
             g_n = (a > 0.f) ? 1.0f / a : 0.f;
+            // |mean| within 1 / 128 of max|x|: the deviations are at most a hundredth of what 1 / max|x| normalises by and
+            // would sit in (or below) binary16's subnormal range -- such rows take the per-chunk power of two as well
+            heavy_n = fabsf(mu_n.hi) > 0.9921875f * a;
         }
         const float* xr = P.x + (size_t)row_n * ns;
         const bool al = (reinterpret_cast<uintptr_t>(xr + s0) & 15) == 0;
@@ -218,11 +222,13 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool tail = tail_n;
         const int n_valid = ns + ((P.xnext && P.n_next > 0) ? P.n_next : 0) - c0 - P.shift;     // samples of the stage that exist
         float gsc = g_n, osx = 1.f;                                 // x scale applied before the split, and what undoes it
+        const float gout = g_n;                                     // the normalisation's factor, applied to the outputs when a chunk scales itself
+        const bool own_scale = !P.maxabs || heavy_n;                // wave- and workgroup-uniform (one row per chunk)
         mm_half* bh = lds + (size_t)buf * 2 * kMmArr;
         mm_half* bl = bh + kMmArr;
         // ---- convert the loaded chunk: (x - mu) * scale -> hi / lo halves in LDS
-        if (!P.maxabs) {
-            // no row maximum from the caller: this chunk's own power of two.  (With a row maximum the rows are scaled by
+        if (own_scale) {
+            // no row maximum from the caller, or a row that is all offset: this chunk's own power of two.  (With a row maximum the rows are scaled by
             // 1 / max|x| alone: a row whose signal is small against its offset then sits low in the binary16 range, which is
             // harmless -- v_cvt_f16_f32 and the matrix instruction keep binary16 subnormals, scripts/probe/denorm_probe.py:
             // taps at 1e-7 of the largest one still come out at 3e-7 -- and the per-chunk reduction costs a barrier, 3 %.)
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 float s[4] = {demean(v.x, mu) * gsc, demean(v.y, mu) * gsc, demean(v.z, mu) * gsc, demean(v.w, mu) * gsc};
                 // caller-supplied statistics (or the next file's head) may leave |v| beyond binary16's range: inf - inf would turn
                 // a whole tile into NaN where the float32 forms stay finite; the clamp is one v_med3_f32
-                if (P.maxabs) static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; s[e] = mm_clamp_half(s[e]); });
+                if (!own_scale) static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; s[e] = mm_clamp_half(s[e]); });
                 if (tail) {                                          // beyond the data: the zero padding of the correlation
                     const int a0 = 4 * (tid + q * kMmThreads);
                     static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; if (a0 + e >= n_valid) s[e] = 0.f; });
@@ -274,7 +280,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         float* ya = P.y0 + (size_t)row * ns;
         float* yb = KS1 ? P.y1 + (size_t)row * ns : nullptr;
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
-        const float o0 = osc0 * osx, o1 = osc1 * osx;
+        const float oxs = (own_scale && P.maxabs) ? osx * gout : osx;
+        const float o0 = osc0 * oxs, o1 = osc1 * oxs;
         // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
         // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
         // so an LDS round trip hides under 12 matrix instructions instead of stalling the wave at every k-step

@@ -44,6 +44,12 @@ pmc_mfma)
     PMC_GROUPS=mfma PMC_CMD="python $GRAFT_REPO_ROOT/scripts/time_image.py" bash scripts/pmc.sh $OUT/pmc_mfma_image > /dev/null 2>&1; cp $OUT/pmc_mfma_image/summary.txt $OUT/pmc_mfma_image.txt
     rm -rf $OUT/pmc_mfma_xcorr $OUT/pmc_mfma_xcorr_long $OUT/pmc_mfma_stream $OUT/pmc_mfma_image
     grep -h -A 6 "xcorr_mm_rows\|stft_mm_rows\|filter2d_mm_rows" $OUT/pmc_mfma_*.txt | head -80 ;;
+seed_shifts)
+    # the whole GPU suite on shifted seeds (tests/conftest.py: D4W_SEED_SHIFT): different random cases through the same tests
+    for k in ${SHIFTS:-1 2 3 4}; do
+        D4W_SEED_SHIFT=$k timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -25 > $OUT/pytest_gpu_seed_shift_$k.log
+        echo "shift $k: $(grep -E "passed|failed|error" $OUT/pytest_gpu_seed_shift_$k.log | tail -1)"
+    done ;;
 *) echo "unknown step $what" ;;
 esac
 done

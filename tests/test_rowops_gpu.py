@@ -241,7 +241,7 @@ def test_correlogram_matrix_core_form_is_float32_grade(dw):
         assert e_far < 1e-5
 
 
-@pytest.mark.parametrize("offset", [1e3, 1e4, 1e5])
+@pytest.mark.parametrize("offset", [1e3, 1e4, 1e5, 1e6])
 def test_offset_heavy_rows_hold_the_bar_on_every_form(dw, offset):
     """detect.py:157 de-means in float64 and accepts any row.  Rows whose offset is 10^3 .. 10^5 x their signal's deviation and a
     template with a non-zero sum (so that an error of the mean enters every lag): the float64 row means of d4w_row_stats_f32
