@@ -84,6 +84,11 @@ def _load():
                                        c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_dc_tail_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_double, c_int, c_void_p,
                                           c_void_p]),
+        "d4w_row_prefix_max_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+        "d4w_row_stats_prefix_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "d4w_fk_stats_in_epilogue": (c_int, [c_void_p]),
+        "d4w_xcorr_dc_tail_rows_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_double, c_int, c_void_p,
+                                               c_void_p, c_void_p, ctypes.c_double, c_void_p]),
         "d4w_xcorr_mm_max_support": (c_int, []),
         "d4w_xcorr_mm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_void_p, c_void_p, c_void_p]),

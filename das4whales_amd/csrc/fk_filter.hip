@@ -1725,6 +1725,18 @@ static int fk_set_mask_design_run(d4w_fk_plan* pl, int mode, double k_spacing, d
 
 int d4w_fk_plan_live_rows(const d4w_fk_plan* pl) { return pl ? pl->live_rows : -1; }
 
+// Where the row statistics of a filtered block come from.  The last pass's epilogue pays where a pass-A tile is large: at
+// 20 000 x 120 000 (C1 N1 = 625 points per strip column) it adds 0.2 ms to a 3.7-ms pass against 1.7 ms for a separate sweep
+// of y.  At the 60-s file shapes (C1 N1 = 100) the same epilogue turned a 215-us pass into 390 us (500 us with shorter runs:
+// the per-run reduction is what costs, profiles/r05d/stream_kernels.txt) against 137 us for d4w_row_stats_f32: small tiles
+// on large blocks take the sweep.  Plans without the specialised kernels always sweep.
+static bool fk_stats_in_epilogue(const d4w_fk_plan* pl) {
+    if (!pl->fast) return false;
+    const FkDims& d = pl->dev.d;
+    static const int epi_env = [] { const char* v = getenv("D4W_FK_STATS_EPILOGUE"); return v ? atoi(v) : -1; }();
+    return epi_env >= 0 ? epi_env > 0 : (d.C1 * d.N1 >= 256 || (long long)d.nx * d.ns < (1ll << 22));
+}
+
 static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream, hipEvent_t* ev, double* row_mean,
                         float* row_maxabs);
 
@@ -1769,18 +1781,10 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
     const int persist = pl->num_cu * pl->wg_per_cu;
     const dim3 gridA(std::min(ntA, persist)), gridC(std::min(ntC, persist)), gridB(std::min(ntB, persist));
     hipStream_t st = (hipStream_t)stream;
-    if (pl->fast && row_mean) {
-        // The epilogue pays where a pass-A tile is large: at 20 000 x 120 000 (C1 N1 = 625 points per strip column) it adds
-        // 0.2 ms to a 3.7-ms pass against 1.7 ms for a separate sweep of y.  At the 60-s file shapes (C1 N1 = 100) the same
-        // epilogue turned a 215-us pass into 390 us (500 us with shorter runs: the per-run reduction is what costs,
-        // profiles/r05d/stream_kernels.txt) against 137 us for d4w_row_stats_f32: small tiles on large blocks take the sweep.
-        static const int epi_env = [] { const char* v = getenv("D4W_FK_STATS_EPILOGUE"); return v ? atoi(v) : -1; }();
-        const bool epilogue = epi_env >= 0 ? epi_env > 0 : (d.C1 * d.N1 >= 256 || (long long)d.nx * d.ns < (1ll << 22));
-        if (!epilogue) {
-            int rc = fk_apply_run(pl, x, y, taper, stream, ev, nullptr, nullptr);
-            if (rc) return rc;
-            return d4w_row_stats_f32(y, d.nx, d.ns, row_mean, row_maxabs, stream);
-        }
+    if (pl->fast && row_mean && !fk_stats_in_epilogue(pl)) {
+        int rc = fk_apply_run(pl, x, y, taper, stream, ev, nullptr, nullptr);
+        if (rc) return rc;
+        return d4w_row_stats_f32(y, d.nx, d.ns, row_mean, row_maxabs, stream);
     }
     if (pl->fast) {
         const FkFastEntry& F = *pl->fast;
@@ -1914,6 +1918,8 @@ static int fk_apply_run(d4w_fk_plan* pl, const float* x, float* y, int taper, vo
 int d4w_fk_apply_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, void* stream) {
     return fk_apply_impl(pl, x, y, taper, stream, nullptr);
 }
+
+int d4w_fk_stats_in_epilogue(const d4w_fk_plan* pl) { return pl && fk_stats_in_epilogue(pl) ? 1 : 0; }
 
 int d4w_fk_apply_stats_f32(d4w_fk_plan* pl, const float* x, float* y, int taper, double* row_mean, float* row_maxabs,
                            void* stream) {

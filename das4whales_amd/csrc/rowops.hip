@@ -414,10 +414,69 @@ __global__ __launch_bounds__(kSlThreads) void sos_pass_lanes(SosArgsT<T> A, int 
 // =============================================================================================
 constexpr int kStatThreads = 256;
 
+// Four consecutive de-meaned samples of a row piece (zeros past the end); one 16-byte load where the address allows.
+__device__ __forceinline__ void tail_load4(const float* __restrict__ row, int j, int ns, bool vec, Mean2 m, float (&v)[4]) {
+    if (vec && j + 3 < ns) {
+        const float4 q = *reinterpret_cast<const float4*>(row + j);
+        v[0] = demean(q.x, m); v[1] = demean(q.y, m); v[2] = demean(q.z, m); v[3] = demean(q.w, m);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (j + k < ns) ? demean(row[j + k], m) : 0.f;
+    }
+}
+
+// Workgroup-wide exclusive prefix of the threads' sums `loc` (1024 samples per step): returns the sum of all earlier
+// threads' values, `total` = the whole step's sum.  Two barriers per call (wsum is reused by the next step).
+__device__ __forceinline__ float tail_scan(float loc, float* wsum, float& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float incl = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float n = __shfl_up(incl, off);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    float before = 0.f;
+    total = 0.f;
+    for (int w = 0; w < kStatThreads / 64; ++w) {
+        if (w < wave) before += wsum[w];
+        total += wsum[w];
+    }
+    __syncthreads();
+    return before + incl - loc;
+}
+
+// max_j |P[j]|, P[j] = sum_{i < j} (x[i] - m), of one row by one workgroup (every thread returns the workgroup's value in
+// lane-reduced form: the caller finishes across the waves).  wsum: kStatThreads / 64 floats of LDS.
+__device__ __forceinline__ float prefix_max_sweep(const float* __restrict__ row, int ns, Mean2 m, float* wsum) {
+    const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    const int tid = threadIdx.x;
+    double carry = 0.0;
+    float best = 0.f;
+    for (int j0 = 0; j0 < ns; j0 += 4 * kStatThreads) {
+        float v[4], total;
+        tail_load4(row, j0 + 4 * tid, ns, vec, m, v);
+        float pre = (float)carry + tail_scan((v[0] + v[1]) + (v[2] + v[3]), wsum, total);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pre += v[k];                                     // P[j0 + 4 tid + k + 1] (samples past the end add zero)
+            best = fmaxf(best, fabsf(pre));
+        }
+        carry += (double)total;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    return best;
+}
+
+
 __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restrict__ x, int ns,
-                                                          double* __restrict__ mean, float* __restrict__ maxabs) {
+                                                          double* __restrict__ mean, float* __restrict__ maxabs,
+                                                          float* __restrict__ pmax) {
     __shared__ double red_s[kStatThreads / 64];
     __shared__ float red_m[kStatThreads / 64];
+    __shared__ double s_mean;
     const float* row = x + (size_t)blockIdx.x * ns;
     const float pv = row[0];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, mx = 0.f;
@@ -483,8 +542,26 @@ __global__ __launch_bounds__(kStatThreads) void row_stats(const float* __restric
             ts += red_s[w];
             tm = fmaxf(tm, red_m[w]);
         }
-        mean[blockIdx.x] = (double)pv + ts / (double)ns;
+        s_mean = (double)pv + ts / (double)ns;
+        mean[blockIdx.x] = s_mean;
         maxabs[blockIdx.x] = tm;
+    }
+    if (!pmax) return;
+    // the prefix maxima of the de-meaned row (row_prefix_max below) in the same launch: the second sweep of a 60-s row finds
+    // it in L2
+    __syncthreads();
+    const double mu = s_mean;
+    Mean2 m;
+    m.hi = (float)mu;
+    m.lo = (float)(mu - (double)m.hi);
+    float best = prefix_max_sweep(row, ns, m, red_m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red_m[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = red_m[0];
+        for (int w = 1; w < kStatThreads / 64; ++w) b = fmaxf(b, red_m[w]);
+        pmax[blockIdx.x] = b;
     }
 }
 
@@ -598,11 +675,35 @@ __global__ __launch_bounds__(kStatThreads) void raw2strain_rows_vec(const T* __r
 // One workgroup walks a row in order (chunks of 1024 samples, workgroup prefix sum, float64 carry).
 // Negligible for the fin-whale templates (|coef| ~ 5e-7) and applied by the host only when it matters.
 // =============================================================================================
+// max_j |P[j]|, P[j] = sum_{i < j} (x[i] - m): what the DC-tail term of a row can reach, |coef| g max|P| -- the number the
+// per-row decision of xcorr_dc_tail is taken on (a band-passed row has prefix sums of a few samples' size, a drifting one of
+// ns/4 samples' size: the term's weight is a property of the DATA, not of the template alone).
+__global__ __launch_bounds__(kStatThreads) void row_prefix_max(const float* __restrict__ x, int ns,
+                                                               const double* __restrict__ mean, float* __restrict__ pmax) {
+    __shared__ float wsum[kStatThreads / 64];
+    __shared__ float red[kStatThreads / 64];
+    const float* row = x + (size_t)blockIdx.x * ns;
+    const float best = prefix_max_sweep(row, ns, mean2_load(mean, blockIdx.x), wsum);
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        float b = red[0];
+        for (int w = 1; w < kStatThreads / 64; ++w) b = fmaxf(b, red[w]);
+        pmax[blockIdx.x] = b;
+    }
+}
+
+// pmax / rowmax / eps (all or none): the per-row decision -- a row whose term cannot exceed eps x its own largest
+// correlation (rowmax: the correlator's epilogue, d4w_xcorr_mm_rowmax_f32) is left as it is, every other row gets the term
+// and its rowmax entry is formed again over the updated lags.
 __global__ __launch_bounds__(kStatThreads) void xcorr_dc_tail(const float* __restrict__ x, int ns,
                                                               const double* __restrict__ mean,
                                                               const float* __restrict__ maxabs, float coef, int L,
-                                                              float* __restrict__ y) {
+                                                              float* __restrict__ y, const float* __restrict__ pmax,
+                                                              float* __restrict__ rowmax, float eps) {
     __shared__ float wsum[kStatThreads / 64];
+    __shared__ float red[kStatThreads / 64];
     const float* row = x + (size_t)blockIdx.x * ns;
     float* out = y + (size_t)blockIdx.x * ns;
     const Mean2 m = mean2_load(mean, blockIdx.x);
@@ -612,38 +713,37 @@ __global__ __launch_bounds__(kStatThreads) void xcorr_dc_tail(const float* __res
         g = (a > 0.f) ? 1.0f / a : 0.f;
     }
     const float cg = coef * g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (pmax && fabsf(cg) * pmax[blockIdx.x] <= eps * fmaxf(rowmax[blockIdx.x], 0.f)) return;
+    const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    const int tid = threadIdx.x;
     double carry = 0.0;                                      // sum of (x - m) over all earlier chunks
+    float best = -INFINITY;
     for (int j0 = 0; j0 < ns; j0 += 4 * kStatThreads) {
-        float v[4], loc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = j0 + 4 * tid + k;
-            v[k] = (j < ns) ? demean(row[j], m) : 0.f;
-            loc += v[k];
-        }
-        float incl = loc;                                    // inclusive scan of the threads' sums
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float n = __shfl_up(incl, off);
-            if (lane >= off) incl += n;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        float before = 0.f, total = 0.f;
-        for (int w = 0; w < kStatThreads / 64; ++w) {
-            if (w < wave) before += wsum[w];
-            total += wsum[w];
-        }
-        float pre = (float)carry + before + incl - loc;      // P[j0 + 4 tid]
+        float v[4], total;
+        tail_load4(row, j0 + 4 * tid, ns, vec, m, v);
+        float pre = (float)carry + tail_scan((v[0] + v[1]) + (v[2] + v[3]), wsum, total);      // P[j0 + 4 tid]
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int j = j0 + 4 * tid + k;                  // P[j] belongs to lag j - L
-            if (j >= L && j < ns) out[j - L] += cg * pre;
+            if (j >= L && j < ns) {
+                const float o = out[j - L] + cg * pre;
+                out[j - L] = o;
+                best = fmaxf(best, o);
+            }
             pre += v[k];
         }
         carry += (double)total;
-        __syncthreads();
+    }
+    if (!rowmax) return;
+    for (int k = max(ns - L, 0) + tid; k < ns; k += kStatThreads) best = fmaxf(best, out[k]);     // the lags the term leaves alone
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        float b = red[0];
+        for (int w = 1; w < kStatThreads / 64; ++w) b = fmaxf(b, red[w]);
+        rowmax[blockIdx.x] = b;
     }
 }
 
@@ -1008,17 +1108,36 @@ int d4w_raw2strain_f32(const void* raw, int raw_dtype, int ns, int c0, int cstep
     return D4W_OK;
 }
 
+int d4w_xcorr_dc_tail_rows_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs, double coef,
+                               int support, float* y, const float* pmax, float* rowmax, double eps, void* stream) {
+    if (!x || !y || nx < 1 || ns < 1 || support < 1) return fail(D4W_EINVAL, "bad argument");
+    if (pmax && (!rowmax || !(eps >= 0.0))) return fail(D4W_EINVAL, "the per-row decision needs pmax, rowmax and eps >= 0");
+    if (coef == 0.0 || support >= ns) return D4W_OK;
+    D4W_LAUNCH(xcorr_dc_tail, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs, (float)coef, support, y, pmax,
+               rowmax, (float)eps);
+    return D4W_OK;
+}
+
 int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs, double coef,
                           int support, float* y, void* stream) {
-    if (!x || !y || nx < 1 || ns < 1 || support < 1) return fail(D4W_EINVAL, "bad argument");
-    if (coef == 0.0 || support >= ns) return D4W_OK;
-    D4W_LAUNCH(xcorr_dc_tail, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs, (float)coef, support, y);
+    return d4w_xcorr_dc_tail_rows_f32(x, nx, ns, mean, maxabs, coef, support, y, nullptr, nullptr, 0.0, stream);
+}
+
+int d4w_row_prefix_max_f32(const float* x, int nx, int ns, const double* mean, float* pmax, void* stream) {
+    if (!x || !pmax || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(row_prefix_max, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, pmax);
     return D4W_OK;
 }
 
 int d4w_row_stats_f32(const float* x, int nx, int ns, double* mean, float* maxabs, void* stream) {
     if (!x || !mean || !maxabs || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
-    D4W_LAUNCH(row_stats, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs);
+    D4W_LAUNCH(row_stats, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs, (float*)nullptr);
+    return D4W_OK;
+}
+
+int d4w_row_stats_prefix_f32(const float* x, int nx, int ns, double* mean, float* maxabs, float* pmax, void* stream) {
+    if (!x || !mean || !maxabs || !pmax || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
+    D4W_LAUNCH(row_stats, dim3(nx), dim3(kStatThreads), 0, stream, x, ns, mean, maxabs, pmax);
     return D4W_OK;
 }
 

@@ -83,14 +83,15 @@ def _xf_prepared(grp, device, ws=True):
 _row_stats_memo = {}        # (data_ptr, shape, device) -> (weakref to the tensor, its version, (mean, maxabs))
 
 
-def _row_stats_cached(x):
+def _row_stats_cached(x, prefix=False):
     """(mean, max|.|) of the rows of a CUDA tensor, remembered while the SAME tensor (identity and version counter) is asked
     again: the reference's scripts call compute_cross_correlogram once per template on one block
-    (scripts/main_mfdetect.py:79-80), which would read it twice just for the normalisation."""
+    (scripts/main_mfdetect.py:79-80), which would read it twice just for the normalisation.  prefix=True: (mean, max|.|,
+    prefix maxima) from one launch (d4w_row_stats_prefix_f32; what _apply_tails decides on)."""
     import weakref
     nx, ns = x.shape
     # per stream: statistics formed on one stream are not ordered before a kernel of another
-    key = (x.data_ptr(), nx, ns, str(x.device), int(torch.cuda.current_stream(x.device).cuda_stream))
+    key = (x.data_ptr(), nx, ns, str(x.device), int(torch.cuda.current_stream(x.device).cuda_stream), bool(prefix))
     with _cache_lock:
         ent = _row_stats_memo.get(key)
         if ent is not None and ent[0]() is x and ent[1] == x._version:
@@ -98,12 +99,18 @@ def _row_stats_cached(x):
     with torch.cuda.device(x.device):
         mean = torch.empty(nx, dtype=torch.float64, device=x.device)      # float64 (hi + lo for the kernels): d4w.h
         mx = torch.empty(nx, dtype=torch.float32, device=x.device)
-        check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))
+        if prefix:
+            pm = torch.empty(nx, dtype=torch.float32, device=x.device)
+            check(lib.d4w_row_stats_prefix_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.ptr(pm), dev.stream_ptr(x)))
+            res = (mean, mx, pm)
+        else:
+            check(lib.d4w_row_stats_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(x)))
+            res = (mean, mx)
     with _cache_lock:
         if len(_row_stats_memo) > 8:
             _row_stats_memo.clear()
-        _row_stats_memo[key] = (weakref.ref(x), x._version, (mean, mx))
-    return mean, mx
+        _row_stats_memo[key] = (weakref.ref(x), x._version, res)
+    return res
 
 
 def _xcorr_method(taps_list, ns, method):
@@ -273,41 +280,64 @@ def _tail_coef(template):
     return float(t.mean() / np.max(np.abs(t)))
 
 
-# The DC tail is added when its predicted size relative to the correlogram exceeds this.  On white data the tail is
-# ~ 0.35 |coef| sqrt(ns / E) of the correlogram's maximum, E = sum of the squared normalised taps (measured 0.29-0.37 over
-# random templates of 5-137 samples, scripts/probe/fuzz_case_xcorr.py): half the parity bar of 1e-5.  The fin-whale
-# templates on 60-s files come to 3.3e-6 / 4.7e-6 and stay without it; a 19-sample random template with a residual mean
-# comes to 1.9e-5 and gets it (the former rule |coef| sqrt(ns) > 1e-4 ignored the template's energy and let that one pass).
-TAIL_THRESHOLD = 5e-6
+# The DC tail of a zero-padded template (detect.py:158) is |coef| g times a PREFIX SUM of the de-meaned row: 3-5e-6 of the
+# correlogram's maximum for the fin-whale templates on white 60-s rows, 3e-8 on band-passed rows, 1e-3 on rows that drift --
+# a property of the data, so the decision is taken per row on the data (round 5; rounds 1-4 predicted it from the template
+# assuming white rows and let drifting rows pass with 2-9e-4): a row is left without the term only when the term cannot
+# exceed TAIL_EPS of that row's own largest correlation (d4w_row_prefix_max_f32 bounds it, the correlator's epilogue gives
+# the row maximum), every other row receives it.
+TAIL_EPS = 1e-6
 
 
-def _tail_size(coef, taps, ns):
-    """Predicted size of the DC-tail term relative to the correlogram's maximum (white rows)."""
-    e = float(np.sum(np.asarray(taps, dtype=np.float64) ** 2))
-    return 0.35 * abs(coef) * np.sqrt(ns / max(e, 1e-30))
+def _prefix_max(x, mean):
+    """max_j |sum_{i<j} (x - mean)| per row (d4w_row_prefix_max_f32): one read of x, shared by all templates."""
+    nx, ns = x.shape
+    with torch.cuda.device(x.device):
+        pm = torch.empty(nx, dtype=torch.float32, device=x.device)
+        check(lib.d4w_row_prefix_max_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(pm), dev.stream_ptr(x)))
+    return pm
+
+
+def _apply_tails(x, stats, outs, taps, coefs, row_max, exact_tail=None, pmax=None):
+    """Adds the DC-tail term of every template with a non-zero coefficient to its correlogram in place.  exact_tail None:
+    per-row decision (TAIL_EPS) where the correlator left its row maxima, every row otherwise; True: every row; False:
+    none.  Row maxima of the rows that changed are formed again by the kernel.  pmax: the rows' prefix maxima when the
+    caller has them already (dsp.FkPlan.apply_stats_prefix)."""
+    if exact_tail is False or not any(c != 0.0 for c in coefs):
+        return
+    nx, ns = x.shape
+    mean, mx = stats
+    by_row = exact_tail is None and row_max is not None and len(row_max) == len(outs)
+    pm = (pmax if pmax is not None else _prefix_max(x, mean)) if by_row else None
+    with torch.cuda.device(x.device):
+        for k, (o, tp, c) in enumerate(zip(outs, taps, coefs)):
+            if c == 0.0:
+                continue
+            rm = row_max[k] if row_max is not None and len(row_max) == len(outs) else None
+            check(lib.d4w_xcorr_dc_tail_rows_f32(dev.ptr(x), nx, ns, dev.ptr(mean), dev.ptr(mx), float(c), len(tp),
+                                                 dev.out_ptr(o), dev.ptr(pm) if by_row else None,
+                                                 dev.out_ptr(rm) if rm is not None else None,
+                                                 TAIL_EPS if by_row else 0.0, dev.stream_ptr(x)))
 
 
 def compute_cross_correlograms(data, templates, exact_tail=None):
     """Several templates against one block (detect.compute_cross_correlogram for each) -- what
     scripts/main_mfdetect.py:79-80 does with two separate calls.  exact_tail: True / False forces /
-    skips the DC-tail term of the zero-padded template (detect.py:158); None applies it when it is not
-    negligible (TAIL_THRESHOLD)."""
+    skips the DC-tail term of the zero-padded template (detect.py:158) on every row; None (default) decides per row
+    on the data and leaves out only what cannot exceed TAIL_EPS of the row's largest correlation (_apply_tails)."""
     if getattr(data, "ndim", 0) != 2:
         raise ValueError("data must be a 2-D [channel x time] array")
     xd = dev.to_device_f32(data)
     nx, ns = xd.shape
     taps = [_normalised_support(t) for t in templates]
     coefs = [_tail_coef(t) for t in templates]
-    need_tail = [exact_tail if exact_tail is not None else _tail_size(c, tp, ns) > TAIL_THRESHOLD for c, tp in zip(coefs, taps)]
-    stats = None
-    if any(need_tail):
-        stats = _row_stats_cached(xd)
-    outs = _xcorr_device(xd, taps, normalize=True, stats=stats)
-    for o, tp, c, need in zip(outs, taps, coefs, need_tail):
-        if need and c != 0.0:
-            with torch.cuda.device(xd.device):
-                check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(xd), nx, ns, dev.ptr(stats[0]), dev.ptr(stats[1]), c, len(tp),
-                                                dev.out_ptr(o), dev.stream_ptr(xd)))
+    tails = exact_tail is not False and any(c != 0.0 for c in coefs)
+    by_row = tails and exact_tail is None and _xcorr_method(taps, ns, "auto") == "mm"      # the form that leaves row maxima
+    stats = _row_stats_cached(xd, prefix=by_row) if tails else None
+    rmax = [] if by_row else None
+    outs = _xcorr_device(xd, taps, normalize=True, stats=stats[:2] if stats else None, row_max=rmax)
+    if tails:
+        _apply_tails(xd, stats[:2], outs, taps, coefs, rmax, exact_tail, pmax=stats[2] if by_row else None)
     return [dev.like_input(o, data) for o in outs]
 
 

@@ -159,6 +159,26 @@ class FkPlan:
                                              dev.ptr(mx), dev.stream_ptr(x)))
         return out, mean, mx
 
+    def apply_stats_prefix(self, x, out=None, taper=False):
+        """apply_stats() that also returns the rows' prefix maxima max_j |sum_{i<j} (y - mean)| (d4w_row_prefix_max_f32: what
+        bounds the DC-tail term of a zero-padded template, detect._apply_tails).  Where the plan would sweep the result for the
+        statistics anyway (d4w_fk_stats_in_epilogue == 0: the 60-s file shapes) one launch forms all three, the second
+        sweep of a row served by L2."""
+        if int(lib.d4w_fk_stats_in_epilogue(self._h)):
+            out, mean, mx = self.apply_stats(x, out=out, taper=taper)
+            pm = torch.empty(self.nx, dtype=torch.float32, device=x.device)
+            with torch.cuda.device(self.device):
+                check(lib.d4w_row_prefix_max_f32(dev.ptr(out), self.nx, self.ns, dev.ptr(mean), dev.ptr(pm), dev.stream_ptr(x)))
+            return out, mean, mx, pm
+        out = self.apply(x, out=out, taper=taper)
+        mean = torch.empty(self.nx, dtype=torch.float64, device=x.device)
+        mx = torch.empty(self.nx, dtype=torch.float32, device=x.device)
+        pm = torch.empty(self.nx, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(self.device):
+            check(lib.d4w_row_stats_prefix_f32(dev.ptr(out), self.nx, self.ns, dev.ptr(mean), dev.ptr(mx), dev.ptr(pm),
+                                               dev.stream_ptr(x)))
+        return out, mean, mx, pm
+
     def apply_timed(self, x, out=None, taper=False):
         """Like apply() but returns (out, [ms per pass A, C, B, C', A']) via HIP events."""
         if out is None:
@@ -294,16 +314,20 @@ def _fk_apply(trace, fk_filter_matrix, tapering):
     return dev.like_input(y, trace)
 
 
-def _fk_apply_stats(x, fk_filter_matrix, tapering=False):
+def _fk_apply_stats(x, fk_filter_matrix, tapering=False, prefix=False):
     """fk_filter_filt of a float32 CUDA block that also returns (float64 row means, float32 row maxima) of the result from
     the last pass's epilogue -- what the matched filter that follows normalises by (detect.py:157); None for odd record
-    lengths (the doubled-record form has no such epilogue)."""
+    lengths (the doubled-record form has no such epilogue).  prefix=True: (means, maxima, prefix maxima)
+    (FkPlan.apply_stats_prefix)."""
     nx, ns = x.shape
     if ns % 2:
         return _fk_apply_odd(x, fk_filter_matrix, tapering), None
     plan = get_fk_plan(nx, ns, x.device)
     with plan.lock:
         plan.set_mask(fk_filter_matrix)
+        if prefix:
+            y, mean, mx, pm = plan.apply_stats_prefix(x, taper=tapering)
+            return y, (mean, mx, pm)
         y, mean, mx = plan.apply_stats(x, taper=tapering)
     return y, (mean, mx)
 

@@ -80,7 +80,9 @@ class FileStream:
         stats = None
         if self.fk_mask is not None:
             # the row means / maxima the matched filter normalises by come out of the f-k filter's last pass
-            y, stats = dsp._fk_apply_stats(y, self.fk_mask) if self.taps else (dsp.fk_filter_filt(y, self.fk_mask), None)
+            # (and, for zero-padded templates, the prefix maxima their DC-tail term is decided on)
+            y, stats = dsp._fk_apply_stats(y, self.fk_mask, prefix=any(c != 0.0 for c in self.tail)) if self.taps \
+                else (dsp.fk_filter_filt(y, self.fk_mask), None)
         if self._on_filtered is not None:
             self._on_filtered(idx, y)
         return idx, y, stats
@@ -93,13 +95,19 @@ class FileStream:
             return out
         nx, ns = y.shape
         from ._lib import lib, check
+        pm = None
         if stats is not None:
-            mean, mx = stats
+            mean, mx = stats[:2]
+            pm = stats[2] if len(stats) > 2 else None
         else:
             with torch.cuda.device(y.device):
                 mean = torch.empty(nx, dtype=torch.float64, device=y.device)
                 mx = torch.empty(nx, dtype=torch.float32, device=y.device)
-                check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
+                if any(c != 0.0 for c in self.tail):
+                    pm = torch.empty(nx, dtype=torch.float32, device=y.device)
+                    check(lib.d4w_row_stats_prefix_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.ptr(pm), dev.stream_ptr(y)))
+                else:
+                    check(lib.d4w_row_stats_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.stream_ptr(y)))
         if next_head is not None and self.lmax > 1 and next_head.is_cuda and next_head.dtype == torch.float32 \
                 and next_head.stride(1) == 1 and detect.xcorr_continuation_ok(self.taps, ns):
             # rows continue into the next file: the kernel reads the head of the next file's rows in place (de-meaned
@@ -117,12 +125,9 @@ class FileStream:
                 ext = y
             cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
             cs = [dsp._copy_cols(c[:, :ns], torch.empty_like(y)) if c.shape[1] != ns else c for c in cs]
-        for c, tp, coef in zip(cs, self.taps, self.tail):
-            if coef != 0.0 and detect._tail_size(coef, tp, ns) > detect.TAIL_THRESHOLD:
-                with torch.cuda.device(y.device):
-                    check(lib.d4w_xcorr_dc_tail_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), float(coef), len(tp),
-                                                    dev.out_ptr(c), dev.stream_ptr(y)))
-                out.pop("row_max", None)         # formed before this term was added
+        # the DC tail of zero-padded templates, decided per row on the data (detect._apply_tails: the band-passed rows of
+        # a stream have prefix sums of a few samples' size and are left alone; the row maxima stay valid either way)
+        detect._apply_tails(y, (mean, mx), cs, self.taps, self.tail, out.get("row_max"), pmax=pm)
         out["correlograms"] = cs
         return out
 

@@ -120,6 +120,10 @@ int d4w_fk_apply_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, voi
  * other shapes run d4w_row_stats_f32 afterwards.  Feed them to d4w_xcorr_fft_f32 / d4w_xcorr_lens_f32. */
 int d4w_fk_apply_stats_f32(d4w_fk_plan* plan, const float* x, float* y, int taper, double* row_mean,
                            float* row_maxabs, void* stream);
+/* 1 when d4w_fk_apply_stats_f32 on this plan forms the statistics in the last pass's epilogue, 0 when it sweeps y afterwards
+ * (small pass tiles on large blocks, the 60-s file shapes; unspecialised shapes): a caller that also wants the rows' prefix
+ * maxima then runs d4w_fk_apply_f32 + d4w_row_stats_prefix_f32 for the same traffic. */
+int d4w_fk_stats_in_epilogue(const d4w_fk_plan* plan);
 
 /* Same as d4w_fk_apply_f32 but brackets each of the five passes (A, C, B, C', A') with HIP events
  * on `stream`, synchronises, and returns their durations in milliseconds in ms5_host[0..4].
@@ -280,10 +284,24 @@ int d4w_xcorr_lens_f32(const float* x, int nx, int ns, const double* mean, const
  *   y[c][k] += coef * g[c] * sum_{i < k + support} (x[c][i] - m[c]),  k + support < ns,
  * coef = mean(template) / max|template| over the zero-padded length, support = length of the non-zero
  * part.  Added in place to a correlogram produced by d4w_xcorr_*_f32 with the same mean / maxabs.
- * |coef| ~ 5e-7 for the fin-whale templates (a 3-5e-6 effect on a 60-s file), so hosts apply it only when its predicted size,
- * ~ 0.35 |coef| sqrt(ns / sum taps^2) of the correlogram's maximum on white rows, is not negligible (the Python mirror: 5e-6). */
+ * |coef| ~ 5e-7 for the fin-whale templates: a 3-5e-6 effect on a 60-s file of WHITE rows, 3e-8 on band-passed rows, 1e-3 on
+ * rows that drift (the term is |coef| g times a PREFIX SUM of the de-meaned row: its weight is a property of the data).
+ *
+ * d4w_row_prefix_max_f32:  pmax[c] = max_j |sum_{i < j} (x[c][i] - m[c])|  -- the most the term of row c can reach is
+ *     |coef| g[c] pmax[c]; one read of x.
+ * d4w_xcorr_dc_tail_rows_f32: the same update with a per-row decision: with pmax / rowmax given (rowmax[c] = max over the
+ *     lags of y[c][:], d4w_xcorr_mm_rowmax_f32's epilogue) a row with |coef| g pmax <= eps max(rowmax, 0) is left alone --
+ *     the omitted term is below eps of that row's largest correlation, whatever the data --, every other row receives the
+ *     term and its rowmax entry is formed again.  pmax = rowmax = NULL: every row (d4w_xcorr_dc_tail_f32).  The Python
+ *     mirror runs this with eps = 1e-6 (a tenth of the parity bar) whenever a zero-padded template has a non-zero mean. */
 int d4w_xcorr_dc_tail_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs,
                           double coef, int support, float* y, void* stream);
+int d4w_row_prefix_max_f32(const float* x, int nx, int ns, const double* mean, float* pmax, void* stream);
+/* d4w_row_stats_f32 and d4w_row_prefix_max_f32 in one launch (the second sweep of a 60-s row is served by L2) */
+int d4w_row_stats_prefix_f32(const float* x, int nx, int ns, double* mean, float* maxabs, float* pmax, void* stream);
+int d4w_xcorr_dc_tail_rows_f32(const float* x, int nx, int ns, const double* mean, const float* maxabs,
+                               double coef, int support, float* y, const float* pmax, float* rowmax, double eps,
+                               void* stream);
 
 /* Overlap-save FFT form of the same correlation for short templates (support <=
  * d4w_xcorr_fft_max_support() = 161 samples; the fin-whale templates have 136 / 156): blocks of

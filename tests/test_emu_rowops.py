@@ -262,6 +262,60 @@ def test_xcorr_dc_tail_exact(emu):
         assert rel(y, ref) < TOL, (nx, ns, L, rel(y, ref))
 
 
+def test_xcorr_dc_tail_is_decided_per_row_on_the_data(emu):
+    """The DC-tail term's weight is a property of the row (|coef| g x a prefix sum of the de-meaned row): d4w_row_prefix_max_f32
+    bounds it, d4w_xcorr_dc_tail_rows_f32 leaves a row alone only when the term cannot exceed eps of the row's own largest
+    correlation, and forms the row maximum of every row it changes again.  Rows: white, band-limited (no low frequencies:
+    tiny prefix sums), a slow drift and a step (prefix sums of ns/4 samples' size: 1e-3 of the correlogram with the
+    fin-whale template, which a rule that predicts the term from the template alone lets pass)."""
+    rng = np.random.default_rng(120)
+    fs, ns = 200.0, 6000
+    t = np.arange(ns) / fs
+    tpl = orc.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)
+    L = int(np.nonzero(tpl)[0][-1]) + 1
+    coef = tpl.mean() / np.max(np.abs(tpl))
+    assert coef != 0.0
+    w = rng.standard_normal((4, ns))
+    band = sps.sosfiltfilt(sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos"), rng.standard_normal(ns))
+    x = np.stack([w[0], band, 0.05 * w[1] + np.sin(2 * np.pi * t / 30.0), np.where(t < 15, 1.0, -1.0) + 0.01 * w[2]]) + 0.3
+    nx = len(x)
+    ref = orc.compute_cross_correlogram(x, tpl)
+    (y,), mean, mx = xcorr_emu(emu, x, [norm_taps(tpl)])
+    row_err = lambda k: np.max(np.abs(y[k] - ref[k])) / np.max(np.abs(ref[k]))
+    before = [row_err(k) for k in range(nx)]
+    assert before[1] < 1e-6 and before[2] > 1e-4 and before[3] > 1e-4, before      # the hole: drift and step rows without the term
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    pm = np.empty(nx, dtype=np.float32)
+    assert emu.d4w_row_prefix_max_f32(vp(xf), nx, ns, vp(mean), vp(pm), None) == 0, emu.d4w_last_error()
+    d = xf.astype(np.float64) - mean[:, None]
+    P = np.abs(np.cumsum(d, axis=1)).max(axis=1)
+    assert np.allclose(pm, P, rtol=1e-4, atol=1e-3 * np.abs(d).max()), (pm, P)
+    # the same maxima together with the statistics in one launch
+    mean2, mx2, pm2 = np.empty(nx), np.empty(nx, dtype=np.float32), np.empty(nx, dtype=np.float32)
+    assert emu.d4w_row_stats_prefix_f32(vp(xf), nx, ns, vp(mean2), vp(mx2), vp(pm2), None) == 0, emu.d4w_last_error()
+    assert np.array_equal(mean2, mean) and np.array_equal(mx2, mx) and np.array_equal(pm2, pm)
+    rmax = y.max(axis=1).astype(np.float32)
+    rmax0 = rmax.copy()
+    y0 = y.copy()
+    eps = 1e-6
+    rc = emu.d4w_xcorr_dc_tail_rows_f32(vp(xf), nx, ns, vp(mean), vp(mx), ctypes.c_double(coef), L, vp(y), vp(pm), vp(rmax),
+                                         ctypes.c_double(eps), None)
+    assert rc == 0, emu.d4w_last_error()
+    changed = [not np.array_equal(y[k], y0[k]) for k in range(nx)]
+    assert changed == [True, False, True, True], changed
+    for k in range(nx):
+        assert row_err(k) < (eps * 1.5 if not changed[k] else 2e-6), (k, row_err(k))
+        assert rmax[k] == y[k].max()
+    assert rmax[1] == rmax0[1]
+    # pmax without rowmax is refused; without either, every row gets the term (d4w_xcorr_dc_tail_f32)
+    assert emu.d4w_xcorr_dc_tail_rows_f32(vp(xf), nx, ns, vp(mean), vp(mx), ctypes.c_double(coef), L, vp(y), vp(pm), None,
+                                          ctypes.c_double(eps), None) == -1
+    y1 = y0.copy()
+    assert emu.d4w_xcorr_dc_tail_rows_f32(vp(xf), nx, ns, vp(mean), vp(mx), ctypes.c_double(coef), L, vp(y1), None, None,
+                                          ctypes.c_double(0.0), None) == 0
+    assert not np.array_equal(y1[1], y0[1]) and np.array_equal(y1[0], y[0])
+
+
 def test_bandpass_low_edge_uses_float64_states(emu):
     """A 5 Hz band edge at 200 Hz puts poles at radius > 0.98: the float32 recursion's rounding noise
     (2e-5) exceeds the budget, the library switches to float64 states (float32 I/O)."""

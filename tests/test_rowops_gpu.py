@@ -273,6 +273,48 @@ def test_offset_heavy_rows_hold_the_bar_on_every_form(dw, offset):
     assert rel(got, orc.compute_cross_correlogram(xs, tfull)) < TOL
 
 
+def test_zero_padded_template_on_rows_that_drift(dw):
+    """detect.py:158 de-means the template over its zero-padded length, which leaves -mean/max on the padded part: a term of
+    |coef| g x (a prefix sum of the de-meaned row).  3e-6 of the correlogram on white rows, 3e-8 on band-passed rows -- and
+    3e-4 .. 1e-3 on rows with a slow drift or a step, which the rule of rounds 1-4 (a prediction from the template, white rows
+    assumed) let pass.  The public call with its defaults against the oracle on white, band-limited, drifting and stepped
+    rows, per row (every row against ITS OWN maximum), for one and for two templates; the rows that keep the term out are
+    the band-limited ones only."""
+    import scipy.signal as sps
+    rng = np.random.default_rng(121)
+    ns = 12000
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+    lf = orc.gen_template_fincall(t, FS, 14.7, 21.8, 0.78)
+    sos = sps.butter(8, [14 / (FS / 2), 30 / (FS / 2)], "bp", output="sos")
+    w = rng.standard_normal((40, ns))
+    rows = []
+    for k in range(10):
+        rows += [w[4 * k], sps.sosfiltfilt(sos, w[4 * k + 1]), 0.05 * w[4 * k + 2] + np.sin(2 * np.pi * t / (20.0 + 7 * k) + k),
+                 np.where(t < 5.0 * (k + 1), 1.0, -1.0) + 0.01 * w[4 * k + 3]]
+    x = np.stack(rows) + 0.2
+    nx = len(x)
+    xs = x.astype(np.float32)
+    refs = [orc.compute_cross_correlogram(xs.astype(np.float64), tp) for tp in (hf, lf)]
+    per_row = lambda y, ref: np.max(np.abs(np.asarray(y, dtype=np.float64) - ref), axis=1) / np.max(np.abs(ref), axis=1)
+    xd = torch.from_numpy(xs).cuda()
+    got = dw.detect.compute_cross_correlograms(xd, [hf, lf])
+    for y, ref in zip(got, refs):
+        e = per_row(y.cpu().numpy(), ref)
+        print("zero-padded template, worst row error by kind (white, band, drift, step): %s" % ["%.1e" % e[k::4].max() for k in range(4)])
+        assert e.max() < TOL, e
+    one = dw.detect.compute_cross_correlogram(xs, hf)                        # host in, host out
+    assert per_row(one, refs[0]).max() < TOL
+    # what the term is worth here, and which rows the per-row rule leaves alone
+    bare = dw.detect.compute_cross_correlograms(xd, [hf, lf], exact_tail=False)
+    e0 = per_row(bare[0].cpu().numpy(), refs[0])
+    assert e0[2::4].min() > 1e-4 and e0[3::4].min() > 1e-4 and e0[1::4].max() < 1e-6, e0
+    same = (bare[0] == got[0]).all(dim=1).cpu().numpy()
+    assert same[1::4].all() and not same[0::4].any() and not same[2::4].any() and not same[3::4].any(), same
+    full = dw.detect.compute_cross_correlograms(xd, [hf, lf], exact_tail=True)
+    assert per_row(full[0].cpu().numpy(), refs[0]).max() < TOL
+
+
 def test_row_statistics_are_not_reused_after_a_raw_pointer_write(dw):
     """the library writes through raw pointers, which torch's version counter does not see -- `plan.apply(x_i,
     out=y); compute_cross_correlogram(y, tpl)` in a per-file loop must not find file 0's row statistics on file 1.  Every
