@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libd4w.so")
+# D4W_LIB: another build of the same library (probe builds with extra instrumentation, scripts/probe/fp_timing.sh)
+LIB_PATH = os.environ.get("D4W_LIB") or os.path.join(_HERE, "lib", "libd4w.so")
 
 D4W_OK = 0
 _ERRORS = {-1: ValueError, -2: MemoryError, -3: RuntimeError}

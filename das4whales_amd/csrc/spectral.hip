@@ -913,6 +913,76 @@ __device__ __forceinline__ float fp_walk(const float* __restrict__ r, const floa
     return lmin;
 }
 
+// The same decision taken by a whole WAVE for one side of one candidate: lane l looks at entry l of the phase (sample,
+// block summary or super-block summary), two ballots give the first entry that stops the walk (max > v) and the first one
+// that satisfies it (min <= lim), and the earlier of the two decides -- one LDS round trip and ~30 instructions per phase
+// where the lane-per-side walk takes a round trip and ~150 instructions per 4-8 entries.  A row whose candidates are few
+// (an envelope with thr a fraction of its strongest peak: ~10 per row) leaves 60 of 64 lanes idle in fp_walk and still
+// pays its issue slots in every wave of the workgroup: 23 of 78 thousand cycles per row at 11020 x 12000
+// (scripts/probe/fp_timing.py); fp_scan runs this form when the sides are few.  Returns whether the running minimum
+// reaches lim before a sample > v or the row end (fp_walk(...) <= lim); q, v, lim are wave-uniform.
+template <int DIR>
+__device__ __forceinline__ int fp_wave_phase(const float hi, const float lo, bool in, float v, float lim, int& first) {
+    const unsigned long long h = __ballot(in && hi > v), sfy = __ballot(in && lo <= lim);
+    const int fh = h ? __builtin_ctzll(h) : 64, fs = sfy ? __builtin_ctzll(sfy) : 64;
+    first = fh;
+    return fs < fh ? 2 : (h ? 1 : 0);
+}
+
+template <int DIR>
+__device__ __forceinline__ bool fp_walk_wave(const float* __restrict__ r, const float2* __restrict__ s1,
+                                             const float2* __restrict__ s2, int ns, int nb, int nb2, int bshift, int q,
+                                             float v, float lim, int lane) {
+    const int BS = 1 << bshift, SB = BS * kFpFan;
+    if (v <= lim) return true;                                // thr <= 0: the peak itself is its base
+    auto samples = [&](int n) -> int {                        // 2 satisfied, 1 stopped (q at the stopper), 0 ran out (q past them)
+        for (int done = 0; done < n; done += 64) {
+            const int j = q + DIR * lane, m = min(64, n - done);
+            const bool in = lane < m && j >= 0 && j < ns;
+            const float u = r[min(max(j, 0), ns - 1)];
+            int first;
+            const int st = fp_wave_phase<DIR>(u, u, in, v, lim, first);
+            if (st == 2) return 2;
+            if (st == 1) { q += DIR * first; return 1; }
+            q += DIR * m;
+        }
+        return 0;
+    };
+    auto blocks = [&](const float2* sm, int nent, int shift, int n, int step) -> int {
+        for (int done = 0; done < n; done += 64) {
+            const int e = (q + DIR * lane * step) >> shift, m = min(64, n - done);
+            const bool in = lane < m && e >= 0 && e < nent;
+            const float2 sv = sm[min(max(e, 0), nent - 1)];
+            int first;
+            const int st = fp_wave_phase<DIR>(sv.x, sv.y, in, v, lim, first);
+            if (st == 2) return 2;
+            if (st == 1) { q += DIR * first * step; return 1; }
+            q += DIR * m * step;
+        }
+        return 0;
+    };
+    // the phases of fp_walk, entry for entry
+    int n = (DIR < 0) ? ((q + 1) & (BS - 1)) : ((BS - (q & (BS - 1))) & (BS - 1));
+    if (DIR > 0) n = min(n, ns - q);
+    int st = samples(n);
+    if (st) return st == 2;
+    if ((DIR < 0) ? (q < 0) : (q >= ns)) return false;
+    const int blk = q >> bshift;
+    n = (DIR < 0) ? ((blk + 1) & (kFpFan - 1)) : ((kFpFan - (blk & (kFpFan - 1))) & (kFpFan - 1));
+    if (DIR > 0) n = min(n, nb - blk);
+    st = blocks(s1, nb, bshift, n, BS);
+    if (st == 2) return true;
+    if (st == 0) {
+        if ((DIR < 0) ? (q < 0) : (q >= ns)) return false;
+        const int sb = q >> (bshift + 5);
+        n = (DIR < 0) ? sb + 1 : nb2 - sb;
+        st = blocks(s2, nb2, bshift + 5, n, SB);
+        if (st != 1) return st == 2;                                        // satisfied, or the row end without a base
+        if (blocks(s1, nb, bshift, kFpFan, BS) == 2) return true;         // blocks of the stopping super-block
+    }
+    return samples(BS) == 2;
+}
+
 // LDS tables of the picker for one row (after `lead` bytes the caller uses itself)
 struct FpLds {
     float2* s1;        // [nb]  (max, min) of every block
@@ -1194,7 +1264,17 @@ __device__ __forceinline__ int fp_sweep_segments(const float* __restrict__ rg, c
 //       candidate c.  Walking inside the marking loop instead made a wave pay the SUM of its lanes' walks (one lane
 //       walking, 63 masked): 0.72 of 0.97 ms at 11020 x 12000 with ~15 picks per row.
 // r: the row (LDS or global).  Ends with the accepted peaks in T.bits; the last barrier is the caller's.
+#ifdef D4W_FP_TIMING      // probe builds only (scripts/probe/fp_timing.py): cycles of workgroup 0's thread 0 between phase marks
+__device__ unsigned long long g_fp_t[16];
+#define FP_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_fp_t[k], t_ - fp_t0); fp_t0 = t_; } } while (0)
+#define FP_T0 unsigned long long fp_t0 = clock64()
+#else
+#define FP_MARK(k) do {} while (0)
+#define FP_T0 do {} while (0)
+#endif
+
 constexpr int kFpList = 4096;          // candidates per walk round
+constexpr int kFpWaveSides = 64;       // up to this many walk sides per round a wave takes a side (fp_walk_wave)
 static_assert(kFpSegW + kFpSegE + kFpSegC + kFpSegC / 2 + kFpThreads / 64 <= kFpList, "the window and its lists live in the candidate list");
 
 __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds& T, int ns, int nb, int nb2, int bshift,
@@ -1203,6 +1283,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
     // mark_from: first sample whose maxima are still to be marked (0: the whole row; > 0: fp_sweep_segments has dealt with
     // the samples before it -- a multiple of 4 -- and left in T.cand only the maxima it could not settle inside their window)
     const int lane = tid & 63, wave = tid >> 6;
+    FP_T0;
     float gmin = INFINITY;
     for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
     if (mark_from == 0) {
@@ -1248,13 +1329,35 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
         }
     }
     __syncthreads();
+    FP_MARK(4);                                               // marking sweep
     // walks + acceptance of the `total` candidates listed in T.clist (any order: accepted peaks go to a bitmap)
     auto walk_listed = [&](int total) {
+        FP_MARK(5);                                           // counting + listing
         for (int w2 = tid; w2 < kFpList / 32; w2 += kFpThreads) cfail[w2] = 0u;
         __syncthreads();
+        FP_MARK(6);
         // the left and the right walk of a candidate run on two lanes (a walk is a chain of dependent LDS reads: with
         // ~20 candidates per row most lanes idle anyway); a direction whose base is too high marks the candidate failed
         // ... dealt round-robin to the waves: a wave pays the longest of its lanes' walks in every phase of fp_walk
+        if (2 * total <= kFpWaveSides) {
+            // few sides: a wave per side (fp_walk_wave), everything wave-uniform
+            for (int c2 = wave; c2 < 2 * total; c2 += kFpThreads / 64) {
+                const int c = c2 >> 1;
+                const int i = T.clist[c];
+                const float v = r[i];
+                int ia = i + 1;
+                while (ia < ns - 1 && r[ia] == v) ++ia;
+                bool ok = r[ia] < v && !((double)v - thr < (double)gmin);
+                if (ok) {
+                    const double dl = (double)v - thr;
+                    float lim = (float)dl;
+                    if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
+                    ok = (c2 & 1) ? fp_walk_wave<+1>(r, T.s1, T.s2, ns, nb, nb2, bshift, ia, v, lim, lane)
+                                  : fp_walk_wave<-1>(r, T.s1, T.s2, ns, nb, nb2, bshift, i - 1, v, lim, lane);
+                }
+                if (!ok && lane == 0) atomicOr(&cfail[c >> 5], 1u << (c & 31));
+            }
+        } else
         for (int c2 = (tid & 63) * (kFpThreads / 64) + (tid >> 6); c2 < 2 * total; c2 += kFpThreads) {
             const int c = c2 >> 1;
             const int i = T.clist[c];
@@ -1273,7 +1376,9 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             }
             if (!ok) atomicOr(&cfail[c >> 5], 1u << (c & 31));
         }
+        FP_MARK(7);                                           // thread 0's own walk
         __syncthreads();
+        FP_MARK(8);                                           // ... and the wait for the longest one
         for (int c = tid; c < total; c += kFpThreads) {
             if ((cfail[c >> 5] >> (c & 31)) & 1u) continue;
             const int i = T.clist[c];
@@ -1284,6 +1389,7 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
             atomicOr(&T.bits[mid >> 5], 1u << (mid & 31));
         }
         __syncthreads();
+        FP_MARK(9);                                           // acceptance
     };
     // all candidates of the row in ONE list when they fit (the usual case: a walk phase costs its longest walk, however
     // few lanes walk), else one round of kFpList / 16 bitmap words at a time
@@ -1400,6 +1506,7 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     const FpLds T = fp_lds(smem_raw, nb, nb2, nwords);
     const float* rg = x + (size_t)blockIdx.x * ns;
     const int tid = threadIdx.x;
+    FP_T0;
     for (int w = tid; w < nwords; w += kFpThreads) T.bits[w] = 0u;
     const bool al16 = (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
     const bool vec4 = bshift == 5 && al16;
@@ -1414,10 +1521,12 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
         fp_summaries1(STAGED ? T.rowl : rg, T, ns, nb, bshift, tid);
     }
     __syncthreads();
+    FP_MARK(0);                                               // staged + block summaries
     fp_summaries2(T, nb, nb2, tid);
     if (sweep)
         for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
     __syncthreads();
+    FP_MARK(1);
     int mark_from = 0;
     if (sweep) {
         float gmin = INFINITY;
@@ -1427,7 +1536,9 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     fp_scan(STAGED ? T.rowl : rg, T, ns, nb, nb2, bshift, thr, nwords, wave_tot, cfail, STAGED ? (ns & 3) == 0 : al16,
             mark_from, tid);
     __syncthreads();
+    FP_MARK(2);                                               // marking + listing + walks
     fp_emit(T, nwords, idx + (size_t)blockIdx.x * cap, counts + blockIdx.x, cap, wave_tot, tid);
+    FP_MARK(3);
 }
 
 // picks of all rows as ONE packed 2 x K table (detect.convert_pick_times, detect.py:277-303: row 0 = channel,
@@ -1700,6 +1811,18 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
     }
     return D4W_OK;
 }
+
+#ifdef D4W_FP_TIMING
+int d4w_fp_timing_read(unsigned long long* host16, int reset) {
+    D4W_HIP(hipDeviceSynchronize());
+    D4W_HIP(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_fp_t), sizeof(g_fp_t)));
+    if (reset) {
+        unsigned long long z[16] = {};
+        D4W_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fp_t), z, sizeof(z)));
+    }
+    return D4W_OK;
+}
+#endif
 
 int d4w_pick_offsets_i64(const int32_t* counts, int nx, int64_t* offsets, int64_t* summary2, void* stream) {
     if (!counts || !offsets || !summary2 || nx < 1) return fail(D4W_EINVAL, "bad argument");

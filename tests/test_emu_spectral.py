@@ -252,6 +252,40 @@ def test_find_peaks_matches_scipy(emu):
     assert cnt[0] == len(ref0) and np.array_equal(idx[0], ref0[:4])
 
 
+@pytest.mark.parametrize("ns", [2900, 12000, 17000])
+def test_find_peaks_few_candidates_take_the_wave_walk(emu, ns):
+    """Rows whose candidates are few (an envelope with the threshold a fraction of its strongest peak, ~10 maxima worth a
+    walk per row) walk with a whole wave per side (fp_walk_wave: ballots over samples / block summaries / super-block
+    summaries); every decision equals scipy's: smooth envelopes with bursts (walks of thousands of samples that end at a
+    higher burst, at a deep dip or at the row end), plateaus on the burst tops, a burst cut by either row end, staged rows and
+    rows read in place (17 000 samples), thresholds from 'only the strongest' to 'every burst'."""
+    rng = np.random.default_rng(77 + ns)
+    nx = 7
+    t = np.arange(ns)
+    x = np.empty((nx, ns), dtype=np.float32)
+    for c in range(nx):
+        env = 0.05 + 0.02 * np.abs(rng.standard_normal(ns))
+        env = np.convolve(env, np.ones(9) / 9, "same")
+        for k in range(int(rng.integers(3, 14))):
+            p, w, a = rng.integers(0, ns), rng.uniform(15, 300), rng.uniform(0.2, 1.0)
+            env += a * np.exp(-0.5 * ((t - p) / w) ** 2)
+        x[c] = env
+    x[1] = np.round(x[1] * 40) / 40                                   # plateaus on tops and bases
+    x[2, :40] += np.linspace(2.0, 0.0, 40)                            # the largest sample on the left edge
+    x[3, -25:] += np.linspace(0.0, 2.0, 25)                           # ... and on the right edge
+    x[4] = x[4].max() - x[4]                                          # inverted: wide tops, narrow deep dips
+    for frac in (0.9, 0.45, 0.2, 0.08):
+        thr = frac * float(x.max() - x.min())
+        cap = 1024
+        idx = np.full((nx, cap), -1, dtype=np.int32)
+        cnt = np.empty(nx, dtype=np.int32)
+        ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
+        for c in range(nx):
+            ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+            assert cnt[c] == len(ref), (ns, frac, c, cnt[c], len(ref))
+            assert np.array_equal(idx[c, :cnt[c]], ref), (ns, frac, c)
+
+
 def test_pick_times_golden(emu, golden):
     g = golden("detect_12x2000.npz")
     thr = float(g["thr"])
