@@ -414,15 +414,19 @@ def bench_stream(args, world, rank, device, dist):
         st = stream.FileStream(fs, 14, 30, templates=[hf, lf], fk_mask=mask, halo=halo, prev_tail=prev_tail, on_filtered=on_filtered)
         npicks = 0
 
+        picks = []
+
         def detect_on(done):
-            n = 0
+            # nothing here waits for the device: the threshold 0.45 max(corr) (scripts/main_mfdetect.py:82,95) is formed on the
+            # device from the correlator's row maxima, the pickers are launched and their tables are sized when the run looks
+            # at them (below, inside the timed region)
             for r in done:
                 rm = r.get("row_max")          # per-row maxima from the correlator's epilogue (the last file of a run: one read)
-                thr = 0.45 * ddet.correlogram_max(r["correlograms"][0], rm[0] if rm else None)
+                thr = ddet.Threshold(0.45, ddet.correlogram_max(r["correlograms"][0], rm[0] if rm else None, on_device=True))
                 for c in r["correlograms"]:
-                    n += ddet.pick_times_env(c, thr).total
+                    picks.append(ddet.pick_times_env(c, thr, lazy=True))
                 ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)
-            return n
+            return 0
         if ingest is not None:
             ingest.upload(0, host_raws[0])
             for j in range(F):
@@ -436,6 +440,7 @@ def bench_stream(args, world, rank, device, dist):
         npicks += detect_on(st.flush(next_head=next_head, next_filtered_head=filtered_head if nxt_filt is not None else None))
         if "send" in pend:
             pend["send"].wait()
+        npicks += sum(p.total for p in picks)          # sizes and packs every pick table of the run (one 16-byte copy each)
         return npicks
 
     for _ in range(max(1, args.warmup // 2)):

@@ -125,6 +125,7 @@ def _load():
         "d4w_spectrocorr_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_int, c_void_p, c_void_p]),
         "d4w_find_peaks_f32": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_int, c_void_p]),
+        "d4w_find_peaks_dthr_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_double, c_void_p, c_void_p, c_int, c_void_p]),
         "d4w_pick_offsets_i64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_pack_picks_i64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
         "d4w_minmax_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),

@@ -734,36 +734,49 @@ __host__ __device__ constexpr int sc_width(int nk) { return (kScTile + nk + 2 + 
 // Four consecutive lags per lane: a lane reads its window of a strip row in 16-byte pieces (conflict-free) and every piece
 // feeds 16 FMAs -- a quarter of the LDS reads of one lag per lane -- with the 7 kernel taps a piece meets as wave-uniform
 // scalars; the strip itself is filled with eight global loads in flight per lane.
+// The strip of the NEXT frequency rows is already in registers while this one is worked on (one exposed load latency per
+// workgroup instead of one per chunk: the kernel was bound by those waits and by an integer division per staged sample, 0.44 ms
+// for a 0.86-GB spectrogram at 11020 x 12000; round 5).
+// FL strip rows of M pieces per lane and chunk (FL x M x kScThreads >= FL x width staged samples: 4 x 5 for kernels of up to
+// ~120 frames, 2 x 10, 1 x 20 beyond), chosen by the host from the kernel's length.
+template <int FL, int M>
 __global__ __launch_bounds__(kScThreads) void spectro_corr(const float* __restrict__ S, int nf, int nt,
                                                            const float* __restrict__ K, int nk, int off, int nout,
                                                            const float* __restrict__ med, int zero_ends,
                                                            float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float strip[kScLdsFloats];
+    static_assert(FL * M * kScThreads <= kScLdsFloats + FL * kScThreads, "a chunk fits the strip");
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * kScTile;
     const int width = sc_width(nk);
-    const int fchunk = max(1, kScLdsFloats / width);
+    constexpr int fchunk = FL;
     const float* Sc = S + (size_t)blockIdx.y * nf * nt;
     float acc[kScPer] = {0.f, 0.f, 0.f, 0.f};
+    float q[FL][M];
+    auto fetch = [&](int f0) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int j = tid + m * kScThreads, sidx = t0 + j - off;
+            const bool in = j < width && sidx >= 0 && sidx < nt;
+#pragma unroll
+            for (int fl = 0; fl < FL; ++fl) q[fl][m] = (in && f0 + fl < nf) ? Sc[(size_t)(f0 + fl) * nt + sidx] : 0.f;
+        }
+    };
+    auto stash = [&](int f0) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int j = tid + m * kScThreads;
+#pragma unroll
+            for (int fl = 0; fl < FL; ++fl)
+                if (j < width && f0 + fl < nf) strip[fl * width + j] = q[fl][m];
+        }
+    };
+    fetch(0);
     for (int f0 = 0; f0 < nf; f0 += fchunk) {
         const int fn = min(fchunk, nf - f0);
-        constexpr int kAhead = 8;
-        for (int w0 = tid; w0 < fn * width; w0 += kAhead * kScThreads) {
-            float q[kAhead];
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k) {
-                const int w = w0 + k * kScThreads;
-                const int fl = w / width, j = w - fl * width;
-                const int s = t0 + j - off;
-                q[k] = (w < fn * width && s >= 0 && s < nt) ? Sc[(size_t)(f0 + fl) * nt + s] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k) {
-                const int w = w0 + k * kScThreads;
-                if (w < fn * width) strip[w] = q[k];
-            }
-        }
+        stash(f0);
         __syncthreads();
+        if (f0 + fchunk < nf) fetch(f0 + fchunk);                 // in flight during the products below
         for (int fl = 0; fl < fn; ++fl) {
             const float* kr = K + (size_t)(f0 + fl) * nk;
             const float4* sr4 = reinterpret_cast<const float4*>(strip + fl * width) + tid;
@@ -778,9 +791,9 @@ __global__ __launch_bounds__(kScThreads) void spectro_corr(const float* __restri
                     if (j >= 0 && j < nk) {
                         const float tap = kr[j];
 #pragma unroll
-                        for (int q = 0; q < kScPer; ++q) {
-                            const int e = d - 3 + q;
-                            if (e >= 0 && e < 4) acc[q] = fmaf(v[e], tap, acc[q]);
+                        for (int qq = 0; qq < kScPer; ++qq) {
+                            const int e = d - 3 + qq;
+                            if (e >= 0 && e < 4) acc[qq] = fmaf(v[e], tap, acc[qq]);
                         }
                     }
                 }
@@ -789,10 +802,10 @@ __global__ __launch_bounds__(kScThreads) void spectro_corr(const float* __restri
         __syncthreads();
     }
 #pragma unroll
-    for (int q = 0; q < kScPer; ++q) {
-        const int t = t0 + kScPer * tid + q;
+    for (int qq = 0; qq < kScPer; ++qq) {
+        const int t = t0 + kScPer * tid + qq;
         if (t < nout) {
-            float v = acc[q] / (med[blockIdx.y] * (float)nk);
+            float v = acc[qq] / (med[blockIdx.y] * (float)nk);
             if (zero_ends && (t == 0 || t == nout - 1)) v = 0.f;
             if (v < 0.f) v = 0.f;                                    // NaN (0/0 on an all-zero row) passes through
             out[(size_t)blockIdx.y * nout + t] = v;
@@ -921,27 +934,31 @@ __device__ __forceinline__ float fp_walk(const float* __restrict__ r, const floa
 // pays its issue slots in every wave of the workgroup: 23 of 78 thousand cycles per row at 11020 x 12000
 // (scripts/probe/fp_timing.py); fp_scan runs this form when the sides are few.  Returns whether the running minimum
 // reaches lim before a sample > v or the row end (fp_walk(...) <= lim); q, v, lim are wave-uniform.
-template <int DIR>
-__device__ __forceinline__ int fp_wave_phase(const float hi, const float lo, bool in, float v, float lim, int& first) {
-    const unsigned long long h = __ballot(in && hi > v), sfy = __ballot(in && lo <= lim);
+// W lanes per side (W = 16: four sides per wave advance together; sides in different phases diverge and reconverge
+// after every phase): gl = lane within the group, gs = the group's first lane.
+template <int W>
+__device__ __forceinline__ int fp_group_phase(const float hi, const float lo, bool in, float v, float lim, int gs, int& first) {
+    constexpr unsigned long long kMask = (W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull);
+    const unsigned long long h = (__ballot(in && hi > v) >> gs) & kMask, sfy = (__ballot(in && lo <= lim) >> gs) & kMask;
     const int fh = h ? __builtin_ctzll(h) : 64, fs = sfy ? __builtin_ctzll(sfy) : 64;
     first = fh;
     return fs < fh ? 2 : (h ? 1 : 0);
 }
 
-template <int DIR>
+template <int W>
 __device__ __forceinline__ bool fp_walk_wave(const float* __restrict__ r, const float2* __restrict__ s1,
-                                             const float2* __restrict__ s2, int ns, int nb, int nb2, int bshift, int q,
-                                             float v, float lim, int lane) {
+                                             const float2* __restrict__ s2, int ns, int nb, int nb2, int bshift, int DIR,
+                                             int q, float v, float lim, int lane) {
     const int BS = 1 << bshift, SB = BS * kFpFan;
+    const int gl = lane & (W - 1), gs = lane & ~(W - 1);
     if (v <= lim) return true;                                // thr <= 0: the peak itself is its base
     auto samples = [&](int n) -> int {                        // 2 satisfied, 1 stopped (q at the stopper), 0 ran out (q past them)
-        for (int done = 0; done < n; done += 64) {
-            const int j = q + DIR * lane, m = min(64, n - done);
-            const bool in = lane < m && j >= 0 && j < ns;
+        for (int done = 0; done < n; done += W) {
+            const int j = q + DIR * gl, m = min(W, n - done);
+            const bool in = gl < m && j >= 0 && j < ns;
             const float u = r[min(max(j, 0), ns - 1)];
             int first;
-            const int st = fp_wave_phase<DIR>(u, u, in, v, lim, first);
+            const int st = fp_group_phase<W>(u, u, in, v, lim, gs, first);
             if (st == 2) return 2;
             if (st == 1) { q += DIR * first; return 1; }
             q += DIR * m;
@@ -949,12 +966,12 @@ __device__ __forceinline__ bool fp_walk_wave(const float* __restrict__ r, const 
         return 0;
     };
     auto blocks = [&](const float2* sm, int nent, int shift, int n, int step) -> int {
-        for (int done = 0; done < n; done += 64) {
-            const int e = (q + DIR * lane * step) >> shift, m = min(64, n - done);
-            const bool in = lane < m && e >= 0 && e < nent;
+        for (int done = 0; done < n; done += W) {
+            const int e = (q + DIR * gl * step) >> shift, m = min(W, n - done);
+            const bool in = gl < m && e >= 0 && e < nent;
             const float2 sv = sm[min(max(e, 0), nent - 1)];
             int first;
-            const int st = fp_wave_phase<DIR>(sv.x, sv.y, in, v, lim, first);
+            const int st = fp_group_phase<W>(sv.x, sv.y, in, v, lim, gs, first);
             if (st == 2) return 2;
             if (st == 1) { q += DIR * first * step; return 1; }
             q += DIR * m * step;
@@ -1274,7 +1291,11 @@ __device__ unsigned long long g_fp_t[16];
 #endif
 
 constexpr int kFpList = 4096;          // candidates per walk round
-constexpr int kFpWaveSides = 64;       // up to this many walk sides per round a wave takes a side (fp_walk_wave)
+constexpr int kFpWaveSides = 256;      // up to this many walk sides per round a group of lanes takes a side (fp_walk_wave)
+#ifndef D4W_FP_GROUP
+#define D4W_FP_GROUP 16
+#endif
+constexpr int kFpGroup = D4W_FP_GROUP; // lanes per side
 static_assert(kFpSegW + kFpSegE + kFpSegC + kFpSegC / 2 + kFpThreads / 64 <= kFpList, "the window and its lists live in the candidate list");
 
 __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds& T, int ns, int nb, int nb2, int bshift,
@@ -1286,11 +1307,68 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
     FP_T0;
     float gmin = INFINITY;
     for (int k = 0; k < nb2; ++k) gmin = fminf(gmin, T.s2[k].y);
-    if (mark_from == 0) {
+    int* ccount = wave_tot + kFpThreads / 64;                 // (zeroed by the kernel before its first barrier)
+    // 32-sample blocks, the whole row still to mark: a block whose maximum cannot reach the threshold (almost all of them
+    // when thr is a fraction of the strongest peak) costs one summary read; the others are looked at by half a wave each, a
+    // lane per sample, their bitmap word is stored whole (no zeroing pass, no atomics) and their candidates go straight
+    // into the list -- the sample-by-sample marking sweep of the whole row was 8 of 28 thousand cycles of this function at
+    // 11020 x 12000 (scripts/probe/fp_timing.py), the separate counting pass 2.5.  (A lane per hot block, 32 samples
+    // each, cost the same 8: every wave with one hot lane pays the whole scan.)
+    bool by_block = vec4 && bshift == 5 && mark_from == 0;
+    if (by_block) {
+        // the threshold test in float32: vcut = the smallest float v with !((double)v - thr < (double)gmin) (the test is
+        // monotone in v: float -> double is exact, the float64 subtraction rounds monotonically)
+        float vcut = (float)((double)gmin + thr);
+        for (int k = 0; k < 4 && (double)vcut - thr < (double)gmin; ++k) vcut = nextafterf(vcut, INFINITY);
+        for (int k = 0; k < 4; ++k) {
+            const float below = nextafterf(vcut, -INFINITY);
+            if ((double)below - thr < (double)gmin || below == vcut) break;
+            vcut = below;
+        }
+        const bool vcut_ok = !((double)vcut - thr < (double)gmin) && ((double)nextafterf(vcut, -INFINITY) - thr < (double)gmin);
+        // (1) the blocks worth a look, listed from the END of the candidate list (a row whose candidates and hot blocks
+        // together exceed the list takes the round-by-round path below, which lists from the bitmap again)
+        int* hcount = ccount + 1;
+        for (int bk = tid; bk < nwords; bk += kFpThreads) {                     // nwords == nb
+            if (!((double)T.s1[bk].x - thr < (double)gmin)) T.clist[kFpList - 1 - atomicAdd(hcount, 1)] = bk;
+            else T.cand[bk] = 0u;
+        }
+        __syncthreads();
+        // (2) half a wave per hot block, a lane per sample: one ballot gives the block's bitmap word
+        // (a row where a quarter of the blocks are hot -- thr small against the row's range -- is cheaper in the sweep of
+        // all samples below: 0.36 against 0.48 ms at thr = 0)
+        const int nhot = *hcount, l = lane & 31;
+        if (4 * nhot > nb) by_block = false;
+        for (int h0 = 0; by_block && h0 < nhot; h0 += kFpThreads / 32) {      // wave-uniform trip count
+            const int h = h0 + (tid >> 5);
+            const int bk = T.clist[kFpList - 1 - min(h, nhot - 1)];
+            const int i = (bk << 5) + l;
+            const bool in = h < nhot && i >= 1 && i < ns - 1;
+            const float v = r[min(i, ns - 1)], a = r[max(i - 1, 0)], b = r[min(i + 1, ns - 1)];
+            const bool pk = in && a < v && !(b > v) && (vcut_ok ? v >= vcut : !((double)v - thr < (double)gmin));
+            unsigned m = (unsigned)(__ballot(pk) >> (lane & 32));
+            if (l == 0 && h < nhot) {
+                T.cand[bk] = m;
+                if (m) {
+                    const int cnt = __popc(m);
+                    int p = atomicAdd(ccount, cnt);
+                    if (p + cnt + nhot <= kFpList) {
+                        while (m) {
+                            const int bit = __builtin_ctz(m);
+                            m &= m - 1u;
+                            T.clist[p++] = (bk << 5) + bit;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!by_block && mark_from == 0) {
         for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
         __syncthreads();
     }
-    if (vec4) {
+    if (by_block) {
+    } else if (vec4) {
         // four samples per lane: one 16-byte read and the two neighbours instead of three reads per sample; four such
         // groups in flight per lane (rows too long for LDS are read from global memory here)
         const float4* r4 = reinterpret_cast<const float4*>(r);
@@ -1340,8 +1418,9 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
         // ~20 candidates per row most lanes idle anyway); a direction whose base is too high marks the candidate failed
         // ... dealt round-robin to the waves: a wave pays the longest of its lanes' walks in every phase of fp_walk
         if (2 * total <= kFpWaveSides) {
-            // few sides: a wave per side (fp_walk_wave), everything wave-uniform
-            for (int c2 = wave; c2 < 2 * total; c2 += kFpThreads / 64) {
+            // few sides: kFpGroup lanes per side (fp_walk_wave), everything uniform within a group
+            constexpr int kPerWave = 64 / kFpGroup;
+            for (int c2 = wave * kPerWave + lane / kFpGroup; c2 < 2 * total; c2 += (kFpThreads / 64) * kPerWave) {
                 const int c = c2 >> 1;
                 const int i = T.clist[c];
                 const float v = r[i];
@@ -1352,10 +1431,10 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
                     const double dl = (double)v - thr;
                     float lim = (float)dl;
                     if ((double)lim > dl) lim = nextafterf(lim, -INFINITY);
-                    ok = (c2 & 1) ? fp_walk_wave<+1>(r, T.s1, T.s2, ns, nb, nb2, bshift, ia, v, lim, lane)
-                                  : fp_walk_wave<-1>(r, T.s1, T.s2, ns, nb, nb2, bshift, i - 1, v, lim, lane);
+                    ok = fp_walk_wave<kFpGroup>(r, T.s1, T.s2, ns, nb, nb2, bshift, (c2 & 1) ? 1 : -1, (c2 & 1) ? ia : i - 1, v, lim,
+                                                lane);
                 }
-                if (!ok && lane == 0) atomicOr(&cfail[c >> 5], 1u << (c & 31));
+                if (!ok && (lane & (kFpGroup - 1)) == 0) atomicOr(&cfail[c >> 5], 1u << (c & 31));
             }
         } else
         for (int c2 = (tid & 63) * (kFpThreads / 64) + (tid >> 6); c2 < 2 * total; c2 += kFpThreads) {
@@ -1393,27 +1472,33 @@ __device__ __forceinline__ void fp_scan(const float* __restrict__ r, const FpLds
     };
     // all candidates of the row in ONE list when they fit (the usual case: a walk phase costs its longest walk, however
     // few lanes walk), else one round of kFpList / 16 bitmap words at a time
-    int* ccount = wave_tot + kFpThreads / 64;
-    int mine = 0;
-    for (int w = tid; w < nwords; w += kFpThreads) mine += __popc(T.cand[w]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
-    if (lane == 0) wave_tot[wave] = mine;
-    if (tid == 0) *ccount = 0;
-    __syncthreads();
     int total_all = 0;
-    for (int k = 0; k < kFpThreads / 64; ++k) total_all += wave_tot[k];
-    if (total_all <= kFpList) {
-        for (int w = tid; w < nwords; w += kFpThreads) {
-            unsigned word = T.cand[w];
-            if (!word) continue;
-            int p = atomicAdd(ccount, __popc(word));
-            while (word) {
-                const int bit = __builtin_ctz(word);
-                word &= word - 1u;
-                T.clist[p++] = (w << 5) + bit;
+    if (by_block) {
+        total_all = *ccount;                                  // listed already when they fit ...
+        if (total_all + ccount[1] > kFpList) total_all = kFpList + 1;        // ... beside the hot-block list
+    } else {
+        int mine = 0;
+        for (int w = tid; w < nwords; w += kFpThreads) mine += __popc(T.cand[w]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+        if (lane == 0) wave_tot[wave] = mine;
+        if (tid == 0) *ccount = 0;
+        __syncthreads();
+        for (int k = 0; k < kFpThreads / 64; ++k) total_all += wave_tot[k];
+        if (total_all <= kFpList) {
+            for (int w = tid; w < nwords; w += kFpThreads) {
+                unsigned word = T.cand[w];
+                if (!word) continue;
+                int p = atomicAdd(ccount, __popc(word));
+                while (word) {
+                    const int bit = __builtin_ctz(word);
+                    word &= word - 1u;
+                    T.clist[p++] = (w << 5) + bit;
+                }
             }
         }
+    }
+    if (total_all <= kFpList) {
         walk_listed(total_all);
         return;
     }
@@ -1494,11 +1579,15 @@ __device__ __forceinline__ FpLds fp_lds(unsigned char* p, int nb, int nb2, int n
 }
 
 template <bool STAGED>
-__global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr,
+__global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __restrict__ x, int ns, double thr0,
                                                               int bshift, int* __restrict__ idx,
-                                                              int* __restrict__ counts, int cap) {
+                                                              int* __restrict__ counts, int cap,
+                                                              const float* __restrict__ thr_dev) {
+    // thr_dev: the threshold is thr0 x a DEVICE value (d4w_find_peaks_dthr_f32: "0.45 of the largest correlation" without the
+    // host waiting for that maximum), formed in float64 like the host's 0.45 * float(c.max())
+    const double thr = thr_dev ? thr0 * (double)*thr_dev : thr0;
     D4W_DYN_LDS(smem_raw);
-    __shared__ int wave_tot[kFpThreads / 64 + 1];              // + the candidate counter of fp_scan
+    __shared__ int wave_tot[kFpThreads / 64 + 2];              // + the candidate and hot-block counters of fp_scan
     __shared__ unsigned cfail[kFpList / 32];
     __shared__ unsigned char hot[kFpSegMax];                   // fp_sweep_segments: windows worth loading
     const int BS = 1 << bshift, nb = (ns + BS - 1) >> bshift, nb2 = (nb + kFpFan - 1) / kFpFan;
@@ -1507,6 +1596,7 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
     const float* rg = x + (size_t)blockIdx.x * ns;
     const int tid = threadIdx.x;
     FP_T0;
+    if (tid == 0) wave_tot[kFpThreads / 64] = wave_tot[kFpThreads / 64 + 1] = 0;     // fp_scan's candidate / hot-block counters
     for (int w = tid; w < nwords; w += kFpThreads) T.bits[w] = 0u;
     const bool al16 = (ns & 3) == 0 && ((reinterpret_cast<size_t>(rg) & 15) == 0);
     const bool vec4 = bshift == 5 && al16;
@@ -1784,18 +1874,25 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
         return fail(D4W_EINVAL, "bad argument");
     if (sc_width(nk) > kScLdsFloats) return fail(D4W_EINVAL, "kernel of %d frames is too long", nk);
     if (nx > 65535) return fail(D4W_EINVAL, "nx = %d exceeds the grid limit 65535", nx);
-    D4W_LAUNCH(spectro_corr, dim3(ceil_div(nout, kScTile), nx), dim3(kScThreads), 0, stream, S, nf, nt, K, nk, off,
-               nout, med, zero_ends, out);
+    const dim3 grid(ceil_div(nout, kScTile), nx);
+    const int width = sc_width(nk);
+    if (width <= 5 * kScThreads)
+        D4W_LAUNCH((spectro_corr<4, 5>), grid, dim3(kScThreads), 0, stream, S, nf, nt, K, nk, off, nout, med, zero_ends, out);
+    else if (width <= 10 * kScThreads)
+        D4W_LAUNCH((spectro_corr<2, 10>), grid, dim3(kScThreads), 0, stream, S, nf, nt, K, nk, off, nout, med, zero_ends, out);
+    else
+        D4W_LAUNCH((spectro_corr<1, 20>), grid, dim3(kScThreads), 0, stream, S, nf, nt, K, nk, off, nout, med, zero_ends, out);
     return D4W_OK;
 }
 
-int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx, int32_t* counts, int cap,
-                       void* stream) {
+static int find_peaks_launch(const float* x, int nx, int ns, double prominence, const float* thr_dev, int32_t* idx,
+                             int32_t* counts, int cap, void* stream) {
     if (!x || !idx || !counts || nx < 1 || ns < 1 || cap < 1) return fail(D4W_EINVAL, "bad argument");
     int bshift = 5;                                            // 32-sample blocks, larger for very long rows
     while (((ns + (1 << bshift) - 1) >> bshift) > kFpMaxBlocks) ++bshift;
     const int nb = (ns + (1 << bshift) - 1) >> bshift;
-    const bool staged = (ns <= kFpRowLds);
+    static const int staged_env = [] { const char* v = getenv("D4W_FP_STAGED"); return v ? atoi(v) : -1; }();   // A/B switch
+    const bool staged = staged_env >= 0 ? (staged_env > 0 && ns <= kFpRowLds) : (ns <= kFpRowLds);
     const int nb2 = (nb + kFpFan - 1) / kFpFan;
     const size_t lds = ((size_t)2 * ((nb + nb2 + 1) & ~1) + 2 * (size_t)((((ns + 31) >> 5) + 3) & ~3) + (size_t)kFpList +
                         (staged ? (size_t)ns : 0)) * sizeof(float);
@@ -1803,13 +1900,24 @@ int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_
     if (staged) {
         sp_allow_lds(find_peaks_prom<true>, lds);
         D4W_LAUNCH(find_peaks_prom<true>, dim3(nx), dim3(kFpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
-                   (int*)counts, cap);
+                   (int*)counts, cap, thr_dev);
     } else {
         sp_allow_lds(find_peaks_prom<false>, lds);
         D4W_LAUNCH(find_peaks_prom<false>, dim3(nx), dim3(kFpThreads), lds, stream, x, ns, prominence, bshift, (int*)idx,
-                   (int*)counts, cap);
+                   (int*)counts, cap, thr_dev);
     }
     return D4W_OK;
+}
+
+int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx, int32_t* counts, int cap,
+                       void* stream) {
+    return find_peaks_launch(x, nx, ns, prominence, nullptr, idx, counts, cap, stream);
+}
+
+int d4w_find_peaks_dthr_f32(const float* x, int nx, int ns, const float* value, double scale, int32_t* idx, int32_t* counts,
+                            int cap, void* stream) {
+    if (!value) return fail(D4W_EINVAL, "NULL argument");
+    return find_peaks_launch(x, nx, ns, scale, value, idx, counts, cap, stream);
 }
 
 #ifdef D4W_FP_TIMING

@@ -214,16 +214,32 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
     return outs
 
 
-def correlogram_max(c, row_max=None):
+def correlogram_max(c, row_max=None, on_device=False):
     """np.max(corr_m) of a correlogram as a Python float (scripts/main_mfdetect.py:82: the detection threshold is half the
     largest correlation): from the per-row maxima the matrix-core correlator left in its epilogue when they are given
     (stream.FileStream results carry them: one 2-value reduction over nx numbers), else one read of the block -- the
-    library's own reduction either way, one 8-byte copy to the host."""
+    library's own reduction either way, one 8-byte copy to the host.  on_device=True: the value stays on the device (a
+    1-element float32 CUDA tensor, no copy, no wait) for `Threshold(0.45, value)` below."""
     src = row_max if row_max is not None else dev.to_device_f32(c)
     mm = torch.empty(2, dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
         check(lib.d4w_minmax_f32(dev.ptr(src), int(src.numel()), dev.ptr(mm), dev.stream_ptr(src)))
-    return float(mm.cpu()[1])
+    return mm[1:2] if on_device else float(mm.cpu()[1])
+
+
+class Threshold:
+    """A pick threshold formed on the device: scale x value[0] (value: a 1-element float32 CUDA tensor, e.g.
+    correlogram_max(c, on_device=True)) -- the reference's `0.45 * np.max(corr_m)` (scripts/main_mfdetect.py:82,95) without the
+    host waiting for the maximum; the product is formed in float64 like the host's.  Accepted wherever pick_times /
+    pick_times_env take a threshold."""
+
+    def __init__(self, scale, value):
+        if not (dev.is_tensor(value) and value.is_cuda and value.dtype == torch.float32 and value.numel() == 1):
+            raise ValueError("value must be a 1-element float32 CUDA tensor")
+        self.scale, self.value = float(scale), value
+
+    def __float__(self):
+        return self.scale * float(self.value.cpu().reshape(-1)[0])
 
 
 def xcorr_continuation_ok(taps_list, ns):
@@ -379,9 +395,18 @@ class PickRows(collections.abc.Sequence):
 
     __hash__ = None
 
-    def __init__(self, packed, counts):
-        self.packed, self.counts = packed, counts
+    def __init__(self, packed, counts, resolve=None):
+        """resolve: a callable returning the packed table, run on first use (pick_times*(..., lazy=True): the picker has
+        been launched, the one host synchronisation of the call -- the table's size -- waits until somebody looks)."""
+        self._packed, self.counts, self._resolve = packed, counts, resolve
         self._host = None
+
+    @property
+    def packed(self):
+        if self._packed is None:
+            self._packed = self._resolve()
+            self._resolve = None
+        return self._packed
 
     def _rows(self):
         if self._host is None:
@@ -420,9 +445,11 @@ _PICK_CAP = {}                       # (nx, ns) -> index slots per row worth all
 _PICK_CAP_BYTES = 8 << 30            # ... while the index table stays below this
 
 
-def _find_peaks_device(c, threshold, cap0=1024):
+def _find_peaks_device(c, threshold, cap0=1024, lazy=False):
     """c: float32 CUDA [nx, ns] -> PickRows.  One host synchronisation per call (total and largest per-row count);
-    the ragged result is compacted on the device."""
+    the ragged result is compacted on the device.  threshold: a number or a Threshold (formed on the device).  lazy=True:
+    the picker is launched and the synchronisation (and the compaction behind it) is left to the first look at the result
+    -- a chain over many blocks keeps the device busy and looks at the end; `c` stays alive until then."""
     nx, ns = c.shape
     # the widest row of the last call on this shape is the first guess of the next one: a stream of blocks with dense picks
     # (raw correlograms: thousands per row) would otherwise run the picker twice per block
@@ -430,33 +457,54 @@ def _find_peaks_device(c, threshold, cap0=1024):
     if nx * hint * 4 > _PICK_CAP_BYTES:
         hint = 0
     cap = max(1, min(ns // 2 + 1, max(int(cap0), hint)))
-    with torch.cuda.device(c.device):
-        while True:
-            idx = torch.empty((nx, cap), dtype=torch.int32, device=c.device)
-            cnt = torch.empty(nx, dtype=torch.int32, device=c.device)
+    on_dev = isinstance(threshold, Threshold)
+    if on_dev and threshold.value.device != c.device:
+        raise ValueError("the threshold's value lives on another device than the block")
+    cnt = torch.empty(nx, dtype=torch.int32, device=c.device)
+    off = torch.empty(nx, dtype=torch.int64, device=c.device)
+    summ = torch.empty(2, dtype=torch.int64, device=c.device)
+    stream = torch.cuda.current_stream(c.device)
+
+    def launch(cap):
+        idx = torch.empty((nx, cap), dtype=torch.int32, device=c.device)
+        if on_dev:
+            check(lib.d4w_find_peaks_dthr_f32(dev.ptr(c), nx, ns, dev.ptr(threshold.value), threshold.scale, dev.ptr(idx),
+                                              dev.ptr(cnt), cap, int(stream.cuda_stream)))
+        else:
             check(lib.d4w_find_peaks_f32(dev.ptr(c), nx, ns, float(threshold), dev.ptr(idx), dev.ptr(cnt), cap,
-                                         dev.stream_ptr(c)))
-            off = torch.empty(nx, dtype=torch.int64, device=c.device)
-            summ = torch.empty(2, dtype=torch.int64, device=c.device)
-            check(lib.d4w_pick_offsets_i64(dev.ptr(cnt), nx, dev.ptr(off), dev.ptr(summ), dev.stream_ptr(c)))
-            need, total = (int(v) for v in summ.cpu())           # the call's one host synchronisation (a 16-byte copy)
-            _PICK_CAP[(nx, ns)] = need + need // 4 + 16 if need > cap0 else 0
-            if need <= cap:
-                break
-            cap = min(ns // 2 + 1, max(need, 2 * cap))          # rare: a row with more peaks than the first guess
-        packed = torch.empty((2, total), dtype=torch.int64, device=c.device)
-        check(lib.d4w_pack_picks_i64(dev.ptr(idx), dev.ptr(cnt), dev.ptr(off), nx, cap, total,
-                                     dev.ptr(packed) if total else None, dev.stream_ptr(c)))
-    return PickRows(packed, cnt)
+                                         int(stream.cuda_stream)))
+        check(lib.d4w_pick_offsets_i64(dev.ptr(cnt), nx, dev.ptr(off), dev.ptr(summ), int(stream.cuda_stream)))
+        return idx
+
+    def finish(idx, cap):
+        with torch.cuda.device(c.device), torch.cuda.stream(stream):
+            while True:
+                need, total = (int(v) for v in summ.cpu())       # the call's one host synchronisation (a 16-byte copy)
+                _PICK_CAP[(nx, ns)] = need + need // 4 + 16 if need > cap0 else 0
+                if need <= cap:
+                    break
+                cap = min(ns // 2 + 1, max(need, 2 * cap))      # rare: a row with more peaks than the first guess
+                idx = launch(cap)
+            packed = torch.empty((2, total), dtype=torch.int64, device=c.device)
+            check(lib.d4w_pack_picks_i64(dev.ptr(idx), dev.ptr(cnt), dev.ptr(off), nx, cap, total,
+                                         dev.ptr(packed) if total else None, int(stream.cuda_stream)))
+        return packed
+
+    with torch.cuda.device(c.device):
+        idx = launch(cap)
+    if lazy:
+        return PickRows(None, cnt, resolve=lambda: finish(idx, cap))
+    return PickRows(finish(idx, cap), cnt)
 
 
-def pick_times_env(corr_m, threshold):
-    """Per row find_peaks(|hilbert(corr)|, prominence=threshold)[0] -- reference detect.py:169-195."""
+def pick_times_env(corr_m, threshold, lazy=False):
+    """Per row find_peaks(|hilbert(corr)|, prominence=threshold)[0] -- reference detect.py:169-195.  threshold: a number or a
+    Threshold (formed on the device); lazy: see _find_peaks_device (both beyond the reference's signature)."""
     from . import dsp
     if getattr(corr_m, "ndim", 0) != 2:
         raise ValueError("corr_m must be a 2-D [channel x time] array")
     env = dsp._analytic(dev.to_device_f32(corr_m), 0)
-    return _find_peaks_device(env, threshold)
+    return _find_peaks_device(env, threshold, lazy=lazy)
 
 
 def process_corr(corr, threshold):
@@ -471,11 +519,11 @@ def pick_times_par(corr_m, threshold):
     return pick_times_env(corr_m, threshold)
 
 
-def pick_times(corr_m, threshold):
-    """Per row find_peaks(corr, prominence=threshold)[0] -- reference detect.py:249-274."""
+def pick_times(corr_m, threshold, lazy=False):
+    """Per row find_peaks(corr, prominence=threshold)[0] -- reference detect.py:249-274 (threshold / lazy: pick_times_env)."""
     if getattr(corr_m, "ndim", 0) != 2:
         raise ValueError("corr_m must be a 2-D [channel x time] array")
-    return _find_peaks_device(dev.to_device_f32(corr_m), threshold)
+    return _find_peaks_device(dev.to_device_f32(corr_m), threshold, lazy=lazy)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -487,6 +487,11 @@ int d4w_spectrocorr_f32(const float* S, int nx, int nf, int nt, const float* K, 
  * ------------------------------------------------------------------------------------------ */
 int d4w_find_peaks_f32(const float* x, int nx, int ns, double prominence, int32_t* idx,
                        int32_t* counts, int cap, void* stream);
+/* The same with the threshold formed on the device: prominence = scale * value[0] (float64 product of the float32 DEVICE
+ * scalar, exactly the host's 0.45 * float(np.max(corr)) of scripts/main_mfdetect.py:82,95) -- a chain that takes its
+ * threshold from the block's largest correlation (d4w_minmax_f32, d4w_xcorr_mm_rowmax_f32) need not wait for it. */
+int d4w_find_peaks_dthr_f32(const float* x, int nx, int ns, const float* value, double scale, int32_t* idx,
+                            int32_t* counts, int cap, void* stream);
 /* offsets[c] = counts[0] + ... + counts[c] (int64, what d4w_pack_picks_i64 places the rows by) and
  * summary2 = {max_c counts[c], sum_c counts[c]} (DEVICE int64[2]: the capacity check and the table size of one picker call). */
 int d4w_pick_offsets_i64(const int32_t* counts, int nx, int64_t* offsets, int64_t* summary2, void* stream);

@@ -10,7 +10,8 @@
 //
 // Model: one OS thread; each HIP thread of a workgroup is a ucontext fiber.  __syncthreads()
 // blocks a fiber until every live fiber of the block has arrived; wave-level operations
-// (__shfl*, __ballot) block until every live fiber of the 64-lane wave has arrived.
+// (__shfl*) block until every live fiber of the 64-lane wave has arrived; __ballot until every live fiber of the wave is at
+// a ballot or parked at a barrier (divergent code: lanes that do not take part read as 0, like lanes masked out of EXEC).
 // Workgroups run one after another (HIP promises no inter-block ordering anyway).
 #pragma once
 #ifndef D4W_EMU
@@ -110,7 +111,7 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 // fiber scheduler
 // ------------------------------------------------------------------------------------------
 namespace hipemu {
-enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3, WAIT_BALLOT = 4 };
 struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
@@ -180,6 +181,23 @@ inline void run_block(unsigned nthreads, dim3 block) {
                 for (unsigned t = lo; t < hi; ++t)
                     if (g_fibers[t].state == WAIT_WAVE) g_fibers[t].state = RUNNABLE;
                 released = true;
+                continue;
+            }
+            // __ballot in divergent code (lane groups of a wave in different loop trips, lanes that have left for the next
+            // barrier): the lanes that are not at a ballot do not take part and read as 0, like lanes masked out of EXEC.
+            // (Shuffles keep the strict rule above: every live lane of the wave must arrive.)
+            unsigned balloting = 0, parked = 0;
+            for (unsigned t = lo; t < hi; ++t) {
+                if (g_fibers[t].state == WAIT_BALLOT) ++balloting;
+                if (g_fibers[t].state == WAIT_BLOCK) ++parked;
+            }
+            if (balloting && balloting + parked == live) {
+                const unsigned gen = g_shfl_gen[w] & 1u;
+                for (unsigned t = lo; t < hi; ++t) {
+                    if (g_fibers[t].state == WAIT_BALLOT) g_fibers[t].state = RUNNABLE;
+                    else g_exch[gen][t] = 0;
+                }
+                released = true;
             }
         }
         if (!released) {
@@ -242,13 +260,13 @@ inline T wave_exchange(T v, int src_lane_rel /* lane within wave to read from */
     (void)me;
     return out;
 }
-// predicate of every lane of the wave as a 64-bit mask (all lanes of the wave must be alive and call it)
+// predicate of every lane of the wave as a 64-bit mask (lanes parked at a barrier or finished read as 0)
 inline unsigned long long wave_ballot(int pred) {
     int wave = g_lin_tid / 64;
     int base = wave * 64;
     unsigned gen = g_shfl_gen[wave] & 1u;
     g_exch[gen][g_lin_tid] = pred ? 1u : 0u;
-    yield(WAIT_WAVE);
+    yield(WAIT_BALLOT);
     if ((g_shfl_gen[wave] & 1u) == gen) g_shfl_gen[wave]++;
     unsigned nthreads = g_blockDim.x * g_blockDim.y * g_blockDim.z;
     unsigned long long out = 0ull;

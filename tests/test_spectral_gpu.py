@@ -168,6 +168,41 @@ def test_picks_random_rows_vs_scipy(dw):
             assert np.array_equal(got[c], ref), (thr, c)
 
 
+def test_picks_with_few_candidates_vs_scipy(dw):
+    """The regime of the detection chain: smooth envelopes, the threshold a fraction of the strongest peak, ~10 maxima worth a
+    prominence walk per row (a group of lanes per walk side, hot blocks marked by half a wave each -- spectral.hip fp_scan);
+    bursts cut by the row ends, plateaus, rows of 12 000 (staged in LDS) and 20 000 samples (read in place), every row
+    against SciPy at several thresholds; the same picks with the threshold formed on the device (detect.Threshold) and
+    with the result looked at later (lazy=True)."""
+    import scipy.signal as sps
+    for ns in (12000, 20000):
+        rng = np.random.default_rng(300 + ns)
+        nx = 96
+        t = np.arange(ns)
+        x = np.empty((nx, ns), dtype=np.float32)
+        for c in range(nx):
+            env = np.convolve(0.05 + 0.02 * np.abs(rng.standard_normal(ns)), np.ones(9) / 9, "same")
+            for k in range(int(rng.integers(2, 40))):
+                p, w, a = rng.integers(0, ns), rng.uniform(15, 300), rng.uniform(0.2, 1.0)
+                env += a * np.exp(-0.5 * ((t - p) / w) ** 2)
+            x[c] = env
+        x[1] = np.round(x[1] * 40) / 40
+        x[2, :40] += np.linspace(2.0, 0.0, 40)
+        x[3, -25:] += np.linspace(0.0, 2.0, 25)
+        x[4] = x[4].max() - x[4]
+        xd = torch.from_numpy(x).cuda()
+        top = xd.max().reshape(1)                                  # a device scalar
+        for frac in (0.9, 0.45, 0.2, 0.08, 0.02):
+            thr = frac * float(top.cpu()[0])
+            got = dw.detect.pick_times(xd, thr)
+            late = dw.detect.pick_times(xd, dw.detect.Threshold(frac, top), lazy=True)
+            assert late._packed is None                            # nothing has been looked at yet
+            for c in range(nx):
+                ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+                assert np.array_equal(got[c], ref), (ns, frac, c, len(got[c]), len(ref))
+            assert late.total == got.total and torch.equal(late.packed, got.packed) and torch.equal(late.counts, got.counts)
+
+
 def test_picks_long_rows_window_sweep_vs_scipy(dw):
     """Rows beyond the LDS staging limit (detect.pick_times on raw 120 000-sample correlograms, detect.py:249-274): the
     windowed sweep over turning points (spectral.hip fp_sweep_segments) -- raw correlograms of noise (a maximum every ~9
