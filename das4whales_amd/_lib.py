@@ -48,6 +48,7 @@ def _load():
         "d4w_fkd_plan_destroy": (c_int, [c_void_p]),
         "d4w_fkd_plan_info": (c_int, [c_void_p, P(c_int)]),
         "d4w_fkd_plan_q1_owner": (c_int, [c_void_p, P(c_int)]),
+        "d4w_fkd_plan_live_columns": (c_int, [c_void_p, P(c_int)]),
         "d4w_fkd_set_mask_dense_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
         "d4w_fkd_set_mask_design_f32": (c_int, [c_void_p, c_int, ctypes.c_double, ctypes.c_double, P(ctypes.c_double),
                                                 c_int, c_int, c_void_p, c_void_p]),

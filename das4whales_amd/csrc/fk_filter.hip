@@ -779,6 +779,7 @@ extern "C" {
 static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d4w_fkd_plan** out);
 }
 static int fkd_set_mask_dense_affine(d4w_fkd_plan* pl, const float* mask_shifted, float a, float b, int on, void* stream);
+static void fkd_set_prune(d4w_fkd_plan* pl, double prune_eps);      // the gain level the next mask's dead columns are decided by
 
 struct d4w_fk_plan {
     FkDev dev;
@@ -1404,7 +1405,8 @@ static int fk_set_mask_impl(d4w_fk_plan* pl, const float* mask_shifted, double p
 
 static int fk_set_mask_run(d4w_fk_plan* pl, const float* mask_shifted, double prune_eps, void* stream, FkAffine aff) {
     if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
-    if (pl && pl->big) {                            // (no dead-row pruning on this path: prune_eps has nothing to act on)
+    if (pl && pl->big) {                            // (no dead-row pruning on this path: prune_eps acts on the Bluestein channel phase's columns)
+        fkd_set_prune(pl->big, prune_eps);
         int rc = fkd_set_mask_dense_affine(pl->big, mask_shifted, aff.a, aff.b, aff.on, stream);
         if (rc == D4W_OK) pl->has_mask = true;
         return rc;
@@ -1704,6 +1706,7 @@ static int fk_set_mask_design_run(d4w_fk_plan* pl, int mode, double k_spacing, d
                                   int i0, int i1, const double* hrow_dev, double prune_eps, void* stream) {
     if (pl && pl->big) {
         if (!(prune_eps >= 0.0 && prune_eps < 1.0)) return fail(D4W_EINVAL, "prune_eps = %g not in [0, 1)", prune_eps);
+        fkd_set_prune(pl->big, prune_eps);
         int rc = d4w_fkd_set_mask_design_f32(pl->big, mode, k_spacing, t_spacing, params8_host, i0, i1, hrow_dev, stream);
         if (rc == D4W_OK) pl->has_mask = true;
         return rc;
@@ -2100,6 +2103,7 @@ struct FkdBz {
     size_t pitch;             // slab row pitch (complex)
     int nx, ncol, inv;        // rows of the slab, valid columns of this chunk, 1: conjugated tables
     float scale;
+    const int* cols;          // NULL: scratch column t = slab column t; else slab column cols[t] (the live columns, below)
 };
 
 template <bool GENERIC>
@@ -2127,7 +2131,7 @@ __global__ __launch_bounds__(kMaxThreads) void fkd_bz_passA_fwd(FkDev P, FkdBz Z
                 if (row < Z.nx && col < Z.ncol) {
                     float2 ch = Z.chirp[row];
                     if (Z.inv) ch.y = -ch.y;
-                    v = c_mul(slab[(size_t)row * Z.pitch + col], ch);
+                    v = c_mul(slab[(size_t)row * Z.pitch + (Z.cols ? Z.cols[col] : col)], ch);
                 }
             }
             pf[it] = v;
@@ -2208,7 +2212,7 @@ __global__ __launch_bounds__(kMaxThreads) void fkd_bz_passA_inv(FkDev P, FkdBz Z
             if (row < Z.nx && col < Z.ncol) {
                 float2 ch = Z.chirp[row];
                 if (Z.inv) ch.y = -ch.y;
-                slab[(size_t)row * Z.pitch + col] = c_mul(tile[w], c_scale(ch, Z.scale));
+                slab[(size_t)row * Z.pitch + (Z.cols ? Z.cols[col] : col)] = c_mul(tile[w], c_scale(ch, Z.scale));
             }
         }
         lds_barrier();
@@ -2510,6 +2514,15 @@ struct d4w_fkd_plan {
     float2* bz_S = nullptr;                 // [bz_L][bz_W]
     const float2* bz_chirp = nullptr;       // [nx]    exp(-i pi n^2 / nx)
     const float2* bz_filt = nullptr;        // [bz_L]  FFT of the wrapped conjugate chirp / bz_L at the row positions of cp
+    // the slab columns whose folded gains (or whose Hermitian partner column's) are not all zero: the only ones whose channel
+    // transform matters -- a dead column leaves the pair op as zeros whatever it held, and the inverse transform of zeros is
+    // zeros.  A fin-whale band of 14-30 Hz keeps a third of the columns (the band and its mirror image in the packed
+    // spectrum): 19 997 x 120 000 runs 6 scratch chunks per direction instead of 18.
+    int* bz_cols = nullptr;                 // [W] DEVICE, the first bz_nlive entries in use
+    unsigned* bz_flags = nullptr;           // [W] DEVICE scratch of the scan (column maxima, then the live flags)
+    int bz_nlive = -1;                      // -1: every column (no list)
+    double prune_eps = 0.0;                 // opt-in gain level (x the largest gain) below which a column counts as dead
+    std::vector<int> h_jqpart, h_mirror0;   // host copies of the pair op's column maps
     // ---- ns / 2 with a prime factor > 31: the same for the time transform of the packed rows (fkd_bt_*); the half
     //      spectrum then comes out in natural order, N1 = 1, N2 = ns / 2, while tp describes the length-bt_L transform
     int bt_L = 0, bt_R = 0;                 // transform length (0: off), rows per scratch chunk
@@ -2887,6 +2900,7 @@ static int fkd_plan_build(int nx, int ns, int world, int rank, bool want_mask, d
     std::vector<float2> wrow(N1), wcol(N2);
     for (int q1 = 0; q1 < N1; ++q1) wrow[q1] = wexp(f_n1[q1], ns);
     for (int i = 0; i < N2; ++i) wcol[i] = wexp((long long)N1 * f_n2[i], ns);
+    pl->h_jqpart = jqpart; pl->h_mirror0 = mirror0;
     std::vector<int> myq = pl->myq;
     if (myq.empty()) myq.push_back(0);
     const int *c_rowk, *c_k1, *c_k2, *c_q1of;
@@ -2953,9 +2967,94 @@ int d4w_fkd_plan_info(const d4w_fkd_plan* pl, int* info) {
     return D4W_OK;
 }
 
+/* info2 = {slab columns the Bluestein channel phase transforms with the mask set last, slab columns} ({0, 0}: the plan's
+ * channel phase is not the global-memory Bluestein form) */
+int d4w_fkd_plan_live_columns(const d4w_fkd_plan* pl, int* info2) {
+    if (!pl || !info2) return fail(D4W_EINVAL, "NULL argument");
+    const int W = (int)pl->myq.size() * pl->N2;
+    info2[0] = pl->bz_L ? (pl->bz_nlive >= 0 ? pl->bz_nlive : W) : 0;
+    info2[1] = pl->bz_L ? W : 0;
+    return D4W_OK;
+}
+
 int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* pl, int* owner) {
     if (!pl || !owner) return fail(D4W_EINVAL, "NULL argument");
     memcpy(owner, pl->owner.data(), pl->owner.size() * sizeof(int));
+    return D4W_OK;
+}
+
+}  // extern "C"
+namespace d4w {
+// colmax[c] = max over the rows of |folded gain| at slab column c, as the bits of a non-negative float (NaN: +inf)
+__global__ __launch_bounds__(kThreads) void fkd_col_max(const float* __restrict__ mask, int nx, int W,
+                                                        unsigned* __restrict__ colmax) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    float m = 0.f;
+    for (int r = blockIdx.y; r < nx; r += gridDim.y) {
+        const float g = fabsf(mask[(size_t)r * W + c]);
+        m = (g != g) ? INFINITY : fmaxf(m, g);
+    }
+    atomicMax(&colmax[c], __float_as_uint(m));
+}
+// the gains of the columns that are not transformed become exact zeros (they are below fk_zero_gain, the level the
+// specialised plans drop as well)
+__global__ __launch_bounds__(kThreads) void fkd_zero_dead_cols(float* __restrict__ mask, int nx, int W,
+                                                               const unsigned* __restrict__ live) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W || live[c]) return;
+    for (int r = blockIdx.y; r < nx; r += gridDim.y) mask[(size_t)r * W + c] = 0.f;
+}
+}  // namespace d4w
+extern "C" {
+
+// The live columns of a Bluestein channel phase (see d4w_fkd_plan::bz_cols): column maxima of the folded mask, the zero-gain
+// level of fk_zero_gain (2^-24 / sqrt(nx ns) of the largest gain: the Gaussian tails of hybrid_ninf never reach an exact
+// zero), closure under the pair op's column map, one small copy each way.  D4W_FKD_BZ_BAND=0 keeps every column (A/B).
+static int fkd_bz_live_columns(d4w_fkd_plan* pl, void* stream) {
+    pl->bz_nlive = -1;
+    static const int band_env = [] { const char* v = getenv("D4W_FKD_BZ_BAND"); return v ? atoi(v) : 1; }();
+    const int nq = (int)pl->myq.size(), N2 = pl->N2, W = nq * N2;
+    if (!pl->bz_L || !band_env || nq == 0 || !pl->d_mask) return D4W_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (!pl->bz_cols) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)W * sizeof(int)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the live-column list failed");
+        pl->cp.allocs.push_back(p); pl->bz_cols = (int*)p;
+        if (hipMalloc(&p, (size_t)W * sizeof(unsigned)) != hipSuccess) return fail(D4W_ENOMEM, "hipMalloc of the live-column flags failed");
+        pl->cp.allocs.push_back(p); pl->bz_flags = (unsigned*)p;
+    }
+    const dim3 grid(ceil_div(W, kThreads), std::min(pl->nx, 64));
+    D4W_HIP(hipMemsetAsync(pl->bz_flags, 0, (size_t)W * sizeof(unsigned), st));
+    D4W_LAUNCH(fkd_col_max, grid, dim3(kThreads), 0, stream, (const float*)pl->d_mask, pl->nx, W, pl->bz_flags);
+    std::vector<unsigned> cm((size_t)W);
+    D4W_HIP(hipMemcpyAsync(cm.data(), pl->bz_flags, (size_t)W * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    D4W_HIP(hipStreamSynchronize(st));
+    float gmax = 0.f;
+    for (int c = 0; c < W; ++c) { float g; memcpy(&g, &cm[c], 4); if (g < INFINITY) gmax = std::max(gmax, g); }
+    FkDims dd{};
+    dd.nx = pl->nx; dd.ns = pl->ns;
+    const float zero_gain = (float)fk_zero_gain(dd, pl->prune_eps, (double)gmax);
+    std::vector<unsigned> live((size_t)W, 0u);
+    auto is_live = [&](size_t c) { float g; memcpy(&g, &cm[c], 4); return g > zero_gain; };
+    for (int jq = 0; jq < nq; ++jq) {
+        const bool k1zero = (pl->myq[jq] == 0);
+        const int jp = pl->h_jqpart[jq];
+        for (int i = 0; i < N2; ++i) {
+            const int j = k1zero ? pl->h_mirror0[i] : (N2 - 1 - i);
+            const size_t a = (size_t)jq * N2 + i, b = (size_t)jp * N2 + j;
+            if (is_live(a) || is_live(b) || (k1zero && i == 0)) live[a] = live[b] = 1u;     // (the DC / Nyquist column: gains in d_nyq)
+        }
+    }
+    std::vector<int> cols;
+    cols.reserve((size_t)W);
+    for (int c = 0; c < W; ++c) if (live[c]) cols.push_back(c);
+    if ((int)cols.size() >= W) return D4W_OK;                                     // nothing to skip
+    D4W_HIP(hipMemcpyAsync(pl->bz_cols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    D4W_HIP(hipMemcpyAsync(pl->bz_flags, live.data(), (size_t)W * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    D4W_LAUNCH(fkd_zero_dead_cols, grid, dim3(kThreads), 0, stream, pl->d_mask, pl->nx, W, (const unsigned*)pl->bz_flags);
+    D4W_HIP(hipStreamSynchronize(st));                                            // (the host vectors go out of scope)
+    pl->bz_nlive = (int)cols.size();
     return D4W_OK;
 }
 
@@ -3037,6 +3136,7 @@ static int fkd_set_mask_src(d4w_fkd_plan* pl, const FkdMaskSrc& src, void* strea
         if (int rc = fkd_launch_fold(src, pl->nx, pl->ns, pl->N1, pl->N2, nq, (const int*)pl->d_rowk, (const int*)pl->d_q1of,
                                      (const int*)pl->d_k1, (const int*)pl->d_k2, pl->d_mask, pl->d_nyq, stream))
             return rc;
+    if (int rc = fkd_bz_live_columns(pl, stream)) return rc;
     pl->has_mask = true;
     return D4W_OK;
 }
@@ -3049,6 +3149,7 @@ int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* pl, const float* mask_shifted, void
 }
 
 }  // extern "C"
+static void fkd_set_prune(d4w_fkd_plan* pl, double prune_eps) { pl->prune_eps = prune_eps; }
 static int fkd_set_mask_dense_affine(d4w_fkd_plan* pl, const float* mask_shifted, float a, float b, int on, void* stream) {
     if (!pl || !mask_shifted || !pl->d_mask) return fail(D4W_EINVAL, "NULL argument");
     if (on && pl->sp) return fail(D4W_EINVAL, "the packed distributed plan folds no affine map");
@@ -3239,15 +3340,20 @@ int d4w_fkd_chan_apply_f32(d4w_fkd_plan* pl, float* slab, void* stream) {
         const int W = nq * pl->N2, Wc = pl->bz_W, L = pl->bz_L;
         float2* S = pl->bz_S;
         (void)L;
+        // the live columns only, gathered into the scratch through the list (dead columns: zeros out of the pair op)
+        const bool listed = pl->bz_nlive >= 0;
+        const int Wl = listed ? pl->bz_nlive : W;
         for (int inv = 0; inv < 2; ++inv) {
-            for (int c0 = 0; c0 < W; c0 += Wc) {
+            for (int c0 = 0; c0 < Wl; c0 += Wc) {
                 FkdBz Z;
                 Z.chirp = pl->bz_chirp; Z.filt = pl->bz_filt; Z.pitch = (size_t)W; Z.nx = pl->nx;
-                Z.ncol = std::min(Wc, W - c0); Z.inv = inv;
+                Z.ncol = std::min(Wc, Wl - c0); Z.inv = inv;
                 Z.scale = inv ? (float)(1.0 / ((double)pl->nx * (double)pl->M)) : 1.0f;
-                if ((rc = launch_k(pl->gen_c1 ? fkd_bz_passA_fwd<true> : fkd_bz_passA_fwd<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, Z, (const float2*)(d2 + c0), S, ntA))) return rc;
+                Z.cols = listed ? pl->bz_cols + c0 : nullptr;
+                float2* base = listed ? d2 : d2 + c0;
+                if ((rc = launch_k(pl->gen_c1 ? fkd_bz_passA_fwd<true> : fkd_bz_passA_fwd<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, Z, (const float2*)base, S, ntA))) return rc;
                 if ((rc = launch_k(pl->gen_c2 ? fkd_bz_passC<true> : fkd_bz_passC<false>, dim3(std::min(ntC, persist)), blk, pl->lds_c2, stream, P, Z, S, ntC))) return rc;
-                if ((rc = launch_k(pl->gen_c1 ? fkd_bz_passA_inv<true> : fkd_bz_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, Z, (const float2*)S, d2 + c0, ntA))) return rc;
+                if ((rc = launch_k(pl->gen_c1 ? fkd_bz_passA_inv<true> : fkd_bz_passA_inv<false>, dim3(std::min(ntA, persist)), blk, pl->lds_c1, stream, P, Z, (const float2*)S, base, ntA))) return rc;
             }
             if (!inv && (rc = launch_k(fkd_pair_slab, dim3(std::min(ceil_div(pl->N2, kThreads), 8), pl->nx, nq), dim3(kThreads), 0,
                                         stream, pl->slab, d2))) return rc;

@@ -175,6 +175,10 @@ int d4w_fkd_plan_create(int nx, int ns, int world, int rank, d4w_fkd_plan** plan
 int d4w_fkd_plan_destroy(d4w_fkd_plan* plan);
 int d4w_fkd_plan_info(const d4w_fkd_plan* plan, int* info12_host);
 int d4w_fkd_plan_q1_owner(const d4w_fkd_plan* plan, int* owner_host /* [N1] */);
+/* The Bluestein channel phase transforms only the slab columns whose folded gains -- or whose Hermitian partner column's --
+ * are not all zero with the mask set last (the others leave the pair op as zeros): info2 = {those, all slab columns},
+ * {0, 0} when the channel phase is not the global-memory Bluestein form.  D4W_FKD_BZ_BAND=0 transforms every column. */
+int d4w_fkd_plan_live_columns(const d4w_fkd_plan* plan, int* info2_host);
 /* mask: the full dense [nx][ns] float32 mask on the fftshift-ed grid (as d4w_fk_set_mask_dense_f32);
  * only the owned sub-rows are folded and kept */
 int d4w_fkd_set_mask_dense_f32(d4w_fkd_plan* plan, const float* mask_shifted, void* stream);

@@ -134,6 +134,35 @@ def test_dist_channel_count_with_large_prime_factor(emu, nx, ns, world, chunk, m
         assert rel(fk_sharded_emu(emu, x, np.ones((nx, ns)), world), x) < TOL
 
 
+@pytest.mark.parametrize("nx,ns,world,chunk", [(37, 96, 1, 7), (74, 120, 2, 0), (131, 80, 1, 5)])
+def test_dist_bluestein_channel_phase_transforms_the_live_columns_only(emu, nx, ns, world, chunk, monkeypatch):
+    """A band mask (zero outside a frequency band, as every mask of the reference's designs is) on the global-memory Bluestein
+    channel phase: only the slab columns whose folded gains -- or whose Hermitian partner column's -- are not all zero go
+    through the scratch (d4w_fkd_plan::bz_cols), the others leave the pair op as zeros.  Symmetric bands, a band on the
+    positive frequencies only (the partner closure), a band touching DC and Nyquist, a chunk narrower than the live set; the
+    same result with the list switched off."""
+    if chunk:
+        monkeypatch.setenv("D4W_FKD_BZ_CHUNK", str(chunk))
+    rng = np.random.default_rng(nx * 7 + world)
+    x = rng.standard_normal((nx, ns))
+    f = np.arange(-(ns // 2), ns - ns // 2) / (ns / 2.0)                  # the mask's fftshift-ed frequency grid
+    for keep in ((np.abs(f) >= 0.15) & (np.abs(f) <= 0.35), (f >= 0.2) & (f <= 0.5), (np.abs(f) <= 0.1) | (np.abs(f) >= 0.9)):
+        m = rng.uniform(0.1, 1, (nx, ns)) * keep[None, :]
+        ref = orc.fk_filter_filt(x, m)
+        seen = []
+
+        def setter(rk, m=m):
+            assert emu.d4w_fkd_set_mask_dense_f32(rk.h, vp(np.ascontiguousarray(m, dtype=np.float32)), None) == 0
+            info = (ctypes.c_int * 2)()
+            assert emu.d4w_fkd_plan_live_columns(rk.h, info) == 0
+            seen.append(tuple(info))
+        y = fk_sharded_emu(emu, x, m, world, setter=setter)
+        assert rel(y, ref) < TOL
+        live, total = sum(a for a, _ in seen), sum(b for _, b in seen)
+        assert total == ns // 2 and 0 < live < 0.8 * total, seen            # (the band and its mirror image)
+    assert rel(fk_sharded_emu(emu, x, np.zeros((nx, ns)), world), np.ones((nx, ns))) == 1.0      # all-zero mask: zeros
+
+
 @pytest.mark.parametrize("nx,ns,world", [(12, 74, 1), (10, 2 * 41 * 3, 2), (37, 2 * 43, 3)])
 def test_dist_record_length_with_large_prime_factor(emu, nx, ns, world):
     """ns / 2 with a prime factor > 31 on the generic distributed plan: the local rows' time transform is the global-memory
