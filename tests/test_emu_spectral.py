@@ -179,6 +179,31 @@ def test_row_median(emu, n):
     assert np.allclose(med, np.median(v.astype(np.float64), axis=1), rtol=1e-6, atol=0)
 
 
+def test_row_median_even_counts_and_narrow_rows(emu):
+    """Rows of the detector's size with an even count: magnitudes spread over octaves, everything inside one quarter-octave
+    (one top-digit bin holds the whole row), the upper middle value in the NEXT bin / many bins above the lower one, all-equal
+    rows, negative rows, a lower middle value alone in its bin.  (Written for a variant that compacted the selected bin into
+    LDS after the first sweep -- two sweeps instead of three, no faster: 437 -> 439 us per file, the kernel is bound by its
+    histogram atomics, not by the sweeps -- and kept for the cases.)"""
+    rng = np.random.default_rng(99)
+    n = 19514                                                                # even
+    rows = [np.abs(rng.standard_normal(n)) * rng.uniform(0.5, 2.0, n),      # spread over octaves: compacted
+            1.0 + 0.05 * rng.random(n),                                      # one quarter-octave bin: 19 514 keys > the buffer
+            np.concatenate((np.full(n // 2, 1.0), np.full(n // 2, 1.5))),    # lower middle the last 1.0, upper middle 1.5
+            np.concatenate((np.full(n // 2, 1.0), 1e6 + rng.random(n // 2))),   # upper middle many bins above
+            np.full(n, -3.25),
+            -np.abs(rng.standard_normal(n)),
+            np.concatenate((rng.random(n // 2 - 1) * 0.5, [0.75], 4.0 + rng.random(n // 2)))]   # lower middle alone in its bin
+    v = np.stack([rng.permutation(r) for r in rows]).astype(np.float32)
+    med = np.empty(len(v), dtype=np.float32)
+    ok(emu, emu.d4w_row_median_f32(vp(v), len(v), ctypes.c_size_t(n), vp(med), None))
+    ref = np.median(v.astype(np.float64), axis=1)
+    assert np.array_equal(med, ref.astype(np.float32)), (med, ref)
+    vo = np.ascontiguousarray(v[:, :n - 1])                                  # odd count
+    ok(emu, emu.d4w_row_median_f32(vp(vo), len(vo), ctypes.c_size_t(n - 1), vp(med), None))
+    assert np.array_equal(med, np.median(vo.astype(np.float64), axis=1).astype(np.float32))
+
+
 def spectrocorr(lib, S, K, off, nout, zero_ends=0):
     Sf = np.ascontiguousarray(S, dtype=np.float32)
     Kf = np.ascontiguousarray(K, dtype=np.float32)
