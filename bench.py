@@ -22,6 +22,7 @@ import argparse
 import json
 import os
 import sys
+import contextlib
 import time
 
 import numpy as np
@@ -396,6 +397,8 @@ def bench_stream(args, world, rank, device, dist):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
+    det_streams = [torch.cuda.Stream(device) for _ in range(max(0, min(2, int(getattr(args, "detector_streams", 2)))))]
+
     def run():
         pend = {}
         nxt_filt = torch.empty((nx, lmax - 1), dtype=torch.float32, device=device) if (world > 1 and rank < world - 1) else None
@@ -414,18 +417,28 @@ def bench_stream(args, world, rank, device, dist):
         st = stream.FileStream(fs, 14, 30, templates=[hf, lf], fk_mask=mask, halo=halo, prev_tail=prev_tail, on_filtered=on_filtered)
         npicks = 0
 
-        picks = []
+        picks, keep = [], []
+        main = torch.cuda.current_stream(device)
 
         def detect_on(done):
             # nothing here waits for the device: the threshold 0.45 max(corr) (scripts/main_mfdetect.py:82,95) is formed on the
             # device from the correlator's row maxima, the pickers are launched and their tables are sized when the run looks
-            # at them (below, inside the timed region)
+            # at them (below, inside the timed region).  The two detectors of a file are independent of each other and of the
+            # next file's filters: with --detector-streams 2 (default) the envelope picks and the spectrogram correlation
+            # run on a stream each beside the filter chain (their kernels are one workgroup per row, bound by latency
+            # chains, not by bytes: they fill each other's gaps); the results of the run stay referenced until the streams
+            # are joined, so no block is handed out again while another stream still reads it.
             for r in done:
-                rm = r.get("row_max")          # per-row maxima from the correlator's epilogue (the last file of a run: one read)
-                thr = ddet.Threshold(0.45, ddet.correlogram_max(r["correlograms"][0], rm[0] if rm else None, on_device=True))
-                for c in r["correlograms"]:
-                    picks.append(ddet.pick_times_env(c, thr, lazy=True))
-                ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95)
+                keep.append(r)
+                for sd in det_streams:
+                    sd.wait_stream(main)
+                with torch.cuda.stream(det_streams[0]) if det_streams else contextlib.nullcontext():
+                    rm = r.get("row_max")      # per-row maxima from the correlator's epilogue (the last file of a run: one read)
+                    thr = ddet.Threshold(0.45, ddet.correlogram_max(r["correlograms"][0], rm[0] if rm else None, on_device=True))
+                    for c in r["correlograms"]:
+                        picks.append(ddet.pick_times_env(c, thr, lazy=True))
+                with torch.cuda.stream(det_streams[-1]) if det_streams else contextlib.nullcontext():
+                    keep.append(ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95))
             return 0
         if ingest is not None:
             ingest.upload(0, host_raws[0])
@@ -441,6 +454,8 @@ def bench_stream(args, world, rank, device, dist):
         if "send" in pend:
             pend["send"].wait()
         npicks += sum(p.total for p in picks)          # sizes and packs every pick table of the run (one 16-byte copy each)
+        for sd in det_streams:
+            main.wait_stream(sd)
         return npicks
 
     for _ in range(max(1, args.warmup // 2)):
@@ -472,7 +487,7 @@ def bench_stream(args, world, rank, device, dist):
                "value": nfiles * float(nx) * ns / dt, "unit": "channel-samples/s", "n_gpus": world, "steps": reps * F, "warmup": args.warmup,
                "ms_per_step": dt / (reps * F) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
                "data": "synthetic", "files_per_s": nfiles / dt, "detections_per_s": npicks / dt, "detections": npicks,
-               "injected_notes_per_file": ncall, "channels_per_note": span,
+               "injected_notes_per_file": ncall, "channels_per_note": span, "detector_streams": len(det_streams),
                "ingest": ({"from": "pinned host memory, double-buffered upload on a side stream (data_handle.PinnedIngest)",
                            "h2d_GBps_one_file": h2d_gbs, "file_bytes": nx * ns * 4,
                            "h2d_ms_per_file_under_load": float(np.mean([a_.elapsed_time(b_) for a_, b_ in ingest.timing])) if ingest.timing else None,
@@ -613,6 +628,8 @@ def main():
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="4000x12000", help="CPU baseline block (BASELINE configs[0] shape, run in full)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--detector-streams", type=int, default=2,
+                    help="--config stream: HIP streams the two detectors of a file run on beside the filter chain (0: one stream for everything)")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask / hybrid_ninf f-k timings")
     ap.add_argument("--prune-eps", type=float, default=4e-6,
                     help="opt-in tail pruning threshold of the fk_hybrid_ninf_pruned block (relative to the mask maximum)")

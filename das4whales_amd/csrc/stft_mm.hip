@@ -209,7 +209,15 @@ extern "C" int d4w_stft_mm_eligible(int n_fft, int hop, int bin_lo, int bin_hi) 
            bin_lo >= 0 && bin_hi >= bin_lo && bin_hi - bin_lo + 1 <= 16 && bin_hi <= n_fft / 2;
 }
 
+static int stft_mag_mm_run(const float* x, float* S, int nx, int ns, int n_fft, int hop, int bin_lo, int bin_hi, void* stream);
 extern "C" int d4w_stft_mag_mm_f32(const float* x, float* S, int nx, int ns, int n_fft, int hop, int bin_lo, int bin_hi, void* stream) {
+    int rc = hazard_enter(1, stream);      // (never beside the overlap-save FFT kernels: d4w_internal.h)
+    if (rc) return rc;
+    rc = stft_mag_mm_run(x, S, nx, ns, n_fft, hop, bin_lo, bin_hi, stream);
+    const int rl = hazard_leave(1, stream);
+    return rc ? rc : rl;
+}
+static int stft_mag_mm_run(const float* x, float* S, int nx, int ns, int n_fft, int hop, int bin_lo, int bin_hi, void* stream) {
     if (!x || !S || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (!d4w_stft_mm_eligible(n_fft, hop, bin_lo, bin_hi))
         return fail(D4W_EINVAL, "n_fft = %d / hop = %d / bins [%d, %d] have no matrix-core STFT (n_fft % 32 == 0 <= 160, hop % 8 == 0 <= 32, <= 16 bins)",

@@ -34,6 +34,14 @@ constexpr int kXfPad = 160;                        // lags lost per block = max 
 constexpr int kXfStep = kXfB - kXfPad;             // 3936 lags per block
 constexpr int kXfThreads = 128;               // one item per thread in every stage
 constexpr int kXfRowP = kXfMB + kXfNG;             // LDS row pitch: one pad element per group
+#ifndef D4W_XF_LDSPAD
+#define D4W_XF_LDSPAD 0
+#endif
+#ifndef D4W_XF_LDSPAD_BACK
+#define D4W_XF_LDSPAD_BACK D4W_XF_LDSPAD
+#endif
+constexpr int kXfLdsPad = D4W_XF_LDSPAD;           // probe builds: unused bytes in front of ...
+constexpr int kXfLdsPadBack = D4W_XF_LDSPAD_BACK;  // ... and behind the blocks kernel's LDS
 
 __host__ __device__ constexpr int xf_ad(int e) { return e + e / kXfNC; }
 // frequency held by position e after the three DIF stages (digits a', b', d)
@@ -130,8 +138,23 @@ __device__ __forceinline__ c2 xf_ld(const float4* p) {
     const float4 v = lds_read4(p);
     return c2{v2_make(v.x, v.y), v2_make(v.z, v.w)};
 }
+// Two 8-byte LDS stores, NOT one ds_write_b128 (round 5): with the matrix-core STFT (stft_mm_rows) resident on the same CU from
+// another HIP stream, 16-byte LDS stores of these kernels sporadically lost the first dword of each 8-byte half -- whole
+// blocks of the first row of a row pair came out 1-10 % off in a few workgroups per launch (scripts/probe/stream_race2.py:
+// 6 of 6 trials with ds_write_b128, 0 of 12 with two ds_write_b64; full barriers, cleared LDS, plain global stores and
+// padded LDS on the neighbour's side changed nothing; no other pair of the library's kernels showed it).  Not understood
+// beyond that; D4W_XF_ST128 (probe builds) restores the 16-byte store for the A/B.
 __device__ __forceinline__ void xf_st(float4* p, c2 v) {
+#if !defined(D4W_XF_ST128) && !defined(D4W_EMU)
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef volatile f2_t __attribute__((address_space(3))) * lds_f2_ptr;
+    f2_t lo, hi;
+    lo.x = v2_x(v.re); lo.y = v2_y(v.re); hi.x = v2_x(v.im); hi.y = v2_y(v.im);
+    ((lds_f2_ptr)p)[0] = lo;
+    ((lds_f2_ptr)p)[1] = hi;
+#else
     *p = make_float4(v2_x(v.re), v2_y(v.re), v2_x(v.im), v2_y(v.im));
+#endif
 }
 
 // FUSED (two templates off ONE read and ONE forward transform of the block): 256 threads; waves 0-1 run
@@ -164,7 +187,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     // (the gain the subtracted constant would have had)
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
     D4W_DYN_LDS(smem_raw);
-    float4* buf = reinterpret_cast<float4*>(smem_raw);          // [ROWP] block spectra of both rows, then each template's correlation
+    float4* buf = reinterpret_cast<float4*>(smem_raw + kXfLdsPad);   // [ROWP] block spectra of both rows, then each template's correlation
     float2* tw1 = reinterpret_cast<float2*>(buf + (FUSED ? 2 : 1) * ROWP);        // [M1]
     float2* tw2 = tw1 + M1;                                     // [NB][NC]
     const int tsel = FUSED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
@@ -1035,6 +1058,40 @@ constexpr size_t kXfWsFloats = 2 * 2 * kXfMB + 8 + 2 * kXfM1 * 2 + 2 * kXfNG + 2
 
 using namespace d4w;
 
+// ---- the cross-stream fence between this file's kernels and stft_mm_rows (d4w_internal.h: hazard_enter / hazard_leave)
+#include <mutex>
+namespace d4w {
+namespace {
+std::mutex g_hz_mu;
+hipEvent_t g_hz_ev[16][2];          // [device][family]: recorded behind the family's last launch
+bool g_hz_have[16][2];
+}
+int hazard_enter(int self, void* stream) {
+    static const int on = [] { const char* v = getenv("D4W_HAZARD_FENCE"); return v ? atoi(v) : 1; }();
+    if (!on) return D4W_OK;
+    int devid = 0;
+    D4W_HIP(hipGetDevice(&devid));
+    if (devid < 0 || devid >= 16) return D4W_OK;
+    std::lock_guard<std::mutex> lk(g_hz_mu);
+    if (g_hz_have[devid][1 - self]) D4W_HIP(hipStreamWaitEvent((hipStream_t)stream, g_hz_ev[devid][1 - self], 0));
+    return D4W_OK;
+}
+int hazard_leave(int self, void* stream) {
+    static const int on = [] { const char* v = getenv("D4W_HAZARD_FENCE"); return v ? atoi(v) : 1; }();
+    if (!on) return D4W_OK;
+    int devid = 0;
+    D4W_HIP(hipGetDevice(&devid));
+    if (devid < 0 || devid >= 16) return D4W_OK;
+    std::lock_guard<std::mutex> lk(g_hz_mu);
+    if (!g_hz_have[devid][self]) {
+        D4W_HIP(hipEventCreateWithFlags(&g_hz_ev[devid][self], hipEventDisableTiming));
+        g_hz_have[devid][self] = true;
+    }
+    D4W_HIP(hipEventRecord(g_hz_ev[devid][self], (hipStream_t)stream));
+    return D4W_OK;
+}
+}  // namespace d4w
+
 extern "C" {
 
 int d4w_xcorr_fft_max_support(void) { return kXfPad + 1; }
@@ -1046,7 +1103,7 @@ int d4w_xcorr_fft_f32(const float* x, int nx, int ns, const double* mean, const 
     return d4w_xcorr_fft_cont_f32(x, nx, ns, nullptr, 0, 0, mean, maxabs, taps, ntpl, ltaps, len0, len1, y0, y1, ws, stream);
 }
 
-int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
+static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
                            const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
                            float* y1, void* ws, void* stream) {
     if (!x || !y0 || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
@@ -1072,7 +1129,7 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
         D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(ntpl * kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, ntpl,
                    ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2) + kXfLdsPad + kXfLdsPadBack;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1142,6 +1199,16 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
     return D4W_OK;
 }
 
+int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
+                           const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0,
+                           float* y1, void* ws, void* stream) {
+    int rc = hazard_enter(0, stream);      // (never beside stft_mm_rows: d4w_internal.h)
+    if (rc) return rc;
+    rc = d4w_xcorr_fft_cont_f32_run(x, nx, ns, xnext, ld_next, n_next, mean, maxabs, taps, ntpl, ltaps, len0, len1, y0, y1, ws, stream);
+    const int rl = hazard_leave(0, stream);
+    return rc ? rc : rl;
+}
+
 /* Zero-phase FIR along time by overlap-save FFT blocks (the interior of a zero-phase IIR filter: its two-sided
  * response truncated where it has decayed): y[r][n] = sum_j taps[j] x[r][n - K + j], j < 2K + 1, for K <= n < ns - K.
  * The columns within K of either row end are NOT written.  first[r] (a constant per row, e.g. the row's first sample)
@@ -1154,7 +1221,7 @@ int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, co
     return d4w_fir_fft_cols_f32(x, nx, ns, taps, K, first, dc_gain, y, K, ns - K, ws, stream);
 }
 
-int d4w_fir_fft_cols_f32(const float* x0, int nx, int ns0, const float* taps, int K, const float* first, double dc_gain,
+static int d4w_fir_fft_cols_f32_run(const float* x0, int nx, int ns0, const float* taps, int K, const float* first, double dc_gain,
                          float* y0, int col0, int col1, void* ws, void* stream) {
     if (!x0 || !y0 || !ws || nx < 1 || ns0 < 1) return fail(D4W_EINVAL, "bad argument");
     if (K < 0 || (K & 1) || K > d4w_fir_fft_max_halfwidth()) return fail(D4W_EINVAL, "half width %d must be even and <= %d", K, d4w_fir_fft_max_halfwidth());
@@ -1180,14 +1247,23 @@ int d4w_fir_fft_cols_f32(const float* x0, int nx, int ns0, const float* taps, in
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns_out, step), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2) + kXfLdsPad + kXfLdsPadBack;
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
                (float*)nullptr, step, K, ns_out, (float)dc_gain, XfHalo{}, first, ld);
     return D4W_OK;
 }
 
-int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int ld_left, int n_left, const float* right,
+int d4w_fir_fft_cols_f32(const float* x0, int nx, int ns0, const float* taps, int K, const float* first, double dc_gain,
+                         float* y0, int col0, int col1, void* ws, void* stream) {
+    int rc = hazard_enter(0, stream);      // (never beside stft_mm_rows: d4w_internal.h)
+    if (rc) return rc;
+    rc = d4w_fir_fft_cols_f32_run(x0, nx, ns0, taps, K, first, dc_gain, y0, col0, col1, ws, stream);
+    const int rl = hazard_leave(0, stream);
+    return rc ? rc : rl;
+}
+
+static int d4w_fir_fft_halo_f32_run(const float* x, int nx, int ns, const float* left, int ld_left, int n_left, const float* right,
                          int ld_right, int n_right, const float* taps, int K, const float* first, double dc_gain, float* y,
                          void* ws, void* stream) {
     if (!x || !y || !ws || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
@@ -1211,13 +1287,23 @@ int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int 
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2) + kXfLdsPad + kXfLdsPadBack;
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
     D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
                (float*)nullptr, step, 0, ns, (float)dc_gain, H, first, 0);
     return D4W_OK;
+}
+
+int d4w_fir_fft_halo_f32(const float* x, int nx, int ns, const float* left, int ld_left, int n_left, const float* right,
+                         int ld_right, int n_right, const float* taps, int K, const float* first, double dc_gain, float* y,
+                         void* ws, void* stream) {
+    int rc = hazard_enter(0, stream);      // (never beside stft_mm_rows: d4w_internal.h)
+    if (rc) return rc;
+    rc = d4w_fir_fft_halo_f32_run(x, nx, ns, left, ld_left, n_left, right, ld_right, n_right, taps, K, first, dc_gain, y, ws, stream);
+    const int rl = hazard_leave(0, stream);
+    return rc ? rc : rl;
 }
 
 }  // extern "C"

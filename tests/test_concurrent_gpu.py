@@ -1,0 +1,79 @@
+"""Kernels of the library beside each other on different HIP streams: a result must not depend on what else is resident on
+the compute units.  Round 5 found one pair where it did -- the overlap-save FFT kernels (band-pass, FFT-form matched filter)
+with the matrix-core STFT running on another stream: 16-byte LDS stores of the former sporadically lost dwords (1-10 % errors
+in whole blocks of a few rows per launch; scripts/probe/stream_race2.py, csrc/xcorr_fft.hip xf_st).  Every stage of the
+detection chain alone -> reference; then again with the STFT / the matched filter / the band-pass running on two other
+streams, compared bit for bit."""
+import numpy as np
+import pytest
+import scipy.signal as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+FS = 200.0
+
+
+def test_results_do_not_depend_on_kernels_of_other_streams():
+    assert torch.cuda.is_available()
+    from das4whales_amd import detect as ddet, dsp as ddsp
+    from das4whales_amd._lib import lib, check
+    nx, ns, halo = 11020, 12000, 1024
+    device = torch.device("cuda")
+    t = np.arange(ns) / FS
+    taps = [ddet._normalised_support(ddet.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)),
+            ddet._normalised_support(ddet.gen_template_fincall(t, FS, 14.7, 21.8, 0.78))]
+    g = torch.Generator(device=device).manual_seed(5)
+    a, b, c, load_in = (torch.randn((nx, ns), device=device, generator=g) for _ in range(4))
+    sos = sp.butter(8, [14 / (FS / 2), 30 / (FS / 2)], "bp", output="sos")
+    S0, _ = ddsp._stft_mag(load_in, 160, 8, 11, 23, want_max=False)
+    ker = np.random.default_rng(0).random((13, 19))
+    yb = ddsp._sosfiltfilt_between(b, a[:, -halo:], c[:, :halo], sos)
+    env = ddsp._analytic(yb, 0)
+    sides = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+    main = torch.cuda.current_stream(device)
+
+    def neighbours(kind):
+        keep = []
+        for sd in sides:
+            sd.wait_stream(main)
+        with torch.cuda.stream(sides[0]):
+            if kind == "stft":
+                check(lib.d4w_stft_mag_f32(load_in.data_ptr(), S0.data_ptr(), None, nx, ns, 160, 8, 11, 23,
+                                           torch.cuda.current_stream().cuda_stream))
+            elif kind == "mm":
+                keep.append(ddet._xcorr_device(load_in, taps, normalize=True))
+            else:
+                keep.append(ddsp._sosfiltfilt_between(load_in, a[:, -halo:], c[:, :halo], sos))
+        with torch.cuda.stream(sides[1]):
+            keep.append(ddsp._analytic(load_in, 0))
+        return keep
+
+    stages = {
+        "band-pass between two files (d4w_fir_fft_halo_f32)": lambda: ddsp._sosfiltfilt_between(b, a[:, -halo:], c[:, :halo], sos),
+        "band-pass of one file (d4w_fir_fft_cols_f32 + row ends)": lambda: ddsp._sosfiltfilt_device(b, sos, 51),
+        "matched filter, FFT form": lambda: torch.cat(ddet._xcorr_device(yb, taps, normalize=True, method="fft")),
+        "matched filter, matrix cores": lambda: torch.cat(ddet._xcorr_device(yb, taps, normalize=True, row_max=[])),
+        "recursion (lane per row: 16-byte LDS stores)": lambda: ddsp._sosfiltfilt_recursive(b[:2048], np.ascontiguousarray(sos), 51),
+        "envelope": lambda: ddsp._analytic(yb, 0),
+        "picks (16-byte LDS staging)": lambda: ddet._find_peaks_device(env, 0.25).packed,
+        "f-k filter (dense mask: pass B with 16-byte LDS stores)": lambda: ddsp.fk_filter_filt(yb, MASK),
+        "STFT": lambda: ddsp._stft_mag(b, 160, 8, 11, 23, want_max=False)[0],
+        "spectrogram correlation": lambda: ddet._spectrocorr_device(S0, ker, ker.shape[1] // 2, S0.shape[2]),
+    }
+    MASK = ddsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419, FS)
+    bad = []
+    for name, fn in stages.items():
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        for kind in ("stft", "mm", "fir"):
+            for trial in range(3):
+                k = neighbours(kind)
+                out = fn()
+                for sd in sides:
+                    main.wait_stream(sd)
+                torch.cuda.synchronize()
+                if not torch.equal(out, ref):
+                    d = (out.double() - ref.double()).abs().max() / ref.double().abs().max()
+                    bad.append((name, kind, trial, float(d.cpu())))
+                del k, out
+    assert not bad, bad
