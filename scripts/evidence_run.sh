@@ -13,6 +13,12 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | grep "^{" > $O/bench_line.json; cut -c1-300 $O/bench_line.json
 timeout 900 python bench.py --stages bp,fk,mf --steps 10 --warmup 3 --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_bp_fk_mf.json; cut -c1-200 $O/bench_bp_fk_mf.json
 timeout 900 python bench.py --config stream --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_1gpu.json; cut -c1-600 $O/bench_stream_1gpu.json
+# ... everything on ONE stream (the default puts the two detectors of a file on a side stream each)
+timeout 900 python bench.py --config stream --steps 10 --warmup 2 --detector-streams 0 --no-cpu 2>/dev/null | grep "^{" > $O/bench_stream_1gpu_one_stream.json; cut -c1-300 $O/bench_stream_1gpu_one_stream.json
+# round 5: the chain with the detectors on side streams against itself on one stream (which result differs: nothing, since the
+# cross-stream fence), and every stage beside the matrix-core STFT with the fence switched off (the hazard itself)
+timeout 300 python scripts/probe/stream_race.py 2>/dev/null | grep "^{" | cut -c1-300 > $O/stream_race.txt; tail -3 $O/stream_race.txt
+(D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py; [ -f das4whales_amd/lib/probe/libd4w_st128.so ] && D4W_LIB=$PWD/das4whales_amd/lib/probe/libd4w_st128.so D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py) 2>/dev/null | grep "trials" > $O/stream_race2_fence_off.txt; cut -c1-160 $O/stream_race2_fence_off.txt
 # the same chain with the raw files in pinned host memory (double-buffered upload on a side stream): 8 files per run as above, and
 # 24 files per run (the first upload and the drain weigh less: the steady-state rate against the PCIe bound)
 timeout 900 python bench.py --config stream --from-host --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_from_host.json; cut -c1-300 $O/bench_stream_from_host.json
@@ -34,6 +40,7 @@ timeout 600 python scripts/time_shapes.py 13223x12000 8000x12000 11020x12000 551
 # shapes beyond the direct kernels: prime channel counts / record lengths (Bluestein forms), loop-free prime radices (generic kernels)
 timeout 600 python scripts/time_shapes.py 4099x12000 10007x12000 19997x12000 11020x12014 11020x12002 10007x12014 2>/dev/null | grep "^{" > $O/time_any_shape.txt; cut -c1-60,180-330 $O/time_any_shape.txt
 timeout 300 python scripts/time_bluestein_rows.py 2>/dev/null | grep "^{" > $O/time_bluestein_rows.txt; cat $O/time_bluestein_rows.txt
+timeout 500 python scripts/probe/time_bz_band.py 2>/dev/null | grep "^{" > $O/time_bz_band.txt; cut -c1-200 $O/time_bz_band.txt
 (NX=4000 timeout 250 python scripts/time_long_rows.py; NX=20000 timeout 250 python scripts/time_long_rows.py) 2>/dev/null | grep "^{" > $O/time_long_rows.txt
 timeout 250 python scripts/time_fk_filt.py 2>/dev/null | grep "^{" > $O/time_fk_filt.txt
 (timeout 300 python scripts/time_api_sweep.py; NX=11020 NS=12000 timeout 300 python scripts/time_api_sweep.py) 2>/dev/null | grep "^{" > $O/time_api_sweep.txt

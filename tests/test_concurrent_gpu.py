@@ -4,6 +4,8 @@ with the matrix-core STFT running on another stream: 16-byte LDS stores of the f
 in whole blocks of a few rows per launch; scripts/probe/stream_race2.py, csrc/xcorr_fft.hip xf_st).  Every stage of the
 detection chain alone -> reference; then again with the STFT / the matched filter / the band-pass running on two other
 streams, compared bit for bit."""
+import os
+
 import numpy as np
 import pytest
 import scipy.signal as sp
@@ -66,7 +68,7 @@ def test_results_do_not_depend_on_kernels_of_other_streams():
         ref = fn().clone()
         torch.cuda.synchronize()
         for kind in ("stft", "mm", "fir"):
-            for trial in range(3):
+            for trial in range(int(os.environ.get("D4W_CONC_TRIALS", 3))):
                 k = neighbours(kind)
                 out = fn()
                 for sd in sides:
