@@ -40,6 +40,7 @@ timeout 600 python scripts/time_shapes.py 13223x12000 8000x12000 11020x12000 551
 # shapes beyond the direct kernels: prime channel counts / record lengths (Bluestein forms), loop-free prime radices (generic kernels)
 timeout 600 python scripts/time_shapes.py 4099x12000 10007x12000 19997x12000 11020x12014 11020x12002 10007x12014 2>/dev/null | grep "^{" > $O/time_any_shape.txt; cut -c1-60,180-330 $O/time_any_shape.txt
 timeout 300 python scripts/time_bluestein_rows.py 2>/dev/null | grep "^{" > $O/time_bluestein_rows.txt; cat $O/time_bluestein_rows.txt
+[ -x scripts/probe/lds_isolation ] && (for sz in "42608 38912" "42608 45056" "43008 43008"; do timeout 120 scripts/probe/lds_isolation $sz 30; done) > $O/lds_isolation.txt 2>&1
 timeout 500 python scripts/probe/time_bz_band.py 2>/dev/null | grep "^{" > $O/time_bz_band.txt; cut -c1-200 $O/time_bz_band.txt
 (NX=4000 timeout 250 python scripts/time_long_rows.py; NX=20000 timeout 250 python scripts/time_long_rows.py) 2>/dev/null | grep "^{" > $O/time_long_rows.txt
 timeout 250 python scripts/time_fk_filt.py 2>/dev/null | grep "^{" > $O/time_fk_filt.txt
