@@ -42,6 +42,9 @@ constexpr int kXfRowP = kXfMB + kXfNG;             // LDS row pitch: one pad ele
 #endif
 constexpr int kXfLdsPad = D4W_XF_LDSPAD;           // probe builds: unused bytes in front of ...
 constexpr int kXfLdsPadBack = D4W_XF_LDSPAD_BACK;  // ... and behind the blocks kernel's LDS
+#ifdef D4W_XF_SELFCHECK
+__device__ unsigned long long g_xf_check[8];       // [pass][dword of the 16-byte word]: LDS words that did not hold what was written
+#endif
 
 __host__ __device__ constexpr int xf_ad(int e) { return e + e / kXfNC; }
 // frequency held by position e after the three DIF stages (digits a', b', d)
@@ -139,11 +142,10 @@ __device__ __forceinline__ c2 xf_ld(const float4* p) {
     return c2{v2_make(v.x, v.y), v2_make(v.z, v.w)};
 }
 // Two 8-byte LDS stores, NOT one ds_write_b128 (round 5): with the matrix-core STFT (stft_mm_rows) resident on the same CU from
-// another HIP stream, 16-byte LDS stores of these kernels sporadically lost the first dword of each 8-byte half -- whole
-// blocks of the first row of a row pair came out 1-10 % off in a few workgroups per launch (scripts/probe/stream_race2.py:
-// 6 of 6 trials with ds_write_b128, 0 of 12 with two ds_write_b64; full barriers, cleared LDS, plain global stores and
-// padded LDS on the neighbour's side changed nothing; no other pair of the library's kernels showed it).  Not understood
-// beyond that; D4W_XF_ST128 (probe builds) restores the 16-byte store for the A/B.
+// another HIP stream, whole blocks of the first row of a row pair came out 1-10 % off in a few workgroups per launch
+// (scripts/probe/stream_race2.py: 6 of 6 trials with ds_write_b128, 1 of 24 / 2 of 45 with two ds_write_b64).  Not understood
+// (d4w_internal.h: hazard_enter) -- the fence there is what makes the results safe, this is belt and
+// braces at no cost; D4W_XF_ST128 (probe builds) restores the 16-byte store for the A/B.
 __device__ __forceinline__ void xf_st(float4* p, c2 v) {
 #if !defined(D4W_XF_ST128) && !defined(D4W_EMU)
     typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -307,6 +309,19 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                 constexpr int a = decltype(aa)::value;
                 xf_st(buf + xf_ad(j1 + a * M1), (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]));
             });
+#ifdef D4W_XF_SELFCHECK       // probe builds: does the LDS hold what this lane has just written? (and again after a barrier and a wait)
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass) { __syncthreads(); for (int w = 0; w < 64; ++w) __builtin_amdgcn_s_sleep(16); __syncthreads(); }
+                static_for<NA>([&](auto aa) {
+                    constexpr int a = decltype(aa)::value;
+                    const c2 want = (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]);
+                    const float4 got = lds_read4(buf + xf_ad(j1 + a * M1));
+                    const float w4[4] = {v2_x(want.re), v2_y(want.re), v2_x(want.im), v2_y(want.im)}, g4[4] = {got.x, got.y, got.z, got.w};
+                    for (int q = 0; q < 4; ++q)
+                        if (__float_as_uint(w4[q]) != __float_as_uint(g4[q])) atomicAdd(&g_xf_check[pass * 4 + q], 1ull);
+                });
+            }
+#endif
         }
         // the middle stage's table operands: issued here, in flight across S2
         float2 GA[NC], GB[NC];
@@ -1214,6 +1229,14 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
  * The columns within K of either row end are NOT written.  first[r] (a constant per row, e.g. the row's first sample)
  * is subtracted from the samples before the transform and first[r] * dc_gain added back (dc_gain = sum of the taps
  * as the exact filter has it), which keeps a large offset out of the float32 transform. */
+#ifdef D4W_XF_SELFCHECK
+int d4w_xf_selfcheck_read(unsigned long long* host8, int reset) {
+    D4W_HIP(hipDeviceSynchronize());
+    D4W_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_xf_check), sizeof(g_xf_check)));
+    if (reset) { unsigned long long z[8] = {}; D4W_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xf_check), z, sizeof(z))); }
+    return D4W_OK;
+}
+#endif
 int d4w_fir_fft_max_halfwidth(void) { return (kXfB - 2048) / 2; }
 
 int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,

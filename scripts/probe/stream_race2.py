@@ -123,3 +123,10 @@ for name, fn in list(stages.items())[:int(os.environ.get("NSTAGES", 99))]:
                                   "out finite": bool(torch.isfinite(out).all().cpu())}), flush=True)
         del k
     print(json.dumps({"stage": name, "trials": 6, "differing": bad, "worst_rel": worst if bad else 0.0}), flush=True)
+    if os.environ.get("SELFCHECK"):                    # probe build with -DD4W_XF_SELFCHECK (build_variant.sh)
+        import ctypes
+        from das4whales_amd._lib import lib as _l
+        buf8 = (ctypes.c_ulonglong * 8)()
+        _l.d4w_xf_selfcheck_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _l.d4w_xf_selfcheck_read(buf8, 1)
+        print(json.dumps({"stage": name, "LDS words that did not hold what the lane wrote, by dword [right after the store x4 | after a barrier and a wait x4]": list(buf8)}), flush=True)
