@@ -48,6 +48,13 @@ def load():
         if "6" in LOAD:                                      # ... on a few rows only (presence, not pressure)
             from das4whales_amd._lib import lib, check
             check(lib.d4w_stft_mag_f32(load_in.data_ptr(), S0.data_ptr(), None, 64, ns, 160, 8, 11, 23, torch.cuda.current_stream().cuda_stream))
+        for kind, ch in ((0, "M"), (1, "V"), (2, "L")):       # synthetic neighbours: matrix instructions / vector FMAs / LDS traffic only
+            if ch in LOAD:
+                import ctypes
+                bl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libburners.so"))
+                bl.burn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+                rc = bl.burn(kind, torch.cuda.current_stream().cuda_stream, BURN_OUT.data_ptr(), 256 * 3, int(os.environ.get("BURN_ITERS", 20000)))
+                assert rc == 0, rc
         if "7" in LOAD:                                      # the overlap-save band-pass as the neighbour
             keep.append(ddsp._sosfiltfilt_between(load_in, a[:, -halo:], c[:, :halo], sos))
         if "4" in LOAD:                                      # the matrix-core matched filter as the neighbour
@@ -64,6 +71,7 @@ def load():
     return keep
 
 
+BURN_OUT = torch.empty(256 * 3 * 256, dtype=torch.float32, device=device)
 S0, _ = ddsp._stft_mag(load_in, 160, 8, 11, 23, want_max=False)
 KER = np.random.default_rng(0).random((13, 19))
 MED0 = torch.ones(nx, dtype=torch.float32, device=device)
