@@ -2,7 +2,7 @@
 the compute units.  Round 5 found one pair where it did -- the overlap-save FFT kernels (band-pass, FFT-form matched filter)
 with the matrix-core STFT running on another stream: 16-byte LDS stores of the former sporadically lost dwords (1-10 % errors
 in whole blocks of a few rows per launch; scripts/probe/stream_race2.py, csrc/xcorr_fft.hip xf_st).  Every stage of the
-detection chain alone -> reference; then again with the STFT / the matched filter / the band-pass running on two other
+detection chain alone -> reference; then again with the STFT / the matched filter / the band-pass / filter2d running on two other
 streams, compared bit for bit."""
 import os
 
@@ -17,7 +17,7 @@ FS = 200.0
 
 def test_results_do_not_depend_on_kernels_of_other_streams():
     assert torch.cuda.is_available()
-    from das4whales_amd import detect as ddet, dsp as ddsp
+    from das4whales_amd import detect as ddet, dsp as ddsp, improcess
     from das4whales_amd._lib import lib, check
     nx, ns, halo = 11020, 12000, 1024
     device = torch.device("cuda")
@@ -44,6 +44,8 @@ def test_results_do_not_depend_on_kernels_of_other_streams():
                                            torch.cuda.current_stream().cuda_stream))
             elif kind == "mm":
                 keep.append(ddet._xcorr_device(load_in, taps, normalize=True))
+            elif kind == "f2d":                                  # the Gabor detector's filter2d on the matrix cores
+                keep.append(improcess._filter2d_device(load_in, GABOR))
             else:
                 keep.append(ddsp._sosfiltfilt_between(load_in, a[:, -halo:], c[:, :halo], sos))
         with torch.cuda.stream(sides[1]):
@@ -63,11 +65,12 @@ def test_results_do_not_depend_on_kernels_of_other_streams():
         "spectrogram correlation": lambda: ddet._spectrocorr_device(S0, ker, ker.shape[1] // 2, S0.shape[2]),
     }
     MASK = ddsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419, FS)
+    GABOR = improcess.gabor_filt_design(improcess.angle_fromspeed(1500.0, FS, 2.0419, [0, nx, 1]))
     bad = []
     for name, fn in stages.items():
         ref = fn().clone()
         torch.cuda.synchronize()
-        for kind in ("stft", "mm", "fir"):
+        for kind in ("stft", "mm", "fir", "f2d"):
             for trial in range(int(os.environ.get("D4W_CONC_TRIALS", 3))):
                 k = neighbours(kind)
                 out = fn()
