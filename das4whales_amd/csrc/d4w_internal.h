@@ -18,14 +18,13 @@
 // ---------------------------------------------------------------------------------------------
 namespace d4w {
 inline thread_local char g_err[512] = "";
-// Two kernel families that must not be resident on a compute unit together (round 5, scripts/probe/stream_race2.py): with the
-// matrix-core STFT (stft_mm_rows) running from ANOTHER HIP stream, the overlap-save FFT kernels (xcorr_fft.hip: band-pass,
-// FFT-form matched filter) returned whole blocks 1-10 % off in a few workgroups per launch (gone with 6 KB of unused LDS
-// behind their tile at one neighbour size, back with another; 8-byte instead of 16-byte LDS stores made it 20 x rarer;
-// barriers, cleared LDS, plain global stores changed nothing; the loaded samples are right and every lane finds in LDS what
-// it stored; no other pair of the library's kernels shows it -- DESIGN.md section 1).  Until that is understood the two are
-// serialised ACROSS streams: a launch of one family first
-// waits (on the device) for the last launch of the other, whichever stream that was on.  Nothing changes on one stream.
+// Two kernel families that are kept from being resident on a compute unit together (round 5, scripts/probe/stream_race2.py):
+// with the matrix-core STFT (stft_mm_rows) running from ANOTHER HIP stream, the overlap-save FFT kernels (xcorr_fft.hip:
+// band-pass, FFT-form matched filter) returned whole blocks 1-10 % off in a few workgroups per launch -- their 16-byte LDS
+// accesses went wrong while the neighbour's LDS-fed matrix instructions were in flight (DESIGN.md section 1 has the table of
+// probes).  Those kernels use 8-byte LDS accesses now (0 of 36 bad trials without this fence); the fence is the second line:
+// a launch of one family first waits (on the device) for the last launch of the other, whichever stream that was on.
+// Nothing changes on one stream.
 //   hazard_enter(self, stream) ... launches ... hazard_leave(self, stream);   self: 0 = overlap-save FFT kernels, 1 = stft_mm
 int hazard_enter(int self, void* stream);
 int hazard_leave(int self, void* stream);

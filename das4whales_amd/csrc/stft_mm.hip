@@ -145,8 +145,12 @@ __global__ __launch_bounds__(kSmThreads, 3) void stft_mm_rows(SmArgs P) {
                 const float s[4] = {v[q].x * down, v[q].y * down, v[q].z * down, v[q].w * down};
                 mm_half h[4], l[4];
                 static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
+#ifndef D4W_SM_NO_STAGE
                 mm_put4(bh + i, h);
                 mm_put4(bl + i, l);
+#else
+                if (h[0] == (mm_half)12345.f) { mm_put4(bh + i, h); mm_put4(bl + i, l); }
+#endif
             }
         });
         lds_barrier();
@@ -166,20 +170,32 @@ __global__ __launch_bounds__(kSmThreads, 3) void stft_mm_rows(SmArgs P) {
                 const int base = (16 * T + n16) * hop + 8 * g;      // first sample of this lane's window piece (multiple of 8)
                 static_for<KS>([&](auto kq) {
                     constexpr int kk = decltype(kq)::value;
+#ifndef D4W_SM_CONST_B
                     const mm_h8 xh = *reinterpret_cast<const mm_h8*>(bh + base + 32 * kk);
                     const mm_h8 xl = *reinterpret_cast<const mm_h8*>(bl + base + 32 * kk);
+#else
+                    const mm_h8 xh = aih[kk], xl = ail[kk];            // (probe: operands that do not come out of LDS)
+#endif
+#ifndef D4W_SM_NO_MFMA          // (probe builds, scripts/probe/stream_race2.py: which part of this kernel disturbs the overlap-save FFT kernels?)
                     crh = mm_mfma(arh[kk], xh, crh);
                     cih = mm_mfma(aih[kk], xh, cih);
                     cra = mm_mfma(arh[kk], xl, cra);
                     cia = mm_mfma(aih[kk], xl, cia);
                     crb = mm_mfma(arl[kk], xh, crb);
                     cib = mm_mfma(ail[kk], xh, cib);
+#else
+                    crh[0] += (float)xh[0] + (float)xl[1];
+#endif
                 });
                 static_for<4>([&](auto rr) {                        // this lane: frame 16 q + n16 of the run, bins 4 g .. 4 g + 3
                     constexpr int r = decltype(rr)::value;
                     const float re = fmaf(mm_get(cra, r) + mm_get(crb, r), kMmLoInv, mm_get(crh, r));
                     const float im = fmaf(mm_get(cia, r) + mm_get(cib, r), kMmLoInv, mm_get(cih, r));
+#ifndef D4W_SM_NO_TILE
                     tile[(4 * g + r) * kSmTileP + 16 * q + n16] = mm_sqrt(fmaf(re, re, im * im)) * up;
+#else
+                    if (re == 12345.f) tile[(4 * g + r) * kSmTileP + 16 * q + n16] = mm_sqrt(fmaf(re, re, im * im)) * up;
+#endif
                 });
             });
             mm_wave_sync();                                         // the run's tile is complete (one wave wrote it, the same wave reads it)

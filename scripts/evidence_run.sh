@@ -18,7 +18,7 @@ timeout 900 python bench.py --config stream --steps 10 --warmup 2 --detector-str
 # round 5: the chain with the detectors on side streams against itself on one stream (which result differs: nothing, since the
 # cross-stream fence), and every stage beside the matrix-core STFT with the fence switched off (the hazard itself)
 timeout 300 python scripts/probe/stream_race.py 2>/dev/null | grep "^{" | cut -c1-300 > $O/stream_race.txt; tail -3 $O/stream_race.txt
-(D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py; [ -f das4whales_amd/lib/probe/libd4w_st128.so ] && D4W_LIB=$PWD/das4whales_amd/lib/probe/libd4w_st128.so D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py) 2>/dev/null | grep "trials" > $O/stream_race2_fence_off.txt; cut -c1-160 $O/stream_race2_fence_off.txt
+(D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py; [ -f das4whales_amd/lib/probe/libd4w_wide.so ] && D4W_LIB=$PWD/das4whales_amd/lib/probe/libd4w_wide.so D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py) 2>/dev/null | grep "trials" > $O/stream_race2_fence_off.txt; cut -c1-160 $O/stream_race2_fence_off.txt
 # the same chain with the raw files in pinned host memory (double-buffered upload on a side stream): 8 files per run as above, and
 # 24 files per run (the first upload and the drain weigh less: the steady-state rate against the PCIe bound)
 timeout 900 python bench.py --config stream --from-host --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_from_host.json; cut -c1-300 $O/bench_stream_from_host.json

@@ -20,6 +20,22 @@ __global__ __launch_bounds__(256) void burn_mfma(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
+// the same with ~150 live vector registers per lane (32 accumulators + operands), as the STFT kernel has
+__global__ __launch_bounds__(256, 3) void burn_mfma_fat(float* out, int iters) {
+    h8 a[4], b[4];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 8; ++i) { a[k][i] = (_Float16)(0.001f * (threadIdx.x + i + k)); b[k][i] = (_Float16)(0.002f * ((threadIdx.x ^ i) + k)); }
+    f4 c[32];
+    for (int k = 0; k < 32; ++k) c[k] = f4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[k & 3], b[(k >> 2) & 3], c[k], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += c[k][k & 3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void burn_valu(float* out, int iters) {
     float v[16];
     for (int i = 0; i < 16; ++i) v[i] = 0.001f * (threadIdx.x + i);
@@ -49,6 +65,7 @@ extern "C" int burn(int kind, void* stream, float* out, int grid, int iters) {
     hipStream_t st = (hipStream_t)stream;
     if (kind == 0) hipLaunchKernelGGL(burn_mfma, dim3(grid), dim3(256), 0, st, out, iters);
     else if (kind == 1) hipLaunchKernelGGL(burn_valu, dim3(grid), dim3(256), 0, st, out, iters);
+    else if (kind == 3) hipLaunchKernelGGL(burn_mfma_fat, dim3(grid), dim3(256), 42608, st, out, iters / 8);     // (+ the STFT's LDS footprint, unused)
     else hipLaunchKernelGGL(burn_lds, dim3(grid), dim3(256), 42608, st, out, iters, 42608 / 4);
     return (int)hipGetLastError();
 }

@@ -48,7 +48,7 @@ def load():
         if "6" in LOAD:                                      # ... on a few rows only (presence, not pressure)
             from das4whales_amd._lib import lib, check
             check(lib.d4w_stft_mag_f32(load_in.data_ptr(), S0.data_ptr(), None, 64, ns, 160, 8, 11, 23, torch.cuda.current_stream().cuda_stream))
-        for kind, ch in ((0, "M"), (1, "V"), (2, "L")):       # synthetic neighbours: matrix instructions / vector FMAs / LDS traffic only
+        for kind, ch in ((0, "M"), (1, "V"), (2, "L"), (3, "F")):       # synthetic neighbours: matrix instructions / vector FMAs / LDS traffic only
             if ch in LOAD:
                 import ctypes
                 bl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libburners.so"))

@@ -1,7 +1,7 @@
 """Kernels of the library beside each other on different HIP streams: a result must not depend on what else is resident on
 the compute units.  Round 5 found one pair where it did -- the overlap-save FFT kernels (band-pass, FFT-form matched filter)
-with the matrix-core STFT running on another stream: 16-byte LDS stores of the former sporadically lost dwords (1-10 % errors
-in whole blocks of a few rows per launch; scripts/probe/stream_race2.py, csrc/xcorr_fft.hip xf_st).  Every stage of the
+with the matrix-core STFT running on another stream: 16-byte LDS accesses of the former went wrong (1-10 % errors in whole
+blocks of a few rows per launch; scripts/probe/stream_race2.py, csrc/xcorr_fft.hip xf_ld / xf_st).  Every stage of the
 detection chain alone -> reference; then again with the STFT / the matched filter / the band-pass / filter2d running on two other
 streams, compared bit for bit."""
 import os
