@@ -22,8 +22,9 @@ inline thread_local char g_err[512] = "";
 // with the matrix-core STFT (stft_mm_rows) running from ANOTHER HIP stream, the overlap-save FFT kernels (xcorr_fft.hip:
 // band-pass, FFT-form matched filter) returned whole blocks 1-10 % off in a few workgroups per launch -- their 16-byte LDS
 // accesses went wrong while the neighbour's LDS-fed matrix instructions were in flight (DESIGN.md section 1 has the table of
-// probes).  Those kernels use 8-byte LDS accesses now (0 of 36 bad trials without this fence); the fence is the second line:
-// a launch of one family first waits (on the device) for the last launch of the other, whichever stream that was on.
+// probes).  Those kernels use 8-byte LDS accesses now (one bad trial in forty without this fence instead of every one); the
+// fence is what makes the results safe: a launch of one family first waits (on the device) for the last launch of the
+// other, whichever stream that was on.
 // Nothing changes on one stream.
 //   hazard_enter(self, stream) ... launches ... hazard_leave(self, stream);   self: 0 = overlap-save FFT kernels, 1 = stft_mm
 int hazard_enter(int self, void* stream);
