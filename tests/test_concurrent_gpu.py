@@ -71,7 +71,7 @@ def test_results_do_not_depend_on_kernels_of_other_streams():
         ref = fn().clone()
         torch.cuda.synchronize()
         for kind in ("stft", "mm", "fir", "f2d"):
-            for trial in range(int(os.environ.get("D4W_CONC_TRIALS", 3))):
+            for trial in range(int(os.environ.get("D4W_CONC_TRIALS", 6))):
                 k = neighbours(kind)
                 out = fn()
                 for sd in sides:
