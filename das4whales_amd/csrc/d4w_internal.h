@@ -22,7 +22,8 @@ inline thread_local char g_err[512] = "";
 // with the matrix-core STFT (stft_mm_rows) running from ANOTHER HIP stream, the overlap-save FFT kernels (xcorr_fft.hip:
 // band-pass, FFT-form matched filter) returned whole blocks 1-10 % off in a few workgroups per launch -- their 16-byte LDS
 // accesses went wrong while the neighbour's LDS-fed matrix instructions were in flight (DESIGN.md section 1 has the table of
-// probes).  Those kernels use 8-byte LDS accesses now (one bad trial in forty without this fence instead of every one); the
+// probes).  Those kernels store to LDS 8 bytes at a time now (one bad trial in twenty-five without this fence instead of
+// every one); the
 // fence is what makes the results safe: a launch of one family first waits (on the device) for the last launch of the
 // other, whichever stream that was on.
 // Nothing changes on one stream.

@@ -137,18 +137,18 @@ __device__ __forceinline__ void xf_pair(c2 A, c2 Bs, float2 w, float2 gf, float2
 }
 
 // LDS element: (re_A, re_B, im_A, im_B)
-// LDS tile accesses of these kernels are 8 bytes wide, NOT 16 (round 5).  With the matrix-core STFT (stft_mm_rows) resident on
+// LDS tile STORES of these kernels are 8 bytes wide, not 16 (round 5).  With the matrix-core STFT (stft_mm_rows) resident on
 // the same CU from another HIP stream, whole blocks of the first row of a row pair -- dwords 0 and 2 of the tile's 16-byte
 // words -- came out 1-10 % off in a few workgroups per launch (scripts/probe/stream_race2.py, fence off: 6 of 6 trials with
-// ds_read_b128 + ds_write_b128, 1 of 24 / 2 of 45 with 8-byte stores only, 0 of 36 and later 3 of 120 with 8-byte reads and
-// stores: narrower accesses are less exposed, not immune -- the cross-stream fence is what makes the results safe).  The
+// ds_read_b128 + ds_write_b128, 1 of 24 / 2 of 45 with 8-byte stores, 0 of 36 and later 3 of 120 with 8-byte reads as
+// well: narrower accesses are less exposed, not immune -- the cross-stream fence is what makes the results safe).  The
 // neighbour needs its matrix instructions AND their operands coming out of LDS for it (without either: 0 of 12; without its
-// LDS writes: still 6 of 6), synthetic matrix / vector / LDS neighbours do nothing: what it looks like is 16-byte LDS return
-// data of one wave going wrong while another wave's LDS-fed matrix instructions are in flight.  Not understood beyond that
-// (d4w_internal.h: hazard_enter).  Cost: band-pass
-// 5.75 -> 5.86 ms at 20 000 x 120 000.  D4W_XF_LD128 / D4W_XF_ST128 (probe builds) restore the 16-byte forms.
+// LDS writes: still 6 of 6), synthetic matrix / vector / LDS neighbours do nothing.  Not understood beyond that (DESIGN.md
+// section 1; d4w_internal.h: hazard_enter).  The 8-byte stores cost nothing and stay; 8-byte READS cost 2 % (cols) to 10 %
+// (between two files) of the band-pass and buy nothing over the stores once the fence is there: D4W_XF_LD64 (probe builds)
+// selects them, D4W_XF_ST128 the 16-byte stores.
 __device__ __forceinline__ c2 xf_ld(const float4* p) {
-#if !defined(D4W_XF_LD128) && !defined(D4W_EMU)
+#if defined(D4W_XF_LD64) && !defined(D4W_EMU)
     typedef float f2_t __attribute__((ext_vector_type(2)));
     typedef const volatile f2_t __attribute__((address_space(3))) * lds_f2_ptr;
     const f2_t lo = ((lds_f2_ptr)p)[0], hi = ((lds_f2_ptr)p)[1];

@@ -8,7 +8,7 @@ name=$1; shift
 python -c "import __graft_entry__ as g; g.build()" > /dev/null
 mkdir -p das4whales_amd/lib/probe
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I include"
-/opt/rocm/bin/hipcc $F -DD4W_XF_ST128 -DD4W_XF_LD128 -c das4whales_amd/csrc/xcorr_fft.hip -o das4whales_amd/lib/probe/xf.$name.o &
+/opt/rocm/bin/hipcc $F -DD4W_XF_ST128 -c das4whales_amd/csrc/xcorr_fft.hip -o das4whales_amd/lib/probe/xf.$name.o &
 /opt/rocm/bin/hipcc $F "$@" -c das4whales_amd/csrc/stft_mm.hip -o das4whales_amd/lib/probe/sm.$name.o &
 wait
 objs=$(ls das4whales_amd/lib/obj/*.o | grep -v "/xcorr_fft.hip.o\|/stft_mm.hip.o")
