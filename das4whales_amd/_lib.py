@@ -71,6 +71,8 @@ def _load():
         "d4w_sosfiltfilt_ends_ws_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
         "d4w_sosfiltfilt_ends_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+        "d4w_sosfiltfilt_ends_sides_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, P(ctypes.c_double), P(ctypes.c_double), c_int, c_int,
+                                             c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
         "d4w_design_mask_f32": (c_int, [c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, P(ctypes.c_double),
                                         c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_flip_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

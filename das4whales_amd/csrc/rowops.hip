@@ -1045,7 +1045,13 @@ size_t d4w_sosfiltfilt_ends_ws_bytes(int nx, int piece, int padlen) {
 
 int d4w_sosfiltfilt_ends_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi, int nsec, int padlen,
                              int piece, int keep, int phase, void* ws, void* stream) {
+    return d4w_sosfiltfilt_ends_sides_f32(x, y, nx, ns, sos, zi, nsec, padlen, piece, keep, phase, 3, ws, stream);
+}
+
+int d4w_sosfiltfilt_ends_sides_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi, int nsec,
+                                   int padlen, int piece, int keep, int phase, int sides, void* ws, void* stream) {
     if (!x || !y || !sos || !zi || !ws) return fail(D4W_EINVAL, "NULL argument");
+    if (sides < 1 || sides > 3) return fail(D4W_EINVAL, "sides = %d (1 left, 2 right, 3 both)", sides);
     if (x == y) return fail(D4W_EINVAL, "the row ends are read from x while y is written: x and y must not alias");
     if (nx < 1 || ns < 1 || padlen < 0) return fail(D4W_EINVAL, "bad shape %d x %d (padlen %d)", nx, ns, padlen);
     if (nsec < 1 || nsec > kSosMaxSec) return fail(D4W_EINVAL, "nsec = %d not in 1..%d", nsec, kSosMaxSec);
@@ -1062,6 +1068,13 @@ int d4w_sosfiltfilt_ends_f32(const float* x, float* y, int nx, int ns, const dou
     // rows 0 .. nx-1: the left pieces x[r][0 .. piece), rows nx .. 2 nx - 1: the right pieces x[r][ns - piece .. ns); the
     // forward outputs of all 2 nx pieces side by side in the workspace; the backward pass writes the `keep` outer samples of
     // each piece straight into y (left: [0, keep), right: piece samples [piece - keep, piece) = y[r][ns - keep .. ns))
+    if (sides != 3) {
+        // one end only (a file whose other end continues into a neighbour: das4whales_amd/stream.py): nx pieces, all of one kind
+        const long long off = (sides == 2) ? (long long)ns - piece : 0;
+        const SlRows xr1{x + off, (size_t)ns, 0, nx}, tr1{t, (size_t)piece, 0, nx}, yr1{y + off, (size_t)ns, 0, nx};
+        const int k0 = (sides == 2) ? piece - keep : 0, k1 = (sides == 2) ? piece : keep;
+        return sos_lanes_both(nsec, precise, A, Ad, xr1, tr1, yr1, k0, k1, k0, k1, edge, nx, piece, padlen, xr1, (float)dcg2, stream, phase);
+    }
     const SlRows xr{x, (size_t)ns, (long long)ns - piece, nx}, tr{t, (size_t)piece, (long long)nx * piece, nx};
     const SlRows yr{y, (size_t)ns, (long long)ns - piece, nx};
     return sos_lanes_both(nsec, precise, A, Ad, xr, tr, yr, 0, keep, piece - keep, piece, edge, 2 * nx, piece, padlen, xr, (float)dcg2,

@@ -631,6 +631,45 @@ def _sosfiltfilt_between(x, left, right, sos):
     return y
 
 
+def _sosfiltfilt_one_neighbour(x, left, right, sos, padlen):
+    """Zero-phase filter of rows that continue on ONE side (the first file of a record: `left` is None, its left end is a true
+    record end; the last file: `right` is None): the overlap-save pass of _sosfiltfilt_between with a stand-in halo on the
+    free side (the file's own columns: any finite samples do, the outputs they reach are replaced), then filtfilt's edge rule
+    on that side's row-end pieces (d4w_sosfiltfilt_ends_sides_f32), whose E outer outputs overwrite the stand-in's reach.
+    No concatenated copy of file + halo, no cropped copy of the result (round 5: 0.45 ms per edge file of 11 020 x 12 000).
+    Returns None when the form does not apply."""
+    if (left is None) == (right is None):
+        return None
+    sos = np.ascontiguousarray(np.atleast_2d(np.asarray(sos, dtype=np.float64)))
+    zp = _zero_phase_taps(sos, x.device)
+    if zp is None:
+        return None
+    t, K, E, dcg = zp
+    P = 2 * E
+    nx, ns = x.shape
+    have = right if left is None else left
+    if not (dev.is_tensor(have) and have.is_cuda and have.dtype == torch.float32 and have.dim() == 2 and have.stride(1) == 1
+            and have.shape[0] == nx and have.shape[1] >= K and x.is_contiguous()) or ns < 4 * P or P <= padlen or E < K:
+        return None
+    lv = x[:, :K] if left is None else left[:, left.shape[1] - K:]
+    rv = x[:, ns - K:] if right is None else right
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        first = torch.empty((nx, 1), dtype=torch.float32, device=x.device)
+        _copy_cols(x[:, :1], first)
+        ent = _fir_workspace(t, x.device)
+        check(lib.d4w_fir_fft_halo_f32(dev.ptr(x), nx, ns, lv.data_ptr(), int(lv.stride(0)), int(K), rv.data_ptr(),
+                                       int(rv.stride(0)), int(K), None if ent[1] else dev.ptr(t), int(K), dev.ptr(first),
+                                       dcg, dev.out_ptr(y), dev.ptr(ent[0]), dev.stream_ptr(x)))
+        ent[1] = True
+        zi = _sos_host(sos)["zi"]
+        ws = torch.empty(int(lib.d4w_sosfiltfilt_ends_ws_bytes(nx, P, padlen)), dtype=torch.uint8, device=x.device)
+        check(lib.d4w_sosfiltfilt_ends_sides_f32(dev.ptr(x), dev.out_ptr(y), nx, ns, sos.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                 zi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), sos.shape[0], int(padlen), int(P),
+                                                 int(E), 0, 1 if left is None else 2, dev.ptr(ws), dev.stream_ptr(x)))
+    return y
+
+
 def _sosfiltfilt_recursive(x, sos, padlen, seg_len=None, warm=None):
     """The exact second-order-section recursion (forward + backward launch, 16 B per sample)."""
     import scipy.signal as sp

@@ -19,6 +19,8 @@ band-passed and f-k filtered file i+1 exists, i.e. when file i+2 has arrived.  p
 results that became final; flush() closes the stream (the last file ends like a stand-alone file).
 All arithmetic runs in the HIP library through dsp / detect; this module only moves halos around.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -61,9 +63,15 @@ class FileStream:
             y = dsp._sosfiltfilt_between(cur if cur.is_contiguous() else cur.contiguous(), left, right, self._sos)
             if y is not None:
                 return y
-        # the first / last file of a record (one neighbour only) or a response longer than the halo: the pieces side by
-        # side in one buffer (one strided-copy launch per piece, no torch.cat), filtered with filtfilt's edge rule at the
-        # true record ends, the file's own columns copied out
+        if (left is None) != (right is None) and os.environ.get("D4W_STREAM_EDGE_FIR", "1") != "0":
+            # the first / last file of a record: the same pass with a stand-in halo on the free side, filtfilt's edge rule
+            # on that side's row ends afterwards (no concatenated copy, no cropped copy)
+            y = dsp._sosfiltfilt_one_neighbour(cur if cur.is_contiguous() else cur.contiguous(), left, right, self._sos, 51)
+            if y is not None:
+                return y
+        # a response longer than the halo (or a stand-alone file): the pieces side by side in one buffer (one strided-copy
+        # launch per piece, no torch.cat), filtered with filtfilt's edge rule at the true record ends, the file's own
+        # columns copied out
         parts = [p for p in (left, cur, right) if p is not None]
         ext = dsp._concat_cols(parts) if len(parts) > 1 else (cur if cur.is_contiguous() else cur.contiguous())
         y = dsp._sosfiltfilt_device(ext, self._sos, 51)

@@ -242,6 +242,11 @@ int d4w_sosfiltfilt_f32(const float* x, float* y, int nx, int ns, const double* 
 size_t d4w_sosfiltfilt_ends_ws_bytes(int nx, int piece, int padlen);
 int d4w_sosfiltfilt_ends_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi, int nsec,
                              int padlen, int piece, int keep, int phase, void* ws, void* stream);
+/* The same for ONE row end: sides = 1 the left pieces only, 2 the right pieces only (3 = both = the call above) -- a file
+ * whose other end continues into a neighbouring file (das4whales_amd/stream.py: the first / last file of a record takes
+ * d4w_fir_fft_halo_f32 with a stand-in halo on its free side and this call for that side's `keep` columns, after it). */
+int d4w_sosfiltfilt_ends_sides_f32(const float* x, float* y, int nx, int ns, const double* sos, const double* zi, int nsec,
+                                   int padlen, int piece, int keep, int phase, int sides, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused ingest (the step in front of the path): data_handle.load_das_data's channel selection and

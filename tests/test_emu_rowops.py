@@ -661,3 +661,15 @@ def test_row_end_pieces_in_place(emu, phases):
     assert np.max(np.abs(y[:, ns - keep:] - right[:, piece - keep:])) < TOL * scale
     assert np.all(y[:, keep:ns - keep] == 7.5)
     assert emu.d4w_sosfiltfilt_ends_f32(vp(x), vp(x), nx, ns, vp(sos), vp(zi), sos.shape[0], padlen, piece, keep, 0, vp(ws), None) != 0
+    # one end only (the first / last file of a stream): exactly that side's columns of the two-sided result, the rest untouched
+    for sides, sl in ((1, slice(0, keep)), (2, slice(ns - keep, ns))):
+        y1 = np.full_like(x, 7.5)
+        for ph in phases:
+            rc = emu.d4w_sosfiltfilt_ends_sides_f32(vp(x), vp(y1), nx, ns, vp(sos), vp(zi), sos.shape[0], padlen, piece, keep, ph, sides,
+                                                    vp(ws), None)
+            assert rc == 0, emu.d4w_last_error()
+        assert np.array_equal(y1[:, sl], y[:, sl])
+        mask = np.ones(ns, dtype=bool)
+        mask[sl] = False
+        assert np.all(y1[:, mask] == 7.5)
+    assert emu.d4w_sosfiltfilt_ends_sides_f32(vp(x), vp(y), nx, ns, vp(sos), vp(zi), sos.shape[0], padlen, piece, keep, 0, 4, vp(ws), None) != 0
