@@ -131,7 +131,12 @@ class FileStream:
                 ext = dsp._concat_cols([y, next_head[:, :self.lmax - 1]])
             else:
                 ext = y
-            cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx))
+            # (a file without a successor -- the record's last -- still gets its row maxima from the correlator's epilogue:
+            # the DC-tail decision per row and correlogram_max need no sweep of the correlograms then)
+            rmax = [] if ext is y else None
+            cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx), row_max=rmax)
+            if rmax and len(rmax) == len(cs):
+                out["row_max"] = rmax
             cs = [dsp._copy_cols(c[:, :ns], torch.empty_like(y)) if c.shape[1] != ns else c for c in cs]
         # the DC tail of zero-padded templates, decided per row on the data (detect._apply_tails: the band-passed rows of
         # a stream have prefix sums of a few samples' size and are left alone; the row maxima stay valid either way)

@@ -64,9 +64,7 @@ def test_stream_equals_concatenated_record(with_fk):
                 assert torch.equal(rm, c.max(dim=1).values)
                 assert dw.detect.correlogram_max(c, rm) == float(c.max()) == dw.detect.correlogram_max(c)
         else:
-            # absent only for the record's last file (no continuation: the general correlator path); the DC tail of the
-            # zero-padded templates (detect.py:158), where a row receives it, forms that row's maximum again
-            assert i == nfiles - 1
+            raise AssertionError("every file of a stream carries the row maxima of its correlograms (round 5: the last one too)")
     # a stand-alone file (the reference's per-file run) differs from the stream at the file edges
     alone = dw.dsp.bp_filt(rec[:, ns:2 * ns], FS, 14, 30)
     assert rel(alone, F[:, ns:2 * ns]) > 1e-3
