@@ -435,7 +435,11 @@ def bench_stream(args, world, rank, device, dist):
                 with torch.cuda.stream(det_streams[0]) if det_streams else contextlib.nullcontext():
                     rm = r.get("row_max")      # per-row maxima from the correlator's epilogue (the last file of a run: one read)
                     thr = ddet.Threshold(0.45, ddet.correlogram_max(r["correlograms"][0], rm[0] if rm else None, on_device=True))
-                    for c in r["correlograms"]:
+                    cs = r["correlograms"]
+                    both = ddet.stacked_pair(cs[0], cs[1]) if len(cs) == 2 and os.environ.get("D4W_BENCH_STACK", "1") != "0" else None
+                    # the HF and LF correlograms of a file sit back to back (one fused correlator launch): their envelopes and
+                    # picks at the common threshold are one launch each over 2 nx rows
+                    for c in ([both] if both is not None else cs):
                         picks.append(ddet.pick_times_env(c, thr, lazy=True))
                 with torch.cuda.stream(det_streams[-1]) if det_streams else contextlib.nullcontext():
                     keep.append(ddet.compute_cross_correlogram_spectrocorr(r["filtered"], fs, [14., 30.], kernel, 0.8, 0.95))

@@ -172,7 +172,10 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
             mean, mx = _row_stats_cached(x)
         for i in range(0, len(taps_list), 2):                      # two templates per read of x
             grp = taps_list[i:i + 2]
-            ys = [torch.empty_like(x) for _ in grp]
+            # the correlograms of a fused pair sit back to back in one allocation: a consumer that treats both alike (envelope
+            # picks at one threshold) can take them as ONE [2 nx, ns] block (stacked_pair below) -- one launch per operator
+            pair = torch.empty((len(grp),) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            ys = [pair[k] for k in range(len(grp))]
             if how == "mm":
                 taps, lt, _, _ = _xf_prepared(grp, x.device, ws=False)
                 rm = [torch.empty(nx, dtype=torch.float32, device=x.device) for _ in grp] if row_max is not None else None
@@ -212,6 +215,16 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
                                          dev.stream_ptr(x)))
             outs.extend(ys)
     return outs
+
+
+def stacked_pair(c0, c1):
+    """The two correlograms of one fused correlator launch as ONE [2 nx, ns] tensor (no copy) when they sit back to back in one
+    allocation (what _xcorr_device produces for a template pair), else None.  Rows 0 .. nx-1 are c0's, nx .. 2 nx-1 are c1's."""
+    b0, b1 = getattr(c0, "_base", None), getattr(c1, "_base", None)
+    if (b0 is None or b0 is not b1 or b0.dim() != 3 or b0.shape[0] != 2 or not b0.is_contiguous() or c0.shape != c1.shape
+            or c0.data_ptr() != b0.data_ptr() or c1.data_ptr() != b0.data_ptr() + c0.numel() * c0.element_size()):
+        return None
+    return b0.view(2 * c0.shape[0], c0.shape[1])
 
 
 def correlogram_max(c, row_max=None, on_device=False):
