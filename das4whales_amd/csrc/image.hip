@@ -52,6 +52,29 @@ __global__ __launch_bounds__(kImThreads) void minmax_reduce(const float* __restr
     }
 }
 
+// small inputs (the per-row maxima a detection threshold is taken from: nx values): one workgroup, one launch
+__global__ __launch_bounds__(kImThreads) void minmax_small(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    __shared__ float red_lo[kImThreads / 64], red_hi[kImThreads / 64];
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t i = threadIdx.x; i < n; i += kImThreads) {
+        const float v = x[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = lo; red_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kImThreads / 64; ++w) { lo = fminf(lo, red_lo[w]); hi = fmaxf(hi, red_hi[w]); }
+        // through the same order-preserving keys as the three-launch form (what a NaN or a -0 turns into is the same)
+        out[0] = im_unkey(im_key(lo));
+        out[1] = im_unkey(im_key(hi));
+    }
+}
+
 __global__ void minmax_decode(unsigned* keys) {
     float* f = reinterpret_cast<float*>(keys);
     const float lo = im_unkey(keys[0]), hi = im_unkey(keys[1]);
@@ -309,6 +332,10 @@ extern "C" {
 
 int d4w_minmax_f32(const float* x, size_t n, float* minmax, void* stream) {
     if (!x || !minmax || n < 1) return fail(D4W_EINVAL, "bad argument");
+    if (n <= (size_t)64 * 1024) {                                 // (round 5: one launch instead of three)
+        D4W_LAUNCH(minmax_small, dim3(1), dim3(kImThreads), 0, stream, x, n, minmax);
+        return D4W_OK;
+    }
     unsigned* keys = reinterpret_cast<unsigned*>(minmax);
     D4W_LAUNCH(minmax_init, dim3(1), dim3(1), 0, stream, keys);
     // >= 4096 values per workgroup: every workgroup ends with two atomics on the same pair of words, and 4096 workgroups of

@@ -1652,9 +1652,9 @@ __global__ __launch_bounds__(kSpThreads) void pack_picks(const int* __restrict__
 constexpr int kOffThreads = 1024;
 __global__ __launch_bounds__(kOffThreads) void pick_offsets(const int* __restrict__ cnt, int nx, long long* __restrict__ off,
                                                             long long* __restrict__ summary) {
-    __shared__ long long part[kOffThreads];
+    __shared__ long long wsum[kOffThreads / 64];
     __shared__ int pmax[kOffThreads / 64];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nx + kOffThreads - 1) / kOffThreads;
     const int a = min(tid * per, nx), b = min(a + per, nx);
     long long s = 0;
@@ -1664,17 +1664,24 @@ __global__ __launch_bounds__(kOffThreads) void pick_offsets(const int* __restric
         s += c;
         m = max(m, c);
     }
-    part[tid] = s;
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
-    if ((tid & 63) == 0) pmax[tid >> 6] = m;
-    __syncthreads();
-    for (int o = 1; o < kOffThreads; o <<= 1) {            // Hillis-Steele over the thread sums
-        const long long v = (tid >= o) ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // inclusive scan of the threads' sums: inside a wave by shuffles, across the 16 waves through LDS (two barriers in all;
+    // the Hillis-Steele form over 1024 threads took twenty)
+    long long incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
     }
-    long long run = part[tid] - s;                         // exclusive prefix of this thread's rows
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) pmax[wave] = m;
+    __syncthreads();
+    long long before = 0, total = 0;
+    for (int w = 0; w < kOffThreads / 64; ++w) {
+        if (w < wave) before += wsum[w];
+        total += wsum[w];
+    }
+    long long run = before + incl - s;                     // exclusive prefix of this thread's rows
     for (int i = a; i < b; ++i) {
         run += cnt[i];
         off[i] = run;
@@ -1683,7 +1690,7 @@ __global__ __launch_bounds__(kOffThreads) void pick_offsets(const int* __restric
         int mm = 0;
         for (int w = 0; w < kOffThreads / 64; ++w) mm = max(mm, pmax[w]);
         summary[0] = mm;
-        summary[1] = part[kOffThreads - 1];
+        summary[1] = total;
     }
 }
 
