@@ -638,6 +638,12 @@ def main():
     ap.add_argument("--prune-eps", type=float, default=4e-6,
                     help="opt-in tail pruning threshold of the fk_hybrid_ninf_pruned block (relative to the mask maximum)")
     ap.add_argument("--stages", type=str, default="fk,mf", help="comma list of bp, fk, mf")
+    ap.add_argument("--api", type=str, default="public", choices=["public", "private"],
+                    help="'public' (default since round 6): the timed step is the package's PUBLIC calls -- dsp.bp_filt, "
+                         "dsp.fk_filter_filt(x, mask), detect.compute_cross_correlograms(y, [hf, lf]) with the full-length "
+                         "zero-padded templates the reference's scripts build (the DC tail of detect.py:158 included) -- i.e. "
+                         "exactly what the parity tests certify; 'private': the composition of rounds 1-5 (FkPlan.apply_stats + "
+                         "detect._xcorr_device on support-only templates, no tail term); the other one is timed beside it")
     ap.add_argument("--no-fused-stats", action="store_true",
                     help="matched-filter row statistics by a separate pass over the filtered block instead of the f-k epilogue")
     ap.add_argument("--shard", type=str, default="auto", choices=["auto", "replicas", "channel"],
@@ -714,7 +720,10 @@ def main():
     x = torch.randn((nx, ns), dtype=torch.float32, device=device, generator=gen)
     y = torch.empty_like(x)
     opts = [int(v) for v in args.plan.split(",")] if args.plan else None
-    plan = dw.dsp.FkPlan(nx, ns, opts=opts, device=device)
+    # the plan the public calls use for this shape and device (dsp.get_fk_plan); --plan builds a private one (private api only)
+    if opts is not None and args.api == "public":
+        raise SystemExit("--plan overrides need --api private (the public calls own their plan)")
+    plan = dw.dsp.FkPlan(nx, ns, opts=opts, device=device) if opts is not None else dw.dsp.get_fk_plan(nx, ns, device)
     # the mask of BASELINE's configs: dsp.fk_filter_design defaults (speed fan 1400/1450/3400/3500
     # m/s), designed on the device by the product's own design kernel
     mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)
@@ -731,7 +740,11 @@ def main():
     import scipy.signal as sps
     sos_bp = sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos")
 
-    def step():
+    # the full-length templates of the reference's scripts (scripts/main_mfdetect.py:64-69: zero beyond the call's duration)
+    tpl_full = [ddet.gen_template_fincall(time_ax, fs, 17.8, 28.8, 0.68), ddet.gen_template_fincall(time_ax, fs, 14.7, 21.8, 0.78)]
+    mask_pub = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs)      # the same design, handed to the public call every step
+
+    def step_private():
         cur = x
         if "bp" in stages:
             cur = ddsp._sosfiltfilt_device(cur, sos_bp, 51)
@@ -747,6 +760,28 @@ def main():
         if "mf" in stages:
             return ddet._xcorr_device(cur, tpl, normalize=True, stats=st)
         return cur
+
+    def step_public():
+        # the calls a notebook makes on a block that lives on the device (CUDA tensor in -> CUDA tensor out)
+        cur = x
+        if "bp" in stages:
+            cur = dw.dsp.bp_filt(cur, fs, 14.0, 30.0)
+        if "fk" in stages:
+            cur = dw.dsp.fk_filter_filt(cur, mask_pub)       # (the plan recognises the mask it folded last: no re-fold)
+        if "mf" in stages:
+            return dw.detect.compute_cross_correlograms(cur, tpl_full)
+        return cur
+
+    step = step_public if args.api == "public" else step_private
+    other = step_private if args.api == "public" else step_public
+
+    def timed_loop(fn, n):
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t_) / n * 1e3
 
     for _ in range(args.warmup):
         step()
@@ -769,6 +804,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     samples = float(nx) * ns
     value = samples * world / (dt / args.steps)
+    # the other composition on the same box, right behind the timed region (not part of `value`)
+    ms_other = None
+    if opts is None:
+        try:
+            other()
+            ms_other = timed_loop(other, max(3, args.steps // 2))
+        except Exception as e:                           # noqa: BLE001
+            ms_other = "failed: %r" % (e,)
 
     # per-stage / per-kernel timing with HIP events on the launch stream (torch's current stream
     # is the stream every d4w_* call is issued on), averaged over the same K steps
@@ -784,6 +827,10 @@ def main():
     acc = np.zeros(5)
     mf_how = ddet._xcorr_method(tpl, ns, "auto")        # the kernel the step's matched filter runs on ("mm" unless overridden)
     mf_k = {"mf_row_stats": 0.0, "mf_xcorr_mm": 0.0, "mf_xcorr_fft_fused": 0.0, "mf_xcorr_fft_blocks_1tpl": 0.0}
+    # the public step adds the zero-padded templates' DC tail inside the correlator (detect._tails_in_kernel): the kernel timed
+    # below is that launch
+    coefs = [ddet._tail_coef(t) for t in tpl_full]
+    mf_tails = coefs if (args.api == "public" and ddet._tails_in_kernel(tpl, coefs, ns, mf_how)) else None
     for _ in range(args.steps):
         if "bp" in stages:
             stage_ms["bp_sosfiltfilt"] = stage_ms.get("bp_sosfiltfilt", 0.0) + ev_time(
@@ -801,14 +848,17 @@ def main():
             src = y if "fk" in stages else x
             stage_ms["mf_xcorr" if fused else "mf_rowstats_xcorr"] = stage_ms.get(
                 "mf_xcorr" if fused else "mf_rowstats_xcorr", 0.0) + ev_time(
-                lambda: ddet._xcorr_device(src, tpl, normalize=True, stats=st))
+                lambda: ddet._xcorr_device(src, tpl, normalize=True, stats=st, tails=mf_tails))
             # the stage's kernels one by one: row_stats, the two-template matrix-core kernel the step runs (ONE launch), and
             # for reference the overlap-save FFT kernels of rounds 1-3 (fused two-template launch, one-template form)
             mean = torch.empty(nx, dtype=torch.float64, device=device)
             mx = torch.empty(nx, dtype=torch.float32, device=device)
             mf_k["mf_row_stats"] += ev_time(lambda: dw._lib.check(dw._lib.lib.d4w_row_stats_f32(
                 src.data_ptr(), nx, ns, mean.data_ptr(), mx.data_ptr(), torch.cuda.current_stream().cuda_stream)))
-            mf_k["mf_xcorr_mm"] += ev_time(lambda: ddet._xcorr_device(src, tpl, normalize=True, method="mm", stats=(mean, mx)))
+            mf_k["mf_xcorr_mm"] += ev_time(lambda: ddet._xcorr_device(src, tpl, normalize=True, method="mm", stats=(mean, mx), tails=mf_tails))
+            if mf_tails is not None:                    # the same launch without the tail term (the kernel of rounds 4-5), for reference
+                mf_k["mf_xcorr_mm_no_tail"] = mf_k.get("mf_xcorr_mm_no_tail", 0.0) + ev_time(
+                    lambda: ddet._xcorr_device(src, tpl, normalize=True, method="mm", stats=(mean, mx)))
             mf_k["mf_xcorr_fft_fused"] += ev_time(lambda: ddet._xcorr_device(src, tpl, normalize=False, method="fft"))
             one = 0.0
             for tp in tpl:
@@ -836,11 +886,14 @@ def main():
                 continue                     # not part of the step: two templates run as ONE fused launch
             if k == "mf_xcorr_fft_fused" and (len(tpl) != 2 or mf_how != "fft"):
                 continue                     # reference only unless D4W_XCORR_METHOD=fft puts it back into the step
+            if k == "mf_xcorr_mm_no_tail":
+                continue                     # reference only: the public step launches the kernel with the tail term
             cand[k] = kernel_ms[k]
         alg_bytes["mf_row_stats"] = 4.0 * samples
         alg_bytes["mf_xcorr_fft_blocks_1tpl"] = 8.0 * samples      # read the block, write one correlogram
         alg_bytes["mf_xcorr_fft_fused"] = 12.0 * samples           # read the block once, write two correlograms
         alg_bytes["mf_xcorr_mm"] = (4.0 + 4.0 * len(tpl)) * samples  # read the block once, write one correlogram per template
+        alg_bytes["mf_xcorr_mm_no_tail"] = alg_bytes["mf_xcorr_mm"]
     if "bp" in stages:
         cand["bp_sosfiltfilt"] = stage_ms["bp_sosfiltfilt"]
         alg_bytes["bp_sosfiltfilt"] = 8.0 * samples         # read once, write once
@@ -866,7 +919,11 @@ def main():
                 "kernel_ms": kernel_ms, "stage_ms": stage_ms}
     if "fk" in stages:
         fk_gbs = 24.0 * samples / (float(acc.sum()) * 1e-3) / 1e9
+        # two names for two numbers that are easy to mix up: fk_in_step_frac = the filter as the step runs it (with the row
+        # statistics in the last pass's epilogue when the matched filter follows; = fk_algorithmic_frac), fk_alone_frac = the
+        # same mask without that epilogue (= fk_classic.fk_algorithmic_frac, filled in below)
         roofline.update({"fk_algorithmic_GBps": fk_gbs, "fk_algorithmic_frac": fk_gbs / HBM_PEAK_GBS,
+                         "fk_in_step_frac": fk_gbs / HBM_PEAK_GBS, "fk_alone_frac": None,
                          "fk_only_samples_per_s": samples / (float(acc.sum()) * 1e-3),
                          "fk_live_wavenumber_rows": live_rows, "fk_order": main_order})
         def time_mask(m, **set_kw):
@@ -889,6 +946,7 @@ def main():
             # the step's own mask once more WITHOUT the row-statistics epilogue the matched filter asks of the last pass
             # (fk_algorithmic_frac above includes it): the f-k filter alone, like the blocks that follow
             roofline["fk_classic"] = time_mask(dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], dx, fs))
+            roofline["fk_alone_frac"] = roofline["fk_classic"]["fk_algorithmic_frac"]
             # a fully dense mask (nothing skipped) and the design every reference script uses,
             # hybrid_ninf_filter_design(1350, 1450, 3300, 3450, 14, 30) (scripts/main_mfdetect.py:46-47), exact and
             # with the opt-in tail pruning (rows whose folded gain stays below prune_eps * max are treated as dead)
@@ -923,6 +981,12 @@ def main():
                "config": {"workload": "%d channels x %d samples float32 per GPU, classic f-k fan mask "
                                       "(fk_filter_design defaults), stages %s, HF+LF fin-call templates"
                                       % (nx, ns, "+".join(stages)),
+                          "api": args.api,
+                          "api_note": ("the timed step is the public calls dsp.fk_filter_filt(x, mask) + detect.compute_cross_correlograms(y, "
+                                       "[hf, lf]) on full-length zero-padded templates (DC tail of detect.py:158 included)"
+                                       if args.api == "public" else
+                                       "the timed step is FkPlan.apply_stats + detect._xcorr_device on support-only templates (rounds 1-5)"),
+                          ("ms_per_step_private_composition" if args.api == "public" else "ms_per_step_public_calls"): ms_other,
                           "plan": plan.info(), "parallelism": "independent channel blocks x%d" % world},
                "roofline": roofline}
         if world == 1 and not args.no_cpu:

@@ -7,8 +7,14 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# D4W_LIB: another build of the same library (probe builds with extra instrumentation, scripts/probe/fp_timing.sh)
-LIB_PATH = os.environ.get("D4W_LIB") or os.path.join(_HERE, "lib", "libd4w.so")
+_PACKAGED = os.path.join(_HERE, "lib", "libd4w.so")
+# D4W_LIB: another build of the same library (probe builds with extra instrumentation, scripts/probe/fp_timing.sh).  Never
+# silently: a variable left over from a probe session would make every result come from that build.
+LIB_PATH = os.environ.get("D4W_LIB") or _PACKAGED
+if os.path.abspath(LIB_PATH) != os.path.abspath(_PACKAGED):
+    import warnings
+    warnings.warn("das4whales_amd: D4W_LIB=%s replaces the packaged library %s for this process" % (LIB_PATH, _PACKAGED),
+                  RuntimeWarning, stacklevel=2)
 
 D4W_OK = 0
 _ERRORS = {-1: ValueError, -2: MemoryError, -3: RuntimeError}
@@ -98,6 +104,11 @@ def _load():
                                      c_int, c_int, c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_mm_rowmax_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "d4w_xcorr_mm_tail_max_support": (c_int, []),
+        "d4w_xcorr_mm_tail_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),
+        "d4w_xcorr_mm_tail_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                          c_int, c_int, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
         "d4w_xcorr_fft_max_support": (c_int, []),
         "d4w_xcorr_fft_ws_bytes": (ctypes.c_size_t, []),
         "d4w_xcorr_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

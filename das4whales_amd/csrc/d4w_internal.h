@@ -26,8 +26,12 @@ inline thread_local char g_err[512] = "";
 // every one); the
 // fence is what makes the results safe: a launch of one family first waits (on the device) for the last launch of the
 // other, whichever stream that was on.
-// Nothing changes on one stream.
-//   hazard_enter(self, stream) ... launches ... hazard_leave(self, stream);   self: 0 = overlap-save FFT kernels, 1 = stft_mm
+// Nothing changes on one stream.  hazard_enter returns HOLDING the fence's host mutex and hazard_leave releases it: wait, launches
+// and record are one critical section (two host threads cannot both pass the wait before either has recorded).  Limits: the
+// fence is per process (two processes that share one GPU are not ordered against each other: give each process its own GPU,
+// as every launcher of this package does) and knows the devices 0..63 (beyond: the call fails).
+//   rc = hazard_enter(self, stream); if (rc) return rc; ... launches ...; hazard_leave(self, stream);   (always paired)
+//   self: 0 = overlap-save FFT kernels, 1 = stft_mm
 int hazard_enter(int self, void* stream);
 int hazard_leave(int self, void* stream);
 

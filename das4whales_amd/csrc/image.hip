@@ -26,6 +26,11 @@ __device__ __forceinline__ float im_unkey(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// quiet NaN with the sign bit clear (its key is the largest there is; the negated one's the smallest)
+__device__ __forceinline__ float kImNaN() { return __uint_as_float(0x7FC00000u); }
+__device__ __forceinline__ float im_nanmin(float a, float b) { return (a != a) ? a : (b != b) ? b : fminf(a, b); }
+__device__ __forceinline__ float im_nanmax(float a, float b) { return (a != a) ? a : (b != b) ? b : fmaxf(a, b); }
+
 __global__ void minmax_init(unsigned* keys) {
     keys[0] = 0xffffffffu;
     keys[1] = 0u;
@@ -34,20 +39,25 @@ __global__ void minmax_init(unsigned* keys) {
 __global__ __launch_bounds__(kImThreads) void minmax_reduce(const float* __restrict__ x, size_t n, unsigned* keys) {
     __shared__ float red_lo[kImThreads / 64], red_hi[kImThreads / 64];
     float lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
     for (size_t i = (size_t)blockIdx.x * kImThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kImThreads) {
         const float v = x[i];
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
+        bad |= (v != v);
     }
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
-    if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = lo; red_hi[threadIdx.x >> 6] = hi; }
+    // np.min / np.max propagate NaN (fminf / fmaxf drop it): a NaN anywhere makes both results NaN
+    bad = __any(bad) != 0;
+    if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = bad ? -kImNaN() : lo; red_hi[threadIdx.x >> 6] = bad ? kImNaN() : hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kImThreads / 64; ++w) { lo = fminf(lo, red_lo[w]); hi = fmaxf(hi, red_hi[w]); }
-        atomicMin(&keys[0], im_key(lo));
+        lo = red_lo[0]; hi = red_hi[0];
+        for (int w = 1; w < kImThreads / 64; ++w) { lo = im_nanmin(lo, red_lo[w]); hi = im_nanmax(hi, red_hi[w]); }
+        atomicMin(&keys[0], im_key(lo));                 // (-NaN has the smallest key, +NaN the largest: either one sticks)
         atomicMax(&keys[1], im_key(hi));
     }
 }
@@ -56,19 +66,24 @@ __global__ __launch_bounds__(kImThreads) void minmax_reduce(const float* __restr
 __global__ __launch_bounds__(kImThreads) void minmax_small(const float* __restrict__ x, size_t n, float* __restrict__ out) {
     __shared__ float red_lo[kImThreads / 64], red_hi[kImThreads / 64];
     float lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
     for (size_t i = threadIdx.x; i < n; i += kImThreads) {
         const float v = x[i];
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
+        bad |= (v != v);
     }
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
-    if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = lo; red_hi[threadIdx.x >> 6] = hi; }
+    // np.min / np.max propagate NaN (fminf / fmaxf drop it): a NaN anywhere makes both results NaN
+    bad = __any(bad) != 0;
+    if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = bad ? -kImNaN() : lo; red_hi[threadIdx.x >> 6] = bad ? kImNaN() : hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kImThreads / 64; ++w) { lo = fminf(lo, red_lo[w]); hi = fmaxf(hi, red_hi[w]); }
+        lo = red_lo[0]; hi = red_hi[0];
+        for (int w = 1; w < kImThreads / 64; ++w) { lo = im_nanmin(lo, red_lo[w]); hi = im_nanmax(hi, red_hi[w]); }
         // through the same order-preserving keys as the three-launch form (what a NaN or a -0 turns into is the same)
         out[0] = im_unkey(im_key(lo));
         out[1] = im_unkey(im_key(hi));

@@ -87,9 +87,13 @@ static inline int mm_num_cus() {
 // *p = max(*p, v) for floats with the two native integer atomics (no float max atomic on this part; no compare-and-swap
 // loop): a non-negative v orders like its bits as a signed integer, a negative one like the REVERSE of its bits as an
 // unsigned integer, and a non-negative value always beats the bit pattern of a negative one in either view.  *p starts at -inf.
+// A NaN enters as the quiet-NaN pattern 0x7FC00000 and STAYS (np.max propagates NaN): as a signed integer it beats every
+// non-negative float and every negative one's pattern; as an unsigned integer it lies below every negative float's pattern,
+// so the later atomicMin of a negative value leaves it alone.
 __device__ __forceinline__ void mm_atomic_fmax(float* p, float v) {
     if (v >= 0.f) atomicMax(reinterpret_cast<int*>(p), __float_as_int(v + 0.f));      // -0 enters as +0
     else if (v == v) atomicMin(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+    else atomicMax(reinterpret_cast<int*>(p), 0x7FC00000);
 }
 
 // v = hi + lo / 2048 to 22-23 significant bits.  v is pinned to ONE float32 value first: left alone, hipcc contracts the
@@ -101,6 +105,43 @@ __device__ __forceinline__ void mm_split(float v, mm_half& hi, mm_half& lo) {
 #endif
     hi = mm_to_half(v);
     lo = mm_to_half((v - mm_to_float(hi)) * kMmLoScale);
+}
+
+// Four consecutive samples split and stored: ph[0..3] = hi, pl[0..3] = lo (8-byte LDS stores).  The same values as four
+// mm_split calls, in 10 vector instructions instead of 20 (plus the waits the partial writes ask for) (round 6: the conversion phase of xcorr_mm_rows is a third of that
+// kernel's time): v_cvt_pk_f16_f32 rounds two samples into one packed register, and v_fma_mixlo / mixhi_f16 form
+// rn16(fma(hi, -2048, 2048 v)) = rn16((v - hi) 2048) straight from the binary16 half they read (both products are exact, so
+// this is the residual of mm_split bit for bit) into the two halves of the packed lo register -- no float32 copy of hi, no
+// separate subtract / multiply / convert / pack.  (s_nop: a partial register write must not be followed at once by a reader.)
+__device__ __forceinline__ void mm_split_put4(const float (&v)[4], mm_half* ph, mm_half* pl) {
+#ifdef D4W_EMU
+    mm_half h[4], l[4];
+    for (int e = 0; e < 4; ++e) mm_split(v[e], h[e], l[e]);
+    mm_put4(ph, h);
+    mm_put4(pl, l);
+#else
+    const float m = -kMmLoScale;
+    auto pair = [&](float a, float b, unsigned& h, unsigned& l) {      // two samples per block: few registers live at once
+        const float ka = a * kMmLoScale, kb = b * kMmLoScale;
+        asm volatile(
+            "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+            "s_nop 0\n\t"
+            "v_fma_mixlo_f16 %1, %0, %6, %4 op_sel_hi:[1,0,0]\n\t"
+            "s_nop 0\n\t"
+            "v_fma_mixhi_f16 %1, %0, %6, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(h), "=&v"(l)
+            : "v"(a), "v"(b), "v"(ka), "v"(kb), "s"(m));
+    };
+    unsigned h01, h23, l01, l23;
+    pair(v[0], v[1], h01, l01);
+    pair(v[2], v[3], h23, l23);
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    u2_t hv, lv;
+    hv.x = h01; hv.y = h23; lv.x = l01; lv.y = l23;
+    *reinterpret_cast<u2_t*>(ph) = hv;
+    *reinterpret_cast<u2_t*>(pl) = lv;
+#endif
 }
 
 // power of two >= a (a >= 0, finite): the scale that keeps a block of values inside [-1, 1] without rounding them

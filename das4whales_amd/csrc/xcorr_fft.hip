@@ -1089,32 +1089,46 @@ using namespace d4w;
 #include <mutex>
 namespace d4w {
 namespace {
+constexpr int kHzMaxDev = 64;
 std::mutex g_hz_mu;
-hipEvent_t g_hz_ev[16][2];          // [device][family]: recorded behind the family's last launch
-bool g_hz_have[16][2];
-}
-int hazard_enter(int self, void* stream) {
+hipEvent_t g_hz_ev[kHzMaxDev][2];   // [device][family]: recorded behind the family's last launch
+bool g_hz_have[kHzMaxDev][2];
+bool hazard_on() {
     static const int on = [] { const char* v = getenv("D4W_HAZARD_FENCE"); return v ? atoi(v) : 1; }();
-    if (!on) return D4W_OK;
+    return on != 0;
+}
+}
+// ONE critical section from the wait to the record: hazard_enter returns with the mutex held (unless it fails), hazard_leave
+// records the family's event behind the launches and releases it.  Two host threads can therefore not both pass the wait
+// before either has recorded -- the gap the round-5 form had: thread A waits on B's (not yet recorded) event,
+// thread B waits on A's, both launch, the two families run side by side.
+int hazard_enter(int self, void* stream) {
+    if (!hazard_on()) return D4W_OK;
     int devid = 0;
     D4W_HIP(hipGetDevice(&devid));
-    if (devid < 0 || devid >= 16) return D4W_OK;
-    std::lock_guard<std::mutex> lk(g_hz_mu);
-    if (g_hz_have[devid][1 - self]) D4W_HIP(hipStreamWaitEvent((hipStream_t)stream, g_hz_ev[devid][1 - self], 0));
+    if (devid < 0 || devid >= kHzMaxDev)
+        return fail(D4W_EINVAL, "device %d is beyond the %d devices the cross-stream fence keeps events for", devid, kHzMaxDev);
+    g_hz_mu.lock();
+    if (g_hz_have[devid][1 - self]) {
+        const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, g_hz_ev[devid][1 - self], 0);
+        if (e != hipSuccess) {
+            g_hz_mu.unlock();
+            return fail(D4W_EHIP, "hipStreamWaitEvent failed: %s (cross-stream fence)", hipGetErrorString(e));
+        }
+    }
     return D4W_OK;
 }
 int hazard_leave(int self, void* stream) {
-    static const int on = [] { const char* v = getenv("D4W_HAZARD_FENCE"); return v ? atoi(v) : 1; }();
-    if (!on) return D4W_OK;
+    if (!hazard_on()) return D4W_OK;
     int devid = 0;
-    D4W_HIP(hipGetDevice(&devid));
-    if (devid < 0 || devid >= 16) return D4W_OK;
-    std::lock_guard<std::mutex> lk(g_hz_mu);
-    if (!g_hz_have[devid][self]) {
-        D4W_HIP(hipEventCreateWithFlags(&g_hz_ev[devid][self], hipEventDisableTiming));
-        g_hz_have[devid][self] = true;
+    hipError_t e = hipGetDevice(&devid);
+    if (e == hipSuccess && !g_hz_have[devid][self]) {
+        e = hipEventCreateWithFlags(&g_hz_ev[devid][self], hipEventDisableTiming);
+        g_hz_have[devid][self] = (e == hipSuccess);
     }
-    D4W_HIP(hipEventRecord(g_hz_ev[devid][self], (hipStream_t)stream));
+    if (e == hipSuccess) e = hipEventRecord(g_hz_ev[devid][self], (hipStream_t)stream);
+    g_hz_mu.unlock();
+    if (e != hipSuccess) return fail(D4W_EHIP, "cross-stream fence: %s", hipGetErrorString(e));
     return D4W_OK;
 }
 }  // namespace d4w

@@ -76,28 +76,112 @@ struct MmArgs {
     int nx, ns, ld_next, n_next, ltaps, len0, len1;
     float* rowmax0;         // [nx] or NULL: max over the lags of every row of y0 (y1), formed in the epilogue (float bits,
     float* rowmax1;         //   initialised to -inf by the host; combined with integer atomics, mm_atomic_fmax)
+    int clamp;              // scaled samples are clamped into binary16's finite range before the split (continuations, D4W_MM_CLAMP=1)
     int shift;              // the taps given are taps [shift, shift + len0) of a longer template: lag k reads x[k + shift + n]
     int accumulate;         // add to y0 instead of overwriting it (the later sections of a long template)
+    // TAIL kernels (the zero-padded template's constant tail, detect.py:158, added in the epilogue -- see xcorr_mm_rows):
+    float tail0, tail1;             // mean(t) / max|t| of template 0 / 1 over its zero-padded length (0: nothing to add)
+    unsigned long long* gran;       // [nx][chunks per row] {tag << 32 | float bits}: every chunk's normalised de-meaned sum
+    int* tickets;                   // [8] next chunk of each XCD range (gran and tickets are zeroed by the host per launch)
 };
 
-// KS0 / KS1: k-steps of template 0 / 1 (KS1 = 0: one template); WPS: workgroups per compute unit the registers are budgeted for
-template <int KS0, int KS1, int WPS>
+// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside the 16-lane DPP rows, then row_bcast:15 /
+// row_bcast:31 carry the row totals on (six v_add_f32 with DPP operands, no LDS traffic)
+__device__ __forceinline__ float mm_wave_scan(float v) {
+#ifdef D4W_EMU
+    const int lane = (int)(threadIdx.x & 63);
+    for (int off = 1; off < 64; off <<= 1) {
+        const float n = __shfl_up(v, (unsigned)off);
+        if (lane >= off) v += n;
+    }
+    return v;
+#else
+    auto dpp = [](float x, auto ctrl, auto rmask) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});      // row_shr:1
+    v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});      // row_shr:2
+    v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});      // row_shr:4
+    v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});      // row_shr:8
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});      // row_bcast:15 -> rows 1, 3
+    v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});      // row_bcast:31 -> rows 2, 3
+    return v;
+#endif
+}
+
+// the 8-byte granule {tag, float}: ONE relaxed agent-scope store / load each (global_store / global_load_dwordx2 sc1: written
+// through, read past the L1), so a reader sees either the zero the host left or the complete pair -- no fence, nothing else
+// is handed over (MI355X guide: granule hand-off)
+__device__ __forceinline__ void mm_gran_store(unsigned long long* p, float v) {
+    const unsigned long long g = (1ull << 32) | (unsigned long long)__float_as_uint(v);
+#ifdef D4W_EMU
+    *p = g;
+#else
+    __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ unsigned long long mm_gran_load(const unsigned long long* p) {
+#ifdef D4W_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+// KS0 / KS1: k-steps of template 0 / 1 (KS1 = 0: one template); WPS: workgroups per compute unit the registers are budgeted for.
+//
+// TAIL: the kernel also adds the constant tail of the de-meaned ZERO-PADDED template (detect.py:158 normalises the template over
+// its padded length, which leaves -mean(t) / max|t| on the padding): lag k receives  tail_t * P[k + L_t],  P[j] = sum_{i < j} xh[i]
+// the prefix sum of the normalised row, for k + L_t < ns (L_t a multiple of 4: the host extends the support by the padding's
+// own value).  Rounds 1-5 added the term in a second pass over x and y, decided per row on prefix maxima from a third sweep
+// (d4w_row_stats_prefix_f32, d4w_xcorr_dc_tail_rows_f32): the public call cost 1.5 x the kernel.  Here it is exact for every
+// row at no extra pass:
+//   * the conversion phase already holds every sample of the chunk: a wave prefix scan (DPP) of the scaled samples goes to
+//     LDS beside the binary16 halves (local prefix per 256-thread segment + the segments' offsets), and the epilogue reads
+//     P[k + L] for its four lags with one 16-byte LDS read per template;
+//   * the prefix at the chunk's START is the sum of the row's earlier chunks, which other workgroups hold: every workgroup
+//     PUBLISHES its chunk's sum as an 8-byte {tag, value} granule right after its conversion (before it waits for anything)
+//     and, when its first tile is done, reads the granules of the row's earlier chunks (a spin only if one is late);
+//   * chunks are CLAIMED from a ticket counter per XCD range instead of being dealt statically, two chunks ahead: a chunk
+//     is then only ever held by a RUNNING workgroup and waits point to smaller chunk numbers only, so the scheme cannot
+//     deadlock whatever part of the grid is resident (a neighbour kernel may hold compute units).  Summation orders are
+//     fixed (per lane, DPP tree, segment order, xor tree over the granules): results do not depend on timing.
+template <int KS0, int KS1, int WPS, bool TAIL = false>
 __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     constexpr int KSM = KS0 > KS1 ? KS0 : KS1;
     using GEO = MmGeom<KSM>;
     constexpr int kMmHalo = GEO::Halo, kMmStage = GEO::Stage, kMmQ = GEO::Q, kMmLastQ = GEO::LastQ, kMmArr = GEO::Arr;
+    constexpr int kSeg = 4 * kMmQ;                                  // 256-thread segments of a stage (1024 samples each), <= 20
     D4W_DYN_LDS(smem_raw);
     mm_half* lds = reinterpret_cast<mm_half*>(smem_raw);           // [2 buffers][hi | lo][kMmArr]
     float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [2][4] chunk maxima of the waves
+    float* pl = red + 8;                                            // TAIL: [2][kMmArr] prefix sums inside a wave's segment
+    float* wt = pl + 2 * kMmArr;                                    // TAIL: [2][kSeg] the segments' totals
+    float* wo = wt + 2 * kSeg;                                      // TAIL: [4 waves][kSeg] prefix at each segment's start
+    int* tkl = reinterpret_cast<int*>(wo + 4 * kSeg);               // TAIL: [2] tickets on their way from thread 0 to the workgroup
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = mm_uniform(tid >> 6);
     const int n16 = lane & 15, g = lane >> 4;
     const int ns = P.ns;
 
+    // ---- the chunks of this workgroup: XCD j (workgroup id mod 8) owns the contiguous range [j T / 8, (j + 1) T / 8)
+    const int nchunk = (ns + kMmCH - 1) / kMmCH;
+    const long long total = (long long)P.nx * nchunk;
+    const int nparts = min(8, (int)gridDim.x);
+    const int xcd = (int)blockIdx.x % nparts, wq = (int)blockIdx.x / nparts, nq = ((int)gridDim.x - xcd + nparts - 1) / nparts;
+    const long long lo_c = total * xcd / nparts, hi_c = total * (xcd + 1) / nparts;
+    if constexpr (TAIL) {
+        if (tid == 0) {                                             // the first two claims (their latency hides under the fragment build)
+            tkl[0] = atomicAdd(P.tickets + xcd, 1);
+            tkl[1] = atomicAdd(P.tickets + xcd, 1);
+        }
+    }
+
     // ---- the templates' Toeplitz fragments: A_t[kk][i = n16][u = 32 kk + 8 g + j] = t[u - i] / ts_t, split hi / lo
     mm_h8 a0h[KS0], a0l[KS0];
     mm_h8 a1h[KS1 ? KS1 : 1], a1l[KS1 ? KS1 : 1];
     float osc0 = 1.f, osc1 = 1.f;                                   // output scales: the power of two taken out of the taps
+    long long c_n = lo_c + wq, c_nn = 0;
     {
         // taps -> LDS first (zero outside the support), so that the 8 x KS fragment values of a lane are LDS reads
         float* tl = reinterpret_cast<float*>(smem_raw);              // [2][16 + kMmHalo] before the row buffers are in use
@@ -131,22 +215,18 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         };
         build(tl, P.len0, a0h, a0l, std::integral_constant<int, KS0>{}, osc0);
         if constexpr (KS1 > 0) build(tl + TLP, P.len1, a1h, a1l, std::integral_constant<int, KS1>{}, osc1);
+        if constexpr (TAIL) {                                       // (tkl lies beyond the tap staging area: thread 0's claims are visible now)
+            c_n = lo_c + mm_uniform(tkl[0]);
+            c_nn = lo_c + mm_uniform(tkl[1]);
+        }
         __syncthreads();                                            // the row buffers take this space over
     }
-
-    // ---- the chunks of this workgroup: XCD j (workgroup id mod 8) owns the contiguous range [j T / 8, (j + 1) T / 8)
-    const int nchunk = (ns + kMmCH - 1) / kMmCH;
-    const long long total = (long long)P.nx * nchunk;
-    const int nparts = min(8, (int)gridDim.x);
-    const int xcd = (int)blockIdx.x % nparts, wq = (int)blockIdx.x / nparts, nq = ((int)gridDim.x - xcd + nparts - 1) / nparts;
-    const long long lo_c = total * xcd / nparts, hi_c = total * (xcd + 1) / nparts;
 
     float4 pre[kMmQ];                                               // the chunk being loaded (raw samples)
     Mean2 mu_n{0.f, 0.f};                                           // its row's mean (hi + lo) ...
     float g_n = 1.f;                                                // ... and 1 / maxabs
     bool heavy_n = false;                                           // the row is (nearly) all offset: scale it chunk by chunk
     bool tail_n = false;                                            // the chunk reaches beyond the row (wave-uniform)
-    long long c_n = lo_c + wq;
     int row_n = 0, c0_n = 0;
 
     auto issue = [&](long long c) {                                 // global loads of chunk c into pre[]
@@ -216,7 +296,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     if (c_n < hi_c) issue(c_n);
     int buf = 0;
     const bool want_max = P.rowmax0 != nullptr;                     // kernel argument: a scalar branch
-    for (long long c = c_n; c < hi_c; c += nq) {
+    bool dead = false;                                              // TAIL: a granule never arrived (outputs poisoned from there on, no further waits)
+    for (long long c = c_n; c < hi_c;) {
         const int row = row_n, c0 = c0_n;
         const Mean2 mu = mu_n;
         const bool tail = tail_n;
@@ -226,6 +307,12 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool own_scale = !P.maxabs || heavy_n;                // wave- and workgroup-uniform (one row per chunk)
         mm_half* bh = lds + (size_t)buf * 2 * kMmArr;
         mm_half* bl = bh + kMmArr;
+        // the chunk after the next one: thread 0 asks for its ticket now, the workgroup learns it behind this chunk's barrier
+        int tk_new = 0;
+        const long long c_next = TAIL ? c_nn : c + nq;
+        if constexpr (TAIL) {
+            if (tid == 0) tk_new = atomicAdd(P.tickets + xcd, 1);
+        }
         // ---- convert the loaded chunk: (x - mu) * scale -> hi / lo halves in LDS
         if (own_scale) {
             // no row maximum from the caller, or a row that is all offset: this chunk's own power of two.  (With a row maximum the rows are scaled by
@@ -254,27 +341,40 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             m = fmaxf(fmaxf(red[4 * buf], red[4 * buf + 1]), fmaxf(red[4 * buf + 2], red[4 * buf + 3]));
             mm_pow2_scale(m, osx, gsc);
         }
+        const float mlg = -mu.lo * gsc;
         static_for<kMmQ>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
-            if (q < kMmQ - 1 || tid < kMmLastQ) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            const bool mine = q < kMmQ - 1 || tid < kMmLastQ;
+            const int at = mm_pidx(4 * (tid + q * kMmThreads));
+            if (mine) {
                 const float4 v = pre[q];
-                float s[4] = {demean(v.x, mu) * gsc, demean(v.y, mu) * gsc, demean(v.z, mu) * gsc, demean(v.w, mu) * gsc};
-                // caller-supplied statistics (or the next file's head) may leave |v| beyond binary16's range: inf - inf would turn
-                // a whole tile into NaN where the float32 forms stay finite; the clamp is one v_med3_f32
-                if (!own_scale) static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; s[e] = mm_clamp_half(s[e]); });
+                // ((x - hi) - lo) g as (x - hi) g - lo g: the two-float mean at the instruction count of a float32 one (x - hi is
+                // exact where the offset dominates, the product is rounded once)
+                s[0] = fmaf(v.x - mu.hi, gsc, mlg); s[1] = fmaf(v.y - mu.hi, gsc, mlg); s[2] = fmaf(v.z - mu.hi, gsc, mlg); s[3] = fmaf(v.w - mu.hi, gsc, mlg);
+                // the next file's head (or statistics that are not the rows' own, D4W_MM_CLAMP=1) may leave |v| beyond binary16's
+                // range: inf - inf would turn a whole tile into NaN where the float32 forms stay finite; one v_med3_f32 per
+                // sample, only where asked for (a kernel argument: a scalar branch)
+                if (P.clamp && !own_scale) static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; s[e] = mm_clamp_half(s[e]); });
                 if (tail) {                                          // beyond the data: the zero padding of the correlation
                     const int a0 = 4 * (tid + q * kMmThreads);
                     static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; if (a0 + e >= n_valid) s[e] = 0.f; });
                 }
-                mm_half h[4], l[4];
-                static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
-                const int at = mm_pidx(4 * (tid + q * kMmThreads));
-                mm_put4(bh + at, h);
-                mm_put4(bl + at, l);
+                mm_split_put4(s, bh + at, bl + at);
+            }
+            if constexpr (TAIL) {
+                // prefix sums of the scaled samples inside this wave's segment (every lane takes part: the idle ones add zeros)
+                const float p1 = s[0], p2 = s[0] + s[1], p3 = p2 + s[2], t4 = p3 + s[3];
+                const float inc = mm_wave_scan(t4), exc = inc - t4;
+                if (mine) *reinterpret_cast<float4*>(pl + (size_t)buf * kMmArr + at) = make_float4(exc, exc + p1, exc + p2, exc + p3);
+                if (lane == 63) wt[buf * kSeg + 4 * q + wv] = inc;
             }
         });
         // ---- next chunk's loads fly across the barrier and the matrix phase
-        if (c + nq < hi_c) issue(c + nq);
+        if (c_next < hi_c) issue(c_next);
+        if constexpr (TAIL) {
+            if (tid == 0) tkl[buf] = tk_new;
+        }
         lds_barrier();
         // ---- 16 tiles of 256 lags, 4 per wave: C[i][a] (+)= A[i][u] B[u][a]
         float* ya = P.y0 + (size_t)row * ns;
@@ -282,6 +382,22 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
         const float oxs = (own_scale && P.maxabs) ? osx * gout : osx;
         const float o0 = osc0 * oxs, o1 = osc1 * oxs;
+        // TAIL: the segments' start offsets (this wave's own table), the chunk's sum published, the earlier chunks' granules asked for
+        const int cin = c0 / kMmCH;                                 // the chunk's number inside its row
+        unsigned long long gv = 0ull;
+        float pst = 0.f;                                            // prefix of the normalised row at the chunk's first sample
+        const float* plb = pl + (size_t)buf * kMmArr;
+        const float* wob = wo + wv * kSeg;
+        if constexpr (TAIL) {
+            c_nn = lo_c + mm_uniform(tkl[buf]);
+            const float w = lane < kSeg ? wt[buf * kSeg + lane] : 0.f;
+            const float inc = mm_wave_scan(w);
+            if (lane < kSeg) wo[wv * kSeg + lane] = inc - w;
+            if (wv == 0 && lane == 15)                              // samples 0 .. 4095 of the stage = segments 0 .. 15: the chunk's own samples
+                mm_gran_store(P.gran + (size_t)row * nchunk + cin, inc * oxs);
+            mm_wave_sync();
+            if (lane < min(cin, 64)) gv = mm_gran_load(P.gran + (size_t)row * nchunk + lane);
+        }
         // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
         // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
         // so an LDS round trip hides under 12 matrix instructions instead of stalling the wave at every k-step
@@ -298,6 +414,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         });
         mm_f4 c0h = mm_zero(), c0l = mm_zero(), c1h = mm_zero(), c1l = mm_zero();
         float vmax0 = -INFINITY, vmax1 = -INFINITY;                 // this lane's largest stored value of the chunk
+        float vsum = 0.f;                                           // ... and a sum that is NaN when any stored value was (np.max propagates NaN)
         static_for<NST>([&](auto ss) {
             constexpr int s_ = decltype(ss)::value, ti = s_ / KSM, kk = s_ % KSM;
             if constexpr (s_ + PF < NST) {
@@ -319,7 +436,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             mm_sched_fence();
             if constexpr (kk == KSM - 1) {                          // the tile is complete: scale, combine, stream out
                 const int T = wv + 4 * ti;
-                const int k = c0 + 256 * T + 16 * n16 + 4 * g;      // this lane's four lags
+                const int kl = 256 * T + 16 * n16 + 4 * g;          // this lane's four lags inside the chunk ...
+                const int k = c0 + kl;                              // ... and inside the row
                 float r0[4], r1[4];
                 static_for<4>([&](auto rr) {
                     constexpr int r = decltype(rr)::value;
@@ -327,6 +445,46 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                     if constexpr (KS1 > 0) r1[r] = fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)) * o1;
                 });
                 c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
+                if constexpr (TAIL) {
+                    if constexpr (ti == 0) {
+                        // the row's earlier chunks: their sums were published before their workgroups waited for anything, and
+                        // they were claimed before this chunk -- normally all here by now; a late one is polled (bounded: a
+                        // granule that never arrives poisons the outputs instead of hanging the device)
+                        if (cin > 0) {
+                            for (int base = 0; base < cin; base += 64) {
+                                const int n = min(cin - base, 64);
+                                unsigned long long gq = (base == 0) ? gv : 0ull;
+                                int spins = 0;
+                                while (true) {
+                                    const bool ok = lane >= n || (unsigned)(gq >> 32) == 1u;
+                                    if (__all(ok)) break;
+                                    if (dead || ++spins > (1 << 20)) { dead = true; gq = (1ull << 32) | 0x7FC00000ull; break; }
+#ifndef D4W_EMU
+                                    __builtin_amdgcn_s_sleep(4);
+#endif
+                                    if (!ok) gq = mm_gran_load(P.gran + (size_t)row * nchunk + base + lane);
+                                }
+                                float v = lane < n ? __uint_as_float((unsigned)gq) : 0.f;
+                                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                                pst += v;
+                            }
+                        }
+                    }
+                    auto add_tail = [&](float (&r)[4], float tc, int L) {
+                        if (tc != 0.f) {                             // kernel argument: a scalar branch
+                            const int idx = kl + L;                  // L % 4 == 0: the four prefixes are one 16-byte word of one segment
+                            const float4 pv = *reinterpret_cast<const float4*>(plb + idx);
+                            const float base = fmaf(wob[idx >> 8], oxs, pst);
+                            const float t0 = fmaf(pv.x, oxs, base), t1 = fmaf(pv.y, oxs, base), t2 = fmaf(pv.z, oxs, base), t3 = fmaf(pv.w, oxs, base);
+                            if (k + L < ns) r[0] = fmaf(tc, t0, r[0]);
+                            if (k + 1 + L < ns) r[1] = fmaf(tc, t1, r[1]);
+                            if (k + 2 + L < ns) r[2] = fmaf(tc, t2, r[2]);
+                            if (k + 3 + L < ns) r[3] = fmaf(tc, t3, r[3]);
+                        }
+                    };
+                    add_tail(r0, P.tail0, P.len0);
+                    if constexpr (KS1 > 0) add_tail(r1, P.tail1, P.len1);
+                }
                 if (valign && k + 3 < ns) {
                     if (KS1 == 0 && P.accumulate) {                 // a later section of a long template
                         const float4 o = mm_load4_stream(reinterpret_cast<const float4*>(ya + k));
@@ -336,7 +494,11 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                     if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
                     if (want_max) {
                         vmax0 = fmaxf(vmax0, fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));
-                        if constexpr (KS1 > 0) vmax1 = fmaxf(vmax1, fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
+                        vsum += (r0[0] + r0[1]) + (r0[2] + r0[3]);
+                        if constexpr (KS1 > 0) {
+                            vmax1 = fmaxf(vmax1, fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
+                            vsum += (r1[0] + r1[1]) + (r1[2] + r1[3]);
+                        }
                     }
                 } else {                                            // a row end or an unaligned row (tiles beyond the row: nothing)
                     for (int r = 0; r < 4; ++r)
@@ -346,7 +508,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                             if constexpr (KS1 > 0) yb[k + r] = r1[r];
                             if (want_max) {
                                 vmax0 = fmaxf(vmax0, v0);
-                                if constexpr (KS1 > 0) vmax1 = fmaxf(vmax1, r1[r]);
+                                vsum += v0;
+                                if constexpr (KS1 > 0) { vmax1 = fmaxf(vmax1, r1[r]); vsum += r1[r]; }
                             }
                         }
                 }
@@ -357,12 +520,17 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 vmax0 = fmaxf(vmax0, __shfl_xor(vmax0, o));
                 if constexpr (KS1 > 0) vmax1 = fmaxf(vmax1, __shfl_xor(vmax1, o));
             }
+            // a NaN among the stored values: the row's maximum is NaN, as np.max has it (fmaxf drops NaN; the sum does not -- it
+            // is also NaN for a chunk that holds +inf and -inf, where a NaN maximum is no loss).  Both templates read the same
+            // samples, so a NaN in one is a NaN in the other.
+            const bool bad = __any(vsum != vsum);
             if (lane == 0) {
-                mm_atomic_fmax(P.rowmax0 + row, vmax0);
-                if constexpr (KS1 > 0) mm_atomic_fmax(P.rowmax1 + row, vmax1);
+                mm_atomic_fmax(P.rowmax0 + row, bad ? __uint_as_float(0x7FC00000u) : vmax0);
+                if constexpr (KS1 > 0) mm_atomic_fmax(P.rowmax1 + row, bad ? __uint_as_float(0x7FC00000u) : vmax1);
             }
         }
         buf ^= 1;
+        c = c_next;
     }
 }
 
@@ -416,32 +584,117 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
 int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
                             const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0, float* y1,
                             float* rowmax0, float* rowmax1, void* stream) {
+    return d4w_xcorr_mm_tail_f32(x, nx, ns, xnext, ld_next, n_next, mean, maxabs, taps, ntpl, ltaps, len0, len1, 0.0, 0.0, y0, y1,
+                                 rowmax0, rowmax1, nullptr, stream);
+}
+
+// longest support the kernels take WITH the zero-padded template's tail added in the epilogue: one launch per template
+int d4w_xcorr_mm_tail_max_support(void) { return (32 * kMmKSMax - 15) / 4 * 4; }
+
+size_t d4w_xcorr_mm_tail_ws_bytes(int nx, int ns) {
+    if (nx < 1 || ns < 1) return 0;
+    return ((size_t)nx * (size_t)ceil_div(ns, kMmCH) + 8) * sizeof(unsigned long long) * 2;     // granules + tickets, per template launch
+}
+
+int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
+                          const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, double tail0, double tail1,
+                          float* y0, float* y1, float* rowmax0, float* rowmax1, void* ws, void* stream) {
     if (!x || !y0 || !taps || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (ntpl == 2 && ((rowmax0 == nullptr) != (rowmax1 == nullptr))) return fail(D4W_EINVAL, "rowmax0 and rowmax1 go together");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
     if (xnext && (n_next < 0 || ld_next < n_next)) return fail(D4W_EINVAL, "a continuation needs 0 <= n_next <= ld_next");
-    if (ntpl == 1) len1 = len0;
+    if (ntpl == 1) { len1 = len0; tail1 = 0.0; }
     if (len0 < 1 || len1 < 1 || len0 > ltaps || len1 > ltaps || std::max(len0, len1) > d4w_xcorr_mm_max_support())
         return fail(D4W_EINVAL, "template supports (%d, %d) must lie in 1..min(ltaps = %d, %d)", len0, len1, ltaps, d4w_xcorr_mm_max_support());
+    const bool tails = tail0 != 0.0 || tail1 != 0.0;
+    if (tails) {
+        // the tail is a prefix sum of the NORMALISED row read 16 bytes at a time: statistics, supports that are multiples of 4
+        // (the caller extends a support by the padding's own value, -tail: detect.py:158) and one launch per template
+        if (!mean || !maxabs || !ws) return fail(D4W_EINVAL, "the zero-padded template's tail needs the rows' statistics and a workspace (d4w_xcorr_mm_tail_ws_bytes)");
+        if ((len0 & 3) || (len1 & 3) || std::max(len0, len1) > d4w_xcorr_mm_tail_max_support())
+            return fail(D4W_EINVAL, "with a tail the supports (%d, %d) must be multiples of 4 and <= %d", len0, len1, d4w_xcorr_mm_tail_max_support());
+    }
     MmArgs P;
     P.x = x; P.xnext = xnext; P.mean = mean; P.maxabs = maxabs; P.taps = taps; P.y0 = y0; P.y1 = y1;
     P.nx = nx; P.ns = ns; P.ld_next = ld_next; P.n_next = xnext ? n_next : 0; P.ltaps = ltaps; P.len0 = len0; P.len1 = len1;
     P.shift = 0; P.accumulate = 0;
+    static const int env_clamp = [] { const char* v = getenv("D4W_MM_CLAMP"); return v ? atoi(v) : 0; }();
+    P.clamp = (xnext != nullptr && n_next > 0) || env_clamp;
     P.rowmax0 = rowmax0; P.rowmax1 = (ntpl == 2) ? rowmax1 : nullptr;
+    P.tail0 = (float)tail0; P.tail1 = (float)tail1; P.gran = nullptr; P.tickets = nullptr;
     if (rowmax0) {                                                  // -inf: the identity of the epilogue's integer-atomic float max
         D4W_HIP(hipMemsetD32Async((hipDeviceptr_t)rowmax0, (int)0xFF800000u, (size_t)nx, (hipStream_t)stream));
         if (ntpl == 2) D4W_HIP(hipMemsetD32Async((hipDeviceptr_t)rowmax1, (int)0xFF800000u, (size_t)nx, (hipStream_t)stream));
     }
-    const long long total = (long long)nx * ceil_div(ns, kMmCH);
+    const int nchunk = ceil_div(ns, kMmCH);
+    const long long total = (long long)nx * nchunk;
     // persistent workgroups per compute unit: 2 for two templates (207 VGPRs: the Toeplitz fragments of both templates stay
     // in registers; a 168-register build for three workgroups spills and ran 8.5 ms against 6.6), 3 for one template
     // (149 VGPRs), 2 for the deeper one-template kernels.  D4W_MM_WGS overrides the count (measurements).
     static const int env_wgs = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 0; return n < 0 ? 0 : (n > 8 ? 8 : n); }();
     const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
     const bool fused = ntpl == 2 && std::max(ks0, ks1) <= kMmKS;
-    const int per_cu = env_wgs ? env_wgs : ((ntpl == 1 && ks0 <= kMmKS) ? 3 : 2);
+    // (with a tail the prefix sums take 17 KiB more LDS per buffer: two workgroups per compute unit at most)
+    const int per_cu = env_wgs ? std::min(env_wgs, tails ? 2 : 8) : ((ntpl == 1 && ks0 <= kMmKS && !tails) ? 3 : 2);
     const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
+    auto lds_of = [](int arr, bool tl) {
+        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * arr + 6 * 20) * sizeof(float) + 2 * sizeof(int) : 0);
+    };
+    if (tails) {
+        // one launch per template group; its granules and tickets start from zero
+        const size_t half = ((size_t)nx * nchunk + 8) * sizeof(unsigned long long);
+        auto prep = [&](MmArgs& Q, int which) -> int {
+            char* base = (char*)ws + (size_t)which * half;
+            D4W_HIP(hipMemsetAsync(base, 0, half, (hipStream_t)stream));
+            Q.gran = (unsigned long long*)base;
+            Q.tickets = (int*)(base + (size_t)nx * nchunk * sizeof(unsigned long long));
+            return D4W_OK;
+        };
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<5, kMmKS, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKS, kMmKS, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKS, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKSLong, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<12, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKSMax, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            attr = true;
+        }
+        if (fused) {
+            int rc = prep(P, 0);
+            if (rc) return rc;
+            const size_t lds = lds_of(MmGeom<kMmKS>::Arr, true);
+            if (ks0 <= 5)
+                D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2, true>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+            else
+                D4W_LAUNCH((xcorr_mm_rows<kMmKS, kMmKS, 2, true>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+            return D4W_OK;
+        }
+        for (int t = 0; t < ntpl; ++t) {
+            MmArgs Q = P;
+            Q.taps = taps + (size_t)t * ltaps;
+            Q.len0 = Q.len1 = t ? len1 : len0;
+            Q.tail0 = t ? (float)tail1 : (float)tail0;
+            Q.tail1 = 0.f;
+            Q.y0 = t ? y1 : y0;
+            Q.y1 = nullptr;
+            Q.rowmax0 = t ? rowmax1 : rowmax0;
+            Q.rowmax1 = nullptr;
+            int rc = prep(Q, t);
+            if (rc) return rc;
+            const int ks = ceil_div(Q.len0 + 15, 32);
+            if (ks <= kMmKS)
+                D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr, true), stream, Q);
+            else if (ks <= kMmKSLong)
+                D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr, true), stream, Q);
+            else if (ks <= 12)
+                D4W_LAUNCH((xcorr_mm_rows<12, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<12>::Arr, true), stream, Q);
+            else
+                D4W_LAUNCH((xcorr_mm_rows<kMmKSMax, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSMax>::Arr, true), stream, Q);
+        }
+        return D4W_OK;
+    }
     if (!fused) {
         // one template, or a support beyond 177 samples: the templates one after the other through the one-template kernels
         // (the Toeplitz fragments of one template alone fill the registers the fused kernel splits between two)
@@ -449,8 +702,7 @@ int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, 
         if (rc == D4W_OK && ntpl == 2) rc = mm_one_template(P, taps + ltaps, len1, y1, rowmax1, grid, stream);
         return rc;
     }
-    auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
-    const size_t lds = lds_of(MmGeom<kMmKS>::Arr);
+    const size_t lds = lds_of(MmGeom<kMmKS>::Arr, false);
     if (ks0 <= 5)
         D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
     else

@@ -113,6 +113,19 @@ def _row_stats_cached(x, prefix=False):
     return res
 
 
+def _remember_row_stats(x, stats):
+    """Deposits (float64 row means, float32 row maxima) somebody else formed for the CUDA tensor x as it is now -- the f-k
+    filter's last pass leaves them in its epilogue (dsp._fk_apply) -- so that the matched filter that follows does not read
+    the block again for its normalisation (detect.py:157).  Dropped like any memo entry when x is written to."""
+    import weakref
+    nx, ns = x.shape
+    key = (x.data_ptr(), nx, ns, str(x.device), int(torch.cuda.current_stream(x.device).cuda_stream), False)
+    with _cache_lock:
+        if len(_row_stats_memo) > 8:
+            _row_stats_memo.clear()
+        _row_stats_memo[key] = (weakref.ref(x), x._version, tuple(stats[:2]))
+
+
 def _xcorr_method(taps_list, ns, method):
     """The kernel a correlation runs on: "mm" (banded-Toeplitz product on the matrix cores: two templates of <= 177 samples in
     one launch, one template of <= 497 per launch, longer ones in 496-tap sections up to d4w_xcorr_mm_max_support(); the
@@ -145,8 +158,22 @@ def _xcorr_method(taps_list, ns, method):
     return "direct"
 
 
-def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None, row_max=None):
+def _tails_in_kernel(taps_list, coefs, ns, how):
+    """Whether the zero-padded templates' constant tails (detect.py:158) can be added inside the matrix-core correlator
+    (d4w_xcorr_mm_tail_f32: exact on every row, no second pass): the matrix-core form, supports -- extended to a multiple of 4
+    by the padding's own value -- of at most d4w_xcorr_mm_tail_max_support() samples and shorter than the rows.
+    D4W_XCORR_TAIL=pass keeps the two-pass form of rounds 1-5 (A/B measurements)."""
+    import os
+    if how != "mm" or not any(c != 0.0 for c in coefs) or os.environ.get("D4W_XCORR_TAIL", "kernel") == "pass":
+        return False
+    longest = max(-(-len(t) // 4) * 4 for t in taps_list)
+    return longest <= int(lib.d4w_xcorr_mm_tail_max_support()) and longest < ns
+
+
+def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None, row_max=None, tails=None):
     """x: float32 CUDA [nx, ns]; taps_list: 1..n host float64 vectors -> list of CUDA tensors.
+    tails: optional list of the templates' DC-tail coefficients (_tail_coef) to be added inside the matrix-core kernel
+    (the caller has checked _tails_in_kernel; needs normalize=True).
     method: "mm" (matrix cores), "fft" (overlap-save), "direct", or "auto" (_xcorr_method).
     stats: optional (mean, maxabs) CUDA tensors of the rows, e.g. from FkPlan.apply_stats.
     cont: optional (tensor [nx, >= n], n): the record continues -- the last lags read the first n samples of these rows
@@ -156,6 +183,12 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
     nx, ns = x.shape
     outs = []
     how = _xcorr_method(taps_list, ns, method)
+    if tails is not None:
+        if how != "mm" or not normalize or len(tails) != len(taps_list):
+            raise ValueError("in-kernel template tails need the matrix-core form, normalize=True and one coefficient per template")
+        # the support becomes a multiple of 4 (the kernel reads the prefix sums 16 bytes at a time): the extra taps carry the
+        # value the zero-padded, de-meaned template has there, -mean(t) / max|t| (detect.py:158)
+        taps_list = [np.concatenate((np.asarray(t, dtype=np.float64), np.full((-len(t)) % 4, -float(c)))) for t, c in zip(taps_list, tails)]
     if cont is not None:
         nxt, n_next = cont
         if not (how in ("mm", "fft") and (how == "mm" or len(taps_list) == 2) and nxt.is_cuda and nxt.dtype == torch.float32
@@ -179,15 +212,17 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
             if how == "mm":
                 taps, lt, _, _ = _xf_prepared(grp, x.device, ws=False)
                 rm = [torch.empty(nx, dtype=torch.float32, device=x.device) for _ in grp] if row_max is not None else None
-                check(lib.d4w_xcorr_mm_rowmax_f32(dev.ptr(x), nx, ns,
-                                                  dev.ptr(cont[0]) if cont is not None else None,
-                                                  int(cont[0].stride(0)) if cont is not None else 0,
-                                                  int(cont[1]) if cont is not None else 0,
-                                                  dev.ptr(mean) if normalize else None, dev.ptr(mx) if normalize else None,
-                                                  dev.ptr(taps), len(grp), lt, len(grp[0]), len(grp[-1]),
-                                                  dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
-                                                  dev.ptr(rm[0]) if rm else None, dev.ptr(rm[1]) if rm and len(rm) > 1 else None,
-                                                  dev.stream_ptr(x)))
+                tc = [float(c) for c in tails[i:i + 2]] if tails is not None else [0.0]
+                tws = torch.empty(int(lib.d4w_xcorr_mm_tail_ws_bytes(nx, ns)), dtype=torch.uint8, device=x.device) if any(tc) else None
+                check(lib.d4w_xcorr_mm_tail_f32(dev.ptr(x), nx, ns,
+                                                dev.ptr(cont[0]) if cont is not None else None,
+                                                int(cont[0].stride(0)) if cont is not None else 0,
+                                                int(cont[1]) if cont is not None else 0,
+                                                dev.ptr(mean) if normalize else None, dev.ptr(mx) if normalize else None,
+                                                dev.ptr(taps), len(grp), lt, len(grp[0]), len(grp[-1]), tc[0], tc[-1] if len(grp) > 1 else 0.0,
+                                                dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
+                                                dev.ptr(rm[0]) if rm else None, dev.ptr(rm[1]) if rm and len(rm) > 1 else None,
+                                                dev.ptr(tws) if tws is not None else None, dev.stream_ptr(x)))
                 outs.extend(ys)
                 if rm:
                     row_max.extend(rm)
@@ -361,10 +396,16 @@ def compute_cross_correlograms(data, templates, exact_tail=None):
     taps = [_normalised_support(t) for t in templates]
     coefs = [_tail_coef(t) for t in templates]
     tails = exact_tail is not False and any(c != 0.0 for c in coefs)
-    by_row = tails and exact_tail is None and _xcorr_method(taps, ns, "auto") == "mm"      # the form that leaves row maxima
+    how = _xcorr_method(taps, ns, "auto")                   # decided once (an override that does not apply warns once)
+    if tails and _tails_in_kernel(taps, coefs, ns, how):
+        # round 6: the term is formed inside the correlator (prefix sums in its sample-conversion phase) -- exact on every row,
+        # one pass over the block, no per-row decision
+        outs = _xcorr_device(xd, taps, normalize=True, method=how, stats=_row_stats_cached(xd), tails=coefs)
+        return [dev.like_input(o, data) for o in outs]
+    by_row = tails and exact_tail is None and how == "mm"      # the form that leaves row maxima
     stats = _row_stats_cached(xd, prefix=by_row) if tails else None
     rmax = [] if by_row else None
-    outs = _xcorr_device(xd, taps, normalize=True, stats=stats[:2] if stats else None, row_max=rmax)
+    outs = _xcorr_device(xd, taps, normalize=True, method=how, stats=stats[:2] if stats else None, row_max=rmax)
     if tails:
         _apply_tails(xd, stats[:2], outs, taps, coefs, rmax, exact_tail, pmax=stats[2] if by_row else None)
     return [dev.like_input(o, data) for o in outs]

@@ -308,9 +308,24 @@ def _fk_apply(trace, fk_filter_matrix, tapering):
     device = trace.device if dev.is_tensor(trace) and trace.is_cuda else None
     plan = get_fk_plan(nx, ns, device)
     x = dev.to_device_f32(trace, plan.device)
+    # A CUDA block in, a CUDA block out: the reference's chain goes on to the matched filter (scripts/main_mfdetect.py:55-80),
+    # which normalises every row by its mean and max|.| (detect.py:157).  Where the filter's last pass can leave the two in its
+    # epilogue for 2-3 % of its time (d4w_fk_stats_in_epilogue: the long-row shapes, where a separate sweep of the result costs
+    # 12 %) it does, and the result carries them (detect._remember_row_stats) -- detect.compute_cross_correlogram on that
+    # tensor then starts at the correlator.  D4W_FK_STATS_HINT=0: never.
+    import os
+    hint = (device is not None and trace.dtype == torch.float32 and os.environ.get("D4W_FK_STATS_HINT", "1") != "0")
+    stats = None
     with plan.lock:                                              # the mask this call folds is the mask this call applies
         plan.set_mask(fk_filter_matrix)
-        y = plan.apply(x, taper=tapering)
+        if hint and int(lib.d4w_fk_stats_in_epilogue(plan._h)):
+            y, mean, mx = plan.apply_stats(x, taper=tapering)
+            stats = (mean, mx)
+        else:
+            y = plan.apply(x, taper=tapering)
+    if stats is not None:
+        from . import detect
+        detect._remember_row_stats(y, stats)
     return dev.like_input(y, trace)
 
 

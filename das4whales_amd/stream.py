@@ -84,7 +84,10 @@ class FileStream:
         """The oldest waiting raw file now has its right halo (or the stream ends): filter it."""
         idx, cur = self._raw.pop(0)
         y = self._bandpass(self._prev_tail, cur, right_head)
-        self._prev_tail = cur[:, -self.halo:] if self.halo > 0 else None     # a view: the kernels take a row pitch
+        # the tail is COPIED (one strided-copy launch, nx x halo floats): a view would keep the whole raw file alive -- and
+        # require the caller to leave it unmodified -- for one more push, just to hold 1024 columns of it (ADVICE r05)
+        self._prev_tail = dsp._copy_cols(cur[:, -self.halo:], torch.empty((cur.shape[0], self.halo), dtype=cur.dtype, device=cur.device)) \
+            if self.halo > 0 else None
         stats = None
         if self.fk_mask is not None:
             # the row means / maxima the matched filter normalises by come out of the f-k filter's last pass
@@ -147,7 +150,13 @@ class FileStream:
     # ------------------------------------------------------------------------------------------
     def push(self, block):
         """Next file ([channel x time], NumPy or CUDA tensor).  Returns the list of results that became
-        final (dicts with "index", "filtered" and "correlograms"), possibly empty."""
+        final (dicts with "index", "filtered" and "correlograms"), possibly empty.
+
+        Lifetime of a pushed buffer: a float32 CUDA tensor is NOT copied -- file i is read in place by the work that
+        push(i + 1) (or flush()) enqueues, and by nothing later (its last `halo` columns are copied out then).  A caller
+        that recycles its input buffers may therefore overwrite file i's buffer, in stream order on the stream push() ran
+        on, once push(i + 1) has returned: two alternating buffers are enough.  (NumPy blocks and tensors of another
+        dtype are converted into a tensor the stream owns; the caller's array is free as soon as push() returns.)"""
         x = dev.to_device_f32(block)
         self._raw.append((self._n, x))
         self._n += 1

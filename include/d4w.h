@@ -342,8 +342,10 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
  *   correlation to float32 rounding), one read of x and one write per correlogram, no workspace.
  * supports <= d4w_xcorr_mm_max_support() = 7936; ntpl = 1 or 2 (fused into one launch while both supports are <= 177; beyond,
  * one launch per template up to 497 taps -- the 450-sample template of scripts/main_mfdetect.py:70 --, and longer templates in
- * sections of 496 taps, each section one launch that reads x shifted by its first tap and accumulates into y); non-finite samples spread over the 256 lags of their tile in both templates, and scaled
- * samples beyond binary16's range (caller-supplied statistics of another tensor) are clamped to +-65504;
+ * sections of 496 taps, each section one launch that reads x shifted by its first tap and accumulates into y); non-finite samples spread over the 256 lags of their tile in both templates.
+ * mean / maxabs must be the rows' OWN statistics (|x - mean| / maxabs <= 2): with a continuation (xnext), whose head is scaled by
+ * the row's statistics, and under D4W_MM_CLAMP=1 scaled samples beyond binary16's range are clamped to +-65504; elsewhere
+ * statistics of another tensor can turn tiles into NaN (round 6: the clamp cost 2 % of the kernel on every call);
  * taps DEVICE [ntpl][ltaps], always needed (the
  * Toeplitz fragments are built in the kernel); mean / maxabs as d4w_xcorr_lens_f32 (maxabs == NULL: every 4096-lag chunk
  * is scaled by its own power of two); xnext / ld_next / n_next as d4w_xcorr_fft_cont_f32 (NULL, 0, 0: zeros behind the row). */
@@ -357,6 +359,22 @@ int d4w_xcorr_mm_f32(const float* x, int nx, int ns, const float* xnext, int ld_
 int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
                             const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
                             int len0, int len1, float* y0, float* y1, float* rowmax0, float* rowmax1, void* stream);
+/* The same, with the constant TAIL of the de-meaned zero-padded template added in the kernel's epilogue -- the whole of
+ * detect.compute_cross_correlogram (detect.py:156-166: the template is normalised over its zero-padded length, detect.py:158, which
+ * leaves -mean(t) / max|t| on the padding) in ONE pass over x, exact on every row:
+ *   y_t[c][k] += tail_t * g[c] * sum_{i < k + len_t} (x[c][i] - m[c]),  k + len_t < ns;   tail_t = mean(t) / max|t| (0: no term).
+ * (d4w_xcorr_dc_tail_rows_f32 adds the same term in a second pass over x and y, decided per row; this entry replaces the pair for
+ * supports up to d4w_xcorr_mm_tail_max_support() = 496.)  The prefix sum is formed inside the kernel: local prefix scans in the
+ * sample-conversion phase, each 4096-lag chunk's sum handed to the workgroups that hold the row's later chunks as an 8-byte
+ * {tag, value} granule, chunks claimed from a ticket counter (csrc/xcorr_mm.hip).  Needs mean and maxabs; len0 / len1 multiples of
+ * 4 (a caller extends a support by the padding's own value -tail_t); ws: DEVICE workspace of d4w_xcorr_mm_tail_ws_bytes(nx, ns)
+ * bytes (zeroed by the call).  tail0 == tail1 == 0: d4w_xcorr_mm_rowmax_f32 (ws may be NULL). */
+int d4w_xcorr_mm_tail_max_support(void);
+size_t d4w_xcorr_mm_tail_ws_bytes(int nx, int ns);
+int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
+                          const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
+                          int len0, int len1, double tail0, double tail1, float* y0, float* y1,
+                          float* rowmax0, float* rowmax1, void* ws, void* stream);
 
 /* Zero-phase FIR along time by overlap-save FFT blocks -- the INTERIOR of dsp.bp_filt / scipy.signal.sosfiltfilt
  * (dsp.py:859-880): away from the row ends a zero-phase IIR filter is the convolution with its two-sided response

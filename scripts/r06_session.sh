@@ -1,0 +1,57 @@
+#!/bin/bash
+# Round-6 GPU sessions (gpurun -- 'bash scripts/r06_session.sh <name> <what...>'); results under gpurun_out/<name>/
+set -u
+OUT=gpurun_out/$1; shift
+mkdir -p $OUT
+export TMPDIR=/tmp
+R=$PWD
+for what in "$@"; do
+case $what in
+foreign)
+    # the victims of the cross-stream hazard beside kernels of OTHER libraries (hipBLASLt / rocBLAS GEMMs, MIOpen
+    # conv), one neighbour family per process (a crash inside one library must not take the others' rows with it)
+    rm -f $OUT/concurrency_trials.txt
+    for fam in "matmul f16" "matmul bf16" "conv2d"; do
+        tag=$(echo $fam | tr ' ' '_')
+        D4W_FOREIGN_ONLY="$fam" D4W_CONC_TRIALS=${TRIALS:-40} D4W_CONC_REPORT=$R/$OUT/concurrency_trials.txt PYTHONFAULTHANDLER=1 \
+            timeout 900 python -u -m pytest tests/test_concurrent_gpu.py -q -m gpu -s -k foreign > $OUT/pytest_foreign_$tag.log 2>&1
+        echo "foreign neighbours '$fam': rc $? $(grep -E "passed|failed|error" $OUT/pytest_foreign_$tag.log | tail -1)"
+    done
+    cat $OUT/concurrency_trials.txt ;;
+concurrent)
+    D4W_CONC_TRIALS=${TRIALS:-40} D4W_CONC_REPORT=$R/$OUT/concurrency_trials_own.txt timeout 1500 python -m pytest tests/test_concurrent_gpu.py -q -m gpu -s -k "not foreign" 2>&1 | tail -30 > $OUT/pytest_concurrent.log
+    tail -8 $OUT/pytest_concurrent.log ;;
+ab_r4)
+    # the round-4 library (_ab/r4 = 35dbda3, built here) against HEAD on ONE box, alternating three times
+    for i in 1 2 3; do
+        for tree in _ab/r4 .; do
+            tag=$([ $tree = . ] && echo HEAD || echo r4)
+            (cd $tree && timeout 300 python scripts/time_xcorr_mm.py 2>/dev/null | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('$tag pass $i  xcorr_mm two templates %.3f ms (min %.3f)  one template %.3f  no normalise %.3f  fft form %.3f' % (d['mm_ms_median_min'][0], d['mm_ms_median_min'][1], d['mm_ms_one_template'][0], d['mm_ms_no_normalise'][0], d['fft_ms_median_min'][0]))")
+            (cd $tree && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu --no-dense 2>/dev/null | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); r = d['roofline']
+print('$tag pass $i  bench ms/step %.3f  frac %.3f ' % (d['ms_per_step'], r['frac']), ' '.join('%s=%.2f' % (k.replace('fk_pass', ''), v) for k, v in r.get('kernel_ms', {}).items()), ' '.join('%s=%.2f' % (k, v) for k, v in r.get('stage_ms', {}).items()))")
+        done
+    done 2>&1 | tee $OUT/ab_r4_vs_head.txt ;;
+copy_ceiling)
+    timeout 600 scripts/probe/copy_ceiling > $OUT/copy_ceiling.txt 2>&1; grep -c TB $OUT/copy_ceiling.txt; sort -t'|' -k8 $OUT/copy_ceiling.txt | grep "^copy" | sort -k2 -t'|' | awk -F'|' '{print}' | sort -t'|' -k8 -r | head -12 ;;
+tests_all)
+    timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -40 > $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
+smoke)
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -5 $OUT/smoke.log ;;
+tests_mf)
+    timeout 1800 python -u -m pytest tests/test_rowops_gpu.py tests/test_fuzz_gpu.py tests/test_fk_gpu.py tests/test_stream_gpu.py tests/test_pipeline_gpu.py -x -q -m gpu 2>&1 | tail -40 > $OUT/pytest_mf.log; tail -25 $OUT/pytest_mf.log ;;
+bench)
+    timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench_line.json ;;
+bench_nocpu)
+    timeout 900 python bench.py --no-cpu > $OUT/bench_line_nocpu.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench_line_nocpu.json ;;
+api_sweep)
+    (timeout 300 python scripts/time_api_sweep.py; NX=11020 NS=12000 timeout 300 python scripts/time_api_sweep.py) 2>/dev/null | grep "^{" > $OUT/time_api_sweep.txt; cat $OUT/time_api_sweep.txt ;;
+xcorr_mm)
+    timeout 600 python scripts/time_xcorr_mm.py > $OUT/time_xcorr_mm.txt 2>&1; cat $OUT/time_xcorr_mm.txt ;;
+*) echo "unknown step $what" ;;
+esac
+done

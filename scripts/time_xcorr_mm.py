@@ -14,12 +14,12 @@ tpl = [ddet._normalised_support(ddet.gen_template_fincall(t, fs, 17.8, 28.8, 0.6
 mean, mx = ddet._row_stats_cached(x)             # float64 means, float32 maxima (d4w_row_stats_f32)
 
 
-def timeit(method, normalize=True, tl=tpl):
+def timeit(method, normalize=True, tl=tpl, tails=None):
     ts = []
     for i in range(10):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        ys = ddet._xcorr_device(x, tl, normalize=normalize, method=method, stats=(mean, mx) if normalize else None)
+        ys = ddet._xcorr_device(x, tl, normalize=normalize, method=method, stats=(mean, mx) if normalize else None, tails=tails)
         b.record(); b.synchronize()
         ts.append(a.elapsed_time(b)); del ys
     return float(np.median(ts[3:])), float(np.min(ts[3:]))
@@ -37,6 +37,19 @@ for m in ("mm", "fft"):
     out[m + "_ms_median_min"] = timeit(m)
 out["mm_ms_no_normalise"] = timeit("mm", normalize=False)
 out["mm_ms_one_template"] = timeit("mm", tl=tpl[1:])
+# round 6: the same launches with the zero-padded templates' DC tail added in the epilogue (what the public call runs)
+full = [ddet.gen_template_fincall(t, fs, 17.8, 28.8, 0.68), ddet.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)]
+coefs = [ddet._tail_coef(f) for f in full]
+out["mm_tail_ms_median_min"] = timeit("mm", tails=coefs)
+out["mm_tail_ms_one_template"] = timeit("mm", tl=tpl[1:], tails=coefs[1:])
+ys = ddet._xcorr_device(x, tpl, normalize=True, method="mm", stats=(mean, mx), tails=coefs)
+import scipy.signal as sps
+reft = []
+for k, f in enumerate(full):
+    tn = (f - f.mean()) / np.max(np.abs(f))
+    reft.append(np.stack([sps.correlate(r, tn, mode="full", method="fft")[ns - 1:] for r in xn]))
+out["mm_tail_err_vs_f64"] = [float(np.max(np.abs(ys[k][rows].double().cpu().numpy() - reft[k])) / np.max(np.abs(reft[k]))) for k in range(2)]
+del ys
 gb = 12.0 * nx * ns / 1e9
 out["mm_TBps"] = gb / out["mm_ms_median_min"][0]
 out["fft_TBps"] = gb / out["fft_ms_median_min"][0]

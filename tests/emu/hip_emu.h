@@ -312,6 +312,9 @@ template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline unsigned long long __ballot(int pred) { return hipemu::wave_ballot(pred); }
+// (used in wave-uniform code of full waves only: every lane of the wave votes)
+static inline int __any(int pred) { return hipemu::wave_ballot(pred) != 0ull; }
+static inline int __all(int pred) { return hipemu::wave_ballot(!pred) == 0ull; }
 
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

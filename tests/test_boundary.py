@@ -76,3 +76,19 @@ def test_missing_library_fails_loudly(tmp_path):
                        capture_output=True, text=True, env=env)
     assert r.returncode != 0
     assert "no CPU fallback" in r.stderr or "not found" in r.stderr
+
+
+def test_library_override_is_announced(built, tmp_path):
+    """D4W_LIB swaps the shared object under the whole package (probe builds): it must say so -- a variable left
+    over from a probe session would otherwise make every result come from that build unnoticed."""
+    import shutil
+    other = tmp_path / "libd4w_probe.so"
+    shutil.copy(built, other)
+    code = "import sys, warnings; sys.path.insert(0, %r); import das4whales_amd._lib as L; print(L.LIB_PATH)" % ROOT
+    env = dict(os.environ, D4W_LIB=str(other))
+    r = subprocess.run([sys.executable, "-W", "always", "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert str(other) in r.stdout and "D4W_LIB" in r.stderr and "replaces the packaged library" in r.stderr
+    env.pop("D4W_LIB")
+    r = subprocess.run([sys.executable, "-W", "always", "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "D4W_LIB" not in r.stderr

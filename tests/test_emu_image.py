@@ -41,6 +41,14 @@ def test_minmax_scale_threshold_mask(emu):
     assert np.array_equal(y, x * m)
     neg = f32([-3.0, -1.0, -2.0])
     assert emu.d4w_minmax_f32(vp(neg), sz(3), vp(mm), None) == 0 and mm[0] == -3 and mm[1] == -1
+    # np.min / np.max propagate NaN (the threshold 0.45 * np.max(corr) of scripts/main_mfdetect.py:82 is NaN then, and picks nothing):
+    # both forms of the reduction (one workgroup for small inputs, the three-launch form) do too
+    for n in (700, 300 * 1200):
+        bad = rng.random(n).astype(np.float32) - 0.5
+        bad[n // 3] = np.nan
+        assert emu.d4w_minmax_f32(vp(bad), sz(n), vp(mm), None) == 0 and np.isnan(mm[0]) and np.isnan(mm[1]), (n, mm)
+        bad[n // 3] = 2.0
+        assert emu.d4w_minmax_f32(vp(bad), sz(n), vp(mm), None) == 0 and mm[0] == bad.min() and mm[1] == 2.0
 
 
 @pytest.mark.parametrize("h,w,oh,ow", [(40, 120, 4, 12), (37, 101, 3, 10), (4, 12, 40, 120), (50, 33, 17, 80), (9, 300, 9, 30)])

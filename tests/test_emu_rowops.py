@@ -623,6 +623,99 @@ def test_xcorr_mm_row_maxima_from_the_epilogue(emu, l0, l1):
     assert emu.d4w_xcorr_mm_rowmax_f32(vp(x), nx, ns, None, 0, 0, None, None, vp(taps), 2, lt, l0, l1, vp(y0), vp(y1), vp(m0), None, None) != 0
 
 
+def xcorr_mm_tail_emu(lib, x, templates, want_max=False):
+    """d4w_xcorr_mm_tail_f32 the way detect.compute_cross_correlograms drives it: supports extended to a multiple of 4 by the
+    padding's own value, tail coefficients mean(t) / max|t| over the zero-padded length."""
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    nx, ns = xf.shape
+    taps_list, coefs = [], []
+    for tpl in templates:
+        tp, c = norm_taps(tpl), float(tpl.mean() / np.max(np.abs(tpl)))
+        taps_list.append(np.concatenate((tp, np.full((-len(tp)) % 4, -c))))
+        coefs.append(c)
+    lt = max(len(t) for t in taps_list)
+    taps = np.zeros((len(taps_list), lt), dtype=np.float32)
+    for i, t in enumerate(taps_list):
+        taps[i, :len(t)] = t
+    mean, mx = np.empty(nx, dtype=np.float64), np.empty(nx, dtype=np.float32)
+    assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
+    lib.d4w_xcorr_mm_tail_ws_bytes.restype = ctypes.c_size_t
+    ws = np.full(int(lib.d4w_xcorr_mm_tail_ws_bytes(nx, ns)), 0xAB, dtype=np.uint8)       # (the call zeroes what it uses)
+    ys = [np.full_like(xf, np.nan) for _ in taps_list]
+    rm = [np.full(nx, np.nan, np.float32) for _ in taps_list] if want_max else [None] * 2
+    rc = lib.d4w_xcorr_mm_tail_f32(vp(xf), nx, ns, None, 0, 0, vp(mean), vp(mx), vp(taps), len(taps_list), lt, len(taps_list[0]),
+                                   len(taps_list[-1]), ctypes.c_double(coefs[0]), ctypes.c_double(coefs[-1] if len(coefs) > 1 else 0.0),
+                                   vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None,
+                                   vp(rm[0]) if want_max else None, vp(rm[1]) if want_max and len(ys) > 1 else None, vp(ws), None)
+    assert rc == 0, lib.d4w_last_error()
+    return (ys, rm) if want_max else ys
+
+
+def test_zero_padded_template_tail_inside_the_matrix_core_correlator(emu):
+    """Round 6: the constant tail of the de-meaned zero-padded template (detect.py:158) is added in the correlator's own epilogue
+    (prefix scan in the conversion phase + the earlier chunks' sums as granules): the whole of detect.compute_cross_correlogram
+    in one pass, on EVERY row -- white, band-limited, a slow drift, a step (the rows a white-noise prediction let through at
+    3e-4 .. 2e-3 in rounds 1-4) -- for rows of several chunks, ragged row ends, both fin-call templates in one launch, one
+    template alone, a template with a clearly non-zero mean, supports that are not multiples of 4."""
+    rng = np.random.default_rng(606)
+    fs, ns = 200.0, 13001                       # 4 chunks of 4096 lags, the last one ragged
+    t = np.arange(ns) / fs
+    hf = orc.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)
+    lf = orc.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)
+    w = rng.standard_normal((4, ns))
+    band = sps.sosfiltfilt(sps.butter(8, [14 / (fs / 2), 30 / (fs / 2)], "bp", output="sos"), rng.standard_normal(ns))
+    x = np.stack([w[0], band, 0.05 * w[1] + np.sin(2 * np.pi * t / 50.0), np.where(t < 40, 1.0, -1.0) + 0.01 * w[2],
+                  w[3] + 3.0]) + 0.3
+    xf = np.ascontiguousarray(x, dtype=np.float32).astype(np.float64)          # the float32 rows the kernel sees
+    refs = [orc.compute_cross_correlogram(xf, tp) for tp in (hf, lf)]
+    (yh, yl), (mh, ml) = xcorr_mm_tail_emu(emu, x, [hf, lf], want_max=True)
+    for y, ref, name in ((yh, refs[0], "hf"), (yl, refs[1], "lf")):
+        for k in range(len(x)):
+            e = np.max(np.abs(y[k] - ref[k])) / np.max(np.abs(ref[k]))
+            assert e < 2e-6, (name, k, e)
+    assert np.array_equal(mh, yh.max(axis=1)) and np.array_equal(ml, yl.max(axis=1))     # maxima of the FINAL values
+    # without the term the drifting rows are far off (what the term is worth)
+    plain = xcorr_mm_emu(emu, x, [norm_taps(hf)])[0]
+    assert np.max(np.abs(plain[2] - refs[0][2])) / np.max(np.abs(refs[0][2])) > 1e-4
+    # one template alone (the one-template kernels), a support that is not a multiple of 4, a clearly non-zero mean
+    tpl = np.zeros(ns)
+    tpl[:203] = np.abs(rng.standard_normal(203)) + 0.2
+    (y1,) = xcorr_mm_tail_emu(emu, x, [tpl])
+    ref1 = orc.compute_cross_correlogram(xf, tpl)
+    for k in range(len(x)):
+        e = np.max(np.abs(y1[k] - ref1[k])) / np.max(np.abs(ref1[k]))
+        assert e < 2e-6, ("one template", k, e)
+    (y2,) = xcorr_mm_tail_emu(emu, x, [lf])
+    assert np.max(np.abs(y2 - refs[1])) / np.max(np.abs(refs[1])) < 2e-6
+    # the contract: supports that are multiples of 4, statistics and a workspace
+    taps = np.zeros((1, 8), np.float32)
+    mean, mx = np.zeros(5), np.ones(5, np.float32)
+    y = np.empty((5, ns), np.float32)
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    assert emu.d4w_xcorr_mm_tail_f32(vp(xs), 5, ns, None, 0, 0, vp(mean), vp(mx), vp(taps), 1, 8, 7, 7, ctypes.c_double(1e-3),
+                                     ctypes.c_double(0.0), vp(y), None, None, None, vp(y), None) == -1
+    assert emu.d4w_xcorr_mm_tail_f32(vp(xs), 5, ns, None, 0, 0, vp(mean), vp(mx), vp(taps), 1, 8, 8, 8, ctypes.c_double(1e-3),
+                                     ctypes.c_double(0.0), vp(y), None, None, None, None, None) == -1
+
+
+def test_row_maximum_of_a_row_with_nan_is_nan(emu):
+    """np.max propagates NaN (scripts/main_mfdetect.py:82 takes the threshold from it); the epilogue's float max used to drop it
+    (ADVICE r05): a row that holds a NaN sample now leaves NaN as its row maximum, the other rows theirs."""
+    rng = np.random.default_rng(9)
+    nx, ns = 3, 9000
+    x = np.ascontiguousarray(rng.standard_normal((nx, ns)), dtype=np.float32)
+    x[1, 4500] = np.nan
+    t0, t1 = rng.standard_normal(136), rng.standard_normal(156)
+    taps = np.zeros((2, 156), dtype=np.float32)
+    taps[0, :136], taps[1, :156] = t0, t1
+    y0, y1 = np.empty_like(x), np.empty_like(x)
+    m0, m1 = np.empty(nx, np.float32), np.empty(nx, np.float32)
+    assert emu.d4w_xcorr_mm_rowmax_f32(vp(x), nx, ns, None, 0, 0, None, None, vp(taps), 2, 156, 136, 156, vp(y0), vp(y1), vp(m0), vp(m1), None) == 0
+    assert np.isnan(m0[1]) and np.isnan(m1[1]) and np.isnan(y0[1]).any()
+    for k in (0, 2):
+        assert m0[k] == y0[k].max() and m1[k] == y1[k].max()
+
+
 @pytest.mark.parametrize("order,nx,ns", [(10, 13, 700), (9, 5, 130), (3, 67, 1205), (8, 1, 64)])
 def test_sos_sections_on_adjacent_lanes(emu, order, nx, ns):
     """sos_pass_lanes (one exact segment per row: the sections of a row on adjacent lanes, outputs handed on by a DPP move):

@@ -251,3 +251,54 @@ def test_record_length_with_large_prime_factor(dw, nx, ns):
     m = orc.hybrid_ninf_filter_design((nx, ns), [0, nx * 4, 4], 2.0419046878814697, 200.0, 1350., 1450., 3300, 3450, 14., 30.)
     assert rel(dw.dsp.fk_filter_filt(x, m), orc.fk_filter_filt(x, m)) < TOL
     assert rel(dw.dsp.fk_filter_filt(x, m, tapering=True), orc.fk_filter_filt(x, m, tapering=True)) < TOL
+
+
+def test_benchmark_step_is_the_public_calls_and_matches_the_oracle(dw):
+    """bench.py's timed step since round 6: dsp.fk_filter_filt(x, mask) -> detect.compute_cross_correlograms(y, [hf, lf]) on a
+    device-resident 20 000 x 120 000 block, full-length zero-padded templates (reference scripts/main_mfdetect.py:55-80).  The
+    filter's last pass leaves the rows' mean / max|.| for the matched filter (detect._remember_row_stats), the correlator adds
+    the template's DC tail (detect.py:158) itself.  Five rows of the composition against the oracle's
+    compute_cross_correlogram of the same filtered rows in float64; then a drifting and a stepped row written INTO the filtered
+    block (the remembered statistics must be dropped, the tail term -- 1e-3 of such a row's correlogram -- must be there)."""
+    import numpy as np
+    import torch
+    from oracle import d4w_oracle as orc
+    nx, ns, fs = 20000, 120000, 200.0
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("needs ~60 GB of HBM")
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn((nx, ns), device="cuda", generator=gen) + 0.1
+    mask = dw.dsp.fk_filter_design((nx, ns), [0, nx, 1], 2.0419046878814697, fs)
+    t = np.arange(ns) / fs
+    hf = dw.detect.gen_template_fincall(t, fs, 17.8, 28.8, 0.68)
+    lf = dw.detect.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)
+    y = dw.dsp.fk_filter_filt(x, mask)
+    del x
+    # the statistics travel with the result ...
+    mean, mx = dw.detect._row_stats_cached(y)
+    assert torch.allclose(mx, y.abs().amax(dim=1), rtol=1e-6, atol=0)
+    assert float((mean - y.double().mean(dim=1)).abs().max()) < 1e-6 * float(mx.max())
+    c_hf, c_lf = dw.detect.compute_cross_correlograms(y, [hf, lf])
+    rows = [0, 1, 7777, 10000, nx - 1]
+    yr = y[rows].double().cpu().numpy()
+    for c, tp, name in ((c_hf, hf, "HF"), (c_lf, lf, "LF")):
+        ref = orc.compute_cross_correlogram(yr, tp)
+        got = c[rows].cpu().numpy()
+        for k in range(len(rows)):
+            e = float(np.max(np.abs(got[k] - ref[k])) / np.max(np.abs(ref[k])))
+            assert e < 2e-6, (name, rows[k], e)
+    del c_hf, c_lf
+    # ... and are dropped when the block is written to: rows that drift / step, through the same public call
+    tt = torch.arange(ns, device="cuda", dtype=torch.float32) / fs
+    y[5] = 0.05 * y[5] + torch.sin(2 * np.pi * tt / 300.0)
+    y[6] = torch.where(tt < 200.0, 1.0, -1.0) + 0.01 * y[6]
+    c_hf, c_lf = dw.detect.compute_cross_correlograms(y, [hf, lf])
+    rows = [4, 5, 6]
+    yr = y[rows].double().cpu().numpy()
+    for c, tp, name in ((c_hf, hf, "HF"), (c_lf, lf, "LF")):
+        ref = orc.compute_cross_correlogram(yr, tp)
+        got = c[rows].cpu().numpy()
+        for k in range(len(rows)):
+            e = float(np.max(np.abs(got[k] - ref[k])) / np.max(np.abs(ref[k])))
+            assert e < 2e-6, (name, "after the rows were rewritten", rows[k], e)

@@ -192,3 +192,38 @@ def test_edge_files_with_and_without_the_copies(nx, ns, halo, monkeypatch):
         assert rel(outs["1"][i][0], Fi) < tol and rel(outs["0"][i][0], Fi) < tol, (i, rel(outs["1"][i][0], Fi), rel(outs["0"][i][0], Fi))
         assert rel(outs["1"][i][0], outs["0"][i][0]) < 2 * tol
         assert rel(outs["1"][i][1], outs["0"][i][1]) < 2 * tol
+
+
+def test_stream_with_two_recycled_input_buffers():
+    """A caller that alternates TWO float32 CUDA buffers and pushes them directly (no copy): file i's buffer is overwritten
+    with file i + 2 right after push(i + 1) -- the lifetime push() documents.  The stream keeps its own copy of the `halo`
+    tail columns (a view of the pushed tensor would hand the band-pass of file i + 1 a left halo from file i + 2)."""
+    from das4whales_amd import stream
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    nx, ns, nfiles = 64, 6000, 5
+    rec = torch.randn((nx, ns * nfiles), device="cuda", generator=gen) + 0.2
+    t = np.arange(ns) / FS
+    hf = orc.gen_template_fincall(t, FS, 17.8, 28.8, 0.68)
+
+    def run(recycle):
+        st = stream.FileStream(FS, 14, 30, templates=[hf], halo=1024)
+        bufs = [torch.empty((nx, ns), device="cuda"), torch.empty((nx, ns), device="cuda")]
+        out = []
+        for i in range(nfiles):
+            if recycle:
+                b = bufs[i % 2]
+                b.copy_(rec[:, i * ns:(i + 1) * ns])          # overwrites file i - 2, whose successor has been pushed
+            else:
+                b = rec[:, i * ns:(i + 1) * ns].clone()
+            out += st.push(b)
+        out += st.flush()
+        return {r["index"]: (r["filtered"].clone(), r["correlograms"][0].clone()) for r in out}
+
+    a, b = run(False), run(True)
+    assert sorted(a) == sorted(b) == list(range(nfiles))
+    for i in range(nfiles):
+        assert torch.equal(a[i][0], b[i][0]), ("band-pass of file %d depends on the recycled buffer" % i)
+        assert torch.equal(a[i][1], b[i][1]), ("correlogram of file %d depends on the recycled buffer" % i)
+    F = orc.bp_filt(rec.double().cpu().numpy(), FS, 14, 30)
+    for i in range(nfiles):
+        assert rel(b[i][0].cpu().numpy(), F[:, i * ns:(i + 1) * ns]) < TOL
