@@ -161,6 +161,44 @@ def replicas_step_ms(args, stages, world, rank, device, dist):
     return float(tt.item()) / args.steps * 1e3
 
 
+_RCCL_LOG = None
+
+
+def _rccl_debug_capture(rank):
+    """Before init_process_group at N > 1: have RCCL write its tuning decisions (which algorithm / protocol a collective of a given
+    size runs as) to a file of this rank, unless the caller has set NCCL_DEBUG himself.  One line per collective call into a
+    file: noise against an 8-GB transfer.  Read back by _rccl_all_gather_summary()."""
+    global _RCCL_LOG
+    if "NCCL_DEBUG" in os.environ:
+        return
+    _RCCL_LOG = "/tmp/d4w_rccl_rank%d_%d.log" % (rank, os.getpid())
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "TUNING,COLL"
+    os.environ["NCCL_DEBUG_FILE"] = _RCCL_LOG
+
+
+def _rccl_all_gather_summary():
+    """Algorithm / protocol RCCL chose for the all-gathers of this run, from the rank's debug file: {"AllGather <bytes>": "algo RING
+    proto SIMPLE", ...} for the largest few sizes; a note when this RCCL build printed nothing of the kind."""
+    import re
+    if not _RCCL_LOG or not os.path.exists(_RCCL_LOG):
+        return "not captured (NCCL_DEBUG was set by the caller, or no debug file was written)"
+    algos = {0: "TREE", 1: "RING", 2: "COLLNET_DIRECT", 3: "COLLNET_CHAIN", 4: "NVLS", 5: "NVLS_TREE"}
+    protos = {0: "LL", 1: "LL128", 2: "SIMPLE"}
+    found = {}
+    try:
+        for line in open(_RCCL_LOG, errors="replace"):
+            m = re.search(r"AllGather:?\s+(\d+)\s+Bytes\s*->\s*Algo\s+(\d+)\s+proto\s+(\d+)", line)
+            if m:
+                nb, al, pr = int(m.group(1)), int(m.group(2)), int(m.group(3))
+                found[nb] = "algo %s proto %s" % (algos.get(al, al), protos.get(pr, pr))
+    except OSError as e:
+        return "debug file unreadable: %r" % (e,)
+    if not found:
+        return "this RCCL build logged no 'AllGather: N Bytes -> Algo a proto p' lines (NCCL_DEBUG_SUBSYS=TUNING,COLL)"
+    return {"AllGather %d B" % nb: found[nb] for nb in sorted(found, reverse=True)[:4]}
+
+
 def bench_channel_sharded(args, stages, world, rank, device, dist):
     """BASELINE configs[3]: ONE nx x ns block sharded by contiguous channel block over the ranks; a step
     is the exact distributed f-k filter (time phase, all-to-all, channel phase, all-to-all, inverse
@@ -194,7 +232,8 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         else:
             y = plan.apply(x_loc) if "fk" in stages else x_loc
         # the all-gather of the filtered t-x matrix travels behind the matched filter of the local rows
-        pend = shard.all_gather_rows(y, nx, async_op=True) if (gather and nx % world == 0) else None
+        direct = args.gather_how == "direct"
+        pend = shard.all_gather_rows(y, nx, async_op=True, how=args.gather_how) if (gather and (direct or nx % world == 0)) else None
         out = ddet._xcorr_device(y, tpl, normalize=True, stats=st) if "mf" in stages else None
         if pend is not None:
             pend[1].wait()
@@ -228,7 +267,7 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     stage_ms = {}
     for rep_i in range(3):
         plan.marks = []
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
         st = None
         if fused_stats:
@@ -240,11 +279,14 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
         if "mf" in stages:
             ddet._xcorr_device(y, tpl, normalize=True, stats=st)
         ev[2].record()
-        if args.gather or world > 1:                     # timed beside the step when it is not part of it
+        if args.gather or world > 1:                     # both forms, timed beside the step (alone on the links, nothing overlapped)
             shard.all_gather_rows(y, nx)
         ev[3].record()
-        ev[3].synchronize()
-        for k, (a_, b_) in {"fk_filter": (0, 1), "matched_filter": (1, 2), "all_gather": (2, 3)}.items():
+        if args.gather or world > 1:
+            shard.all_gather_rows(y, nx, how="direct")
+        ev[4].record()
+        ev[4].synchronize()
+        for k, (a_, b_) in {"fk_filter": (0, 1), "matched_filter": (1, 2), "all_gather": (2, 3), "all_gather_direct": (3, 4)}.items():
             stage_ms[k] = stage_ms.get(k, 0.0) + ev[a_].elapsed_time(ev[b_]) / 3
         if "mf" in stages and "picks_error" not in stage_ms:
             # what a deployment would gather instead of the 9.6-GB t-x matrix: the envelope picks of the local
@@ -281,8 +323,13 @@ def bench_channel_sharded(args, stages, world, rank, device, dist):
     plan_info = {"N1": plan.N1, "N2": plan.N2, "sub_rows_owned": plan.nq, "sub_rows_per_rank": plan.sub_rows_per_rank(),
                  "channel_phase_balance": round(plan.channel_phase_balance(), 4), "packed": bool(plan.packed),
                  "exchange_row_chunks": plan.exchange_chunks() if plan.packed else None}
-    gather_info = {"in_timed_step": "t-x matrix (all_gather_rows)" if args.gather else "none: outputs stay sharded",
-                   "all_gather_tx_ms": stage_ms.get("all_gather"), "tx_bytes_into_every_gpu": 4.0 * nx * ns * (world - 1) / world,
+    gather_info = {"in_timed_step": ("t-x matrix (all_gather_rows, how=%s)" % args.gather_how) if args.gather else "none: outputs stay sharded",
+                   "all_gather_tx_ms": stage_ms.get("all_gather"), "all_gather_tx_direct_ms": stage_ms.get("all_gather_direct"),
+                   "forms": {"collective": "one dist.all_gather_into_tensor; RCCL's choice below (a ring all-gather is bound by ONE xGMI "
+                                           "link: >= 55 ms for 8.4 GB at N = 8, SURVEY 8e)",
+                             "direct": "N - 1 grouped isend / irecv pairs per rank, all point-to-point links busy (>= 7.8 ms for the same bytes)"},
+                   "rccl_all_gather": _rccl_all_gather_summary() if world > 1 else "n/a at N = 1",
+                   "tx_bytes_into_every_gpu": 4.0 * nx * ns * (world - 1) / world,
                    "picks_env_local_ms": stage_ms.get("picks_env_local"), "all_gather_picks_ms": stage_ms.get("all_gather_picks"),
                    "picks_gathered": stage_ms.get("picks_gathered")}
     kernels = "shape-specialised" if plan.packed else "generic"
@@ -588,7 +635,11 @@ def bench_gloo_emulated(args, stages, world, rank):
     t1 = time.perf_counter()
     y_all = shard.all_gather_rows(y, nx)
     t2 = time.perf_counter()
+    y_dir = shard.all_gather_rows(y, nx, how="direct")           # N - 1 grouped isend / irecv pairs per rank
+    t2d = time.perf_counter()
+    same_forms = bool(torch.equal(y_all, y_dir))
     hit = torch.nonzero(y > 3.0 * y.std()).t().contiguous()
+    t2p = time.perf_counter()
     tab = shard.all_gather_picks(hit, a)
     t3 = time.perf_counter()
     err = None
@@ -608,7 +659,8 @@ def bench_gloo_emulated(args, stages, world, rank):
                                      "plan": {"N1": plan.N1, "N2": plan.N2, "sub_rows_per_rank": plan.sub_rows_per_rank(),
                                               "channel_phase_balance": round(plan.channel_phase_balance(), 4)}},
                           "gather": {"in_timed_step": "none: outputs stay sharded", "all_gather_tx_ms": (t2 - t1) * 1e3,
-                                     "all_gather_picks_ms": (t3 - t2) * 1e3, "picks_gathered": int(tab.shape[1])},
+                                     "all_gather_tx_direct_ms": (t2d - t2) * 1e3, "direct_equals_collective": same_forms,
+                                     "all_gather_picks_ms": (t3 - t2p) * 1e3, "picks_gathered": int(tab.shape[1])},
                           "rel_err_vs_oracle": err}), flush=True)
     dist.destroy_process_group()
 
@@ -656,6 +708,11 @@ def main():
                          "their correlograms stay with their rank; the t-x all-gather and the gather of the picks are timed "
                          "separately and reported under roofline.stage_ms_rank0 / gather)")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
+    ap.add_argument("--gather-how", type=str, default="collective", choices=["collective", "direct"],
+                    help="--shard channel: how the filtered t-x matrix is reassembled inside the timed step: 'collective' = one "
+                         "dist.all_gather_into_tensor (RCCL picks the algorithm; a ring is bound by ONE xGMI link, SURVEY 8e), "
+                         "'direct' = N - 1 grouped isend / irecv pairs per rank, every point-to-point link busy "
+                         "(shard.all_gather_rows(how='direct')); the other form is timed beside the step and both are printed")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the second (replicas, weak-scaling) measurement")
     ap.add_argument("--force-replicas", action="store_true", help="run the second measurement at N = 1 as well (exercises the N > 1 code path)")
     args = ap.parse_args()
@@ -695,6 +752,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         import datetime
+        if world > 1 and rank == 0:
+            _rccl_debug_capture(rank)
         # a rank that dies must not leave the others waiting for the default half hour
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
     if args.config == "stream":

@@ -81,7 +81,7 @@ struct MmArgs {
     int accumulate;         // add to y0 instead of overwriting it (the later sections of a long template)
     // TAIL kernels (the zero-padded template's constant tail, detect.py:158, added in the epilogue -- see xcorr_mm_rows):
     float tail0, tail1;             // mean(t) / max|t| of template 0 / 1 over its zero-padded length (0: nothing to add)
-    unsigned long long* gran;       // [nx][chunks per row] {tag << 32 | float bits}: every chunk's normalised de-meaned sum
+    unsigned long long* gran;       // [nx][chunks per row][4 waves] {tag << 32 | float bits}: each wave's share of a chunk's normalised de-meaned sum
     int* tickets;                   // [8] next chunk of each XCD range (gran and tickets are zeroed by the host per launch)
 };
 
@@ -139,10 +139,11 @@ __device__ __forceinline__ unsigned long long mm_gran_load(const unsigned long l
 //   * the conversion phase already holds every sample of the chunk: a wave prefix scan (DPP) of the scaled samples goes to
 //     LDS beside the binary16 halves (local prefix per 256-thread segment + the segments' offsets), and the epilogue reads
 //     P[k + L] for its four lags with one 16-byte LDS read per template;
-//   * the prefix at the chunk's START is the sum of the row's earlier chunks, which other workgroups hold: every workgroup
-//     PUBLISHES its chunk's sum as an 8-byte {tag, value} granule right after its conversion (before it waits for anything)
-//     and, when its first tile is done, reads the granules of the row's earlier chunks (a spin only if one is late);
-//   * chunks are CLAIMED from a ticket counter per XCD range instead of being dealt statically, two chunks ahead: a chunk
+//   * the prefix at the chunk's START is the sum of the row's earlier chunks, which other workgroups hold: at the top of an
+//     iteration every wave PUBLISHES its share of the chunk's sum as an 8-byte {tag, value} granule (before the workgroup waits
+//     for anything), asks for the shares of the row's earlier chunks, and looks at them behind its conversion phase -- before
+//     the next chunk's loads are issued, so that a poll never queues behind them (a spin only if a share is late);
+//   * chunks are CLAIMED from a ticket counter per XCD range instead of being dealt statically, three chunks ahead: a chunk
 //     is then only ever held by a RUNNING workgroup and waits point to smaller chunk numbers only, so the scheme cannot
 //     deadlock whatever part of the grid is resident (a neighbour kernel may hold compute units).  Summation orders are
 //     fixed (per lane, DPP tree, segment order, xor tree over the granules): results do not depend on timing.
@@ -170,10 +171,16 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     const int nparts = min(8, (int)gridDim.x);
     const int xcd = (int)blockIdx.x % nparts, wq = (int)blockIdx.x / nparts, nq = ((int)gridDim.x - xcd + nparts - 1) / nparts;
     const long long lo_c = total * xcd / nparts, hi_c = total * (xcd + 1) / nparts;
+    // Tickets are asked for where their return does not wait for anything else: a wave's memory operations return in order, so
+    // the value of an atomic is there once everything ISSUED BEFORE it has returned -- asked for right behind the next chunk's
+    // loads and looked at one iteration later (when those loads have been consumed anyway), the output stores of the matrix
+    // phase in between are not waited for.  Thread 0 carries the pending ticket; the workgroup learns it behind the barrier.
+    int tk_pending = 0;
     if constexpr (TAIL) {
-        if (tid == 0) {                                             // the first two claims (their latency hides under the fragment build)
+        if (tid == 0) {                                             // the first three claims (their latency hides under the fragment build)
             tkl[0] = atomicAdd(P.tickets + xcd, 1);
             tkl[1] = atomicAdd(P.tickets + xcd, 1);
+            tk_pending = atomicAdd(P.tickets + xcd, 1);
         }
     }
 
@@ -307,11 +314,27 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool own_scale = !P.maxabs || heavy_n;                // wave- and workgroup-uniform (one row per chunk)
         mm_half* bh = lds + (size_t)buf * 2 * kMmArr;
         mm_half* bl = bh + kMmArr;
-        // the chunk after the next one: thread 0 asks for its ticket now, the workgroup learns it behind this chunk's barrier
-        int tk_new = 0;
         const long long c_next = TAIL ? c_nn : c + nq;
+        // TAIL: this wave's share of the chunk's sum goes out FIRST (before this workgroup waits for anything), then the shares of
+        // the row's earlier chunks are asked for; they are looked at behind the conversion phase, before the next chunk's loads
+        // are issued -- a wave's memory operations return in order, and a poll queued behind 17 KB of HBM loads would wait for
+        // them (the first build of this kernel did exactly that: 20.7 ms instead of 6.2).
+        const int cin = c0 / kMmCH;                                 // the chunk's number inside its row
+        unsigned long long gv0 = 0ull, gv1 = 0ull;
+        float pst = 0.f;                                            // prefix of the normalised row at the chunk's first sample
         if constexpr (TAIL) {
-            if (tid == 0) tk_new = atomicAdd(P.tickets + xcd, 1);
+            const float mlgn = -mu.lo * g_n;
+            float part = 0.f;
+            static_for<(kMmCH / (4 * kMmThreads))>([&](auto qq) {   // the chunk's OWN samples: the first 4096 of the stage
+                constexpr int q = decltype(qq)::value;
+                const float4 v = pre[q];
+                part += (fmaf(v.x - mu.hi, g_n, mlgn) + fmaf(v.y - mu.hi, g_n, mlgn)) + (fmaf(v.z - mu.hi, g_n, mlgn) + fmaf(v.w - mu.hi, g_n, mlgn));
+            });
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            unsigned long long* grow = P.gran + ((size_t)row * nchunk) * 4;
+            if (lane == 0) mm_gran_store(grow + 4 * cin + wv, part);
+            if (lane < 4 * cin) gv0 = mm_gran_load(grow + lane);
+            if (lane + 64 < 4 * cin) gv1 = mm_gran_load(grow + lane + 64);
         }
         // ---- convert the loaded chunk: (x - mu) * scale -> hi / lo halves in LDS
         if (own_scale) {
@@ -351,7 +374,11 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 const float4 v = pre[q];
                 // ((x - hi) - lo) g as (x - hi) g - lo g: the two-float mean at the instruction count of a float32 one (x - hi is
                 // exact where the offset dominates, the product is rounded once)
+#ifdef D4W_MM_V_FLOATMEAN          // (probe builds: what the two-float mean costs)
+                s[0] = (v.x - mu.hi) * gsc; s[1] = (v.y - mu.hi) * gsc; s[2] = (v.z - mu.hi) * gsc; s[3] = (v.w - mu.hi) * gsc;
+#else
                 s[0] = fmaf(v.x - mu.hi, gsc, mlg); s[1] = fmaf(v.y - mu.hi, gsc, mlg); s[2] = fmaf(v.z - mu.hi, gsc, mlg); s[3] = fmaf(v.w - mu.hi, gsc, mlg);
+#endif
                 // the next file's head (or statistics that are not the rows' own, D4W_MM_CLAMP=1) may leave |v| beyond binary16's
                 // range: inf - inf would turn a whole tile into NaN where the float32 forms stay finite; one v_med3_f32 per
                 // sample, only where asked for (a kernel argument: a scalar branch)
@@ -360,7 +387,14 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                     const int a0 = 4 * (tid + q * kMmThreads);
                     static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; if (a0 + e >= n_valid) s[e] = 0.f; });
                 }
+#ifdef D4W_MM_V_OLDSPLIT
+                mm_half h[4], l[4];
+                static_for<4>([&](auto ee) { constexpr int e = decltype(ee)::value; mm_split(s[e], h[e], l[e]); });
+                mm_put4(bh + at, h);
+                mm_put4(bl + at, l);
+#else
                 mm_split_put4(s, bh + at, bl + at);
+#endif
             }
             if constexpr (TAIL) {
                 // prefix sums of the scaled samples inside this wave's segment (every lane takes part: the idle ones add zeros)
@@ -370,10 +404,36 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 if (lane == 63) wt[buf * kSeg + 4 * q + wv] = inc;
             }
         });
+        if constexpr (TAIL) {
+            // the earlier chunks of the row were claimed before this one and their shares went out at the top of their owners'
+            // iterations: normally all here by now; a late one is polled (bounded: a share that never arrives poisons the outputs
+            // instead of hanging the device)
+            const int ng = 4 * cin;
+            for (int base = 0; base < ng; base += 64) {
+                const int n = min(ng - base, 64);
+                unsigned long long gq = (base == 0) ? gv0 : (base == 64) ? gv1 : 0ull;
+                int spins = 0;
+                while (true) {
+                    const bool ok = lane >= n || (unsigned)(gq >> 32) == 1u;
+                    if (__all(ok)) break;
+                    if (dead || ++spins > (1 << 20)) { dead = true; gq = (1ull << 32) | 0x7FC00000ull; break; }
+#ifndef D4W_EMU
+                    __builtin_amdgcn_s_sleep(2);
+#endif
+                    if (!ok) gq = mm_gran_load(P.gran + ((size_t)row * nchunk) * 4 + base + lane);
+                }
+                float v = lane < n ? __uint_as_float((unsigned)gq) : 0.f;
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                pst += v;
+            }
+        }
         // ---- next chunk's loads fly across the barrier and the matrix phase
         if (c_next < hi_c) issue(c_next);
         if constexpr (TAIL) {
-            if (tid == 0) tkl[buf] = tk_new;
+            if (tid == 0) {
+                tkl[buf] = tk_pending;                              // asked for one iteration ago: the chunk after the next one
+                tk_pending = atomicAdd(P.tickets + xcd, 1);
+            }
         }
         lds_barrier();
         // ---- 16 tiles of 256 lags, 4 per wave: C[i][a] (+)= A[i][u] B[u][a]
@@ -382,10 +442,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
         const float oxs = (own_scale && P.maxabs) ? osx * gout : osx;
         const float o0 = osc0 * oxs, o1 = osc1 * oxs;
-        // TAIL: the segments' start offsets (this wave's own table), the chunk's sum published, the earlier chunks' granules asked for
-        const int cin = c0 / kMmCH;                                 // the chunk's number inside its row
-        unsigned long long gv = 0ull;
-        float pst = 0.f;                                            // prefix of the normalised row at the chunk's first sample
+        // TAIL: the segments' start offsets (this wave's own table)
         const float* plb = pl + (size_t)buf * kMmArr;
         const float* wob = wo + wv * kSeg;
         if constexpr (TAIL) {
@@ -393,10 +450,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             const float w = lane < kSeg ? wt[buf * kSeg + lane] : 0.f;
             const float inc = mm_wave_scan(w);
             if (lane < kSeg) wo[wv * kSeg + lane] = inc - w;
-            if (wv == 0 && lane == 15)                              // samples 0 .. 4095 of the stage = segments 0 .. 15: the chunk's own samples
-                mm_gran_store(P.gran + (size_t)row * nchunk + cin, inc * oxs);
             mm_wave_sync();
-            if (lane < min(cin, 64)) gv = mm_gran_load(P.gran + (size_t)row * nchunk + lane);
         }
         // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
         // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
@@ -446,30 +500,6 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 });
                 c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
                 if constexpr (TAIL) {
-                    if constexpr (ti == 0) {
-                        // the row's earlier chunks: their sums were published before their workgroups waited for anything, and
-                        // they were claimed before this chunk -- normally all here by now; a late one is polled (bounded: a
-                        // granule that never arrives poisons the outputs instead of hanging the device)
-                        if (cin > 0) {
-                            for (int base = 0; base < cin; base += 64) {
-                                const int n = min(cin - base, 64);
-                                unsigned long long gq = (base == 0) ? gv : 0ull;
-                                int spins = 0;
-                                while (true) {
-                                    const bool ok = lane >= n || (unsigned)(gq >> 32) == 1u;
-                                    if (__all(ok)) break;
-                                    if (dead || ++spins > (1 << 20)) { dead = true; gq = (1ull << 32) | 0x7FC00000ull; break; }
-#ifndef D4W_EMU
-                                    __builtin_amdgcn_s_sleep(4);
-#endif
-                                    if (!ok) gq = mm_gran_load(P.gran + (size_t)row * nchunk + base + lane);
-                                }
-                                float v = lane < n ? __uint_as_float((unsigned)gq) : 0.f;
-                                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                                pst += v;
-                            }
-                        }
-                    }
                     auto add_tail = [&](float (&r)[4], float tc, int L) {
                         if (tc != 0.f) {                             // kernel argument: a scalar branch
                             const int idx = kl + L;                  // L % 4 == 0: the four prefixes are one 16-byte word of one segment
@@ -494,10 +524,14 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                     if constexpr (KS1 > 0) mm_store4(yb + k, r1[0], r1[1], r1[2], r1[3]);
                     if (want_max) {
                         vmax0 = fmaxf(vmax0, fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])));
+#ifndef D4W_MM_V_NONAN
                         vsum += (r0[0] + r0[1]) + (r0[2] + r0[3]);
+#endif
                         if constexpr (KS1 > 0) {
                             vmax1 = fmaxf(vmax1, fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
+#ifndef D4W_MM_V_NONAN
                             vsum += (r1[0] + r1[1]) + (r1[2] + r1[3]);
+#endif
                         }
                     }
                 } else {                                            // a row end or an unaligned row (tiles beyond the row: nothing)
@@ -589,11 +623,12 @@ int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, 
 }
 
 // longest support the kernels take WITH the zero-padded template's tail added in the epilogue: one launch per template
-int d4w_xcorr_mm_tail_max_support(void) { return (32 * kMmKSMax - 15) / 4 * 4; }
+// (the 12-step kernel: the 16-step one has no registers left for the prefix sums)
+int d4w_xcorr_mm_tail_max_support(void) { return (32 * 12 - 15) / 4 * 4; }
 
 size_t d4w_xcorr_mm_tail_ws_bytes(int nx, int ns) {
     if (nx < 1 || ns < 1) return 0;
-    return ((size_t)nx * (size_t)ceil_div(ns, kMmCH) + 8) * sizeof(unsigned long long) * 2;     // granules + tickets, per template launch
+    return ((size_t)nx * (size_t)ceil_div(ns, kMmCH) * 4 + 8) * sizeof(unsigned long long) * 2;     // 4 granules per chunk + tickets, per template launch
 }
 
 int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
@@ -639,16 +674,17 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
     const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
     auto lds_of = [](int arr, bool tl) {
-        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * arr + 6 * 20) * sizeof(float) + 2 * sizeof(int) : 0);
+        const int seg = 4 * ceil_div(arr - 8, 4 * kMmThreads);          // MmGeom::Q segments of 1024 samples x 4 waves
+        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * arr + 6 * seg) * sizeof(float) + 2 * sizeof(int) : 0);
     };
     if (tails) {
         // one launch per template group; its granules and tickets start from zero
-        const size_t half = ((size_t)nx * nchunk + 8) * sizeof(unsigned long long);
+        const size_t half = ((size_t)nx * nchunk * 4 + 8) * sizeof(unsigned long long);
         auto prep = [&](MmArgs& Q, int which) -> int {
             char* base = (char*)ws + (size_t)which * half;
             D4W_HIP(hipMemsetAsync(base, 0, half, (hipStream_t)stream));
             Q.gran = (unsigned long long*)base;
-            Q.tickets = (int*)(base + (size_t)nx * nchunk * sizeof(unsigned long long));
+            Q.tickets = (int*)(base + (size_t)nx * nchunk * 4 * sizeof(unsigned long long));
             return D4W_OK;
         };
         static bool attr = false;
@@ -658,7 +694,6 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
             (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKS, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKSLong, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<12, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKSMax, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             attr = true;
         }
         if (fused) {
@@ -688,10 +723,8 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
                 D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr, true), stream, Q);
             else if (ks <= kMmKSLong)
                 D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr, true), stream, Q);
-            else if (ks <= 12)
-                D4W_LAUNCH((xcorr_mm_rows<12, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<12>::Arr, true), stream, Q);
             else
-                D4W_LAUNCH((xcorr_mm_rows<kMmKSMax, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSMax>::Arr, true), stream, Q);
+                D4W_LAUNCH((xcorr_mm_rows<12, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<12>::Arr, true), stream, Q);
         }
         return D4W_OK;
     }

@@ -92,11 +92,19 @@ class FileStream:
         if self.fk_mask is not None:
             # the row means / maxima the matched filter normalises by come out of the f-k filter's last pass
             # (and, for zero-padded templates, the prefix maxima their DC-tail term is decided on)
-            y, stats = dsp._fk_apply_stats(y, self.fk_mask, prefix=any(c != 0.0 for c in self.tail)) if self.taps \
+            y, stats = dsp._fk_apply_stats(y, self.fk_mask, prefix=self._want_prefix(y.shape[1])) if self.taps \
                 else (dsp.fk_filter_filt(y, self.fk_mask), None)
         if self._on_filtered is not None:
             self._on_filtered(idx, y)
         return idx, y, stats
+
+    def _tails_in_kernel(self, ns):
+        """Round 6: the zero-padded templates' DC tail is added inside the matrix-core correlator where that applies
+        (detect._tails_in_kernel) -- no prefix maxima, no second pass."""
+        return bool(self.taps) and detect._tails_in_kernel(self.taps, self.tail, ns, detect._xcorr_method(self.taps, ns, "auto"))
+
+    def _want_prefix(self, ns):
+        return any(c != 0.0 for c in self.tail) and not self._tails_in_kernel(ns)
 
     def _correlate(self, idx, y, next_head, stats=None):
         """Correlograms of filtered file `y`, its last lags completed with `next_head` (or cut short); stats = (row means,
@@ -114,7 +122,7 @@ class FileStream:
             with torch.cuda.device(y.device):
                 mean = torch.empty(nx, dtype=torch.float64, device=y.device)
                 mx = torch.empty(nx, dtype=torch.float32, device=y.device)
-                if any(c != 0.0 for c in self.tail):
+                if self._want_prefix(ns):
                     pm = torch.empty(nx, dtype=torch.float32, device=y.device)
                     check(lib.d4w_row_stats_prefix_f32(dev.ptr(y), nx, ns, dev.ptr(mean), dev.ptr(mx), dev.ptr(pm), dev.stream_ptr(y)))
                 else:
@@ -124,9 +132,16 @@ class FileStream:
             # rows continue into the next file: the kernel reads the head of the next file's rows in place (de-meaned
             # like the file's own samples) -- no concatenated copy, no cropped copies of the correlograms
             rmax = []
-            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, self.lmax - 1), row_max=rmax)
+            inker = self._tails_in_kernel(ns)
+            # (with the tail inside the kernel the supports are extended to multiples of 4: the continuation covers those taps too)
+            n_cont = (-(-self.lmax // 4) * 4 if inker else self.lmax) - 1
+            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, min(n_cont, next_head.shape[1])),
+                                      row_max=rmax, tails=self.tail if inker else None)
             if len(rmax) == len(cs):
                 out["row_max"] = rmax        # max over the lags of every row, per template (detect.correlogram_max)
+            if inker:
+                out["correlograms"] = cs
+                return out
         else:
             if next_head is not None and self.lmax > 1:
                 # the padding must enter de-meaned like the file's own samples (the kernel subtracts the mean from
@@ -137,9 +152,13 @@ class FileStream:
             # (a file without a successor -- the record's last -- still gets its row maxima from the correlator's epilogue:
             # the DC-tail decision per row and correlogram_max need no sweep of the correlograms then)
             rmax = [] if ext is y else None
-            cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx), row_max=rmax)
+            inker = ext is y and self._tails_in_kernel(ns)
+            cs = detect._xcorr_device(ext, self.taps, normalize=True, stats=(mean, mx), row_max=rmax, tails=self.tail if inker else None)
             if rmax and len(rmax) == len(cs):
                 out["row_max"] = rmax
+            if inker:
+                out["correlograms"] = cs
+                return out
             cs = [dsp._copy_cols(c[:, :ns], torch.empty_like(y)) if c.shape[1] != ns else c for c in cs]
         # the DC tail of zero-padded templates, decided per row on the data (detect._apply_tails: the band-passed rows of
         # a stream have prefix sums of a few samples' size and are left alone; the row maxima stay valid either way)

@@ -364,9 +364,9 @@ int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, 
  * leaves -mean(t) / max|t| on the padding) in ONE pass over x, exact on every row:
  *   y_t[c][k] += tail_t * g[c] * sum_{i < k + len_t} (x[c][i] - m[c]),  k + len_t < ns;   tail_t = mean(t) / max|t| (0: no term).
  * (d4w_xcorr_dc_tail_rows_f32 adds the same term in a second pass over x and y, decided per row; this entry replaces the pair for
- * supports up to d4w_xcorr_mm_tail_max_support() = 496.)  The prefix sum is formed inside the kernel: local prefix scans in the
- * sample-conversion phase, each 4096-lag chunk's sum handed to the workgroups that hold the row's later chunks as an 8-byte
- * {tag, value} granule, chunks claimed from a ticket counter (csrc/xcorr_mm.hip).  Needs mean and maxabs; len0 / len1 multiples of
+ * supports up to d4w_xcorr_mm_tail_max_support() = 368.)  The prefix sum is formed inside the kernel: local prefix scans in the
+ * sample-conversion phase, each 4096-lag chunk's sum handed to the workgroups that hold the row's later chunks as 8-byte
+ * {tag, value} granules (one per wave), chunks claimed from a ticket counter (csrc/xcorr_mm.hip).  Needs mean and maxabs; len0 / len1 multiples of
  * 4 (a caller extends a support by the padding's own value -tail_t); ws: DEVICE workspace of d4w_xcorr_mm_tail_ws_bytes(nx, ns)
  * bytes (zeroed by the call).  tail0 == tail1 == 0: d4w_xcorr_mm_rowmax_f32 (ws may be NULL). */
 int d4w_xcorr_mm_tail_max_support(void);

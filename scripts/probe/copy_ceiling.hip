@@ -78,6 +78,64 @@ __global__ __launch_bounds__(256) void stream_k(const char* __restrict__ s, char
     if (MODE == READ && acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
 }
 
+// persistent WAVES that claim their chunks from a ticket counter (one global counter, or one per XCD range) instead of a static
+// stride: a chunk = U x 1 KiB per wave; the ticket of the chunk after the next one is requested at the top of an iteration, so
+// the atomic's latency is off the path.  The point: statically dealt persistent workgroups drift apart over a pass, the window
+// of addresses in flight widens and the DRAM pages opened per byte go up; tickets keep the window as tight as the hardware's
+// in-order dispatch of a naive grid does.
+template <int MODE, int U, int AUXL, int AUXS, bool PERXCD>
+__global__ __launch_bounds__(256) void stream_ticket(const char* __restrict__ s, char* __restrict__ d, char* __restrict__ d2,
+                                                     size_t nchunks, unsigned* tickets, float* sink) {
+    constexpr unsigned CB = U * 1024u;
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7;
+    unsigned* tk = tickets + (PERXCD ? xcd * 32 : 0);              // counters 128 B apart
+    const size_t lo = PERXCD ? nchunks * xcd / 8 : 0, hi = PERXCD ? nchunks * (xcd + 1) / 8 : nchunks;
+    // the returned value is looked at as late as possible: memory operations of a wave return in order, so asking for the
+    // ticket at once would drain the loads and stores issued before it
+    auto ask = [&]() -> unsigned {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(tk, 1u);
+        return t;
+    };
+    auto claim = [&]() -> size_t { return lo + (size_t)__builtin_amdgcn_readfirstlane(ask()); };
+    const unsigned voff = lane * 16u;
+    f4 v[U], w[U];
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](size_t cc, f4 (&r)[U]) {
+        const auto rs = rsrc_of(s + cc * CB, CB);
+#pragma unroll
+        for (int q = 0; q < U; ++q) r[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + q * 1024u, 0, AUXL));
+    };
+    size_t c = claim(), cn = claim();
+    if (MODE != WRITE) { if (c < hi) load(c, v); }
+    else {
+#pragma unroll
+        for (int q = 0; q < U; ++q) v[q] = f4{1.f, 2.f, 3.f, (float)q};
+    }
+    while (c < hi) {
+        const unsigned traw = ask();                                 // two ahead; consumed at the end of the iteration
+#pragma unroll
+        for (int q = 0; q < U; ++q) w[q] = v[q];
+        if (MODE != WRITE && cn < hi) load(cn, v);
+        if (MODE == READ) {
+#pragma unroll
+            for (int q = 0; q < U; ++q) acc += w[q];
+        } else {
+            const auto rd = rsrc_of(d + c * CB, CB);
+#pragma unroll
+            for (int q = 0; q < U; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w[q]), rd, voff + q * 1024u, 0, AUXS);
+            if (MODE == R1W2) {
+                const auto r2 = rsrc_of(d2 + c * CB, CB);
+#pragma unroll
+                for (int q = 0; q < U; ++q) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, w[q] + 1.f), r2, voff + q * 1024u, 0, AUXS);
+            }
+        }
+        c = cn; cn = lo + (size_t)__builtin_amdgcn_readfirstlane(traw);
+    }
+    if (MODE == READ && acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+}
+
 // the naive form: one element per thread
 __global__ __launch_bounds__(256) void naive_copy(const f4* __restrict__ s, f4* __restrict__ d, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -133,6 +191,20 @@ static float run(const char* s, char* d, char* d2, size_t bytes, int wgs_per_cu,
     return ms;
 }
 
+template <int MODE, int U, int AUXL, int AUXS, bool PERXCD>
+static float run_ticket(const char* s, char* d, char* d2, size_t bytes, int wgs_per_cu, unsigned* tickets, float* sink) {
+    const size_t nchunks = bytes / (U * 1024u);
+    const float ms = timeit([&] {
+        (void)hipMemsetAsync(tickets, 0, 8 * 128, 0);
+        hipLaunchKernelGGL((stream_ticket<MODE, U, AUXL, AUXS, PERXCD>), dim3(256 * wgs_per_cu), dim3(256), 0, 0, s, d, d2, nchunks, tickets, sink);
+    });
+    printf("%-8s | tickets %-7s | %2d KiB per wave | %d WG/CU | ld %-10s st %-10s | %5.2f GB | %7.3f ms | %5.2f TB/s\n", mode_name(MODE),
+           PERXCD ? "per XCD" : "global", U, wgs_per_cu, MODE == WRITE ? "-" : aux_name(AUXL), MODE == READ ? "-" : aux_name(AUXS), bytes * 1e-9, ms,
+           bytes_of(MODE, bytes) / ms * 1e-9);
+    fflush(stdout);
+    return ms;
+}
+
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
     CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
@@ -158,6 +230,30 @@ int main(int argc, char** argv) {
     { float ms = timeit([&] { CK(hipMemcpyAsync(d, s, big, hipMemcpyDeviceToDevice, 0)); });
       printf("hipMemcpyAsync D2D: %7.3f ms %5.2f TB/s\n", ms, 2.0 * big / ms * 1e-9); }
 
+    if (argc > 1 && !strcmp(argv[1], "tickets")) {
+        unsigned* tickets; CK(hipMalloc(&tickets, 8 * 128));
+        printf("# 8. persistent waves with TICKETED chunks (global counter / one per XCD range), against the static maps of section 2\n");
+        for (int w : {1, 2, 4, 8}) {
+            run_ticket<COPY, 1, 0, 0, false>(s, d, d2, big, w, tickets, sink); run_ticket<COPY, 2, 0, 0, false>(s, d, d2, big, w, tickets, sink);
+            run_ticket<COPY, 4, 0, 0, false>(s, d, d2, big, w, tickets, sink); run_ticket<COPY, 8, 0, 0, false>(s, d, d2, big, w, tickets, sink);
+            run_ticket<COPY, 1, 0, 0, true>(s, d, d2, big, w, tickets, sink); run_ticket<COPY, 2, 0, 0, true>(s, d, d2, big, w, tickets, sink);
+            run_ticket<COPY, 4, 0, 0, true>(s, d, d2, big, w, tickets, sink); run_ticket<COPY, 8, 0, 0, true>(s, d, d2, big, w, tickets, sink);
+        }
+        for (int w : {2, 4, 8}) {
+            run_ticket<COPY, 4, 2, 2, false>(s, d, d2, big, w, tickets, sink); run_ticket<COPY, 4, 2, 16, false>(s, d, d2, big, w, tickets, sink);
+            run_ticket<INPLACE, 4, 0, 0, false>(s, s, d2, big, w, tickets, sink); run_ticket<INPLACE, 4, 2, 2, false>(s, s, d2, big, w, tickets, sink);
+            run_ticket<INPLACE, 4, 0, 0, true>(s, s, d2, big, w, tickets, sink); run_ticket<INPLACE, 4, 2, 2, true>(s, s, d2, big, w, tickets, sink);
+            run_ticket<R1W2, 4, 0, 0, false>(s, d, d2, big, w, tickets, sink); run_ticket<R1W2, 4, 0, 2, false>(s, d, d2, big, w, tickets, sink);
+            run_ticket<R1W2, 4, 0, 2, true>(s, d, d2, big, w, tickets, sink);
+            run_ticket<READ, 4, 0, 0, false>(s, d, d2, big, w, tickets, sink); run_ticket<READ, 4, 2, 0, false>(s, d, d2, big, w, tickets, sink);
+            run_ticket<WRITE, 4, 0, 0, false>(s, d, d2, big, w, tickets, sink); run_ticket<WRITE, 4, 0, 2, false>(s, d, d2, big, w, tickets, sink);
+        }
+        // the static reference points again, in this process
+        run<COPY, ROUND_ROBIN, 4, 0, 0>(s, d, d2, big, 2, sink); run<COPY, XCD_RANGES, 4, 0, 0>(s, d, d2, big, 1, sink);
+        { float ms = timeit([&] { hipLaunchKernelGGL(naive_copy, dim3((unsigned)(n4 / 256)), dim3(256), 0, 0, (const f4*)s, (f4*)d, n4); });
+          printf("naive 1 x 16 B per thread, grid %zu: %7.3f ms %5.2f TB/s\n", n4 / 256, ms, 2.0 * big / ms * 1e-9); }
+        return 0;
+    }
     printf("# 2. walk order x run length x workgroups per CU (copy, plain policy, 9.6 GB)\n");
 #define SWEEP_MAP(MAPK) \
     for (int w : {1, 2, 4, 8}) { run<COPY, MAPK, 1, 0, 0>(s, d, d2, big, w, sink); run<COPY, MAPK, 2, 0, 0>(s, d, d2, big, w, sink); \

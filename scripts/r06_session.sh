@@ -38,6 +38,25 @@ print('$tag pass $i  bench ms/step %.3f  frac %.3f ' % (d['ms_per_step'], r['fra
     done 2>&1 | tee $OUT/ab_r4_vs_head.txt ;;
 copy_ceiling)
     timeout 600 scripts/probe/copy_ceiling > $OUT/copy_ceiling.txt 2>&1; grep -c TB $OUT/copy_ceiling.txt; sort -t'|' -k8 $OUT/copy_ceiling.txt | grep "^copy" | sort -k2 -t'|' | awk -F'|' '{print}' | sort -t'|' -k8 -r | head -12 ;;
+fk_policy)
+    # cache-policy bits of the f-k passes' block accesses (csrc/d4w_internal.h: D4W_FK_LD / D4W_FK_ST): variant builds of the library
+    # (scripts/probe/build_variant.sh fknt|fkntld|fkntst fk_filter.hip -DD4W_FK_LD=1 ...) against the packaged one, same box
+    for rep in 1 2; do
+      for tag in base fknt fkntld fkntst; do
+        lib=$R/das4whales_amd/lib/probe/libd4w_$tag.so
+        [ $tag = base ] && lib=$R/das4whales_amd/lib/libd4w.so
+        [ -f $lib ] || continue
+        D4W_LIB=$lib timeout 300 python -W ignore scripts/time_fk_masks.py classic ninf dense 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    print('$tag rep $rep %-8s %-13s total %6.2f ms  passes %s  frac %.3f' % (d['mask'], d['order'], d['total_ms'], d['ms'], d['frac_24B']))"
+      done
+    done 2>&1 | tee $OUT/fk_policy_ab.txt ;;
+mm_variants)
+    bash scripts/probe/mm_variants.sh run $OUT ;;
+tickets)
+    timeout 600 scripts/probe/copy_ceiling tickets > $OUT/copy_ceiling_tickets.txt 2>&1; cat $OUT/copy_ceiling_tickets.txt ;;
 tests_all)
     timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -40 > $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
 smoke)

@@ -47,6 +47,9 @@ def test_bench_gpus8_self_launch_gloo():
     assert len(per) == 8 and sum(per) == plan["N1"]
     assert abs(plan["channel_phase_balance"] - plan["N1"] / (8.0 * max(per))) < 1e-3
     assert out["gather"]["all_gather_tx_ms"] > 0 and out["gather"]["all_gather_picks_ms"] > 0
+    # both ways of reassembling the t-x matrix are printed (one collective, or N - 1 point-to-point pairs per rank
+    # with every link busy) and agree
+    assert out["gather"]["all_gather_tx_direct_ms"] > 0 and out["gather"]["direct_equals_collective"] is True
 
 
 def test_bench_refuses_more_gpus_than_visible():

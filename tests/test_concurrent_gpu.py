@@ -97,10 +97,10 @@ def _foreign_neighbour_factory(device):
     for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
         sa, sb = rnd((64, 512, 256), dt), rnd((64, 256, 512), dt)             # 64 small products: small tiles, short kernels
         ba, bb = rnd((8192, 4096), dt), rnd((4096, 8192), dt)                  # 256 x 256 macro tiles, a grid of 1024
-        ka, kb = rnd((256, 131072), dt), rnd((131072, 256), dt)                # one output tile's worth of C, K = 131072: split-K
+        ka, kb = rnd((256, 32768), dt), rnd((32768, 256), dt)                  # one output tile's worth of C, K = 32768: split-K
         ops["matmul %s small tiles" % tag] = lambda sa=sa, sb=sb: [torch.bmm(sa, sb) for _ in range(6)]
         ops["matmul %s 256x256 tiles" % tag] = lambda ba=ba, bb=bb: [torch.matmul(ba, bb) for _ in range(2)]
-        ops["matmul %s split-K" % tag] = lambda ka=ka, kb=kb: [torch.matmul(ka, kb) for _ in range(6)]
+        ops["matmul %s split-K" % tag] = lambda ka=ka, kb=kb: [torch.matmul(ka, kb) for _ in range(3)]
     img, wgt = rnd((16, 64, 128, 128), torch.float16), rnd((64, 64, 3, 3), torch.float16)
     ops["conv2d f16"] = lambda: [torch.nn.functional.conv2d(img, wgt, padding=1) for _ in range(3)]
     return ops

@@ -40,6 +40,13 @@ def test_golden_all_masks(dw, golden):
     yt = dw.dsp.fk_filter_filt(xc, g["m_classic"], tapering=True)
     assert rel(yt, g["y_classic_taper"]) < TOL
     assert np.array_equal(xc, x)            # not modified in place (documented deviation)
+    # opt-in: the reference's side effect (dsp.py:744-745 tapers the caller's array on the way), NumPy and CUDA inputs
+    yt2 = dw.dsp.fk_filter_filt(xc, g["m_classic"], tapering=True, inplace_taper=True)
+    assert rel(yt2, g["y_classic_taper"]) < TOL
+    assert rel(xc, orc.taper_data(x.copy())) < TOL and not np.array_equal(xc, x)
+    xg = torch.from_numpy(x).float().cuda()
+    yt3 = dw.dsp.fk_filter_sparsefilt(xg, g["m_classic"], tapering=True, inplace_taper=True)
+    assert rel(yt3.cpu().numpy(), g["y_classic_taper"]) < TOL and rel(xg.cpu().numpy(), orc.taper_data(x.copy())) < TOL
 
 
 def test_golden_second_shape_and_coo(dw, golden):

@@ -305,14 +305,31 @@ def test_zero_padded_template_on_rows_that_drift(dw):
         assert e.max() < TOL, e
     one = dw.detect.compute_cross_correlogram(xs, hf)                        # host in, host out
     assert per_row(one, refs[0]).max() < TOL
-    # what the term is worth here, and which rows the per-row rule leaves alone
+    # what the term is worth here
     bare = dw.detect.compute_cross_correlograms(xd, [hf, lf], exact_tail=False)
     e0 = per_row(bare[0].cpu().numpy(), refs[0])
     assert e0[2::4].min() > 1e-4 and e0[3::4].min() > 1e-4 and e0[1::4].max() < 1e-6, e0
+    # round 6: the default adds the term inside the correlator (d4w_xcorr_mm_tail_f32), on EVERY row -- no row keeps the bare value,
+    # the band-limited ones move by less than 1e-6 of their maximum
     same = (bare[0] == got[0]).all(dim=1).cpu().numpy()
-    assert same[1::4].all() and not same[0::4].any() and not same[2::4].any() and not same[3::4].any(), same
+    assert not same.any(), same
+    moved = per_row(got[0].cpu().numpy(), bare[0].cpu().numpy().astype(np.float64))
+    assert moved[1::4].max() < 1e-6 and moved[2::4].min() > 1e-4, moved
     full = dw.detect.compute_cross_correlograms(xd, [hf, lf], exact_tail=True)
     assert per_row(full[0].cpu().numpy(), refs[0]).max() < TOL
+    # ... and the two-pass form of rounds 1-5 (prefix maxima + d4w_xcorr_dc_tail_rows_f32, decided per row) still stands behind
+    # D4W_XCORR_TAIL=pass: the rows it leaves alone are the band-limited ones only, and it agrees with the in-kernel form
+    import os
+    os.environ["D4W_XCORR_TAIL"] = "pass"
+    try:
+        old = dw.detect.compute_cross_correlograms(xd, [hf, lf])
+    finally:
+        del os.environ["D4W_XCORR_TAIL"]
+    same_old = (bare[0] == old[0]).all(dim=1).cpu().numpy()
+    assert same_old[1::4].all() and not same_old[0::4].any() and not same_old[2::4].any() and not same_old[3::4].any(), same_old
+    for a, b, ref in zip(old, got, refs):
+        assert per_row(a.cpu().numpy(), ref).max() < TOL
+        assert per_row(a.cpu().numpy(), b.cpu().numpy().astype(np.float64)).max() < 3e-6
 
 
 def test_row_statistics_are_not_reused_after_a_raw_pointer_write(dw):

@@ -42,18 +42,23 @@ def _worker(rank, world, port, nx, ns, q):
         y_local = fn(x[a:b])
         y = shard.all_gather_rows(y_local, nx)
         y2 = shard.map_channel_blocks(fn, x)
-        ok = bool(torch.equal(y, fn(x)) and torch.equal(y2, y))
+        # the direct form (N - 1 grouped isend / irecv pairs straight into the result's row ranges: every point-to-point link
+        # busy), blocking and behind other work
+        y3 = shard.all_gather_rows(y_local, nx, how="direct")
+        y4, work = shard.all_gather_rows(y_local, nx, how="direct", async_op=True)
+        work.wait()
+        ok = bool(torch.equal(y, fn(x)) and torch.equal(y2, y) and torch.equal(y3, y) and torch.equal(y4, y))
         q.put((rank, ok, (a, b)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nx,ns", [(10, 33), (7, 16)])                # even and uneven blocks
-def test_all_gather_rows_world2(nx, ns):
+@pytest.mark.parametrize("world,nx,ns", [(2, 10, 33), (2, 7, 16), (3, 8, 5), (3, 2, 9)])    # even / uneven blocks, a rank without rows
+def test_all_gather_rows(world, nx, ns):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, nx, ns, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nx, ns, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -62,7 +67,7 @@ def test_all_gather_rows_world2(nx, ns):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     blocks = sorted(b for _, _, b in res)
-    assert blocks[0][0] == 0 and blocks[0][1] == blocks[1][0] and blocks[1][1] == nx
+    assert blocks[0][0] == 0 and blocks[-1][1] == nx and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
 
 
 def _picks_worker(rank, world, port, nx, q):
