@@ -105,10 +105,9 @@ def _load():
         "d4w_xcorr_mm_rowmax_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
         "d4w_xcorr_mm_tail_max_support": (c_int, []),
-        "d4w_xcorr_mm_tail_ws_bytes": (ctypes.c_size_t, [c_int, c_int]),
         "d4w_xcorr_mm_tail_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                           c_int, c_int, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p]),
+                                          c_void_p]),
         "d4w_xcorr_fft_max_support": (c_int, []),
         "d4w_xcorr_fft_ws_bytes": (ctypes.c_size_t, []),
         "d4w_xcorr_fft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

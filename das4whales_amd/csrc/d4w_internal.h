@@ -140,33 +140,41 @@ __device__ __forceinline__ int d4w_mul24(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ float d4w_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
 
-// Cache policy of the f-k passes' streaming accesses to the block (round 6, scripts/probe/copy_ceiling.hip: a block of 9.6 GB is
-// read once and written once per pass and never fits a cache; non-temporal loads read at up to 7.4 TB/s against 6.5 plain,
-// an in-place pass with nt loads + nt stores ran 5.68 against 5.38 TB/s).  D4W_FK_LD / D4W_FK_ST: 0 = plain, 1 = nt.
-#ifndef D4W_FK_LD
-#define D4W_FK_LD 0
-#endif
-#ifndef D4W_FK_ST
-#define D4W_FK_ST 0
-#endif
+// Cache policy of the f-k passes' streaming accesses to the block (round 6).  A 9.6-GB block is read once and written once per
+// pass and never fits a cache; scripts/probe/copy_ceiling.hip: non-temporal loads read at up to 7.4 TB/s against 6.5 plain, an
+// in-place sweep with nt loads + nt stores ran 5.68 against 5.38 TB/s.  In the passes themselves (variant builds on one box,
+// profiles/r06c/fk_policy_ab.txt) it pays where a pass reads and writes the same tile in place AND nothing reads the result
+// back soon: pass A' (3.57-3.75 ms against 3.80-3.86) and pass C forward (2.43-2.45 against 2.52-2.53); on pass A forward nt
+// STORES cost 8 % (4.18 against 3.87-3.92 ms: its output is pass C's input) and pass C inverse is a wash.  NT = 1: non-temporal.
+template <int NT>
 __device__ __forceinline__ float2 fk_ldg(const float2* p) {
-#if D4W_FK_LD == 1 && !defined(D4W_EMU)
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p));
-    return make_float2(v.x, v.y);
-#else
+#ifndef D4W_EMU
+    if constexpr (NT == 1) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p));
+        return make_float2(v.x, v.y);
+    }
+#endif
     return *p;
-#endif
 }
+template <int NT>
 __device__ __forceinline__ void fk_stg(float2* p, float2 v) {
-#if D4W_FK_ST == 1 && !defined(D4W_EMU)
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    f2v t; t.x = v.x; t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<f2v*>(p));
-#else
-    *p = v;
+#ifndef D4W_EMU
+    if constexpr (NT == 1) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v t; t.x = v.x; t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<f2v*>(p));
+        return;
+    }
 #endif
+    *p = v;
 }
+#ifndef D4W_FK_NT_AINV
+#define D4W_FK_NT_AINV 1
+#endif
+#ifndef D4W_FK_NT_CFWD
+#define D4W_FK_NT_CFWD 1
+#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() on gfx9 lowers to
 // `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, which would drain the global prefetch loads and the

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
                 const float2* p = src + (size_t)c2 * G::M + col;
                 static_for<G::C1>([&](auto cc) {
                     constexpr int c1 = decltype(cc)::value;
-                    R.pf[c1] = fk_ldg(p + (size_t)c1 * G::C2 * G::M);
+                    R.pf[c1] = fk_ldg<0>(p + (size_t)c1 * G::C2 * G::M);
                 });
                 R.tw = P.twt[col];
                 if (TAPER) R.win = P.win[col];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_fwd(FkDev P, const float2* 
                 float2* o = dst + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
                 static_for<G::N1>([&](auto kk) {
                     constexpr int q1 = decltype(kk)::value;
-                    fk_stg(o + q1 * G::N2, c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur)));
+                    fk_stg<0>(o + q1 * G::N2, c_mul(v[q1], c_mul(tw_cur[q1 * G::TA + tt], tc_cur)));
                 });
             } else if constexpr (MODE == 1) {
                 dft<G::N1>(v);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
                 const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
                 static_for<G::N1>([&](auto kk) {
                     constexpr int q1 = decltype(kk)::value;
-                    R.pf[q1] = fk_ldg(p + q1 * G::N2);
+                    R.pf[q1] = fk_ldg<D4W_FK_NT_AINV>(p + q1 * G::N2);
                 });
                 R.tc = P.twc[hi * G::C2 + c2];
             } else if constexpr (MODE == 1) {            // sub-rows of local row c2 C1 + hi from the packed buffer
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv(FkDev P, float2* __rest
                 float2* o = data + (size_t)c2 * G::M + hi * G::N2 + b0 + tt;
                 static_for<G::C1>([&](auto cc) {
                     constexpr int c1 = decltype(cc)::value;
-                    fk_stg(o + (size_t)c1 * G::C2 * G::M, c_scale(v[c1], P.scale));
+                    fk_stg<D4W_FK_NT_AINV>(o + (size_t)c1 * G::C2 * G::M, c_scale(v[c1], P.scale));
                 });
             } else if constexpr (MODE == 1) {            // C1 consecutive local rows, no channel transform
                 float2* o = data + (size_t)c2 * G::C1 * G::M + hi * G::N2 + b0 + tt;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
                 const float2* p = data + ((size_t)hi * G::C2 + c2) * G::M + b0 + tt;
                 static_for<G::N1>([&](auto kk) {
                     constexpr int q1 = decltype(kk)::value;
-                    R.pf[q1] = fk_ldg(p + q1 * G::N2);
+                    R.pf[q1] = fk_ldg<D4W_FK_NT_AINV>(p + q1 * G::N2);
                 });
                 R.tc = P.twc[hi * G::C2 + c2];
             } else {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(G::THRA) void fkf_passA_inv_stats(FkDev P, float2* 
                 static_for<G::C1>([&](auto cc) {
                     constexpr int c1 = decltype(cc)::value;
                     const float2 y2 = c_scale(v[c1], P.scale);
-                    fk_stg(o + (size_t)c1 * G::C2 * G::M, y2);
+                    fk_stg<D4W_FK_NT_AINV>(o + (size_t)c1 * G::C2 * G::M, y2);
                     asum[c1] += y2.x + y2.y;
                     amax[c1] = fmaxf(amax[c1], fmaxf(fabsf(y2.x), fabsf(y2.y)));
                 });
@@ -755,14 +755,14 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
             const float2* bh = base + (size_t)hi * PITCH();
             static_for<RA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
-                pf[a] = fk_ldg(bh + (size_t)(a * RB) * PITCH());
+                pf[a] = fk_ldg<D4W_FK_NT_CFWD>(bh + (size_t)(a * RB) * PITCH());
             });
         } else {
             const unsigned bits = livel[q * RA + hi];       // dead rows are zeros by construction
             const float2* bh = base + (size_t)(hi * RB) * PITCH();
             static_for<RB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
-                pf[b] = ((bits >> b) & 1u) ? fk_ldg(bh + (size_t)b * PITCH()) : make_float2(0.f, 0.f);
+                pf[b] = ((bits >> b) & 1u) ? fk_ldg<0>(bh + (size_t)b * PITCH()) : make_float2(0.f, 0.f);
             });
         }
     };
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 const unsigned bits = livel[q * RA + hi];   // dead rows are never read again
                 static_for<RB>([&](auto bb) {
                     constexpr int b = decltype(bb)::value;
-                    if ((bits >> b) & 1u) fk_stg(base + (size_t)(hi * RB) * PITCH() + (size_t)b * PITCH(), v[b]);
+                    if ((bits >> b) & 1u) fk_stg<D4W_FK_NT_CFWD>(base + (size_t)(hi * RB) * PITCH() + (size_t)b * PITCH(), v[b]);
                 });
             } else {
                 float2 pw[RA];
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(G::THRC) void fkf_passC(FkDev P, FkFastDev F, float
                 idft<RA>(v);
                 static_for<RA>([&](auto aa) {
                     constexpr int a = decltype(aa)::value;
-                    fk_stg(base + (size_t)hi * PITCH() + (size_t)(a * RB) * PITCH(), v[a]);
+                    fk_stg<0>(base + (size_t)hi * PITCH() + (size_t)(a * RB) * PITCH(), v[a]);
                 });
             }
         }

@@ -81,8 +81,6 @@ struct MmArgs {
     int accumulate;         // add to y0 instead of overwriting it (the later sections of a long template)
     // TAIL kernels (the zero-padded template's constant tail, detect.py:158, added in the epilogue -- see xcorr_mm_rows):
     float tail0, tail1;             // mean(t) / max|t| of template 0 / 1 over its zero-padded length (0: nothing to add)
-    unsigned long long* gran;       // [nx][chunks per row][4 waves] {tag << 32 | float bits}: each wave's share of a chunk's normalised de-meaned sum
-    int* tickets;                   // [8] next chunk of each XCD range (gran and tickets are zeroed by the host per launch)
 };
 
 // inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside the 16-lane DPP rows, then row_bcast:15 /
@@ -109,45 +107,31 @@ __device__ __forceinline__ float mm_wave_scan(float v) {
 #endif
 }
 
-// the 8-byte granule {tag, float}: ONE relaxed agent-scope store / load each (global_store / global_load_dwordx2 sc1: written
-// through, read past the L1), so a reader sees either the zero the host left or the complete pair -- no fence, nothing else
-// is handed over (MI355X guide: granule hand-off)
-__device__ __forceinline__ void mm_gran_store(unsigned long long* p, float v) {
-    const unsigned long long g = (1ull << 32) | (unsigned long long)__float_as_uint(v);
-#ifdef D4W_EMU
-    *p = g;
-#else
-    __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ unsigned long long mm_gran_load(const unsigned long long* p) {
-#ifdef D4W_EMU
-    return *p;
-#else
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-
 // KS0 / KS1: k-steps of template 0 / 1 (KS1 = 0: one template); WPS: workgroups per compute unit the registers are budgeted for.
 //
 // TAIL: the kernel also adds the constant tail of the de-meaned ZERO-PADDED template (detect.py:158 normalises the template over
 // its padded length, which leaves -mean(t) / max|t| on the padding): lag k receives  tail_t * P[k + L_t],  P[j] = sum_{i < j} xh[i]
-// the prefix sum of the normalised row, for k + L_t < ns (L_t a multiple of 4: the host extends the support by the padding's
-// own value).  Rounds 1-5 added the term in a second pass over x and y, decided per row on prefix maxima from a third sweep
-// (d4w_row_stats_prefix_f32, d4w_xcorr_dc_tail_rows_f32): the public call cost 1.5 x the kernel.  Here it is exact for every
-// row at no extra pass:
-//   * the conversion phase already holds every sample of the chunk: a wave prefix scan (DPP) of the scaled samples goes to
-//     LDS beside the binary16 halves (local prefix per 256-thread segment + the segments' offsets), and the epilogue reads
-//     P[k + L] for its four lags with one 16-byte LDS read per template;
-//   * the prefix at the chunk's START is the sum of the row's earlier chunks, which other workgroups hold: at the top of an
-//     iteration every wave PUBLISHES its share of the chunk's sum as an 8-byte {tag, value} granule (before the workgroup waits
-//     for anything), asks for the shares of the row's earlier chunks, and looks at them behind its conversion phase -- before
-//     the next chunk's loads are issued, so that a poll never queues behind them (a spin only if a share is late);
-//   * chunks are CLAIMED from a ticket counter per XCD range instead of being dealt statically, three chunks ahead: a chunk
-//     is then only ever held by a RUNNING workgroup and waits point to smaller chunk numbers only, so the scheme cannot
-//     deadlock whatever part of the grid is resident (a neighbour kernel may hold compute units).  Summation orders are
-//     fixed (per lane, DPP tree, segment order, xor tree over the granules): results do not depend on timing.
-template <int KS0, int KS1, int WPS, bool TAIL = false>
+// the prefix sum of the normalised row (P[j >= ns] = the row's sum = 0).  Rounds 1-5 added the term in a second pass over x and y,
+// decided per row on prefix maxima from a third sweep (d4w_row_stats_prefix_f32, d4w_xcorr_dc_tail_rows_f32): the public call
+// cost 1.5 x the kernel.  Here it is exact for every row at no extra pass, in two pieces:
+//   * INSIDE a block of 16 lags the term is itself a Toeplitz product: P[16 a + i + L] - P[16 a] = sum_{u < L + i} xh[16 a + u],
+//     i.e. the taps t[d] + tail for -15 <= d < L in place of t[d] (d = u - i; zero beyond) -- the matrix instructions that form
+//     the correlation form it with it, for nothing (the staged taps get the constant added, that is all);
+//   * what remains is ONE number per block of 16 lags, tail * P[16 a]: the conversion phase sums each lane's four samples, a
+//     wave prefix scan (DPP) gives the prefix at every fourth lane = every block of 16 samples, one float per block goes to
+//     LDS (1 KiB per chunk), and a tile's epilogue adds tail * (row prefix at the chunk + segment offset + block prefix) to its
+//     lags.  A wave's tiles are the segments it converted itself: only the 16 segment totals cross waves;
+//   * the prefix at the chunk's START is carried in a register (float64): a workgroup of a TAIL kernel walks the chunks of ONE
+//     ROW in order and takes whole rows (row = workgroup + k x grid) instead of chunks dealt over the grid.  (The first two
+//     builds kept the chunk dealing and handed every chunk's sum to the workgroups holding the row's later chunks -- 8-byte
+//     {tag, value} granules, ticketed chunks: correct, and 3.4 x slower than the kernel without the term, 21.9 against 6.4 ms:
+//     a granule takes several microseconds from one compute unit to another while the memory system is saturated, and every
+//     chunk waited for one; the third build kept a full prefix array in LDS, 17 KiB per buffer: 8.1 against 6.1 ms;
+//     profiles/r06b, r06c, r06d.)  The price of whole rows is the tail of the launch (20 000 rows over 512 workgroups: 39.06
+//     rows each) and 512 streams a row apart instead of 8 compact windows.
+// WMAX: the epilogue also leaves the rows' maxima (P.rowmax0 / rowmax1) -- a separate instantiation, so that the kernels without
+// them carry neither the branches nor the registers (round 5 had it as a kernel-argument branch in every tile's epilogue).
+template <int KS0, int KS1, int WPS, bool TAIL = false, bool WMAX = false>
 __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     constexpr int KSM = KS0 > KS1 ? KS0 : KS1;
     using GEO = MmGeom<KSM>;
@@ -156,10 +140,9 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     D4W_DYN_LDS(smem_raw);
     mm_half* lds = reinterpret_cast<mm_half*>(smem_raw);           // [2 buffers][hi | lo][kMmArr]
     float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [2][4] chunk maxima of the waves
-    float* pl = red + 8;                                            // TAIL: [2][kMmArr] prefix sums inside a wave's segment
-    float* wt = pl + 2 * kMmArr;                                    // TAIL: [2][kSeg] the segments' totals
-    float* wo = wt + 2 * kSeg;                                      // TAIL: [4 waves][kSeg] prefix at each segment's start
-    int* tkl = reinterpret_cast<int*>(wo + 4 * kSeg);               // TAIL: [2] tickets on their way from thread 0 to the workgroup
+    constexpr int kBlk = kMmCH / 16;                                // blocks of 16 lags per chunk (256)
+    float* pb = red + 8;                                            // TAIL: [2][kBlk] prefix at every block of 16 samples, inside its wave's segment
+    float* wt = pb + 2 * kBlk;                                      // TAIL: [2][16] the segments' totals (a segment = 256 samples = one wave's share of 1024)
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = mm_uniform(tid >> 6);
     const int n16 = lane & 15, g = lane >> 4;
@@ -171,24 +154,26 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     const int nparts = min(8, (int)gridDim.x);
     const int xcd = (int)blockIdx.x % nparts, wq = (int)blockIdx.x / nparts, nq = ((int)gridDim.x - xcd + nparts - 1) / nparts;
     const long long lo_c = total * xcd / nparts, hi_c = total * (xcd + 1) / nparts;
-    // Tickets are asked for where their return does not wait for anything else: a wave's memory operations return in order, so
-    // the value of an atomic is there once everything ISSUED BEFORE it has returned -- asked for right behind the next chunk's
-    // loads and looked at one iteration later (when those loads have been consumed anyway), the output stores of the matrix
-    // phase in between are not waited for.  Thread 0 carries the pending ticket; the workgroup learns it behind the barrier.
-    int tk_pending = 0;
-    if constexpr (TAIL) {
-        if (tid == 0) {                                             // the first three claims (their latency hides under the fragment build)
-            tkl[0] = atomicAdd(P.tickets + xcd, 1);
-            tkl[1] = atomicAdd(P.tickets + xcd, 1);
-            tk_pending = atomicAdd(P.tickets + xcd, 1);
-        }
-    }
-
     // ---- the templates' Toeplitz fragments: A_t[kk][i = n16][u = 32 kk + 8 g + j] = t[u - i] / ts_t, split hi / lo
     mm_h8 a0h[KS0], a0l[KS0];
     mm_h8 a1h[KS1 ? KS1 : 1], a1l[KS1 ? KS1 : 1];
     float osc0 = 1.f, osc1 = 1.f;                                   // output scales: the power of two taken out of the taps
-    long long c_n = lo_c + wq, c_nn = 0;
+    // TAIL: whole rows (row = workgroup + k x grid), their chunks in order; else chunk lo_c + wq + k nq of the XCD's range
+#ifdef D4W_MM_V_TAIL_DEALT          // (probe builds: the tail kernels with the chunks dealt over the grid -- WRONG prefixes, timing only)
+    constexpr bool kRows = false;
+#else
+    constexpr bool kRows = TAIL;
+#endif
+    auto next_chunk = [&](long long c) -> long long {
+        if constexpr (kRows) {
+            const long long r = c / nchunk;
+            return (c - r * nchunk + 1 < nchunk) ? c + 1 : (r + (long long)gridDim.x) * nchunk;
+        } else {
+            return c + nq;
+        }
+    };
+    const long long end_c = kRows ? total : hi_c;
+    long long c_n = kRows ? (long long)blockIdx.x * nchunk : lo_c + wq;
     {
         // taps -> LDS first (zero outside the support), so that the 8 x KS fragment values of a lane are LDS reads
         float* tl = reinterpret_cast<float*>(smem_raw);              // [2][16 + kMmHalo] before the row buffers are in use
@@ -196,7 +181,11 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         for (int i = tid; i < 2 * TLP; i += kMmThreads) {
             const int t = i / TLP, u = i - t * TLP - 15;
             const int L = t ? P.len1 : P.len0;
-            tl[i] = (u >= 0 && u < L && (t == 0 || KS1 > 0)) ? P.taps[(size_t)t * P.ltaps + u] : 0.f;
+            float tv = (u >= 0 && u < L && (t == 0 || KS1 > 0)) ? P.taps[(size_t)t * P.ltaps + u] : 0.f;
+            if constexpr (TAIL) {                                   // the term inside a block of 16 lags: t[d] + tail for every d < L
+                if (u < L && (t == 0 || KS1 > 0)) tv += t ? P.tail1 : P.tail0;
+            }
+            tl[i] = tv;
         }
         __syncthreads();
         auto build = [&](const float* tp, int L, auto& ah, auto& al, auto ks, float& osc) {
@@ -222,10 +211,6 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         };
         build(tl, P.len0, a0h, a0l, std::integral_constant<int, KS0>{}, osc0);
         if constexpr (KS1 > 0) build(tl + TLP, P.len1, a1h, a1l, std::integral_constant<int, KS1>{}, osc1);
-        if constexpr (TAIL) {                                       // (tkl lies beyond the tap staging area: thread 0's claims are visible now)
-            c_n = lo_c + mm_uniform(tkl[0]);
-            c_nn = lo_c + mm_uniform(tkl[1]);
-        }
         __syncthreads();                                            // the row buffers take this space over
     }
 
@@ -300,11 +285,12 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         }
     };
 
-    if (c_n < hi_c) issue(c_n);
+    if (c_n < end_c) issue(c_n);
     int buf = 0;
-    const bool want_max = P.rowmax0 != nullptr;                     // kernel argument: a scalar branch
-    bool dead = false;                                              // TAIL: a granule never arrived (outputs poisoned from there on, no further waits)
-    for (long long c = c_n; c < hi_c;) {
+    constexpr bool want_max = WMAX;
+    // TAIL: prefix of the normalised row at the chunk's first sample, a float64 kept as two wave-uniform floats (scalar registers)
+    float pst_hi = 0.f, pst_lo = 0.f;
+    for (long long c = c_n; c < end_c;) {
         const int row = row_n, c0 = c0_n;
         const Mean2 mu = mu_n;
         const bool tail = tail_n;
@@ -314,28 +300,10 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool own_scale = !P.maxabs || heavy_n;                // wave- and workgroup-uniform (one row per chunk)
         mm_half* bh = lds + (size_t)buf * 2 * kMmArr;
         mm_half* bl = bh + kMmArr;
-        const long long c_next = TAIL ? c_nn : c + nq;
-        // TAIL: this wave's share of the chunk's sum goes out FIRST (before this workgroup waits for anything), then the shares of
-        // the row's earlier chunks are asked for; they are looked at behind the conversion phase, before the next chunk's loads
-        // are issued -- a wave's memory operations return in order, and a poll queued behind 17 KB of HBM loads would wait for
-        // them (the first build of this kernel did exactly that: 20.7 ms instead of 6.2).
+        const long long c_next = next_chunk(c);
         const int cin = c0 / kMmCH;                                 // the chunk's number inside its row
-        unsigned long long gv0 = 0ull, gv1 = 0ull;
-        float pst = 0.f;                                            // prefix of the normalised row at the chunk's first sample
-        if constexpr (TAIL) {
-            const float mlgn = -mu.lo * g_n;
-            float part = 0.f;
-            static_for<(kMmCH / (4 * kMmThreads))>([&](auto qq) {   // the chunk's OWN samples: the first 4096 of the stage
-                constexpr int q = decltype(qq)::value;
-                const float4 v = pre[q];
-                part += (fmaf(v.x - mu.hi, g_n, mlgn) + fmaf(v.y - mu.hi, g_n, mlgn)) + (fmaf(v.z - mu.hi, g_n, mlgn) + fmaf(v.w - mu.hi, g_n, mlgn));
-            });
-            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-            unsigned long long* grow = P.gran + ((size_t)row * nchunk) * 4;
-            if (lane == 0) mm_gran_store(grow + 4 * cin + wv, part);
-            if (lane < 4 * cin) gv0 = mm_gran_load(grow + lane);
-            if (lane + 64 < 4 * cin) gv1 = mm_gran_load(grow + lane + 64);
-        }
+        if (TAIL && cin == 0) { pst_hi = 0.f; pst_lo = 0.f; }
+        const float pst = pst_hi;
         // ---- convert the loaded chunk: (x - mu) * scale -> hi / lo halves in LDS
         if (own_scale) {
             // no row maximum from the caller, or a row that is all offset: this chunk's own power of two.  (With a row maximum the rows are scaled by
@@ -396,45 +364,20 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 mm_split_put4(s, bh + at, bl + at);
 #endif
             }
-            if constexpr (TAIL) {
-                // prefix sums of the scaled samples inside this wave's segment (every lane takes part: the idle ones add zeros)
-                const float p1 = s[0], p2 = s[0] + s[1], p3 = p2 + s[2], t4 = p3 + s[3];
-                const float inc = mm_wave_scan(t4), exc = inc - t4;
-                if (mine) *reinterpret_cast<float4*>(pl + (size_t)buf * kMmArr + at) = make_float4(exc, exc + p1, exc + p2, exc + p3);
-                if (lane == 63) wt[buf * kSeg + 4 * q + wv] = inc;
+#ifdef D4W_MM_V_TAIL_NOSCAN         // (probe builds: no prefix scan, no tail term -- timing only)
+            if constexpr (false) {
+#else
+            if constexpr (TAIL && q < kMmCH / (4 * kMmThreads)) {   // the chunk's own 4096 samples (the halo adds no block of lags)
+#endif
+                // prefix of the scaled samples at every fourth lane = every block of 16 samples, inside this wave's segment
+                const float t4 = (s[0] + s[1]) + (s[2] + s[3]);
+                const float inc = mm_wave_scan(t4);
+                if ((lane & 3) == 0) pb[buf * kBlk + 64 * q + 16 * wv + (lane >> 2)] = inc - t4;
+                if (lane == 63) wt[buf * 16 + 4 * q + wv] = inc;
             }
         });
-        if constexpr (TAIL) {
-            // the earlier chunks of the row were claimed before this one and their shares went out at the top of their owners'
-            // iterations: normally all here by now; a late one is polled (bounded: a share that never arrives poisons the outputs
-            // instead of hanging the device)
-            const int ng = 4 * cin;
-            for (int base = 0; base < ng; base += 64) {
-                const int n = min(ng - base, 64);
-                unsigned long long gq = (base == 0) ? gv0 : (base == 64) ? gv1 : 0ull;
-                int spins = 0;
-                while (true) {
-                    const bool ok = lane >= n || (unsigned)(gq >> 32) == 1u;
-                    if (__all(ok)) break;
-                    if (dead || ++spins > (1 << 20)) { dead = true; gq = (1ull << 32) | 0x7FC00000ull; break; }
-#ifndef D4W_EMU
-                    __builtin_amdgcn_s_sleep(2);
-#endif
-                    if (!ok) gq = mm_gran_load(P.gran + ((size_t)row * nchunk) * 4 + base + lane);
-                }
-                float v = lane < n ? __uint_as_float((unsigned)gq) : 0.f;
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                pst += v;
-            }
-        }
         // ---- next chunk's loads fly across the barrier and the matrix phase
-        if (c_next < hi_c) issue(c_next);
-        if constexpr (TAIL) {
-            if (tid == 0) {
-                tkl[buf] = tk_pending;                              // asked for one iteration ago: the chunk after the next one
-                tk_pending = atomicAdd(P.tickets + xcd, 1);
-            }
-        }
+        if (c_next < end_c) issue(c_next);
         lds_barrier();
         // ---- 16 tiles of 256 lags, 4 per wave: C[i][a] (+)= A[i][u] B[u][a]
         float* ya = P.y0 + (size_t)row * ns;
@@ -442,15 +385,26 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
         const float oxs = (own_scale && P.maxabs) ? osx * gout : osx;
         const float o0 = osc0 * oxs, o1 = osc1 * oxs;
-        // TAIL: the segments' start offsets (this wave's own table)
-        const float* plb = pl + (size_t)buf * kMmArr;
-        const float* wob = wo + wv * kSeg;
+        // TAIL: the prefix at each segment's start (lane l: segment l) and the chunk's sum, which moves the row's prefix on (every
+        // wave forms the same values from the same LDS words)
+        float segoff = 0.f;
         if constexpr (TAIL) {
-            c_nn = lo_c + mm_uniform(tkl[buf]);
-            const float w = lane < kSeg ? wt[buf * kSeg + lane] : 0.f;
+            const float w = lane < 16 ? wt[buf * 16 + lane] : 0.f;
             const float inc = mm_wave_scan(w);
-            if (lane < kSeg) wo[wv * kSeg + lane] = inc - w;
-            mm_wave_sync();
+            segoff = inc - w;
+#ifdef D4W_EMU
+            const float own = __shfl(inc, 15);
+#else
+            const float own = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 15));
+#endif
+            const double pd = ((double)pst_hi + (double)pst_lo) + (double)(own * oxs);
+            const float ph = (float)pd, pl2 = (float)(pd - (double)ph);
+#ifdef D4W_EMU
+            pst_hi = ph; pst_lo = pl2;
+#else
+            pst_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ph)));
+            pst_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl2)));
+#endif
         }
         // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
         // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
@@ -499,21 +453,25 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                     if constexpr (KS1 > 0) r1[r] = fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)) * o1;
                 });
                 c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
+#ifdef D4W_MM_V_TAIL_NOSCAN
+                if constexpr (false) {
+#else
                 if constexpr (TAIL) {
-                    auto add_tail = [&](float (&r)[4], float tc, int L) {
-                        if (tc != 0.f) {                             // kernel argument: a scalar branch
-                            const int idx = kl + L;                  // L % 4 == 0: the four prefixes are one 16-byte word of one segment
-                            const float4 pv = *reinterpret_cast<const float4*>(plb + idx);
-                            const float base = fmaf(wob[idx >> 8], oxs, pst);
-                            const float t0 = fmaf(pv.x, oxs, base), t1 = fmaf(pv.y, oxs, base), t2 = fmaf(pv.z, oxs, base), t3 = fmaf(pv.w, oxs, base);
-                            if (k + L < ns) r[0] = fmaf(tc, t0, r[0]);
-                            if (k + 1 + L < ns) r[1] = fmaf(tc, t1, r[1]);
-                            if (k + 2 + L < ns) r[2] = fmaf(tc, t2, r[2]);
-                            if (k + 3 + L < ns) r[3] = fmaf(tc, t3, r[3]);
-                        }
-                    };
-                    add_tail(r0, P.tail0, P.len0);
-                    if constexpr (KS1 > 0) add_tail(r1, P.tail1, P.len1);
+#endif
+                    // tile T = the segment this wave converted: prefix at the block's first sample = row prefix at the chunk +
+                    // segment offset + block prefix (the same number for both templates and for the lane's four lags)
+#ifdef D4W_EMU
+                    const float so = __shfl(segoff, T);
+#else
+                    const float so = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, segoff), T));
+#endif
+                    const float pbk = fmaf(so + pb[buf * kBlk + 16 * T + n16], oxs, pst);
+                    const float a0 = P.tail0 * pbk;
+                    r0[0] += a0; r0[1] += a0; r0[2] += a0; r0[3] += a0;
+                    if constexpr (KS1 > 0) {
+                        const float a1 = P.tail1 * pbk;
+                        r1[0] += a1; r1[1] += a1; r1[2] += a1; r1[3] += a1;
+                    }
                 }
                 if (valign && k + 3 < ns) {
                     if (KS1 == 0 && P.accumulate) {                 // a later section of a long template
@@ -578,6 +536,13 @@ int d4w_xcorr_mm_max_support(void) { return kMmSection * kMmMaxSections; }
 
 // one template of any support <= d4w_xcorr_mm_max_support(): sections of kMmSection taps, the first one overwriting y, the
 // later ones (x shifted by the section's first tap) accumulating into it
+// launch of xcorr_mm_rows<KS0, KS1, WPS, TAIL> with or without the row maxima
+#define D4W_MM_LAUNCH(KS0, KS1, WPS, TAIL, grid, lds, stream, Q)                                                              \
+    do {                                                                                                                      \
+        if ((Q).rowmax0) D4W_LAUNCH((xcorr_mm_rows<KS0, KS1, WPS, TAIL, true>), dim3(grid), dim3(kMmThreads), lds, stream, Q);  \
+        else D4W_LAUNCH((xcorr_mm_rows<KS0, KS1, WPS, TAIL, false>), dim3(grid), dim3(kMmThreads), lds, stream, Q);             \
+    } while (0)
+
 static int mm_one_template(MmArgs P, const float* taps, int len, float* y, float* rowmax, int grid, void* stream) {
     auto lds_of = [](int arr) { return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float); };
     const int nsec = (len <= 32 * kMmKSMax - 15) ? 1 : ceil_div(len, kMmSection);
@@ -597,13 +562,13 @@ static int mm_one_template(MmArgs P, const float* taps, int len, float* y, float
         Q.rowmax1 = nullptr;
         const int ks = ceil_div(Q.len0 + 15, 32);
         if (ks <= kMmKS)
-            D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr), stream, Q);
+            D4W_MM_LAUNCH(kMmKS, 0, 3, false, grid, lds_of(MmGeom<kMmKS>::Arr), stream, Q);
         else if (ks <= kMmKSLong)
-            D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr), stream, Q);
+            D4W_MM_LAUNCH(kMmKSLong, 0, 2, false, grid, lds_of(MmGeom<kMmKSLong>::Arr), stream, Q);
         else if (ks <= 12)
-            D4W_LAUNCH((xcorr_mm_rows<12, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<12>::Arr), stream, Q);
+            D4W_MM_LAUNCH(12, 0, 2, false, grid, lds_of(MmGeom<12>::Arr), stream, Q);
         else
-            D4W_LAUNCH((xcorr_mm_rows<kMmKSMax, 0, 2>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSMax>::Arr), stream, Q);
+            D4W_MM_LAUNCH(kMmKSMax, 0, 2, false, grid, lds_of(MmGeom<kMmKSMax>::Arr), stream, Q);
     }
     return D4W_OK;
 }
@@ -619,21 +584,15 @@ int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, 
                             const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, float* y0, float* y1,
                             float* rowmax0, float* rowmax1, void* stream) {
     return d4w_xcorr_mm_tail_f32(x, nx, ns, xnext, ld_next, n_next, mean, maxabs, taps, ntpl, ltaps, len0, len1, 0.0, 0.0, y0, y1,
-                                 rowmax0, rowmax1, nullptr, stream);
+                                 rowmax0, rowmax1, stream);
 }
 
 // longest support the kernels take WITH the zero-padded template's tail added in the epilogue: one launch per template
-// (the 12-step kernel: the 16-step one has no registers left for the prefix sums)
-int d4w_xcorr_mm_tail_max_support(void) { return (32 * 12 - 15) / 4 * 4; }
-
-size_t d4w_xcorr_mm_tail_ws_bytes(int nx, int ns) {
-    if (nx < 1 || ns < 1) return 0;
-    return ((size_t)nx * (size_t)ceil_div(ns, kMmCH) * 4 + 8) * sizeof(unsigned long long) * 2;     // 4 granules per chunk + tickets, per template launch
-}
+int d4w_xcorr_mm_tail_max_support(void) { return 32 * kMmKSMax - 15; }
 
 int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next, const double* mean,
                           const float* maxabs, const float* taps, int ntpl, int ltaps, int len0, int len1, double tail0, double tail1,
-                          float* y0, float* y1, float* rowmax0, float* rowmax1, void* ws, void* stream) {
+                          float* y0, float* y1, float* rowmax0, float* rowmax1, void* stream) {
     if (!x || !y0 || !taps || nx < 1 || ns < 1) return fail(D4W_EINVAL, "bad argument");
     if (ntpl == 2 && ((rowmax0 == nullptr) != (rowmax1 == nullptr))) return fail(D4W_EINVAL, "rowmax0 and rowmax1 go together");
     if (ntpl < 1 || ntpl > 2 || (ntpl == 2 && !y1)) return fail(D4W_EINVAL, "ntpl = %d (1 or 2 templates per call)", ntpl);
@@ -643,11 +602,10 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
         return fail(D4W_EINVAL, "template supports (%d, %d) must lie in 1..min(ltaps = %d, %d)", len0, len1, ltaps, d4w_xcorr_mm_max_support());
     const bool tails = tail0 != 0.0 || tail1 != 0.0;
     if (tails) {
-        // the tail is a prefix sum of the NORMALISED row read 16 bytes at a time: statistics, supports that are multiples of 4
-        // (the caller extends a support by the padding's own value, -tail: detect.py:158) and one launch per template
-        if (!mean || !maxabs || !ws) return fail(D4W_EINVAL, "the zero-padded template's tail needs the rows' statistics and a workspace (d4w_xcorr_mm_tail_ws_bytes)");
-        if ((len0 & 3) || (len1 & 3) || std::max(len0, len1) > d4w_xcorr_mm_tail_max_support())
-            return fail(D4W_EINVAL, "with a tail the supports (%d, %d) must be multiples of 4 and <= %d", len0, len1, d4w_xcorr_mm_tail_max_support());
+        // the tail is a prefix sum of the NORMALISED row: the rows' statistics, and one launch per template
+        if (!mean || !maxabs) return fail(D4W_EINVAL, "the zero-padded template's tail needs the rows' statistics (mean, maxabs)");
+        if (std::max(len0, len1) > d4w_xcorr_mm_tail_max_support())
+            return fail(D4W_EINVAL, "with a tail the supports (%d, %d) must be <= %d", len0, len1, d4w_xcorr_mm_tail_max_support());
     }
     MmArgs P;
     P.x = x; P.xnext = xnext; P.mean = mean; P.maxabs = maxabs; P.taps = taps; P.y0 = y0; P.y1 = y1;
@@ -656,7 +614,7 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
     static const int env_clamp = [] { const char* v = getenv("D4W_MM_CLAMP"); return v ? atoi(v) : 0; }();
     P.clamp = (xnext != nullptr && n_next > 0) || env_clamp;
     P.rowmax0 = rowmax0; P.rowmax1 = (ntpl == 2) ? rowmax1 : nullptr;
-    P.tail0 = (float)tail0; P.tail1 = (float)tail1; P.gran = nullptr; P.tickets = nullptr;
+    P.tail0 = (float)tail0; P.tail1 = (float)tail1;
     if (rowmax0) {                                                  // -inf: the identity of the epilogue's integer-atomic float max
         D4W_HIP(hipMemsetD32Async((hipDeviceptr_t)rowmax0, (int)0xFF800000u, (size_t)nx, (hipStream_t)stream));
         if (ntpl == 2) D4W_HIP(hipMemsetD32Async((hipDeviceptr_t)rowmax1, (int)0xFF800000u, (size_t)nx, (hipStream_t)stream));
@@ -669,41 +627,21 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
     static const int env_wgs = [] { const char* v = getenv("D4W_MM_WGS"); const int n = v ? atoi(v) : 0; return n < 0 ? 0 : (n > 8 ? 8 : n); }();
     const int ks0 = ceil_div(len0 + 15, 32), ks1 = ceil_div(len1 + 15, 32);
     const bool fused = ntpl == 2 && std::max(ks0, ks1) <= kMmKS;
-    // (with a tail the prefix sums take 17 KiB more LDS per buffer: two workgroups per compute unit at most)
-    const int per_cu = env_wgs ? std::min(env_wgs, tails ? 2 : 8) : ((ntpl == 1 && ks0 <= kMmKS && !tails) ? 3 : 2);
+    const int per_cu = env_wgs ? env_wgs : ((ntpl == 1 && ks0 <= kMmKS) ? 3 : 2);
     const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
     auto lds_of = [](int arr, bool tl) {
-        const int seg = 4 * ceil_div(arr - 8, 4 * kMmThreads);          // MmGeom::Q segments of 1024 samples x 4 waves
-        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * arr + 6 * seg) * sizeof(float) + 2 * sizeof(int) : 0);
+        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * (kMmCH / 16) + 2 * 16) * sizeof(float) : 0);
     };
     if (tails) {
-        // one launch per template group; its granules and tickets start from zero
-        const size_t half = ((size_t)nx * nchunk * 4 + 8) * sizeof(unsigned long long);
-        auto prep = [&](MmArgs& Q, int which) -> int {
-            char* base = (char*)ws + (size_t)which * half;
-            D4W_HIP(hipMemsetAsync(base, 0, half, (hipStream_t)stream));
-            Q.gran = (unsigned long long*)base;
-            Q.tickets = (int*)(base + (size_t)nx * nchunk * 4 * sizeof(unsigned long long));
-            return D4W_OK;
-        };
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<5, kMmKS, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKS, kMmKS, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKS, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<kMmKSLong, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)xcorr_mm_rows<12, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            attr = true;
-        }
+        // whole rows per workgroup (the prefix is carried along a row): at most one workgroup per row
+        const int grid_t = (int)std::min<long long>((long long)nx, (long long)ncu * per_cu);
         if (fused) {
-            int rc = prep(P, 0);
-            if (rc) return rc;
             const size_t lds = lds_of(MmGeom<kMmKS>::Arr, true);
             if (ks0 <= 5)
-                D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2, true>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+                D4W_MM_LAUNCH(5, kMmKS, 2, true, grid_t, lds, stream, P);
             else
-                D4W_LAUNCH((xcorr_mm_rows<kMmKS, kMmKS, 2, true>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+                D4W_MM_LAUNCH(kMmKS, kMmKS, 2, true, grid_t, lds, stream, P);
             return D4W_OK;
         }
         for (int t = 0; t < ntpl; ++t) {
@@ -716,15 +654,20 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
             Q.y1 = nullptr;
             Q.rowmax0 = t ? rowmax1 : rowmax0;
             Q.rowmax1 = nullptr;
-            int rc = prep(Q, t);
-            if (rc) return rc;
             const int ks = ceil_div(Q.len0 + 15, 32);
-            if (ks <= kMmKS)
-                D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr, true), stream, Q);
+            if (ks <= kMmKS) {
+                // (three workgroups per compute unit fit the registers only without the row maxima)
+                if (Q.rowmax0)
+                    D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 2, true, true>), dim3(grid_t), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr, true), stream, Q);
+                else
+                    D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3, true, false>), dim3(grid_t), dim3(kMmThreads), lds_of(MmGeom<kMmKS>::Arr, true), stream, Q);
+            }
             else if (ks <= kMmKSLong)
-                D4W_LAUNCH((xcorr_mm_rows<kMmKSLong, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<kMmKSLong>::Arr, true), stream, Q);
+                D4W_MM_LAUNCH(kMmKSLong, 0, 2, true, grid_t, lds_of(MmGeom<kMmKSLong>::Arr, true), stream, Q);
+            else if (ks <= 12)
+                D4W_MM_LAUNCH(12, 0, 2, true, grid_t, lds_of(MmGeom<12>::Arr, true), stream, Q);
             else
-                D4W_LAUNCH((xcorr_mm_rows<12, 0, 2, true>), dim3(grid), dim3(kMmThreads), lds_of(MmGeom<12>::Arr, true), stream, Q);
+                D4W_MM_LAUNCH(kMmKSMax, 0, 2, true, grid_t, lds_of(MmGeom<kMmKSMax>::Arr, true), stream, Q);
         }
         return D4W_OK;
     }
@@ -737,9 +680,9 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
     }
     const size_t lds = lds_of(MmGeom<kMmKS>::Arr, false);
     if (ks0 <= 5)
-        D4W_LAUNCH((xcorr_mm_rows<5, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+        D4W_MM_LAUNCH(5, kMmKS, 2, false, grid, lds, stream, P);
     else
-        D4W_LAUNCH((xcorr_mm_rows<kMmKS, kMmKS, 2>), dim3(grid), dim3(kMmThreads), lds, stream, P);
+        D4W_MM_LAUNCH(kMmKS, kMmKS, 2, false, grid, lds, stream, P);
     return D4W_OK;
 }
 

@@ -160,13 +160,13 @@ def _xcorr_method(taps_list, ns, method):
 
 def _tails_in_kernel(taps_list, coefs, ns, how):
     """Whether the zero-padded templates' constant tails (detect.py:158) can be added inside the matrix-core correlator
-    (d4w_xcorr_mm_tail_f32: exact on every row, no second pass): the matrix-core form, supports -- extended to a multiple of 4
-    by the padding's own value -- of at most d4w_xcorr_mm_tail_max_support() samples and shorter than the rows.
+    (d4w_xcorr_mm_tail_f32: exact on every row, no second pass): the matrix-core form, supports of at most
+    d4w_xcorr_mm_tail_max_support() samples (one launch per template) and shorter than the rows.
     D4W_XCORR_TAIL=pass keeps the two-pass form of rounds 1-5 (A/B measurements)."""
     import os
     if how != "mm" or not any(c != 0.0 for c in coefs) or os.environ.get("D4W_XCORR_TAIL", "kernel") == "pass":
         return False
-    longest = max(-(-len(t) // 4) * 4 for t in taps_list)
+    longest = max(len(t) for t in taps_list)
     return longest <= int(lib.d4w_xcorr_mm_tail_max_support()) and longest < ns
 
 
@@ -186,9 +186,6 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
     if tails is not None:
         if how != "mm" or not normalize or len(tails) != len(taps_list):
             raise ValueError("in-kernel template tails need the matrix-core form, normalize=True and one coefficient per template")
-        # the support becomes a multiple of 4 (the kernel reads the prefix sums 16 bytes at a time): the extra taps carry the
-        # value the zero-padded, de-meaned template has there, -mean(t) / max|t| (detect.py:158)
-        taps_list = [np.concatenate((np.asarray(t, dtype=np.float64), np.full((-len(t)) % 4, -float(c)))) for t, c in zip(taps_list, tails)]
     if cont is not None:
         nxt, n_next = cont
         if not (how in ("mm", "fft") and (how == "mm" or len(taps_list) == 2) and nxt.is_cuda and nxt.dtype == torch.float32
@@ -213,7 +210,6 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
                 taps, lt, _, _ = _xf_prepared(grp, x.device, ws=False)
                 rm = [torch.empty(nx, dtype=torch.float32, device=x.device) for _ in grp] if row_max is not None else None
                 tc = [float(c) for c in tails[i:i + 2]] if tails is not None else [0.0]
-                tws = torch.empty(int(lib.d4w_xcorr_mm_tail_ws_bytes(nx, ns)), dtype=torch.uint8, device=x.device) if any(tc) else None
                 check(lib.d4w_xcorr_mm_tail_f32(dev.ptr(x), nx, ns,
                                                 dev.ptr(cont[0]) if cont is not None else None,
                                                 int(cont[0].stride(0)) if cont is not None else 0,
@@ -222,7 +218,7 @@ def _xcorr_device(x, taps_list, normalize, method="auto", stats=None, cont=None,
                                                 dev.ptr(taps), len(grp), lt, len(grp[0]), len(grp[-1]), tc[0], tc[-1] if len(grp) > 1 else 0.0,
                                                 dev.ptr(ys[0]), dev.ptr(ys[1]) if len(ys) > 1 else None,
                                                 dev.ptr(rm[0]) if rm else None, dev.ptr(rm[1]) if rm and len(rm) > 1 else None,
-                                                dev.ptr(tws) if tws is not None else None, dev.stream_ptr(x)))
+                                                dev.stream_ptr(x)))
                 outs.extend(ys)
                 if rm:
                     row_max.extend(rm)

@@ -133,9 +133,7 @@ class FileStream:
             # like the file's own samples) -- no concatenated copy, no cropped copies of the correlograms
             rmax = []
             inker = self._tails_in_kernel(ns)
-            # (with the tail inside the kernel the supports are extended to multiples of 4: the continuation covers those taps too)
-            n_cont = (-(-self.lmax // 4) * 4 if inker else self.lmax) - 1
-            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, min(n_cont, next_head.shape[1])),
+            cs = detect._xcorr_device(y, self.taps, normalize=True, stats=(mean, mx), cont=(next_head, self.lmax - 1),
                                       row_max=rmax, tails=self.tail if inker else None)
             if len(rmax) == len(cs):
                 out["row_max"] = rmax        # max over the lags of every row, per template (detect.correlogram_max)

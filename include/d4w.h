@@ -364,17 +364,15 @@ int d4w_xcorr_mm_rowmax_f32(const float* x, int nx, int ns, const float* xnext, 
  * leaves -mean(t) / max|t| on the padding) in ONE pass over x, exact on every row:
  *   y_t[c][k] += tail_t * g[c] * sum_{i < k + len_t} (x[c][i] - m[c]),  k + len_t < ns;   tail_t = mean(t) / max|t| (0: no term).
  * (d4w_xcorr_dc_tail_rows_f32 adds the same term in a second pass over x and y, decided per row; this entry replaces the pair for
- * supports up to d4w_xcorr_mm_tail_max_support() = 368.)  The prefix sum is formed inside the kernel: local prefix scans in the
- * sample-conversion phase, each 4096-lag chunk's sum handed to the workgroups that hold the row's later chunks as 8-byte
- * {tag, value} granules (one per wave), chunks claimed from a ticket counter (csrc/xcorr_mm.hip).  Needs mean and maxabs; len0 / len1 multiples of
- * 4 (a caller extends a support by the padding's own value -tail_t); ws: DEVICE workspace of d4w_xcorr_mm_tail_ws_bytes(nx, ns)
- * bytes (zeroed by the call).  tail0 == tail1 == 0: d4w_xcorr_mm_rowmax_f32 (ws may be NULL). */
+ * supports up to d4w_xcorr_mm_tail_max_support() = 497: one launch per template.)  Inside a block of 16 lags the term is part of
+ * the Toeplitz product itself (the constant added to the staged taps); per block one prefix from a scan in the sample-conversion
+ * phase; the prefix at a chunk's start carried along the row in float64 -- a workgroup walks whole rows (csrc/xcorr_mm.hip).
+ * Needs mean and maxabs.  tail0 == tail1 == 0: d4w_xcorr_mm_rowmax_f32. */
 int d4w_xcorr_mm_tail_max_support(void);
-size_t d4w_xcorr_mm_tail_ws_bytes(int nx, int ns);
 int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, int ld_next, int n_next,
                           const double* mean, const float* maxabs, const float* taps, int ntpl, int ltaps,
                           int len0, int len1, double tail0, double tail1, float* y0, float* y1,
-                          float* rowmax0, float* rowmax1, void* ws, void* stream);
+                          float* rowmax0, float* rowmax1, void* stream);
 
 /* Zero-phase FIR along time by overlap-save FFT blocks -- the INTERIOR of dsp.bp_filt / scipy.signal.sosfiltfilt
  * (dsp.py:859-880): away from the row ends a zero-phase IIR filter is the convolution with its two-sided response

@@ -9,7 +9,12 @@ build)
     bash scripts/probe/build_variant.sh mm_oldsplit xcorr_mm.hip -DD4W_MM_V_OLDSPLIT
     bash scripts/probe/build_variant.sh mm_nonan xcorr_mm.hip -DD4W_MM_V_NONAN
     bash scripts/probe/build_variant.sh mm_floatmean xcorr_mm.hip -DD4W_MM_V_FLOATMEAN
-    bash scripts/probe/build_variant.sh mm_ch8192 xcorr_mm.hip -DD4W_MM_CH=8192 ;;
+    bash scripts/probe/build_variant.sh mm_ch8192 xcorr_mm.hip -DD4W_MM_CH=8192
+    bash scripts/probe/build_variant.sh mm_taildealt xcorr_mm.hip -DD4W_MM_V_TAIL_DEALT
+    bash scripts/probe/build_variant.sh mm_tailnoscan xcorr_mm.hip -DD4W_MM_V_TAIL_NOSCAN ;;
+build_tail)
+    bash scripts/probe/build_variant.sh mm_taildealt xcorr_mm.hip -DD4W_MM_V_TAIL_DEALT
+    bash scripts/probe/build_variant.sh mm_tailnoscan xcorr_mm.hip -DD4W_MM_V_TAIL_NOSCAN ;;
 run)
     OUT=$2; mkdir -p $OUT
     fmt='
@@ -24,7 +29,7 @@ for l in sys.stdin:
 '
     for rep in 1 2; do
         (cd _ab/r4 && timeout 300 python scripts/time_xcorr_mm.py 2>/dev/null | python -c "$fmt" "r4        rep $rep")
-        for tag in base mm_oldsplit mm_nonan mm_floatmean mm_ch8192; do
+        for tag in ${TAGS:-base mm_oldsplit mm_nonan mm_floatmean mm_ch8192 mm_taildealt mm_tailnoscan}; do
             lib=$PWD/das4whales_amd/lib/probe/libd4w_$tag.so
             [ $tag = base ] && lib=$PWD/das4whales_amd/lib/libd4w.so
             [ -f $lib ] || continue

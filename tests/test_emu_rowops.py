@@ -624,36 +624,35 @@ def test_xcorr_mm_row_maxima_from_the_epilogue(emu, l0, l1):
 
 
 def xcorr_mm_tail_emu(lib, x, templates, want_max=False):
-    """d4w_xcorr_mm_tail_f32 the way detect.compute_cross_correlograms drives it: supports extended to a multiple of 4 by the
-    padding's own value, tail coefficients mean(t) / max|t| over the zero-padded length."""
+    """d4w_xcorr_mm_tail_f32 the way detect.compute_cross_correlograms drives it: the templates' supports, tail coefficients
+    mean(t) / max|t| over the zero-padded length."""
     xf = np.ascontiguousarray(x, dtype=np.float32)
     nx, ns = xf.shape
     taps_list, coefs = [], []
     for tpl in templates:
         tp, c = norm_taps(tpl), float(tpl.mean() / np.max(np.abs(tpl)))
-        taps_list.append(np.concatenate((tp, np.full((-len(tp)) % 4, -c))))
+        taps_list.append(tp)
         coefs.append(c)
-    lt = max(len(t) for t in taps_list)
+    lt = max(4, -(-max(len(t) for t in taps_list) // 4) * 4)
     taps = np.zeros((len(taps_list), lt), dtype=np.float32)
     for i, t in enumerate(taps_list):
         taps[i, :len(t)] = t
     mean, mx = np.empty(nx, dtype=np.float64), np.empty(nx, dtype=np.float32)
     assert lib.d4w_row_stats_f32(vp(xf), nx, ns, vp(mean), vp(mx), None) == 0
-    lib.d4w_xcorr_mm_tail_ws_bytes.restype = ctypes.c_size_t
-    ws = np.full(int(lib.d4w_xcorr_mm_tail_ws_bytes(nx, ns)), 0xAB, dtype=np.uint8)       # (the call zeroes what it uses)
     ys = [np.full_like(xf, np.nan) for _ in taps_list]
     rm = [np.full(nx, np.nan, np.float32) for _ in taps_list] if want_max else [None] * 2
     rc = lib.d4w_xcorr_mm_tail_f32(vp(xf), nx, ns, None, 0, 0, vp(mean), vp(mx), vp(taps), len(taps_list), lt, len(taps_list[0]),
                                    len(taps_list[-1]), ctypes.c_double(coefs[0]), ctypes.c_double(coefs[-1] if len(coefs) > 1 else 0.0),
                                    vp(ys[0]), vp(ys[1]) if len(ys) > 1 else None,
-                                   vp(rm[0]) if want_max else None, vp(rm[1]) if want_max and len(ys) > 1 else None, vp(ws), None)
+                                   vp(rm[0]) if want_max else None, vp(rm[1]) if want_max and len(ys) > 1 else None, None)
     assert rc == 0, lib.d4w_last_error()
     return (ys, rm) if want_max else ys
 
 
 def test_zero_padded_template_tail_inside_the_matrix_core_correlator(emu):
     """Round 6: the constant tail of the de-meaned zero-padded template (detect.py:158) is added in the correlator's own epilogue
-    (prefix scan in the conversion phase + the earlier chunks' sums as granules): the whole of detect.compute_cross_correlogram
+    (inside a block of 16 lags as part of the Toeplitz product itself, one prefix per block from a scan in the conversion phase,
+    the prefix at a chunk's start carried along the row): the whole of detect.compute_cross_correlogram
     in one pass, on EVERY row -- white, band-limited, a slow drift, a step (the rows a white-noise prediction let through at
     3e-4 .. 2e-3 in rounds 1-4) -- for rows of several chunks, ragged row ends, both fin-call templates in one launch, one
     template alone, a template with a clearly non-zero mean, supports that are not multiples of 4."""
@@ -687,15 +686,12 @@ def test_zero_padded_template_tail_inside_the_matrix_core_correlator(emu):
         assert e < 2e-6, ("one template", k, e)
     (y2,) = xcorr_mm_tail_emu(emu, x, [lf])
     assert np.max(np.abs(y2 - refs[1])) / np.max(np.abs(refs[1])) < 2e-6
-    # the contract: supports that are multiples of 4, statistics and a workspace
+    # the contract: the rows' statistics
     taps = np.zeros((1, 8), np.float32)
-    mean, mx = np.zeros(5), np.ones(5, np.float32)
     y = np.empty((5, ns), np.float32)
     xs = np.ascontiguousarray(x, dtype=np.float32)
-    assert emu.d4w_xcorr_mm_tail_f32(vp(xs), 5, ns, None, 0, 0, vp(mean), vp(mx), vp(taps), 1, 8, 7, 7, ctypes.c_double(1e-3),
-                                     ctypes.c_double(0.0), vp(y), None, None, None, vp(y), None) == -1
-    assert emu.d4w_xcorr_mm_tail_f32(vp(xs), 5, ns, None, 0, 0, vp(mean), vp(mx), vp(taps), 1, 8, 8, 8, ctypes.c_double(1e-3),
-                                     ctypes.c_double(0.0), vp(y), None, None, None, None, None) == -1
+    assert emu.d4w_xcorr_mm_tail_f32(vp(xs), 5, ns, None, 0, 0, None, None, vp(taps), 1, 8, 8, 8, ctypes.c_double(1e-3),
+                                     ctypes.c_double(0.0), vp(y), None, None, None, None) == -1
 
 
 def test_row_maximum_of_a_row_with_nan_is_nan(emu):

@@ -308,4 +308,6 @@ def test_benchmark_step_is_the_public_calls_and_matches_the_oracle(dw):
         got = c[rows].cpu().numpy()
         for k in range(len(rows)):
             e = float(np.max(np.abs(got[k] - ref[k])) / np.max(np.abs(ref[k])))
-            assert e < 2e-6, (name, "after the rows were rewritten", rows[k], e)
+            # (the smooth rows' correlograms are small against the rows themselves -- the templates have no response at 1 / 300 Hz --
+            # so float32 rounding of the products weighs more against the row's own maximum: 5e-6 here; without the tail term 1e-3)
+            assert e < 1e-5, (name, "after the rows were rewritten", rows[k], e)
