@@ -34,17 +34,6 @@ constexpr int kXfPad = 160;                        // lags lost per block = max 
 constexpr int kXfStep = kXfB - kXfPad;             // 3936 lags per block
 constexpr int kXfThreads = 128;               // one item per thread in every stage
 constexpr int kXfRowP = kXfMB + kXfNG;             // LDS row pitch: one pad element per group
-#ifndef D4W_XF_LDSPAD
-#define D4W_XF_LDSPAD 0
-#endif
-#ifndef D4W_XF_LDSPAD_BACK
-#define D4W_XF_LDSPAD_BACK D4W_XF_LDSPAD
-#endif
-constexpr int kXfLdsPad = D4W_XF_LDSPAD;           // probe builds: unused bytes in front of ...
-constexpr int kXfLdsPadBack = D4W_XF_LDSPAD_BACK;  // ... and behind the blocks kernel's LDS
-#ifdef D4W_XF_SELFCHECK
-__device__ unsigned long long g_xf_check[8];       // [pass][dword of the 16-byte word]: LDS words that did not hold what was written
-#endif
 
 __host__ __device__ constexpr int xf_ad(int e) { return e + e / kXfNC; }
 // frequency held by position e after the three DIF stages (digits a', b', d)
@@ -140,26 +129,18 @@ __device__ __forceinline__ void xf_pair(c2 A, c2 Bs, float2 w, float2 gf, float2
 // LDS tile STORES of these kernels are 8 bytes wide, not 16 (round 5).  With the matrix-core STFT (stft_mm_rows) resident on
 // the same CU from another HIP stream, whole blocks of the first row of a row pair -- dwords 0 and 2 of the tile's 16-byte
 // words -- came out 1-10 % off in a few workgroups per launch (scripts/probe/stream_race2.py, fence off: 6 of 6 trials with
-// ds_read_b128 + ds_write_b128, 1 of 24 / 2 of 45 with 8-byte stores, 0 of 36 and later 3 of 120 with 8-byte reads as
-// well: narrower accesses are less exposed, not immune -- the cross-stream fence is what makes the results safe).  The
-// neighbour needs its matrix instructions AND their operands coming out of LDS for it (without either: 0 of 12; without its
-// LDS writes: still 6 of 6), synthetic matrix / vector / LDS neighbours do nothing.  Not understood beyond that (DESIGN.md
-// section 1; d4w_internal.h: hazard_enter).  The 8-byte stores cost nothing and stay; 8-byte READS cost 2 % (cols) to 10 %
-// (between two files) of the band-pass and buy nothing over the stores once the fence is there: D4W_XF_LD64 (probe builds)
-// selects them, D4W_XF_ST128 the 16-byte stores.
+// ds_read_b128 + ds_write_b128, 1 of 24 / 2 of 45 with 8-byte stores).  The two families are fenced against each other across
+// streams (hazard_enter / hazard_leave below); round 6 ran these kernels beside kernels of OTHER libraries -- hipBLASLt / rocBLAS
+// GEMMs in binary16 and bfloat16 (small tiles, 256 x 256 macro tiles, split-K), MIOpen's binary16 convolution -- 40 trials per
+// pair bit for bit (tests/test_concurrent_gpu.py, profiles/r06*/concurrency_trials.txt): nothing moved, so the exposure is this
+// library's own pair, and the probe switches of round 5 (16-byte stores, 8-byte reads, LDS padding, the in-kernel read-back
+// check) are gone from this file; scripts/probe/ and DESIGN.md section 1 keep what they found.
 __device__ __forceinline__ c2 xf_ld(const float4* p) {
-#if defined(D4W_XF_LD64) && !defined(D4W_EMU)
-    typedef float f2_t __attribute__((ext_vector_type(2)));
-    typedef const volatile f2_t __attribute__((address_space(3))) * lds_f2_ptr;
-    const f2_t lo = ((lds_f2_ptr)p)[0], hi = ((lds_f2_ptr)p)[1];
-    return c2{v2_make(lo.x, lo.y), v2_make(hi.x, hi.y)};
-#else
     const float4 v = lds_read4(p);
     return c2{v2_make(v.x, v.y), v2_make(v.z, v.w)};
-#endif
 }
 __device__ __forceinline__ void xf_st(float4* p, c2 v) {
-#if !defined(D4W_XF_ST128) && !defined(D4W_EMU)
+#if !defined(D4W_EMU)
     typedef float f2_t __attribute__((ext_vector_type(2)));
     typedef volatile f2_t __attribute__((address_space(3))) * lds_f2_ptr;
     f2_t lo, hi;
@@ -201,7 +182,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     // (the gain the subtracted constant would have had)
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
     D4W_DYN_LDS(smem_raw);
-    float4* buf = reinterpret_cast<float4*>(smem_raw + kXfLdsPad);   // [ROWP] block spectra of both rows, then each template's correlation
+    float4* buf = reinterpret_cast<float4*>(smem_raw);   // [ROWP] block spectra of both rows, then each template's correlation
     float2* tw1 = reinterpret_cast<float2*>(buf + (FUSED ? 2 : 1) * ROWP);        // [M1]
     float2* tw2 = tw1 + M1;                                     // [NB][NC]
     const int tsel = FUSED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
@@ -321,19 +302,6 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
                 constexpr int a = decltype(aa)::value;
                 xf_st(buf + xf_ad(j1 + a * M1), (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]));
             });
-#ifdef D4W_XF_SELFCHECK       // probe builds: does the LDS hold what this lane has just written? (and again after a barrier and a wait)
-            for (int pass = 0; pass < 2; ++pass) {
-                if (pass) { __syncthreads(); for (int w = 0; w < 64; ++w) __builtin_amdgcn_s_sleep(16); __syncthreads(); }
-                static_for<NA>([&](auto aa) {
-                    constexpr int a = decltype(aa)::value;
-                    const c2 want = (a == 0) ? pf[0] : c2_mulw(pf[a], pw[a]);
-                    const float4 got = lds_read4(buf + xf_ad(j1 + a * M1));
-                    const float w4[4] = {v2_x(want.re), v2_y(want.re), v2_x(want.im), v2_y(want.im)}, g4[4] = {got.x, got.y, got.z, got.w};
-                    for (int q = 0; q < 4; ++q)
-                        if (__float_as_uint(w4[q]) != __float_as_uint(g4[q])) atomicAdd(&g_xf_check[pass * 4 + q], 1ull);
-                });
-            }
-#endif
         }
         // the middle stage's table operands: issued here, in flight across S2
         float2 GA[NC], GB[NC];
@@ -1170,7 +1138,7 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
         D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(ntpl * kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, ntpl,
                    ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2) + kXfLdsPad + kXfLdsPadBack;
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1255,14 +1223,6 @@ int d4w_xcorr_fft_cont_f32(const float* x, int nx, int ns, const float* xnext, i
  * The columns within K of either row end are NOT written.  first[r] (a constant per row, e.g. the row's first sample)
  * is subtracted from the samples before the transform and first[r] * dc_gain added back (dc_gain = sum of the taps
  * as the exact filter has it), which keeps a large offset out of the float32 transform. */
-#ifdef D4W_XF_SELFCHECK
-int d4w_xf_selfcheck_read(unsigned long long* host8, int reset) {
-    D4W_HIP(hipDeviceSynchronize());
-    D4W_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_xf_check), sizeof(g_xf_check)));
-    if (reset) { unsigned long long z[8] = {}; D4W_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xf_check), z, sizeof(z))); }
-    return D4W_OK;
-}
-#endif
 int d4w_fir_fft_max_halfwidth(void) { return (kXfB - 2048) / 2; }
 
 int d4w_fir_fft_f32(const float* x, int nx, int ns, const float* taps, int K, const float* first, double dc_gain,
@@ -1296,7 +1256,7 @@ static int d4w_fir_fft_cols_f32_run(const float* x0, int nx, int ns0, const floa
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns_out, step), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2) + kXfLdsPad + kXfLdsPadBack;
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
                (float*)nullptr, step, K, ns_out, (float)dc_gain, XfHalo{}, first, ld);
@@ -1336,7 +1296,7 @@ static int d4w_fir_fft_halo_f32_run(const float* x, int nx, int ns, const float*
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2) + kXfLdsPad + kXfLdsPadBack;
+    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};

@@ -140,8 +140,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     D4W_DYN_LDS(smem_raw);
     mm_half* lds = reinterpret_cast<mm_half*>(smem_raw);           // [2 buffers][hi | lo][kMmArr]
     float* red = reinterpret_cast<float*>(lds + 4 * kMmArr);       // [2][4] chunk maxima of the waves
-    constexpr int kBlk = kMmCH / 16;                                // blocks of 16 lags per chunk (256)
-    float* pb = red + 8;                                            // TAIL: [2][kBlk] prefix at every block of 16 samples, inside its wave's segment
+    constexpr int kBlk = kMmCH / 4;                                 // lanes x loads of a chunk's own samples (1024): one prefix each, every fourth one is a block of 16's
+    float* pb = red + 8;                                            // TAIL: [2][kBlk] prefix before each lane's four samples, inside its wave's segment
     float* wt = pb + 2 * kBlk;                                      // TAIL: [2][16] the segments' totals (a segment = 256 samples = one wave's share of 1024)
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = mm_uniform(tid >> 6);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 // prefix of the scaled samples at every fourth lane = every block of 16 samples, inside this wave's segment
                 const float t4 = (s[0] + s[1]) + (s[2] + s[3]);
                 const float inc = mm_wave_scan(t4);
-                if ((lane & 3) == 0) pb[buf * kBlk + 64 * q + 16 * wv + (lane >> 2)] = inc - t4;
+                pb[buf * kBlk + kMmThreads * q + tid] = inc - t4;        // (every lane stores: no exec-mask juggling; the epilogue reads every fourth)
                 if (lane == 63) wt[buf * 16 + 4 * q + wv] = inc;
             }
         });
@@ -447,32 +447,29 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 const int kl = 256 * T + 16 * n16 + 4 * g;          // this lane's four lags inside the chunk ...
                 const int k = c0 + kl;                              // ... and inside the row
                 float r0[4], r1[4];
-                static_for<4>([&](auto rr) {
-                    constexpr int r = decltype(rr)::value;
-                    r0[r] = fmaf(mm_get(c0l, r), kMmLoInv, mm_get(c0h, r)) * o0;
-                    if constexpr (KS1 > 0) r1[r] = fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)) * o1;
-                });
-                c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
+                float a0 = 0.f, a1 = 0.f;                           // TAIL: tail_t x (prefix at the block's first sample), the same for the lane's four lags
 #ifdef D4W_MM_V_TAIL_NOSCAN
                 if constexpr (false) {
 #else
                 if constexpr (TAIL) {
 #endif
-                    // tile T = the segment this wave converted: prefix at the block's first sample = row prefix at the chunk +
-                    // segment offset + block prefix (the same number for both templates and for the lane's four lags)
+                    // tile T = the segment this wave converted: row prefix at the chunk + segment offset + block prefix
 #ifdef D4W_EMU
                     const float so = __shfl(segoff, T);
 #else
                     const float so = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, segoff), T));
 #endif
-                    const float pbk = fmaf(so + pb[buf * kBlk + 16 * T + n16], oxs, pst);
-                    const float a0 = P.tail0 * pbk;
-                    r0[0] += a0; r0[1] += a0; r0[2] += a0; r0[3] += a0;
-                    if constexpr (KS1 > 0) {
-                        const float a1 = P.tail1 * pbk;
-                        r1[0] += a1; r1[1] += a1; r1[2] += a1; r1[3] += a1;
-                    }
+                    const float pbk = fmaf(so + pb[buf * kBlk + kMmThreads * ti + 64 * wv + 4 * n16], oxs, pst);
+                    a0 = P.tail0 * pbk;
+                    a1 = P.tail1 * pbk;
                 }
+                static_for<4>([&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    // (the tail's addend rides the scaling multiply: an FMA instead of a multiply)
+                    r0[r] = fmaf(fmaf(mm_get(c0l, r), kMmLoInv, mm_get(c0h, r)), o0, a0);
+                    if constexpr (KS1 > 0) r1[r] = fmaf(fmaf(mm_get(c1l, r), kMmLoInv, mm_get(c1h, r)), o1, a1);
+                });
+                c0h = mm_zero(); c0l = mm_zero(); c1h = mm_zero(); c1l = mm_zero();
                 if (valign && k + 3 < ns) {
                     if (KS1 == 0 && P.accumulate) {                 // a later section of a long template
                         const float4 o = mm_load4_stream(reinterpret_cast<const float4*>(ya + k));
@@ -631,7 +628,7 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
     const int ncu = mm_num_cus();
     const int grid = (int)std::min<long long>(total, (long long)ncu * per_cu);
     auto lds_of = [](int arr, bool tl) {
-        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * (kMmCH / 16) + 2 * 16) * sizeof(float) : 0);
+        return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * (kMmCH / 4) + 2 * 16) * sizeof(float) : 0);
     };
     if (tails) {
         // whole rows per workgroup (the prefix is carried along a row): at most one workgroup per row

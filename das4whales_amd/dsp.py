@@ -716,6 +716,21 @@ def _sosfiltfilt_recursive(x, sos, padlen, seg_len=None, warm=None):
     return y
 
 
+def _rerun_check(fn, what):
+    """D4W_VERIFY_RERUN=1 (opt-in): the overlap-save FFT kernels behind the zero-phase filters once returned blocks
+    that depended on a kernel of ANOTHER stream resident beside them (fenced for the library's own pair, clean
+    beside every foreign neighbour tried, mechanism open).  With the switch the filter runs twice and the two results are
+    compared bit for bit; a difference raises instead of passing on.  Costs the second run and one host synchronisation."""
+    import os
+    y = fn()
+    if os.environ.get("D4W_VERIFY_RERUN", "0") == "1":
+        y2 = fn()
+        if not torch.equal(y, y2):
+            raise RuntimeError("%s: two runs on the same input differ (max %.3e): a result depended on what else was resident on the "
+                               "device -- see DESIGN.md section 1" % (what, float((y - y2).abs().max())))
+    return y
+
+
 def _sosfiltfilt_device(x, sos, padlen, seg_len=None, warm=None):
     """x: float32 CUDA tensor [nx, ns] -> filtered tensor (new).  Long rows with a response short enough for one FFT
     block run the overlap-save form (interior) + the recursion at the row ends; everything else the recursion.
@@ -756,7 +771,7 @@ def sosfiltfilt(sos, x, axis=-1, padtype="odd", padlen=None):
         ntaps -= min((sos[:, 2] == 0).sum(), (sos[:, 5] == 0).sum())
         padlen = 3 * ntaps
     xd = dev.to_device_f32(x2)
-    y = _sosfiltfilt_device(xd, sos, int(padlen))
+    y = _rerun_check(lambda: _sosfiltfilt_device(xd, sos, int(padlen)), "sosfiltfilt")
     y = y[0] if was1d else y
     return dev.like_input(y, x)
 
@@ -770,7 +785,7 @@ def bp_filt(data, fs, fmin, fmax):
     sos = _bp_sos(float(fs), float(fmin), float(fmax))
     x2, was1d = _rows_2d(data)
     xd = dev.to_device_f32(x2)
-    y = _sosfiltfilt_device(xd, sos, 51)
+    y = _rerun_check(lambda: _sosfiltfilt_device(xd, sos, 51), "bp_filt")
     y = y[0] if was1d else y
     return dev.like_input(y, data)
 

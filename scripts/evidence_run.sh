@@ -11,6 +11,8 @@ R=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; grep "smoke" $O/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | grep "^{" > $O/bench_line.json; cut -c1-300 $O/bench_line.json
+# round 6: the default line times the PUBLIC calls; the composition of rounds 1-5 (plan.apply_stats + _xcorr_device, no tail term) beside it
+timeout 900 python bench.py --steps 20 --warmup 5 --api private --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_line_private_api.json; cut -c1-200 $O/bench_line_private_api.json
 timeout 900 python bench.py --stages bp,fk,mf --steps 10 --warmup 3 --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_bp_fk_mf.json; cut -c1-200 $O/bench_bp_fk_mf.json
 timeout 900 python bench.py --config stream --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_1gpu.json; cut -c1-600 $O/bench_stream_1gpu.json
 # ... everything on ONE stream (the default puts the two detectors of a file on a side stream each)
@@ -18,7 +20,10 @@ timeout 900 python bench.py --config stream --steps 10 --warmup 2 --detector-str
 # round 5: the chain with the detectors on side streams against itself on one stream (which result differs: nothing, since the
 # cross-stream fence), and every stage beside the matrix-core STFT with the fence switched off (the hazard itself)
 timeout 300 python scripts/probe/stream_race.py 2>/dev/null | grep "^{" | cut -c1-300 > $O/stream_race.txt; tail -3 $O/stream_race.txt
-(D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py; [ -f das4whales_amd/lib/probe/libd4w_wide.so ] && D4W_LIB=$PWD/das4whales_amd/lib/probe/libd4w_wide.so D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py) 2>/dev/null | grep "trials" > $O/stream_race2_fence_off.txt; cut -c1-160 $O/stream_race2_fence_off.txt
+(D4W_HAZARD_FENCE=0 LOAD=5 NSTAGES=7 timeout 300 python scripts/probe/stream_race2.py) 2>/dev/null | grep "trials" > $O/stream_race2_fence_off.txt; cut -c1-160 $O/stream_race2_fence_off.txt
+# round 6: the victims beside kernels of OTHER libraries on side streams (hipBLASLt / rocBLAS GEMMs, MIOpen conv), 10 trials per pair here
+# (the 40-trial run is profiles/r06e)
+for fam in "matmul f16" "matmul bf16" "conv2d"; do D4W_FOREIGN_ONLY="$fam" D4W_CONC_TRIALS=10 D4W_CONC_REPORT=$R/$O/concurrency_trials_foreign.txt timeout 600 python -u -m pytest tests/test_concurrent_gpu.py -q -m gpu -s -k foreign > /dev/null 2>&1; done; tail -3 $O/concurrency_trials_foreign.txt
 # the same chain with the raw files in pinned host memory (double-buffered upload on a side stream): 8 files per run as above, and
 # 24 files per run (the first upload and the drain weigh less: the steady-state rate against the PCIe bound)
 timeout 900 python bench.py --config stream --from-host --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_from_host.json; cut -c1-300 $O/bench_stream_from_host.json

@@ -22,7 +22,13 @@ out["snr_tr_array_env"] = ev(lambda: dw.dsp.snr_tr_array(x, env=True))
 out["bp_filt"] = ev(lambda: dw.dsp.bp_filt(x, fs, 14, 30))
 sos = dw.dsp.butterworth_filter([2, 5.0, "hp"], fs)
 out["sosfiltfilt_hp2"] = ev(lambda: dw.dsp.sosfiltfilt(sos, x, axis=1))
-out["compute_cross_correlogram_1tpl"] = ev(lambda: dw.detect.compute_cross_correlogram(x, hf))
+out["compute_cross_correlogram_1tpl"] = ev(lambda: dw.detect.compute_cross_correlogram(x, hf))      # (row statistics remembered)
+def fresh():
+    torch.autograd.graph.increment_version(x)          # as if x had just been written: the statistics are formed again
+    return dw.detect.compute_cross_correlogram(x, hf)
+out["compute_cross_correlogram_1tpl_fresh_block"] = ev(fresh)
+lf = dw.detect.gen_template_fincall(t, fs, 14.7, 21.8, 0.78)
+out["compute_cross_correlograms_2tpl"] = ev(lambda: dw.detect.compute_cross_correlograms(x, [hf, lf]))
 c = dw.detect.compute_cross_correlogram(x, hf)
 thr = 0.45 * float(c.max())
 out["pick_times"] = ev(lambda: dw.detect.pick_times(c, thr))
