@@ -167,8 +167,18 @@ struct XfHalo {
     int ld_left, n_left, ld_right, n_right, v0;
 };
 
-template <int NT, bool FUSED, bool HALO = false>      // HALO: a separate instantiation, the plain kernels keep their code
-__global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
+// SUBS (round 6): blocks of a row pair that ONE workgroup transforms side by side, each on its own kXfThreads threads and its own
+// LDS -- the one-template kernel runs SUBS = 4: 512 threads and 152 KiB, i.e. the whole LDS of a compute unit (the launch asks for
+// 159 KiB), with the occupancy the four 128-thread workgroups per CU had before.  The point is what CANNOT be resident beside it:
+// these kernels returned wrong blocks with certain LDS-fed matrix kernels on the same CU (the library's own STFT in round 5; a
+// rocBLAS GEMM, 256 x 32768 x 256 in binary16 / bfloat16, in 39-40 of 40 trials in round 6), and with the CU's LDS claimed no
+// kernel that needs LDS can be (0 of 20 trials each; profiles/r06g/splitk_neighbour.txt).  Blocks beyond the row's last one do
+// nothing (their lags lie outside the output) but keep the barriers' company.
+constexpr int kXfSubs = 4;
+constexpr size_t kXfItemLds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+
+template <int NT, bool FUSED, bool HALO = false, int SUBS = 1>      // HALO: a separate instantiation, the plain kernels keep their code
+__global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) void xcorr_fft_blocks(XfTables T, const float* __restrict__ x, int nx,
                                                                   int ns, const double* __restrict__ mean,
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1,
@@ -181,12 +191,22 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     // (the zero-phase FIR use, d4w_fir_fft_f32: taps centred at yshift); dcg: mean[row] * dcg is added to every output
     // (the gain the subtracted constant would have had)
     constexpr int NA = kXfNA, NB = kXfNB, NC = kXfNC, M1 = kXfM1, MB = kXfMB, ROWP = kXfRowP;
+    static_assert(!(FUSED && SUBS > 1), "sub-blocks are for the one-template kernel");
     D4W_DYN_LDS(smem_raw);
-    float4* buf = reinterpret_cast<float4*>(smem_raw);   // [ROWP] block spectra of both rows, then each template's correlation
+#ifdef D4W_EMU
+    const int sub = SUBS > 1 ? (int)(threadIdx.x >> 7) : 0;
+#else
+    const int sub = SUBS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;          // 128 threads = two whole waves
+#endif
+    float4* buf = reinterpret_cast<float4*>(smem_raw + (size_t)sub * kXfItemLds);   // [ROWP] block spectra of both rows, then each template's correlation
     float2* tw1 = reinterpret_cast<float2*>(buf + (FUSED ? 2 : 1) * ROWP);        // [M1]
     float2* tw2 = tw1 + M1;                                     // [NB][NC]
+#ifdef D4W_EMU
+    const int tsel = FUSED ? (int)(threadIdx.x >> 7) : 0;
+#else
     const int tsel = FUSED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
-    const int tid = FUSED ? (int)(threadIdx.x & (kXfThreads - 1)) : (int)threadIdx.x;
+#endif
+    const int tid = (FUSED || SUBS > 1) ? (int)(threadIdx.x & (kXfThreads - 1)) : (int)threadIdx.x;
     const bool fwd = !FUSED || tsel == 0;                         // this wave runs the forward stages
     float4* mine = FUSED ? (tsel ? buf : buf + ROWP) : buf;       // row buffer of this wave's template
     if (fwd) {
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(FUSED ? 2 * kXfThreads : kXfThreads, 2) void xcorr_
     const int rowA = 2 * blockIdx.y;
     const bool hasB = rowA + 1 < nx;
     const int rowB = hasB ? rowA + 1 : rowA;
-    const int k0 = blockIdx.x * step;                           // first lag / first sample of the block
+    const int k0 = ((int)blockIdx.x * SUBS + sub) * step;       // first lag / first sample of the block
     const size_t pitch = ld ? (size_t)ld : (size_t)ns;
     const float* xa = x + (size_t)rowA * pitch;
     const float* xb = x + (size_t)rowB * pitch;
@@ -1101,6 +1121,15 @@ int hazard_leave(int self, void* stream) {
 }
 }  // namespace d4w
 
+// Every workgroup of the overlap-save kernels asks for 159 KiB of LDS whatever it uses: no other workgroup that needs LDS fits on
+// its compute unit (see xcorr_fft_blocks: SUBS).  The one-template kernel fills the claim with four blocks' worth of threads;
+// the fused two-template forms (method = "fft", an A/B reference since round 4) run one workgroup per CU instead of two for it.
+// D4W_XF_LDS_CLAIM=n: n KiB instead (0: only what the kernel uses -- the A/B that shows the hazard).
+static size_t xf_lds_claim(size_t need) {
+    static const int kib = [] { const char* v = getenv("D4W_XF_LDS_CLAIM"); return v ? atoi(v) : 159; }();
+    return kib > 0 ? std::max(need, (size_t)kib * 1024) : need;
+}
+
 extern "C" {
 
 int d4w_xcorr_fft_max_support(void) { return kXfPad + 1; }
@@ -1138,11 +1167,11 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
         D4W_LAUNCH(xcf_spectra, dim3(ceil_div(std::max(ntpl * kXfMB, kXfNA * kXfM1), 256)), dim3(256), 0, stream, taps, ntpl,
                    ltaps, len0, len1, gp, gn, tw1, tw2, wg, twa);
     const dim3 grid(ceil_div(ns, kXfStep), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+    const size_t lds = xf_lds_claim((size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2));
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, false, kXfSubs>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     // D4W_XF_TPAIR=1: both templates off ONE read of x (one row per workgroup, the two correlations
@@ -1154,7 +1183,7 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
     if (ntpl == 2 && pairmode && nx <= 65535) {
         static bool attr2 = false;
         if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)xcorr_fft_tpair, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_tpair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr2 = true;
         }
         D4W_LAUNCH(xcorr_fft_tpair, dim3(grid.x, nx), dim3(kXfThreads), lds, stream, T, x, ns, mean, maxabs, y0, y1);
@@ -1176,11 +1205,11 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
         if (taps)
             D4W_LAUNCH(xcf_tables4, dim3(ceil_div(2 * kXfMB, 256)), dim3(256), 0, stream, taps, ltaps, len0, len1, gp4, gn, q1, q2,
                        q3, qg, qp);
-        const size_t lds4 = 2 * (size_t)kX4RowP * sizeof(float4) + (256 + 32) * sizeof(float2);
+        const size_t lds4 = xf_lds_claim(2 * (size_t)kX4RowP * sizeof(float4) + (256 + 32) * sizeof(float2));
         static bool attr4 = false;
         if (!attr4) {
-            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)xcorr_fft_fused4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr4 = true;
         }
         if (xnext)
@@ -1193,7 +1222,7 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
     }
     if (xnext) return fail(D4W_EINVAL, "a continuation runs the four-stage fused kernel only (D4W_XF_FUSED / D4W_XF_TPAIR are set)");
     if (ntpl == 2 && fusedmode) {
-        const size_t lds2 = 2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
+        const size_t lds2 = xf_lds_claim(2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2));
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,
                    kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0);
         return D4W_OK;
@@ -1202,7 +1231,8 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
         XfTables Tt = T;
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
-        D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, Tt, x, nx, ns, mean, maxabs,
+        D4W_LAUNCH((xcorr_fft_blocks<1, false, false, kXfSubs>), dim3(ceil_div((int)grid.x, kXfSubs), grid.y), dim3(kXfSubs * kXfThreads),
+                   xf_lds_claim(kXfSubs * kXfItemLds), stream, Tt, x, nx, ns, mean, maxabs,
                    t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0);
     }
     return D4W_OK;
@@ -1256,9 +1286,10 @@ static int d4w_fir_fft_cols_f32_run(const float* x0, int nx, int ns0, const floa
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns_out, step), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
-    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    D4W_LAUNCH((xcorr_fft_blocks<1, false>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
+    const size_t lds = xf_lds_claim((size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2));
+    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, false, kXfSubs>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    D4W_LAUNCH((xcorr_fft_blocks<1, false, false, kXfSubs>), dim3(ceil_div((int)grid.x, kXfSubs), grid.y), dim3(kXfSubs * kXfThreads),
+               xf_lds_claim(kXfSubs * kXfItemLds), stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
                (float*)nullptr, step, K, ns_out, (float)dc_gain, XfHalo{}, first, ld);
     return D4W_OK;
 }
@@ -1296,11 +1327,12 @@ static int d4w_fir_fft_halo_f32_run(const float* x, int nx, int ns, const float*
                    tw1, tw2, wg, twa);
     const int step = kXfB - 2 * K;
     const dim3 grid(ceil_div(ns, step), ceil_div(nx, 2));
-    const size_t lds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
-    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    const size_t lds = xf_lds_claim((size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2));
+    (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true, kXfSubs>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
-    D4W_LAUNCH((xcorr_fft_blocks<1, false, true>), grid, dim3(kXfThreads), lds, stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
+    D4W_LAUNCH((xcorr_fft_blocks<1, false, true, kXfSubs>), dim3(ceil_div((int)grid.x, kXfSubs), grid.y), dim3(kXfSubs * kXfThreads),
+               xf_lds_claim(kXfSubs * kXfItemLds), stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
                (float*)nullptr, step, 0, ns, (float)dc_gain, H, first, 0);
     return D4W_OK;
 }

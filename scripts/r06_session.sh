@@ -53,6 +53,28 @@ for l in sys.stdin:
     print('$tag rep $rep %-8s %-13s total %6.2f ms  passes %s  frac %.3f' % (d['mask'], d['order'], d['total_ms'], d['ms'], d['frac_24B']))"
       done
     done 2>&1 | tee $OUT/fk_policy_ab.txt ;;
+splitk)
+    # the foreign neighbour that moved the overlap-save kernels' results (r06f): which knob makes it go away
+    (timeout 200 python scripts/probe/splitk_neighbour.py
+     D4W_XF_LDS_CLAIM=159 timeout 300 python scripts/probe/splitk_neighbour.py
+     D4W_XF_LDS_CLAIM=80 timeout 300 python scripts/probe/splitk_neighbour.py
+     SHAPE=256,8192,256 timeout 200 python scripts/probe/splitk_neighbour.py
+     SHAPE=1024,32768,1024 timeout 200 python scripts/probe/splitk_neighbour.py
+     DT=bf16 D4W_XF_LDS_CLAIM=159 timeout 300 python scripts/probe/splitk_neighbour.py) 2>/dev/null | grep "^{" | tee $OUT/splitk_neighbour.txt
+    # what the library runs for that product
+    (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_sk -o sk -- python -c "
+import torch
+a = torch.randn((256, 32768), device='cuda').half(); b = torch.randn((32768, 256), device='cuda').half()
+for _ in range(5): c = torch.matmul(a, b)
+torch.cuda.synchronize()" > /dev/null 2>&1)
+    f=$(find $OUT/prof_sk -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-200 "$f" | head -8 | tee $OUT/splitk_kernels.txt; rm -rf $OUT/prof_sk ;;
+claimed)
+    # the overlap-save kernels claim the CU's LDS (xcorr_fft_blocks SUBS = 4, 159 KiB): the split-K neighbour again, the library's own
+    # neighbours WITHOUT the cross-stream fence, and what the band-pass costs now
+    (timeout 200 python scripts/probe/splitk_neighbour.py; DT=bf16 timeout 200 python scripts/probe/splitk_neighbour.py
+     D4W_XF_LDS_CLAIM=0 timeout 200 python scripts/probe/splitk_neighbour.py) 2>/dev/null | grep "^{" | tee $OUT/splitk_neighbour_claimed.txt
+    D4W_HAZARD_FENCE=0 D4W_CONC_TRIALS=${TRIALS:-40} timeout 1200 python -u -m pytest tests/test_concurrent_gpu.py -q -m gpu -s -k "other_streams" 2>&1 | tail -5 | tee $OUT/pytest_concurrent_fence_off.log
+    (timeout 600 python scripts/time_bp.py; D4W_XF_LDS_CLAIM=0 timeout 600 python scripts/time_bp.py) 2>/dev/null | grep "^{" | tee $OUT/time_bp_claimed_then_unclaimed.txt ;;
 mm_variants)
     bash scripts/probe/mm_variants.sh run $OUT ;;
 tickets)

@@ -546,6 +546,20 @@ def test_xcorr_mm_ragged(emu, nx, ns, l0, l1):
                                 vp(z0), None, None) != 0
 
 
+def test_xcorr_mm_longest_template_in_sections(emu):
+    """The longest template the matrix-core form takes, 16 sections of 496 taps = 7936 (what 'auto' routes there instead of the
+    direct form since round 5; measured 3 x faster per tap than the direct FIR at 700 and 1024 taps, profiles/r05g): sixteen
+    launches that accumulate into y in float32 -- against float64 at the kernel's usual 2e-6."""
+    rng = np.random.default_rng(7936)
+    nx, ns, L = 2, 12000, 16 * 496
+    x = rng.standard_normal((nx, ns)) + 0.25
+    t0 = rng.standard_normal(L)
+    (y0,) = xcorr_mm_emu(emu, x, [t0], normalize=False)
+    for c in range(nx):
+        e = rel(y0[c], orc.shift_xcorr(x[c], np.pad(t0, (0, ns - L))))
+        assert e < 2e-6, (c, e)
+
+
 @pytest.mark.parametrize("nx,ns", [(3, 4100), (2, 9000), (2, 4096 * 2)])
 def test_xcorr_mm_continuation(emu, nx, ns):
     """The record continues in xnext: same numbers as correlating [x | head] with x's own statistics."""
