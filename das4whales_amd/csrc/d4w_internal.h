@@ -18,18 +18,15 @@
 // ---------------------------------------------------------------------------------------------
 namespace d4w {
 inline thread_local char g_err[512] = "";
-// Two kernel families that are kept from being resident on a compute unit together (round 5, scripts/probe/stream_race2.py):
-// with the matrix-core STFT (stft_mm_rows) running from ANOTHER HIP stream, the overlap-save FFT kernels (xcorr_fft.hip:
-// band-pass, FFT-form matched filter) returned whole blocks 1-10 % off in a few workgroups per launch -- their 16-byte LDS
-// accesses went wrong while the neighbour's LDS-fed matrix instructions were in flight (DESIGN.md section 1 has the table of
-// probes).  Those kernels store to LDS 8 bytes at a time now (one bad trial in twenty-five without this fence instead of
-// every one); the
-// fence is what makes the results safe: a launch of one family first waits (on the device) for the last launch of the
-// other, whichever stream that was on.
-// Nothing changes on one stream.  hazard_enter returns HOLDING the fence's host mutex and hazard_leave releases it: wait, launches
-// and record are one critical section (two host threads cannot both pass the wait before either has recorded).  Limits: the
-// fence is per process (two processes that share one GPU are not ordered against each other: give each process its own GPU,
-// as every launcher of this package does) and knows the devices 0..63 (beyond: the call fails).
+// Two kernel families that must not be resident on a compute unit together (round 5, scripts/probe/stream_race2.py): with the
+// matrix-core STFT (stft_mm_rows) running from ANOTHER HIP stream, the overlap-save FFT kernels (xcorr_fft.hip: band-pass,
+// FFT-form matched filter) returned whole blocks 1-10 % off in a few workgroups per launch.  Round 5 serialised the two families
+// across streams with this fence; round 6 found a FOREIGN kernel with the same effect (a rocBLAS GEMM), which no fence can know,
+// and made the overlap-save kernels claim their compute unit's LDS instead (xcorr_fft.hip: xf_lds_claim, SUBS) -- nothing that
+// needs LDS can be resident beside them.  The fence is OFF by default now (D4W_HAZARD_FENCE=1 turns it on): a launch of one
+// family then first waits (on the device) for the last launch of the other, whichever stream that was on.  hazard_enter returns
+// HOLDING the fence's host mutex and hazard_leave releases it: wait, launches and record are one critical section (two host
+// threads cannot both pass the wait before either has recorded).  Limits: per process; devices 0..63 (beyond: the call fails).
 //   rc = hazard_enter(self, stream); if (rc) return rc; ... launches ...; hazard_leave(self, stream);   (always paired)
 //   self: 0 = overlap-save FFT kernels, 1 = stft_mm
 int hazard_enter(int self, void* stream);

@@ -129,12 +129,15 @@ __device__ __forceinline__ void xf_pair(c2 A, c2 Bs, float2 w, float2 gf, float2
 // LDS tile STORES of these kernels are 8 bytes wide, not 16 (round 5).  With the matrix-core STFT (stft_mm_rows) resident on
 // the same CU from another HIP stream, whole blocks of the first row of a row pair -- dwords 0 and 2 of the tile's 16-byte
 // words -- came out 1-10 % off in a few workgroups per launch (scripts/probe/stream_race2.py, fence off: 6 of 6 trials with
-// ds_read_b128 + ds_write_b128, 1 of 24 / 2 of 45 with 8-byte stores).  The two families are fenced against each other across
-// streams (hazard_enter / hazard_leave below); round 6 ran these kernels beside kernels of OTHER libraries -- hipBLASLt / rocBLAS
-// GEMMs in binary16 and bfloat16 (small tiles, 256 x 256 macro tiles, split-K), MIOpen's binary16 convolution -- 40 trials per
-// pair bit for bit (tests/test_concurrent_gpu.py, profiles/r06*/concurrency_trials.txt): nothing moved, so the exposure is this
-// library's own pair, and the probe switches of round 5 (16-byte stores, 8-byte reads, LDS padding, the in-kernel read-back
-// check) are gone from this file; scripts/probe/ and DESIGN.md section 1 keep what they found.
+// ds_read_b128 + ds_write_b128, 1 of 24 / 2 of 45 with 8-byte stores).  Round 5 fenced the two families against each other across
+// streams (hazard_enter / hazard_leave below).  Round 6 ran these kernels beside kernels of OTHER libraries (hipBLASLt / rocBLAS
+// GEMMs in binary16 and bfloat16, MIOpen's convolution; tests/test_concurrent_gpu.py): clean beside every one of them except
+// a rocBLAS product 256 x 32768 x 256 (Tensile MT64x64x128), beside which 39-40 of 40 trials came out up to 37 % off -- a
+// fence cannot know such a neighbour.  So the kernels now exclude co-residency by construction: every workgroup claims the
+// compute unit's LDS (xcorr_fft_blocks: SUBS, xf_lds_claim): 0 of 20 trials beside that product, and beside the library's own
+// STFT without the fence.  The 8-byte stores stay (free); the probe switches of round 5 (16-byte stores, 8-byte reads, LDS
+// padding, the in-kernel read-back check) are gone from this file -- D4W_XF_LDS_CLAIM=0 is the A/B that shows the hazard;
+// scripts/probe/ and DESIGN.md section 1 keep what the probes found.  The mechanism on the hardware's side is still not known.
 __device__ __forceinline__ c2 xf_ld(const float4* p) {
     const float4 v = lds_read4(p);
     return c2{v2_make(v.x, v.y), v2_make(v.z, v.w)};
@@ -174,6 +177,12 @@ struct XfHalo {
 // rocBLAS GEMM, 256 x 32768 x 256 in binary16 / bfloat16, in 39-40 of 40 trials in round 6), and with the CU's LDS claimed no
 // kernel that needs LDS can be (0 of 20 trials each; profiles/r06g/splitk_neighbour.txt).  Blocks beyond the row's last one do
 // nothing (their lags lie outside the output) but keep the barriers' company.
+#ifndef D4W_XF_LOOP
+#define D4W_XF_LOOP 1
+#endif
+#ifndef D4W_XF_SPIN
+#define D4W_XF_SPIN 0
+#endif
 constexpr int kXfSubs = 4;
 constexpr size_t kXfItemLds = (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2);
 
@@ -183,7 +192,7 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
                                                                   const float* __restrict__ maxabs,
                                                                   float* __restrict__ y0, float* __restrict__ y1,
                                                                   int step, int yshift, int ns_out, float dcg, XfHalo H,
-                                                                  const float* __restrict__ pivot, int ld) {
+                                                                  const float* __restrict__ pivot, int ld, int ngrp) {
     // mean: the rows' float64 means (matched filter); pivot: instead, a float32 value per row that is taken off the samples
     // and given back through dcg (the zero-phase FIR's dynamic-range pivot, d4w_fir_fft_f32); ld: row pitch of x and y when
     // the rows handed over are a column window of longer rows (d4w_fir_fft_cols_f32), 0 = ns
@@ -213,10 +222,31 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
         tw1[tid] = T.tw1[tid];
         tw2[tid] = T.tw2[tid];
     }
+    // SUBS > 1: the two waves of a sub-block meet at THEIR OWN barrier -- an LDS counter both add to -- so that the four blocks of
+    // a workgroup run out of step with each other like the four workgroups per CU they replace (with one shared s_barrier all
+    // eight waves load, wait and store together and nothing hides the memory latency: 8.1 against 5.7 ms at 20 000 x 120 000)
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem_raw + (size_t)SUBS * kXfItemLds) + sub;
+    if constexpr (SUBS > 1) {
+        if (tid == 0) *cnt = 0u;
+        __syncthreads();
+    }
+    auto bar = [&]() {
+#ifndef D4W_EMU
+        if constexpr (SUBS > 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's LDS traffic is done
+            unsigned old = 0;
+            if ((tid & 63) == 0) old = atomicAdd(cnt, 1u);                      // ds_add_rtn_u32
+            const unsigned target = ((unsigned)__builtin_amdgcn_readfirstlane((int)old) | 1u) + 1u;   // both waves of barrier #j leave the count at 2 (j + 1)
+            while ((int)(*reinterpret_cast<volatile unsigned*>(cnt) - target) < 0) __builtin_amdgcn_s_sleep(D4W_XF_SPIN);
+            asm volatile("" ::: "memory");
+            return;
+        }
+#endif
+        lds_barrier();
+    };
     const int rowA = 2 * blockIdx.y;
     const bool hasB = rowA + 1 < nx;
     const int rowB = hasB ? rowA + 1 : rowA;
-    const int k0 = ((int)blockIdx.x * SUBS + sub) * step;       // first lag / first sample of the block
     const size_t pitch = ld ? (size_t)ld : (size_t)ns;
     const float* xa = x + (size_t)rowA * pitch;
     const float* xb = x + (size_t)rowB * pitch;
@@ -232,6 +262,17 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
         gb_ = (b > 0.f) ? 1.0f / b : 0.f;
     }
     const v2f sc = v2_make(ga_ / (float)MB, gb_ / (float)MB);
+    // a workgroup walks the groups of SUBS blocks grp, grp + gridDim.x, ... of its row pair (SUBS = 1: its one block)
+    int grp = (int)blockIdx.x;
+    do {
+    // (the table operands below depend on the lane only: left alone the compiler hoists ~70 registers' worth of them out of
+    // this loop and spills; an opaque zero in their addresses keeps them where they are used -- they are L1 / L2 hits)
+    int lz = 0;
+#ifndef D4W_EMU
+    if constexpr (SUBS > 1) asm volatile("" : "+v"(lz));          // (per lane: the lanes' table addresses are formed in here too)
+#endif
+    const int tl = tid + lz;                                    // the lane's item number, opaque per group for the same reason
+    const int k0 = (grp * SUBS + sub) * step;                   // first lag / first sample of the block
     const int c0 = HALO ? H.v0 + k0 - H.n_left : k0;             // the block's first sample in the row's own coordinates
     // 8-byte aligned sample pairs (the base may be a column window of longer rows: the address decides, not the index)
     const bool veca = ((reinterpret_cast<uintptr_t>(xa + c0) & 7) == 0), vecb = ((reinterpret_cast<uintptr_t>(xb + c0) & 7) == 0);
@@ -244,19 +285,19 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
     // self-paired groups 0 and NB / 2 (see the MID stage)
     int Gi, PG;
     {
-        const int p = tid;
+        const int p = tl;
         if (p < 112) { const int g = 1 + (p >> 4), b = p & 15; Gi = g * NB + b; PG = (NA - g) * NB + (NB - 1 - b); }
         else if (p < 120) { const int b = p - 112; Gi = (NA / 2) * NB + b; PG = (NA / 2) * NB + (NB - 1 - b); }
         else if (p < 127) { const int b = p - 119; Gi = b; PG = NB - b; }
         else { Gi = 0; PG = NB / 2; }
     }
-    const bool selfitem = (tid == 127);
+    const bool selfitem = (tl == 127);
     static_for<NT>([&](auto tt) {
         constexpr int t = decltype(tt)::value;
         // ---------------- S1: radix NA on the packed samples z[m] = x[k0 + 2m] + i x[k0 + 2m + 1], m = j1 + a M1
         c2 pf[NA];
         {
-            const int j1 = tid;
+            const int j1 = tl;
             // sample c of the row in its own coordinates; outside [0, ns) the neighbours' halos (de-meaned alike), then zeros
             auto sample = [&](const float* xr, int row, Mean2 mu, int c) -> float {
                 if (HALO && c < 0) {
@@ -313,10 +354,10 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
             }
         }
         float2 pw[NA];
-        xf_pw_load<NA>(T.twa, tid, pw);                             // in flight together with the samples
-        if (t == 0) __syncthreads();                                // twiddle tables visible
+        xf_pw_load<NA>(T.twa, tl, pw);                        // in flight together with the samples
+        if (t == 0) bar();                                          // twiddle tables visible (and, from the second group on, the last reads of the row buffer done)
         if (fwd) {
-            const int j1 = tid;
+            const int j1 = tl;
             dftp<NA>(pf);
             static_for<NA>([&](auto aa) {
                 constexpr int a = decltype(aa)::value;
@@ -336,10 +377,10 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
         }
         const float gny = T.gn[FUSED ? tsel : t];
         const float2 wa0 = T.wg[Gi], wb0 = T.wg[PG];       // W_B^f, f = f0(G) + 256 d: W_B^(256 d) are literals
-        lds_barrier();
+        bar();
         // ---------------- S2: radix NB in place, x W_M1^(j2 b')
         if (fwd) {
-            const int g = tid >> 3, j2 = tid & 7;
+            const int g = tl >> 3, j2 = tl & 7;
             c2 v[NB];
             static_for<NB>([&](auto bb) {
                 constexpr int b = decltype(bb)::value;
@@ -351,7 +392,7 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
                 xf_st(buf + xf_ad(g * M1 + j2 + b * NC), (b == 0) ? v[0] : c2_mulw(v[b], tw2[b * NC + j2]));
             });
         }
-        lds_barrier();
+        bar();
         // ---------------- per template: MID (radix NC on a group and its Hermitian partner group, pair op,
         //                  inverse radix NC), S2' and S1'.  Item p < 127: a proper pair (Gi < PG); p = 127: the
         //                  two self-paired groups 0 (digit partner (NC - d) % NC, f = 0 pairs with the Nyquist
@@ -369,7 +410,7 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
             dftp<NC>(a);
             dftp<NC>(b);
         }
-        if (FUSED) lds_barrier();                                   // every read of the spectrum precedes the in-place writes
+        if (FUSED) bar();                                   // every read of the spectrum precedes the in-place writes
         {
             c2 ra[NC], rb[NC];
             if (!selfitem) {
@@ -406,12 +447,12 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
                 xf_st(ob + d, rb[d]);
             });
         }
-        lds_barrier();
+        bar();
         float2 pwi[NA];
-        xf_pw_load<NA>(T.twa, tid, pwi);                            // for S1', in flight across S2'
+        xf_pw_load<NA>(T.twa, tl, pwi);                       // for S1', in flight across S2'
         // ---------------- S2': inverse radix NB
         {
-            const int g = tid >> 3, j2 = tid & 7;
+            const int g = tl >> 3, j2 = tl & 7;
             c2 v[NB];
             static_for<NB>([&](auto bb) {
                 constexpr int bq = decltype(bb)::value;
@@ -424,10 +465,10 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
                 xf_st(mine + xf_ad(g * M1 + j2 + bq * NC), v[bq]);
             });
         }
-        lds_barrier();
+        bar();
         // ---------------- S1': inverse radix NA -> lags k0 + 2m, k0 + 2m + 1 (m = j1 + a M1), the first S of them
         {
-            const int j1 = tid;
+            const int j1 = tl;
             c2 v[NA];
             static_for<NA>([&](auto aa) {
                 constexpr int aq = decltype(aa)::value;
@@ -476,8 +517,11 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
                 });
             }
         }
-        if (t + 1 < NT) lds_barrier();                          // the row buffer is rewritten by the next template
+        if (t + 1 < NT) bar();                          // the row buffer is rewritten by the next template
     });
+    if constexpr (SUBS == 1 || !D4W_XF_LOOP) break;             // no loop in the generated code (D4W_XF_LOOP=0: one group per workgroup)
+    grp += (int)gridDim.x;
+    } while (grp < ngrp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1081,8 +1125,11 @@ constexpr int kHzMaxDev = 64;
 std::mutex g_hz_mu;
 hipEvent_t g_hz_ev[kHzMaxDev][2];   // [device][family]: recorded behind the family's last launch
 bool g_hz_have[kHzMaxDev][2];
+// Off by default since round 6: the overlap-save kernels claim their compute unit's LDS (xf_lds_claim), so the matrix-core STFT
+// cannot be resident beside them whatever stream it comes from (40 trials per pair without the fence: profiles/r06h).
+// D4W_HAZARD_FENCE=1 puts the cross-stream serialisation of round 5 back.
 bool hazard_on() {
-    static const int on = [] { const char* v = getenv("D4W_HAZARD_FENCE"); return v ? atoi(v) : 1; }();
+    static const int on = [] { const char* v = getenv("D4W_HAZARD_FENCE"); return v ? atoi(v) : 0; }();
     return on != 0;
 }
 }
@@ -1125,6 +1172,36 @@ int hazard_leave(int self, void* stream) {
 // its compute unit (see xcorr_fft_blocks: SUBS).  The one-template kernel fills the claim with four blocks' worth of threads;
 // the fused two-template forms (method = "fft", an A/B reference since round 4) run one workgroup per CU instead of two for it.
 // D4W_XF_LDS_CLAIM=n: n KiB instead (0: only what the kernel uses -- the A/B that shows the hazard).
+static int mm_num_cus_xf() {
+#ifdef D4W_EMU
+    return 2;
+#else
+    static int cached[64] = {0};
+    int devid = 0, v = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return 256;
+    if (devid >= 0 && devid < 64 && cached[devid] > 0) return cached[devid];
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) {
+        if (devid >= 0 && devid < 64) cached[devid] = v;
+        return v;
+    }
+    return 256;
+#endif
+}
+
+// grid of the SUBS-block kernel for `g` = (blocks per row, row pairs): a workgroup walks the groups of its row pair -- all of
+// them when the row pairs alone fill the chip twice over, so that a workgroup lives for a whole row (one workgroup per CU: nothing
+// covers the next one's start-up), else as many walkers per row pair as it takes
+static dim3 xf_sub_grid(dim3 g) {
+    const int ngrp = ceil_div((int)g.x, kXfSubs), ncu = mm_num_cus_xf();
+#if defined(D4W_XF_LOOP) && D4W_XF_LOOP
+    const int per_row = std::max(1, std::min(ngrp, ceil_div(2 * ncu, (int)g.y)));
+#else
+    const int per_row = ngrp;
+    (void)ncu;
+#endif
+    return dim3(per_row, g.y);
+}
+
 static size_t xf_lds_claim(size_t need) {
     static const int kib = [] { const char* v = getenv("D4W_XF_LDS_CLAIM"); return v ? atoi(v) : 159; }();
     return kib > 0 ? std::max(need, (size_t)kib * 1024) : need;
@@ -1224,16 +1301,16 @@ static int d4w_xcorr_fft_cont_f32_run(const float* x, int nx, int ns, const floa
     if (ntpl == 2 && fusedmode) {
         const size_t lds2 = xf_lds_claim(2 * (size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2));
         D4W_LAUNCH((xcorr_fft_blocks<1, true>), grid, dim3(2 * kXfThreads), lds2, stream, T, x, nx, ns, mean, maxabs, y0, y1,
-                   kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0);
+                   kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0, (int)grid.x);
         return D4W_OK;
     }
     for (int t = 0; t < ntpl; ++t) {
         XfTables Tt = T;
         Tt.gp = gp + (size_t)t * kXfMB;
         Tt.gn = gn + t;
-        D4W_LAUNCH((xcorr_fft_blocks<1, false, false, kXfSubs>), dim3(ceil_div((int)grid.x, kXfSubs), grid.y), dim3(kXfSubs * kXfThreads),
-                   xf_lds_claim(kXfSubs * kXfItemLds), stream, Tt, x, nx, ns, mean, maxabs,
-                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0);
+        D4W_LAUNCH((xcorr_fft_blocks<1, false, false, kXfSubs>), xf_sub_grid(grid), dim3(kXfSubs * kXfThreads),
+                   xf_lds_claim(kXfSubs * kXfItemLds + 16), stream, Tt, x, nx, ns, mean, maxabs,
+                   t == 0 ? y0 : y1, (float*)nullptr, kXfStep, 0, ns, 0.f, XfHalo{}, (const float*)nullptr, 0, ceil_div((int)grid.x, kXfSubs));
     }
     return D4W_OK;
 }
@@ -1288,9 +1365,9 @@ static int d4w_fir_fft_cols_f32_run(const float* x0, int nx, int ns0, const floa
     const dim3 grid(ceil_div(ns_out, step), ceil_div(nx, 2));
     const size_t lds = xf_lds_claim((size_t)kXfRowP * sizeof(float4) + 2 * kXfM1 * sizeof(float2));
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, false, kXfSubs>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    D4W_LAUNCH((xcorr_fft_blocks<1, false, false, kXfSubs>), dim3(ceil_div((int)grid.x, kXfSubs), grid.y), dim3(kXfSubs * kXfThreads),
-               xf_lds_claim(kXfSubs * kXfItemLds), stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
-               (float*)nullptr, step, K, ns_out, (float)dc_gain, XfHalo{}, first, ld);
+    D4W_LAUNCH((xcorr_fft_blocks<1, false, false, kXfSubs>), xf_sub_grid(grid), dim3(kXfSubs * kXfThreads),
+               xf_lds_claim(kXfSubs * kXfItemLds + 16), stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
+               (float*)nullptr, step, K, ns_out, (float)dc_gain, XfHalo{}, first, ld, ceil_div((int)grid.x, kXfSubs));
     return D4W_OK;
 }
 
@@ -1331,9 +1408,9 @@ static int d4w_fir_fft_halo_f32_run(const float* x, int nx, int ns, const float*
     (void)hipFuncSetAttribute((const void*)xcorr_fft_blocks<1, false, true, kXfSubs>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // lag k of the virtual row starting K samples before the row = output sample k of the row
     XfHalo H{left, right, ld_left, n_left, ld_right, n_right, n_left - K};
-    D4W_LAUNCH((xcorr_fft_blocks<1, false, true, kXfSubs>), dim3(ceil_div((int)grid.x, kXfSubs), grid.y), dim3(kXfSubs * kXfThreads),
-               xf_lds_claim(kXfSubs * kXfItemLds), stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
-               (float*)nullptr, step, 0, ns, (float)dc_gain, H, first, 0);
+    D4W_LAUNCH((xcorr_fft_blocks<1, false, true, kXfSubs>), xf_sub_grid(grid), dim3(kXfSubs * kXfThreads),
+               xf_lds_claim(kXfSubs * kXfItemLds + 16), stream, T, x, nx, ns, (const double*)nullptr, (const float*)nullptr, y,
+               (float*)nullptr, step, 0, ns, (float)dc_gain, H, first, 0, ceil_div((int)grid.x, kXfSubs));
     return D4W_OK;
 }
 

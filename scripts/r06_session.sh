@@ -75,6 +75,11 @@ claimed)
      D4W_XF_LDS_CLAIM=0 timeout 200 python scripts/probe/splitk_neighbour.py) 2>/dev/null | grep "^{" | tee $OUT/splitk_neighbour_claimed.txt
     D4W_HAZARD_FENCE=0 D4W_CONC_TRIALS=${TRIALS:-40} timeout 1200 python -u -m pytest tests/test_concurrent_gpu.py -q -m gpu -s -k "other_streams" 2>&1 | tail -5 | tee $OUT/pytest_concurrent_fence_off.log
     (timeout 600 python scripts/time_bp.py; D4W_XF_LDS_CLAIM=0 timeout 600 python scripts/time_bp.py) 2>/dev/null | grep "^{" | tee $OUT/time_bp_claimed_then_unclaimed.txt ;;
+bp_forms)
+    # band-pass with the LDS-claiming kernel: sub-block barriers, one group per workgroup (default) against the walking form (probe build)
+    (timeout 600 python scripts/time_bp.py; D4W_LIB=$R/das4whales_amd/lib/probe/libd4w_xfloop.so timeout 600 python -W ignore scripts/time_bp.py
+     D4W_LIB=$R/das4whales_amd/lib/probe/libd4w_xfspin.so timeout 600 python -W ignore scripts/time_bp.py) 2>/dev/null | grep "^{" | cut -c1-160 | tee $OUT/time_bp_forms.txt
+    (timeout 200 python scripts/probe/splitk_neighbour.py; D4W_LIB=$R/das4whales_amd/lib/probe/libd4w_xfloop.so timeout 200 python -W ignore scripts/probe/splitk_neighbour.py) 2>/dev/null | grep "^{" | cut -c1-420 | tee $OUT/splitk_neighbour_forms.txt ;;
 mm_variants)
     bash scripts/probe/mm_variants.sh run $OUT ;;
 tickets)
