@@ -444,7 +444,7 @@ def bench_stream(args, world, rank, device, dist):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
-    det_streams = [torch.cuda.Stream(device) for _ in range(max(0, min(2, int(getattr(args, "detector_streams", 2)))))]
+    det_streams = [torch.cuda.Stream(device) for _ in range(max(0, min(2, int(getattr(args, "detector_streams", 0)))))]
 
     def run():
         pend = {}
@@ -684,8 +684,10 @@ def main():
     ap.add_argument("--plan", type=str, default="", help="C1,C2,N1,N2,TA,TC override")
     ap.add_argument("--cpu-sample", type=str, default="4000x12000", help="CPU baseline block (BASELINE configs[0] shape, run in full)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--detector-streams", type=int, default=2,
-                    help="--config stream: HIP streams the two detectors of a file run on beside the filter chain (0: one stream for everything)")
+    ap.add_argument("--detector-streams", type=int, default=0,
+                    help="--config stream: HIP streams the two detectors of a file run on beside the filter chain (0, the default since "
+                         "round 6: one stream for everything -- 201 against 188 files/s: the band-pass kernel owns its compute units' LDS "
+                         "now and shares them with nothing; 2 was the default of round 5)")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-mask / hybrid_ninf f-k timings")
     ap.add_argument("--prune-eps", type=float, default=4e-6,
                     help="opt-in tail pruning threshold of the fk_hybrid_ninf_pruned block (relative to the mask maximum)")

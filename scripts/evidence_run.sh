@@ -15,8 +15,8 @@ timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | grep "^{" > $O/b
 timeout 900 python bench.py --steps 20 --warmup 5 --api private --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_line_private_api.json; cut -c1-200 $O/bench_line_private_api.json
 timeout 900 python bench.py --stages bp,fk,mf --steps 10 --warmup 3 --no-cpu --no-dense 2>/dev/null | grep "^{" > $O/bench_bp_fk_mf.json; cut -c1-200 $O/bench_bp_fk_mf.json
 timeout 900 python bench.py --config stream --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_stream_1gpu.json; cut -c1-600 $O/bench_stream_1gpu.json
-# ... everything on ONE stream (the default puts the two detectors of a file on a side stream each)
-timeout 900 python bench.py --config stream --steps 10 --warmup 2 --detector-streams 0 --no-cpu 2>/dev/null | grep "^{" > $O/bench_stream_1gpu_one_stream.json; cut -c1-300 $O/bench_stream_1gpu_one_stream.json
+# ... with the two detectors of a file on a side stream each (the default of round 5; since round 6 everything runs on one stream)
+timeout 900 python bench.py --config stream --steps 10 --warmup 2 --detector-streams 2 --no-cpu 2>/dev/null | grep "^{" > $O/bench_stream_1gpu_detector_side_streams.json; cut -c1-300 $O/bench_stream_1gpu_detector_side_streams.json
 # round 5: the chain with the detectors on side streams against itself on one stream (which result differs: nothing, since the
 # cross-stream fence), and every stage beside the matrix-core STFT with the fence switched off (the hazard itself)
 timeout 300 python scripts/probe/stream_race.py 2>/dev/null | grep "^{" | cut -c1-300 > $O/stream_race.txt; tail -3 $O/stream_race.txt

@@ -44,6 +44,12 @@ if "--traffic" in sys.argv:
         if (name == "xcorr_fft_blocks" and "<1, true" in k) or name == "xcorr_fft_fused4":
             name = "xcorr_fft_fused"                    # the two-template launch (one read, two correlograms)
         name = alias.get(name, name)
+        if name == "xcorr_mm_rows":
+            # xcorr_mm_rows<KS0, KS1, WPS, TAIL, WMAX>: the kernel with the zero-padded template's tail (what the public step
+            # launches, round 6) under the plain name, the one without it beside it
+            targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            if not (len(targs) >= 4 and targs[3] == "true"):
+                name = "xcorr_mm_rows_no_tail"
         # gfx950: FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM), so kernels whose reads
         # are >= 128-byte contiguous per row piece are doubled: every pass of the shape-specialised f-k kernels reads
         # 128-byte strips (TA = TC = 16 complex).  Only the GENERIC pass C at TC = 8 (64-byte strips) is counted in

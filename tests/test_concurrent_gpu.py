@@ -108,9 +108,11 @@ def _foreign_neighbour_factory(device):
 
 def test_results_do_not_depend_on_foreign_matrix_kernels():
     """The victims of round 5's hazard (the overlap-save FFT kernels: dsp.bp_filt, the band-pass between two files, the FFT-form
-    matched filter) and the library's other LDS-heavy stages beside kernels of OTHER libraries on two side streams, fence on
-    (it knows nothing of these neighbours): bit for bit against the same call alone.  D4W_CONC_TRIALS=40 is the evidence run
-    (profiles/r06*/concurrency_trials.txt)."""
+    matched filter) and the library's other LDS-heavy stages beside kernels of OTHER libraries on two side streams: bit for bit
+    against the same call alone.  D4W_CONC_TRIALS=40 is the evidence run (profiles/r06h/concurrency_trials.txt).  This test is
+    what found the hazard OUTSIDE the library in round 6: beside a 256 x 32768 x 256 product (rocBLAS, binary16 and bfloat16) the
+    three overlap-save kernels differed in 39-40 of 40 trials, up to 37 % off (profiles/r06f) -- since then their workgroups
+    claim the compute unit's LDS (xcorr_fft.hip: SUBS, xf_lds_claim) and nothing that needs LDS can be resident beside them."""
     assert torch.cuda.is_available()
     from das4whales_amd import detect as ddet, dsp as ddsp
     nx, ns, halo = 11020, 12000, 1024
