@@ -80,6 +80,12 @@ bp_forms)
     (timeout 600 python scripts/time_bp.py; D4W_LIB=$R/das4whales_amd/lib/probe/libd4w_xfloop.so timeout 600 python -W ignore scripts/time_bp.py
      D4W_LIB=$R/das4whales_amd/lib/probe/libd4w_xfspin.so timeout 600 python -W ignore scripts/time_bp.py) 2>/dev/null | grep "^{" | cut -c1-160 | tee $OUT/time_bp_forms.txt
     (timeout 200 python scripts/probe/splitk_neighbour.py; D4W_LIB=$R/das4whales_amd/lib/probe/libd4w_xfloop.so timeout 200 python -W ignore scripts/probe/splitk_neighbour.py) 2>/dev/null | grep "^{" | cut -c1-420 | tee $OUT/splitk_neighbour_forms.txt ;;
+mm_wgs)
+    # how much the third workgroup per CU is worth to the one-template correlator (the two-template one has registers for two)
+    for w in 3 2 1; do D4W_MM_WGS=$w timeout 300 python scripts/time_xcorr_mm.py 2>/dev/null | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('D4W_MM_WGS=$w  two templates %.3f  one template %.3f  tail two %.3f  tail one %.3f' % (d['mm_ms_median_min'][0], d['mm_ms_one_template'][0], d['mm_tail_ms_median_min'][0], d['mm_tail_ms_one_template'][0]))"; done | tee $OUT/mm_wgs.txt ;;
 mm_variants)
     bash scripts/probe/mm_variants.sh run $OUT ;;
 tickets)
