@@ -131,8 +131,17 @@ __device__ __forceinline__ float mm_wave_scan(float v) {
 //     rows each) and 512 streams a row apart instead of 8 compact windows.
 // WMAX: the epilogue also leaves the rows' maxima (P.rowmax0 / rowmax1) -- a separate instantiation, so that the kernels without
 // them carry neither the branches nor the registers (round 5 had it as a kernel-argument branch in every tile's epilogue).
-template <int KS0, int KS1, int WPS, bool TAIL = false, bool WMAX = false>
+// WSPLIT (round 6; measured slower, kept behind D4W_MM_FUSED=3): two templates with the WAVES split between them -- waves 0, 1 run template 0 and waves 2, 3 template 1, eight
+// tiles each, instead of every wave running both templates on four tiles.  A wave then keeps ONE template's Toeplitz fragments
+// (44 registers instead of 88): the kernel fits three workgroups per compute unit like the one-template kernel (163 against 201
+// registers), and the third workgroup is worth 8.5 % to that kernel (profiles/r06l/mm_wgs.txt).  The matrix work per wave is the
+// same (144 instructions per chunk); the sample fragments are read from LDS by two waves instead of one -- and that is what it
+// loses on: 6.32 against 6.11 ms for the kernel where every wave runs both templates (profiles/r06m/mm_wave_split.txt).
+// Instantiated as <KS, 0, 3, ., ., true>: the one-template code with the template, output, tail coefficient and row maxima
+// chosen by the wave.
+template <int KS0, int KS1, int WPS, bool TAIL = false, bool WMAX = false, bool WSPLIT = false>
 __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
+    static_assert(!(WSPLIT && KS1 > 0), "the wave-split kernel is the one-template code run by two wave pairs");
     constexpr int KSM = KS0 > KS1 ? KS0 : KS1;
     using GEO = MmGeom<KSM>;
     constexpr int kMmHalo = GEO::Halo, kMmStage = GEO::Stage, kMmQ = GEO::Q, kMmLastQ = GEO::LastQ, kMmArr = GEO::Arr;
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
     const int lane = tid & 63, wv = mm_uniform(tid >> 6);
     const int n16 = lane & 15, g = lane >> 4;
     const int ns = P.ns;
+    const int tsel = WSPLIT ? (wv >> 1) : 0;                        // WSPLIT: the template this wave runs (wave-uniform)
 
     // ---- the chunks of this workgroup: XCD j (workgroup id mod 8) owns the contiguous range [j T / 8, (j + 1) T / 8)
     const int nchunk = (ns + kMmCH - 1) / kMmCH;
@@ -181,9 +191,9 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         for (int i = tid; i < 2 * TLP; i += kMmThreads) {
             const int t = i / TLP, u = i - t * TLP - 15;
             const int L = t ? P.len1 : P.len0;
-            float tv = (u >= 0 && u < L && (t == 0 || KS1 > 0)) ? P.taps[(size_t)t * P.ltaps + u] : 0.f;
+            float tv = (u >= 0 && u < L && (t == 0 || KS1 > 0 || WSPLIT)) ? P.taps[(size_t)t * P.ltaps + u] : 0.f;
             if constexpr (TAIL) {                                   // the term inside a block of 16 lags: t[d] + tail for every d < L
-                if (u < L && (t == 0 || KS1 > 0)) tv += t ? P.tail1 : P.tail0;
+                if (u < L && (t == 0 || KS1 > 0 || WSPLIT)) tv += t ? P.tail1 : P.tail0;
             }
             tl[i] = tv;
         }
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 });
             });
         };
-        build(tl, P.len0, a0h, a0l, std::integral_constant<int, KS0>{}, osc0);
+        build(tl + (WSPLIT ? tsel * TLP : 0), WSPLIT && tsel ? P.len1 : P.len0, a0h, a0l, std::integral_constant<int, KS0>{}, osc0);
         if constexpr (KS1 > 0) build(tl + TLP, P.len1, a1h, a1l, std::integral_constant<int, KS1>{}, osc1);
         __syncthreads();                                            // the row buffers take this space over
     }
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         if (c_next < end_c) issue(c_next);
         lds_barrier();
         // ---- 16 tiles of 256 lags, 4 per wave: C[i][a] (+)= A[i][u] B[u][a]
-        float* ya = P.y0 + (size_t)row * ns;
+        float* ya = ((WSPLIT && tsel) ? P.y1 : P.y0) + (size_t)row * ns;
         float* yb = KS1 ? P.y1 + (size_t)row * ns : nullptr;
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
         const float oxs = (own_scale && P.maxabs) ? osx * gout : osx;
@@ -409,7 +419,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
         // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
         // so an LDS round trip hides under 12 matrix instructions instead of stalling the wave at every k-step
-        constexpr int NTW = kMmCH / 256 / 4, NST = NTW * KSM, PF = 2;
+        constexpr int NTW = kMmCH / 256 / (WSPLIT ? 2 : 4), NST = NTW * KSM, PF = 2;
+        auto tile_of = [&](int ti) { return WSPLIT ? (wv & 1) + 2 * ti : wv + 4 * ti; };     // the wave's ti-th tile
         auto frag = [&](const mm_half* arr, int T, int kk) -> mm_h8 {
             const int gr = 32 * T + 2 * n16 + g + 4 * kk;           // 16-byte granule: sample 256 T + 16 n16 + 32 kk + 8 g
             return *reinterpret_cast<const mm_h8*>(arr + mm_pidx(8 * gr));
@@ -417,8 +428,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         mm_h8 fh[PF + 1], fl[PF + 1];
         static_for<PF>([&](auto ss) {
             constexpr int s_ = decltype(ss)::value;
-            fh[s_] = frag(bh, wv + 4 * (s_ / KSM), s_ % KSM);
-            fl[s_] = frag(bl, wv + 4 * (s_ / KSM), s_ % KSM);
+            fh[s_] = frag(bh, tile_of(s_ / KSM), s_ % KSM);
+            fl[s_] = frag(bl, tile_of(s_ / KSM), s_ % KSM);
         });
         mm_f4 c0h = mm_zero(), c0l = mm_zero(), c1h = mm_zero(), c1l = mm_zero();
         float vmax0 = -INFINITY, vmax1 = -INFINITY;                 // this lane's largest stored value of the chunk
@@ -426,8 +437,8 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         static_for<NST>([&](auto ss) {
             constexpr int s_ = decltype(ss)::value, ti = s_ / KSM, kk = s_ % KSM;
             if constexpr (s_ + PF < NST) {
-                fh[(s_ + PF) % (PF + 1)] = frag(bh, wv + 4 * ((s_ + PF) / KSM), (s_ + PF) % KSM);
-                fl[(s_ + PF) % (PF + 1)] = frag(bl, wv + 4 * ((s_ + PF) / KSM), (s_ + PF) % KSM);
+                fh[(s_ + PF) % (PF + 1)] = frag(bh, tile_of((s_ + PF) / KSM), (s_ + PF) % KSM);
+                fl[(s_ + PF) % (PF + 1)] = frag(bl, tile_of((s_ + PF) / KSM), (s_ + PF) % KSM);
             }
             mm_sched_fence();
             const mm_h8 xh = fh[s_ % (PF + 1)], xl = fl[s_ % (PF + 1)];
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             if constexpr (kk < KS1) c1l = mm_mfma(a1l[kk], xh, c1l);
             mm_sched_fence();
             if constexpr (kk == KSM - 1) {                          // the tile is complete: scale, combine, stream out
-                const int T = wv + 4 * ti;
+                const int T = tile_of(ti);
                 const int kl = 256 * T + 16 * n16 + 4 * g;          // this lane's four lags inside the chunk ...
                 const int k = c0 + kl;                              // ... and inside the row
                 float r0[4], r1[4];
@@ -459,8 +470,9 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
 #else
                     const float so = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, segoff), T));
 #endif
-                    const float pbk = fmaf(so + pb[buf * kBlk + kMmThreads * ti + 64 * wv + 4 * n16], oxs, pst);
-                    a0 = P.tail0 * pbk;
+                    // (tile T = segment T of the stage = load T / 4 of wave T % 4)
+                    const float pbk = fmaf(so + pb[buf * kBlk + kMmThreads * (T >> 2) + 64 * (T & 3) + 4 * n16], oxs, pst);
+                    a0 = ((WSPLIT && tsel) ? P.tail1 : P.tail0) * pbk;
                     a1 = P.tail1 * pbk;
                 }
                 static_for<4>([&](auto rr) {
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
             // samples, so a NaN in one is a NaN in the other.
             const bool bad = __any(vsum != vsum);
             if (lane == 0) {
-                mm_atomic_fmax(P.rowmax0 + row, bad ? __uint_as_float(0x7FC00000u) : vmax0);
+                mm_atomic_fmax(((WSPLIT && tsel) ? P.rowmax1 : P.rowmax0) + row, bad ? __uint_as_float(0x7FC00000u) : vmax0);
                 if constexpr (KS1 > 0) mm_atomic_fmax(P.rowmax1 + row, bad ? __uint_as_float(0x7FC00000u) : vmax1);
             }
         }
@@ -630,9 +642,23 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
     auto lds_of = [](int arr, bool tl) {
         return (size_t)4 * arr * sizeof(mm_half) + 8 * sizeof(float) + (tl ? ((size_t)2 * (kMmCH / 4) + 2 * 16) * sizeof(float) : 0);
     };
+    // two templates of <= 177 samples: every wave both templates, two workgroups per CU (the kernel of rounds 4-6).  D4W_MM_FUSED=3:
+    // the wave-split kernel at three workgroups per CU -- built and measured in round 6, 6.32 against 6.11 ms (with the tail 6.84
+    // against 6.66): the second read of every sample fragment costs more than the third workgroup brings (profiles/r06m)
+    static const int fused_form = [] { const char* v = getenv("D4W_MM_FUSED"); return v ? atoi(v) : 2; }();
+    const int per_cu_ws = env_wgs ? env_wgs : 3;
+#define D4W_MM_LAUNCH_WS(TAIL, grid, lds, Q)                                                                                            \
+    do {                                                                                                                                \
+        if ((Q).rowmax0) D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3, TAIL, true, true>), dim3(grid), dim3(kMmThreads), lds, stream, Q);       \
+        else D4W_LAUNCH((xcorr_mm_rows<kMmKS, 0, 3, TAIL, false, true>), dim3(grid), dim3(kMmThreads), lds, stream, Q);                  \
+    } while (0)
     if (tails) {
         // whole rows per workgroup (the prefix is carried along a row): at most one workgroup per row
         const int grid_t = (int)std::min<long long>((long long)nx, (long long)ncu * per_cu);
+        if (fused && fused_form != 2) {
+            D4W_MM_LAUNCH_WS(true, (int)std::min<long long>((long long)nx, (long long)ncu * per_cu_ws), lds_of(MmGeom<kMmKS>::Arr, true), P);
+            return D4W_OK;
+        }
         if (fused) {
             const size_t lds = lds_of(MmGeom<kMmKS>::Arr, true);
             if (ks0 <= 5)
@@ -676,6 +702,10 @@ int d4w_xcorr_mm_tail_f32(const float* x, int nx, int ns, const float* xnext, in
         return rc;
     }
     const size_t lds = lds_of(MmGeom<kMmKS>::Arr, false);
+    if (fused_form != 2) {
+        D4W_MM_LAUNCH_WS(false, (int)std::min<long long>(total, (long long)ncu * per_cu_ws), lds, P);
+        return D4W_OK;
+    }
     if (ks0 <= 5)
         D4W_MM_LAUNCH(5, kMmKS, 2, false, grid, lds, stream, P);
     else
