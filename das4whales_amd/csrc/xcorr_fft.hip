@@ -230,14 +230,14 @@ __global__ __launch_bounds__((FUSED ? 2 : SUBS) * kXfThreads, SUBS > 1 ? 1 : 2) 
         if (tid == 0) *cnt = 0u;
         __syncthreads();
     }
+    unsigned bar_epoch = 0;                                         // barriers this wave has been through x 2: what the counter reads when both waves are there
     auto bar = [&]() {
 #ifndef D4W_EMU
         if constexpr (SUBS > 1) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's LDS traffic is done
-            unsigned old = 0;
-            if ((tid & 63) == 0) old = atomicAdd(cnt, 1u);                      // ds_add_rtn_u32
-            const unsigned target = ((unsigned)__builtin_amdgcn_readfirstlane((int)old) | 1u) + 1u;   // both waves of barrier #j leave the count at 2 (j + 1)
-            while ((int)(*reinterpret_cast<volatile unsigned*>(cnt) - target) < 0) __builtin_amdgcn_s_sleep(D4W_XF_SPIN);
+            bar_epoch += 2u;
+            if ((tid & 63) == 0) (void)atomicAdd(cnt, 1u);                      // ds_add_u32, nothing returned: the wave knows what to wait for
+            while ((int)(*reinterpret_cast<volatile unsigned*>(cnt) - bar_epoch) < 0) __builtin_amdgcn_s_sleep(D4W_XF_SPIN);
             asm volatile("" ::: "memory");
             return;
         }

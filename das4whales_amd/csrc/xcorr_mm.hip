@@ -395,27 +395,7 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
         const bool valign = ((reinterpret_cast<uintptr_t>(ya + c0) & 15) == 0) && (!KS1 || (reinterpret_cast<uintptr_t>(yb + c0) & 15) == 0);
         const float oxs = (own_scale && P.maxabs) ? osx * gout : osx;
         const float o0 = osc0 * oxs, o1 = osc1 * oxs;
-        // TAIL: the prefix at each segment's start (lane l: segment l) and the chunk's sum, which moves the row's prefix on (every
-        // wave forms the same values from the same LDS words)
-        float segoff = 0.f;
-        if constexpr (TAIL) {
-            const float w = lane < 16 ? wt[buf * 16 + lane] : 0.f;
-            const float inc = mm_wave_scan(w);
-            segoff = inc - w;
-#ifdef D4W_EMU
-            const float own = __shfl(inc, 15);
-#else
-            const float own = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 15));
-#endif
-            const double pd = ((double)pst_hi + (double)pst_lo) + (double)(own * oxs);
-            const float ph = (float)pd, pl2 = (float)(pd - (double)ph);
-#ifdef D4W_EMU
-            pst_hi = ph; pst_lo = pl2;
-#else
-            pst_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ph)));
-            pst_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl2)));
-#endif
-        }
+        float segoff = 0.f;                                         // TAIL: the prefix at each segment's start (lane l: segment l), formed at the first tile's end
         // the wave's four tiles as ONE software pipeline over (tile, k-step): the fragment pair of step s + PF is requested
         // before the six products of step s are issued (mm_sched_fence keeps hipcc from sinking the reads back to their use),
         // so an LDS round trip hides under 12 matrix instructions instead of stalling the wave at every k-step
@@ -457,6 +437,29 @@ __global__ __launch_bounds__(kMmThreads, WPS) void xcorr_mm_rows(MmArgs P) {
                 const int T = tile_of(ti);
                 const int kl = 256 * T + 16 * n16 + 4 * g;          // this lane's four lags inside the chunk ...
                 const int k = c0 + kl;                              // ... and inside the row
+                if constexpr (ti == 0) {
+                    // (here, not ahead of the matrix instructions: nothing before the first tile's end needs it)
+                // TAIL: the prefix at each segment's start (lane l: segment l) and the chunk's sum, which moves the row's prefix on (every
+                // wave forms the same values from the same LDS words)
+                if constexpr (TAIL) {
+                    const float w = lane < 16 ? wt[buf * 16 + lane] : 0.f;
+                    const float inc = mm_wave_scan(w);
+                    segoff = inc - w;
+        #ifdef D4W_EMU
+                    const float own = __shfl(inc, 15);
+        #else
+                    const float own = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc), 15));
+        #endif
+                    const double pd = ((double)pst_hi + (double)pst_lo) + (double)(own * oxs);
+                    const float ph = (float)pd, pl2 = (float)(pd - (double)ph);
+        #ifdef D4W_EMU
+                    pst_hi = ph; pst_lo = pl2;
+        #else
+                    pst_hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ph)));
+                    pst_lo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl2)));
+        #endif
+                }
+                }
                 float r0[4], r1[4];
                 float a0 = 0.f, a1 = 0.f;                           // TAIL: tail_t x (prefix at the block's first sample), the same for the lane's four lags
 #ifdef D4W_MM_V_TAIL_NOSCAN

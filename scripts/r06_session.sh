@@ -87,6 +87,9 @@ import sys, json
 d = json.loads(sys.stdin.readline())
 print('D4W_MM_FUSED=$f rep $rep two templates %.3f (min %.3f)  no normalise %.3f  with tail %.3f (min %.3f)  err %s tail err %s' % (d['mm_ms_median_min'][0], d['mm_ms_median_min'][1], d['mm_ms_no_normalise'][0], d['mm_tail_ms_median_min'][0], d['mm_tail_ms_median_min'][1], d['mm_err_vs_f64'], d['mm_tail_err_vs_f64']))"; done; done | tee $OUT/mm_wave_split.txt
     (NX=11020 NS=12000 D4W_MM_FUSED=3 timeout 300 python scripts/time_xcorr_mm.py; NX=11020 NS=12000 D4W_MM_FUSED=2 timeout 300 python scripts/time_xcorr_mm.py) 2>/dev/null | grep "^{" | cut -c1-700 | tee -a $OUT/mm_wave_split.txt ;;
+bp_now)
+    timeout 600 python scripts/time_bp.py 2>/dev/null | grep "^{" | cut -c1-170 | tee $OUT/time_bp.txt
+    (timeout 200 python scripts/probe/splitk_neighbour.py; DT=bf16 timeout 200 python scripts/probe/splitk_neighbour.py) 2>/dev/null | grep "^{" | cut -c1-420 | tee $OUT/splitk_neighbour.txt ;;
 mm_wgs)
     # how much the third workgroup per CU is worth to the one-template correlator (the two-template one has registers for two)
     for w in 3 2 1; do D4W_MM_WGS=$w timeout 300 python scripts/time_xcorr_mm.py 2>/dev/null | grep "^{" | python -c "
