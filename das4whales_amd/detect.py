@@ -320,24 +320,49 @@ def shift_nxcorr(x, y):
     return c / (np.std(xv) * np.std(yv) * len(xv))
 
 
-def _normalised_support(template):
-    """detect.py:158: (template - mean) / max|template| over the zero-padded length; returns the
-    non-zero support of the ORIGINAL template (the constant -mean/max tail on the padded part is
-    handled by _tail_coef / d4w_xcorr_dc_tail_f32)."""
+_tpl_memo = {}      # digest of a template's bytes -> (normalised support, tail coefficient)
+
+
+def _template_parts(template):
+    """(normalised support, tail coefficient) of a template, remembered by the CONTENT of the vector (a 64-bit digest of its
+    bytes: 0.1 ms for a 120 000-sample template against 0.8 ms for the mean / max / support sweeps -- the reference's scripts call
+    compute_cross_correlogram once per template and block with the same two vectors, scripts/main_mfdetect.py:79-80)."""
     t = _host_vec(template)
+    try:
+        import xxhash
+        key = (t.shape[0], xxhash.xxh3_64_intdigest(t.tobytes()))
+    except Exception:                                    # noqa: BLE001  (no xxhash: a slower digest, same behaviour)
+        import hashlib
+        key = (t.shape[0], hashlib.blake2b(t.tobytes(), digest_size=8).digest())
+    with _cache_lock:
+        hit = _tpl_memo.get(key)
+    if hit is not None:
+        return hit
     a = np.max(np.abs(t))
     if a == 0:
         raise ValueError("template is all zeros")
-    return ((t - t.mean()) / a)[:_support(t)]
+    sup = _support(t)
+    taps = ((t - t.mean()) / a)[:sup]
+    taps.setflags(write=False)
+    coef = 0.0 if sup >= len(t) else float(t.mean() / a)
+    with _cache_lock:
+        if len(_tpl_memo) > 64:
+            _tpl_memo.clear()
+        _tpl_memo[key] = (taps, coef)
+    return taps, coef
+
+
+def _normalised_support(template):
+    """detect.py:158: (template - mean) / max|template| over the zero-padded length; returns the
+    non-zero support of the ORIGINAL template (the constant -mean/max tail on the padded part is
+    handled by _tail_coef / d4w_xcorr_mm_tail_f32 / d4w_xcorr_dc_tail_f32)."""
+    return _template_parts(template)[0]
 
 
 def _tail_coef(template):
     """mean(template) / max|template| over the zero-padded length: minus the constant that detect.py:158
     leaves on the padded part (0 when the template fills its whole length)."""
-    t = _host_vec(template)
-    if _support(t) >= len(t):
-        return 0.0
-    return float(t.mean() / np.max(np.abs(t)))
+    return _template_parts(template)[1]
 
 
 # The DC tail of a zero-padded template (detect.py:158) is |coef| g times a PREFIX SUM of the de-meaned row: 3-5e-6 of the
