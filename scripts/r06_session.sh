@@ -114,6 +114,45 @@ api_sweep)
     (timeout 300 python scripts/time_api_sweep.py; NX=11020 NS=12000 timeout 300 python scripts/time_api_sweep.py) 2>/dev/null | grep "^{" > $OUT/time_api_sweep.txt; cat $OUT/time_api_sweep.txt ;;
 xcorr_mm)
     timeout 600 python scripts/time_xcorr_mm.py > $OUT/time_xcorr_mm.txt 2>&1; cat $OUT/time_xcorr_mm.txt ;;
+envelope_ab)    # (D4W_AN_PAIR exists only in a build with scripts/probe/analytic_pair.h pasted in: the build profiles/r06q measured)
+    # the envelope at the file shape -- analytic_rows (one row's M-point transform, scalar butterflies) against
+    # analytic_rows_pair (the row's two M/2-point sub-transforms in packed registers), same process order alternated, plus thread counts
+    for i in 1 2; do
+        for pair in 0 1; do
+            echo "D4W_AN_PAIR=$pair pass $i: $(D4W_AN_PAIR=$pair NX=11020 NS=12000 timeout 300 python scripts/time_spectral.py 2>/dev/null | grep '^{' | cut -c1-330)"
+        done
+    done 2>&1 | tee $OUT/envelope_ab.txt
+    for thr in 256 320 384 512; do
+        echo "pair, $thr threads: $(D4W_AN_THREADS=$thr NX=11020 NS=12000 timeout 300 python scripts/time_spectral.py 2>/dev/null | grep '^{' | cut -c1-120)"
+    done 2>&1 | tee -a $OUT/envelope_ab.txt ;;
+spectral_tests)
+    timeout 1800 python -u -m pytest tests/test_spectral_gpu.py tests/test_stream_gpu.py tests/test_pipeline_gpu.py tests/test_reference_suite_gpu.py tests/test_image_gpu.py -x -q -m gpu 2>&1 | tail -30 > $OUT/pytest_spectral.log; tail -8 $OUT/pytest_spectral.log ;;
+stream)
+    timeout 900 python bench.py --config stream --steps 10 --warmup 2 --no-cpu 2>/dev/null | grep "^{" > $OUT/bench_stream_1gpu.json; cut -c1-400 $OUT/bench_stream_1gpu.json
+    timeout 300 python scripts/stream_kernels.py 2>/dev/null | grep -v "^$" > $OUT/stream_kernels.txt; head -30 $OUT/stream_kernels.txt ;;
+valu_rate)
+    timeout 120 scripts/ubench/valu_rate > $OUT/valu_rate.txt 2>&1; cat $OUT/valu_rate.txt ;;
+envelope_pmc)
+    # SQ counters of the two envelope kernels (own rocprofv3 passes, --kernel-trace only)
+    for pair in 0 1; do
+        i=0
+        for g in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+            i=$((i + 1))
+            (cd /tmp && D4W_AN_PAIR=$pair timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $R/$OUT/pmc_env/p${pair}_$i -o pmc -- python $R/scripts/time_env.py > /dev/null 2>&1)
+        done
+    done
+    python - <<PY | tee $OUT/pmc_envelope.txt
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/pmc_env/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "analytic_rows" in row["Kernel_Name"]:
+            acc[row["Kernel_Name"].split("(")[0][:40]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k in sorted(acc):
+    for c, v in sorted(acc[k].items()):
+        print("%-42s %-24s n=%d avg=%.4g" % (k, c, len(v), sum(v) / len(v)))
+PY
+    rm -rf $OUT/pmc_env ;;
 *) echo "unknown step $what" ;;
 esac
 done
