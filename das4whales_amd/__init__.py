@@ -15,4 +15,15 @@ from . import fkjit  # noqa: F401
 
 fkjit.load_cached()     # shape-specialised f-k kernels compiled on demand earlier (lib/jit/*.so)
 
-__all__ = ["dsp", "detect", "data_handle", "stream", "improcess"]
+
+
+def set_strict_reference(on=True):
+    """Reproduce the reference where this package's defaults deliberately differ: dsp.fk_filter_filt / fk_filter_sparsefilt with
+    tapering=True taper the caller's array in place (reference dsp.py:744-745), detect.compute_cross_correlogram gives a NaN row
+    for an all-zero channel (the reference's 0 / 0, detect.py:157).  Returns the previous setting."""
+    old = detect.STRICT_REFERENCE
+    detect.STRICT_REFERENCE = bool(on)
+    return old
+
+
+__all__ = ["dsp", "detect", "data_handle", "stream", "improcess", "set_strict_reference"]

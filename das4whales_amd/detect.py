@@ -80,6 +80,10 @@ def _xf_prepared(grp, device, ws=True):
     return ent
 
 
+# das4whales_amd.set_strict_reference(True): the reference's side effects and degenerate values where this package's defaults
+# differ: tapering=True tapers the caller's array (dsp.py:744-745), an all-zero row correlates to NaN (detect.py:157)
+STRICT_REFERENCE = False
+
 _row_stats_memo = {}        # (data_ptr, shape, device) -> (weakref to the tensor, its version, (mean, maxabs))
 
 
@@ -405,11 +409,32 @@ def _apply_tails(x, stats, outs, taps, coefs, row_max, exact_tail=None, pmax=Non
                                                  TAIL_EPS if by_row else 0.0, dev.stream_ptr(x)))
 
 
-def compute_cross_correlograms(data, templates, exact_tail=None):
+def _nan_dead_rows(xd, outs):
+    """zero_rows="nan": an all-zero row (a dead channel) is 0 / 0 in the reference's normalisation (detect.py:157) and its
+    correlogram NaN; the kernels give zeros.  One masked fill per correlogram, only when asked for."""
+    dead = _row_stats_cached(xd)[1] == 0
+    for o in outs:
+        o[dead] = float("nan")
+
+
+def compute_cross_correlograms(data, templates, exact_tail=None, zero_rows=None):
     """Several templates against one block (detect.compute_cross_correlogram for each) -- what
     scripts/main_mfdetect.py:79-80 does with two separate calls.  exact_tail: True / False forces /
     skips the DC-tail term of the zero-padded template (detect.py:158) on every row; None (default) decides per row
-    on the data and leaves out only what cannot exceed TAIL_EPS of the row's largest correlation (_apply_tails)."""
+    on the data and leaves out only what cannot exceed TAIL_EPS of the row's largest correlation (_apply_tails).
+    zero_rows: "zeros" (default) / "nan" -- what an all-zero row gives; "nan" is the reference's 0 / 0
+    (default "nan" under das4whales_amd.set_strict_reference(True))."""
+    if zero_rows is None:
+        zero_rows = "nan" if STRICT_REFERENCE else "zeros"
+    if zero_rows not in ("zeros", "nan"):
+        raise ValueError('zero_rows must be "zeros" or "nan"')
+    xd, outs = _correlograms(data, templates, exact_tail)
+    if zero_rows == "nan":
+        _nan_dead_rows(xd, outs)
+    return [dev.like_input(o, data) for o in outs]
+
+
+def _correlograms(data, templates, exact_tail):
     if getattr(data, "ndim", 0) != 2:
         raise ValueError("data must be a 2-D [channel x time] array")
     xd = dev.to_device_f32(data)
@@ -421,24 +446,23 @@ def compute_cross_correlograms(data, templates, exact_tail=None):
     if tails and _tails_in_kernel(taps, coefs, ns, how):
         # round 6: the term is formed inside the correlator (prefix sums in its sample-conversion phase) -- exact on every row,
         # one pass over the block, no per-row decision
-        outs = _xcorr_device(xd, taps, normalize=True, method=how, stats=_row_stats_cached(xd), tails=coefs)
-        return [dev.like_input(o, data) for o in outs]
+        return xd, _xcorr_device(xd, taps, normalize=True, method=how, stats=_row_stats_cached(xd), tails=coefs)
     by_row = tails and exact_tail is None and how == "mm"      # the form that leaves row maxima
     stats = _row_stats_cached(xd, prefix=by_row) if tails else None
     rmax = [] if by_row else None
     outs = _xcorr_device(xd, taps, normalize=True, method=how, stats=stats[:2] if stats else None, row_max=rmax)
     if tails:
         _apply_tails(xd, stats[:2], outs, taps, coefs, rmax, exact_tail, pmax=stats[2] if by_row else None)
-    return [dev.like_input(o, data) for o in outs]
+    return xd, outs
 
 
-def compute_cross_correlogram(data, template, exact_tail=None):
+def compute_cross_correlogram(data, template, exact_tail=None, zero_rows=None):
     """Peak-normalised matched filter, every row against `template` -- reference detect.py:140-166.
 
     Rows: (x - mean) / max|x| (max of the un-de-meaned row, detect.py:157).  Output is floating
     point (the reference's np.empty_like would truncate integer input); an all-zero row gives
-    zeros where the reference divides by zero."""
-    return compute_cross_correlograms(data, [template], exact_tail=exact_tail)[0]
+    zeros where the reference divides by zero -- zero_rows="nan" gives the reference's NaN row."""
+    return compute_cross_correlograms(data, [template], exact_tail=exact_tail, zero_rows=zero_rows)[0]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -347,21 +347,31 @@ def _fk_apply_stats(x, fk_filter_matrix, tapering=False, prefix=False):
     return y, (mean, mx)
 
 
-def fk_filter_filt(trace, fk_filter_matrix, tapering=False, inplace_taper=False):
+def _strict_reference():
+    from . import detect
+    return bool(detect.STRICT_REFERENCE)
+
+
+def fk_filter_filt(trace, fk_filter_matrix, tapering=False, inplace_taper=None):
     """Apply a pre-computed f-k mask (dense, on the fftshift-ed grid) -- reference dsp.py:725-756.
 
     By default `tapering=True` applies the Tukey window inside the filter's first pass and leaves `trace` as it was (SURVEY.md
     A.7 (N)); the reference tapers the caller's array IN PLACE on the way (dsp.py:744-745 -> taper_data, dsp.py:721).
-    inplace_taper=True reproduces that side effect: `trace` comes back tapered, the result is the same."""
+    inplace_taper=True reproduces that side effect: `trace` comes back tapered, the result is the same (the default under
+    das4whales_amd.set_strict_reference(True))."""
+    if inplace_taper is None:
+        inplace_taper = _strict_reference()
     if tapering and inplace_taper:
         taper_data(trace)
         tapering = False
     return _fk_apply(trace, fk_filter_matrix, tapering)
 
 
-def fk_filter_sparsefilt(trace, fk_filter_matrix, tapering=False, inplace_taper=False):
+def fk_filter_sparsefilt(trace, fk_filter_matrix, tapering=False, inplace_taper=None):
     """Same with a sparse.COO mask -- reference dsp.py:759-786 (dense masks are accepted too).  inplace_taper: as above
     (the reference's dsp.py:775-776)."""
+    if inplace_taper is None:
+        inplace_taper = _strict_reference()
     if tapering and inplace_taper:
         taper_data(trace)
         tapering = False

@@ -156,6 +156,48 @@ def test_correlogram_known_answer(dw):
     assert abs(c[1, tau] - expect) / expect < 1e-4
 
 
+def test_strict_reference_switch(dw):
+    """das4whales_amd.set_strict_reference(True): what the reference does where the package's defaults differ on purpose --
+    an all-zero channel correlates to NaN (0 / 0 at detect.py:157; the oracle, restating it, gives NaN too) and tapering=True
+    tapers the caller's array in place (dsp.py:744-745).  Also as per-call options, and off again afterwards."""
+    import torch
+    import warnings
+    ns = 2000
+    time = np.arange(ns) / FS
+    hf = dw.detect.gen_template_fincall(time, FS, 17.8, 28.8, 0.68)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((4, ns))
+    x[2] = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.compute_cross_correlogram(x, hf)
+    assert np.all(np.isnan(ref[2]))
+    c = dw.detect.compute_cross_correlogram(x, hf)
+    assert np.all(c[2] == 0) and rel(c[[0, 1, 3]], ref[[0, 1, 3]]) < TOL
+    cn = dw.detect.compute_cross_correlogram(x, hf, zero_rows="nan")
+    assert np.all(np.isnan(cn[2])) and np.array_equal(cn[[0, 1, 3]], c[[0, 1, 3]])
+    with pytest.raises(ValueError):
+        dw.detect.compute_cross_correlogram(x, hf, zero_rows="inf")
+    xt = torch.from_numpy(rng.standard_normal((64, 480)).astype(np.float32)).cuda()
+    mask = dw.dsp.fk_filter_design((64, 480), [0, 64, 1], 2.04, FS)
+    before = xt.clone()
+    assert dw.set_strict_reference(True) is False
+    try:
+        cs = dw.detect.compute_cross_correlograms(x, [hf, hf])
+        assert all(np.all(np.isnan(ci[2])) and np.array_equal(ci[[0, 1, 3]], c[[0, 1, 3]]) for ci in cs)
+        y_strict = dw.dsp.fk_filter_filt(xt, mask, tapering=True)
+        tapered = before.clone()
+        dw.dsp.taper_data(tapered)
+        assert torch.equal(xt, tapered) and not torch.equal(xt, before)
+    finally:
+        assert dw.set_strict_reference(False) is True
+    x2 = before.clone()
+    y = dw.dsp.fk_filter_filt(x2, mask, tapering=True)
+    assert torch.equal(x2, before)                                  # default: the caller's array is left alone
+    assert float((y - y_strict).abs().max()) <= 2e-6 * float(y.abs().max())
+    assert np.all(dw.detect.compute_cross_correlogram(x, hf)[2] == 0)
+
+
 def test_correlogram_config1_block(dw):
     nx, ns = 4000, 12000
     x = orc.synth_block(nx, ns, fs=FS, step=4, seed=99, n_calls=6, n_waves=4) * 1e9
