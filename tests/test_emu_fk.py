@@ -327,3 +327,25 @@ def test_fuzz_generic_kernels_with_prime_radices(emu):
         y = fk_emu(emu, x, m, opts=[-1, 0, 0, 0, 0, 0], taper=taper)
         assert rel(y, orc.fk_filter_filt(x, m, tapering=bool(taper))) < TOL, (nx, 2 * M)
         done += 1
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3, 5, 64, 67, 480, 12000])
+def test_taper_touches_the_ramps_only_and_equals_the_full_product(emu, ns):
+    """d4w_taper_f32 multiplies the two cosine ramps of tukey(ns, 0.03) and leaves the flat part alone (x * 1.0f is x): bit for bit
+    the float32 product with the whole window, for any length incl. the degenerate ones, NaN / inf / -0 in the flat part untouched,
+    and the reference's literal vector (tests/test_dsp.py:85-88)."""
+    import scipy.signal.windows as sw
+    rng = np.random.default_rng(ns)
+    x = (rng.standard_normal((3, ns)) * 1e3).astype(np.float32)
+    if ns >= 64:
+        x[1, ns // 2] = np.nan
+        x[2, ns // 2] = -0.0
+        x[0, ns // 2 + 1] = np.inf
+    want = x * sw.tukey(ns, 0.03).astype(np.float32)[None, :]
+    y = x.copy()
+    assert emu.d4w_taper_f32(vp(y), 3, ns, None) == 0, emu.d4w_last_error()
+    assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
+    if ns == 5:
+        v = np.array([[1.0, 2.0, 3.0, 4.0, 5.0]], dtype=np.float32)
+        assert emu.d4w_taper_f32(vp(v), 1, 5, None) == 0
+        assert np.array_equal(v, [[0.0, 2.0, 3.0, 4.0, 0.0]])
