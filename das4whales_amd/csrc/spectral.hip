@@ -306,38 +306,59 @@ __global__ __launch_bounds__(kAnMaxThreads) void analytic_rows(RowFftDev F, cons
     }
 }
 
-// population variance of every row (np.std(x, axis=1)**2, dsp.py:975-976): two sweeps of the row
-// (mean, then centred sum of squares; the second sweep hits L2)
+// population variance of every row (np.std(x, axis=1)**2, dsp.py:975-976) in ONE sweep.  Every lane sums d = x - c and d^2 in
+// float64 over its share of the row, c = the first sample it meets (its own shift: the shifted-data form is exact enough as
+// long as the lane's ~ns / 256 samples are not many orders of magnitude closer to each other than to c); the lanes' (count,
+// mean, M2) triples are then merged pairwise with the parallel update of Chan et al., M2 = M2a + M2b + delta^2 na nb / (na + nb),
+// which has no cancellation at all.  Rounds 1-5 swept twice (mean, then centred squares: 2.2 ms per sweep of a
+// 20 000 x 120 000 block -- the second sweep of a 480-KB row does not come out of L2).
+struct VarAcc { double n, mean, m2; };
+__device__ __forceinline__ VarAcc var_merge(VarAcc a, VarAcc b) {
+    const double n = a.n + b.n;
+    if (n == 0.0) return VarAcc{0.0, 0.0, 0.0};
+    const double delta = b.mean - a.mean;
+    return VarAcc{n, a.mean + delta * (b.n / n), a.m2 + b.m2 + delta * delta * (a.n * b.n / n)};
+}
 __global__ __launch_bounds__(kSpThreads) void row_var(const float* __restrict__ x, int ns, float* __restrict__ var) {
-    __shared__ float red[kSpThreads / 64];
-    __shared__ float s_mean;
+    __shared__ double red[3][kSpThreads / 64];
     const float* row = x + (size_t)blockIdx.x * ns;
     const int tid = threadIdx.x;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        const float mu = sweep ? s_mean : 0.f;
-        float s0 = 0.f, s1 = 0.f;
-        int i = tid;
-        for (; i + kSpThreads < ns; i += 2 * kSpThreads) {
-            const float a = row[i] - mu, b = row[i + kSpThreads] - mu;
-            s0 += sweep ? a * a : a;
-            s1 += sweep ? b * b : b;
-        }
-        if (i < ns) {
-            const float a = row[i] - mu;
-            s0 += sweep ? a * a : a;
-        }
-        float s = s0 + s1;
+    double s1 = 0.0, s2 = 0.0, c = 0.0, cnt = 0.0;
+    auto take = [&](float v) {
+        const double d = (double)v - c;
+        s1 += d;
+        s2 = fma(d, d, s2);
+    };
+    if ((ns & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        const int n4 = ns >> 2;
+        if (tid < n4) c = (double)r4[tid].x;
+        constexpr int kAhead = 4;                                   // 16-byte loads in flight per lane
+        for (int i0 = tid; i0 < n4; i0 += kAhead * kSpThreads) {
+            float4 q[kAhead];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-        if ((tid & 63) == 0) red[tid / 64] = s;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.f;
-            for (int w = 0; w < kSpThreads / 64; ++w) t += red[w];
-            if (sweep) var[blockIdx.x] = t / (float)ns;
-            else s_mean = t / (float)ns;
+            for (int k = 0; k < kAhead; ++k) {
+                const int i = i0 + k * kSpThreads;
+                if (i < n4) q[k] = r4[i];
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+                if (i0 + k * kSpThreads < n4) { take(q[k].x); take(q[k].y); take(q[k].z); take(q[k].w); cnt += 4.0; }
         }
-        __syncthreads();
+    } else {
+        if (tid < ns) c = (double)row[tid];
+        for (int i = tid; i < ns; i += kSpThreads) { take(row[i]); cnt += 1.0; }
+    }
+    VarAcc a{cnt, cnt > 0.0 ? c + s1 / cnt : 0.0, cnt > 0.0 ? fmax(s2 - s1 * s1 / cnt, 0.0) : 0.0};
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        a = var_merge(a, VarAcc{__shfl_xor(a.n, off), __shfl_xor(a.mean, off), __shfl_xor(a.m2, off)});
+    if ((tid & 63) == 0) { red[0][tid / 64] = a.n; red[1][tid / 64] = a.mean; red[2][tid / 64] = a.m2; }
+    __syncthreads();
+    if (tid == 0) {
+        VarAcc t{red[0][0], red[1][0], red[2][0]};
+        for (int w = 1; w < kSpThreads / 64; ++w) t = var_merge(t, VarAcc{red[0][w], red[1][w], red[2][w]});
+        var[blockIdx.x] = (float)(t.m2 / (double)ns);
     }
 }
 

@@ -66,6 +66,28 @@ def test_snr_golden(emu, golden):
     assert np.allclose(y, r["snr_expected"], atol=1e-4)
 
 
+@pytest.mark.parametrize("ns", [1, 2, 3, 7, 64, 255, 1000, 1003, 12000])
+def test_row_variance_one_sweep(emu, ns):
+    """d4w_row_var_f32 (np.std(x, axis=1)**2 of dsp.py:975) in one sweep: lane-wise shifted float64 sums merged by the parallel
+    update -- against float64 np.var on rows that break the textbook one-pass formula: an offset a million standard deviations
+    away, a first sample that is an outlier, a constant row, a silent row; aligned and unaligned (odd) row lengths."""
+    rng = np.random.default_rng(ns)
+    x = rng.standard_normal((6, ns))
+    x[1] += 1e6
+    x[2, 0] = 1e7
+    x[3] = 3.25
+    x[4] = 0.0
+    x[5] *= 1e-10
+    xf = np.ascontiguousarray(x, dtype=np.float32)
+    var = np.full(6, np.nan, dtype=np.float32)
+    ok(emu, emu.d4w_row_var_f32(vp(xf), 6, ns, vp(var), None))
+    ref = np.var(xf.astype(np.float64), axis=1)
+    assert var[3] == 0 and var[4] == 0
+    live = ref > 0
+    assert np.all(np.abs(var[live] - ref[live]) <= 3e-7 * ref[live]), (var, ref)
+    assert np.all(var[~live] == 0)
+
+
 def test_instant_freq_golden(emu, golden):
     g = golden("fk_40x480.npz")
     fs = float(g["fs"])
