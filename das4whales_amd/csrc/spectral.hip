@@ -1638,6 +1638,18 @@ __global__ __launch_bounds__(kFpThreads) void find_peaks_prom(const float* __res
         for (int w = tid; w < nwords; w += kFpThreads) T.cand[w] = 0u;
     __syncthreads();
     FP_MARK(1);
+    {
+        // A peak's prominence is its height less the higher of two minima of the row: never more than (row maximum - row minimum).
+        // A row that cannot reach the threshold -- most channels of a file carry no call above 0.45 of the file's largest
+        // correlation -- is done here: no candidates, no walks, no bitmap scan.  (Exact: the difference is formed in float64 like the walks', and the
+        // test is false for a NaN, which then takes the full path.)
+        float gmax = -INFINITY, gmin2 = INFINITY;
+        for (int k = 0; k < nb2; ++k) { const float2 e = T.s2[k]; gmax = fmaxf(gmax, e.x); gmin2 = fminf(gmin2, e.y); }
+        if ((double)gmax - (double)gmin2 < thr) {
+            if (tid == 0) counts[blockIdx.x] = 0;
+            return;
+        }
+    }
     int mark_from = 0;
     if (sweep) {
         float gmin = INFINITY;

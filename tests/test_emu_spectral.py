@@ -271,6 +271,35 @@ def test_xcorr_valid_mode_golden(emu, golden):
     assert rel(out[0], g["xcorr_v"]) < TOL and out[0, 0] == 0 and out[0, -1] == 0
 
 
+@pytest.mark.parametrize("ns", [40, 1500, 12000, 20000])
+def test_find_peaks_rows_that_cannot_reach_the_threshold(emu, ns):
+    """Rows whose (maximum - minimum) is below the prominence threshold leave the kernel after the summaries (no peak of such a row
+    can have that prominence); rows exactly AT the threshold and above it do not: every row against scipy, staged rows (<= 16 384
+    samples) and rows read in place, a quiet file with one loud channel as the detector sees it."""
+    rng = np.random.default_rng(ns)
+    nx = 7
+    x = np.abs(rng.standard_normal((nx, ns))).astype(np.float32)
+    x[2, ns // 3] = 30.0                                             # the loud channel
+    x[3] = 0.25
+    x[3, 5] = 0.25 + 8.0                                             # prominence exactly the threshold (8.0 is exact in float32)
+    x[4] = 0.25
+    x[4, 5] = np.nextafter(np.float32(8.25), np.float32(0))          # ... one ulp below it
+    x[5, 7] = np.nan
+    x[6, ns // 2] = 9.0
+    thr = 8.0
+    cap = 64
+    idx = np.full((nx, cap), -1, dtype=np.int32)
+    cnt = np.full(nx, -1, dtype=np.int32)
+    ok(emu, emu.d4w_find_peaks_f32(vp(x), nx, ns, ctypes.c_double(thr), vp(idx), vp(cnt), cap, None))
+    for c in range(nx):
+        if c == 5:
+            continue                                                 # (a NaN row: scipy's answer depends on comparison order; only "no crash")
+        ref = sps.find_peaks(x[c].astype(np.float64), prominence=thr)[0]
+        assert cnt[c] == len(ref), c
+        assert np.array_equal(idx[c, :cnt[c]], ref)
+    assert cnt[0] == 0 and cnt[1] == 0 and cnt[2] == 1 and cnt[3] == 1 and cnt[4] == 0 and cnt[6] == 1
+
+
 def test_find_peaks_matches_scipy(emu):
     rng = np.random.default_rng(5)
     nx, ns = 6, 1500
