@@ -47,7 +47,8 @@ def test_detection_chain_on_s_small_with_injected_calls():
     for got, ref in zip(c, c_ref):
         assert rel(got.cpu().numpy(), ref) < 3 * TOL
     # --- picks: the same index sets as scipy on the float64 chain (marginal peaks per the 8(a) rule), calls found
-    found = 0
+    found = found_ref = 0
+    import scipy.signal as sps
     for k, (got, ref) in enumerate(zip(c, c_ref)):
         thr = 0.45 * float(np.max(ref))
         picks = dw.detect.pick_times_env(got, thr)
@@ -60,14 +61,23 @@ def test_detection_chain_on_s_small_with_injected_calls():
         for call in calls:
             if call["template"] != k:
                 continue
-            hit = False
+            hit = hit_ref = False
             for ch, arr in call["flank"]:                     # the flanks of the moveout (the apex is removed by the non-infinite fan)
                 row = np.asarray(picks[ch])
                 hit |= bool(row.size and np.min(np.abs(row - arr)) <= 8)
+                row_ref = sps.find_peaks(env_ref[ch], prominence=thr)[0]        # the float64 chain's answer for the same note
+                hit_ref |= bool(row_ref.size and np.min(np.abs(row_ref - arr)) <= 8)
             found += int(hit)
+            found_ref += int(hit_ref)
     nlook = sum(1 for call in calls if call["flank"])
-    print("injected notes found on a flank of their moveout: %d of %d (%d with a flank inside the block)" % (found, len(calls), nlook))
-    assert nlook >= 4 and found >= nlook - 1
+    print("injected notes found on a flank of their moveout: %d of %d (%d with a flank inside the block; the float64 chain finds %d)"
+          % (found, len(calls), nlook, found_ref))
+    # parity: what the reference chain detects, the product detects (a marginal peak may fall either way: one note of slack)
+    assert found >= found_ref - 1 and found <= found_ref + 1
+    # the scene itself (only for the pinned seed: under D4W_SEED_SHIFT the synthetic notes land elsewhere and some drown -- in
+    # both chains alike, which the line above checks)
+    if int(__import__("os").environ.get("D4W_SEED_SHIFT", "0")) == 0:
+        assert nlook >= 4 and found >= nlook - 1
 
 
 def test_stream_per_file_fk_with_the_scripts_mask():
